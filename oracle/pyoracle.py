@@ -1,0 +1,415 @@
+"""ctypes binding of the CPU ORACLE (oracle/libygz_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under ygz_slam_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MAX_LEVELS = 8
+
+
+def build(force=False, variant=""):
+    """Compile the oracle with gcc (seconds).  variant '' or 'o3'."""
+    name = "libygz_oracle.so" if not variant else "libygz_oracle_%s.so" % variant
+    path = os.path.join(_HERE, name)
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(path)) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
+    return path
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("levels", C.c_int), ("w", C.c_int * MAX_LEVELS), ("h", C.c_int * MAX_LEVELS),
+                ("img", C.POINTER(C.c_uint8) * MAX_LEVELS)]
+
+
+class DetectParams(C.Structure):
+    _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("cell_size", C.c_int),
+                ("detection_threshold", C.c_double), ("pyramid_levels", C.c_int),
+                ("nms_tie_suppress", C.c_int)]
+
+
+class Keypoint(C.Structure):
+    _fields_ = [("px", C.c_double), ("py", C.c_double), ("level", C.c_int), ("score", C.c_float),
+                ("angle", C.c_float), ("desc", C.c_uint8 * 32)]
+
+
+KP_DTYPE = np.dtype([("px", "<f8"), ("py", "<f8"), ("level", "<i4"), ("score", "<f4"),
+                     ("angle", "<f4"), ("desc", "u1", (32,))], align=True)
+assert KP_DTYPE.itemsize == C.sizeof(Keypoint)
+
+
+class SE3(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3)]
+
+    @staticmethod
+    def from_array(a):          # a: 7 doubles qx qy qz qw tx ty tz
+        s = SE3()
+        for i in range(4):
+            s.q[i] = float(a[i])
+        for i in range(3):
+            s.t[i] = float(a[4 + i])
+        return s
+
+    def to_array(self):
+        return np.array(list(self.q) + list(self.t), dtype=np.float64)
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float)]
+
+
+class KltParams(C.Structure):
+    _fields_ = [("win", C.c_int), ("max_level", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double),
+                ("min_eig_threshold", C.c_double), ("use_initial_flow", C.c_int)]
+
+
+class SparseAlignStats(C.Structure):
+    _fields_ = [("n_iter_total", C.c_int), ("n_meas_last", C.c_int), ("chi2_last", C.c_double),
+                ("iters_per_level", C.c_int * MAX_LEVELS)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("poses", C.POINTER(C.c_double)), ("pose_fixed", C.POINTER(C.c_uint8)),
+                ("points", C.POINTER(C.c_double)), ("edge_pose", C.POINTER(C.c_int32)),
+                ("edge_point", C.POINTER(C.c_int32)), ("obs", C.POINTER(C.c_double)),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double)]
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _u8(a):
+    return _p(a, C.c_uint8)
+
+
+def _f64(a):
+    return _p(a, C.c_double)
+
+
+class Oracle:
+    """Thin numpy front-end; every method names the yo_* function it calls."""
+
+    def __init__(self, variant=""):
+        self.lib = C.CDLL(build(variant=variant))
+        L = self.lib
+        L.yo_shi_tomasi.restype = C.c_float
+        L.yo_fast_atan2.restype = C.c_float
+        L.yo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.yo_ic_angle.restype = C.c_float
+        L.yo_ic_angle.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_double]
+        L.yo_orb_descriptor.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_int, C.c_float, C.POINTER(C.c_uint8)]
+        L.yo_sparse_align.restype = C.c_size_t
+        L.yo_sparse_align_linearize.restype = C.c_double
+        L.yo_ba_linearize.restype = C.c_double
+        L.yo_ba_edge_error.argtypes = [C.POINTER(C.c_double)] * 3 + [C.c_double] * 4 + [C.POINTER(C.c_double)]
+        L.yo_ba_edge_jacobians.argtypes = [C.POINTER(C.c_double)] * 2 + [C.c_double] * 2 + [C.POINTER(C.c_double)] * 2
+        L.yo_find_direct_projection.argtypes = [
+            C.POINTER(Camera), C.POINTER(Pyramid), C.POINTER(SE3), C.POINTER(Pyramid), C.POINTER(SE3),
+            C.POINTER(C.c_double), C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+
+    # ---- images ----
+    def bgr2gray(self, bgr):
+        h, w, _ = bgr.shape
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        out = np.empty((h, w), np.uint8)
+        self.lib.yo_bgr2gray(_u8(bgr), w, h, w * 3, _u8(out))
+        return out
+
+    def pyr_down(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.yo_pyr_down(_u8(img), w, h, _u8(out))
+        return out
+
+    def pyramid(self, gray, levels=3):
+        lv = [np.ascontiguousarray(gray, np.uint8)]
+        for _ in range(1, levels):
+            lv.append(self.pyr_down(lv[-1]))
+        return lv
+
+    @staticmethod
+    def _pyr_struct(levels):
+        p = Pyramid()
+        p.levels = len(levels)
+        for i, im in enumerate(levels):
+            assert im.flags["C_CONTIGUOUS"] and im.dtype == np.uint8
+            p.w[i] = im.shape[1]
+            p.h[i] = im.shape[0]
+            p.img[i] = _u8(im)
+        return p
+
+    # ---- FAST ----
+    def fast_detect(self, img, thr):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        xy = np.empty((w * h, 2), np.int16)
+        n = self.lib.yo_fast10_detect(_u8(img), w, h, w, int(thr), _p(xy, C.c_int16), w * h)
+        return xy[:n].copy()
+
+    def fast_score(self, img, xy, thr):
+        img = np.ascontiguousarray(img, np.uint8)
+        xy = np.ascontiguousarray(xy, np.int16)
+        sc = np.empty(len(xy), np.int32)
+        self.lib.yo_fast10_score(_u8(img), img.shape[1], _p(xy, C.c_int16), len(xy), int(thr), _p(sc, C.c_int))
+        return sc
+
+    def fast_score_closed_form(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        p = C.cast(C.addressof(_u8(img).contents) + y * img.shape[1] + x, C.POINTER(C.c_uint8))
+        return self.lib.yo_fast10_score_closed_form(p, img.shape[1])
+
+    def fast_nonmax(self, xy, scores, tie_suppress=0):
+        xy = np.ascontiguousarray(xy, np.int16)
+        scores = np.ascontiguousarray(scores, np.int32)
+        nm = np.empty(max(len(xy), 1), np.int32)
+        m = self.lib.yo_fast_nonmax_3x3(_p(xy, C.c_int16), _p(scores, C.c_int), len(xy), tie_suppress, _p(nm, C.c_int))
+        return nm[:m].copy()
+
+    def level_corners(self, img, thr, tie_suppress=0):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        xy = np.empty((w * h, 2), np.int16)
+        sc = np.empty(w * h, np.int32)
+        m = self.lib.yo_detect_level_corners(_u8(img), w, h, int(thr), tie_suppress, _p(xy, C.c_int16), _p(sc, C.c_int), w * h)
+        return xy[:m].copy(), sc[:m].copy()
+
+    # ---- extractor ----
+    def default_params(self, w=640, h=480, levels=3):
+        p = DetectParams()
+        self.lib.yo_detect_params_default(C.byref(p))
+        p.image_width, p.image_height, p.pyramid_levels = w, h, levels
+        return p
+
+    def shi_tomasi(self, img, u, v):
+        img = np.ascontiguousarray(img, np.uint8)
+        return float(self.lib.yo_shi_tomasi(_u8(img), img.shape[1], img.shape[0], img.shape[1], int(u), int(v)))
+
+    def fast_atan2(self, y, x):
+        return float(self.lib.yo_fast_atan2(float(y), float(x)))
+
+    def ic_angle(self, img, ptx, pty):
+        img = np.ascontiguousarray(img, np.uint8)
+        return float(self.lib.yo_ic_angle(_u8(img), img.shape[1], img.shape[0], float(ptx), float(pty)))
+
+    def orb_descriptor(self, img, px, py, level, angle):
+        img = np.ascontiguousarray(img, np.uint8)
+        d = np.empty(32, np.uint8)
+        self.lib.yo_orb_descriptor(_u8(img), img.shape[1], img.shape[0], float(px), float(py), int(level), float(angle), _u8(d))
+        return d
+
+    def detect(self, levels, params=None, occupied=None):
+        """levels: list of uint8 level images.  Returns KP_DTYPE structured array."""
+        prm = params or self.default_params(levels[0].shape[1], levels[0].shape[0], len(levels))
+        pyr = self._pyr_struct(levels)
+        rows = -(-prm.image_height // prm.cell_size)
+        cols = -(-prm.image_width // prm.cell_size)
+        out = np.zeros(rows * cols, KP_DTYPE)
+        occ = None
+        if occupied is not None:
+            occupied = np.ascontiguousarray(occupied, np.uint8)
+            occ = _u8(occupied)
+        n = self.lib.yo_detect(C.byref(pyr), C.byref(prm), occ, out.ctypes.data_as(C.POINTER(Keypoint)))
+        return out[:n].copy()
+
+    def describe(self, levels, kps):
+        pyr = self._pyr_struct(levels)
+        kps = np.ascontiguousarray(kps, KP_DTYPE).copy()
+        self.lib.yo_describe(C.byref(pyr), kps.ctypes.data_as(C.POINTER(Keypoint)), len(kps))
+        return kps
+
+    # ---- hamming ----
+    def descriptor_distance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return int(self.lib.yo_descriptor_distance(_u8(a), _u8(b)))
+
+    def hamming_nn(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.empty(len(q), np.int32)
+        d = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.int32)
+        self.lib.yo_hamming_nn(_u8(q), len(q), _u8(t), len(t), _p(idx, C.c_int32), _p(d, C.c_int32), _p(d2, C.c_int32))
+        return idx, d, d2
+
+    def bf_match(self, q, t, cross_check=1):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.empty(len(q), np.int32)
+        d = np.empty(len(q), np.int32)
+        n = self.lib.yo_bf_match(_u8(q), len(q), _u8(t), len(t), int(cross_check), _p(idx, C.c_int32), _p(d, C.c_int32))
+        return idx, d, n
+
+    def good_match_filter(self, idx, dist):
+        idx = np.ascontiguousarray(idx, np.int32)
+        dist = np.ascontiguousarray(dist, np.int32)
+        keep = np.empty(len(idx), np.uint8)
+        n = self.lib.yo_good_match_filter(_p(idx, C.c_int32), _p(dist, C.c_int32), len(idx), _u8(keep))
+        return keep.astype(bool), n
+
+    # ---- SE3 ----
+    def se3_exp(self, v):
+        v = np.ascontiguousarray(v, np.float64)
+        T = SE3()
+        self.lib.yo_se3_exp(_f64(v), C.byref(T))
+        return T.to_array()
+
+    def se3_log(self, T7):
+        T = SE3.from_array(T7)
+        out = np.empty(6)
+        self.lib.yo_se3_log(C.byref(T), _f64(out))
+        return out
+
+    def se3_mul(self, A7, B7):
+        A, B, Cc = SE3.from_array(A7), SE3.from_array(B7), SE3()
+        self.lib.yo_se3_mul(C.byref(A), C.byref(B), C.byref(Cc))
+        return Cc.to_array()
+
+    def se3_inv(self, A7):
+        A, B = SE3.from_array(A7), SE3()
+        self.lib.yo_se3_inv(C.byref(A), C.byref(B))
+        return B.to_array()
+
+    def se3_act(self, T7, p):
+        T = SE3.from_array(T7)
+        p = np.ascontiguousarray(p, np.float64)
+        out = np.empty(3)
+        self.lib.yo_se3_act(C.byref(T), _f64(p), _f64(out))
+        return out
+
+    def camera(self):
+        c = Camera()
+        self.lib.yo_camera_default(C.byref(c))
+        return c
+
+    # ---- alignment ----
+    def align2d(self, cur, pwb, patch, u, v, n_iter=10):
+        cur = np.ascontiguousarray(cur, np.uint8)
+        pwb = np.ascontiguousarray(pwb, np.uint8)
+        patch = np.ascontiguousarray(patch, np.uint8)
+        uu, vv = C.c_double(u), C.c_double(v)
+        chi2, it = C.c_float(0), C.c_int(0)
+        ok = self.lib.yo_align2d(_u8(cur), cur.shape[1], cur.shape[0], cur.shape[1], _u8(pwb), _u8(patch), n_iter,
+                                 C.byref(uu), C.byref(vv), C.byref(chi2), C.byref(it))
+        return bool(ok), uu.value, vv.value, chi2.value, it.value
+
+    def find_direct_projection(self, ref_levels, T_ref, cur_levels, T_cur, px_ref, depth, level_ref, px_cur, cam=None):
+        cam = cam or self.camera()
+        pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)
+        Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
+        pxr = np.ascontiguousarray(px_ref, np.float64)
+        pxc = np.ascontiguousarray(px_cur, np.float64).copy()
+        sl = C.c_int(0)
+        ok = self.lib.yo_find_direct_projection(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc),
+                                                _f64(pxr), float(depth), int(level_ref), _f64(pxc), C.byref(sl))
+        return bool(ok), pxc, sl.value
+
+    def sparse_align(self, ref_levels, T_ref, cur_levels, T_cur, px, depth, has_mp, max_level=2, min_level=0,
+                     n_iter=30, cam=None):
+        cam = cam or self.camera()
+        pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)
+        Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
+        px = np.ascontiguousarray(px, np.float64)
+        depth = np.ascontiguousarray(depth, np.float64)
+        has_mp = np.ascontiguousarray(has_mp, np.uint8)
+        st = SparseAlignStats()
+        n = self.lib.yo_sparse_align(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc), _f64(px),
+                                     _f64(depth), _u8(has_mp), len(depth), max_level, min_level, n_iter, C.byref(st))
+        return int(n), Tc.to_array(), st
+
+    def sparse_align_linearize(self, ref_levels, cur_levels, T_cur_ref, px, depth, has_mp, level, visible=None, cam=None):
+        cam = cam or self.camera()
+        pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)
+        T = SE3.from_array(T_cur_ref)
+        px = np.ascontiguousarray(px, np.float64)
+        depth = np.ascontiguousarray(depth, np.float64)
+        has_mp = np.ascontiguousarray(has_mp, np.uint8)
+        vis = np.zeros(len(depth), np.uint8) if visible is None else np.ascontiguousarray(visible, np.uint8).copy()
+        H, J = np.empty(36), np.empty(6)
+        nm = C.c_int(0)
+        chi2 = self.lib.yo_sparse_align_linearize(C.byref(cam), C.byref(pr), C.byref(pc), C.byref(T), _f64(px),
+                                                  _f64(depth), _u8(has_mp), len(depth), level, _u8(vis), _f64(H),
+                                                  _f64(J), C.byref(nm))
+        return float(chi2), H.reshape(6, 6), J, nm.value, vis
+
+    def ldlt6_solve(self, H, b):
+        H = np.ascontiguousarray(H, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        x = np.empty(6)
+        ok = self.lib.yo_ldlt6_solve(_f64(H), _f64(b), _f64(x))
+        return bool(ok), x
+
+    # ---- KLT ----
+    def klt_params(self):
+        p = KltParams()
+        self.lib.yo_klt_params_default(C.byref(p))
+        return p
+
+    def klt_track(self, prev, nxt, prev_pts, next_pts_init, params=None):
+        prm = params or self.klt_params()
+        prev = np.ascontiguousarray(prev, np.uint8)
+        nxt = np.ascontiguousarray(nxt, np.uint8)
+        pp = np.ascontiguousarray(prev_pts, np.float32)
+        npts = np.ascontiguousarray(next_pts_init, np.float32).copy()
+        st = np.empty(len(pp), np.uint8)
+        err = np.empty(len(pp), np.float32)
+        self.lib.yo_klt_track(_u8(prev), _u8(nxt), prev.shape[1], prev.shape[0], _p(pp, C.c_float), _p(npts, C.c_float),
+                              len(pp), C.byref(prm), _u8(st), _p(err, C.c_float))
+        return npts, st, err
+
+    # ---- BA ----
+    def ba_linearize(self, poses, pose_fixed, points, edge_pose, edge_point, obs, cam=None, huber_delta=5.991):
+        cam = cam or self.camera()
+        poses = np.ascontiguousarray(poses, np.float64)
+        pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
+        points = np.ascontiguousarray(points, np.float64)
+        edge_pose = np.ascontiguousarray(edge_pose, np.int32)
+        edge_point = np.ascontiguousarray(edge_point, np.int32)
+        obs = np.ascontiguousarray(obs, np.float64)
+        pb = BaProblem(len(poses), len(points), len(edge_pose), _f64(poses), _u8(pose_fixed), _f64(points),
+                       _p(edge_pose, C.c_int32), _p(edge_point, C.c_int32), _f64(obs),
+                       float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), float(huber_delta))
+        K, P, E = len(poses), len(points), len(edge_pose)
+        out = dict(Hpp=np.empty((K, 6, 6)), bp=np.empty((K, 6)), Hll=np.empty((P, 3, 3)), bl=np.empty((P, 3)),
+                   Hpl=np.empty((E, 6, 3)), err=np.empty((E, 2)), chi2_edge=np.empty(E))
+        out["chi2"] = float(self.lib.yo_ba_linearize(C.byref(pb), _f64(out["Hpp"]), _f64(out["bp"]), _f64(out["Hll"]),
+                                                     _f64(out["bl"]), _f64(out["Hpl"]), _f64(out["err"]),
+                                                     _f64(out["chi2_edge"])))
+        return out
+
+    def ba_edge(self, pose, pt, obs, cam=None):
+        cam = cam or self.camera()
+        pose = np.ascontiguousarray(pose, np.float64)
+        pt = np.ascontiguousarray(pt, np.float64)
+        obs = np.ascontiguousarray(obs, np.float64)
+        err, Jp, Jx = np.empty(2), np.empty(6), np.empty(12)
+        self.lib.yo_ba_edge_error(_f64(pose), _f64(pt), _f64(obs), float(cam.fx), float(cam.fy), float(cam.cx),
+                                  float(cam.cy), _f64(err))
+        self.lib.yo_ba_edge_jacobians(_f64(pose), _f64(pt), float(cam.fx), float(cam.fy), _f64(Jp), _f64(Jx))
+        return err, Jp.reshape(2, 3), Jx.reshape(2, 6)
+
+    def ba_edge_norm(self, pose_tw, pt, obs_n):
+        pose_tw = np.ascontiguousarray(pose_tw, np.float64)
+        pt = np.ascontiguousarray(pt, np.float64)
+        obs_n = np.ascontiguousarray(obs_n, np.float64)
+        err, Jp, Jx = np.empty(2), np.empty(6), np.empty(12)
+        self.lib.yo_ba_edge_error_norm(_f64(pose_tw), _f64(pt), _f64(obs_n), _f64(err))
+        self.lib.yo_ba_edge_jacobians_norm(_f64(pose_tw), _f64(pt), _f64(Jp), _f64(Jx))
+        return err, Jp.reshape(2, 3), Jx.reshape(2, 6)
+
+    def ba_pose_oplus(self, pose, upd):
+        pose = np.ascontiguousarray(pose, np.float64).copy()
+        upd = np.ascontiguousarray(upd, np.float64)
+        self.lib.yo_ba_pose_oplus(_f64(pose), _f64(upd))
+        return pose
