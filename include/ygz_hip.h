@@ -1,0 +1,187 @@
+/*
+ * ygz_hip.h -- C ABI of the MI355X (gfx950) implementation of ygz-slam's per-frame hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  The C++
+ * class surfaces (include/ygz/...: ygz::Frame, FeatureDetector, Matcher, Tracker, ba::)
+ * sit on top of it; INTEGRATION.md shows the bindings.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *  - every function returns int: YGZ_OK (0) or a negative YGZ_E_* code; nothing throws or
+ *    aborts (reference error conventions are bool/count returns);
+ *  - a context owns all device memory (HBM) and one HIP stream; functions on the same
+ *    context are not thread-safe, different contexts are independent (one per GPU/thread);
+ *  - compute entry points are asynchronous on the context's stream and operate on data that
+ *    is already resident in HBM; the ygz_hip_*_upload / *_download / get_* functions move
+ *    host data and synchronise;
+ *  - "slot" = index of a frame resident in HBM ([0, max_frames)); kernels are batched over
+ *    contiguous slot ranges;
+ *  - poses are 7 doubles (qx,qy,qz,qw,tx,ty,tz) = Sophus::SE3 (unit quaternion+translation);
+ *    descriptors are 32 bytes per row (8 x u32), byte i bit j = BRIEF test 8i+j.
+ */
+#ifndef YGZ_HIP_H_
+#define YGZ_HIP_H_
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YGZ_OK              0
+#define YGZ_E_INVALID      -1   /* bad argument */
+#define YGZ_E_HIP          -2   /* a HIP runtime call failed (see ygz_hip_last_hip_error) */
+#define YGZ_E_NO_DEVICE    -3   /* no usable gfx950 device */
+#define YGZ_E_CAPACITY     -4   /* slot / keypoint / batch capacity exceeded */
+#define YGZ_E_STATE        -5   /* call order violated (e.g. detect before pyramid) */
+
+#define YGZ_MAX_LEVELS      8
+
+typedef struct ygz_hip_ctx ygz_hip_ctx;
+
+typedef struct {
+    int   image_width, image_height;  /* level-0 size; config/default.yaml:15-16 (640x480) */
+    int   pyramid_levels;             /* Basic/Frame.h:23 (3) */
+    int   cell_size;                  /* feature.cell, default.yaml:50 (10) */
+    int   fast_threshold;             /* feature.detection_threshold, default.yaml:51 (15) */
+    int   nms_tie_suppress;           /* 0: drop a corner iff a neighbour is strictly greater */
+    int   max_frames;                 /* frame slots resident in HBM */
+    float fx, fy, cx, cy;             /* PinholeCamera float intrinsics, Basic/Camera.h:107 */
+    int   debug_maps;                 /* !=0: keep per-pixel FAST score / NMS maps for parity tests */
+} ygz_hip_params;
+
+/* keypoints of one frame, structure-of-arrays (mirror of ygz::Feature, Basic/Feature.h:15-36) */
+typedef struct {
+    double  *px;       /* [n][2] level-0 pixel  (Feature::_pixel) */
+    int32_t *level;    /* [n]                   (Feature::_level) */
+    float   *score;    /* [n] Shi-Tomasi        (Feature::_score) */
+    float   *angle;    /* [n] degrees           (Feature::_angle) */
+    uint8_t *desc;     /* [n][32]               (Feature::_desc) */
+} ygz_kpt_soa;
+
+/* ---- context ---------------------------------------------------------------------------- */
+void ygz_hip_default_params(ygz_hip_params *p);
+/* stream: an existing hipStream_t to launch on (e.g. torch's current stream), or NULL to create one */
+int  ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, void *stream);
+void ygz_hip_destroy(ygz_hip_ctx *ctx);
+int  ygz_hip_synchronize(ygz_hip_ctx *ctx);
+const char *ygz_hip_error_string(int code);
+int  ygz_hip_last_hip_error(const ygz_hip_ctx *ctx);
+int  ygz_hip_max_keypoints(const ygz_hip_ctx *ctx);     /* = number of grid cells */
+/* HIP-event timing on the context's stream (bench.py roofline leg) */
+int  ygz_hip_timer_begin(ygz_hip_ctx *ctx);
+int  ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms);   /* synchronises */
+
+/* ---- A1: frame store + pyramid -- replaces Frame::InitFrame / CreateImagePyramid
+ *      (src/Basic/Frame.cpp:22-40: cv::cvtColor BGR2GRAY + cv::pyrDown per level) -------------- */
+int  ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int stride_bytes);
+int  ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int stride_bytes);
+/* builds levels 1..pyramid_levels-1 (and level 0 from BGR when from_bgr!=0) for n slots */
+int  ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr);
+int  ygz_hip_download_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst /* w_l*h_l */);
+int  ygz_hip_level_size(const ygz_hip_ctx *ctx, int level, int *w, int *h);
+
+/* ---- A2-A7: extractor -- replaces FeatureDetector::Detect
+ *      (src/Algorithm/FeatureDetector.cpp:345-444: fast_corner_detect_10 + fast_corner_score_10
+ *      + fast_nonmax_3x3 per level, per-cell best Shi-Tomasi, IC_Angle, ComputeOrbDescriptor) ---- */
+/* occupied: host [n_slots][cells] bytes (SetExistingFeatures, :446-464) or NULL.  Results stay
+ * in HBM (keypoint SoA per slot, cell-index order == the order Detect pushes to _features). */
+int  ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *occupied);
+int  ygz_hip_keypoint_count(ygz_hip_ctx *ctx, int slot, int *n);
+int  ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capacity, int *n);
+/* FeatureDetector::ComputeAngleAndDescriptor(Frame*) (:580-588): replaces the keypoint list of
+ * `slot` by the given pixels/levels and (re)computes angle + descriptor for them */
+int  ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px /*[n][2]*/, const int32_t *level, int n);
+/* parity/debug (needs debug_maps): per-pixel maps of one level after ygz_hip_detect:
+ * score[y*w+x] = 0 (no FAST-10 corner at the threshold) or fast_corner_score_10 + 1;
+ * nms[y*w+x]   = 1 iff the corner survives fast_nonmax_3x3 */
+int  ygz_hip_get_fast_maps(ygz_hip_ctx *ctx, int slot, int level, uint8_t *score, uint8_t *nms);
+
+/* ---- M1-M3: 256-bit Hamming matcher -- replaces Matcher::DescriptorDistance
+ *      (src/Algorithm/Matcher.cpp:30-43) and cv::BFMatcher(NORM_HAMMING, crossCheck).match()
+ *      (test/test_orb_match.cpp:86-93) -------------------------------------------------------- */
+/* descriptor sets of slots (query_slot[i], train_slot[i]), i < n_pairs, as left by detect/describe.
+ * cross_check: 0 plain nearest neighbour, 1 OpenCV cross-check, 2 strict mutual NN.
+ * Results per pair stay in HBM; fetch with ygz_hip_get_matches. */
+int  ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32_t *train_slot,
+                         int n_pairs, int cross_check);
+/* re-run the matcher on the pair table uploaded by the last ygz_hip_match_slots (no host copies) */
+int  ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check);
+int  ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx /*[nq]*/, int32_t *dist /*[nq]*/,
+                         int capacity, int *nq);
+/* stand-alone form on host descriptor arrays (uploads, matches, downloads).  dist2 (second-best
+ * distance, Matcher::SearchByBoW :242-246 ratio test) may be NULL and needs cross_check==0. */
+int  ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                           int cross_check, int32_t *train_idx, int32_t *dist, int32_t *dist2);
+
+/* ---- L1-L2: patch alignment -- replaces Matcher::FindDirectProjection (Matcher.cpp:356-417:
+ *      GetWarpAffineMatrix, GetBestSearchLevel, WarpAffine, cvutils::Align2D CVUtils.cpp:186-318) -- */
+typedef struct {
+    int    ref_slot, cur_slot;
+    double T_ref[7], T_cur[7];      /* Frame::_TCW of the two frames */
+} ygz_align_pair;
+/* n candidates: px_ref [n][2], depth_ref [n] (>=0; Feature::_depth or z of World2Camera),
+ * level_ref [n], px_cur [n][2] in (prediction) / out (refined), search_level [n] out,
+ * ok [n] out (the bool FindDirectProjection returns).  Host arrays; synchronises. */
+int  ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair,
+                                    const double *px_ref, const double *depth_ref, const int32_t *level_ref,
+                                    double *px_cur, int32_t *search_level, uint8_t *ok, int n);
+/* bare cvutils::Align2D on host-provided patches against level `level` of `cur_slot`:
+ * pwb [n][100], patch [n][64], uv [n][2] in/out (level pixels), ok [n], chi2 [n] (may be NULL) */
+int  ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pwb, const uint8_t *patch,
+                     double *uv, uint8_t *ok, float *chi2, int n, int n_iter);
+
+/* ---- L3: sparse image alignment -- replaces SparseImgAlign::run
+ *      (src/Algorithm/SparseImageAlign.cpp:21-50 + NLLSSolver::optimizeGaussNewton,
+ *      include/ygz/Algorithm/NLSSolver_impl.hpp:15-89; what Matcher::SparseImageAlignment calls) --- */
+/* features of the reference frame: px [n][2], depth [n], has_mappoint [n].  T_cur in/out.
+ * max_level/min_level/n_iter as SparseImgAlign ctor (Matcher.cpp:18: 2,0,30).  n_meas_out =
+ * the size_t run() returns.  The whole Gauss-Newton loop runs on the GPU. */
+int  ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double T_ref[7], int cur_slot, double T_cur[7],
+                          const double *px, const double *depth, const uint8_t *has_mappoint, int n,
+                          int max_level, int min_level, int n_iter, int *n_meas_out, int *iters_out /*[levels] or NULL*/);
+
+/* ---- L4: pyramidal LK -- replaces cv::calcOpticalFlowPyrLK as called by Tracker::TrackKLT
+ *      (src/Algorithm/Tracker.cpp:92-98) ------------------------------------------------------- */
+typedef struct {
+    int win, max_level, max_iter;     /* Tracker.h:25-27, Tracker.cpp:97 (21, 4, 30) */
+    double eps, min_eig_threshold;    /* 0.001, 1e-4 */
+    int use_initial_flow;             /* OPTFLOW_USE_INITIAL_FLOW */
+} ygz_klt_params;
+void ygz_hip_default_klt_params(ygz_klt_params *p);
+/* level-0 images of prev_slot/cur_slot; prev_pts [n][2], next_pts [n][2] in/out, status [n], err [n] */
+int  ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts,
+                       int n, const ygz_klt_params *prm, uint8_t *status, float *err);
+
+/* ---- B1-B5: local-BA edge stack -- replaces the per-iteration work g2o does for
+ *      EdgeSophusSE3ProjectXYZ (include/ygz/G2oTypes.h:84-132: computeError, linearizeOplus) plus
+ *      BaseBinaryEdge::constructQuadraticForm with RobustKernelHuber, as driven by
+ *      ba::LocalBAG2O (src/Algorithm/BA.cpp:386-543, optimize() at :501-502) ----------------------- */
+typedef struct {
+    int n_poses, n_points, n_edges;
+    const double  *poses;        /* [n_poses][6]  g2o vertex order [omega; t] (G2oTypes.h:88) */
+    const uint8_t *pose_fixed;   /* [n_poses] */
+    const double  *points;       /* [n_points][3] */
+    const int32_t *edge_pose;    /* [n_edges] */
+    const int32_t *edge_point;   /* [n_edges] */
+    const double  *obs;          /* [n_edges][2] pixels */
+    double fx, fy, cx, cy;       /* G2oTypes.h:60-66 */
+    double huber_delta;          /* BA.cpp:451 (5.991); <= 0: no robust kernel */
+    int    formulation;          /* 0: pixel residual (G2oTypes.h); 1: normalised plane, pose order
+                                    [t; omega] (legacy include/ygz/g2o_types.h:33-86, src/optimizer.cpp) */
+} ygz_ba_problem;
+/* Outputs (host, any may be NULL): Hpp [n_poses][36], bp [n_poses][6], Hll [n_points][9],
+ * bl [n_points][3], Hpl [n_edges][18] (6x3 = Jpose^T w Jpoint), err [n_edges][2], chi2_edge [n_edges],
+ * chi2 = sum of robustified chi2.  Uploads the problem, runs the kernels, downloads. */
+int  ygz_hip_ba_linearize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *Hpp, double *bp, double *Hll,
+                          double *bl, double *Hpl, double *err, double *chi2_edge, double *chi2);
+/* resident form: upload structure once, then re-linearise for new states without host copies */
+int  ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb);
+int  ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, const double *points);
+int  ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows);
+int  ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, double *Hll, double *bl,
+                         double *Hpl, double *err, double *chi2_edge, double *chi2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YGZ_HIP_H_ */

@@ -1,0 +1,404 @@
+"""GPU parity tests (pytest -m gpu, MI355X): every stage of the hot path through the C ABI
+(ygz_slam_amd._lib -> libygz_hip.so) against the CPU oracle and the committed golden vectors.
+Integer / byte / index stages: bit-exact.  Float stages: the tolerance is written at the assert
+(north_star: LK tracks and BA residuals within 1e-5 relative)."""
+import numpy as np
+import pytest
+from conftest import golden, make_ctx
+from ygz_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+LUT = np.array([bin(i).count("1") for i in range(256)])
+
+
+def _frames(n, w, h, seed=1, step=0.5, identity_first=True):
+    tex, m = synth.make_texture(seed, w, h, margin=max(80, w // 4))
+    poses = synth.trajectory(n, seed + 10, step)
+    if identity_first:
+        poses[0] = [0, 0, 0, 1, 0, 0, 0]
+    out = [synth.render(tex, m, poses[i], w, h, 1.0, seed * 1000 + i) for i in range(n)]
+    return np.stack([o[0] for o in out]), poses, np.stack([o[1] for o in out])
+
+
+def _corner_maps(oracle, img, thr, tie):
+    xy = oracle.fast_detect(img, thr)
+    sc = oracle.fast_score(img, xy, thr)
+    nm = oracle.fast_nonmax(xy, sc, tie)
+    smap = np.zeros(img.shape, np.uint8)
+    nmap = np.zeros(img.shape, np.uint8)
+    smap[xy[:, 1], xy[:, 0]] = sc + 1
+    nmap[xy[nm, 1], xy[nm, 0]] = 1
+    return smap, nmap
+
+
+def _kp_check(kp, ok_):
+    assert len(kp["level"]) == len(ok_)
+    assert np.array_equal(kp["px"][:, 0], ok_["px"]) and np.array_equal(kp["px"][:, 1], ok_["py"])
+    assert np.array_equal(kp["level"], ok_["level"])
+    assert np.array_equal(np.isnan(kp["score"]), np.isnan(ok_["score"]))
+    m = ~np.isnan(ok_["score"])
+    assert np.array_equal(kp["score"][m], ok_["score"][m])
+    assert np.array_equal(kp["angle"], ok_["angle"])
+    assert np.array_equal(kp["desc"], ok_["desc"])
+
+
+# ------------------------------------------------------------------------------------- A1
+@pytest.mark.parametrize("w,h", [(640, 480), (67, 45), (333, 251)])
+def test_gray_and_pyramid_bit_exact(hip_lib, oracle, w, h):
+    rng = np.random.default_rng(w * 7 + h)
+    bgr = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+    ctx = make_ctx(hip_lib, width=w, height=h, levels=3, max_frames=2)
+    for s in range(2):
+        ctx.upload_bgr(s, bgr[s])
+    ctx.build_pyramid(0, 2, from_bgr=True)
+    for s in range(2):
+        lv = oracle.pyramid(oracle.bgr2gray(bgr[s]), 3)
+        for L in range(3):
+            assert np.array_equal(ctx.download_level(s, L), lv[L]), (s, L)
+    ctx.close()
+
+
+def test_pyramid_golden(hip_lib):
+    g = golden("image")
+    h, w = g["img"].shape
+    ctx = make_ctx(hip_lib, width=w, height=h, levels=3, max_frames=1)
+    ctx.upload_gray(0, g["img"])
+    ctx.build_pyramid(0, 1)
+    assert np.array_equal(ctx.download_level(0, 1), g["l1"]) and np.array_equal(ctx.download_level(0, 2), g["l2"])
+    hb, wb, _ = g["bgr"].shape
+    c2 = make_ctx(hip_lib, width=wb, height=hb, levels=1, max_frames=1)
+    c2.upload_bgr(0, g["bgr"])
+    c2.build_pyramid(0, 1, from_bgr=True)
+    assert np.array_equal(c2.download_level(0, 0), g["gray"])
+    ctx.close(); c2.close()
+
+
+# ------------------------------------------------------------------------------------- A2-A7
+@pytest.mark.parametrize("w,h,tie", [(640, 480, 0), (640, 480, 1), (333, 251, 0)])
+def test_fast_maps_and_keypoints_bit_exact(hip_lib, oracle, w, h, tie):
+    imgs, _, _ = _frames(2, w, h, seed=2)
+    ctx = make_ctx(hip_lib, width=w, height=h, levels=3, max_frames=2, debug_maps=True, nms_tie_suppress=tie)
+    for s in range(2):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 2)
+    ctx.detect(0, 2)
+    prm = oracle.default_params(w, h, 3)
+    prm.nms_tie_suppress = tie
+    for s in range(2):
+        lv = oracle.pyramid(imgs[s], 3)
+        for L in range(3):
+            smap, nmap = _corner_maps(oracle, lv[L], 15, tie)
+            gs, gn = ctx.get_fast_maps(s, L)
+            assert np.array_equal(gs, smap), ("fast score map", s, L)        # bit-exact FAST corners + scores
+            assert np.array_equal(gn, nmap), ("nms map", s, L)
+        ok_ = oracle.detect(lv, prm)
+        assert len(ok_) > 200
+        _kp_check(ctx.get_keypoints(s), ok_)
+    ctx.close()
+
+
+def test_detect_golden_and_occupied(hip_lib, oracle):
+    g = golden("extract")
+    ctx = make_ctx(hip_lib, width=320, height=240, levels=3, max_frames=2)
+    for s in range(2):
+        ctx.upload_gray(s, g["imgs"][s])
+    ctx.build_pyramid(0, 2)
+    ctx.detect(0, 2)
+    _kp_check(ctx.get_keypoints(0), g["k0"])
+    _kp_check(ctx.get_keypoints(1), g["k1"])
+    occ = np.stack([g["occ"], np.zeros_like(g["occ"])])
+    ctx.detect(0, 2, occupied=occ)                       # Detect(frame, overwrite_existing_features=false)
+    _kp_check(ctx.get_keypoints(0), g["k0occ"])
+    _kp_check(ctx.get_keypoints(1), g["k1"])
+    # call order is enforced
+    with pytest.raises(hip_lib.YgzHipError):
+        c2 = make_ctx(hip_lib, width=320, height=240, levels=3, max_frames=1)
+        c2.detect(0, 1)
+    ctx.close()
+
+
+def test_describe_arbitrary_pixels(hip_lib, oracle):
+    imgs, _, _ = _frames(1, 640, 480, seed=4)
+    rng = np.random.default_rng(0)
+    n = 500
+    level = rng.integers(0, 3, n).astype(np.int32)
+    px = np.stack([rng.uniform(0, 640, n), rng.uniform(0, 480, n)], 1)      # includes border cases (reads wrap / 0)
+    px[:20] = np.floor(px[:20]) + 0.5                                       # cvRound half-to-even cases
+    ctx = make_ctx(hip_lib, max_frames=1)
+    ctx.upload_gray(0, imgs[0]); ctx.build_pyramid(0, 1)
+    ctx.describe(0, px, level)
+    kp = ctx.get_keypoints(0)
+    k = np.zeros(n, oracle.detect(oracle.pyramid(imgs[0], 3)).dtype)
+    k["px"], k["py"], k["level"] = px[:, 0], px[:, 1], level
+    ok_ = oracle.describe(oracle.pyramid(imgs[0], 3), k)
+    assert np.array_equal(kp["angle"], ok_["angle"])
+    assert np.array_equal(kp["desc"], ok_["desc"])
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------- M1-M3
+@pytest.mark.parametrize("nq,nt", [(1000, 1000), (70, 53), (1, 1), (257, 3), (3, 700), (3072, 3072)])
+def test_hamming_bit_exact_indices(hip_lib, oracle, nq, nt):
+    q = synth.random_descriptors(nq, 42 + nq)
+    t = synth.random_descriptors(nt, 43 + nt)
+    if nq > 30 and nt > 12:
+        t[10] = q[3]; t[11] = q[3]; q[20] = q[21]
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for cc in (0, 1, 2):
+        idx, d = ctx.hamming_match(q, t, cc)
+        oi, od, _ = oracle.bf_match(q, t, cc)
+        assert np.array_equal(idx, oi) and np.array_equal(d, od), cc
+    idx, d, d2 = ctx.hamming_match(q, t, 0, want_second=True)
+    oi, od, od2 = oracle.hamming_nn(q, t)
+    assert np.array_equal(idx, oi) and np.array_equal(d, od) and np.array_equal(d2, od2)
+    if nq <= 1000:                                     # independent numpy check of distances
+        D = LUT[q[:, None, :] ^ t[None, :, :]].sum(-1)
+        assert np.array_equal(d, D.min(1)) and np.array_equal(idx, D.argmin(1))
+    ctx.close()
+
+
+def test_hamming_edge_cases_and_golden(hip_lib, oracle):
+    g = golden("hamming")
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for cc in (0, 1, 2):
+        idx, d = ctx.hamming_match(g["q"], g["t"], cc)
+        assert np.array_equal(idx, g["idx%d" % cc]) and np.array_equal(d, g["dist%d" % cc])
+    e = np.zeros((0, 32), np.uint8)
+    idx, d = ctx.hamming_match(g["q"], e, 1)
+    assert np.all(idx == -1) and np.all(d == 2 ** 31 - 1)
+    idx, d = ctx.hamming_match(e, g["t"], 1)
+    assert len(idx) == 0
+    with pytest.raises(hip_lib.YgzHipError):             # capacity: more rows than grid cells
+        ctx.hamming_match(synth.random_descriptors(4000, 1), g["t"], 0)
+    z = np.zeros((5, 32), np.uint8); f = np.full((4, 32), 255, np.uint8)
+    idx, d = ctx.hamming_match(z, f, 0)
+    assert np.all(d == 256) and np.all(idx == 0)         # maximum distance, first index on ties
+    ctx.close()
+
+
+def test_match_slots_on_extracted_frames(hip_lib, oracle):
+    imgs, _, _ = _frames(4, 640, 480, seed=5, step=0.3)
+    ctx = make_ctx(hip_lib, max_frames=4)
+    for s in range(4):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 4); ctx.detect(0, 4)
+    ks = [oracle.detect(oracle.pyramid(imgs[s], 3)) for s in range(4)]
+    for cc in (1, 0, 2):
+        ctx.match_slots([0, 1, 2], [1, 2, 3], cc)
+        for p in range(3):
+            idx, d = ctx.get_matches(p)
+            oi, od, _ = oracle.bf_match(ks[p]["desc"], ks[p + 1]["desc"], cc)
+            assert np.array_equal(idx, oi) and np.array_equal(d, od), (cc, p)
+    ctx.match_slots_again(1)
+    idx, d = ctx.get_matches(0)
+    oi, od, n = oracle.bf_match(ks[0]["desc"], ks[1]["desc"], 1)
+    assert np.array_equal(idx, oi) and n > 100
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------- L1-L2
+def _fdp_inputs(oracle, imgs, poses, depths, n, rng, noise=2.0):
+    k0 = oracle.detect(oracle.pyramid(imgs[0], 3))[:n]
+    px_ref = np.stack([k0["px"], k0["py"]], 1)
+    depth = np.array([depths[0][int(p[1]), int(p[0])] for p in px_ref])
+    Tcr = oracle.se3_mul(poses[1], oracle.se3_inv(poses[0]))
+    R = synth.quat_to_R(Tcr[:4])
+    pc = np.stack([(px_ref[:, 0] - synth.CX) / synth.FX * depth, (px_ref[:, 1] - synth.CY) / synth.FY * depth, depth], 1) @ R.T + Tcr[4:]
+    pred = np.stack([synth.FX * pc[:, 0] / pc[:, 2] + synth.CX, synth.FY * pc[:, 1] / pc[:, 2] + synth.CY], 1)
+    return px_ref, depth, k0["level"].astype(np.int32), pred + rng.uniform(-noise, noise, pred.shape)
+
+
+def test_find_direct_projection_bit_exact(hip_lib, oracle):
+    imgs, poses, depths = _frames(2, 640, 480, seed=6, step=0.6)
+    rng = np.random.default_rng(1)
+    px_ref, depth, level, pred = _fdp_inputs(oracle, imgs, poses, depths, 1000, rng)
+    depth[5] = -1.0                                        # invalid depth -> false (Matcher.cpp:388-392)
+    pred[7] = [3.0, 3.0]                                   # border
+    for T_ref_case in (poses[0], synth.se3_exp([0.02, -0.01, 0.03, 0.01, 0.02, -0.01])):
+        ctx = make_ctx(hip_lib, max_frames=2)
+        for s in range(2):
+            ctx.upload_gray(s, imgs[s])
+        ctx.build_pyramid(0, 2)
+        ok, px, sl = ctx.find_direct_projection(0, T_ref_case, 1, poses[1], px_ref, depth, level, pred)
+        lv0, lv1 = oracle.pyramid(imgs[0], 3), oracle.pyramid(imgs[1], 3)
+        for i in range(len(depth)):
+            o_ok, o_px, o_sl = oracle.find_direct_projection(lv0, T_ref_case, lv1, poses[1], px_ref[i], depth[i], int(level[i]), pred[i])
+            assert ok[i] == o_ok, i
+            if depth[i] >= 0:
+                assert sl[i] == o_sl, i
+                assert np.array_equal(px[i], o_px, equal_nan=True), (i, px[i], o_px)      # bit-exact float path
+        if T_ref_case is poses[0]:
+            assert ok.mean() > 0.5
+        ctx.close()
+
+
+def test_align2d_patches_bit_exact(hip_lib, oracle):
+    imgs, _, _ = _frames(2, 640, 480, seed=7, step=0.2)
+    rng = np.random.default_rng(2)
+    n = 600
+    cx = rng.integers(10, 630, n); cy = rng.integers(10, 470, n)
+    pwb = np.stack([imgs[0][y - 5:y + 5, x - 5:x + 5] for x, y in zip(cx, cy)]).reshape(n, 100)
+    uv = np.stack([cx + rng.uniform(-2, 2, n), cy + rng.uniform(-2, 2, n)], 1)
+    uv[:10] = [[1.0, 1.0]] * 10                             # outside the 4 px margin: breaks at once
+    ctx = make_ctx(hip_lib, max_frames=1)
+    ctx.upload_gray(0, imgs[1]); ctx.build_pyramid(0, 1)
+    ok, out, chi2 = ctx.align2d(0, 0, pwb, uv)
+    for i in range(n):
+        o_ok, u, v, c2, it = oracle.align2d(imgs[1], pwb[i], pwb[i].reshape(10, 10)[1:9, 1:9].copy(), uv[i, 0], uv[i, 1])
+        assert ok[i] == o_ok and out[i, 0] == u and out[i, 1] == v and chi2[i] == np.float32(c2), i
+    ctx.close()
+
+
+def test_fdp_golden(hip_lib):
+    g, e = golden("align"), golden("extract")
+    ctx = make_ctx(hip_lib, width=320, height=240, max_frames=2)
+    for s in range(2):
+        ctx.upload_gray(s, e["imgs"][s])
+    ctx.build_pyramid(0, 2)
+    ok, px, sl = ctx.find_direct_projection(0, e["poses"][0], 1, e["poses"][1], g["px_ref"], g["depth"], g["level"], g["pred"])
+    assert np.array_equal(ok, g["fdp_ok"]) and np.array_equal(sl, g["fdp_sl"]) and np.array_equal(px, g["fdp_px"], equal_nan=True)
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------- L3
+def test_sparse_align(hip_lib, oracle):
+    for (w, h, n, seed) in ((320, 240, 200, 3), (640, 480, 1000, 8)):
+        imgs, poses, depths = _frames(2, w, h, seed=seed, step=0.4)
+        k0 = oracle.detect(oracle.pyramid(imgs[0], 3), oracle.default_params(w, h, 3))[:n]
+        px = np.stack([k0["px"], k0["py"]], 1)
+        depth = np.array([depths[0][int(p[1]), int(p[0])] for p in px])
+        has_mp = np.ones(len(px), np.uint8); has_mp[::9] = 0
+        T_init = oracle.se3_mul(synth.se3_exp([0.004, -0.003, 0.002, 0.001, -0.002, 0.001]), poses[1])
+        ctx = make_ctx(hip_lib, width=w, height=h, max_frames=2)
+        for s in range(2):
+            ctx.upload_gray(s, imgs[s])
+        ctx.build_pyramid(0, 2)
+        nm, T, iters = ctx.sparse_align(0, poses[0], 1, T_init, px, depth, has_mp)
+        onm, oT, st = oracle.sparse_align(oracle.pyramid(imgs[0], 3), poses[0], oracle.pyramid(imgs[1], 3), T_init, px, depth, has_mp)
+        assert nm == onm
+        assert iters == list(st.iters_per_level)[:3]          # same Gauss-Newton trajectory (chi2 reproduced exactly)
+        assert np.allclose(T, oT, rtol=1e-9, atol=1e-11)      # FP64 H/Jres sums differ only in order
+        e0 = np.linalg.norm(oracle.se3_log(oracle.se3_mul(T_init, oracle.se3_inv(poses[1]))))
+        e1 = np.linalg.norm(oracle.se3_log(oracle.se3_mul(T, oracle.se3_inv(poses[1]))))
+        assert e1 < 0.5 * e0
+        ctx.close()
+
+
+def test_sparse_align_golden_and_empty(hip_lib):
+    g, e = golden("align"), golden("extract")
+    ctx = make_ctx(hip_lib, width=320, height=240, max_frames=2)
+    for s in range(2):
+        ctx.upload_gray(s, e["imgs"][s])
+    ctx.build_pyramid(0, 2)
+    nm, T, iters = ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], g["px_ref"], g["depth"], g["has_mp"])
+    assert nm == int(g["sa_nmeas"]) and iters == list(g["sa_iters"])
+    assert np.allclose(T, g["sa_T"], rtol=1e-9, atol=1e-11)
+    nm, T, _ = ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], np.zeros((0, 2)), np.zeros(0), np.zeros(0, np.uint8))
+    assert nm == 0 and np.array_equal(T, g["T_init"])      # run() returns 0 and leaves the pose (SparseImageAlign.cpp:25-29)
+    no_mp = np.zeros(len(g["depth"]), np.uint8)            # no feature has a map point -> nothing visible
+    nm, T, _ = ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], g["px_ref"], g["depth"], no_mp)
+    assert nm == 0
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------- L4
+def test_klt(hip_lib, oracle):
+    for (w, h, n, seed) in ((320, 240, 200, 3), (640, 480, 1000, 9)):
+        imgs, poses, depths = _frames(2, w, h, seed=seed, step=0.5)
+        k0 = oracle.detect(oracle.pyramid(imgs[0], 3), oracle.default_params(w, h, 3))[:n]
+        pts = np.stack([k0["px"], k0["py"]], 1).astype(np.float32)
+        rng = np.random.default_rng(4)
+        init = pts + rng.uniform(-3, 3, pts.shape).astype(np.float32)
+        pts[0] = [2.0, 2.0]; init[0] = [1.0, 1.0]           # window mostly outside: reflect-101 border path
+        ctx = make_ctx(hip_lib, width=w, height=h, max_frames=2)
+        for s in range(2):
+            ctx.upload_gray(s, imgs[s])
+        ctx.build_pyramid(0, 2)
+        out, st, err = ctx.klt_track(0, 1, pts, init)
+        oout, ost, oerr = oracle.klt_track(imgs[0], imgs[1], pts, init)
+        assert np.array_equal(st, ost)
+        m = ost.astype(bool)
+        assert m.mean() > 0.5
+        # tracks within 1e-5 relative (north_star); the float normal-equation sums are tree-ordered on the GPU
+        assert np.all(np.abs(out[m] - oout[m]) <= 1e-5 * np.maximum(1.0, np.abs(oout[m])))
+        assert np.allclose(err[m], oerr[m], rtol=1e-4, atol=1e-4)
+        ctx.close()
+
+
+def test_klt_golden(hip_lib):
+    g, e = golden("align"), golden("extract")
+    ctx = make_ctx(hip_lib, width=320, height=240, max_frames=2)
+    for s in range(2):
+        ctx.upload_gray(s, e["imgs"][s])
+    ctx.build_pyramid(0, 2)
+    out, st, err = ctx.klt_track(0, 1, g["px_ref"].astype(np.float32), g["klt_init"])
+    assert np.array_equal(st, g["klt_status"])
+    m = st.astype(bool)
+    assert np.all(np.abs(out[m] - g["klt_pts"][m]) <= 1e-5 * np.maximum(1.0, np.abs(g["klt_pts"][m])))
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------- B1-B5
+def _ba_close(g, r, tol=1e-5):
+    for k in ("err", "chi2_edge", "Hll", "bl", "Hpl", "Hpp", "bp"):
+        a, b = np.asarray(g[k]), np.asarray(r[k])
+        scale = max(1.0, np.abs(b).max())
+        assert np.all(np.abs(a - b) <= 1e-9 * scale), (k, np.abs(a - b).max(), scale)      # far inside the 1e-5 bar
+    assert abs(g["chi2"] - r["chi2"]) <= 1e-9 * max(1.0, abs(r["chi2"]))
+
+
+def test_ba_golden_known_answer(hip_lib):
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for name in ("ba_exact", "ba_noisy"):
+        g = golden(name)
+        r = ctx.ba_linearize(g["poses"], g["fixed"], g["points"], g["edge_pose"], g["edge_point"], g["obs"])
+        _ba_close(r, {k[2:]: (float(g[k]) if k == "o_chi2" else g[k]) for k in g.files if k.startswith("o_")})
+        if name == "ba_exact":                               # test/test_local_ba.cpp fixture: residuals vanish
+            assert np.abs(r["err"]).max() < 1e-9
+    ctx.close()
+
+
+def test_ba_window_10x2000(hip_lib, oracle):
+    f = synth.ba_window(10, 2000, seed=7)
+    assert len(f["obs"]) > 10000
+    f["obs"][::97] += 30.0                                   # outliers beyond the Huber delta
+    ctx = make_ctx(hip_lib, max_frames=1)
+    g = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+    r = oracle.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+    _ba_close(g, r)
+    # unsorted edge order gives the same blocks (CSR is built by the ABI)
+    perm = np.random.default_rng(0).permutation(len(f["obs"]))
+    g2 = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"][perm], f["edge_point"][perm], f["obs"][perm])
+    assert np.allclose(g2["Hll"], g["Hll"], rtol=1e-12, atol=1e-9) and np.allclose(g2["err"], g["err"][perm])
+    # resident form, 3 LM-like state updates without re-uploading the structure
+    K, P, E = ctx.ba_upload(0, f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+    rng = np.random.default_rng(1)
+    poses, pts = f["poses"].copy(), f["points"].copy()
+    for _ in range(3):
+        poses[1:] += rng.normal(0, 1e-3, poses[1:].shape); pts += rng.normal(0, 1e-3, pts.shape)
+        ctx.ba_set_state(0, poses, pts)
+        ctx.ba_linearize_resident(0, 1)
+        _ba_close(ctx.ba_download(0, K, P, E), oracle.ba_linearize(poses, f["fixed"], pts, f["edge_pose"], f["edge_point"], f["obs"]))
+    # Huber off
+    g3 = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"], huber_delta=0.0)
+    assert abs(g3["chi2"] - g3["chi2_edge"].sum()) < 1e-6 * g3["chi2"]
+    ctx.close()
+
+
+def test_ba_normalised_plane_formulation(hip_lib, oracle):
+    f = synth.ba_window(6, 300, seed=3)
+    cam = oracle.camera()
+    obs_n = np.stack([(f["obs"][:, 0] - cam.cx) / cam.fx, (f["obs"][:, 1] - cam.cy) / cam.fy], 1)
+    poses_tr = np.concatenate([f["poses"][:, 3:], f["poses"][:, :3]], 1)
+    ctx = make_ctx(hip_lib, max_frames=1)
+    g = ctx.ba_linearize(poses_tr, f["fixed"], f["points"], f["edge_pose"], f["edge_point"], obs_n, huber_delta=0.0, formulation=1)
+    Hll = np.zeros_like(g["Hll"]); Hpp = np.zeros_like(g["Hpp"])
+    for e in range(len(obs_n)):
+        ip, il = f["edge_pose"][e], f["edge_point"][e]
+        er, Jp, Jx = oracle.ba_edge_norm(poses_tr[ip], f["points"][il], obs_n[e])
+        assert np.allclose(g["err"][e], er, atol=1e-12)
+        Hll[il] += Jp.T @ Jp
+        if not f["fixed"][ip]:
+            Hpp[ip] += Jx.T @ Jx
+    assert np.allclose(g["Hll"], Hll, rtol=1e-10, atol=1e-12) and np.allclose(g["Hpp"], Hpp, rtol=1e-10, atol=1e-12)
+    ctx.close()

@@ -1,0 +1,319 @@
+"""ctypes loader of libygz_hip.so (the C ABI declared in include/ygz_hip.h).
+
+This is harness plumbing for tests/ and bench.py: numpy arrays in, numpy arrays out, every
+call goes straight through the C ABI.  There is NO fallback path: if the HIP library is
+missing or no gfx950 device is usable the calls raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libygz_hip.so")
+MAX_LEVELS = 8
+
+OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5
+
+
+class YgzHipError(RuntimeError):
+    def __init__(self, code, what, hip_err=0):
+        super().__init__("%s failed: code %d (hip error %d)" % (what, code, hip_err))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("image_width", C.c_int), ("image_height", C.c_int), ("pyramid_levels", C.c_int),
+                ("cell_size", C.c_int), ("fast_threshold", C.c_int), ("nms_tie_suppress", C.c_int),
+                ("max_frames", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("debug_maps", C.c_int)]
+
+
+class KptSoa(C.Structure):
+    _fields_ = [("px", C.POINTER(C.c_double)), ("level", C.POINTER(C.c_int32)), ("score", C.POINTER(C.c_float)),
+                ("angle", C.POINTER(C.c_float)), ("desc", C.POINTER(C.c_uint8))]
+
+
+class AlignPair(C.Structure):
+    _fields_ = [("ref_slot", C.c_int), ("cur_slot", C.c_int), ("T_ref", C.c_double * 7), ("T_cur", C.c_double * 7)]
+
+
+class KltParams(C.Structure):
+    _fields_ = [("win", C.c_int), ("max_level", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double),
+                ("min_eig_threshold", C.c_double), ("use_initial_flow", C.c_int)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("poses", C.POINTER(C.c_double)), ("pose_fixed", C.POINTER(C.c_uint8)),
+                ("points", C.POINTER(C.c_double)), ("edge_pose", C.POINTER(C.c_int32)),
+                ("edge_point", C.POINTER(C.c_int32)), ("obs", C.POINTER(C.c_double)),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double), ("formulation", C.c_int)]
+
+
+# every symbol include/ygz_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_error_string",
+    "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end",
+    "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_level_size",
+    "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_get_fast_maps",
+    "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
+    "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
+    "ygz_hip_default_klt_params", "ygz_hip_klt_track",
+    "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download",
+]
+
+_lib = None
+
+
+def load():
+    """Load the in-tree HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libygz_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ygz_hip_error_string.restype = C.c_char_p
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class HipContext:
+    """One ygz_hip_ctx: owns HBM frame slots on one GPU and one HIP stream."""
+
+    def __init__(self, width=640, height=480, levels=3, max_frames=8, device=0, debug_maps=False, stream=None,
+                 fast_threshold=15, cell_size=10, nms_tie_suppress=0):
+        self.lib = load()
+        p = Params()
+        self.lib.ygz_hip_default_params(C.byref(p))
+        p.image_width, p.image_height, p.pyramid_levels = width, height, levels
+        p.max_frames, p.debug_maps = max_frames, int(debug_maps)
+        p.fast_threshold, p.cell_size, p.nms_tie_suppress = fast_threshold, cell_size, nms_tie_suppress
+        self.params = p
+        self._ctx = C.c_void_p()
+        rc = self.lib.ygz_hip_create(C.byref(self._ctx), device, C.byref(p), C.c_void_p(stream))
+        if rc != OK:
+            self._ctx = C.c_void_p()
+            raise YgzHipError(rc, "ygz_hip_create")
+        self.width, self.height, self.levels, self.max_frames = width, height, levels, max_frames
+        self.cells = self.lib.ygz_hip_max_keypoints(self._ctx)
+
+    def _chk(self, rc, what):
+        if rc != OK:
+            raise YgzHipError(rc, what, self.lib.ygz_hip_last_hip_error(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self.lib.ygz_hip_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._chk(self.lib.ygz_hip_synchronize(self._ctx), "synchronize")
+
+    def timer_begin(self):
+        self._chk(self.lib.ygz_hip_timer_begin(self._ctx), "timer_begin")
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self._chk(self.lib.ygz_hip_timer_end(self._ctx, C.byref(ms)), "timer_end")
+        return ms.value
+
+    # ---- frames
+    def upload_gray(self, slot, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.height, self.width)
+        self._chk(self.lib.ygz_hip_upload_gray(self._ctx, slot, _p(gray, C.c_uint8), self.width), "upload_gray")
+
+    def upload_bgr(self, slot, bgr):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        assert bgr.shape == (self.height, self.width, 3)
+        self._chk(self.lib.ygz_hip_upload_bgr(self._ctx, slot, _p(bgr, C.c_uint8), self.width * 3), "upload_bgr")
+
+    def build_pyramid(self, slot_begin=0, n_slots=1, from_bgr=False):
+        self._chk(self.lib.ygz_hip_build_pyramid(self._ctx, slot_begin, n_slots, int(from_bgr)), "build_pyramid")
+
+    def level_size(self, level):
+        w, h = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.ygz_hip_level_size(self._ctx, level, C.byref(w), C.byref(h)), "level_size")
+        return w.value, h.value
+
+    def download_level(self, slot, level):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        self._chk(self.lib.ygz_hip_download_level(self._ctx, slot, level, _p(out, C.c_uint8)), "download_level")
+        return out
+
+    # ---- extractor
+    def detect(self, slot_begin=0, n_slots=1, occupied=None):
+        occ = None
+        if occupied is not None:
+            occupied = np.ascontiguousarray(occupied, np.uint8).reshape(n_slots, self.cells)
+            occ = _p(occupied, C.c_uint8)
+        self._chk(self.lib.ygz_hip_detect(self._ctx, slot_begin, n_slots, occ), "detect")
+
+    def keypoint_count(self, slot):
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_keypoint_count(self._ctx, slot, C.byref(n)), "keypoint_count")
+        return n.value
+
+    def get_keypoints(self, slot):
+        cap = self.cells
+        px = np.empty((cap, 2), np.float64)
+        level = np.empty(cap, np.int32)
+        score = np.empty(cap, np.float32)
+        angle = np.empty(cap, np.float32)
+        desc = np.empty((cap, 32), np.uint8)
+        soa = KptSoa(_p(px, C.c_double), _p(level, C.c_int32), _p(score, C.c_float), _p(angle, C.c_float), _p(desc, C.c_uint8))
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_get_keypoints(self._ctx, slot, C.byref(soa), cap, C.byref(n)), "get_keypoints")
+        n = n.value
+        return dict(px=px[:n].copy(), level=level[:n].copy(), score=score[:n].copy(), angle=angle[:n].copy(), desc=desc[:n].copy())
+
+    def describe(self, slot, px, level):
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+        level = np.ascontiguousarray(level, np.int32)
+        self._chk(self.lib.ygz_hip_describe(self._ctx, slot, _p(px, C.c_double), _p(level, C.c_int32), len(level)), "describe")
+
+    def get_fast_maps(self, slot, level):
+        w, h = self.level_size(level)
+        score = np.empty((h, w), np.uint8)
+        nms = np.empty((h, w), np.uint8)
+        self._chk(self.lib.ygz_hip_get_fast_maps(self._ctx, slot, level, _p(score, C.c_uint8), _p(nms, C.c_uint8)), "get_fast_maps")
+        return score, nms
+
+    # ---- matcher
+    def match_slots(self, query_slots, train_slots, cross_check=1):
+        q = np.ascontiguousarray(query_slots, np.int32)
+        t = np.ascontiguousarray(train_slots, np.int32)
+        self._chk(self.lib.ygz_hip_match_slots(self._ctx, _p(q, C.c_int32), _p(t, C.c_int32), len(q), cross_check), "match_slots")
+
+    def match_slots_again(self, cross_check=1):
+        self._chk(self.lib.ygz_hip_match_slots_again(self._ctx, cross_check), "match_slots_again")
+
+    def get_matches(self, pair):
+        idx = np.empty(self.cells, np.int32)
+        dist = np.empty(self.cells, np.int32)
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_get_matches(self._ctx, pair, _p(idx, C.c_int32), _p(dist, C.c_int32), self.cells, C.byref(n)), "get_matches")
+        return idx[:n.value].copy(), dist[:n.value].copy()
+
+    def hamming_match(self, q, t, cross_check=1, want_second=False):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.empty(len(q), np.int32)
+        dist = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.int32) if want_second else None
+        self._chk(self.lib.ygz_hip_hamming_match(self._ctx, _p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), cross_check,
+                                                 _p(idx, C.c_int32), _p(dist, C.c_int32),
+                                                 _p(d2, C.c_int32) if want_second else None), "hamming_match")
+        return (idx, dist, d2) if want_second else (idx, dist)
+
+    # ---- alignment
+    def find_direct_projection(self, ref_slot, T_ref, cur_slot, T_cur, px_ref, depth_ref, level_ref, px_cur):
+        pair = AlignPair(ref_slot, cur_slot, (C.c_double * 7)(*T_ref), (C.c_double * 7)(*T_cur))
+        px_ref = np.ascontiguousarray(px_ref, np.float64).reshape(-1, 2)
+        depth_ref = np.ascontiguousarray(depth_ref, np.float64)
+        level_ref = np.ascontiguousarray(level_ref, np.int32)
+        px_cur = np.ascontiguousarray(px_cur, np.float64).reshape(-1, 2).copy()
+        n = len(depth_ref)
+        sl = np.empty(n, np.int32)
+        ok = np.empty(n, np.uint8)
+        self._chk(self.lib.ygz_hip_find_direct_projection(self._ctx, C.byref(pair), _p(px_ref, C.c_double), _p(depth_ref, C.c_double),
+                                                          _p(level_ref, C.c_int32), _p(px_cur, C.c_double), _p(sl, C.c_int32),
+                                                          _p(ok, C.c_uint8), n), "find_direct_projection")
+        return ok.astype(bool), px_cur, sl
+
+    def align2d(self, cur_slot, level, pwb, uv, n_iter=10):
+        pwb = np.ascontiguousarray(pwb, np.uint8).reshape(-1, 100)
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2).copy()
+        n = len(pwb)
+        ok = np.empty(n, np.uint8)
+        chi2 = np.empty(n, np.float32)
+        patch = np.ascontiguousarray(pwb.reshape(n, 10, 10)[:, 1:9, 1:9]).reshape(n, 64)
+        self._chk(self.lib.ygz_hip_align2d(self._ctx, cur_slot, level, _p(pwb, C.c_uint8), _p(patch, C.c_uint8), _p(uv, C.c_double),
+                                           _p(ok, C.c_uint8), _p(chi2, C.c_float), n, n_iter), "align2d")
+        return ok.astype(bool), uv, chi2
+
+    def sparse_align(self, ref_slot, T_ref, cur_slot, T_cur, px, depth, has_mp, max_level=2, min_level=0, n_iter=30):
+        Tr = (C.c_double * 7)(*T_ref)
+        Tc = (C.c_double * 7)(*T_cur)
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+        depth = np.ascontiguousarray(depth, np.float64)
+        has_mp = np.ascontiguousarray(has_mp, np.uint8)
+        nm = C.c_int(0)
+        iters = (C.c_int * MAX_LEVELS)()
+        self._chk(self.lib.ygz_hip_sparse_align(self._ctx, ref_slot, Tr, cur_slot, Tc, _p(px, C.c_double), _p(depth, C.c_double),
+                                                _p(has_mp, C.c_uint8), len(depth), max_level, min_level, n_iter, C.byref(nm), iters),
+                  "sparse_align")
+        return nm.value, np.array(list(Tc)), list(iters)[:self.levels]
+
+    # ---- KLT
+    def klt_params(self):
+        p = KltParams()
+        self.lib.ygz_hip_default_klt_params(C.byref(p))
+        return p
+
+    def klt_track(self, prev_slot, cur_slot, prev_pts, next_pts_init, params=None):
+        prm = params or self.klt_params()
+        pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        npts = np.ascontiguousarray(next_pts_init, np.float32).reshape(-1, 2).copy()
+        st = np.empty(len(pp), np.uint8)
+        err = np.empty(len(pp), np.float32)
+        self._chk(self.lib.ygz_hip_klt_track(self._ctx, prev_slot, cur_slot, _p(pp, C.c_float), _p(npts, C.c_float), len(pp),
+                                             C.byref(prm), _p(st, C.c_uint8), _p(err, C.c_float)), "klt_track")
+        return npts, st, err
+
+    # ---- BA
+    def _ba_problem(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam=None):
+        self._keep = [np.ascontiguousarray(poses, np.float64), np.ascontiguousarray(fixed, np.uint8),
+                      np.ascontiguousarray(points, np.float64), np.ascontiguousarray(edge_pose, np.int32),
+                      np.ascontiguousarray(edge_point, np.int32), np.ascontiguousarray(obs, np.float64)]
+        a = self._keep
+        fx, fy, cx, cy = cam if cam else (float(self.params.fx), float(self.params.fy), float(self.params.cx), float(self.params.cy))
+        return BaProblem(len(a[0]), len(a[2]), len(a[3]), _p(a[0], C.c_double), _p(a[1], C.c_uint8), _p(a[2], C.c_double),
+                         _p(a[3], C.c_int32), _p(a[4], C.c_int32), _p(a[5], C.c_double), fx, fy, cx, cy, float(huber_delta), formulation)
+
+    @staticmethod
+    def _ba_out(K, P, E):
+        return dict(Hpp=np.empty((K, 6, 6)), bp=np.empty((K, 6)), Hll=np.empty((P, 3, 3)), bl=np.empty((P, 3)),
+                    Hpl=np.empty((E, 6, 3)), err=np.empty((E, 2)), chi2_edge=np.empty(E), chi2=np.empty(1))
+
+    def ba_linearize(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None):
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam)
+        o = self._ba_out(pb.n_poses, pb.n_points, pb.n_edges)
+        d = lambda k: _p(o[k], C.c_double)
+        self._chk(self.lib.ygz_hip_ba_linearize(self._ctx, C.byref(pb), d("Hpp"), d("bp"), d("Hll"), d("bl"), d("Hpl"), d("err"),
+                                                d("chi2_edge"), d("chi2")), "ba_linearize")
+        o["chi2"] = float(o["chi2"][0])
+        return o
+
+    def ba_upload(self, window, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None):
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam)
+        self._chk(self.lib.ygz_hip_ba_upload(self._ctx, window, C.byref(pb)), "ba_upload")
+        return pb.n_poses, pb.n_points, pb.n_edges
+
+    def ba_set_state(self, window, poses, points):
+        poses = np.ascontiguousarray(poses, np.float64)
+        points = np.ascontiguousarray(points, np.float64)
+        self._chk(self.lib.ygz_hip_ba_set_state(self._ctx, window, _p(poses, C.c_double), _p(points, C.c_double)), "ba_set_state")
+
+    def ba_linearize_resident(self, window_begin=0, n_windows=1):
+        self._chk(self.lib.ygz_hip_ba_linearize_resident(self._ctx, window_begin, n_windows), "ba_linearize_resident")
+
+    def ba_download(self, window, K, P, E):
+        o = self._ba_out(K, P, E)
+        d = lambda k: _p(o[k], C.c_double)
+        self._chk(self.lib.ygz_hip_ba_download(self._ctx, window, d("Hpp"), d("bp"), d("Hll"), d("bl"), d("Hpl"), d("err"),
+                                               d("chi2_edge"), d("chi2")), "ba_download")
+        o["chi2"] = float(o["chi2"][0])
+        return o

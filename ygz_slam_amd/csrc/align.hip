@@ -1,0 +1,273 @@
+// L1-L2 -- 8x8 inverse-compositional patch alignment + the direct-projection search around it.
+// Replaces cvutils::Align2D (src/Algorithm/CVUtils.cpp:186-318) and Matcher::FindDirectProjection
+// (src/Algorithm/Matcher.cpp:356-466: GetWarpAffineMatrix, GetBestSearchLevel, WarpAffine).
+//
+// Mapping: one lane = one candidate patch, 64 candidates per workgroup.  The reference sums its 64
+// float residual terms in raster order and branches on the result (convergence at 0.03 px,
+// chi2 < 20000), so the per-patch arithmetic is kept in exactly that order (no FMA contraction,
+// explicit _rn ops): results are bit-identical to oracle/align.c.  The affine-warped 10x10
+// reference patch of every lane lives in LDS as pwb[k][lane] (byte k of 64 lanes is contiguous:
+// conflict-free), gradients are re-derived from it instead of being stored; current-image
+// pixels come straight from HBM/L2 (9x9 window per iteration, one new column per step).
+#include "ygz_internal.h"
+#include "se3_dev.h"
+
+struct Cam { float fx, fy, cx, cy; };
+
+__device__ __forceinline__ void pixel2camera_d(const Cam &c, const double px[2], double depth, double out[3])
+{   // Basic/Camera.h:53-59
+    out[0] = (px[0] - c.cx) * depth / c.fx;
+    out[1] = (px[1] - c.cy) * depth / c.fy;
+    out[2] = depth;
+}
+__device__ __forceinline__ void camera2pixel_d(const Cam &c, const double p[3], double out[2])
+{   // Basic/Camera.h:46-51
+    out[0] = c.fx * p[0] / p[2] + c.cx;
+    out[1] = c.fy * p[1] / p[2] + c.cy;
+}
+
+__device__ __forceinline__ float cof3(const float m[9], int i, int j)
+{
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return __fsub_rn(__fmul_rn(m[3 * i1 + j1], m[3 * i2 + j2]), __fmul_rn(m[3 * i1 + j2], m[3 * i2 + j1]));
+}
+
+// cvutils::Align2D core.  pwb: LDS, element k of this lane at pwb[k * 64].
+__device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, const uint8_t *pwb, int n_iter,
+                             double *pu, double *pv, float *chi2_out)
+{
+    // gradient Hessian: J = (0.5*(I[x+1]-I[x-1]), 0.5*(I[y+1]-I[y-1]), 1); every partial sum is a
+    // multiple of 0.25 below 2^22, hence exact in float in any order
+    float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) {
+            const int k = (y + 1) * 10 + (x + 1);
+            const float jx = 0.5f * (float)((int)pwb[(k + 1) * 64] - (int)pwb[(k - 1) * 64]);
+            const float jy = 0.5f * (float)((int)pwb[(k + 10) * 64] - (int)pwb[(k - 10) * 64]);
+            H[0] = __fadd_rn(H[0], __fmul_rn(jx, jx)); H[1] = __fadd_rn(H[1], __fmul_rn(jx, jy)); H[2] = __fadd_rn(H[2], jx);
+            H[4] = __fadd_rn(H[4], __fmul_rn(jy, jy)); H[5] = __fadd_rn(H[5], jy); H[8] = __fadd_rn(H[8], 1.0f);
+        }
+    H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
+    float Hinv[9];
+    {
+        const float c0 = cof3(H, 0, 0), c1 = cof3(H, 1, 0), c2 = cof3(H, 2, 0);
+        const float det = __fadd_rn(__fadd_rn(__fmul_rn(c0, H[0]), __fmul_rn(c1, H[3])), __fmul_rn(c2, H[6]));
+        const float invdet = __fdiv_rn(1.0f, det);
+        Hinv[0] = __fmul_rn(c0, invdet); Hinv[1] = __fmul_rn(c1, invdet); Hinv[2] = __fmul_rn(c2, invdet);
+        Hinv[3] = __fmul_rn(cof3(H, 0, 1), invdet); Hinv[4] = __fmul_rn(cof3(H, 1, 1), invdet); Hinv[5] = __fmul_rn(cof3(H, 2, 1), invdet);
+        Hinv[6] = __fmul_rn(cof3(H, 0, 2), invdet); Hinv[7] = __fmul_rn(cof3(H, 1, 2), invdet); Hinv[8] = __fmul_rn(cof3(H, 2, 2), invdet);
+    }
+    float mean_diff = 0.f;
+    float u = (float)*pu, v = (float)*pv;
+    const float min_update_squared = (float)(0.03 * 0.03);
+    float chi2 = 0.f;
+    bool converged = false;
+    for (int iter = 0; iter < n_iter; ++iter) {
+        chi2 = 0.f;
+        if (u != u || v != v) break;
+        const int u_r = (int)floorf(u), v_r = (int)floorf(v);
+        if (u_r < 4 || v_r < 4 || u_r >= w - 4 || v_r >= h - 4) break;
+        const float sx = __fsub_rn(u, (float)u_r), sy = __fsub_rn(v, (float)v_r);
+        const float wTL = (float)((1.0 - (double)sx) * (1.0 - (double)sy));
+        const float wTR = (float)((double)sx * (1.0 - (double)sy));
+        const float wBL = (float)((1.0 - (double)sx) * (double)sy);
+        const float wBR = __fmul_rn(sx, sy);
+        float J0 = 0.f, J1 = 0.f, J2 = 0.f;
+        for (int y = 0; y < 8; ++y) {
+            const uint8_t *it = cur + (size_t)(v_r + y - 4) * w + (u_r - 4);
+            float tl = (float)it[0], bl = (float)it[w];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float tr = (float)it[x + 1], br = (float)it[w + x + 1];
+                const float sp = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wTL, tl), __fmul_rn(wTR, tr)), __fmul_rn(wBL, bl)), __fmul_rn(wBR, br));
+                const int k = (y + 1) * 10 + (x + 1);
+                const float refv = (float)pwb[k * 64];
+                const float res = __fadd_rn(__fsub_rn(sp, refv), mean_diff);
+                const float jx = 0.5f * (float)((int)pwb[(k + 1) * 64] - (int)pwb[(k - 1) * 64]);
+                const float jy = 0.5f * (float)((int)pwb[(k + 10) * 64] - (int)pwb[(k - 10) * 64]);
+                J0 = __fsub_rn(J0, __fmul_rn(res, jx));
+                J1 = __fsub_rn(J1, __fmul_rn(res, jy));
+                J2 = __fsub_rn(J2, res);
+                chi2 = __fadd_rn(chi2, __fmul_rn(res, res));
+                tl = tr; bl = br;
+            }
+        }
+        const float up0 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[0], J0), __fmul_rn(Hinv[1], J1)), __fmul_rn(Hinv[2], J2));
+        const float up1 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[3], J0), __fmul_rn(Hinv[4], J1)), __fmul_rn(Hinv[5], J2));
+        const float up2 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[6], J0), __fmul_rn(Hinv[7], J1)), __fmul_rn(Hinv[8], J2));
+        u = __fadd_rn(u, up0); v = __fadd_rn(v, up1); mean_diff = __fadd_rn(mean_diff, up2);
+        if (__fadd_rn(__fmul_rn(up0, up0), __fmul_rn(up1, up1)) < min_update_squared) { converged = true; break; }
+    }
+    *pu = (double)u; *pv = (double)v;
+    if (chi2_out) *chi2_out = chi2;
+    return converged && chi2 < 20000.f;
+}
+
+struct FdpArgs {
+    const uint8_t *lvl[YGZ_MAX_LEVELS];
+    int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
+    int n_levels;
+    int ref_slot, cur_slot;
+    Se3 T_ref, T_cur;
+    Cam cam;
+    const double *px_ref, *depth_ref; const int32_t *level_ref;
+    double *px_cur; int32_t *search_level; uint8_t *ok;
+    int n;
+};
+
+// Matcher::FindDirectProjection (Feature* overload, Matcher.cpp:385-417)
+__global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.n) return;
+    uint8_t *pwb = pwb_all + threadIdx.x;
+    const double depth = A.depth_ref[i];
+    if (depth < 0) { A.ok[i] = 0; A.search_level[i] = 0; return; }
+    const int Lr = A.level_ref[i];
+    const double px_ref[2] = { A.px_ref[2 * i], A.px_ref[2 * i + 1] };
+    double pt_ref[3];
+    pixel2camera_d(A.cam, px_ref, depth, pt_ref);
+    Se3 Tri, TCR;
+    se3_inv_d(&A.T_ref, &Tri);
+    se3_mul_d(&A.T_cur, &Tri, &TCR);
+    // GetWarpAffineMatrix (Matcher.cpp:420-436)
+    double Am[4];
+    {
+        double pw[3], pdu[3], pdv[3], q[3], pc[2], pu[2], pv[2];
+        se3_act_d(&Tri, pt_ref, pw);
+        const double s = (double)(1 << Lr);
+        const double pxu[2] = { px_ref[0] + 4.0 * s, px_ref[1] + 0.0 * s };
+        const double pxv[2] = { px_ref[0] + 0.0 * s, px_ref[1] + 4.0 * s };
+        pixel2camera_d(A.cam, pxu, pt_ref[2], pdu);
+        pixel2camera_d(A.cam, pxv, pt_ref[2], pdv);
+        se3_act_d(&TCR, pw, q);  camera2pixel_d(A.cam, q, pc);
+        se3_act_d(&TCR, pdu, q); camera2pixel_d(A.cam, q, pu);
+        se3_act_d(&TCR, pdv, q); camera2pixel_d(A.cam, q, pv);
+        Am[0] = (pu[0] - pc[0]) / 4; Am[2] = (pu[1] - pc[1]) / 4;
+        Am[1] = (pv[0] - pc[0]) / 4; Am[3] = (pv[1] - pc[1]) / 4;
+    }
+    // GetBestSearchLevel (Matcher.h:123-134)
+    int sl = 0;
+    {
+        double D = Am[0] * Am[3] - Am[2] * Am[1];
+        while (D > 3.0 && sl < A.n_levels - 1) { sl += 1; D *= 0.25; }
+    }
+    // WarpAffine (Matcher.cpp:438-466), half_patch_size 5
+    {
+        const int rw = A.w[Lr], rh = A.h[Lr];
+        const uint8_t *img = A.lvl[Lr] + (size_t)A.ref_slot * rw * rh;
+        const double det = Am[0] * Am[3] - Am[2] * Am[1];
+        const double invdet = 1.0 / det;
+        const double R0 = Am[3] * invdet, R1 = -Am[1] * invdet, R2 = -Am[2] * invdet, R3 = Am[0] * invdet;
+        const double rx = px_ref[0] / (double)(1 << Lr), ry = px_ref[1] / (double)(1 << Lr);
+        for (int y = 0; y < 10; ++y)
+            for (int x = 0; x < 10; ++x) {
+                double ppx = (double)(x - 5), ppy = (double)(y - 5);
+                ppx *= (double)(1 << sl); ppy *= (double)(1 << sl);
+                const double qx = (R0 * ppx + R1 * ppy) + rx, qy = (R2 * ppx + R3 * ppy) + ry;
+                uint8_t val = 0;
+                if (!(qx < 0 || qy < 0 || qx >= rw - 1 || qy >= rh - 1)) {
+                    // cvutils::GetBilateralInterpUchar (CVUtils.h:59-71)
+                    const double xx = qx - floor(qx), yy = qy - floor(qy);
+                    const uint8_t *d = img + (size_t)((int)qy) * rw + (int)qx;
+                    val = (uint8_t)((1 - xx) * (1 - yy) * d[0] + xx * (1 - yy) * d[1] + (1 - xx) * yy * d[rw] + xx * yy * d[rw + 1]);
+                }
+                pwb[(y * 10 + x) * 64] = val;
+            }
+    }
+    const int cw = A.w[sl], ch = A.h[sl];
+    const uint8_t *cur = A.lvl[sl] + (size_t)A.cur_slot * cw * ch;
+    double u = A.px_cur[2 * i] / (double)(1 << sl), v = A.px_cur[2 * i + 1] / (double)(1 << sl);
+    const bool good = align2d_core(cur, cw, ch, pwb, 10, &u, &v, nullptr);
+    const double ox = u * (double)(1 << sl), oy = v * (double)(1 << sl);
+    A.px_cur[2 * i] = ox; A.px_cur[2 * i + 1] = oy;
+    A.search_level[i] = sl;
+    const bool inframe = ox >= 10 && ox < A.w[0] - 10 && oy >= 10 && oy < A.h[0] - 10;     // Frame::InFrame(px,10)
+    A.ok[i] = (uint8_t)(inframe && good);
+}
+
+__global__ __launch_bounds__(64) void k_align2d(const uint8_t *__restrict__ cur, int w, int h,
+                                                const uint8_t *__restrict__ pwb_in, double *__restrict__ uv,
+                                                uint8_t *__restrict__ ok, float *__restrict__ chi2, int n, int n_iter)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *pwb = pwb_all + threadIdx.x;
+    for (int k = 0; k < 100; ++k) pwb[k * 64] = pwb_in[(size_t)i * 100 + k];
+    double u = uv[2 * i], v = uv[2 * i + 1];
+    float c2 = 0.f;
+    const bool good = align2d_core(cur, w, h, pwb, n_iter, &u, &v, &c2);
+    uv[2 * i] = u; uv[2 * i + 1] = v; ok[i] = (uint8_t)good; chi2[i] = c2;
+}
+
+static void se3_from7(const double *a, Se3 *T) { for (int k = 0; k < 4; ++k) T->q[k] = a[k]; for (int k = 0; k < 3; ++k) T->t[k] = a[4 + k]; }
+
+extern "C" {
+
+int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair, const double *px_ref, const double *depth_ref,
+                                   const int32_t *level_ref, double *px_cur, int32_t *search_level, uint8_t *ok, int n)
+{
+    if (!ctx || !pair || n < 0) return YGZ_E_INVALID;
+    if (n == 0) return YGZ_OK;
+    if (!px_ref || !depth_ref || !level_ref || !px_cur || !search_level || !ok) return YGZ_E_INVALID;
+    if (pair->ref_slot < 0 || pair->ref_slot >= ctx->prm.max_frames || pair->cur_slot < 0 || pair->cur_slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (!ctx->pyr_valid[pair->ref_slot] || !ctx->pyr_valid[pair->cur_slot]) return YGZ_E_STATE;
+    for (int i = 0; i < n; ++i) if (level_ref[i] < 0 || level_ref[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
+    // device staging: [px_ref 16n][depth 8n][px_cur 16n][level 4n][search 4n][ok n]
+    uint8_t *buf = nullptr;
+    const size_t N = (size_t)n, bytes = N * (16 + 8 + 16 + 4 + 4 + 1) + 64;
+    int rc = ygz_scratch(ctx, SCR_ALIGN_IN, bytes, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    double *d_pxr = (double *)buf, *d_dep = d_pxr + 2 * N, *d_pxc = d_dep + N;
+    int32_t *d_lvl = (int32_t *)(d_pxc + 2 * N), *d_sl = d_lvl + N;
+    uint8_t *d_ok = (uint8_t *)(d_sl + N);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pxr, px_ref, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_dep, depth_ref, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pxc, px_cur, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_lvl, level_ref, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    FdpArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
+    A.n_levels = ctx->prm.pyramid_levels;
+    A.ref_slot = pair->ref_slot; A.cur_slot = pair->cur_slot;
+    se3_from7(pair->T_ref, &A.T_ref); se3_from7(pair->T_cur, &A.T_cur);
+    A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.px_ref = d_pxr; A.depth_ref = d_dep; A.level_ref = d_lvl; A.px_cur = d_pxc; A.search_level = d_sl; A.ok = d_ok; A.n = n;
+    hipLaunchKernelGGL(k_find_direct_projection, dim3(ygz_div_up(n, 64)), dim3(64), 0, ctx->stream, A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_cur, d_pxc, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(search_level, d_sl, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, d_ok, N, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pwb, const uint8_t *patch, double *uv,
+                    uint8_t *ok, float *chi2, int n, int n_iter)
+{
+    (void)patch;     // the 8x8 patch is the interior of the 10x10 one (Matcher.cpp:369-375); kept for signature parity
+    if (!ctx || n < 0 || cur_slot < 0 || cur_slot >= ctx->prm.max_frames || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
+    if (n == 0) return YGZ_OK;
+    if (!pwb || !uv || !ok) return YGZ_E_INVALID;
+    if (!ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
+    uint8_t *buf = nullptr;
+    const size_t N = (size_t)n, bytes = N * (16 + 4 + 100 + 1) + 64;
+    int rc = ygz_scratch(ctx, SCR_ALIGN_IN, bytes, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    double *d_uv = (double *)buf; float *d_chi = (float *)(d_uv + 2 * N);
+    uint8_t *d_pwb = (uint8_t *)(d_chi + N), *d_ok = d_pwb + 100 * N;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_uv, uv, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pwb, pwb, N * 100, hipMemcpyHostToDevice, ctx->stream));
+    const int w = ctx->lw[level], h = ctx->lh[level];
+    hipLaunchKernelGGL(k_align2d, dim3(ygz_div_up(n, 64)), dim3(64), 0, ctx->stream,
+                       ctx->lvl[level] + (size_t)cur_slot * w * h, w, h, d_pwb, d_uv, d_ok, d_chi, n, n_iter);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(uv, d_uv, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, d_ok, N, hipMemcpyDeviceToHost, ctx->stream));
+    if (chi2) YGZ_HIPCHK(ctx, hipMemcpyAsync(chi2, d_chi, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// Context, HBM frame store and host<->device plumbing of the C ABI (include/ygz_hip.h).
+#include "ygz_internal.h"
+#include <string.h>
+#include <math.h>
+#include <new>
+
+extern "C" {
+
+void ygz_hip_default_params(ygz_hip_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->image_width = 640; p->image_height = 480;      // config/default.yaml:15-16
+    p->pyramid_levels = 3;                            // Basic/Frame.h:23
+    p->cell_size = 10; p->fast_threshold = 15;        // default.yaml:50-51
+    p->nms_tie_suppress = 0;
+    p->max_frames = 8;
+    p->fx = 520.9f; p->fy = 521.0f; p->cx = 325.1f; p->cy = 249.7f;   // default.yaml:32-35
+    p->debug_maps = 0;
+}
+
+const char *ygz_hip_error_string(int code)
+{
+    switch (code) {
+    case YGZ_OK: return "ok";
+    case YGZ_E_INVALID: return "invalid argument";
+    case YGZ_E_HIP: return "HIP runtime error";
+    case YGZ_E_NO_DEVICE: return "no usable gfx950 device";
+    case YGZ_E_CAPACITY: return "capacity exceeded";
+    case YGZ_E_STATE: return "call order violated";
+    default: return "unknown error";
+    }
+}
+
+int ygz_hip_last_hip_error(const ygz_hip_ctx *ctx) { return ctx ? ctx->last_hip_error : 0; }
+int ygz_hip_max_keypoints(const ygz_hip_ctx *ctx) { return ctx ? ctx->cells : 0; }
+
+}  // extern "C"
+
+int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out)
+{
+    if (id < 0 || id >= YGZ_N_SCRATCH) return YGZ_E_INVALID;
+    if (ctx->scratch_bytes[id] < bytes) {
+        if (ctx->scratch[id]) { YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->scratch[id]); ctx->scratch[id] = nullptr; }
+        size_t cap = bytes + bytes / 4 + 256;
+        YGZ_HIPCHK(ctx, hipMalloc(&ctx->scratch[id], cap));
+        ctx->scratch_bytes[id] = cap;
+    }
+    *out = ctx->scratch[id];
+    return YGZ_OK;
+}
+
+int ygz_ensure_levels(ygz_hip_ctx *ctx, int n_levels)
+{
+    if (n_levels > YGZ_MAX_LEVELS) return YGZ_E_INVALID;
+    for (int L = ctx->n_levels_alloc; L < n_levels; ++L) {
+        if (L > 0) { ctx->lw[L] = (ctx->lw[L - 1] + 1) / 2; ctx->lh[L] = (ctx->lh[L - 1] + 1) / 2; }
+        // +64 bytes of slack so 4-byte loads of the last pixels stay inside the allocation
+        YGZ_HIPCHK(ctx, hipMalloc(&ctx->lvl[L], (size_t)ctx->prm.max_frames * ctx->lw[L] * ctx->lh[L] + 64));
+        ctx->n_levels_alloc = L + 1;
+    }
+    return YGZ_OK;
+}
+
+extern "C" {
+
+int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, void *stream)
+{
+    if (!out || !prm) return YGZ_E_INVALID;
+    *out = nullptr;
+    if (prm->image_width < 32 || prm->image_height < 32 || prm->image_width > 8192 || prm->image_height > 8192 ||
+        prm->pyramid_levels < 1 || prm->pyramid_levels > YGZ_MAX_LEVELS || prm->cell_size < 1 ||
+        prm->max_frames < 1 || prm->fast_threshold < 0 || prm->fast_threshold > 254)
+        return YGZ_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return YGZ_E_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return YGZ_E_NO_DEVICE;
+    ygz_hip_ctx *ctx = new (std::nothrow) ygz_hip_ctx();
+    if (!ctx) return YGZ_E_INVALID;
+    ctx->prm = *prm;
+    ctx->device = device;
+    int rc = YGZ_OK;
+    do {
+        if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+        else {
+            hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { ctx->last_hip_error = (int)e; rc = YGZ_E_HIP; break; }
+            ctx->own_stream = true;
+        }
+        if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = YGZ_E_HIP; break; }
+        ctx->lw[0] = prm->image_width; ctx->lh[0] = prm->image_height;
+        // FeatureDetector ctor / LoadParams: grid = ceil(size / cell)  (FeatureDetector.cpp:301-302,336-337)
+        ctx->grid_rows = (int)ceil((double)prm->image_height / prm->cell_size);
+        ctx->grid_cols = (int)ceil((double)prm->image_width / prm->cell_size);
+        ctx->cells = ctx->grid_rows * ctx->grid_cols;
+        if ((rc = ygz_ensure_levels(ctx, prm->pyramid_levels)) != YGZ_OK) break;
+        const size_t F = (size_t)prm->max_frames, Cn = (size_t)ctx->cells;
+        hipError_t e = hipSuccess;
+#define A_(ptr, bytes) if (e == hipSuccess) e = hipMalloc((void **)&(ptr), (bytes))
+        A_(ctx->cell_first, F * Cn * 4); A_(ctx->cell_best, F * Cn * 8); A_(ctx->occupied, F * Cn);
+        A_(ctx->kp_px, F * Cn * 16); A_(ctx->kp_level, F * Cn * 4); A_(ctx->kp_score, F * Cn * 4);
+        A_(ctx->kp_angle, F * Cn * 4); A_(ctx->kp_desc, F * Cn * 32); A_(ctx->n_kp, F * 4);
+        A_(ctx->pair_q, F * 4); A_(ctx->pair_t, F * 4);
+        A_(ctx->m_tq, F * Cn * 4); A_(ctx->m_td, F * Cn * 4); A_(ctx->m_key, F * Cn * 8);
+        A_(ctx->m_idx, F * Cn * 4); A_(ctx->m_dist, F * Cn * 4); A_(ctx->m_dist2, F * Cn * 4);
+        if (prm->debug_maps)
+            for (int L = 0; L < prm->pyramid_levels; ++L) {
+                A_(ctx->dbg_score[L], F * ctx->lw[L] * ctx->lh[L]); A_(ctx->dbg_nms[L], F * ctx->lw[L] * ctx->lh[L]);
+            }
+#undef A_
+        if (e != hipSuccess) { ctx->last_hip_error = (int)e; rc = YGZ_E_HIP; break; }
+        if (hipMemsetAsync(ctx->n_kp, 0, F * 4, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(ctx->occupied, 0, F * Cn, ctx->stream) != hipSuccess) { rc = YGZ_E_HIP; break; }
+        ctx->pyr_valid.assign(F, 0);
+    } while (0);
+    if (rc != YGZ_OK) { ygz_hip_destroy(ctx); return rc; }
+    *out = ctx;
+    return YGZ_OK;
+}
+
+void ygz_hip_ba_free_all(ygz_hip_ctx *ctx);   // ba.hip
+
+void ygz_hip_destroy(ygz_hip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ygz_hip_ba_free_all(ctx);
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
+        if (ctx->lvl[L]) (void)hipFree(ctx->lvl[L]);
+        if (ctx->deriv[L]) (void)hipFree(ctx->deriv[L]);
+        if (ctx->dbg_score[L]) (void)hipFree(ctx->dbg_score[L]);
+        if (ctx->dbg_nms[L]) (void)hipFree(ctx->dbg_nms[L]);
+    }
+    void *ptrs[] = { ctx->bgr, ctx->cell_first, ctx->cell_best, ctx->occupied, ctx->kp_px, ctx->kp_level, ctx->kp_score,
+                     ctx->kp_angle, ctx->kp_desc, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->m_tq, ctx->m_td, ctx->m_key,
+                     ctx->m_idx, ctx->m_dist, ctx->m_dist2 };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < YGZ_N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int ygz_hip_synchronize(ygz_hip_ctx *ctx)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_timer_begin(ygz_hip_ctx *ctx)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
+{
+    if (!ctx || !elapsed_ms) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    YGZ_HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
+    YGZ_HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return YGZ_OK;
+}
+
+int ygz_hip_level_size(const ygz_hip_ctx *ctx, int level, int *w, int *h)
+{
+    if (!ctx || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
+    if (w) *w = ctx->lw[level];
+    if (h) *h = ctx->lh[level];
+    return YGZ_OK;
+}
+
+int ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int stride_bytes)
+{
+    if (!ctx || !bgr || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    const int w = ctx->lw[0], h = ctx->lh[0];
+    if (stride_bytes < w * 3) return YGZ_E_INVALID;
+    if (!ctx->bgr) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->bgr, (size_t)ctx->prm.max_frames * w * h * 3 + 64));
+    YGZ_HIPCHK(ctx, hipMemcpy2DAsync(ctx->bgr + (size_t)slot * w * h * 3, (size_t)w * 3, bgr, (size_t)stride_bytes,
+                                     (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pyr_valid[slot] = 0;
+    return YGZ_OK;
+}
+
+int ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int stride_bytes)
+{
+    if (!ctx || !gray || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    const int w = ctx->lw[0], h = ctx->lh[0];
+    if (stride_bytes < w) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipMemcpy2DAsync(ctx->lvl[0] + (size_t)slot * w * h, (size_t)w, gray, (size_t)stride_bytes,
+                                     (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pyr_valid[slot] = 0;
+    return YGZ_OK;
+}
+
+int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr)
+{
+    if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (from_bgr && !ctx->bgr) return YGZ_E_STATE;
+    int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->prm.pyramid_levels);
+    if (rc != YGZ_OK) return rc;
+    for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 1;
+    return YGZ_OK;
+}
+
+int ygz_hip_download_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst)
+{
+    if (!ctx || !dst || slot < 0 || slot >= ctx->prm.max_frames || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
+    const size_t n = (size_t)ctx->lw[level] * ctx->lh[level];
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(dst, ctx->lvl[level] + (size_t)slot * n, n, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// A2-A7 -- grid FAST-10 extractor with ORB orientation + rotated BRIEF.
+// Replaces FeatureDetector::Detect / ComputeAngleAndDescriptor (src/Algorithm/FeatureDetector.cpp:345-444,
+// 467-594) including the libfast calls at :366-381.  Bit-exact with oracle/{fast,orb}.c.
+//
+// Design (not a translation of the CPU loop):
+//  k_fast_select  one workgroup per 64x32 pixel tile of one level of one frame.  The tile (+halo 5)
+//                 is staged once in LDS with 4-byte coalesced loads; every later access is LDS.
+//                 1) 16-bit brighter/darker ring masks -> FAST-10 test (10 contiguous bits by
+//                    shift-AND), corners appended to an LDS work list (dense work for step 2);
+//                 2) per listed corner the score in closed form (max over arcs of the arc minimum,
+//                    equal to libfast's bisection result) into an LDS score tile;
+//                 3) 3x3 non-max suppression on the score tile, InFrame border test, Shi-Tomasi
+//                    from LDS, and the per-cell winner by 64-bit atomicMax on
+//                    (ordered(score) << 32 | ~visit_index): the reference's sequential
+//                    "strictly greater replaces, levels 0->2, raster order" rule is an argmax with
+//                    earliest-visit tie-break, so no ordered compaction of corners is needed.
+//                    A NaN Shi-Tomasi score (sqrt of a slightly negative discriminant) is kept
+//                    order-exact through a second key (atomicMin of visit_index<<1|isnan).
+//  k_compact      one workgroup per frame: block scan over the grid cells -> keypoint SoA in cell order
+//                 (the order Detect pushes features to frame->_features).
+//  k_describe     one wavefront per keypoint: 39x39 neighbourhood in LDS, integer moments by
+//                 wave reduction, cv::fastAtan2 polynomial, 256 tests = 4 ballots of 64 lanes.
+#include "ygz_internal.h"
+#include "../../include/ygz_orb_pattern.h"
+
+#define FT_W    64
+#define FT_H    32
+#define FT_LW   80                 // staged columns: x in [x0-8, x0+72)
+#define FT_LH   42                 // staged rows:    y in [y0-5, y0+37)
+#define FT_X0   8                  // tile column of x0
+#define FT_Y0   5                  // tile row of y0
+#define R1_W    (FT_W + 2)         // corner-test region = interior + 1
+#define R1_H    (FT_H + 2)
+#define R1_LW   68
+
+static __device__ const int c_circ_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+static __device__ const int c_circ_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+
+struct FastArgs {
+    const uint8_t *img;            // level base (slot 0)
+    int w, h, level;
+    int thr, tie;
+    int img_cols, img_rows;        // level-0 size (Frame::_color)
+    int cell, grid_cols, cells;
+    uint32_t *cell_first;
+    unsigned long long *cell_best;
+    const uint8_t *occupied;
+    uint8_t *dbg_score, *dbg_nms;  // may be null
+    int slot_begin;
+};
+
+__device__ __forceinline__ bool ring10(uint32_t m)
+{
+    m |= m << 16;
+    const uint32_t a = m & (m >> 1);
+    const uint32_t b = a & (a >> 2);
+    const uint32_t c = b & (b >> 4);
+    return (c & (a >> 8) & 0xFFFFu) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH][FT_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[R1_H][R1_LW];      // 0 = no corner, else score+1
+    __shared__ uint16_t list[R1_W * R1_H];
+    __shared__ int n_list;
+
+    const int slot = A.slot_begin + blockIdx.z;
+    const size_t npix = (size_t)A.w * A.h;
+    const uint8_t *img = A.img + (size_t)slot * npix;
+    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int tid = threadIdx.x;
+
+    if (tid == 0) n_list = 0;
+    for (int i = tid; i < R1_H * R1_LW / 4; i += 256) reinterpret_cast<uint32_t *>(&sc[0][0])[i] = 0u;
+    const bool aligned = (A.w & 3) == 0;
+    for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
+        const int r = i / (FT_LW / 4), c4 = (i % (FT_LW / 4)) * 4;
+        const int y = y0 - FT_Y0 + r, x = x0 - FT_X0 + c4;
+        uint32_t v = 0;
+        if (y >= 0 && y < A.h) {
+            const uint8_t *row = img + (size_t)y * A.w;
+            if (aligned && x >= 0 && x + 3 < A.w) v = *reinterpret_cast<const uint32_t *>(row + x);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (x + k >= 0 && x + k < A.w) v |= (uint32_t)row[x + k] << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&tile[r][c4]) = v;
+    }
+    __syncthreads();
+
+    // ---- 1) FAST-10 segment test on the interior + 1 ring
+    for (int i = tid; i < R1_W * R1_H; i += 256) {
+        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const int x = x0 - 1 + rx, y = y0 - 1 + ry;
+        if (x < 3 || y < 3 || x >= A.w - 3 || y >= A.h - 3) continue;
+        const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
+        const int p = *c, hi = p + A.thr, lo = p - A.thr;
+        // any 10-arc holds >= 2 of the 4 compass pixels: cheap reject first
+        const int v0 = c[3 * FT_LW], v4 = c[3], v8 = c[-3 * FT_LW], v12 = c[-3];
+        const int nb = (v0 > hi) + (v4 > hi) + (v8 > hi) + (v12 > hi);
+        const int nd = (v0 < lo) + (v4 < lo) + (v8 < lo) + (v12 < lo);
+        if (nb < 2 && nd < 2) continue;
+        uint32_t bright = 0, dark = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int v = c[c_circ_dy[k] * FT_LW + c_circ_dx[k]];
+            bright |= (uint32_t)(v > hi) << k;
+            dark |= (uint32_t)(v < lo) << k;
+        }
+        if (ring10(bright) || ring10(dark)) {
+            const int pos = atomicAdd(&n_list, 1);
+            list[pos] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int n = n_list;
+
+    // ---- 2) score in closed form: max over 10-arcs of min(v-p) (bright) / min(p-v) (dark), minus 1
+    for (int li = tid; li < n; li += 256) {
+        const int i = list[li];
+        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
+        const int p = *c;
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = (int)c[c_circ_dy[k] * FT_LW + c_circ_dx[k]] - p;
+        int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+        int best = -1000;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int mn10 = min(min(mn4[k], mn4[(k + 4) & 15]), mn2[(k + 8) & 15]);
+            const int mx10 = max(max(mx4[k], mx4[(k + 4) & 15]), mx2[(k + 8) & 15]);
+            best = max(best, max(mn10, -mx10));
+        }
+        sc[ry][rx] = (uint8_t)(best - 1 + 1);          // score = best-1 in [thr,254]; stored +1
+    }
+    __syncthreads();
+
+    // ---- 3) NMS + border + Shi-Tomasi + per-cell winner
+    const int scale = 1 << A.level;
+    for (int li = tid; li < n; li += 256) {
+        const int i = list[li];
+        const int ry = i / R1_W, rx = i - ry * R1_W;
+        if (rx < 1 || rx > FT_W || ry < 1 || ry > FT_H) continue;        // ring pixels belong to neighbours
+        const int x = x0 - 1 + rx, y = y0 - 1 + ry;
+        const int s = sc[ry][rx];
+        if (A.dbg_score) A.dbg_score[(size_t)slot * npix + (size_t)y * A.w + x] = (uint8_t)s;
+        bool keep = true;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (dx == 0 && dy == 0) continue;
+                const int o = sc[ry + dy][rx + dx];
+                keep = keep && !(A.tie ? (o >= s) : (o > s));
+            }
+        if (!keep) continue;
+        if (A.dbg_nms) A.dbg_nms[(size_t)slot * npix + (size_t)y * A.w + x] = 1;
+        // Frame::InFrame(px,20,L) with level coords divided by 2^L again (Basic/Frame.h:67-71)
+        if (!(x >= 20 * scale && x < (A.img_cols - 20) * scale && y >= 20 * scale && y < (A.img_rows - 20) * scale)) continue;
+        const int gy = (y * scale) / A.cell, gx = (x * scale) / A.cell;
+        const int k = gy * A.grid_cols + gx;
+        if (k < 0 || k >= A.cells) continue;
+        if (A.occupied[(size_t)slot * A.cells + k]) continue;
+        // FeatureDetector::ShiTomasiScore (:467-507) on the LDS tile
+        float score = 0.0f;
+        if (!(x - 4 < 1 || x + 4 >= A.w - 1 || y - 4 < 1 || y + 4 >= A.h - 1)) {
+            float dXX = 0.f, dYY = 0.f, dXY = 0.f;
+            const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
+            for (int yy = -4; yy < 4; ++yy)
+#pragma unroll
+                for (int xx = -4; xx < 4; ++xx) {
+                    const uint8_t *q = c + yy * FT_LW + xx;
+                    const float dx = (float)((int)q[1] - (int)q[-1]);
+                    const float dy = (float)((int)q[FT_LW] - (int)q[-FT_LW]);
+                    dXX = __fadd_rn(dXX, __fmul_rn(dx, dx));
+                    dYY = __fadd_rn(dYY, __fmul_rn(dy, dy));
+                    dXY = __fadd_rn(dXY, __fmul_rn(dx, dy));
+                }
+            dXX = __fmul_rn(dXX, 1.0f / 128.0f); dYY = __fmul_rn(dYY, 1.0f / 128.0f); dXY = __fmul_rn(dXY, 1.0f / 128.0f);
+            const float tr = __fadd_rn(dXX, dYY);
+            const float disc = __fsub_rn(__fmul_rn(tr, tr),
+                                         __fmul_rn(4.0f, __fsub_rn(__fmul_rn(dXX, dYY), __fmul_rn(dXY, dXY))));
+            score = __fmul_rn(0.5f, __fsub_rn(tr, __fsqrt_rn(disc)));
+        }
+        const uint32_t visit = ((uint32_t)A.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
+        const bool isnan_ = score != score;
+        atomicMin(&A.cell_first[(size_t)slot * A.cells + k], (visit << 1) | (isnan_ ? 1u : 0u));
+        if (!isnan_) {
+            const unsigned long long key = ((unsigned long long)ygz_f2ord(score) << 32) | (unsigned long long)(~visit);
+            atomicMax(&A.cell_best[(size_t)slot * A.cells + k], key);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ cell_first,
+                                                  const unsigned long long *__restrict__ cell_best, int cells,
+                                                  double *__restrict__ kp_px, int32_t *__restrict__ kp_level,
+                                                  float *__restrict__ kp_score, int32_t *__restrict__ n_kp, int slot_begin)
+{
+    __shared__ int wave_sum[16];
+    const int slot = slot_begin + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (cells + 1023) / 1024;
+    const int k0 = tid * per;
+    const uint32_t *cf = cell_first + (size_t)slot * cells;
+    int cnt = 0;
+    for (int j = 0; j < per; ++j) { const int k = k0 + j; if (k < cells && cf[k] != 0xFFFFFFFFu) ++cnt; }
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    if (lane == 63) wave_sum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wave_sum[w];
+    int pos = base + incl - cnt;
+    for (int j = 0; j < per; ++j) {
+        const int k = k0 + j;
+        if (k >= cells) break;
+        const uint32_t f = cf[k];
+        if (f == 0xFFFFFFFFu) continue;
+        uint32_t visit; float score;
+        if (f & 1u) { visit = f >> 1; score = __uint_as_float(0x7FC00000u); }
+        else {
+            const unsigned long long b = cell_best[(size_t)slot * cells + k];
+            visit = ~(uint32_t)(b & 0xFFFFFFFFull);
+            score = ygz_ord2f((uint32_t)(b >> 32));
+        }
+        const int L = (int)(visit >> 28), y = (int)((visit >> 14) & 0x3FFFu), x = (int)(visit & 0x3FFFu);
+        const size_t o = (size_t)slot * cells + pos;
+        kp_px[2 * o] = (double)(x << L); kp_px[2 * o + 1] = (double)(y << L);
+        kp_level[o] = L; kp_score[o] = score;
+        ++pos;
+    }
+    if (tid == 1023) n_kp[slot] = base + incl;
+}
+
+// ---------------------------------------------------------------------------------------------
+#define DP_R   19
+#define DP_W   39
+#define DP_N   (DP_W * DP_W)
+
+static __device__ const int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+static __device__ const signed char c_pattern[1024] = { YGZ_ORB_PATTERN_VALUES };
+
+struct DescArgs {
+    const uint8_t *lvl[YGZ_MAX_LEVELS];
+    int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
+    int n_levels, cells;
+    const double *kp_px; const int32_t *kp_level; const int32_t *n_kp;
+    float *kp_angle; uint32_t *kp_desc;
+    int slot_begin;
+};
+
+// cv::fastAtan2 [OpenCV 3.x polynomial]; no FMA contraction
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)2.2204460492503131e-16));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)2.2204460492503131e-16));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_describe(DescArgs A)
+{
+    __shared__ uint8_t patch_all[4][DP_N + 15];
+    const int slot = A.slot_begin + blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kp = blockIdx.x * 4 + wv;
+    if (kp >= A.n_kp[slot]) return;                 // wave-uniform
+    uint8_t *patch = patch_all[wv];
+    const size_t o = (size_t)slot * A.cells + kp;
+    const int L = A.kp_level[o];
+    const int w = A.w[L], h = A.h[L];
+    const uint8_t *img = A.lvl[L] + (size_t)slot * w * h;
+    const double sc = (double)(1 << L);
+    // cvRound(pixel / 2^L): round half to even (FeatureDetector.cpp:514,547)
+    const int cx = (int)rint(A.kp_px[2 * o] / sc), cy = (int)rint(A.kp_px[2 * o + 1] / sc);
+    const long long n = (long long)w * h;
+    for (int i = lane; i < DP_N; i += 64) {
+        const int dy = i / DP_W - DP_R, dx = i - (i / DP_W) * DP_W - DP_R;
+        const long long idx = (long long)(cy + dy) * w + (cx + dx);      // linear addressing as center[dy*step+dx]
+        patch[i] = (idx < 0 || idx >= n) ? (uint8_t)0 : img[idx];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // IC_Angle (:509-537): integer moments over the circular patch
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int v = i / 31 - 15, u = i - (i / 31) * 31 - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= c_umax[av]) {
+            const int I = patch[(v + DP_R) * DP_W + (u + DP_R)];
+            m10 += u * I; m01 += v * I;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    // ComputeOrbDescriptor (:539-578)
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float ang = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    unsigned long long bits[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const signed char *pt = &c_pattern[4 * (64 * j + lane)];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int t0 = patch[(dy0 + DP_R) * DP_W + dx0 + DP_R];
+        const int t1 = patch[(dy1 + DP_R) * DP_W + dx1 + DP_R];
+        bits[j] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        A.kp_angle[o] = angle;
+        uint4 *d = reinterpret_cast<uint4 *>(A.kp_desc + 8 * o);
+        d[0] = make_uint4((uint32_t)bits[0], (uint32_t)(bits[0] >> 32), (uint32_t)bits[1], (uint32_t)(bits[1] >> 32));
+        d[1] = make_uint4((uint32_t)bits[2], (uint32_t)(bits[2] >> 32), (uint32_t)bits[3], (uint32_t)(bits[3] >> 32));
+    }
+}
+
+int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
+{
+    const size_t Cn = (size_t)ctx->cells;
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->cell_first + (size_t)slot_begin * Cn, 0xFF, (size_t)n_slots * Cn * 4, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->cell_best + (size_t)slot_begin * Cn, 0, (size_t)n_slots * Cn * 8, ctx->stream));
+    for (int L = 0; L < ctx->prm.pyramid_levels; ++L) {
+        const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
+        if (ctx->prm.debug_maps) {
+            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->dbg_score[L] + (size_t)slot_begin * npix, 0, (size_t)n_slots * npix, ctx->stream));
+            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->dbg_nms[L] + (size_t)slot_begin * npix, 0, (size_t)n_slots * npix, ctx->stream));
+        }
+        FastArgs A;
+        A.img = ctx->lvl[L]; A.w = ctx->lw[L]; A.h = ctx->lh[L]; A.level = L;
+        A.thr = ctx->prm.fast_threshold; A.tie = ctx->prm.nms_tie_suppress;
+        A.img_cols = ctx->lw[0]; A.img_rows = ctx->lh[0];
+        A.cell = ctx->prm.cell_size; A.grid_cols = ctx->grid_cols; A.cells = ctx->cells;
+        A.cell_first = ctx->cell_first; A.cell_best = ctx->cell_best; A.occupied = ctx->occupied;
+        A.dbg_score = ctx->prm.debug_maps ? ctx->dbg_score[L] : nullptr;
+        A.dbg_nms = ctx->prm.debug_maps ? ctx->dbg_nms[L] : nullptr;
+        A.slot_begin = slot_begin;
+        hipLaunchKernelGGL(k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), n_slots), dim3(256), 0,
+                           ctx->stream, A);
+    }
+    hipLaunchKernelGGL(k_compact, dim3(n_slots), dim3(1024), 0, ctx->stream, ctx->cell_first, ctx->cell_best, ctx->cells,
+                       ctx->kp_px, ctx->kp_level, ctx->kp_score, ctx->n_kp, slot_begin);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return ygz_launch_describe(ctx, slot_begin, n_slots);
+}
+
+int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
+{
+    DescArgs D;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { D.lvl[L] = ctx->lvl[L]; D.w[L] = ctx->lw[L]; D.h[L] = ctx->lh[L]; }
+    D.n_levels = ctx->prm.pyramid_levels; D.cells = ctx->cells;
+    D.kp_px = ctx->kp_px; D.kp_level = ctx->kp_level; D.n_kp = ctx->n_kp;
+    D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin;
+    hipLaunchKernelGGL(k_describe, dim3(ygz_div_up(ctx->cells, 4), n_slots), dim3(256), 0, ctx->stream, D);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+extern "C" {
+
+int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *occupied)
+{
+    if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
+    for (int s = slot_begin; s < slot_begin + n_slots; ++s) if (!ctx->pyr_valid[s]) return YGZ_E_STATE;
+    const size_t Cn = (size_t)ctx->cells;
+    if (occupied) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->occupied + (size_t)slot_begin * Cn, occupied, (size_t)n_slots * Cn,
+                                                  hipMemcpyHostToDevice, ctx->stream));
+    else YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->occupied + (size_t)slot_begin * Cn, 0, (size_t)n_slots * Cn, ctx->stream));
+    return ygz_launch_detect(ctx, slot_begin, n_slots);
+}
+
+int ygz_hip_keypoint_count(ygz_hip_ctx *ctx, int slot, int *n)
+{
+    if (!ctx || !n || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(n, ctx->n_kp + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capacity, int *n_out)
+{
+    if (!ctx || !out || !n_out || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    int n = 0;
+    int rc = ygz_hip_keypoint_count(ctx, slot, &n);
+    if (rc != YGZ_OK) return rc;
+    *n_out = n;
+    if (n > capacity) return YGZ_E_CAPACITY;
+    const size_t o = (size_t)slot * ctx->cells;
+    if (n > 0) {
+        if (out->px) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->px, ctx->kp_px + 2 * o, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->level) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->level, ctx->kp_level + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->score) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->score, ctx->kp_score + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->angle) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->angle, ctx->kp_angle + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (out->desc) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->desc, ctx->kp_desc + 8 * o, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return YGZ_OK;
+}
+
+int ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, int n)
+{
+    if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || n < 0 || (n > 0 && (!px || !level))) return YGZ_E_INVALID;
+    if (n > ctx->cells) return YGZ_E_CAPACITY;
+    if (!ctx->pyr_valid[slot]) return YGZ_E_STATE;
+    for (int i = 0; i < n; ++i) if (level[i] < 0 || level[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
+    const size_t o = (size_t)slot * ctx->cells;
+    if (n > 0) {
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_px + 2 * o, px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_level + o, level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->n_kp + slot, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // &n is a stack variable
+    return ygz_launch_describe(ctx, slot, 1);
+}
+
+int ygz_hip_get_fast_maps(ygz_hip_ctx *ctx, int slot, int level, uint8_t *score, uint8_t *nms)
+{
+    if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || level < 0 || level >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
+    if (!ctx->prm.debug_maps) return YGZ_E_STATE;
+    const size_t npix = (size_t)ctx->lw[level] * ctx->lh[level];
+    if (score) YGZ_HIPCHK(ctx, hipMemcpyAsync(score, ctx->dbg_score[level] + slot * npix, npix, hipMemcpyDeviceToHost, ctx->stream));
+    if (nms) YGZ_HIPCHK(ctx, hipMemcpyAsync(nms, ctx->dbg_nms[level] + slot * npix, npix, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+}  // extern "C"

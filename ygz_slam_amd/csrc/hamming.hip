@@ -1,0 +1,199 @@
+// M1-M3 -- 256-bit Hamming brute-force matcher.
+// Replaces Matcher::DescriptorDistance (src/Algorithm/Matcher.cpp:30-43) and
+// cv::BFMatcher(NORM_HAMMING, crossCheck).match() (test/test_orb_match.cpp:86-93).
+// Bit-exact with oracle/hamming.c (integer arithmetic; first minimum wins ties).
+//
+// k_hamming_nn: lane = one row of set A with its 256-bit descriptor in 8 VGPRs; set B streams
+// through LDS in 256-row tiles (two 16-byte coalesced loads per lane to stage, then every lane
+// reads the SAME tile row -> LDS broadcast, conflict-free); per pair 8 x (v_xor + v_bcnt with
+// accumulate) and a 3-5 op running (min, 2nd min, argmin).  The kernel is VALU-bound by two
+// orders of magnitude (72 KB per 1000x1000 pair vs 1.6e7 lane-ops), so the layout
+// goal is only that the 64 KB of descriptors are read from HBM exactly once per workgroup column.
+// Cross-check (OpenCV batchDistance semantics) = the same kernel run train->query with a fused
+// epilogue: atomicMin(key[nearest query], dist<<32 | train row) -- min distance, then lowest
+// train index, exactly the order-dependent "strictly smaller replaces" rule of OpenCV.
+#include "ygz_internal.h"
+#include <string.h>
+
+#define HM_TILE 256
+
+struct HamArgs {
+    const uint32_t *desc;        // descriptor store: set s at desc + s*set_stride (u32 units)
+    size_t set_stride;
+    const int32_t *set_count;    // [sets] rows per set (device)
+    const int32_t *pair_a, *pair_b;   // [pairs] set ids: every row of a searches b
+    size_t out_stride;           // rows reserved per pair in the outputs
+    int32_t *out_idx, *out_dist, *out_dist2;     // [pairs][out_stride]; dist2 may be null
+    unsigned long long *scatter_key;             // cross-check target [pairs][out_stride] or null
+};
+
+template <bool SECOND>
+__global__ __launch_bounds__(256) void k_hamming_nn(HamArgs A)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tb[HM_TILE][8];
+    const int p = blockIdx.y;
+    const int sa = A.pair_a[p], sb = A.pair_b[p];
+    const int nA = A.set_count[sa], nB = A.set_count[sb];
+    if ((int)(blockIdx.x * 256) >= nA) return;                      // block-uniform
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t *da = A.desc + (size_t)sa * A.set_stride;
+    const uint32_t *db = A.desc + (size_t)sb * A.set_stride;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (row < nA) {
+        a0 = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[0];
+        a1 = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[1];
+    }
+    int best = 0x7FFFFFFF, second = 0x7FFFFFFF, bi = -1;
+    for (int j0 = 0; j0 < nB; j0 += HM_TILE) {
+        __syncthreads();
+        const int jr = j0 + threadIdx.x;
+        if (jr < nB) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(db + 8 * (size_t)jr);
+            reinterpret_cast<uint4 *>(tb[threadIdx.x])[0] = src[0];
+            reinterpret_cast<uint4 *>(tb[threadIdx.x])[1] = src[1];
+        }
+        __syncthreads();
+        const int cnt = min(HM_TILE, nB - j0);
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            const uint4 b0 = reinterpret_cast<const uint4 *>(tb[jj])[0];
+            const uint4 b1 = reinterpret_cast<const uint4 *>(tb[jj])[1];
+            int d = __popc(a0.x ^ b0.x);
+            d += __popc(a0.y ^ b0.y); d += __popc(a0.z ^ b0.z); d += __popc(a0.w ^ b0.w);
+            d += __popc(a1.x ^ b1.x); d += __popc(a1.y ^ b1.y); d += __popc(a1.z ^ b1.z); d += __popc(a1.w ^ b1.w);
+            const bool lt = d < best;
+            if (SECOND) second = lt ? best : min(second, d);
+            bi = lt ? (j0 + jj) : bi;
+            best = lt ? d : best;
+        }
+    }
+    if (row >= nA) return;
+    const size_t o = (size_t)p * A.out_stride + row;
+    A.out_idx[o] = bi; A.out_dist[o] = best;
+    if (SECOND && A.out_dist2) A.out_dist2[o] = second;
+    if (A.scatter_key && bi >= 0)
+        atomicMin(&A.scatter_key[(size_t)p * A.out_stride + bi], ((unsigned long long)(uint32_t)best << 32) | (uint32_t)row);
+}
+
+// cross_check 1: decode the scatter keys; cross_check 2: mutual test qi -> tq
+__global__ __launch_bounds__(256) void k_match_finalize(const int32_t *__restrict__ set_count, const int32_t *__restrict__ pair_q,
+                                                        size_t out_stride, int mode, const unsigned long long *__restrict__ key,
+                                                        const int32_t *__restrict__ tq, int32_t *__restrict__ idx,
+                                                        int32_t *__restrict__ dist)
+{
+    const int p = blockIdx.y;
+    const int nq = set_count[pair_q[p]];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    const size_t o = (size_t)p * out_stride + i;
+    if (mode == 1) {
+        const unsigned long long k = key[o];
+        if (k == ~0ull) { idx[o] = -1; dist[o] = 0x7FFFFFFF; }
+        else { idx[o] = (int32_t)(uint32_t)(k & 0xFFFFFFFFull); dist[o] = (int32_t)(k >> 32); }
+    } else {
+        const int j = idx[o];
+        if (j < 0 || tq[(size_t)p * out_stride + j] != i) { idx[o] = -1; dist[o] = 0x7FFFFFFF; }
+    }
+}
+
+static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, const int32_t *set_count,
+                     const int32_t *pair_q, const int32_t *pair_t, int n_pairs, int max_rows, int cross_check, bool want_second)
+{
+    const size_t Cn = (size_t)ctx->cells;
+    HamArgs A;
+    A.desc = desc; A.set_stride = set_stride; A.set_count = set_count; A.out_stride = Cn;
+    const dim3 grid(ygz_div_up(max_rows, 256), n_pairs), block(256);
+    if (cross_check == 0 || cross_check == 2) {       // query -> train
+        A.pair_a = pair_q; A.pair_b = pair_t;
+        A.out_idx = ctx->m_idx; A.out_dist = ctx->m_dist; A.out_dist2 = want_second ? ctx->m_dist2 : nullptr;
+        A.scatter_key = nullptr;
+        if (want_second) hipLaunchKernelGGL(k_hamming_nn<true>, grid, block, 0, ctx->stream, A);
+        else hipLaunchKernelGGL(k_hamming_nn<false>, grid, block, 0, ctx->stream, A);
+    }
+    if (cross_check == 1 || cross_check == 2) {       // train -> query
+        if (cross_check == 1)
+            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->m_key, 0xFF, (size_t)n_pairs * Cn * 8, ctx->stream));
+        A.pair_a = pair_t; A.pair_b = pair_q;
+        A.out_idx = ctx->m_tq; A.out_dist = ctx->m_td; A.out_dist2 = nullptr;
+        A.scatter_key = (cross_check == 1) ? ctx->m_key : nullptr;
+        hipLaunchKernelGGL(k_hamming_nn<false>, grid, block, 0, ctx->stream, A);
+        hipLaunchKernelGGL(k_match_finalize, grid, block, 0, ctx->stream, set_count, pair_q, Cn, cross_check,
+                           ctx->m_key, ctx->m_tq, ctx->m_idx, ctx->m_dist);
+    }
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+extern "C" {
+
+int ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32_t *train_slot, int n_pairs, int cross_check)
+{
+    if (!ctx || !query_slot || !train_slot || n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
+    if (n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;
+    for (int i = 0; i < n_pairs; ++i)
+        if (query_slot[i] < 0 || query_slot[i] >= ctx->prm.max_frames || train_slot[i] < 0 || train_slot[i] >= ctx->prm.max_frames)
+            return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, query_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, train_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // host arrays may be temporaries
+    ctx->n_pairs = n_pairs;
+    return run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, n_pairs, ctx->cells,
+                     cross_check, false);
+}
+
+// resident variant for pipelines: pair tables already uploaded by a previous ygz_hip_match_slots call
+int ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check)
+{
+    if (!ctx || ctx->n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
+    return run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->n_pairs, ctx->cells,
+                     cross_check, false);
+}
+
+int ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx, int32_t *dist, int capacity, int *nq_out)
+{
+    if (!ctx || pair < 0 || pair >= ctx->n_pairs || !nq_out) return YGZ_E_INVALID;
+    int32_t qslot = 0, nq = 0;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(&qslot, ctx->pair_q + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(&nq, ctx->n_kp + qslot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *nq_out = nq;
+    if (nq > capacity) return YGZ_E_CAPACITY;
+    const size_t o = (size_t)pair * ctx->cells;
+    if (nq > 0) {
+        if (train_idx) YGZ_HIPCHK(ctx, hipMemcpyAsync(train_idx, ctx->m_idx + o, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (dist) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist, ctx->m_dist + o, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return YGZ_OK;
+}
+
+int ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int cross_check,
+                          int32_t *train_idx, int32_t *dist, int32_t *dist2)
+{
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
+    if (dist2 && cross_check != 0) return YGZ_E_INVALID;
+    if (nq > ctx->cells || nt > ctx->cells) return YGZ_E_CAPACITY;        // result rows live in the per-pair buffers
+    if (nq == 0) return YGZ_OK;
+    const size_t stride_u32 = (size_t)(nq > nt ? nq : nt) * 8 + 8;
+    uint8_t *buf = nullptr;
+    int rc = ygz_scratch(ctx, SCR_MATCH_Q, 64 + stride_u32 * 4 * 2, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    int32_t hdr[4] = { nq, nt, 0, 1 };          // counts[2], pair_q, pair_t
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf, hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *d = reinterpret_cast<uint32_t *>(buf + 64);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (nt > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(d + stride_u32, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int32_t *cnt = reinterpret_cast<const int32_t *>(buf);
+    rc = run_match(ctx, d, stride_u32, cnt, cnt + 2, cnt + 3, 1, nq > nt ? nq : nt, cross_check, dist2 != nullptr);
+    if (rc != YGZ_OK) return rc;
+    if (train_idx) YGZ_HIPCHK(ctx, hipMemcpyAsync(train_idx, ctx->m_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist, ctx->m_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist2) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist2, ctx->m_dist2, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_pairs = 0;      // per-pair buffers were reused
+    return YGZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// A1 -- BGR->gray and the 5x5 binomial pyramid (replaces Frame::InitFrame / CreateImagePyramid,
+// src/Basic/Frame.cpp:22-40, i.e. cv::cvtColor(CV_BGR2GRAY) + cv::pyrDown).  Integer arithmetic,
+// bit-exact with oracle/image.c.  HBM-bound: every source byte is read once, every result
+// byte written once; 16-byte accesses per lane.
+#include "ygz_internal.h"
+
+// gray = (1868 B + 9617 G + 4899 R + 8192) >> 14   [OpenCV 3.1 RGB2Gray<uchar>]
+__device__ __forceinline__ uint32_t gray1(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (1868u * b + 9617u * g + 4899u * r + 8192u) >> 14;
+}
+
+// 16 pixels per lane: 3 x 16-byte loads, 1 x 16-byte store.  npix % 16 == 0.
+__global__ __launch_bounds__(256) void k_bgr2gray16(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
+                                                    unsigned npix, int slot_begin)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;          // group of 16 pixels
+    if (i * 16u >= npix) return;
+    const size_t slot = (size_t)(slot_begin + blockIdx.y);
+    const uint4 *src = reinterpret_cast<const uint4 *>(bgr + slot * npix * 3u) + (size_t)i * 3u;
+    const uint4 a = src[0], b = src[1], c = src[2];
+    const uint32_t w[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+    uint32_t out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {        // 4 pixels = 12 bytes = 3 words
+        const uint32_t w0 = w[3 * q], w1 = w[3 * q + 1], w2 = w[3 * q + 2];
+        const uint32_t g0 = gray1(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+        const uint32_t g1 = gray1(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+        const uint32_t g2 = gray1((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+        const uint32_t g3 = gray1((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+        out[q] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+    }
+    reinterpret_cast<uint4 *>(gray + slot * npix)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+__global__ __launch_bounds__(256) void k_bgr2gray1(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
+                                                   unsigned npix, int slot_begin)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= npix) return;
+    const size_t slot = (size_t)(slot_begin + blockIdx.y);
+    const uint8_t *s = bgr + (slot * npix + i) * 3u;
+    gray[slot * npix + i] = (uint8_t)gray1(s[0], s[1], s[2]);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+// cv::pyrDown 8u: separable [1 4 6 4 1], dst = (sum + 128) >> 8, BORDER_REFLECT_101.
+// One block = 64x16 output pixels; the (2*64+3+pad) x (2*16+3) source window is staged in LDS
+// with 4-byte loads (rows start 4-byte aligned when sw % 4 == 0), borders reflected on the fly.
+#define PD_TW 64
+#define PD_TH 16
+#define PD_SW 136          // staged row: source x in [2*ox0 - 4, 2*ox0 + 132)
+#define PD_SH 35           // source y in [2*oy0 - 2, 2*oy0 + 33)
+__global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
+                                                  int sw, int sh, int dw, int dh, int slot_begin)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH][PD_SW];
+    const size_t slot = (size_t)(slot_begin + blockIdx.z);
+    const uint8_t *s = src + slot * (size_t)sw * sh;
+    uint8_t *d = dst + slot * (size_t)dw * dh;
+    const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
+    const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
+    const bool aligned = (sw & 3) == 0;
+    for (int i = threadIdx.x; i < PD_SH * (PD_SW / 4); i += 256) {
+        const int r = i / (PD_SW / 4), c4 = (i % (PD_SW / 4)) * 4;
+        const int sy = reflect101(sy0 + r, sh), sx = sx0 + c4;
+        uint32_t v;
+        if (aligned && sx >= 0 && sx + 3 < sw) {
+            v = *reinterpret_cast<const uint32_t *>(s + (size_t)sy * sw + sx);
+        } else {
+            const uint8_t *row = s + (size_t)sy * sw;
+            v = (uint32_t)row[reflect101(sx, sw)] | ((uint32_t)row[reflect101(sx + 1, sw)] << 8) |
+                ((uint32_t)row[reflect101(sx + 2, sw)] << 16) | ((uint32_t)row[reflect101(sx + 3, sw)] << 24);
+        }
+        *reinterpret_cast<uint32_t *>(&tile[r][c4]) = v;
+    }
+    __syncthreads();
+    // lane = output column, each thread 4 output rows (shares source rows between them)
+    const int tx = threadIdx.x & 63, ty0 = (threadIdx.x >> 6) * 4;
+    const int ox = ox0 + tx;
+    int hrow[11];                                   // horizontal sums of source rows 2*ty0-2 .. 2*ty0+8
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+        const uint8_t *t = &tile[2 * ty0 + r][2 * tx + 2];      // source x = 2*ox - 2
+        hrow[r] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
+    }
+    if (ox < dw) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oy = oy0 + ty0 + k;
+            if (oy < dh) {
+                const int v = hrow[2 * k] + 4 * hrow[2 * k + 1] + 6 * hrow[2 * k + 2] + 4 * hrow[2 * k + 3] + hrow[2 * k + 4];
+                d[(size_t)oy * dw + ox] = (uint8_t)((v + 128) >> 8);
+            }
+        }
+    }
+}
+
+int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr, int up_to_level)
+{
+    int rc = ygz_ensure_levels(ctx, up_to_level);
+    if (rc != YGZ_OK) return rc;
+    const unsigned npix = (unsigned)ctx->lw[0] * (unsigned)ctx->lh[0];
+    if (from_bgr) {
+        if ((npix & 15u) == 0)
+            hipLaunchKernelGGL(k_bgr2gray16, dim3(ygz_div_up((int)(npix / 16), 256), n_slots), dim3(256), 0, ctx->stream,
+                               ctx->bgr, ctx->lvl[0], npix, slot_begin);
+        else
+            hipLaunchKernelGGL(k_bgr2gray1, dim3(ygz_div_up((int)npix, 256), n_slots), dim3(256), 0, ctx->stream,
+                               ctx->bgr, ctx->lvl[0], npix, slot_begin);
+    }
+    for (int L = 1; L < up_to_level; ++L) {
+        const int sw = ctx->lw[L - 1], sh = ctx->lh[L - 1], dw = ctx->lw[L], dh = ctx->lh[L];
+        hipLaunchKernelGGL(k_pyr_down, dim3(ygz_div_up(dw, PD_TW), ygz_div_up(dh, PD_TH), n_slots), dim3(256), 0,
+                           ctx->stream, ctx->lvl[L - 1], ctx->lvl[L], sw, sh, dw, dh, slot_begin);
+    }
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}

@@ -1,0 +1,93 @@
+// Internal declarations shared by the HIP translation units of libygz_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "../../include/ygz_hip.h"
+
+#define YGZ_KLT_LEVELS 5          // Tracker.cpp:97 maxLevel 4 -> 5 levels
+#define YGZ_N_SCRATCH  24
+
+struct ygz_hip_ctx {
+    ygz_hip_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int last_hip_error = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // geometry
+    int n_levels_alloc = 0;                 // image levels with storage (>= pyramid_levels)
+    int lw[YGZ_MAX_LEVELS] = {0}, lh[YGZ_MAX_LEVELS] = {0};
+    int grid_cols = 0, grid_rows = 0, cells = 0;
+
+    // frame store (HBM): level L of slot s at lvl[L] + s*lw[L]*lh[L]
+    uint8_t *lvl[YGZ_MAX_LEVELS] = {nullptr};
+    uint8_t *bgr = nullptr;                 // [max_frames][h][w][3], allocated on first BGR upload
+    std::vector<uint8_t> pyr_valid;         // per slot: pyramid built
+    // Scharr derivative levels for KLT (int16 x2 per pixel), allocated on first KLT call
+    int16_t *deriv[YGZ_MAX_LEVELS] = {nullptr};
+
+    // extractor state per slot
+    uint32_t *cell_first = nullptr;         // [F][cells]  min over candidates of (visit<<1 | isnan)
+    unsigned long long *cell_best = nullptr;// [F][cells]  max over non-NaN of (ordered(score)<<32 | ~visit)
+    uint8_t  *occupied = nullptr;           // [F][cells]
+    double   *kp_px = nullptr;              // [F][cells][2]
+    int32_t  *kp_level = nullptr;           // [F][cells]
+    float    *kp_score = nullptr, *kp_angle = nullptr;
+    uint32_t *kp_desc = nullptr;            // [F][cells][8]
+    int32_t  *n_kp = nullptr;               // [F]
+    uint8_t  *dbg_score[YGZ_MAX_LEVELS] = {nullptr}, *dbg_nms[YGZ_MAX_LEVELS] = {nullptr};
+
+    // matcher state per pair (capacity max_frames pairs)
+    int32_t *pair_q = nullptr, *pair_t = nullptr;   // [F] slot ids
+    int32_t *m_tq = nullptr, *m_td = nullptr;       // [F][cells] nearest query of each train row
+    unsigned long long *m_key = nullptr;            // [F][cells] (dist<<32 | train) per query
+    int32_t *m_idx = nullptr, *m_dist = nullptr, *m_dist2 = nullptr;   // [F][cells] final per query
+    int n_pairs = 0;
+
+    // growable scratch buffers
+    void  *scratch[YGZ_N_SCRATCH] = {nullptr};
+    size_t scratch_bytes[YGZ_N_SCRATCH] = {0};
+
+    // resident BA windows
+    struct BaWindow;
+    std::vector<BaWindow*> ba;
+};
+
+#define YGZ_HIPCHK(ctx, call)                                            \
+    do { hipError_t e_ = (call);                                         \
+         if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return YGZ_E_HIP; } } while (0)
+
+static inline int ygz_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// scratch ids
+enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR_SA_OUT, SCR_SA_WORK,
+       SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_GEN_0 = 16 };
+
+int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
+int ygz_ensure_levels(ygz_hip_ctx *ctx, int n_levels);      // allocates image levels up to n_levels
+
+// launchers implemented in the kernel translation units
+int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr, int up_to_level);
+int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
+int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+#ifdef __HIPCC__
+__device__ __forceinline__ int ygz_lane() { return (int)(threadIdx.x & 63); }
+
+// order-preserving map float -> uint32 (for atomicMax on non-NaN floats)
+__device__ __forceinline__ uint32_t ygz_f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ygz_ord2f(uint32_t o)
+{
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+#endif
