@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
             const float tr = __fadd_rn(dXX, dYY);
             const float disc = __fsub_rn(__fmul_rn(tr, tr),
                                          __fmul_rn(4.0f, __fsub_rn(__fmul_rn(dXX, dYY), __fmul_rn(dXY, dXY))));
-            score = __fmul_rn(0.5f, __fsub_rn(tr, __fsqrt_rn(disc)));
+            score = __fmul_rn(0.5f, __fsub_rn(tr, ygz_sqrtf_cr(disc)));
         }
         const uint32_t visit = ((uint32_t)A.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
         const bool isnan_ = score != score;

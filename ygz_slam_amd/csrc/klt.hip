@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
         float Dd = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
         const float dif = __fsub_rn(A11, A22);
         const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11),
-                                                 __fsqrt_rn(__fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
+                                                 ygz_sqrtf_cr(__fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
                                        (float)(2 * win * win));
         if (minEig < A.min_eig_thr || Dd < 1.192092896e-07f) {
             if (level == 0) status = false;

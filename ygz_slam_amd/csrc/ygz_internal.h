@@ -85,6 +85,9 @@ __device__ __forceinline__ uint32_t ygz_f2ord(float f)
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// correctly rounded float sqrt: the native v_sqrt_f32 path is 1 ulp; sqrt in double then one rounding is
+// exact for float inputs (53 >= 2*24+2 bits)
+__device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((double)x); }
 __device__ __forceinline__ float ygz_ord2f(uint32_t o)
 {
     uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
