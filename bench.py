@@ -57,26 +57,28 @@ class Pipeline:
         c.detect(0, self.B)
         self.kps = [c.get_keypoints(s) for s in range(self.B)]
         self.kp_depth = [np.array([self.depths[s][int(p[1]), int(p[0])] for p in k["px"]]) for s, k in enumerate(self.kps)]
-        self.q = list(range(self.B))
-        self.t = [(i - 1) % self.B for i in range(self.B)]
+        for s in range(self.B):                               # Feature::_depth / _mappoint of the (deterministic) keypoints
+            c.set_keypoint_depths(s, self.kp_depth[s], np.ones(len(self.kp_depth[s]), np.uint8))
+        self.q = list(range(self.B))                          # current frame of pair i
+        self.t = [(i - 1) % self.B for i in range(self.B)]    # its predecessor
         c.match_slots(self.q, self.t, 1)
+        c.track_begin(self.q, self.t, self.poses[self.q], self.poses[self.t], predict=True)
         f = self.ba
         self.ba_dims = [c.ba_upload(w, f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
                         for w in range(self.B)]
         c.synchronize()
 
     def step(self):
+        """the whole hot path over the resident batch: 8 ABI calls, no host<->device copies, no syncs"""
         c = self.ctx
-        c.build_pyramid(0, self.B, from_bgr=True)
-        c.detect(0, self.B)
-        c.match_slots_again(1)
-        for i in range(self.B):
-            p = self.t[i]
-            pts = self.kps[p]["px"].astype(np.float32)
-            c.klt_track(p, i, pts, pts)
-            c.find_direct_projection(p, self.poses[p], i, self.poses[i], self.kps[p]["px"], self.kp_depth[p], self.kps[p]["level"], self.kps[p]["px"])
-            c.sparse_align(p, self.poses[p], i, self.poses[p], self.kps[p]["px"], self.kp_depth[p], np.ones(len(self.kp_depth[p]), np.uint8))
-        c.ba_linearize_resident(0, self.B)
+        c.build_pyramid(0, self.B, from_bgr=True)             # A1  InitFrame
+        c.detect(0, self.B)                                   # A2-A7 FeatureDetector::Detect
+        c.match_slots_again(1)                                # M1-M3 BFMatcher(crossCheck) vs predecessor
+        c.track_reload(True)                                  # track sets from the fresh keypoints
+        c.track_klt()                                         # L4  Tracker::TrackKLT
+        c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D
+        c.track_sparse_align()                                # L3  SparseImgAlign::run
+        c.ba_linearize_resident(0, self.B)                    # B1-B5 one Jacobian/JtJ build per frame
 
     def stage_times(self, reps=3):
         """per-stage HIP-event times (ms per batch), outside the timed region"""
@@ -92,6 +94,10 @@ class Pipeline:
         t("gray_pyramid", lambda: c.build_pyramid(0, self.B, from_bgr=True))
         t("detect_describe", lambda: c.detect(0, self.B))
         t("hamming_crosscheck", lambda: c.match_slots_again(1))
+        t("track_load", lambda: c.track_reload(True))
+        t("klt", c.track_klt)
+        t("direct_projection", c.track_direct)
+        t("sparse_align", c.track_sparse_align)
         t("ba_linearize", lambda: c.ba_linearize_resident(0, self.B))
         return out
 
@@ -132,8 +138,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames resident per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frames resident per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe", default="k_sparse_align", help="kernel timed with HIP events for the roofline leg")
     a = ap.parse_args()
 
     import torch
@@ -166,12 +173,15 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
+    probe_kernel = a.probe
+    pipe.ctx.probe_begin(probe_kernel, 8 * (a.steps + 1) * 8)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
     barrier()
     dt = time.perf_counter() - t0
+    probe_ms, probe_n = pipe.ctx.probe_end()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -180,12 +190,17 @@ def main():
     if rank == 0:
         frames = a.batch * a.steps * world
         stages = pipe.stage_times()
-        # dominant-kernel roofline: filled from the per-stage HIP-event time of the extractor stage
         n_kp = float(np.mean([len(k["level"]) for k in pipe.kps]))
-        alg_bytes = a.batch * (403200 + 8 * 3000 + 100 * 3000)          # FAST scan + NMS corners + Shi-Tomasi windows
-        det_s = stages["detect_describe"] * 1e-3
-        roofline = {"bound": "hbm", "achieved": alg_bytes / det_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": alg_bytes / det_s / 1e9 / 8000.0, "traffic": None, "kernel": "detect stage (k_fast_select+k_compact+k_describe)"}
+        # dominant kernel (see profiles/): algorithmic bytes per launch (DESIGN.md "Measurement") / HIP-event duration
+        alg = {"k_klt": a.batch * n_kp * 5 * 2 * 23 * 23,                  # 23x23 B window, 2 images, 5 levels per point
+               "k_sparse_align": a.batch * n_kp * 3 * 80.0,               # ~80 B per feature-level
+               "k_fast_select": a.batch * (403200 + 8 * 3000 + 100 * 3000),
+               "k_find_direct_projection": a.batch * n_kp * 220.0,
+               "k_hamming_nn": a.batch * 72000.0 * 0.5}.get(probe_kernel, 0.0)
+        avg_s = (probe_ms / max(probe_n, 1)) * 1e-3
+        ach = alg / avg_s / 1e9 if avg_s > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                    "kernel": probe_kernel, "launches": probe_n, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg}
         res = {"metric": "frames/sec (extract+match+LK+local-BA), 640x480, 1000 ORB kpts", "value": frames / dt, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",

@@ -70,6 +70,9 @@ int  ygz_hip_max_keypoints(const ygz_hip_ctx *ctx);     /* = number of grid cell
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
 int  ygz_hip_timer_begin(ygz_hip_ctx *ctx);
 int  ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms);   /* synchronises */
+/* HIP events around EVERY launch of one named kernel (e.g. "k_klt") until probe_end: total time and launch count */
+int  ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launches);
+int  ygz_hip_probe_end(ygz_hip_ctx *ctx, double *total_ms, int *launches);   /* synchronises */
 
 /* ---- A1: frame store + pyramid -- replaces Frame::InitFrame / CreateImagePyramid
  *      (src/Basic/Frame.cpp:22-40: cv::cvtColor BGR2GRAY + cv::pyrDown per level) -------------- */
@@ -151,6 +154,26 @@ void ygz_hip_default_klt_params(ygz_klt_params *p);
 /* level-0 images of prev_slot/cur_slot; prev_pts [n][2], next_pts [n][2] in/out, status [n], err [n] */
 int  ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts,
                        int n, const ygz_klt_params *prm, uint8_t *status, float *err);
+
+/* ---- resident batched tracking: the same L1-L4 kernels over MANY frame pairs per launch, inputs taken from
+ *      the keypoints the extractor left in HBM, no host round trip between stages.  This is the per-frame path
+ *      of VisualOdometry::AddFrame (src/Module/VisualOdometry.cpp:38-107: Tracker::Track -> TrackRefFrame ->
+ *      TrackLocalMap) restructured for throughput; pair i = (cur_slot[i], ref_slot[i]). ------------------------ */
+/* Feature::_depth / Feature::_mappoint of the keypoints of `slot` (keypoint order of ygz_hip_get_keypoints) */
+int  ygz_hip_set_keypoint_depths(ygz_hip_ctx *ctx, int slot, const double *depth, const uint8_t *has_mappoint, int n);
+/* uploads the pair table + poses (T_* [n_pairs][7]) and loads the reference keypoints of every pair into its
+ * track set on the device.  predict != 0: the direct-projection start pixel is the projection of the feature with
+ * (T_cur, T_ref) (LocalMapping::FindCandidates, LocalMapping.cpp:47-80), else the reference pixel itself.
+ * KLT starts from the reference pixels (Tracker::SetReference); sparse alignment starts from T_ref (Matcher.cpp:471). */
+int  ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
+                         const double *T_ref, int n_pairs, int predict);
+int  ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict);       /* device-side reload only (next step, same pairs) */
+int  ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm);
+int  ygz_hip_track_direct(ygz_hip_ctx *ctx);
+int  ygz_hip_track_sparse_align(ygz_hip_ctx *ctx, int max_level, int min_level, int n_iter);
+int  ygz_hip_track_get_klt(ygz_hip_ctx *ctx, int pair, float *pts, uint8_t *status, float *err, int capacity, int *n);
+int  ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *level, uint8_t *ok, int capacity, int *n);
+int  ygz_hip_track_get_pose(ygz_hip_ctx *ctx, int pair, double T[7], int *n_meas, int *iters /*[levels] or NULL*/);
 
 /* ---- B1-B5: local-BA edge stack -- replaces the per-iteration work g2o does for
  *      EdgeSophusSE3ProjectXYZ (include/ygz/G2oTypes.h:84-132: computeError, linearizeOplus) plus

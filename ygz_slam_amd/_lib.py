@@ -54,12 +54,14 @@ class BaProblem(C.Structure):
 # every symbol include/ygz_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_error_string",
-    "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end",
+    "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end", "ygz_hip_probe_begin", "ygz_hip_probe_end",
     "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_level_size",
     "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_get_fast_maps",
     "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
     "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
     "ygz_hip_default_klt_params", "ygz_hip_klt_track",
+    "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
+    "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download",
 ]
 
@@ -127,6 +129,14 @@ class HipContext:
         ms = C.c_float(0)
         self._chk(self.lib.ygz_hip_timer_end(self._ctx, C.byref(ms)), "timer_end")
         return ms.value
+
+    def probe_begin(self, kernel, max_launches=4096):
+        self._chk(self.lib.ygz_hip_probe_begin(self._ctx, kernel.encode(), max_launches), "probe_begin")
+
+    def probe_end(self):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._chk(self.lib.ygz_hip_probe_end(self._ctx, C.byref(ms), C.byref(n)), "probe_end")
+        return ms.value, n.value
 
     # ---- frames
     def upload_gray(self, slot, gray):
@@ -272,6 +282,59 @@ class HipContext:
         self._chk(self.lib.ygz_hip_klt_track(self._ctx, prev_slot, cur_slot, _p(pp, C.c_float), _p(npts, C.c_float), len(pp),
                                              C.byref(prm), _p(st, C.c_uint8), _p(err, C.c_float)), "klt_track")
         return npts, st, err
+
+    # ---- resident batched tracking
+    def set_keypoint_depths(self, slot, depth, has_mp):
+        depth = np.ascontiguousarray(depth, np.float64)
+        has_mp = np.ascontiguousarray(has_mp, np.uint8)
+        self._chk(self.lib.ygz_hip_set_keypoint_depths(self._ctx, slot, _p(depth, C.c_double), _p(has_mp, C.c_uint8), len(depth)),
+                  "set_keypoint_depths")
+
+    def track_begin(self, cur_slots, ref_slots, T_cur, T_ref, predict=True):
+        c = np.ascontiguousarray(cur_slots, np.int32)
+        r = np.ascontiguousarray(ref_slots, np.int32)
+        Tc = np.ascontiguousarray(T_cur, np.float64).reshape(-1, 7)
+        Tr = np.ascontiguousarray(T_ref, np.float64).reshape(-1, 7)
+        self._chk(self.lib.ygz_hip_track_begin(self._ctx, _p(c, C.c_int32), _p(r, C.c_int32), _p(Tc, C.c_double), _p(Tr, C.c_double),
+                                               len(c), int(predict)), "track_begin")
+
+    def track_reload(self, predict=True):
+        self._chk(self.lib.ygz_hip_track_reload(self._ctx, int(predict)), "track_reload")
+
+    def track_klt(self, params=None):
+        prm = params or self.klt_params()
+        self._chk(self.lib.ygz_hip_track_klt(self._ctx, C.byref(prm)), "track_klt")
+
+    def track_direct(self):
+        self._chk(self.lib.ygz_hip_track_direct(self._ctx), "track_direct")
+
+    def track_sparse_align(self, max_level=2, min_level=0, n_iter=30):
+        self._chk(self.lib.ygz_hip_track_sparse_align(self._ctx, max_level, min_level, n_iter), "track_sparse_align")
+
+    def track_get_klt(self, pair):
+        pts = np.empty((self.cells, 2), np.float32)
+        st = np.empty(self.cells, np.uint8)
+        err = np.empty(self.cells, np.float32)
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_track_get_klt(self._ctx, pair, _p(pts, C.c_float), _p(st, C.c_uint8), _p(err, C.c_float), self.cells,
+                                                 C.byref(n)), "track_get_klt")
+        return pts[:n.value].copy(), st[:n.value].copy(), err[:n.value].copy()
+
+    def track_get_direct(self, pair):
+        px = np.empty((self.cells, 2), np.float64)
+        lvl = np.empty(self.cells, np.int32)
+        ok = np.empty(self.cells, np.uint8)
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_track_get_direct(self._ctx, pair, _p(px, C.c_double), _p(lvl, C.c_int32), _p(ok, C.c_uint8), self.cells,
+                                                    C.byref(n)), "track_get_direct")
+        return ok[:n.value].astype(bool), px[:n.value].copy(), lvl[:n.value].copy()
+
+    def track_get_pose(self, pair):
+        T = (C.c_double * 7)()
+        nm = C.c_int(0)
+        iters = (C.c_int * MAX_LEVELS)()
+        self._chk(self.lib.ygz_hip_track_get_pose(self._ctx, pair, T, C.byref(nm), iters), "track_get_pose")
+        return nm.value, np.array(list(T)), list(iters)[:self.levels]
 
     # ---- BA
     def _ba_problem(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam=None):

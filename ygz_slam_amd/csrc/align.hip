@@ -106,31 +106,35 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
 struct FdpArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
-    int n_levels;
-    int ref_slot, cur_slot;
-    Se3 T_ref, T_cur;
+    int n_levels, cells;
     Cam cam;
-    const double *px_ref, *depth_ref; const int32_t *level_ref;
-    double *px_cur; int32_t *search_level; uint8_t *ok;
-    int n;
+    const int32_t *pair_q, *pair_t, *trk_n;       // cur slot, ref slot, candidates per pair
+    const double *pair_T;                         // [pairs][2][7] (T_ref, T_cur)
+    const double *trk_px, *trk_depth; const int32_t *trk_level;
+    double *px_cur; int32_t *search_level; uint8_t *ok;      // [pairs][cells]
 };
 
 // Matcher::FindDirectProjection (Feature* overload, Matcher.cpp:385-417)
 __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
 {
     __shared__ uint8_t pwb_all[100 * 64];
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= A.n) return;
+    const int pair = blockIdx.y;
+    const int ii = blockIdx.x * 64 + threadIdx.x;
+    if (ii >= A.trk_n[pair]) return;
+    const size_t i = (size_t)pair * A.cells + ii;
+    const int ref_slot = A.pair_t[pair], cur_slot = A.pair_q[pair];
     uint8_t *pwb = pwb_all + threadIdx.x;
-    const double depth = A.depth_ref[i];
+    const double depth = A.trk_depth[i];
     if (depth < 0) { A.ok[i] = 0; A.search_level[i] = 0; return; }
-    const int Lr = A.level_ref[i];
-    const double px_ref[2] = { A.px_ref[2 * i], A.px_ref[2 * i + 1] };
+    const int Lr = A.trk_level[i];
+    const double px_ref[2] = { A.trk_px[2 * i], A.trk_px[2 * i + 1] };
     double pt_ref[3];
     pixel2camera_d(A.cam, px_ref, depth, pt_ref);
-    Se3 Tri, TCR;
-    se3_inv_d(&A.T_ref, &Tri);
-    se3_mul_d(&A.T_cur, &Tri, &TCR);
+    Se3 T_ref, T_cur, Tri, TCR;
+    for (int k = 0; k < 4; ++k) { T_ref.q[k] = A.pair_T[14 * (size_t)pair + k]; T_cur.q[k] = A.pair_T[14 * (size_t)pair + 7 + k]; }
+    for (int k = 0; k < 3; ++k) { T_ref.t[k] = A.pair_T[14 * (size_t)pair + 4 + k]; T_cur.t[k] = A.pair_T[14 * (size_t)pair + 11 + k]; }
+    se3_inv_d(&T_ref, &Tri);
+    se3_mul_d(&T_cur, &Tri, &TCR);
     // GetWarpAffineMatrix (Matcher.cpp:420-436)
     double Am[4];
     {
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
     // WarpAffine (Matcher.cpp:438-466), half_patch_size 5
     {
         const int rw = A.w[Lr], rh = A.h[Lr];
-        const uint8_t *img = A.lvl[Lr] + (size_t)A.ref_slot * rw * rh;
+        const uint8_t *img = A.lvl[Lr] + (size_t)ref_slot * rw * rh;
         const double det = Am[0] * Am[3] - Am[2] * Am[1];
         const double invdet = 1.0 / det;
         const double R0 = Am[3] * invdet, R1 = -Am[1] * invdet, R2 = -Am[2] * invdet, R3 = Am[0] * invdet;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
             }
     }
     const int cw = A.w[sl], ch = A.h[sl];
-    const uint8_t *cur = A.lvl[sl] + (size_t)A.cur_slot * cw * ch;
+    const uint8_t *cur = A.lvl[sl] + (size_t)cur_slot * cw * ch;
     double u = A.px_cur[2 * i] / (double)(1 << sl), v = A.px_cur[2 * i + 1] / (double)(1 << sl);
     const bool good = align2d_core(cur, cw, ch, pwb, 10, &u, &v, nullptr);
     const double ox = u * (double)(1 << sl), oy = v * (double)(1 << sl);
@@ -202,10 +206,23 @@ __global__ __launch_bounds__(64) void k_align2d(const uint8_t *__restrict__ cur,
     uv[2 * i] = u; uv[2 * i + 1] = v; ok[i] = (uint8_t)good; chi2[i] = c2;
 }
 
-static void se3_from7(const double *a, Se3 *T) { for (int k = 0; k < 4; ++k) T->q[k] = a[k]; for (int k = 0; k < 3; ++k) T->t[k] = a[4 + k]; }
+int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs)
+{
+    FdpArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
+    A.n_levels = ctx->prm.pyramid_levels; A.cells = ctx->cells;
+    A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
+    A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_level = ctx->trk_level;
+    A.px_cur = ctx->fdp_px; A.search_level = ctx->fdp_level; A.ok = ctx->fdp_ok;
+    YGZ_LAUNCH(ctx, KID_FDP, k_find_direct_projection, dim3(ygz_div_up(ctx->cells, 64), n_pairs), dim3(64), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
 
 extern "C" {
 
+// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
 int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair, const double *px_ref, const double *depth_ref,
                                    const int32_t *level_ref, double *px_cur, int32_t *search_level, uint8_t *ok, int n)
 {
@@ -213,32 +230,22 @@ int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair,
     if (n == 0) return YGZ_OK;
     if (!px_ref || !depth_ref || !level_ref || !px_cur || !search_level || !ok) return YGZ_E_INVALID;
     if (pair->ref_slot < 0 || pair->ref_slot >= ctx->prm.max_frames || pair->cur_slot < 0 || pair->cur_slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[pair->ref_slot] || !ctx->pyr_valid[pair->cur_slot]) return YGZ_E_STATE;
     for (int i = 0; i < n; ++i) if (level_ref[i] < 0 || level_ref[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
-    // device staging: [px_ref 16n][depth 8n][px_cur 16n][level 4n][search 4n][ok n]
-    uint8_t *buf = nullptr;
-    const size_t N = (size_t)n, bytes = N * (16 + 8 + 16 + 4 + 4 + 1) + 64;
-    int rc = ygz_scratch(ctx, SCR_ALIGN_IN, bytes, (void **)&buf);
+    int rc = ygz_track_set_pairs(ctx, &pair->cur_slot, &pair->ref_slot, pair->T_cur, pair->T_ref, 1);
     if (rc != YGZ_OK) return rc;
-    double *d_pxr = (double *)buf, *d_dep = d_pxr + 2 * N, *d_pxc = d_dep + N;
-    int32_t *d_lvl = (int32_t *)(d_pxc + 2 * N), *d_sl = d_lvl + N;
-    uint8_t *d_ok = (uint8_t *)(d_sl + N);
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pxr, px_ref, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_dep, depth_ref, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pxc, px_cur, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_lvl, level_ref, N * 4, hipMemcpyHostToDevice, ctx->stream));
-    FdpArgs A;
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
-    A.n_levels = ctx->prm.pyramid_levels;
-    A.ref_slot = pair->ref_slot; A.cur_slot = pair->cur_slot;
-    se3_from7(pair->T_ref, &A.T_ref); se3_from7(pair->T_cur, &A.T_cur);
-    A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
-    A.px_ref = d_pxr; A.depth_ref = d_dep; A.level_ref = d_lvl; A.px_cur = d_pxc; A.search_level = d_sl; A.ok = d_ok; A.n = n;
-    hipLaunchKernelGGL(k_find_direct_projection, dim3(ygz_div_up(n, 64)), dim3(64), 0, ctx->stream, A);
-    YGZ_HIPCHK(ctx, hipGetLastError());
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_cur, d_pxc, N * 16, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(search_level, d_sl, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, d_ok, N, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t N = (size_t)n;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px_ref, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, depth_ref, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_level, level_ref, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->fdp_px, px_cur, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = ygz_launch_fdp(ctx, 1)) != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_cur, ctx->fdp_px, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(search_level, ctx->fdp_level, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, ctx->fdp_ok, N, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }
@@ -260,7 +267,7 @@ int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pw
     YGZ_HIPCHK(ctx, hipMemcpyAsync(d_uv, uv, N * 16, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pwb, pwb, N * 100, hipMemcpyHostToDevice, ctx->stream));
     const int w = ctx->lw[level], h = ctx->lh[level];
-    hipLaunchKernelGGL(k_align2d, dim3(ygz_div_up(n, 64)), dim3(64), 0, ctx->stream,
+    YGZ_LAUNCH(ctx, KID_ALIGN2D, k_align2d, dim3(ygz_div_up(n, 64)), dim3(64),
                        ctx->lvl[level] + (size_t)cur_slot * w * h, w, h, d_pwb, d_uv, d_ok, d_chi, n, n_iter);
     YGZ_HIPCHK(ctx, hipGetLastError());
     YGZ_HIPCHK(ctx, hipMemcpyAsync(uv, d_uv, N * 16, hipMemcpyDeviceToHost, ctx->stream));

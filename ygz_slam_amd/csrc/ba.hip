@@ -41,8 +41,9 @@ struct BaDev {
     const uint8_t *fixed;
 };
 
-__global__ __launch_bounds__(64) void k_ba_pose_prep(BaDev B)
+__global__ __launch_bounds__(64) void k_ba_pose_prep(const BaDev *__restrict__ wins)
 {
+    const BaDev B = wins[blockIdx.y];
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= B.K) return;
     const double *p = B.poses + 6 * (size_t)k;
@@ -74,8 +75,9 @@ __device__ __forceinline__ void ba_pose_jac(int formulation, double x, double y,
     }
 }
 
-__global__ __launch_bounds__(128) void k_ba_points(BaDev B)
+__global__ __launch_bounds__(128) void k_ba_points(const BaDev *__restrict__ wins)
 {
+    const BaDev B = wins[blockIdx.y];
     const int il = blockIdx.x * 128 + threadIdx.x;
     if (il >= B.P) return;
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
@@ -137,9 +139,11 @@ __global__ __launch_bounds__(128) void k_ba_points(BaDev B)
     for (int i = 0; i < 3; ++i) B.bl[3 * (size_t)il + i] = gl[i];
 }
 
-__global__ __launch_bounds__(256) void k_ba_poses(BaDev B)
+__global__ __launch_bounds__(256) void k_ba_poses(const BaDev *__restrict__ wins)
 {
     __shared__ double red[4][27];
+    const BaDev B = wins[blockIdx.y];
+    if ((int)blockIdx.x >= B.K) return;                // block-uniform
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double acc[27];
 #pragma unroll
@@ -181,9 +185,10 @@ __global__ __launch_bounds__(256) void k_ba_poses(BaDev B)
     }
 }
 
-__global__ __launch_bounds__(1024) void k_ba_chi2(const double *__restrict__ rho0, int E, double *__restrict__ out)
+__global__ __launch_bounds__(1024) void k_ba_chi2(const BaDev *__restrict__ wins)
 {
     __shared__ double red[16];
+    const double *rho0 = wins[blockIdx.x].rho0; const int E = wins[blockIdx.x].E; double *out = wins[blockIdx.x].chi2;
     double v = 0.0;
     for (int e = threadIdx.x; e < E; e += 1024) v += rho0[e];
 #pragma unroll
@@ -199,6 +204,7 @@ extern "C" void ygz_hip_ba_free_all(ygz_hip_ctx *ctx)
 {
     for (auto *w : ctx->ba) ba_free(w);
     ctx->ba.clear();
+    if (ctx->ba_table) { (void)hipFree(ctx->ba_table); ctx->ba_table = nullptr; }
 }
 
 static BaDev ba_dev(const ygz_hip_ctx::BaWindow *w)
@@ -254,6 +260,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     w->pt_off = ii; ii += (size_t)P + 1; w->pose_off = ii; ii += (size_t)K + 1;
     w->fixed = (uint8_t *)ii;
     ctx->ba[window] = w;
+    ctx->ba_table_dirty = true;
     std::vector<uint8_t> fixed(K, 0);
     if (pb->pose_fixed) memcpy(fixed.data(), pb->pose_fixed, K);
     YGZ_HIPCHK(ctx, hipMemcpyAsync(w->poses, pb->poses, (size_t)K * 48, hipMemcpyHostToDevice, ctx->stream));
@@ -285,15 +292,27 @@ int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, cons
 int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows)
 {
     if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size()) return YGZ_E_INVALID;
-    for (int i = window_begin; i < window_begin + n_windows; ++i) {
-        auto *w = ctx->ba[i];
-        if (!w) return YGZ_E_INVALID;
-        const BaDev B = ba_dev(w);
-        hipLaunchKernelGGL(k_ba_pose_prep, dim3(ygz_div_up(w->K, 64)), dim3(64), 0, ctx->stream, B);
-        hipLaunchKernelGGL(k_ba_points, dim3(ygz_div_up(w->P, 128)), dim3(128), 0, ctx->stream, B);
-        hipLaunchKernelGGL(k_ba_poses, dim3(w->K), dim3(256), 0, ctx->stream, B);
-        hipLaunchKernelGGL(k_ba_chi2, dim3(1), dim3(1024), 0, ctx->stream, w->rho0, w->E, w->chi2);
+    for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i]) return YGZ_E_INVALID;
+    if (ctx->ba_table_dirty) {                       // descriptor table of all windows (changes only at upload time)
+        std::vector<BaDev> tab(1024);
+        memset(tab.data(), 0, tab.size() * sizeof(BaDev));
+        ctx->ba_max_K = ctx->ba_max_P = 0;
+        for (size_t i = 0; i < ctx->ba.size() && i < 1024; ++i)
+            if (ctx->ba[i]) {
+                tab[i] = ba_dev(ctx->ba[i]);
+                if (ctx->ba[i]->K > ctx->ba_max_K) ctx->ba_max_K = ctx->ba[i]->K;
+                if (ctx->ba[i]->P > ctx->ba_max_P) ctx->ba_max_P = ctx->ba[i]->P;
+            }
+        if (!ctx->ba_table) YGZ_HIPCHK(ctx, hipMalloc(&ctx->ba_table, 1024 * sizeof(BaDev)));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->ba_table, tab.data(), tab.size() * sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->ba_table_dirty = false;
     }
+    const BaDev *tab = reinterpret_cast<const BaDev *>(ctx->ba_table) + window_begin;
+    YGZ_LAUNCH(ctx, KID_BA_POSE_PREP, k_ba_pose_prep, dim3(ygz_div_up(ctx->ba_max_K, 64), n_windows), dim3(64), tab);
+    YGZ_LAUNCH(ctx, KID_BA_POINTS, k_ba_points, dim3(ygz_div_up(ctx->ba_max_P, 128), n_windows), dim3(128), tab);
+    YGZ_LAUNCH(ctx, KID_BA_POSES, k_ba_poses, dim3(ctx->ba_max_K, n_windows), dim3(256), tab);
+    YGZ_LAUNCH(ctx, KID_BA_CHI2, k_ba_chi2, dim3(n_windows), dim3(1024), tab);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }

@@ -92,7 +92,12 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
         ctx->grid_rows = (int)ceil((double)prm->image_height / prm->cell_size);
         ctx->grid_cols = (int)ceil((double)prm->image_width / prm->cell_size);
         ctx->cells = ctx->grid_rows * ctx->grid_cols;
-        if ((rc = ygz_ensure_levels(ctx, prm->pyramid_levels)) != YGZ_OK) break;
+        // image levels: the frame pyramid plus the extra levels cv::calcOpticalFlowPyrLK builds for the default
+        // tracker (21x21 window, maxLevel 4; buildOpticalFlowPyramid stops when the next level <= window)
+        int klt_levels = 1;
+        { int sw = prm->image_width, sh = prm->image_height;
+          for (int level = 0; level <= 4; ++level) { klt_levels = level + 1; sw = (sw + 1) / 2; sh = (sh + 1) / 2; if (sw <= 21 || sh <= 21) break; } }
+        if ((rc = ygz_ensure_levels(ctx, prm->pyramid_levels > klt_levels ? prm->pyramid_levels : klt_levels)) != YGZ_OK) break;
         const size_t F = (size_t)prm->max_frames, Cn = (size_t)ctx->cells;
         hipError_t e = hipSuccess;
 #define A_(ptr, bytes) if (e == hipSuccess) e = hipMalloc((void **)&(ptr), (bytes))
@@ -133,11 +138,14 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     }
     void *ptrs[] = { ctx->bgr, ctx->cell_first, ctx->cell_best, ctx->occupied, ctx->kp_px, ctx->kp_level, ctx->kp_score,
                      ctx->kp_angle, ctx->kp_desc, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->m_tq, ctx->m_td, ctx->m_key,
-                     ctx->m_idx, ctx->m_dist, ctx->m_dist2 };
+                     ctx->m_idx, ctx->m_dist, ctx->m_dist2, ctx->trk_n, ctx->trk_px, ctx->trk_level, ctx->trk_depth, ctx->trk_has_mp,
+                     ctx->pair_T, ctx->kp_depth, ctx->kp_has_mp, ctx->klt_pts, ctx->klt_err, ctx->klt_status, ctx->fdp_px,
+                     ctx->fdp_level, ctx->fdp_ok, ctx->sa_out, ctx->sa_work };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < YGZ_N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->probe_ev) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -162,6 +170,41 @@ int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
     YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     YGZ_HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     YGZ_HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    return YGZ_OK;
+}
+
+static const char *const k_kernel_names[KID_COUNT] = {
+    "k_bgr2gray", "k_pyr_down", "k_fast_select", "k_compact", "k_describe", "k_hamming_nn", "k_match_finalize", "k_track_load",
+    "k_find_direct_projection", "k_align2d", "k_sparse_align", "k_scharr", "k_klt", "k_ba_pose_prep", "k_ba_points", "k_ba_poses",
+    "k_ba_chi2" };
+
+int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launches)
+{
+    if (!ctx || !kernel_name || max_launches < 1 || max_launches > 65536) return YGZ_E_INVALID;
+    int id = -1;
+    for (int i = 0; i < KID_COUNT; ++i) if (strcmp(kernel_name, k_kernel_names[i]) == 0) id = i;
+    if (id < 0) return YGZ_E_INVALID;
+    while ((int)ctx->probe_ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        YGZ_HIPCHK(ctx, hipEventCreate(&e));
+        ctx->probe_ev.push_back(e);
+    }
+    ctx->probe_used = 0; ctx->probe_id = id;
+    return YGZ_OK;
+}
+
+int ygz_hip_probe_end(ygz_hip_ctx *ctx, double *total_ms, int *launches)
+{
+    if (!ctx || !total_ms || !launches) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (int i = 0; i + 1 < ctx->probe_used; i += 2) {
+        float ms = 0;
+        YGZ_HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->probe_ev[i], ctx->probe_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot; *launches = ctx->probe_used / 2;
+    ctx->probe_id = -1; ctx->probe_used = 0;
     return YGZ_OK;
 }
 
@@ -202,7 +245,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
 {
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     if (from_bgr && !ctx->bgr) return YGZ_E_STATE;
-    int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->prm.pyramid_levels);
+    int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->n_levels_alloc);
     if (rc != YGZ_OK) return rc;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 1;
     return YGZ_OK;

@@ -362,10 +362,9 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
         A.dbg_score = ctx->prm.debug_maps ? ctx->dbg_score[L] : nullptr;
         A.dbg_nms = ctx->prm.debug_maps ? ctx->dbg_nms[L] : nullptr;
         A.slot_begin = slot_begin;
-        hipLaunchKernelGGL(k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), n_slots), dim3(256), 0,
-                           ctx->stream, A);
+        YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), n_slots), dim3(256), A);
     }
-    hipLaunchKernelGGL(k_compact, dim3(n_slots), dim3(1024), 0, ctx->stream, ctx->cell_first, ctx->cell_best, ctx->cells,
+    YGZ_LAUNCH(ctx, KID_COMPACT, k_compact, dim3(n_slots), dim3(1024), ctx->cell_first, ctx->cell_best, ctx->cells,
                        ctx->kp_px, ctx->kp_level, ctx->kp_score, ctx->n_kp, slot_begin);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return ygz_launch_describe(ctx, slot_begin, n_slots);
@@ -378,7 +377,7 @@ int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
     D.n_levels = ctx->prm.pyramid_levels; D.cells = ctx->cells;
     D.kp_px = ctx->kp_px; D.kp_level = ctx->kp_level; D.n_kp = ctx->n_kp;
     D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin;
-    hipLaunchKernelGGL(k_describe, dim3(ygz_div_up(ctx->cells, 4), n_slots), dim3(256), 0, ctx->stream, D);
+    YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe, dim3(ygz_div_up(ctx->cells, 4), n_slots), dim3(256), D);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }

@@ -107,8 +107,8 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
         A.pair_a = pair_q; A.pair_b = pair_t;
         A.out_idx = ctx->m_idx; A.out_dist = ctx->m_dist; A.out_dist2 = want_second ? ctx->m_dist2 : nullptr;
         A.scatter_key = nullptr;
-        if (want_second) hipLaunchKernelGGL(k_hamming_nn<true>, grid, block, 0, ctx->stream, A);
-        else hipLaunchKernelGGL(k_hamming_nn<false>, grid, block, 0, ctx->stream, A);
+        if (want_second) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_nn<true>, grid, block, A);
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_nn<false>, grid, block, A);
     }
     if (cross_check == 1 || cross_check == 2) {       // train -> query
         if (cross_check == 1)
@@ -116,8 +116,8 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
         A.pair_a = pair_t; A.pair_b = pair_q;
         A.out_idx = ctx->m_tq; A.out_dist = ctx->m_td; A.out_dist2 = nullptr;
         A.scatter_key = (cross_check == 1) ? ctx->m_key : nullptr;
-        hipLaunchKernelGGL(k_hamming_nn<false>, grid, block, 0, ctx->stream, A);
-        hipLaunchKernelGGL(k_match_finalize, grid, block, 0, ctx->stream, set_count, pair_q, Cn, cross_check,
+        YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_nn<false>, grid, block, A);
+        YGZ_LAUNCH(ctx, KID_MATCH_FINALIZE, k_match_finalize, grid, block, set_count, pair_q, Cn, cross_check,
                            ctx->m_key, ctx->m_tq, ctx->m_idx, ctx->m_dist);
     }
     YGZ_HIPCHK(ctx, hipGetLastError());

@@ -109,16 +109,15 @@ int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int f
     const unsigned npix = (unsigned)ctx->lw[0] * (unsigned)ctx->lh[0];
     if (from_bgr) {
         if ((npix & 15u) == 0)
-            hipLaunchKernelGGL(k_bgr2gray16, dim3(ygz_div_up((int)(npix / 16), 256), n_slots), dim3(256), 0, ctx->stream,
+            YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray16, dim3(ygz_div_up((int)(npix / 16), 256), n_slots), dim3(256),
                                ctx->bgr, ctx->lvl[0], npix, slot_begin);
         else
-            hipLaunchKernelGGL(k_bgr2gray1, dim3(ygz_div_up((int)npix, 256), n_slots), dim3(256), 0, ctx->stream,
+            YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray1, dim3(ygz_div_up((int)npix, 256), n_slots), dim3(256),
                                ctx->bgr, ctx->lvl[0], npix, slot_begin);
     }
     for (int L = 1; L < up_to_level; ++L) {
         const int sw = ctx->lw[L - 1], sh = ctx->lh[L - 1], dw = ctx->lw[L], dh = ctx->lh[L];
-        hipLaunchKernelGGL(k_pyr_down, dim3(ygz_div_up(dw, PD_TW), ygz_div_up(dh, PD_TH), n_slots), dim3(256), 0,
-                           ctx->stream, ctx->lvl[L - 1], ctx->lvl[L], sw, sh, dw, dh, slot_begin);
+        YGZ_LAUNCH(ctx, KID_PYR_DOWN, k_pyr_down, dim3(ygz_div_up(dw, PD_TW), ygz_div_up(dh, PD_TH), n_slots), dim3(256), ctx->lvl[L - 1], ctx->lvl[L], sw, sh, dw, dh, slot_begin);
     }
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;

@@ -14,9 +14,9 @@
 //             shuffles in a FIXED order.  The integer terms are identical to the oracle's; only the
 //             float summation order differs (tree vs raster), well inside the 1e-5 track tolerance.
 #include "ygz_internal.h"
+#include <vector>
 
 #define KLT_MAXWIN 21
-#define KLT_NPIX   (KLT_MAXWIN * KLT_MAXWIN)
 
 __device__ __forceinline__ int refl101(int i, int n)
 {
@@ -26,10 +26,14 @@ __device__ __forceinline__ int refl101(int i, int n)
 }
 
 // calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1)
-__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img, int16_t *__restrict__ deriv, int w, int h)
+__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img_base, int16_t *__restrict__ deriv_base,
+                                                const int32_t *__restrict__ pair_t, int w, int h)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    const size_t slot = (size_t)pair_t[blockIdx.z];            // reference slot of this pair
+    const uint8_t *img = img_base + slot * (size_t)w * h;
+    int16_t *deriv = deriv_base + slot * (size_t)w * h * 2;
     const int y0 = y > 0 ? y - 1 : (h > 1 ? 1 : 0), y2 = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
     const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
     const uint8_t *r0 = img + (size_t)y0 * w, *r1 = img + (size_t)y * w, *r2 = img + (size_t)y2 * w;
@@ -42,13 +46,15 @@ __global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img,
 }
 
 struct KltArgs {
-    const uint8_t *prev[YGZ_MAX_LEVELS], *next[YGZ_MAX_LEVELS];   // level images of the two slots
-    const int16_t *deriv[YGZ_MAX_LEVELS];                          // Scharr of prev
+    const uint8_t *lvl[YGZ_MAX_LEVELS];                            // level images, slot-major
+    const int16_t *deriv[YGZ_MAX_LEVELS];                          // Scharr images, slot-major
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
-    int max_level, win, max_count, use_initial_flow;
+    int max_level, win, max_count, use_initial_flow, cells;
     double epsilon;            // already squared
     float min_eig_thr;
-    const float *prev_pts; float *next_pts; uint8_t *status; float *err; int n;
+    const int32_t *pair_q, *pair_t, *trk_n;                        // cur slot, ref slot, points per pair
+    const double *trk_px;                                          // [pairs][cells][2] reference pixels
+    float *next_pts; uint8_t *status; float *err;                  // [pairs][cells]
 };
 
 __device__ __forceinline__ float wave_sum_f(float v)
@@ -61,27 +67,47 @@ __device__ __forceinline__ float wave_sum_f(float v)
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
 #define KLT_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
+// 8 consecutive bytes from an arbitrary byte address: 3 aligned dword loads + v_alignbyte (a wave-wide byte
+// gather costs the same address-unit time per instruction as a dword load, so bytes are fetched 8 at a time)
+__device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+}
+#define KLT_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
+#define KLT_BIL9V(v00, v01, v10, v11) KLT_DESCALE((v00) * iw00 + (v01) * iw01 + (v10) * iw10 + (v11) * iw11, 9)
+
+// Lane mapping: 3 lanes per window row, 7 consecutive pixels per lane (21 = 3 x 7; 63 of 64 lanes busy).
+// Interior windows (the common case) fetch their 2 x 8 source bytes per row with 6 dword loads per iteration
+// instead of 28 byte gathers; windows that touch the image border take the reflect-101 per-pixel path.
 __global__ __launch_bounds__(256) void k_klt(KltArgs A)
 {
-    __shared__ int16_t sI[4][KLT_NPIX + 7];
-    __shared__ uint32_t sD[4][KLT_NPIX + 7];      // (ix | iy<<16)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + wv;
-    if (p >= A.n) return;                          // wave-uniform
-    const int win = A.win, npix = win * win;
+    const int pair = blockIdx.y;
+    const int pi = blockIdx.x * 4 + wv;
+    if (pi >= A.trk_n[pair]) return;               // wave-uniform
+    const size_t p = (size_t)pair * A.cells + pi;
+    const size_t ref_slot = (size_t)A.pair_t[pair], cur_slot = (size_t)A.pair_q[pair];
+    const int win = A.win;
     const float half = (float)(win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
-    int16_t *IWin = sI[wv]; uint32_t *DWin = sD[wv];
-    const float ppx = A.prev_pts[2 * p], ppy = A.prev_pts[2 * p + 1];
+    const float ppx = (float)A.trk_px[2 * p], ppy = (float)A.trk_px[2 * p + 1];   // cv::Point2f(fea->_pixel) (Tracker.cpp:85)
     float outx = A.use_initial_flow ? A.next_pts[2 * p] : ppx;
     float outy = A.use_initial_flow ? A.next_pts[2 * p + 1] : ppy;
     bool status = true;
     float errv = 0.f;
+    const int row = lane / 3, x0 = 7 * (lane - 3 * row);
+    const bool act = row < win && x0 < win;
+    const int npx = act ? min(7, win - x0) : 0;
 
     for (int level = A.max_level; level >= 0; --level) {
         const int w = A.w[level], h = A.h[level];
-        const uint8_t *I = A.prev[level], *J = A.next[level];
-        const uint32_t *D = reinterpret_cast<const uint32_t *>(A.deriv[level]);
+        const uint8_t *I = A.lvl[level] + ref_slot * (size_t)w * h, *J = A.lvl[level] + cur_slot * (size_t)w * h;
+        const uint32_t *D = reinterpret_cast<const uint32_t *>(A.deriv[level]) + ref_slot * (size_t)w * h;
         const float s = (float)(1. / (double)(1 << level));
         float prevx = __fmul_rn(ppx, s), prevy = __fmul_rn(ppy, s);
         float nx, ny;
@@ -100,24 +126,54 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
         int iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));
         int iw11 = 16384 - iw00 - iw01 - iw10;
         float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
-        for (int i = lane; i < npix; i += 64) {
-            const int yy = i / win, xx = i - yy * win;
-            const int X = ipx + xx, Y = ipy + yy;
-            const int X0 = refl101(X, w), X1 = refl101(X + 1, w), Y0 = refl101(Y, h), Y1 = refl101(Y + 1, h);
-            const int ival = KLT_DESCALE((int)I[(size_t)Y0 * w + X0] * iw00 + (int)I[(size_t)Y0 * w + X1] * iw01 +
-                                         (int)I[(size_t)Y1 * w + X0] * iw10 + (int)I[(size_t)Y1 * w + X1] * iw11, 9);
-            const bool x0in = X >= 0 && X < w, x1in = X + 1 >= 0 && X + 1 < w, y0in = Y >= 0 && Y < h, y1in = Y + 1 >= 0 && Y + 1 < h;
-            const uint32_t d00 = (x0in && y0in) ? D[(size_t)Y * w + X] : 0u, d01 = (x1in && y0in) ? D[(size_t)Y * w + X + 1] : 0u;
-            const uint32_t d10 = (x0in && y1in) ? D[(size_t)(Y + 1) * w + X] : 0u, d11 = (x1in && y1in) ? D[(size_t)(Y + 1) * w + X + 1] : 0u;
-            const int ixval = KLT_DESCALE((int)(int16_t)(d00 & 0xFFFF) * iw00 + (int)(int16_t)(d01 & 0xFFFF) * iw01 +
-                                          (int)(int16_t)(d10 & 0xFFFF) * iw10 + (int)(int16_t)(d11 & 0xFFFF) * iw11, 14);
-            const int iyval = KLT_DESCALE((int)(int16_t)(d00 >> 16) * iw00 + (int)(int16_t)(d01 >> 16) * iw01 +
-                                          (int)(int16_t)(d10 >> 16) * iw10 + (int)(int16_t)(d11 >> 16) * iw11, 14);
-            IWin[i] = (int16_t)ival;
-            DWin[i] = ((uint32_t)(uint16_t)(int16_t)ixval) | ((uint32_t)(uint16_t)(int16_t)iyval << 16);
-            sA11 = __fadd_rn(sA11, (float)(ixval * ixval));
-            sA12 = __fadd_rn(sA12, (float)(ixval * iyval));
-            sA22 = __fadd_rn(sA22, (float)(iyval * iyval));
+        // the lane's 7 patch values (int16 image <<5, int16 derivatives) stay in registers for the whole level
+        int iI[7], iDx[7], iDy[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { iI[k] = 0; iDx[k] = 0; iDy[k] = 0; }
+        const bool insideI = ipx >= 0 && ipy >= 0 && ipx + win < w && ipy + win < h;
+        if (act) {
+            if (insideI) {
+                const int o = (ipy + row) * w + ipx + x0;
+                uint32_t l0, h0, l1, h1;
+                klt_load8(I + o, l0, h0); klt_load8(I + o + w, l1, h1);
+                uint32_t d0[8], d1[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { d0[k] = D[o + k]; d1[k] = D[o + w + k]; }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    if (k < npx) {
+                        const int ival = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1));
+                        const int ixval = KLT_DESCALE((int)(int16_t)(d0[k] & 0xFFFF) * iw00 + (int)(int16_t)(d0[k + 1] & 0xFFFF) * iw01 +
+                                                      (int)(int16_t)(d1[k] & 0xFFFF) * iw10 + (int)(int16_t)(d1[k + 1] & 0xFFFF) * iw11, 14);
+                        const int iyval = KLT_DESCALE((int)(int16_t)(d0[k] >> 16) * iw00 + (int)(int16_t)(d0[k + 1] >> 16) * iw01 +
+                                                      (int)(int16_t)(d1[k] >> 16) * iw10 + (int)(int16_t)(d1[k + 1] >> 16) * iw11, 14);
+                        iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    if (k < npx) {
+                        const int X = ipx + x0 + k, Y = ipy + row;
+                        const int X0 = refl101(X, w), X1 = refl101(X + 1, w), Y0 = refl101(Y, h), Y1 = refl101(Y + 1, h);
+                        const int ival = KLT_BIL9V((int)I[Y0 * w + X0], (int)I[Y0 * w + X1], (int)I[Y1 * w + X0], (int)I[Y1 * w + X1]);
+                        const bool x0in = X >= 0 && X < w, x1in = X + 1 >= 0 && X + 1 < w, y0in = Y >= 0 && Y < h, y1in = Y + 1 >= 0 && Y + 1 < h;
+                        const uint32_t d00 = (x0in && y0in) ? D[Y * w + X] : 0u, d01 = (x1in && y0in) ? D[Y * w + X + 1] : 0u;
+                        const uint32_t d10 = (x0in && y1in) ? D[(Y + 1) * w + X] : 0u, d11 = (x1in && y1in) ? D[(Y + 1) * w + X + 1] : 0u;
+                        const int ixval = KLT_DESCALE((int)(int16_t)(d00 & 0xFFFF) * iw00 + (int)(int16_t)(d01 & 0xFFFF) * iw01 +
+                                                      (int)(int16_t)(d10 & 0xFFFF) * iw10 + (int)(int16_t)(d11 & 0xFFFF) * iw11, 14);
+                        const int iyval = KLT_DESCALE((int)(int16_t)(d00 >> 16) * iw00 + (int)(int16_t)(d01 >> 16) * iw01 +
+                                                      (int)(int16_t)(d10 >> 16) * iw10 + (int)(int16_t)(d11 >> 16) * iw11, 14);
+                        iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                sA11 = __fadd_rn(sA11, (float)(iDx[k] * iDx[k]));
+                sA12 = __fadd_rn(sA12, (float)(iDx[k] * iDy[k]));
+                sA22 = __fadd_rn(sA22, (float)(iDy[k] * iDy[k]));
+            }
         }
         const float A11 = __fmul_rn(wave_sum_f(sA11), FLT_SCALE), A12 = __fmul_rn(wave_sum_f(sA12), FLT_SCALE),
                     A22 = __fmul_rn(wave_sum_f(sA22), FLT_SCALE);
@@ -145,14 +201,31 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));
             iw11 = 16384 - iw00 - iw01 - iw10;
             float sb1 = 0.f, sb2 = 0.f;
-            for (int i = lane; i < npix; i += 64) {
-                const int yy = i / win, xx = i - yy * win;
-                const int X0 = refl101(inx + xx, w), X1 = refl101(inx + xx + 1, w), Y0 = refl101(iny + yy, h), Y1 = refl101(iny + yy + 1, h);
-                const int diff = KLT_DESCALE((int)J[(size_t)Y0 * w + X0] * iw00 + (int)J[(size_t)Y0 * w + X1] * iw01 +
-                                             (int)J[(size_t)Y1 * w + X0] * iw10 + (int)J[(size_t)Y1 * w + X1] * iw11, 9) - (int)IWin[i];
-                const uint32_t d = DWin[i];
-                sb1 = __fadd_rn(sb1, (float)(diff * (int)(int16_t)(d & 0xFFFF)));
-                sb2 = __fadd_rn(sb2, (float)(diff * (int)(int16_t)(d >> 16)));
+            const bool insideJ = inx >= 0 && iny >= 0 && inx + win < w && iny + win < h;
+            if (act) {
+                if (insideJ) {
+                    const int o = (iny + row) * w + inx + x0;
+                    uint32_t l0, h0, l1, h1;
+                    klt_load8(J + o, l0, h0); klt_load8(J + o + w, l1, h1);
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
+                        if (k < npx) {
+                            sb1 = __fadd_rn(sb1, (float)(diff * iDx[k]));
+                            sb2 = __fadd_rn(sb2, (float)(diff * iDy[k]));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        if (k < npx) {
+                            const int X0 = refl101(inx + x0 + k, w), X1 = refl101(inx + x0 + k + 1, w), Y0 = refl101(iny + row, h), Y1 = refl101(iny + row + 1, h);
+                            const int diff = KLT_BIL9V((int)J[Y0 * w + X0], (int)J[Y0 * w + X1], (int)J[Y1 * w + X0], (int)J[Y1 * w + X1]) - iI[k];
+                            sb1 = __fadd_rn(sb1, (float)(diff * iDx[k]));
+                            sb2 = __fadd_rn(sb2, (float)(diff * iDy[k]));
+                        }
+                    }
+                }
             }
             const float b1 = __fmul_rn(wave_sum_f(sb1), FLT_SCALE), b2 = __fmul_rn(wave_sum_f(sb2), FLT_SCALE);
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), Dd);
@@ -176,12 +249,13 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, aa), bb), 16384.f));
             iw11 = 16384 - iw00 - iw01 - iw10;
             float se = 0.f;
-            for (int i = lane; i < npix; i += 64) {
-                const int yy = i / win, xx = i - yy * win;
-                const int X0 = refl101(inx + xx, w), X1 = refl101(inx + xx + 1, w), Y0 = refl101(iny + yy, h), Y1 = refl101(iny + yy + 1, h);
-                const int diff = KLT_DESCALE((int)J[(size_t)Y0 * w + X0] * iw00 + (int)J[(size_t)Y0 * w + X1] * iw01 +
-                                             (int)J[(size_t)Y1 * w + X0] * iw10 + (int)J[(size_t)Y1 * w + X1] * iw11, 9) - (int)IWin[i];
-                se = __fadd_rn(se, fabsf((float)diff));
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (k < npx) {
+                    const int X0 = refl101(inx + x0 + k, w), X1 = refl101(inx + x0 + k + 1, w), Y0 = refl101(iny + row, h), Y1 = refl101(iny + row + 1, h);
+                    const int diff = KLT_BIL9V((int)J[Y0 * w + X0], (int)J[Y0 * w + X1], (int)J[Y1 * w + X0], (int)J[Y1 * w + X1]) - iI[k];
+                    se = __fadd_rn(se, fabsf((float)diff));
+                }
             }
             errv = __fdiv_rn(__fmul_rn(wave_sum_f(se), 1.f), (float)(32 * win * win));
         }
@@ -190,6 +264,43 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
         A.next_pts[2 * p] = outx; A.next_pts[2 * p + 1] = outy;
         A.status[p] = (uint8_t)status; A.err[p] = errv;
     }
+}
+
+int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
+{
+    if (prm->win < 3 || prm->win > KLT_MAXWIN || prm->max_level < 0 || prm->max_level >= YGZ_MAX_LEVELS) return YGZ_E_INVALID;
+    // buildOpticalFlowPyramid: stop when the next level would not exceed the window
+    int max_level = prm->max_level, sw = ctx->lw[0], sh = ctx->lh[0];
+    for (int level = 0; level <= prm->max_level; ++level) {
+        sw = (sw + 1) / 2; sh = (sh + 1) / 2;
+        if (sw <= prm->win || sh <= prm->win) { max_level = level; break; }
+    }
+    if (max_level + 1 > ctx->n_levels_alloc) {      // non-default tracker: more levels than were built at upload time
+        int rc = ygz_ensure_levels(ctx, max_level + 1);
+        if (rc != YGZ_OK) return rc;
+        for (int s = 0; s < ctx->prm.max_frames; ++s)
+            if (ctx->pyr_valid[s] && (rc = ygz_launch_gray_pyramid(ctx, s, 1, 0, max_level + 1)) != YGZ_OK) return rc;
+    }
+    KltArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = nullptr; A.deriv[L] = nullptr; A.w[L] = A.h[L] = 0; }
+    for (int L = 0; L <= max_level; ++L) {
+        const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
+        if (!ctx->deriv[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->deriv[L], (size_t)ctx->prm.max_frames * npix * 4 + 64));
+        A.lvl[L] = ctx->lvl[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L];
+        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(A.w[L], 64), ygz_div_up(A.h[L], 4), n_pairs), dim3(256),
+                           ctx->lvl[L], ctx->deriv[L], ctx->pair_t, A.w[L], A.h[L]);
+    }
+    A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells;
+    A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);
+    const double eps = prm->eps < 0 ? 0 : (prm->eps > 10 ? 10 : prm->eps);
+    A.epsilon = eps * eps;
+    A.min_eig_thr = (float)prm->min_eig_threshold;
+    A.use_initial_flow = prm->use_initial_flow;
+    A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.trk_px = ctx->trk_px;
+    A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
+    YGZ_LAUNCH(ctx, KID_KLT, k_klt, dim3(ygz_div_up(ctx->cells, 4), n_pairs), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
 }
 
 extern "C" {
@@ -201,59 +312,30 @@ void ygz_hip_default_klt_params(ygz_klt_params *p)
     p->use_initial_flow = 1;
 }
 
+// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
 int ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
                       const ygz_klt_params *prm, uint8_t *status, float *err)
 {
     if (!ctx || !prm || n < 0 || prev_slot < 0 || prev_slot >= ctx->prm.max_frames || cur_slot < 0 || cur_slot >= ctx->prm.max_frames)
         return YGZ_E_INVALID;
-    if (prm->win < 3 || prm->win > KLT_MAXWIN || prm->max_level < 0 || prm->max_level >= YGZ_MAX_LEVELS) return YGZ_E_INVALID;
     if (n == 0) return YGZ_OK;
     if (!prev_pts || !next_pts || !status) return YGZ_E_INVALID;
+    if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[prev_slot] || !ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
-    // buildOpticalFlowPyramid: stop when the next level would not exceed the window
-    int max_level = prm->max_level, sw = ctx->lw[0], sh = ctx->lh[0];
-    for (int level = 0; level <= prm->max_level; ++level) {
-        sw = (sw + 1) / 2; sh = (sh + 1) / 2;
-        if (sw <= prm->win || sh <= prm->win) { max_level = level; break; }
-    }
-    int rc = ygz_ensure_levels(ctx, max_level + 1);
+    const double I7[7] = { 0, 0, 0, 1, 0, 0, 0 };
+    int rc = ygz_track_set_pairs(ctx, &cur_slot, &prev_slot, I7, I7, 1);
     if (rc != YGZ_OK) return rc;
-    // levels beyond the frame pyramid (same cv::pyrDown) for both slots
-    if (max_level + 1 > ctx->prm.pyramid_levels) {
-        if ((rc = ygz_launch_gray_pyramid(ctx, prev_slot, 1, 0, max_level + 1)) != YGZ_OK) return rc;
-        if (cur_slot != prev_slot && (rc = ygz_launch_gray_pyramid(ctx, cur_slot, 1, 0, max_level + 1)) != YGZ_OK) return rc;
-    }
-    KltArgs A;
-    for (int L = 0; L <= max_level; ++L) {
-        const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
-        if (!ctx->deriv[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->deriv[L], npix * 4 + 64));   // one slot's worth, reused
-        A.prev[L] = ctx->lvl[L] + (size_t)prev_slot * npix;
-        A.next[L] = ctx->lvl[L] + (size_t)cur_slot * npix;
-        A.deriv[L] = ctx->deriv[L];
-        A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L];
-        hipLaunchKernelGGL(k_scharr, dim3(ygz_div_up(A.w[L], 64), ygz_div_up(A.h[L], 4)), dim3(256), 0, ctx->stream,
-                           A.prev[L], ctx->deriv[L], A.w[L], A.h[L]);
-    }
-    for (int L = max_level + 1; L < YGZ_MAX_LEVELS; ++L) { A.prev[L] = A.next[L] = nullptr; A.deriv[L] = nullptr; A.w[L] = A.h[L] = 0; }
+    std::vector<double> px((size_t)n * 2);
+    for (int i = 0; i < 2 * n; ++i) px[i] = (double)prev_pts[i];
     const size_t N = (size_t)n;
-    uint8_t *buf = nullptr;
-    rc = ygz_scratch(ctx, SCR_KLT_PTS, N * (8 + 8 + 4 + 1) + 64, (void **)&buf);
-    if (rc != YGZ_OK) return rc;
-    float *d_prev = (float *)buf, *d_next = d_prev + 2 * N, *d_err = d_next + 2 * N; uint8_t *d_st = (uint8_t *)(d_err + N);
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_prev, prev_pts, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_next, next_pts, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    A.max_level = max_level; A.win = prm->win;
-    A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);
-    double eps = prm->eps < 0 ? 0 : (prm->eps > 10 ? 10 : prm->eps);
-    A.epsilon = eps * eps;
-    A.min_eig_thr = (float)prm->min_eig_threshold;
-    A.use_initial_flow = prm->use_initial_flow;
-    A.prev_pts = d_prev; A.next_pts = d_next; A.status = d_st; A.err = d_err; A.n = n;
-    hipLaunchKernelGGL(k_klt, dim3(ygz_div_up(n, 4)), dim3(256), 0, ctx->stream, A);
-    YGZ_HIPCHK(ctx, hipGetLastError());
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(next_pts, d_next, N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(status, d_st, N, hipMemcpyDeviceToHost, ctx->stream));
-    if (err) YGZ_HIPCHK(ctx, hipMemcpyAsync(err, d_err, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px.data(), N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_pts, next_pts, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = ygz_launch_klt(ctx, 1, prm)) != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(next_pts, ctx->klt_pts, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(status, ctx->klt_status, N, hipMemcpyDeviceToHost, ctx->stream));
+    if (err) YGZ_HIPCHK(ctx, hipMemcpyAsync(err, ctx->klt_err, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }

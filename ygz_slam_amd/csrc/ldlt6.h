@@ -4,10 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-__host__ __device__ inline bool ldlt6_solve_d(const double Hin[36], const double b[6], double x[6])
+// workspace variant: m[36], y[6], temp[6], tr[6] provided by the caller (LDS on the device)
+__host__ __device__ inline bool ldlt6_solve_ws(const double Hin[36], const double b[6], double x[6],
+                                               double *m, double *y, double *temp, int *tr)
 {
     const int N = 6;
-    double m[36]; int tr[6];
     for (int i = 0; i < 36; ++i) m[i] = Hin[i];
     for (int k = 0; k < N; ++k) {
         int piv = k; double big = fabs(m[k * N + k]);
@@ -20,7 +21,6 @@ __host__ __device__ inline bool ldlt6_solve_d(const double Hin[36], const double
             for (int i = k + 1; i < piv; ++i) { double t = m[i * N + k]; m[i * N + k] = m[piv * N + i]; m[piv * N + i] = t; }
         }
         if (k > 0) {
-            double temp[6];
             for (int j = 0; j < k; ++j) temp[j] = m[j * N + j] * m[k * N + j];
             double s = 0; for (int j = 0; j < k; ++j) s += m[k * N + j] * temp[j];
             m[k * N + k] -= s;
@@ -33,7 +33,6 @@ __host__ __device__ inline bool ldlt6_solve_d(const double Hin[36], const double
         if (k == 0 && !(fabs(akk) > 0)) { for (int j = 1; j < N; ++j) tr[j] = j; break; }
         if (fabs(akk) > 0) for (int i = k + 1; i < N; ++i) m[i * N + k] /= akk;
     }
-    double y[6];
     for (int i = 0; i < N; ++i) y[i] = b[i];
     for (int k = 0; k < N; ++k) if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
     for (int i = 0; i < N; ++i) for (int j = 0; j < i; ++j) y[i] -= m[i * N + j] * y[j];
@@ -45,4 +44,10 @@ __host__ __device__ inline bool ldlt6_solve_d(const double Hin[36], const double
     for (int k = N - 1; k >= 0; --k) if (tr[k] != k) { double t = y[k]; y[k] = y[tr[k]]; y[tr[k]] = t; }
     for (int i = 0; i < N; ++i) x[i] = y[i];
     return !(x[0] != x[0]);
+}
+
+__host__ __device__ inline bool ldlt6_solve_d(const double Hin[36], const double b[6], double x[6])
+{
+    double m[36], y[6], temp[6]; int tr[6];
+    return ldlt6_solve_ws(Hin, b, x, m, y, temp, tr);
 }

@@ -3,7 +3,7 @@
 // (src/Algorithm/SparseImageAlign.cpp:21-238) and NLLSSolver::optimizeGaussNewton
 // (include/ygz/Algorithm/NLSSolver_impl.hpp:15-89).
 //
-// One workgroup (1024 lanes) per alignment problem; lane = feature (4x4 patch).  Per iteration:
+// One workgroup (512 lanes) per alignment problem; lane = feature (4x4 patch).  Per iteration:
 //   lanes warp their feature, gather the 5x5 current-image window, form 16 residuals, accumulate
 //   their own H (21 unique) / Jres (6) in FP64 registers, and publish res^2;
 //   H/Jres are reduced in a fixed tree order (wave shuffles, then 16 wave partials in order);
@@ -15,23 +15,23 @@
 #include "ygz_internal.h"
 #include "se3_dev.h"
 #include "ldlt6.h"
+#include <stdlib.h>
+#include <stdio.h>
 
-#define SA_THREADS 1024
+#define SA_THREADS 512
 #define SA_CHUNK   4096          // floats of res^2 staged in LDS per pass
 
 struct SaArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
-    int ref_slot, cur_slot;
-    Se3 T_ref, T_cur;
     float fx, fy, cx, cy;
-    const double *px, *depth; const uint8_t *has_mp;
-    int n, max_level, min_level, n_iter;
-    float *patch_cache;      // [n][16]
-    double *jac_cache;       // [n][16][6]
-    uint8_t *visible;        // [n]
-    float *r2;               // [n][16]
-    double *out;             // [7 pose][1 n_meas][YGZ_MAX_LEVELS iters]
+    int cells, max_level, min_level, n_iter;
+    const int32_t *pair_q, *pair_t, *trk_n;       // cur slot, ref slot, features per pair
+    const double *pair_T;                         // [pairs][2][7]; T_ref used here
+    const double *trk_px, *trk_depth; const uint8_t *trk_has_mp;     // [pairs][cells]
+    uint8_t *work; size_t work_stride;            // per pair: jac_cache | patch_cache | r2 | visible
+    double *out;                                  // [pairs][16]: pose 7 (in: initial cur->_TCW, out: result), n_meas, iters
+    double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
 };
 
 __device__ __forceinline__ double wave_sum_d(double v)
@@ -43,32 +43,58 @@ __device__ __forceinline__ double wave_sum_d(double v)
 
 __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
 {
-    __shared__ double red[16][28];
+    __shared__ double red[SA_THREADS / 64][28];
     __shared__ float stage[SA_CHUNK];
     __shared__ Se3 sT;
     __shared__ int s_ctl;                 // 0 continue, 1 leave level
-    __shared__ int s_nmeas_w[16];
+    __shared__ int s_nmeas_w[SA_THREADS / 64];
     __shared__ float s_chi2;
+    __shared__ double s_ldlt[36 + 6 + 6];       // lane-0 solver workspace (LDS instead of private scratch)
+    __shared__ int s_tr[6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = A.n;
+    const int pair = blockIdx.x;
+    const int n = A.trk_n[pair];
+    double *out = A.out + 16 * (size_t)pair;
+    if (n <= 0) {                                      // run() returns 0 and leaves the pose (:25-29)
+        if (tid == 0) { out[7] = 0; for (int l = 0; l < YGZ_MAX_LEVELS; ++l) out[8 + l] = 0; }
+        return;
+    }
+    const int ref_slot = A.pair_t[pair], cur_slot = A.pair_q[pair];
+    const double *px = A.trk_px + 2 * (size_t)pair * A.cells, *depth = A.trk_depth + (size_t)pair * A.cells;
+    const uint8_t *has_mp = A.trk_has_mp + (size_t)pair * A.cells;
+    uint8_t *wk = A.work + (size_t)pair * A.work_stride;
+    double *jac_cache = (double *)wk;                                   // [16*6][cells]  (entry-major: coalesced over features)
+    float *patch_cache = (float *)(jac_cache + 96 * (size_t)A.cells);   // [16][cells]
+    float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [cells][16]
+    uint8_t *visible = (uint8_t *)(r2 + 16 * (size_t)A.cells);          // [cells]
+    uint8_t *used = visible + A.cells;                                  // [cells] feature contributes this iteration
+    Se3 T_ref;
+    for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
+    for (int k = 0; k < 3; ++k) T_ref.t[k] = A.pair_T[14 * (size_t)pair + 4 + k];
     // thread-0 solver state (NLLSSolver::reset, NLSSolver_impl.hpp:283-293)
     double chi2_ = 1e10; bool stop_ = false;
     Se3 old_model;
     int n_meas_last = 0;
+    long long tph[6] = { 0, 0, 0, 0, 0, 0 }, tlast = clock64();
+#define SA_PHASE(k) do { if (tid == 0) { const long long tn_ = clock64(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 
     if (tid == 0) {
-        Se3 Tri; se3_inv_d(&A.T_ref, &Tri);
-        se3_mul_d(&A.T_cur, &Tri, &sT);                 // T_cur_from_ref (SparseImageAlign.cpp:37)
-        for (int l = 0; l < YGZ_MAX_LEVELS; ++l) A.out[8 + l] = 0;
+        Se3 T_cur, Tri;
+        for (int k = 0; k < 4; ++k) T_cur.q[k] = out[k];
+        for (int k = 0; k < 3; ++k) T_cur.t[k] = out[4 + k];
+        se3_inv_d(&T_ref, &Tri);
+        se3_mul_d(&T_cur, &Tri, &sT);                   // T_cur_from_ref (SparseImageAlign.cpp:37)
+        for (int l = 0; l < YGZ_MAX_LEVELS; ++l) out[8 + l] = 0;
     }
-    for (int f = tid; f < n; f += SA_THREADS) A.visible[f] = 0;
-    for (int i = tid; i < n * 16; i += SA_THREADS) A.patch_cache[i] = 0.f;
+    for (int f = tid; f < n; f += SA_THREADS) visible[f] = 0;
+    for (int f = tid; f < n; f += SA_THREADS)
+        for (int pc = 0; pc < 16; ++pc) patch_cache[(size_t)pc * A.cells + f] = 0.f;
     __syncthreads();
 
     for (int level = A.max_level; level >= A.min_level; --level) {
         const int cols = A.w[level], rows = A.h[level];
-        const uint8_t *ref_img = A.lvl[level] + (size_t)A.ref_slot * cols * rows;
-        const uint8_t *cur_img = A.lvl[level] + (size_t)A.cur_slot * cols * rows;
+        const uint8_t *ref_img = A.lvl[level] + (size_t)ref_slot * cols * rows;
+        const uint8_t *cur_img = A.lvl[level] + (size_t)cur_slot * cols * rows;
         const float scale = 1.0f / (float)(1 << level);
         const int border = 3;
         // jacobian_cache_.setZero(); have_ref_patch_cache_ = false (:42-43): each lane clears the
@@ -76,16 +102,15 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
         // precomputeReferencePatches (:59-122)
         const double focal = (double)((A.fx + A.fy) / 2);
         for (int f = tid; f < n; f += SA_THREADS) {
-            const double pxx = A.px[2 * f], pxy = A.px[2 * f + 1];
+            const double pxx = px[2 * f], pxy = px[2 * f + 1];
             const float u_ref = (float)(pxx * scale), v_ref = (float)(pxy * scale);
             const int ui = (int)floorf(u_ref), vi = (int)floorf(v_ref);
-            if (!A.has_mp[f] || ui - border < 0 || vi - border < 0 || ui + border >= cols || vi + border >= rows) {
-                double *jz = A.jac_cache + 96 * (size_t)f;
-                for (int k = 0; k < 96; ++k) jz[k] = 0.0;
+            if (!has_mp[f] || ui - border < 0 || vi - border < 0 || ui + border >= cols || vi + border >= rows) {
+                for (int k = 0; k < 96; ++k) jac_cache[(size_t)k * A.cells + f] = 0.0;
                 continue;
             }
-            A.visible[f] = 1;
-            const double dep = A.depth[f];
+            visible[f] = 1;
+            const double dep = depth[f];
             const double x = (pxx - A.cx) * dep / A.fx, y = (pxy - A.cy) * dep / A.fy;
             const double z_inv = 1. / dep, z_inv_2 = z_inv * z_inv;
             double fj[12];      // cvutils::JacobXYZ2Cam (CVUtils.h:77-99)
@@ -100,12 +125,11 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
                 const uint8_t *p = ref_img + (size_t)(vi + yy - 2) * cols + (ui - 2);
                 for (int xx = 0; xx < 4; ++xx, ++p, ++pc) {
 #define BIL(a, b, c, d) __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w_tl, (float)(a)), __fmul_rn(w_tr, (float)(b))), __fmul_rn(w_bl, (float)(c))), __fmul_rn(w_br, (float)(d)))
-                    A.patch_cache[16 * (size_t)f + pc] = BIL(p[0], p[1], p[cols], p[cols + 1]);
+                    patch_cache[(size_t)pc * A.cells + f] = BIL(p[0], p[1], p[cols], p[cols + 1]);
                     const float dx = __fmul_rn(0.5f, __fsub_rn(BIL(p[1], p[2], p[cols + 1], p[cols + 2]), BIL(p[-1], p[0], p[cols - 1], p[cols])));
                     const float dy = __fmul_rn(0.5f, __fsub_rn(BIL(p[cols], p[1 + cols], p[cols * 2], p[cols * 2 + 1]), BIL(p[-cols], p[1 - cols], p[0], p[1])));
-                    double *jc = A.jac_cache + 6 * ((size_t)f * 16 + pc);
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) jc[k] = ((double)dx * fj[k] + (double)dy * fj[6 + k]) * fl;
+                    for (int k = 0; k < 6; ++k) jac_cache[(size_t)(6 * pc + k) * A.cells + f] = ((double)dx * fj[k] + (double)dy * fj[6 + k]) * fl;
                 }
             }
         }
@@ -113,20 +137,18 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
         if (tid == 0) old_model = sT;
         int it = 0;
         for (; it < A.n_iter; ++it) {
-            // ---- computeResiduals(model, linearize=true) (:124-223)
+            SA_PHASE(0);      // precompute / loop overhead
+            // ---- computeResiduals(model, linearize=true) (:124-223), split in two passes:
+            // pass R (all lanes): warp + bilinear + residuals of the lane's features -> res[f][16] (0 when skipped)
             const Se3 T = sT;
-            double acc[27];
-#pragma unroll
-            for (int k = 0; k < 27; ++k) acc[k] = 0.0;
             int my_meas = 0;
             for (int f = tid; f < n; f += SA_THREADS) {
-                float r2v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) r2v[k] = 0.f;
-                bool use = A.visible[f] != 0;
                 float res[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) res[k] = 0.f;
+                bool use = visible[f] != 0;
                 if (use) {
-                    const double pxx = A.px[2 * f], pxy = A.px[2 * f + 1], dep = A.depth[f];
+                    const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
                     const double xyz_ref[3] = { (pxx - A.cx) * dep / A.fx, (pxy - A.cy) * dep / A.fy, dep };
                     double xyz_cur[3];
                     se3_act_d(&T, xyz_ref, xyz_cur);
@@ -139,31 +161,76 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
                         const float su = __fsub_rn(u_cur, (float)ui), sv = __fsub_rn(v_cur, (float)vi);
                         const float w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv)), w_tr = (float)((double)su * (1.0 - (double)sv));
                         const float w_bl = (float)((1.0 - (double)su) * (double)sv), w_br = __fmul_rn(su, sv);
-                        const float *cache = A.patch_cache + 16 * (size_t)f;
                         int pc = 0;
                         for (int yy = 0; yy < 4; ++yy) {
                             const uint8_t *p = cur_img + (size_t)(vi + yy - 2) * cols + (ui - 2);
 #pragma unroll
                             for (int xx = 0; xx < 4; ++xx, ++pc) {
                                 const float ic = BIL(p[xx], p[xx + 1], p[cols + xx], p[cols + xx + 1]);
-                                const float r = __fsub_rn(ic, cache[pc]);
-                                res[pc] = r;
-                                r2v[pc] = __fmul_rn(__fmul_rn(r, r), 1.0f);
+                                res[pc] = __fsub_rn(ic, patch_cache[(size_t)pc * A.cells + f]);
                             }
                         }
                     }
                 }
-                float4 *dst = reinterpret_cast<float4 *>(A.r2 + 16 * (size_t)f);
-                dst[0] = make_float4(r2v[0], r2v[1], r2v[2], r2v[3]);     dst[1] = make_float4(r2v[4], r2v[5], r2v[6], r2v[7]);
-                dst[2] = make_float4(r2v[8], r2v[9], r2v[10], r2v[11]);   dst[3] = make_float4(r2v[12], r2v[13], r2v[14], r2v[15]);
-                if (use) {
-                    my_meas += 16;
-                    const double *Jc = A.jac_cache + 96 * (size_t)f;
+                float4 *dst = reinterpret_cast<float4 *>(r2 + 16 * (size_t)f);        // r2 buffer holds the residuals
+                dst[0] = make_float4(res[0], res[1], res[2], res[3]);     dst[1] = make_float4(res[4], res[5], res[6], res[7]);
+                dst[2] = make_float4(res[8], res[9], res[10], res[11]);   dst[3] = make_float4(res[12], res[13], res[14], res[15]);
+                used[f] = use ? 1 : 0;
+                if (use) my_meas += 16;
+            }
+#undef BIL
+            {
+                int m = my_meas;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) m += __shfl_xor(m, off);
+                if (lane == 0) s_nmeas_w[wv] = m;
+            }
+            __syncthreads();
+            SA_PHASE(1);      // residual pass
+            if (wv == 0) {
+                // ---- wave 0: chi2 = the reference's FLOAT sum of res*res in feature/pixel order (a skipped feature
+                // contributes 0.0f + ... exactly).  The wave stages 4096 residuals at a time in LDS with coalesced
+                // 16-byte loads; lane 0 runs the dependent add chain (the squares are off the chain).
+                float c = 0.0f;
+                for (int c0 = 0; c0 < n * 16; c0 += SA_CHUNK) {
+                    const int cnt = min(SA_CHUNK, n * 16 - c0);
+                    for (int i = lane * 4; i < cnt; i += 256)
+                        *reinterpret_cast<float4 *>(&stage[i]) = *reinterpret_cast<const float4 *>(&r2[c0 + i]);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        int i = 0;
+                        for (; i + 64 <= cnt; i += 64) {
+                            float4 q[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) q[k] = *reinterpret_cast<const float4 *>(&stage[i + 4 * k]);
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].x, q[k].x), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].y, q[k].y), 1.0f));
+                                c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].z, q[k].z), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].w, q[k].w), 1.0f));
+                            }
+                        }
+                        for (; i < cnt; i += 4) {
+                            const float4 q4 = *reinterpret_cast<const float4 *>(&stage[i]);
+                            c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.x, q4.x), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.y, q4.y), 1.0f));
+                            c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.z, q4.z), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.w, q4.w), 1.0f));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (lane == 0) s_chi2 = c;
+            } else {
+                // ---- waves 1..: H (21 unique) / Jres (6) in FP64 registers, concurrently with the chain above
+                double acc[27];
+#pragma unroll
+                for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+                for (int f = tid - 64; f < n; f += SA_THREADS - 64) {
+                    if (!used[f]) continue;
+#pragma unroll 1
                     for (int pc = 0; pc < 16; ++pc) {
                         double J[6];
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) J[k] = Jc[6 * pc + k];
-                        const double r = (double)res[pc];
+                        for (int k = 0; k < 6; ++k) J[k] = jac_cache[(size_t)(6 * pc + k) * A.cells + f];
+                        const double r = (double)r2[16 * (size_t)f + pc];
                         int q = 0;
 #pragma unroll
                         for (int a = 0; a < 6; ++a) {
@@ -174,47 +241,24 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
                         for (int a = 0; a < 6; ++a) acc[21 + a] -= J[a] * r;
                     }
                 }
-            }
-#undef BIL
-            // ---- fixed-order reduction of H / Jres / n_meas
 #pragma unroll
-            for (int k = 0; k < 27; ++k) { const double s = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = s; }
-            {
-                int m = my_meas;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) m += __shfl_xor(m, off);
-                if (lane == 0) s_nmeas_w[wv] = m;
+                for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
             }
-            if (tid == 0) s_chi2 = 0.0f;
             __syncthreads();
-            // ---- chi2: float sum in feature/pixel order, staged through LDS
-            for (int c0 = 0; c0 < n * 16; c0 += SA_CHUNK) {
-                const int cnt = min(SA_CHUNK, n * 16 - c0);
-                for (int i = tid; i < cnt; i += SA_THREADS) stage[i] = A.r2[c0 + i];
-                __syncthreads();
-                if (tid == 0) {
-                    float c = s_chi2;
-                    for (int i = 0; i < cnt; i += 4) {
-                        const float4 q4 = *reinterpret_cast<const float4 *>(&stage[i]);
-                        c = __fadd_rn(c, q4.x); c = __fadd_rn(c, q4.y); c = __fadd_rn(c, q4.z); c = __fadd_rn(c, q4.w);
-                    }
-                    s_chi2 = c;
-                }
-                __syncthreads();
-            }
+            SA_PHASE(3);      // chain || accumulation
             // ---- lane 0: solve, decide, update (NLSSolver_impl.hpp:40-87)
             if (tid == 0) {
                 double Hm[36], Jr[6], x[6];
                 int q = 0;
                 for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) {
-                    double s = 0; for (int w2 = 0; w2 < 16; ++w2) s += red[w2][q];
+                    double s = 0; for (int w2 = 1; w2 < SA_THREADS / 64; ++w2) s += red[w2][q];
                     Hm[6 * a + b] = s; Hm[6 * b + a] = s; ++q;
                 }
-                for (int a = 0; a < 6; ++a) { double s = 0; for (int w2 = 0; w2 < 16; ++w2) s += red[w2][21 + a]; Jr[a] = s; }
-                int nm = 0; for (int w2 = 0; w2 < 16; ++w2) nm += s_nmeas_w[w2];
+                for (int a = 0; a < 6; ++a) { double s = 0; for (int w2 = 1; w2 < SA_THREADS / 64; ++w2) s += red[w2][21 + a]; Jr[a] = s; }
+                int nm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) nm += s_nmeas_w[w2];
                 n_meas_last = nm;
                 const double new_chi2 = (double)__fdiv_rn(s_chi2, (float)nm);
-                if (!ldlt6_solve_d(Hm, Jr, x)) stop_ = true;
+                if (!ldlt6_solve_ws(Hm, Jr, x, s_ldlt, s_ldlt + 36, s_ldlt + 42, s_tr)) stop_ = true;
                 int ctl = 0;
                 if ((it > 0 && new_chi2 > chi2_) || stop_) { sT = old_model; ctl = 1; }
                 else {
@@ -231,22 +275,45 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
             }
             __syncthreads();
             const int ctl = s_ctl;
+            SA_PHASE(4);      // solve + update
             __syncthreads();
             if (ctl == 2) { ++it; break; }
             if (ctl == 1) break;
         }
-        if (tid == 0 && level < YGZ_MAX_LEVELS) A.out[8 + level] = (double)it;
+        if (tid == 0 && level < YGZ_MAX_LEVELS) out[8 + level] = (double)it;
     }
     if (tid == 0) {
-        Se3 o; se3_mul_d(&sT, &A.T_ref, &o);                 // cur->_TCW = T_cur_from_ref * ref->_TCW (:48)
-        for (int k = 0; k < 4; ++k) A.out[k] = o.q[k];
-        for (int k = 0; k < 3; ++k) A.out[4 + k] = o.t[k];
-        A.out[7] = (double)n_meas_last;
+        Se3 o; se3_mul_d(&sT, &T_ref, &o);                 // cur->_TCW = T_cur_from_ref * ref->_TCW (:48)
+        for (int k = 0; k < 4; ++k) out[k] = o.q[k];
+        for (int k = 0; k < 3; ++k) out[4 + k] = o.t[k];
+        out[7] = (double)n_meas_last;
+        if (A.dbg) for (int k = 0; k < 6; ++k) A.dbg[8 * (size_t)pair + k] = (double)tph[k];
     }
 }
 
-static void se3_from7(const double *a, Se3 *T) { for (int k = 0; k < 4; ++k) T->q[k] = a[k]; for (int k = 0; k < 3; ++k) T->t[k] = a[4 + k]; }
+int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int min_level, int n_iter)
+{
+    SaArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
+    A.fx = ctx->prm.fx; A.fy = ctx->prm.fy; A.cx = ctx->prm.cx; A.cy = ctx->prm.cy;
+    A.cells = ctx->cells; A.max_level = max_level; A.min_level = min_level; A.n_iter = n_iter;
+    A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
+    A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
+    A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
+    A.dbg = nullptr;
+    if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 64, &d) == YGZ_OK) A.dbg = (double *)d; }
+    YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align, dim3(n_pairs), dim3(SA_THREADS), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    if (A.dbg) {
+        double h[8];
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[sa-debug] pair0 cycles (100MHz ticks): overhead %.0f residual %.0f reduce %.0f chain %.0f solve %.0f\n", h[0], h[1], h[2], h[3], h[4]);
+    }
+    return YGZ_OK;
+}
 
+// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
 extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double T_ref[7], int cur_slot, double T_cur[7],
                                     const double *px, const double *depth, const uint8_t *has_mappoint, int n,
                                     int max_level, int min_level, int n_iter, int *n_meas_out, int *iters_out)
@@ -257,29 +324,20 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     if (n_meas_out) *n_meas_out = 0;
     if (n == 0) return YGZ_OK;                                // run() returns 0 without touching the pose (:25-29)
     if (!px || !depth || !has_mappoint) return YGZ_E_INVALID;
+    if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[ref_slot] || !ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
-    const size_t N = (size_t)n;
-    uint8_t *in = nullptr, *work = nullptr; double *out = nullptr;
-    int rc = ygz_scratch(ctx, SCR_SA_IN, N * (16 + 8 + 1) + 64, (void **)&in);
-    if (rc == YGZ_OK) rc = ygz_scratch(ctx, SCR_SA_WORK, N * (64 + 768 + 64 + 1) + 256, (void **)&work);
-    if (rc == YGZ_OK) rc = ygz_scratch(ctx, SCR_SA_OUT, (8 + YGZ_MAX_LEVELS) * 8, (void **)&out);
+    int rc = ygz_track_set_pairs(ctx, &cur_slot, &ref_slot, T_cur, T_ref, 1);
     if (rc != YGZ_OK) return rc;
-    double *d_px = (double *)in, *d_dep = d_px + 2 * N; uint8_t *d_mp = (uint8_t *)(d_dep + N);
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_px, px, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_dep, depth, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_mp, has_mappoint, N, hipMemcpyHostToDevice, ctx->stream));
-    SaArgs A;
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
-    A.ref_slot = ref_slot; A.cur_slot = cur_slot;
-    se3_from7(T_ref, &A.T_ref); se3_from7(T_cur, &A.T_cur);
-    A.fx = ctx->prm.fx; A.fy = ctx->prm.fy; A.cx = ctx->prm.cx; A.cy = ctx->prm.cy;
-    A.px = d_px; A.depth = d_dep; A.has_mp = d_mp; A.n = n; A.max_level = max_level; A.min_level = min_level; A.n_iter = n_iter;
-    A.jac_cache = (double *)work; A.patch_cache = (float *)(A.jac_cache + 96 * N); A.r2 = A.patch_cache + 16 * N;
-    A.visible = (uint8_t *)(A.r2 + 16 * N); A.out = out;
-    hipLaunchKernelGGL(k_sparse_align, dim3(1), dim3(SA_THREADS), 0, ctx->stream, A);
-    YGZ_HIPCHK(ctx, hipGetLastError());
-    double h_out[8 + YGZ_MAX_LEVELS];
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, out, sizeof(h_out), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t N = (size_t)n;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, depth, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_has_mp, has_mappoint, N, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->sa_out, T_cur, 7 * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = ygz_launch_sparse_align(ctx, 1, max_level, min_level, n_iter)) != YGZ_OK) return rc;
+    double h_out[16];
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, sizeof(h_out), hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 7; ++k) T_cur[k] = h_out[k];
     if (n_meas_out) *n_meas_out = (int)(h_out[7] / 16);        // run() returns n_meas_/patch_area_ (:49)

@@ -1,0 +1,208 @@
+// Resident, batched tracking state: the per-frame path of VisualOdometry::AddFrame / LocalMapping::TrackLocalMap
+// (src/Module/VisualOdometry.cpp:38-107, src/Module/LocalMapping.cpp:24-120) run for MANY frame pairs per launch
+// with no host round trip between the stages.  A "track set" per pair holds the reference features
+// (pixel, level, depth, has-map-point); it is filled on the device from the keypoints the extractor left in HBM
+// (k_track_load) or from host arrays by the single-pair entry points of the ABI.
+#include "ygz_internal.h"
+#include "se3_dev.h"
+
+int ygz_track_ensure(ygz_hip_ctx *ctx)
+{
+    if (ctx->trk_alloc) return YGZ_OK;
+    const size_t F = (size_t)ctx->prm.max_frames, Cn = (size_t)ctx->cells;
+    hipError_t e = hipSuccess;
+#define A_(ptr, bytes) if (e == hipSuccess) e = hipMalloc((void **)&(ptr), (bytes))
+    A_(ctx->trk_n, F * 4); A_(ctx->trk_px, F * Cn * 16); A_(ctx->trk_level, F * Cn * 4); A_(ctx->trk_depth, F * Cn * 8);
+    A_(ctx->trk_has_mp, F * Cn); A_(ctx->pair_T, F * 14 * 8); A_(ctx->kp_depth, F * Cn * 8); A_(ctx->kp_has_mp, F * Cn);
+    A_(ctx->klt_pts, F * Cn * 8); A_(ctx->klt_err, F * Cn * 4); A_(ctx->klt_status, F * Cn);
+    A_(ctx->fdp_px, F * Cn * 16); A_(ctx->fdp_level, F * Cn * 4); A_(ctx->fdp_ok, F * Cn); A_(ctx->sa_out, F * 16 * 8);
+    // sparse-align work per pair: jac_cache 768 B + patch_cache 64 B + r2 64 B + visible 1 B per feature
+    ctx->sa_work_stride = ((Cn * (768 + 64 + 64 + 2) + 255) / 256) * 256;
+    A_(ctx->sa_work, F * ctx->sa_work_stride);
+#undef A_
+    if (e != hipSuccess) { ctx->last_hip_error = (int)e; return YGZ_E_HIP; }
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->trk_n, 0, F * 4, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->kp_depth, 0, F * Cn * 8, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->kp_has_mp, 0, F * Cn, ctx->stream));
+    ctx->trk_alloc = true;
+    return YGZ_OK;
+}
+
+int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
+                        const double *T_ref, int n_pairs)
+{
+    if (n_pairs < 1 || n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;
+    for (int i = 0; i < n_pairs; ++i)
+        if (cur_slot[i] < 0 || cur_slot[i] >= ctx->prm.max_frames || ref_slot[i] < 0 || ref_slot[i] >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    int rc = ygz_track_ensure(ctx);
+    if (rc != YGZ_OK) return rc;
+    std::vector<double> T((size_t)n_pairs * 14);
+    for (int i = 0; i < n_pairs; ++i)
+        for (int k = 0; k < 7; ++k) { T[14 * i + k] = T_ref[7 * i + k]; T[14 * i + 7 + k] = T_cur[7 * i + k]; }
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, cur_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, ref_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_T, T.data(), T.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_pairs = n_pairs;
+    return YGZ_OK;
+}
+
+struct LoadArgs {
+    const int32_t *pair_t, *n_kp; int cells;
+    const double *kp_px; const int32_t *kp_level; const double *kp_depth; const uint8_t *kp_has_mp;
+    const double *pair_T;
+    int32_t *trk_n; double *trk_px; int32_t *trk_level; double *trk_depth; uint8_t *trk_has_mp;
+    float *klt_pts; double *fdp_px; double *sa_out;
+    float fx, fy, cx, cy; int predict;
+};
+
+__global__ __launch_bounds__(256) void k_track_load(LoadArgs A)
+{
+    const int p = blockIdx.y, ref = A.pair_t[p];
+    const int n = A.n_kp[ref];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        A.trk_n[p] = n;
+        for (int k = 0; k < 7; ++k) A.sa_out[16 * (size_t)p + k] = A.pair_T[14 * (size_t)p + k];   // current->_TCW = ref->_TCW (Matcher.cpp:471)
+    }
+    if (i >= n) return;
+    const size_t s = (size_t)ref * A.cells + i, d = (size_t)p * A.cells + i;
+    const double x = A.kp_px[2 * s], y = A.kp_px[2 * s + 1], dep = A.kp_depth[s];
+    A.trk_px[2 * d] = x; A.trk_px[2 * d + 1] = y;
+    A.trk_level[d] = A.kp_level[s]; A.trk_depth[d] = dep; A.trk_has_mp[d] = A.kp_has_mp[s];
+    A.klt_pts[2 * d] = (float)x; A.klt_pts[2 * d + 1] = (float)y;            // Tracker::SetReference (Tracker.cpp:27-31)
+    double ox = x, oy = y;
+    if (A.predict && dep > 0) {
+        // candidate projection with the current pose estimate (LocalMapping::FindCandidates, LocalMapping.cpp:47-80)
+        Se3 Tr, Tc, Tri, TCR;
+        for (int k = 0; k < 4; ++k) { Tr.q[k] = A.pair_T[14 * (size_t)p + k]; Tc.q[k] = A.pair_T[14 * (size_t)p + 7 + k]; }
+        for (int k = 0; k < 3; ++k) { Tr.t[k] = A.pair_T[14 * (size_t)p + 4 + k]; Tc.t[k] = A.pair_T[14 * (size_t)p + 11 + k]; }
+        se3_inv_d(&Tr, &Tri); se3_mul_d(&Tc, &Tri, &TCR);
+        const double pr[3] = { (x - A.cx) * dep / A.fx, (y - A.cy) * dep / A.fy, dep };
+        double pc[3];
+        se3_act_d(&TCR, pr, pc);
+        ox = A.fx * pc[0] / pc[2] + A.cx; oy = A.fy * pc[1] / pc[2] + A.cy;
+    }
+    A.fdp_px[2 * d] = ox; A.fdp_px[2 * d + 1] = oy;
+}
+
+static int launch_load(ygz_hip_ctx *ctx, int predict)
+{
+    LoadArgs A;
+    A.pair_t = ctx->pair_t; A.n_kp = ctx->n_kp; A.cells = ctx->cells;
+    A.kp_px = ctx->kp_px; A.kp_level = ctx->kp_level; A.kp_depth = ctx->kp_depth; A.kp_has_mp = ctx->kp_has_mp;
+    A.pair_T = ctx->pair_T;
+    A.trk_n = ctx->trk_n; A.trk_px = ctx->trk_px; A.trk_level = ctx->trk_level; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
+    A.klt_pts = ctx->klt_pts; A.fdp_px = ctx->fdp_px; A.sa_out = ctx->sa_out;
+    A.fx = ctx->prm.fx; A.fy = ctx->prm.fy; A.cx = ctx->prm.cx; A.cy = ctx->prm.cy; A.predict = predict;
+    YGZ_LAUNCH(ctx, KID_TRACK_LOAD, k_track_load, dim3(ygz_div_up(ctx->cells, 256), ctx->n_pairs), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+extern "C" {
+
+int ygz_hip_set_keypoint_depths(ygz_hip_ctx *ctx, int slot, const double *depth, const uint8_t *has_mappoint, int n)
+{
+    if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || n < 0 || n > ctx->cells || (n > 0 && (!depth || !has_mappoint))) return YGZ_E_INVALID;
+    int rc = ygz_track_ensure(ctx);
+    if (rc != YGZ_OK) return rc;
+    if (n > 0) {
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_depth + (size_t)slot * ctx->cells, depth, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_has_mp + (size_t)slot * ctx->cells, has_mappoint, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return YGZ_OK;
+}
+
+int ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
+                        const double *T_ref, int n_pairs, int predict)
+{
+    if (!ctx || !cur_slot || !ref_slot || !T_cur || !T_ref) return YGZ_E_INVALID;
+    int rc = ygz_track_set_pairs(ctx, cur_slot, ref_slot, T_cur, T_ref, n_pairs);
+    if (rc != YGZ_OK) return rc;
+    return launch_load(ctx, predict);
+}
+
+int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
+{
+    if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    return launch_load(ctx, predict);
+}
+
+int ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm)
+{
+    if (!ctx || !prm) return YGZ_E_INVALID;
+    if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    return ygz_launch_klt(ctx, ctx->n_pairs, prm);
+}
+
+int ygz_hip_track_direct(ygz_hip_ctx *ctx)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    return ygz_launch_fdp(ctx, ctx->n_pairs);
+}
+
+int ygz_hip_track_sparse_align(ygz_hip_ctx *ctx, int max_level, int min_level, int n_iter)
+{
+    if (!ctx || min_level < 0 || max_level < min_level || max_level >= ctx->prm.pyramid_levels || n_iter < 0) return YGZ_E_INVALID;
+    if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    return ygz_launch_sparse_align(ctx, ctx->n_pairs, max_level, min_level, n_iter);
+}
+
+static int pair_count(ygz_hip_ctx *ctx, int pair, int *n)
+{
+    if (pair < 0 || pair >= ctx->n_pairs || !ctx->trk_alloc) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(n, ctx->trk_n + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_track_get_klt(ygz_hip_ctx *ctx, int pair, float *pts, uint8_t *status, float *err, int capacity, int *n_out)
+{
+    if (!ctx || !n_out) return YGZ_E_INVALID;
+    int n = 0, rc = pair_count(ctx, pair, &n);
+    if (rc != YGZ_OK) return rc;
+    *n_out = n;
+    if (n > capacity) return YGZ_E_CAPACITY;
+    const size_t o = (size_t)pair * ctx->cells;
+    if (n > 0) {
+        if (pts) YGZ_HIPCHK(ctx, hipMemcpyAsync(pts, ctx->klt_pts + 2 * o, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (status) YGZ_HIPCHK(ctx, hipMemcpyAsync(status, ctx->klt_status + o, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        if (err) YGZ_HIPCHK(ctx, hipMemcpyAsync(err, ctx->klt_err + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return YGZ_OK;
+}
+
+int ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *level, uint8_t *ok, int capacity, int *n_out)
+{
+    if (!ctx || !n_out) return YGZ_E_INVALID;
+    int n = 0, rc = pair_count(ctx, pair, &n);
+    if (rc != YGZ_OK) return rc;
+    *n_out = n;
+    if (n > capacity) return YGZ_E_CAPACITY;
+    const size_t o = (size_t)pair * ctx->cells;
+    if (n > 0) {
+        if (px) YGZ_HIPCHK(ctx, hipMemcpyAsync(px, ctx->fdp_px + 2 * o, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (level) YGZ_HIPCHK(ctx, hipMemcpyAsync(level, ctx->fdp_level + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ok) YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, ctx->fdp_ok + o, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return YGZ_OK;
+}
+
+int ygz_hip_track_get_pose(ygz_hip_ctx *ctx, int pair, double T[7], int *n_meas, int *iters)
+{
+    if (!ctx || pair < 0 || pair >= ctx->n_pairs || !ctx->trk_alloc) return YGZ_E_INVALID;
+    double h[16];
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(h, ctx->sa_out + 16 * (size_t)pair, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (T) for (int k = 0; k < 7; ++k) T[k] = h[k];
+    if (n_meas) *n_meas = (int)(h[7] / 16);                  // run() returns n_meas_/patch_area_ (SparseImageAlign.cpp:49)
+    if (iters) for (int l = 0; l < ctx->prm.pyramid_levels && l < 8; ++l) iters[l] = (int)h[8 + l];
+    return YGZ_OK;
+}
+
+}  // extern "C"

@@ -47,6 +47,32 @@ struct ygz_hip_ctx {
     int32_t *m_idx = nullptr, *m_dist = nullptr, *m_dist2 = nullptr;   // [F][cells] final per query
     int n_pairs = 0;
 
+    // resident tracking state: one "track set" per pair (capacity max_frames pairs), filled either from the
+    // keypoints of the pair's reference slot (device-to-device) or from host arrays (single-pair APIs)
+    bool trk_alloc = false;
+    int32_t *trk_n = nullptr;                // [F]
+    double  *trk_px = nullptr;               // [F][cells][2]  reference pixels (level 0)
+    int32_t *trk_level = nullptr;            // [F][cells]
+    double  *trk_depth = nullptr;            // [F][cells]
+    uint8_t *trk_has_mp = nullptr;           // [F][cells]
+    double  *pair_T = nullptr;               // [F][2][7]  (T_ref, T_cur) of each pair
+    double  *kp_depth = nullptr;             // [F][cells] per-slot keypoint depth (Feature::_depth)
+    uint8_t *kp_has_mp = nullptr;            // [F][cells] Feature::_mappoint != nullptr
+    float   *klt_pts = nullptr;              // [F][cells][2] in/out
+    float   *klt_err = nullptr;              // [F][cells]
+    uint8_t *klt_status = nullptr;           // [F][cells]
+    double  *fdp_px = nullptr;               // [F][cells][2] in/out
+    int32_t *fdp_level = nullptr;            // [F][cells]
+    uint8_t *fdp_ok = nullptr;               // [F][cells]
+    double  *sa_out = nullptr;               // [F][16]: pose 7, n_meas, iters per level
+    uint8_t *sa_work = nullptr;              // [F][sa_work_stride]
+    size_t   sa_work_stride = 0;
+    int      deriv_slots = 0;                // slots covered by the Scharr buffers
+
+    // per-kernel HIP-event probe (bench.py roofline leg): events around every launch of ONE chosen kernel
+    int probe_id = -1, probe_used = 0;
+    std::vector<hipEvent_t> probe_ev;
+
     // growable scratch buffers
     void  *scratch[YGZ_N_SCRATCH] = {nullptr};
     size_t scratch_bytes[YGZ_N_SCRATCH] = {0};
@@ -54,6 +80,9 @@ struct ygz_hip_ctx {
     // resident BA windows
     struct BaWindow;
     std::vector<BaWindow*> ba;
+    void *ba_table = nullptr;                // device array of per-window descriptors
+    bool  ba_table_dirty = true;
+    int   ba_max_K = 0, ba_max_P = 0;
 };
 
 #define YGZ_HIPCHK(ctx, call)                                            \
@@ -61,6 +90,17 @@ struct ygz_hip_ctx {
          if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return YGZ_E_HIP; } } while (0)
 
 static inline int ygz_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// kernel ids for the probe
+enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIBE, KID_HAMMING_NN, KID_MATCH_FINALIZE,
+       KID_TRACK_LOAD, KID_FDP, KID_ALIGN2D, KID_SPARSE_ALIGN, KID_SCHARR, KID_KLT, KID_BA_POSE_PREP, KID_BA_POINTS,
+       KID_BA_POSES, KID_BA_CHI2, KID_COUNT };
+
+#define YGZ_LAUNCH(ctx, kid, kern, grid, block, ...)                                                         \
+    do { const bool pr_ = (ctx)->probe_id == (kid) && (ctx)->probe_used + 2 <= (int)(ctx)->probe_ev.size();    \
+         if (pr_) (void)hipEventRecord((ctx)->probe_ev[(ctx)->probe_used], (ctx)->stream);                     \
+         hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);                                 \
+         if (pr_) { (void)hipEventRecord((ctx)->probe_ev[(ctx)->probe_used + 1], (ctx)->stream); (ctx)->probe_used += 2; } } while (0)
 
 // scratch ids
 enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR_SA_OUT, SCR_SA_WORK,
@@ -73,6 +113,12 @@ int ygz_ensure_levels(ygz_hip_ctx *ctx, int n_levels);      // allocates image l
 int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr, int up_to_level);
 int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
 int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
+int ygz_track_ensure(ygz_hip_ctx *ctx);                      // allocates the resident tracking state
+int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
+                        const double *T_ref, int n_pairs);
+int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm);
+int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs);
+int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int min_level, int n_iter);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
