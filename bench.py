@@ -42,11 +42,11 @@ def build_inputs(batch, rank):
 class Pipeline:
     """Drives the C ABI for one GPU.  Everything it needs is uploaded in setup()."""
 
-    def __init__(self, batch, device, rank):
+    def __init__(self, batch, device, rank, stream=None):
         from ygz_slam_amd import _lib
         self.lib = _lib
         self.B = batch
-        self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device)
+        self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device, stream=stream)
         self.frames, self.poses, self.depths, self.ba = build_inputs(batch, rank)
 
     def setup(self):
@@ -156,8 +156,12 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    pipe = Pipeline(a.batch, local_rank, rank)
+    # one HIP stream shared by torch (RCCL broadcast) and the ABI context, so the exchange is ordered with the kernels
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    pipe = Pipeline(a.batch, local_rank, rank, stream=stream.cuda_stream)
     pipe.setup()
+    n_pts = pipe.ba["points"].size
     map_buf = torch.from_numpy(np.concatenate([pipe.ba["points"].ravel(), pipe.ba["poses"].ravel()])).cuda()
 
     def barrier():
@@ -167,8 +171,9 @@ def main():
         pipe.ctx.synchronize()
 
     def one_step():
-        if dist is not None:                 # the path's only exchange: map points + keyframe poses of the BA window
-            dist.broadcast(map_buf, src=0)
+        if dist is not None:                 # the path's only exchange: map points + keyframe poses of the shared BA window
+            dist.broadcast(map_buf, src=0)   # RCCL over xGMI, ~50 KB, once per BA round
+            pipe.ctx.ba_set_state_device(0, map_buf.data_ptr() + 8 * n_pts, map_buf.data_ptr())
         pipe.step()
 
     for _ in range(a.warmup):

@@ -1,0 +1,44 @@
+// ygz::Matcher -- same surface as include/ygz/Algorithm/Matcher.h:15-152.  Brute-force matching is offered as
+// BruteForceMatch (what test/test_orb_match.cpp:86-93 does with cv::BFMatcher); the BoW-guided searches need the
+// DBoW3 vocabulary that the reference does not ship (.MISSING_LARGE_BLOBS) and are outside the hot-path scope.
+#ifndef YGZ_MATCHER_H_
+#define YGZ_MATCHER_H_
+#include "ygz/Basic/Common.h"
+namespace ygz {
+struct Frame;
+struct MapPoint;
+struct Feature;
+class SparseImgAlign;
+struct DMatch { int queryIdx = -1, trainIdx = -1; float distance = 0; };
+class Matcher {
+public:
+    struct Options {
+        int th_high = 100, th_low = 50;
+        float knnRatio = 0.9f;
+        bool checkOrientation = false;
+        float initMatchRatio = 3.0f;
+        int init_low = 30, init_high = 80;
+        double _max_alignment_motion = 0.2;
+        double _epipolar_dsqr = 1e-4;
+    } _options;
+    static const int HISTO_LENGTH = 30;
+    Matcher();
+    ~Matcher();
+    void SetTCR(const SE3 &TCR) { _TCR_esti = TCR; }
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);                      // Matcher.cpp:30-43
+    int CheckFrameDescriptors(Frame *frame1, Frame *frame2, list<pair<int, int>> &matches);  // Matcher.cpp:45-84
+    // cv::BFMatcher(NORM_HAMMING, crossCheck).match(frame1 descriptors, frame2 descriptors) on the GPU
+    int BruteForceMatch(Frame *frame1, Frame *frame2, vector<DMatch> &matches, bool cross_check = true);
+    bool FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector2d &px_curr, int &search_level);   // Matcher.cpp:356-383
+    bool FindDirectProjection(Frame *ref, Frame *curr, Feature *fea_ref, Vector2d &px_curr, int &search_level); // Matcher.cpp:385-417
+    // the same for many features of `ref` in one launch (what LocalMapping::ProjectMapPoints loops over)
+    int FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Feature *> &fea_ref, vector<Vector2d> &px_curr,
+                                  vector<int> &search_level, vector<bool> &ok);
+    bool SparseImageAlignment(Frame *ref, Frame *current);                                  // Matcher.cpp:468-492
+    SE3 GetTCR() const { return _TCR_esti; }
+private:
+    SparseImgAlign *_align;
+    SE3 _TCR_esti;
+};
+}
+#endif

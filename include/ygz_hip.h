@@ -94,6 +94,8 @@ int  ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int cap
 /* FeatureDetector::ComputeAngleAndDescriptor(Frame*) (:580-588): replaces the keypoint list of
  * `slot` by the given pixels/levels and (re)computes angle + descriptor for them */
 int  ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px /*[n][2]*/, const int32_t *level, int n);
+/* FeatureDetector::ComputeDescriptor(Feature*) (:591-594): descriptor only, with the given angles (degrees) */
+int  ygz_hip_describe_given_angle(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, const float *angle, int n);
 /* parity/debug (needs debug_maps): per-pixel maps of one level after ygz_hip_detect:
  * score[y*w+x] = 0 (no FAST-10 corner at the threshold) or fast_corner_score_10 + 1;
  * nms[y*w+x]   = 1 iff the corner survives fast_nonmax_3x3 */
@@ -200,9 +202,21 @@ int  ygz_hip_ba_linearize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *Hp
 /* resident form: upload structure once, then re-linearise for new states without host copies */
 int  ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb);
 int  ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, const double *points);
+/* same, state already in HBM (device pointers, e.g. the buffer an RCCL broadcast filled); asynchronous */
+int  ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_poses, const double *d_points);
 int  ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows);
 int  ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, double *Hll, double *bl,
                          double *Hpl, double *err, double *chi2_edge, double *chi2);
+
+/* ---- B4: the LM loop of ba::LocalBAG2O (src/Algorithm/BA.cpp:390-395,501-502: g2o OptimizationAlgorithmLevenberg +
+ *      BlockSolver_6_3 with marginalised points).  Linearisations run on the GPU, the reduced pose system on the host.
+ *      poses_io [n_poses][6] / points_io [n_points][3] are updated in place (pb->poses / pb->points are ignored). */
+typedef struct {
+    int    iterations, lm_trials;
+    double chi2_initial, chi2_final, lambda_final;
+} ygz_ba_stats;
+int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
+                         int max_iterations, ygz_ba_stats *stats);
 
 #ifdef __cplusplus
 }

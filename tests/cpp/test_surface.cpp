@@ -1,0 +1,121 @@
+// Exercises the ygz:: class surfaces the way the reference's test programs do (test/test_feature_extraction.cpp,
+// test_orb_match.cpp, test_LK_tracking.cpp, test_feature_alignment.cpp, test_feature_projection.cpp,
+// test_local_ba.cpp), on inputs written by tests/test_gpu_surface.py, and dumps every result as text so the Python
+// side can compare it with the oracle.  Usage: test_surface <in_dir> <out_file>
+#include "ygz/Basic.h"
+#include "ygz/Algorithm.h"
+#include <fstream>
+#include <cstdio>
+using namespace ygz;
+
+static std::vector<uint8_t> slurp(const std::string &p) { std::ifstream f(p, std::ios::binary); return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()); }
+static std::vector<double> slurp_f64(const std::string &p) { auto b = slurp(p); std::vector<double> v(b.size() / 8); memcpy(v.data(), b.data(), v.size() * 8); return v; }
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: %s in_dir out_file\n", argv[0]); return 2; }
+    const std::string in = argv[1];
+    FILE *out = fopen(argv[2], "w");
+    Config::SetParameterFile(in + "/default.yaml");
+    PinholeCamera *cam = new PinholeCamera();
+    Frame::SetCamera(cam);
+    const int W = Config::Get<int>("image.width"), H = Config::Get<int>("image.height");
+    auto poses = slurp_f64(in + "/poses.f64");           // [2][7]
+    auto depth0 = slurp_f64(in + "/depth0.f64");         // [H][W]
+    Frame f[2];
+    std::vector<uint8_t> raw[2] = { slurp(in + "/frame0.bgr"), slurp(in + "/frame1.bgr") };
+    for (int i = 0; i < 2; ++i) {
+        f[i]._color = cv::Mat(H, W, CV_8UC3, raw[i].data());
+        f[i].InitFrame();
+        f[i]._TCW = SE3::from7(&poses[7 * i]);
+        fprintf(out, "pyr %d %zu %d %d %d\n", i, f[i]._pyramid.size(), f[i]._pyramid[2].cols, f[i]._pyramid[2].rows, (int)f[i]._pyramid[2].at<uchar>(5, 7));
+    }
+    // --- test_feature_extraction / test_orb_match
+    FeatureDetector detector;
+    detector.LoadParams();
+    for (int i = 0; i < 2; ++i) {
+        detector.Detect(&f[i]);
+        fprintf(out, "kp %d %zu\n", i, f[i]._features.size());
+        for (Feature *fe : f[i]._features) {
+            fprintf(out, "%.17g %.17g %d %.9g %.9g", fe->_pixel[0], fe->_pixel[1], fe->_level, fe->_score, fe->_angle);
+            for (int k = 0; k < 32; ++k) fprintf(out, " %d", (int)fe->_desc.data[k]);
+            fprintf(out, "\n");
+        }
+    }
+    Matcher matcher;
+    std::vector<DMatch> matches;
+    matcher.BruteForceMatch(&f[0], &f[1], matches, true);
+    fprintf(out, "matches %zu\n", matches.size());
+    for (auto &m : matches) fprintf(out, "%d %d %d\n", m.queryIdx, m.trainIdx, (int)m.distance);
+    fprintf(out, "ddist %d\n", Matcher::DescriptorDistance(f[0]._features[0]->_desc, f[1]._features[0]->_desc));
+    // Detect(frame, false) keeps the old features and fills only free cells
+    {
+        const size_t before = f[1]._features.size();
+        for (size_t k = 0; k < before; k += 2) { delete f[1]._features[k]; f[1]._features[k] = nullptr; }
+        f[1]._features.erase(std::remove(f[1]._features.begin(), f[1]._features.end(), (Feature *)nullptr), f[1]._features.end());
+        const size_t kept = f[1]._features.size();
+        detector.Detect(&f[1], false);
+        fprintf(out, "redetect %zu %zu %zu\n", before, kept, f[1]._features.size());
+    }
+    // --- test_LK_tracking
+    Tracker tracker;
+    tracker.SetReference(&f[0]);
+    tracker.Track(&f[1]);
+    std::vector<Feature *> tf; std::vector<Vector2d> tp;
+    tracker.GetTrackedPixel(tf, tp);
+    fprintf(out, "klt %zu %d %.9g\n", tp.size(), (int)tracker.Status(), tracker.MeanDisparity());
+    for (size_t i = 0; i < tp.size(); ++i) fprintf(out, "%.17g %.17g %.9g %.9g\n", tf[i]->_pixel[0], tf[i]->_pixel[1], tp[i][0], tp[i][1]);
+    // --- depth + map points for the direct methods
+    std::vector<MapPoint *> mps;
+    for (size_t i = 0; i < f[0]._features.size(); ++i) {
+        Feature *fe = f[0]._features[i];
+        fe->_depth = depth0[(size_t)fe->_pixel[1] * W + (size_t)fe->_pixel[0]];
+        if (i % 9 != 0) { MapPoint *mp = new MapPoint; mp->_pos_world = cam->Pixel2World(fe->_pixel, f[0]._TCW, fe->_depth); fe->_mappoint = mp; mps.push_back(mp); }
+    }
+    // --- test_feature_projection: FindDirectProjection per feature (single calls) and batched
+    std::vector<Vector2d> px(f[0]._features.size()); std::vector<int> sl; std::vector<bool> ok;
+    for (size_t i = 0; i < px.size(); ++i) px[i] = f[0]._features[i]->_pixel + Vector2d(1.5, -1.0);
+    matcher.FindDirectProjectionBatch(&f[0], &f[1], f[0]._features, px, sl, ok);
+    fprintf(out, "fdp %zu\n", px.size());
+    for (size_t i = 0; i < px.size(); ++i) fprintf(out, "%d %d %.17g %.17g\n", (int)ok[i], sl[i], px[i][0], px[i][1]);
+    { Vector2d p1 = f[0]._features[3]->_pixel + Vector2d(1.5, -1.0); int l1 = 0;
+      bool o1 = matcher.FindDirectProjection(&f[0], &f[1], f[0]._features[3], p1, l1);
+      fprintf(out, "fdp1 %d %d %.17g %.17g\n", (int)o1, l1, p1[0], p1[1]); }
+    // cvutils::Align2D on a host patch against a pyramid level of frame 1
+    { uint8_t pwb[100], patch[64];
+      const cv::Mat &img = f[0]._pyramid[0];
+      for (int y = 0; y < 10; ++y) for (int x = 0; x < 10; ++x) pwb[y * 10 + x] = img.at<uchar>(200 - 5 + y, 300 - 5 + x);
+      for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) patch[y * 8 + x] = pwb[(y + 1) * 10 + x + 1];
+      Vector2d p(301.2, 199.1);
+      bool o = cvutils::Align2D(f[0]._pyramid[0], pwb, patch, 10, p);
+      fprintf(out, "align2d %d %.17g %.17g\n", (int)o, p[0], p[1]); }
+    // --- test_feature_alignment: Matcher::SparseImageAlignment
+    const SE3 T1_true = f[1]._TCW;
+    bool sa = matcher.SparseImageAlignment(&f[0], &f[1]);
+    double T7[7]; f[1]._TCW.to7(T7);
+    fprintf(out, "sparse %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (int)sa, T7[0], T7[1], T7[2], T7[3], T7[4], T7[5], T7[6]);
+    fprintf(out, "sparse_err %.9g\n", (f[1]._TCW * T1_true.inverse()).log().norm());
+    // --- test_local_ba: 8 keyframes x 16 points, noisy state read from the input directory
+    {
+        auto kp = slurp_f64(in + "/ba_poses7.f64");        // [8][7] noisy T_cw
+        auto pt = slurp_f64(in + "/ba_points.f64");        // [16][3] noisy
+        auto ob = slurp_f64(in + "/ba_obs.f64");           // [16][8][2]
+        Memory::Clean();
+        std::set<Frame *> frames; std::set<MapPoint *> map_points;
+        std::vector<Frame *> by_id;
+        for (int i = 0; i < 8; ++i) { Frame *nf = new Frame(); Memory::RegisterKeyFrame(nf); nf->_TCW = SE3::from7(&kp[7 * i]); frames.insert(nf); by_id.push_back(nf); }
+        std::vector<MapPoint *> mpv;
+        for (int i = 0; i < 16; ++i) {
+            MapPoint *mp = new MapPoint; mp->_id = i; mp->_pos_world = Vector3d(pt[3 * i], pt[3 * i + 1], pt[3 * i + 2]);
+            for (int j = 0; j < 8; ++j) { Feature *fea = new Feature(Vector2d(ob[2 * (8 * i + j)], ob[2 * (8 * i + j) + 1])); fea->_frame = by_id[j]; fea->_mappoint = mp; by_id[j]->_features.push_back(fea); mp->_obs[j] = fea; }
+            map_points.insert(mp); mpv.push_back(mp);
+        }
+        ba::LocalBAStats st;
+        ba::LocalBAG2O(frames, map_points, &st);
+        fprintf(out, "ba %d %d %d %.17g %.17g\n", st.iterations, st.lm_trials, st.outliers, st.chi2_initial, st.chi2_final);
+        for (int i = 0; i < 8; ++i) { double t[7]; by_id[i]->_TCW.to7(t); fprintf(out, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
+        for (int i = 0; i < 16; ++i) fprintf(out, "%.17g %.17g %.17g\n", mpv[i]->_pos_world[0], mpv[i]->_pos_world[1], mpv[i]->_pos_world[2]);
+    }
+    fclose(out);
+    return 0;
+}

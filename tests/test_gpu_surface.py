@@ -1,0 +1,145 @@
+"""GPU test of the C++ class surfaces (include/ygz/..., libygz_host.so): tests/cpp/test_surface.cpp drives
+ygz::Frame / FeatureDetector / Matcher / Tracker / SparseImgAlign / cvutils / ba::LocalBAG2O the way the reference's
+test programs do; its text dump is compared with the oracle here."""
+import os
+import subprocess
+import numpy as np
+import pytest
+from conftest import ROOT
+from ygz_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "tests", "cpp", "test_surface")
+
+
+def _parse(path):
+    lines = open(path).read().split("\n")
+    out, i = {}, 0
+    while i < len(lines):
+        t = lines[i].split()
+        i += 1
+        if not t:
+            continue
+        tag = t[0]
+        if tag == "kp":
+            n = int(t[2]); rows = [lines[i + k].split() for k in range(n)]; i += n
+            out["kp%s" % t[1]] = np.array(rows, dtype=np.float64)
+        elif tag in ("matches", "fdp"):
+            n = int(t[1]); rows = [lines[i + k].split() for k in range(n)]; i += n
+            out[tag] = np.array(rows, dtype=np.float64).reshape(n, -1)
+        elif tag == "klt":
+            n = int(t[1]); rows = [lines[i + k].split() for k in range(n)]; i += n
+            out["klt"] = np.array(rows, dtype=np.float64).reshape(n, -1); out["klt_hdr"] = t[1:]
+        elif tag == "ba":
+            out["ba_hdr"] = [float(x) for x in t[1:]]
+            out["ba_poses"] = np.array([lines[i + k].split() for k in range(8)], dtype=np.float64); i += 8
+            out["ba_points"] = np.array([lines[i + k].split() for k in range(16)], dtype=np.float64); i += 16
+        else:
+            out.setdefault(tag, []).append(t[1:])
+    return out
+
+
+def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
+    assert os.path.exists(BIN), "tests/cpp/test_surface is not built (run __graft_entry__.build())"
+    tex, m = synth.make_texture(21, 640, 480)
+    poses = synth.trajectory(2, 31, 0.3)
+    poses[0] = [0, 0, 0, 1, 0, 0, 0]
+    ims, deps = zip(*[synth.render(tex, m, poses[i], 640, 480, 1.0, 700 + i) for i in range(2)])
+    bgr = [synth.gray_to_bgr(ims[i], i) for i in range(2)]
+    d = str(tmp_path)
+    for i in range(2):
+        bgr[i].tofile(os.path.join(d, "frame%d.bgr" % i))
+    poses.astype(np.float64).tofile(os.path.join(d, "poses.f64"))
+    deps[0].astype(np.float64).tofile(os.path.join(d, "depth0.f64"))
+    open(os.path.join(d, "default.yaml"), "w").write("%YAML:1.0\nimage.width: 640\nimage.height: 480\nframe.pyramid: 3\nfeature.cell: 10\n"
+                                                     "feature.detection_threshold: 15.0\ncamera.fx: 520.9\ncamera.fy: 521.0\ncamera.cx: 325.1\ncamera.cy: 249.7\n")
+    f = synth.ba_fixture_test_local_ba(noise=True, seed=5)
+    T7 = np.array([oracle.se3_exp(np.concatenate([p[3:], p[:3]])) for p in f["poses"]])
+    T7.tofile(os.path.join(d, "ba_poses7.f64")); f["points"].tofile(os.path.join(d, "ba_points.f64"))
+    f["obs"].reshape(16, 8, 2).tofile(os.path.join(d, "ba_obs.f64"))
+    outp = os.path.join(d, "out.txt")
+    subprocess.check_call([BIN, d, outp], timeout=300)
+    r = _parse(outp)
+
+    # Frame::InitFrame: cvtColor + pyrDown
+    gray = [oracle.bgr2gray(b) for b in bgr]
+    lv = [oracle.pyramid(g, 3) for g in gray]
+    for i in range(2):
+        assert [int(x) for x in r["pyr"][i][1:]] == [3, 160, 120, int(lv[i][2][5, 7])]
+    # FeatureDetector::Detect: bit-exact features in _features order
+    ks = [oracle.detect(l) for l in lv]
+    for i in range(2):
+        k = r["kp%d" % i]
+        assert len(k) == len(ks[i])
+        assert np.array_equal(k[:, 0], ks[i]["px"]) and np.array_equal(k[:, 1], ks[i]["py"]) and np.array_equal(k[:, 2], ks[i]["level"])
+        assert np.allclose(k[:, 3], ks[i]["score"], rtol=1e-7) and np.allclose(k[:, 4], ks[i]["angle"], rtol=1e-7)
+        assert np.array_equal(k[:, 5:].astype(np.uint8), ks[i]["desc"])
+    # BFMatcher(crossCheck) + DescriptorDistance
+    oi, od, n = oracle.bf_match(ks[0]["desc"], ks[1]["desc"], 1)
+    q = np.nonzero(oi >= 0)[0]
+    assert np.array_equal(r["matches"][:, 0], q) and np.array_equal(r["matches"][:, 1], oi[q]) and np.array_equal(r["matches"][:, 2], od[q])
+    assert int(r["ddist"][0][0]) == oracle.descriptor_distance(ks[0]["desc"][0], ks[1]["desc"][0])
+    # Detect(frame, overwrite=false): old features kept, only free cells refilled
+    before, kept, after = [int(x) for x in r["redetect"][0]]
+    occ = np.zeros(3072, np.uint8)
+    keep_idx = np.arange(1, before, 2)
+    occ[(ks[1]["py"][keep_idx].astype(int) // 10) * 64 + ks[1]["px"][keep_idx].astype(int) // 10] = 1
+    assert kept == len(keep_idx) and after == kept + len(oracle.detect(lv[1], occupied=occ))
+    # Tracker (KLT + InFrame(20) filter)
+    pts = np.stack([ks[0]["px"], ks[0]["py"]], 1).astype(np.float32)
+    oout, ost, _ = oracle.klt_track(lv[0][0], lv[1][0], pts, pts)
+    good = ost.astype(bool) & (oout[:, 0] >= 20) & (oout[:, 0] < 620) & (oout[:, 1] >= 20) & (oout[:, 1] < 460)
+    assert int(r["klt_hdr"][0]) == good.sum() and int(r["klt_hdr"][1]) == 1
+    assert np.array_equal(r["klt"][:, :2], pts[good].astype(np.float64))
+    assert np.all(np.abs(r["klt"][:, 2:] - oout[good]).max(1) <= 1e-5 * np.maximum(1, np.abs(oout[good]).max(1)))
+    # FindDirectProjection (batched and single) -- bit-exact
+    px0 = np.stack([ks[0]["px"], ks[0]["py"]], 1)
+    depth = np.array([deps[0][int(p[1]), int(p[0])] for p in px0])
+    for i in range(0, len(px0), 7):
+        o_ok, o_px, o_sl = oracle.find_direct_projection(lv[0], poses[0], lv[1], poses[1], px0[i], depth[i], int(ks[0]["level"][i]), px0[i] + [1.5, -1.0])
+        assert int(r["fdp"][i, 0]) == int(o_ok) and int(r["fdp"][i, 1]) == o_sl and np.array_equal(r["fdp"][i, 2:], o_px)
+    assert [float(x) for x in r["fdp1"][0]] == list(r["fdp"][3])
+    pwb = lv[0][0][195:205, 295:305].copy()
+    o_ok, u, v, _, _ = oracle.align2d(lv[0][0], pwb, pwb[1:9, 1:9].copy(), 301.2, 199.1)
+    assert [float(x) for x in r["align2d"][0]] == [float(o_ok), u, v]
+    # Matcher::SparseImageAlignment
+    has_mp = np.array([i % 9 != 0 for i in range(len(px0))], np.uint8)
+    nm, oT, st = oracle.sparse_align(lv[0], poses[0], lv[1], poses[0], px0, depth, has_mp)
+    sp = [float(x) for x in r["sparse"][0]]
+    assert sp[0] == 1.0 and np.allclose(sp[1:], oT, rtol=1e-9, atol=1e-11)
+    assert float(r["sparse_err"][0][0]) < 0.02
+    # ba::LocalBAG2O == ygz_hip_ba_optimize on the same graph; LM must reduce chi2 by orders of magnitude
+    ctx = hip_lib.HipContext(max_frames=1)
+    # the C++ side starts from frame->_TCW.log() (BA.cpp:407-409): feed the ABI the same exp->log round trip
+    lg = np.array([oracle.se3_log(T) for T in T7])
+    poses_in = np.concatenate([lg[:, 3:], lg[:, :3]], 1)
+    po, pt, stt = ctx.ba_optimize(poses_in, f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+    it, trials, outl, c0, c1 = r["ba_hdr"]
+    # ba::LocalBAG2O iterates std::set<Frame*>/<MapPoint*> in POINTER order like the reference (BA.cpp:399,421), so the
+    # vertex/edge order -- and with it the last bits of every sum and the length of the converged LM tail -- changes
+    # from run to run.  What must agree: the initial chi2, the minimum reached, and that the written-back state
+    # reproduces that minimum.
+    assert np.isclose(c0, stt.chi2_initial, rtol=1e-9)
+    assert abs(c1 - stt.chi2_final) <= 1e-3 * stt.chi2_final and it >= 3
+    assert c1 < 0.01 * c0 and c1 < 400
+    lg2 = np.array([oracle.se3_log(T) for T in r["ba_poses"]])
+    back = oracle.ba_linearize(np.concatenate([lg2[:, 3:], lg2[:, :3]], 1), f["fixed"], r["ba_points"], f["edge_pose"], f["edge_point"], f["obs"])
+    assert np.isclose(back["chi2"], c1, rtol=1e-6)
+    assert outl == int((back["chi2_edge"] > 5.991).sum())
+    assert np.allclose(r["ba_poses"][0], T7[0])                      # keyframe 0 fixed
+    ctx.close()
+
+
+def test_ba_optimize_converges_to_ground_truth(hip_lib, oracle):
+    """LocalBA on the transcribed test_local_ba fixture with small noise recovers the true structure (up to the
+    monocular scale gauge, removed by comparing reprojection errors)"""
+    f = synth.ba_fixture_test_local_ba(noise=True, seed=9)
+    ctx = hip_lib.HipContext(max_frames=1)
+    po, pt, st = ctx.ba_optimize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+    r0 = oracle.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
+    r1 = oracle.ba_linearize(po, f["fixed"], pt, f["edge_pose"], f["edge_point"], f["obs"])
+    assert np.isclose(r1["chi2"], st.chi2_final, rtol=1e-9) and np.isclose(r0["chi2"], st.chi2_initial, rtol=1e-9)
+    assert st.iterations >= 3 and r1["chi2"] < 0.01 * r0["chi2"]
+    assert np.sqrt(np.mean(r1["err"] ** 2)) < 1.5            # observation noise sigma = 1 px
+    assert np.array_equal(po[0], f["poses"][0])
+    ctx.close()

@@ -51,18 +51,23 @@ class BaProblem(C.Structure):
                 ("huber_delta", C.c_double), ("formulation", C.c_int)]
 
 
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("lm_trials", C.c_int), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double)]
+
+
 # every symbol include/ygz_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_error_string",
     "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end", "ygz_hip_probe_begin", "ygz_hip_probe_end",
     "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_level_size",
-    "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_get_fast_maps",
+    "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_describe_given_angle", "ygz_hip_get_fast_maps",
     "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
     "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
     "ygz_hip_default_klt_params", "ygz_hip_klt_track",
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
-    "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download",
+    "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
 ]
 
 _lib = None
@@ -360,6 +365,15 @@ class HipContext:
         o["chi2"] = float(o["chi2"][0])
         return o
 
+    def ba_optimize(self, poses, fixed, points, edge_pose, edge_point, obs, iterations=20, huber_delta=5.991, cam=None):
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, 0, cam)
+        po = np.ascontiguousarray(poses, np.float64).copy()
+        pt = np.ascontiguousarray(points, np.float64).copy()
+        st = BaStats()
+        self._chk(self.lib.ygz_hip_ba_optimize(self._ctx, C.byref(pb), _p(po, C.c_double), _p(pt, C.c_double), iterations, C.byref(st)),
+                  "ba_optimize")
+        return po, pt, st
+
     def ba_upload(self, window, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None):
         pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam)
         self._chk(self.lib.ygz_hip_ba_upload(self._ctx, window, C.byref(pb)), "ba_upload")
@@ -369,6 +383,10 @@ class HipContext:
         poses = np.ascontiguousarray(poses, np.float64)
         points = np.ascontiguousarray(points, np.float64)
         self._chk(self.lib.ygz_hip_ba_set_state(self._ctx, window, _p(poses, C.c_double), _p(points, C.c_double)), "ba_set_state")
+
+    def ba_set_state_device(self, window, d_poses_ptr, d_points_ptr):
+        self._chk(self.lib.ygz_hip_ba_set_state_device(self._ctx, window, C.c_void_p(d_poses_ptr), C.c_void_p(d_points_ptr)),
+                  "ba_set_state_device")
 
     def ba_linearize_resident(self, window_begin=0, n_windows=1):
         self._chk(self.lib.ygz_hip_ba_linearize_resident(self._ctx, window_begin, n_windows), "ba_linearize_resident")

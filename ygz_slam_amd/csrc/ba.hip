@@ -289,6 +289,16 @@ int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, cons
     return YGZ_OK;
 }
 
+// device-pointer variant: the new state is already in HBM (e.g. a torch tensor filled by an RCCL broadcast)
+int ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_poses, const double *d_points)
+{
+    if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
+    auto *w = ctx->ba[window];
+    if (d_poses) YGZ_HIPCHK(ctx, hipMemcpyAsync(w->poses, d_poses, (size_t)w->K * 48, hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_points) YGZ_HIPCHK(ctx, hipMemcpyAsync(w->points, d_points, (size_t)w->P * 24, hipMemcpyDeviceToDevice, ctx->stream));
+    return YGZ_OK;
+}
+
 int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows)
 {
     if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size()) return YGZ_E_INVALID;

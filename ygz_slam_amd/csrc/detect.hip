@@ -257,6 +257,7 @@ struct DescArgs {
     const double *kp_px; const int32_t *kp_level; const int32_t *n_kp;
     float *kp_angle; uint32_t *kp_desc;
     int slot_begin;
+    int given_angle;               // !=0: kp_angle is an input (FeatureDetector::ComputeDescriptor, :591-594)
 };
 
 // cv::fastAtan2 [OpenCV 3.x polynomial]; no FMA contraction
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    const float angle = A.given_angle ? A.kp_angle[o] : fast_atan2_deg((float)m01, (float)m10);
     // ComputeOrbDescriptor (:539-578)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
@@ -370,17 +371,19 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
     return ygz_launch_describe(ctx, slot_begin, n_slots);
 }
 
-int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
+static int launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int given_angle)
 {
     DescArgs D;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { D.lvl[L] = ctx->lvl[L]; D.w[L] = ctx->lw[L]; D.h[L] = ctx->lh[L]; }
     D.n_levels = ctx->prm.pyramid_levels; D.cells = ctx->cells;
     D.kp_px = ctx->kp_px; D.kp_level = ctx->kp_level; D.n_kp = ctx->n_kp;
-    D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin;
+    D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin; D.given_angle = given_angle;
     YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe, dim3(ygz_div_up(ctx->cells, 4), n_slots), dim3(256), D);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
+
+int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots) { return launch_describe(ctx, slot_begin, n_slots, 0); }
 
 extern "C" {
 
@@ -423,7 +426,7 @@ int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capa
     return YGZ_OK;
 }
 
-int ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, int n)
+static int describe_impl(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, const float *angle, int n)
 {
     if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || n < 0 || (n > 0 && (!px || !level))) return YGZ_E_INVALID;
     if (n > ctx->cells) return YGZ_E_CAPACITY;
@@ -433,10 +436,22 @@ int ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t
     if (n > 0) {
         YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_px + 2 * o, px, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
         YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_level + o, level, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (angle) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_angle + o, angle, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->n_kp + slot, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // &n is a stack variable
-    return ygz_launch_describe(ctx, slot, 1);
+    return launch_describe(ctx, slot, 1, angle ? 1 : 0);
+}
+
+int ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, int n)
+{
+    return describe_impl(ctx, slot, px, level, nullptr, n);
+}
+
+int ygz_hip_describe_given_angle(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, const float *angle, int n)
+{
+    if (n > 0 && !angle) return YGZ_E_INVALID;
+    return describe_impl(ctx, slot, px, level, angle, n);
 }
 
 int ygz_hip_get_fast_maps(ygz_hip_ctx *ctx, int slot, int level, uint8_t *score, uint8_t *nms)

@@ -3,7 +3,15 @@
 // (sophus/so3.cpp:80-202, sophus/se3.cpp:59-220; Eigen quaternion product / _transformVector /
 // toRotationMatrix), so results agree with oracle/se3.c to the last bits of the libm calls.
 #pragma once
+#ifdef __HIPCC__
 #include <hip/hip_runtime.h>
+#else
+#include <math.h>
+#ifndef __host__
+#define __host__
+#define __device__
+#endif
+#endif
 
 #define YGZ_SMALL_EPS 1e-10
 

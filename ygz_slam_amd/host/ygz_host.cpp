@@ -1,0 +1,617 @@
+// libygz_host.so -- the ygz:: class surfaces (include/ygz/...) on top of the C ABI of libygz_hip.so.
+// Host-side mirror of the reference interfaces for the hot path: same names, argument meaning and return
+// conventions as src/Basic/Frame.cpp, src/Algorithm/{FeatureDetector,Matcher,Tracker,SparseImageAlign,CVUtils}.cpp.
+// All dense work is delegated to the GPU library; there is no CPU fallback (a missing device makes Runtime throw).
+#include "ygz/Basic.h"
+#include "ygz/Algorithm.h"
+#include "ygz/hip/Runtime.h"
+#include "ygz_hip.h"
+#include "../csrc/se3_dev.h"
+#include <fstream>
+#include <stdexcept>
+#include <cstdlib>
+
+int ygz_log::verbosity = 0;
+
+// ------------------------------------------------------------------------------------------ Sophus shim
+namespace Sophus {
+static Se3 to_se3(const SE3 &T) { Se3 s; for (int i = 0; i < 4; ++i) s.q[i] = T.so3_.q_[i]; for (int i = 0; i < 3; ++i) s.t[i] = T.t_[i]; return s; }
+static SE3 from_se3(const Se3 &s) { SE3 T; for (int i = 0; i < 4; ++i) T.so3_.q_[i] = s.q[i]; for (int i = 0; i < 3; ++i) T.t_[i] = s.t[i]; return T; }
+SO3 SO3::exp(const Vector3d &w) { SO3 r; double th; so3_exp_d(w.d, r.q_, &th); return r; }
+Vector3d SO3::log() const { Vector3d o; double th; so3_log_d(q_, o.d, &th); return o; }
+SO3 SO3::inverse() const { SO3 r; r.q_[0] = -q_[0]; r.q_[1] = -q_[1]; r.q_[2] = -q_[2]; r.q_[3] = q_[3]; quat_normalize_d(r.q_); return r; }
+SO3 SO3::operator*(const SO3 &o) const { SO3 r; quat_mul_d(q_, o.q_, r.q_); quat_normalize_d(r.q_); return r; }
+Vector3d SO3::operator*(const Vector3d &p) const { Vector3d o; quat_rotate_d(q_, p.d, o.d); return o; }
+Matrix3d SO3::matrix() const { Matrix3d R; quat_to_R_d(q_, R.m); return R; }
+SE3 SE3::exp(const Vector6d &u) { Se3 s; se3_exp_d(u.d, &s); return from_se3(s); }
+Vector6d SE3::log() const { Vector6d o; Se3 s = to_se3(*this); se3_log_d(&s, o.d); return o; }
+SE3 SE3::inverse() const { Se3 a = to_se3(*this), b; se3_inv_d(&a, &b); return from_se3(b); }
+SE3 SE3::operator*(const SE3 &o) const { Se3 a = to_se3(*this), b = to_se3(o), c; se3_mul_d(&a, &b, &c); return from_se3(c); }
+Vector3d SE3::operator*(const Vector3d &p) const { Se3 a = to_se3(*this); Vector3d o; se3_act_d(&a, p.d, o.d); return o; }
+std::ostream &operator<<(std::ostream &os, const SE3 &T)
+{ os << "q(" << T.so3_.q_[0] << " " << T.so3_.q_[1] << " " << T.so3_.q_[2] << " " << T.so3_.q_[3] << ") t(" << T.t_[0] << " " << T.t_[1] << " " << T.t_[2] << ")"; return os; }
+}
+
+namespace ygz {
+
+// ------------------------------------------------------------------------------------------ Config
+static std::map<std::string, std::string> &cfg()
+{
+    static std::map<std::string, std::string> m = {          // config/default.yaml:8-66
+        {"image.width", "640"}, {"image.height", "480"}, {"camera.fx", "520.9"}, {"camera.fy", "521.0"},
+        {"camera.cx", "325.1"}, {"camera.cy", "249.7"}, {"frame.pyramid", "3"}, {"tracker.min_features", "50"},
+        {"init.min_features", "100"}, {"init.min_disparity", "30"}, {"init.min_inliers", "40"}, {"feature.cell", "10"},
+        {"feature.detection_threshold", "15.0"}, {"matcher.th_low", "65"}, {"matcher.th_high", "100"},
+        {"matcher.init_low", "30"}, {"matcher.init_high", "100"}, {"matcher.knnRatio", "0.7"},
+        {"vo.keyframe.min_rot", "0.1"}, {"vo.keyframe.min_trans", "0.1"}, {"vo.keyframe.min_features", "30"},
+        {"LocalMapping.local_keyframes", "3"}, {"LocalMapping.local_mappoints", "500"} };
+    return m;
+}
+bool Config::SetParameterFile(const std::string &filename)
+{
+    std::ifstream f(filename);
+    if (!f) { LOG(ERROR) << "parameter file " << filename << " does not exist." << endl; return false; }
+    std::string line;
+    while (std::getline(f, line)) {
+        const size_t h = line.find_first_of("#%");
+        if (h != std::string::npos) line = line.substr(0, h);
+        const size_t c = line.find(':');
+        if (c == std::string::npos) continue;
+        auto trim = [](std::string s) { const size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r"); return a == std::string::npos ? std::string() : s.substr(a, b - a + 1); };
+        const std::string k = trim(line.substr(0, c)), v = trim(line.substr(c + 1));
+        if (!k.empty() && !v.empty()) cfg()[k] = v;
+    }
+    return true;
+}
+void Config::Set(const std::string &key, const std::string &value) { cfg()[key] = value; }
+std::string Config::Raw(const std::string &key) { auto it = cfg().find(key); return it == cfg().end() ? std::string("0") : it->second; }
+
+// ------------------------------------------------------------------------------------------ Runtime (context + slots)
+namespace hip {
+struct Runtime::Impl {
+    ygz_hip_ctx *ctx = nullptr;
+    int max_frames = 0, levels = 0, cells = 0;
+    std::vector<Frame *> owner;
+    std::vector<unsigned long long> stamp;
+    unsigned long long clock = 0;
+    std::map<const uint8_t *, std::pair<Frame *, int>> level_of;     // host level data -> (frame, level)
+};
+Runtime &Runtime::Get() { static Runtime r; return r; }
+Runtime::Runtime() : p_(new Impl) {}
+Runtime::~Runtime() { if (p_->ctx) ygz_hip_destroy(p_->ctx); delete p_; }
+void check(int rc, const char *what) { if (rc != YGZ_OK) throw std::runtime_error(std::string(what) + ": " + ygz_hip_error_string(rc)); }
+ygz_hip_ctx *Runtime::ctx()
+{
+    if (!p_->ctx) {
+        ygz_hip_params prm;
+        ygz_hip_default_params(&prm);
+        prm.image_width = Config::Get<int>("image.width"); prm.image_height = Config::Get<int>("image.height");
+        prm.pyramid_levels = Config::Get<int>("frame.pyramid");
+        prm.cell_size = Config::Get<int>("feature.cell");
+        prm.fast_threshold = (int)(short)Config::Get<double>("feature.detection_threshold");   // double -> short at the libfast call (FeatureDetector.cpp:368)
+        prm.fx = Config::Get<float>("camera.fx"); prm.fy = Config::Get<float>("camera.fy");
+        prm.cx = Config::Get<float>("camera.cx"); prm.cy = Config::Get<float>("camera.cy");
+        const char *mf = getenv("YGZ_HIP_MAX_FRAMES");
+        prm.max_frames = mf ? atoi(mf) : 64;
+        const char *dev = getenv("YGZ_HIP_DEVICE");
+        check(ygz_hip_create(&p_->ctx, dev ? atoi(dev) : 0, &prm, nullptr), "ygz_hip_create");
+        p_->max_frames = prm.max_frames; p_->levels = prm.pyramid_levels; p_->cells = ygz_hip_max_keypoints(p_->ctx);
+        p_->owner.assign(prm.max_frames, nullptr); p_->stamp.assign(prm.max_frames, 0);
+    }
+    return p_->ctx;
+}
+int Runtime::cells() { ctx(); return p_->cells; }
+void Runtime::Release(Frame *f)
+{
+    for (auto it = p_->level_of.begin(); it != p_->level_of.end();) { if (it->second.first == f) it = p_->level_of.erase(it); else ++it; }
+    if (f->_hip_slot >= 0 && f->_hip_slot < (int)p_->owner.size() && p_->owner[f->_hip_slot] == f) p_->owner[f->_hip_slot] = nullptr;
+    f->_hip_slot = -1;
+}
+void Runtime::RegisterLevels(Frame *f)
+{
+    for (size_t L = 0; L < f->_pyramid.size(); ++L) p_->level_of[f->_pyramid[L].data] = std::make_pair(f, (int)L);
+}
+bool Runtime::FindLevel(const uint8_t *data, Frame **f, int *level)
+{
+    auto it = p_->level_of.find(data);
+    if (it == p_->level_of.end()) return false;
+    *f = it->second.first; *level = it->second.second;
+    return true;
+}
+// HBM slot of a frame; uploads (again) when the frame was evicted.  gray_only: level 0 is taken from _pyramid[0].
+int Runtime::Resident(Frame *f)
+{
+    ygz_hip_ctx *c = ctx();
+    if (f->_hip_slot >= 0 && p_->owner[f->_hip_slot] == f) { p_->stamp[f->_hip_slot] = ++p_->clock; return f->_hip_slot; }
+    int slot = -1;
+    for (int i = 0; i < p_->max_frames; ++i) if (!p_->owner[i]) { slot = i; break; }
+    if (slot < 0) {                                                   // evict the least recently used frame
+        slot = 0;
+        for (int i = 1; i < p_->max_frames; ++i) if (p_->stamp[i] < p_->stamp[slot]) slot = i;
+        p_->owner[slot]->_hip_slot = -1;
+    }
+    p_->owner[slot] = f; p_->stamp[slot] = ++p_->clock; f->_hip_slot = slot;
+    if (!f->_pyramid.empty() && !f->_pyramid[0].empty()) {
+        check(ygz_hip_upload_gray(c, slot, f->_pyramid[0].data, (int)f->_pyramid[0].step), "upload_gray");
+        check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
+    }
+    return slot;
+}
+}  // namespace hip
+
+// ------------------------------------------------------------------------------------------ Frame
+PinholeCamera *Frame::_camera = nullptr;
+Frame::~Frame() { if (!_features.empty()) CleanAllFeatures(); hip::Runtime::Get().Release(this); }
+
+void Frame::InitFrame()
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    int w = 0, h = 0;
+    ygz_hip_level_size(c, 0, &w, &h);
+    if (_color.empty() || _color.cols != w || _color.rows != h) throw std::runtime_error("Frame::InitFrame: _color does not match image.width/height");
+    rt.Release(this);
+    _pyramid.clear();
+    const int slot = rt.Resident(this);                 // no pyramid yet: slot only
+    if (_color.channels() == 3) {                       // cv::cvtColor(CV_BGR2GRAY) + pyrDown on the GPU (Frame.cpp:27,38)
+        hip::check(ygz_hip_upload_bgr(c, slot, _color.data, (int)_color.step), "upload_bgr");
+        hip::check(ygz_hip_build_pyramid(c, slot, 1, 1), "build_pyramid");
+    } else {
+        hip::check(ygz_hip_upload_gray(c, slot, _color.data, (int)_color.step), "upload_gray");
+        hip::check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
+    }
+    CreateImagePyramid();
+}
+
+void Frame::CreateImagePyramid()
+{   // host mirror of the levels (callers read frame->_pyramid[L])
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    _pyramid.resize(_option._pyramid_level);
+    for (int L = 0; L < _option._pyramid_level; ++L) {
+        int w = 0, h = 0;
+        hip::check(ygz_hip_level_size(c, L, &w, &h), "level_size");
+        _pyramid[L].create(h, w, CV_8UC1);
+        hip::check(ygz_hip_download_level(c, _hip_slot, L, _pyramid[L].data), "download_level");
+    }
+    rt.RegisterLevels(this);
+}
+
+Mat Frame::GetAllDescriptors()
+{
+    Mat alldesp((int)_features.size(), 32, CV_8U);
+    int index = 0;
+    for (Feature *fea : _features) { memcpy(alldesp.ptr<uchar>(index), fea->_desc.data, 32); index++; }
+    return alldesp;
+}
+
+void Frame::CleanAllFeatures()
+{
+    for (size_t i = 0; i < _features.size(); i++) delete _features[i];
+    _features.clear();
+}
+
+// ------------------------------------------------------------------------------------------ Memory
+static std::map<unsigned long, Frame *> g_keyframes;
+static std::map<unsigned long, MapPoint *> g_points;
+static unsigned long g_kf_id = 0, g_pt_id = 0;
+Frame *Memory::RegisterKeyFrame(Frame *frame, bool overwrite)
+{
+    if (!overwrite || g_keyframes.find(frame->_keyframe_id) == g_keyframes.end()) frame->_keyframe_id = g_kf_id++;
+    frame->_is_keyframe = true;
+    g_keyframes[frame->_keyframe_id] = frame;
+    return frame;
+}
+MapPoint *Memory::RegisterMapPoint(MapPoint *mp) { mp->_id = g_pt_id++; g_points[mp->_id] = mp; return mp; }
+Frame *Memory::GetKeyFrame(const unsigned long &id) { auto it = g_keyframes.find(id); return it == g_keyframes.end() ? nullptr : it->second; }
+MapPoint *Memory::GetMapPoint(const unsigned long &id) { auto it = g_points.find(id); return it == g_points.end() ? nullptr : it->second; }
+void Memory::Clean() { g_keyframes.clear(); g_points.clear(); g_kf_id = g_pt_id = 0; }
+
+// ------------------------------------------------------------------------------------------ FeatureDetector
+FeatureDetector::FeatureDetector()
+{
+    _option._grid_rows = (int)ceil(double(_option._image_height) / _option._cell_size);
+    _option._grid_cols = (int)ceil(double(_option._image_width) / _option._cell_size);
+    _old_features = vector<Feature *>(_option._grid_cols * _option._grid_rows, nullptr);
+}
+
+void FeatureDetector::LoadParams()
+{
+    _option._image_width = Config::Get<int>("image.width");
+    _option._image_height = Config::Get<int>("image.height");
+    _option._cell_size = Config::Get<int>("feature.cell");
+    _option._grid_rows = (int)ceil(double(_option._image_height) / _option._cell_size);
+    _option._grid_cols = (int)ceil(double(_option._image_width) / _option._cell_size);
+    _option._detection_threshold = Config::Get<double>("feature.detection_threshold");
+    _old_features = vector<Feature *>(_option._grid_cols * _option._grid_rows, nullptr);
+}
+
+void FeatureDetector::SetExistingFeatures(Frame *frame)
+{
+    for (Feature *&fea : _old_features) fea = nullptr;
+    for (Feature *fea : frame->_features) {
+        int gx = static_cast<int>(fea->_pixel[0] / _option._cell_size);
+        int gy = static_cast<int>(fea->_pixel[1] / _option._cell_size);
+        size_t k = gy * _option._grid_cols + gx;
+        if (k >= _old_features.size()) continue;
+        _old_features[k] = fea;
+    }
+}
+
+void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    const int cells = rt.cells();
+    if ((int)_old_features.size() != cells) throw std::runtime_error("FeatureDetector: grid does not match the context (call LoadParams())");
+    const int slot = rt.Resident(frame);
+    std::vector<uint8_t> occ;
+    if (overwrite_existing_features) {
+        _old_features = vector<Feature *>(cells, nullptr);
+        frame->CleanAllFeatures();
+    } else {
+        SetExistingFeatures(frame);
+        occ.resize(cells);
+        for (int k = 0; k < cells; ++k) occ[k] = _old_features[k] ? 1 : 0;
+    }
+    hip::check(ygz_hip_detect(c, slot, 1, occ.empty() ? nullptr : occ.data()), "detect");
+    std::vector<double> px(2 * (size_t)cells); std::vector<int32_t> lvl(cells); std::vector<float> sc(cells), ang(cells);
+    std::vector<uint8_t> desc(32 * (size_t)cells);
+    ygz_kpt_soa soa = { px.data(), lvl.data(), sc.data(), ang.data(), desc.data() };
+    int n = 0;
+    hip::check(ygz_hip_get_keypoints(c, slot, &soa, cells, &n), "get_keypoints");
+    LOG(INFO) << "old features: " << frame->_features.size() << endl;
+    for (int i = 0; i < n; ++i) {
+        Feature *fea = new Feature(Vector2d(px[2 * i], px[2 * i + 1]), lvl[i], sc[i]);
+        fea->_frame = frame;
+        fea->_angle = ang[i];
+        memcpy(fea->_desc.data, &desc[32 * (size_t)i], 32);
+        frame->_features.push_back(fea);
+    }
+    LOG(INFO) << "add total " << n << " new features." << endl;
+}
+
+static void describe_features(Frame *frame, const vector<Feature *> &feas, bool given_angle)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    const int slot = rt.Resident(frame);
+    const int cells = rt.cells();
+    for (size_t base = 0; base < feas.size(); base += cells) {
+        const int n = (int)std::min((size_t)cells, feas.size() - base);
+        std::vector<double> px(2 * (size_t)n); std::vector<int32_t> lvl(n); std::vector<float> ang(n);
+        for (int i = 0; i < n; ++i) { const Feature *f = feas[base + i]; px[2 * i] = f->_pixel[0]; px[2 * i + 1] = f->_pixel[1]; lvl[i] = f->_level; ang[i] = (float)f->_angle; }
+        if (given_angle) hip::check(ygz_hip_describe_given_angle(c, slot, px.data(), lvl.data(), ang.data(), n), "describe");
+        else hip::check(ygz_hip_describe(c, slot, px.data(), lvl.data(), n), "describe");
+        std::vector<float> oang(n); std::vector<uint8_t> desc(32 * (size_t)n);
+        ygz_kpt_soa soa = { nullptr, nullptr, nullptr, oang.data(), desc.data() };
+        int m = 0;
+        hip::check(ygz_hip_get_keypoints(c, slot, &soa, n, &m), "get_keypoints");
+        for (int i = 0; i < n; ++i) { Feature *f = feas[base + i]; if (!given_angle) f->_angle = oang[i]; memcpy(f->_desc.data, &desc[32 * (size_t)i], 32); }
+    }
+}
+
+void FeatureDetector::ComputeAngleAndDescriptor(Frame *frame) { describe_features(frame, frame->_features, false); }
+void FeatureDetector::ComputeDescriptor(Feature *fea) { describe_features(fea->_frame, vector<Feature *>(1, fea), true); }
+
+// ------------------------------------------------------------------------------------------ Tracker
+Tracker::Tracker() { _option._min_feature_tracking = Config::Get<int>("tracker.min_features"); }
+
+void Tracker::SetReference(Frame *ref)
+{
+    if ((int)ref->_features.size() < _option._min_feature_tracking) {
+        LOG(WARNING) << "Track a reference with little features: " << ref->_features.size() << ", abort." << endl;
+        _status = TRACK_NOT_READY;
+        return;
+    }
+    _ref = ref; _curr = ref; _status = TRACK_GOOD;
+    for (Feature *fea : ref->_features) {
+        _tracked_features.push_back(fea);
+        _px_curr.push_back(cv::Point2f((float)fea->_pixel[0], (float)fea->_pixel[1]));
+    }
+}
+
+void Tracker::Track(Frame *curr)
+{
+    if (_status == TRACK_NOT_READY) { LOG(WARNING) << "reference is not ready, please set reference first! " << endl; return; }
+    else if (_status == TRACK_LOST) { LOG(WARNING) << "track is lost, please reset it" << endl; return; }
+    _curr = curr;
+    TrackKLT();
+    if ((int)_px_curr.size() < _option._min_feature_tracking) {
+        _status = TRACK_LOST;
+        LOG(WARNING) << "Track with little features, set it as lost." << endl;
+    }
+}
+
+void Tracker::GetTrackedPixel(vector<Feature *> &feature1, vector<Vector2d> &pixels2) const
+{
+    for (Feature *fea : _tracked_features) feature1.push_back(fea);
+    for (auto px : _px_curr) pixels2.push_back(Vector2d(px.x, px.y));
+}
+
+void Tracker::TrackKLT()
+{   // cv::calcOpticalFlowPyrLK(ref, cur, pt_ref, pt_curr, ..., Size(21,21), 4, COUNT+EPS(30,1e-3), USE_INITIAL_FLOW)  (Tracker.cpp:92-98)
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    const int cells = rt.cells();
+    vector<float> pt_ref, pt_curr;
+    for (Feature *fea : _tracked_features) { pt_ref.push_back((float)fea->_pixel[0]); pt_ref.push_back((float)fea->_pixel[1]); }
+    for (cv::Point2f &p : _px_curr) { pt_curr.push_back(p.x); pt_curr.push_back(p.y); }
+    const int n = (int)_tracked_features.size();
+    vector<uint8_t> status(n); vector<float> err(n);
+    ygz_klt_params prm;
+    ygz_hip_default_klt_params(&prm);
+    prm.win = (int)_option.klt_win_size; prm.max_iter = _option.klt_max_iter; prm.eps = _option.klt_eps;
+    const int rs = rt.Resident(_ref), cs = rt.Resident(_curr);
+    for (int base = 0; base < n; base += cells) {
+        const int m = std::min(cells, n - base);
+        hip::check(ygz_hip_klt_track(c, rs, cs, &pt_ref[2 * base], &pt_curr[2 * base], m, &prm, &status[base], &err[base]), "klt_track");
+    }
+    _px_curr.clear();
+    size_t iStatus = 0;
+    for (auto iter = _tracked_features.begin(); iter != _tracked_features.end(); iStatus++) {
+        const cv::Point2f p(pt_curr[2 * iStatus], pt_curr[2 * iStatus + 1]);
+        if (!status[iStatus] || !_curr->InFrame(p, 20)) iter = _tracked_features.erase(iter);
+        else { iter++; _px_curr.push_back(p); }
+    }
+}
+
+float Tracker::MeanDisparity() const
+{
+    assert(_tracked_features.size() == _px_curr.size());
+    float mean_disparity = 0;
+    auto iter_ref = _tracked_features.begin();
+    size_t iCur = 0;
+    for (; iter_ref != _tracked_features.end(); iter_ref++, iCur++)
+        mean_disparity += (float)((*iter_ref)->_pixel - Vector2d(_px_curr[iCur].x, _px_curr[iCur].y)).norm();
+    return mean_disparity / _tracked_features.size();
+}
+
+// ------------------------------------------------------------------------------------------ SparseImgAlign
+SparseImgAlign::SparseImgAlign(int max_level, int min_level, int n_iter, Method method, bool, bool)
+    : max_level_(max_level), min_level_(min_level), n_iter_(n_iter)
+{
+    if (method != GaussNewton) LOG(WARNING) << "SparseImgAlign: only GaussNewton is provided (the live path, Matcher.cpp:18)" << endl;
+}
+
+size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
+{
+    if (ref_frame->_features.empty()) return 0;
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    const int n = (int)ref_frame->_features.size();
+    if (n > rt.cells()) throw std::runtime_error("SparseImgAlign::run: more features than grid cells");
+    vector<double> px(2 * (size_t)n), depth(n); vector<uint8_t> has(n);
+    for (int i = 0; i < n; ++i) {
+        const Feature *f = ref_frame->_features[i];
+        px[2 * i] = f->_pixel[0]; px[2 * i + 1] = f->_pixel[1]; depth[i] = f->_depth; has[i] = f->_mappoint != nullptr;
+    }
+    double Tr[7], Tc[7];
+    ref_frame->_TCW.to7(Tr); cur_frame->_TCW.to7(Tc);
+    int n_meas = 0;
+    const int rs = rt.Resident(ref_frame), cs = rt.Resident(cur_frame);
+    hip::check(ygz_hip_sparse_align(c, rs, Tr, cs, Tc, px.data(), depth.data(), has.data(), n, max_level_, min_level_, n_iter_, &n_meas, iters_), "sparse_align");
+    cur_frame->_TCW = SE3::from7(Tc);
+    return (size_t)n_meas;
+}
+
+// ------------------------------------------------------------------------------------------ Matcher
+Matcher::Matcher()
+{
+    _options.th_low = Config::Get<int>("matcher.th_low");
+    _options.th_high = Config::Get<int>("matcher.th_high");
+    _options.init_low = Config::Get<int>("matcher.init_low");
+    _options.init_high = Config::Get<int>("matcher.init_high");
+    _options.knnRatio = (float)Config::Get<int>("matcher.knnRatio");      // read through Get<int> in the reference (Matcher.cpp:17)
+    _align = new SparseImgAlign(2, 0, 30, SparseImgAlign::GaussNewton, false, false);
+}
+Matcher::~Matcher() { delete _align; }
+
+int Matcher::DescriptorDistance(const Mat &a, const Mat &b)
+{   // one pair of 256-bit rows: host popcount (the batched form is BruteForceMatch on the GPU)
+    const uint32_t *pa = a.ptr<uint32_t>(), *pb = b.ptr<uint32_t>();
+    int dist = 0;
+    for (int i = 0; i < 8; i++) dist += __builtin_popcount(pa[i] ^ pb[i]);
+    return dist;
+}
+
+int Matcher::CheckFrameDescriptors(Frame *frame1, Frame *frame2, list<pair<int, int>> &matches)
+{
+    vector<int> distance;
+    for (auto &m : matches) distance.push_back(DescriptorDistance(frame1->_features[m.first]->_desc, frame2->_features[m.second]->_desc));
+    int cnt_good = 0;
+    int best_dist = *std::min_element(distance.begin(), distance.end());
+    best_dist = best_dist > _options.init_low ? best_dist : _options.init_low;
+    best_dist = best_dist < _options.init_high ? best_dist : _options.init_high;
+    int i = 0;
+    for (auto iter = matches.begin(); iter != matches.end(); i++) {
+        if (distance[i] < _options.initMatchRatio * best_dist) { cnt_good++; iter++; }
+        else iter = matches.erase(iter);
+    }
+    return cnt_good;
+}
+
+int Matcher::BruteForceMatch(Frame *frame1, Frame *frame2, vector<DMatch> &matches, bool cross_check)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    Mat d1 = frame1->GetAllDescriptors(), d2 = frame2->GetAllDescriptors();
+    if (d1.rows > rt.cells() || d2.rows > rt.cells()) throw std::runtime_error("BruteForceMatch: more descriptors than grid cells");
+    vector<int32_t> idx(d1.rows), dist(d1.rows);
+    hip::check(ygz_hip_hamming_match(rt.ctx(), d1.data, d1.rows, d2.data, d2.rows, cross_check ? 1 : 0, idx.data(), dist.data(), nullptr), "hamming_match");
+    matches.clear();
+    for (int i = 0; i < d1.rows; ++i) if (idx[i] >= 0) { DMatch m; m.queryIdx = i; m.trainIdx = idx[i]; m.distance = (float)dist[i]; matches.push_back(m); }
+    return (int)matches.size();
+}
+
+int Matcher::FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Feature *> &feas, vector<Vector2d> &px_curr,
+                                       vector<int> &search_level, vector<bool> &ok)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    const int n = (int)feas.size();
+    search_level.assign(n, 0); ok.assign(n, false);
+    if (n == 0) return 0;
+    ygz_align_pair pair;
+    pair.ref_slot = rt.Resident(ref); pair.cur_slot = rt.Resident(curr);
+    ref->_TCW.to7(pair.T_ref); curr->_TCW.to7(pair.T_cur);
+    int good = 0;
+    const int cells = rt.cells();
+    for (int base = 0; base < n; base += cells) {
+        const int m = std::min(cells, n - base);
+        vector<double> pr(2 * (size_t)m), dep(m), pc(2 * (size_t)m); vector<int32_t> lvl(m), sl(m); vector<uint8_t> o(m);
+        for (int i = 0; i < m; ++i) {
+            const Feature *f = feas[base + i];
+            pr[2 * i] = f->_pixel[0]; pr[2 * i + 1] = f->_pixel[1]; dep[i] = f->_depth; lvl[i] = f->_level;
+            pc[2 * i] = px_curr[base + i][0]; pc[2 * i + 1] = px_curr[base + i][1];
+        }
+        hip::check(ygz_hip_find_direct_projection(rt.ctx(), &pair, pr.data(), dep.data(), lvl.data(), pc.data(), sl.data(), o.data(), m), "find_direct_projection");
+        for (int i = 0; i < m; ++i) {
+            px_curr[base + i] = Vector2d(pc[2 * i], pc[2 * i + 1]); search_level[base + i] = sl[i]; ok[base + i] = o[i] != 0; good += o[i] != 0;
+        }
+    }
+    return good;
+}
+
+bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, Feature *fea_ref, Vector2d &px_curr, int &search_level)
+{
+    if (fea_ref->_depth < 0) { LOG(WARNING) << "invalid depth: " << fea_ref->_depth << endl; return false; }
+    assert(fea_ref->_frame == ref);
+    vector<Vector2d> px(1, px_curr); vector<int> sl; vector<bool> ok;
+    FindDirectProjectionBatch(ref, curr, vector<Feature *>(1, fea_ref), px, sl, ok);
+    px_curr = px[0]; search_level = sl[0];
+    return ok[0];
+}
+
+bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector2d &px_curr, int &search_level)
+{
+    Feature *fea = mp->_obs[ref->_keyframe_id];
+    Feature tmp(fea->_pixel, fea->_level);               // same pixel/level, depth from the map point (Matcher.cpp:361-363)
+    tmp._depth = ref->_camera->World2Camera(mp->_pos_world, ref->_TCW)[2];
+    tmp._frame = ref;
+    // NB the reference does not test the depth in this overload; the ABI returns false for depth < 0 (a map point
+    // behind the reference camera), which is the only input on which the two differ.
+    vector<Vector2d> px(1, px_curr); vector<int> sl; vector<bool> ok;
+    FindDirectProjectionBatch(ref, curr, vector<Feature *>(1, &tmp), px, sl, ok);
+    px_curr = px[0]; search_level = sl[0];
+    return ok[0];
+}
+
+bool Matcher::SparseImageAlignment(Frame *ref, Frame *current)
+{
+    current->_TCW = ref->_TCW;
+    _align->run(ref, current);
+    _TCR_esti = current->_TCW * ref->_TCW.inverse();
+    if (_TCR_esti.log().norm() > _options._max_alignment_motion) {
+        LOG(WARNING) << "Too large motion: " << _TCR_esti.log().norm() << ". Reject this estimation. " << endl;
+        _TCR_esti = SE3();
+        current->_TCW = ref->_TCW;
+        return false;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------ cvutils
+namespace cvutils {
+int Align2DBatch(const cv::Mat &cur_img, const uint8_t *pwb, int n, const int n_iter, vector<Vector2d> &px, vector<bool> &ok)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    Frame *f = nullptr; int level = 0;
+    if (!rt.FindLevel(cur_img.data, &f, &level)) throw std::runtime_error("cvutils::Align2D: cur_img is not a pyramid level of an initialised Frame");
+    const int slot = rt.Resident(f);
+    vector<double> uv(2 * (size_t)n); vector<uint8_t> o(n);
+    for (int i = 0; i < n; ++i) { uv[2 * i] = px[i][0]; uv[2 * i + 1] = px[i][1]; }
+    hip::check(ygz_hip_align2d(rt.ctx(), slot, level, pwb, nullptr, uv.data(), o.data(), nullptr, n, n_iter), "align2d");
+    ok.assign(n, false);
+    int good = 0;
+    for (int i = 0; i < n; ++i) { px[i] = Vector2d(uv[2 * i], uv[2 * i + 1]); ok[i] = o[i] != 0; good += o[i] != 0; }
+    return good;
+}
+bool Align2D(const cv::Mat &cur_img, uint8_t *ref_patch_with_border, uint8_t *, const int n_iter, Vector2d &cur_px_estimate, bool)
+{
+    vector<Vector2d> px(1, cur_px_estimate); vector<bool> ok;
+    Align2DBatch(cur_img, ref_patch_with_border, 1, n_iter, px, ok);
+    cur_px_estimate = px[0];
+    return ok[0];
+}
+bool DepthFromTriangulation(const SE3 &T_search_ref, const Vector3d &f_ref, const Vector3d &f_cur, double &depth1, double &depth2, const double &determinant_th)
+{   // CVUtils.h:18-38
+    const Vector3d a0 = T_search_ref.rotation_matrix() * f_ref, a1 = -f_cur;
+    const double m00 = a0.dot(a0), m01 = a0.dot(a1), m11 = a1.dot(a1);
+    const double det = m00 * m11 - m01 * m01;
+    if (det < determinant_th) return false;
+    const Vector3d t = T_search_ref.translation();
+    const double b0 = a0.dot(t), b1 = a1.dot(t);
+    const double d0 = -(m11 * b0 - m01 * b1) / det, d1 = -(-m01 * b0 + m00 * b1) / det;
+    depth1 = fabs(d0); depth2 = fabs(d1);
+    return true;
+}
+}  // namespace cvutils
+
+// ------------------------------------------------------------------------------------------ ba::LocalBAG2O
+namespace ba {
+void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points) { LocalBAG2O(local_keyframes, local_map_points, nullptr); }
+
+void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points, LocalBAStats *stats)
+{   // graph build exactly as src/Algorithm/BA.cpp:397-497, then optimize(20) and the write-back of :504-541
+    hip::Runtime &rt = hip::Runtime::Get();
+    std::map<unsigned long, int> pose_index;            // keyframe id -> vertex
+    std::vector<Frame *> pose_frame;
+    std::vector<double> poses; std::vector<uint8_t> fixed;
+    auto add_pose = [&](Frame *frame, bool fix) {
+        pose_index[frame->_keyframe_id] = (int)pose_frame.size();
+        pose_frame.push_back(frame);
+        const Vector6d lg = frame->_TCW.log();            // esti = [log.tail<3>(); log.head<3>()]  (BA.cpp:407-409)
+        for (int i = 0; i < 3; ++i) poses.push_back(lg[3 + i]);
+        for (int i = 0; i < 3; ++i) poses.push_back(lg[i]);
+        fixed.push_back(fix ? 1 : 0);
+    };
+    for (Frame *frame : local_keyframes) add_pose(frame, frame->_keyframe_id == 0);
+    std::vector<MapPoint *> pts; std::vector<double> points;
+    std::vector<int32_t> edge_pose, edge_point; std::vector<double> obs; std::vector<Feature *> features;
+    for (MapPoint *mp : local_map_points) {
+        if (mp->_bad) continue;
+        const int il = (int)pts.size();
+        pts.push_back(mp);
+        for (int i = 0; i < 3; ++i) points.push_back(mp->_pos_world[i]);
+        for (auto &obs_pair : mp->_obs) {
+            if (obs_pair.second->_bad) continue;
+            Frame *frame = Memory::GetKeyFrame(obs_pair.first);
+            assert(frame != nullptr);
+            if (local_keyframes.find(frame) == local_keyframes.end()) {
+                // keyframes that see local map points but are not local: fixed (BA.cpp:458-477)
+                auto it = pose_index.find(frame->_keyframe_id);
+                if (it == pose_index.end()) add_pose(frame, true);
+                else fixed[it->second] = 1;
+            }
+            edge_pose.push_back(pose_index[frame->_keyframe_id]);
+            edge_point.push_back(il);
+            obs.push_back(obs_pair.second->_pixel[0]); obs.push_back(obs_pair.second->_pixel[1]);
+            features.push_back(obs_pair.second);
+        }
+    }
+    if (pts.empty() || edge_pose.empty()) return;
+    ygz_ba_problem pb;
+    memset(&pb, 0, sizeof(pb));
+    pb.n_poses = (int)pose_frame.size(); pb.n_points = (int)pts.size(); pb.n_edges = (int)edge_pose.size();
+    pb.poses = poses.data(); pb.pose_fixed = fixed.data(); pb.points = points.data();
+    pb.edge_pose = edge_pose.data(); pb.edge_point = edge_point.data(); pb.obs = obs.data();
+    PinholeCamera *cam = Frame::_camera;
+    pb.fx = cam->fx(); pb.fy = cam->fy(); pb.cx = cam->cx(); pb.cy = cam->cy();      // EdgeSophusSE3ProjectXYZ::setCamera
+    pb.huber_delta = 5.991; pb.formulation = 0;                                       // BA.cpp:451
+    ygz_ba_stats st;
+    hip::check(ygz_hip_ba_optimize(rt.ctx(), &pb, poses.data(), points.data(), 20, &st), "ba_optimize");
+    // inlier test on the optimised state: chi2 > 5.991 -> Feature::_bad (BA.cpp:504-515)
+    std::vector<double> chi2_edge(pb.n_edges);
+    hip::check(ygz_hip_ba_linearize(rt.ctx(), &pb, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, chi2_edge.data(), nullptr), "ba_linearize");
+    int cntOutlier = 0;
+    for (size_t i = 0; i < features.size(); ++i) if (chi2_edge[i] > 5.991) { cntOutlier++; features[i]->_bad = true; }
+    for (Frame *frame : local_keyframes) {             // BA.cpp:520-531
+        const double *p = &poses[6 * (size_t)pose_index[frame->_keyframe_id]];
+        Vector6d pose;
+        for (int i = 0; i < 3; ++i) { pose[i] = p[3 + i]; pose[3 + i] = p[i]; }
+        frame->_TCW = SE3::exp(pose);
+    }
+    for (size_t l = 0; l < pts.size(); ++l) pts[l]->_pos_world = Vector3d(points[3 * l], points[3 * l + 1], points[3 * l + 2]);
+    if (stats) { stats->iterations = st.iterations; stats->lm_trials = st.lm_trials; stats->outliers = cntOutlier; stats->chi2_initial = st.chi2_initial; stats->chi2_final = st.chi2_final; }
+}
+}  // namespace ba
+}  // namespace ygz
