@@ -42,7 +42,8 @@ def build_inputs(batch, rank):
 class Pipeline:
     """Drives the C ABI for one GPU.  Everything it needs is uploaded in setup()."""
 
-    def __init__(self, batch, device, rank, stream=None):
+    def __init__(self, batch, device, rank, stream=None, overlap=True):
+        self.overlap = overlap
         from ygz_slam_amd import _lib
         self.lib = _lib
         self.B = batch
@@ -66,6 +67,7 @@ class Pipeline:
         f = self.ba
         self.ba_dims = [c.ba_upload(w, f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
                         for w in range(self.B)]
+        c.set_overlap(self.overlap)
         c.synchronize()
 
     def step(self):
@@ -73,12 +75,15 @@ class Pipeline:
         c = self.ctx
         c.build_pyramid(0, self.B, from_bgr=True)             # A1  InitFrame
         c.detect(0, self.B)                                   # A2-A7 FeatureDetector::Detect
-        c.match_slots_again(1)                                # M1-M3 BFMatcher(crossCheck) vs predecessor
         c.track_reload(True)                                  # track sets from the fresh keypoints
-        c.track_klt()                                         # L4  Tracker::TrackKLT
-        c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D
+        # the next three stages are independent of each other and of KLT / direct projection: with overlap enabled the
+        # ABI forks them onto side streams (latency-bound sparse alignment, FP64 BA and the VALU-bound matcher then run
+        # concurrently with the address-unit-bound KLT); the next step's build_pyramid joins them
         c.track_sparse_align()                                # L3  SparseImgAlign::run
         c.ba_linearize_resident(0, self.B)                    # B1-B5 one Jacobian/JtJ build per frame
+        c.match_slots_again(1)                                # M1-M3 BFMatcher(crossCheck) vs predecessor
+        c.track_klt()                                         # L4  Tracker::TrackKLT
+        c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D
 
     def stage_times(self, reps=3):
         """per-stage HIP-event times (ms per batch), outside the timed region"""
@@ -140,7 +145,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames resident per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--probe", default="k_sparse_align", help="kernel timed with HIP events for the roofline leg")
+    ap.add_argument("--no-overlap", action="store_true", help="run every stage on one stream")
+    ap.add_argument("--probe", default="k_klt", help="kernel timed with HIP events for the roofline leg")
     a = ap.parse_args()
 
     import torch
@@ -159,7 +165,7 @@ def main():
     # one HIP stream shared by torch (RCCL broadcast) and the ABI context, so the exchange is ordered with the kernels
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    pipe = Pipeline(a.batch, local_rank, rank, stream=stream.cuda_stream)
+    pipe = Pipeline(a.batch, local_rank, rank, stream=stream.cuda_stream, overlap=not a.no_overlap)
     pipe.setup()
     n_pts = pipe.ba["points"].size
     map_buf = torch.from_numpy(np.concatenate([pipe.ba["points"].ravel(), pipe.ba["poses"].ravel()])).cuda()

@@ -64,6 +64,11 @@ void ygz_hip_default_params(ygz_hip_params *p);
 int  ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, void *stream);
 void ygz_hip_destroy(ygz_hip_ctx *ctx);
 int  ygz_hip_synchronize(ygz_hip_ctx *ctx);
+/* enable != 0: the resident stages that do not depend on each other -- ygz_hip_track_sparse_align,
+ * ygz_hip_ba_linearize_resident, ygz_hip_match_slots_again -- are launched on side HIP streams forked from the context's
+ * stream, so they overlap with whatever is enqueued after them (KLT, direct projection); every entry point that reads or
+ * overwrites their data, and ygz_hip_synchronize, joins them first.  Off by default. */
+int  ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable);
 const char *ygz_hip_error_string(int code);
 int  ygz_hip_last_hip_error(const ygz_hip_ctx *ctx);
 int  ygz_hip_max_keypoints(const ygz_hip_ctx *ctx);     /* = number of grid cells */

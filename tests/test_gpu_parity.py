@@ -407,10 +407,13 @@ def test_ba_normalised_plane_formulation(hip_lib, oracle):
 
 
 # ------------------------------------------------------------------------------------- resident batched path
-def test_resident_batched_tracking(hip_lib, oracle):
-    """detect -> (device-side) track sets -> KLT / FindDirectProjection / SparseImgAlign for 3 pairs in one launch each"""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_resident_batched_tracking(hip_lib, oracle, overlap):
+    """detect -> (device-side) track sets -> KLT / FindDirectProjection / SparseImgAlign for 3 pairs in one launch each;
+    overlap=True runs sparse alignment on a side stream concurrently with KLT / direct projection"""
     imgs, poses, depths = _frames(4, 640, 480, seed=11, step=0.3)
     ctx = make_ctx(hip_lib, max_frames=4)
+    ctx.set_overlap(overlap)
     for s in range(4):
         ctx.upload_gray(s, imgs[s])
     ctx.build_pyramid(0, 4); ctx.detect(0, 4)
@@ -427,7 +430,7 @@ def test_resident_batched_tracking(hip_lib, oracle):
     cam = oracle.camera()
     for predict in (False, True):
         ctx.track_begin(cur, ref, poses[cur], poses[ref], predict=predict)
-        ctx.track_klt(); ctx.track_direct(); ctx.track_sparse_align()
+        ctx.track_sparse_align(); ctx.track_klt(); ctx.track_direct()
         for p in range(3):
             c, r = cur[p], ref[p]
             px = kps[r]["px"]

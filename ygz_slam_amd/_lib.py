@@ -58,7 +58,7 @@ class BaStats(C.Structure):
 
 # every symbol include/ygz_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_error_string",
+    "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_set_overlap", "ygz_hip_error_string",
     "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end", "ygz_hip_probe_begin", "ygz_hip_probe_end",
     "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_level_size",
     "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_describe_given_angle", "ygz_hip_get_fast_maps",
@@ -126,6 +126,9 @@ class HipContext:
 
     def synchronize(self):
         self._chk(self.lib.ygz_hip_synchronize(self._ctx), "synchronize")
+
+    def set_overlap(self, enable=True):
+        self._chk(self.lib.ygz_hip_set_overlap(self._ctx, int(enable)), "set_overlap")
 
     def timer_begin(self):
         self._chk(self.lib.ygz_hip_timer_begin(self._ctx), "timer_begin")

@@ -106,7 +106,7 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
 struct FdpArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
-    int n_levels, cells;
+    int n_levels, cells, n_pairs;
     Cam cam;
     const int32_t *pair_q, *pair_t, *trk_n;       // cur slot, ref slot, candidates per pair
     const double *pair_T;                         // [pairs][2][7] (T_ref, T_cur)
@@ -118,8 +118,9 @@ struct FdpArgs {
 __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
 {
     __shared__ uint8_t pwb_all[100 * 64];
-    const int pair = blockIdx.y;
-    const int ii = blockIdx.x * 64 + threadIdx.x;
+    int bx, pair;
+    if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
+    const int ii = bx * 64 + threadIdx.x;
     if (ii >= A.trk_n[pair]) return;
     const size_t i = (size_t)pair * A.cells + ii;
     const int ref_slot = A.pair_t[pair], cur_slot = A.pair_q[pair];
@@ -210,12 +211,12 @@ int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs)
 {
     FdpArgs A;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
-    A.n_levels = ctx->prm.pyramid_levels; A.cells = ctx->cells;
+    A.n_levels = ctx->prm.pyramid_levels; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_level = ctx->trk_level;
     A.px_cur = ctx->fdp_px; A.search_level = ctx->fdp_level; A.ok = ctx->fdp_ok;
-    YGZ_LAUNCH(ctx, KID_FDP, k_find_direct_projection, dim3(ygz_div_up(ctx->cells, 64), n_pairs), dim3(64), A);
+    YGZ_LAUNCH(ctx, KID_FDP, k_find_direct_projection, dim3(ygz_div_up(ctx->cells, 64), ygz_round_up8(n_pairs)), dim3(64), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }

@@ -223,6 +223,7 @@ extern "C" {
 
 int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !pb || window < 0 || window > 1023) return YGZ_E_INVALID;
     const int K = pb->n_poses, P = pb->n_points, E = pb->n_edges;
     if (K < 1 || P < 1 || E < 0 || !pb->poses || !pb->points || (E > 0 && (!pb->edge_pose || !pb->edge_point || !pb->obs)))
@@ -281,6 +282,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
 
 int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, const double *points)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
     if (poses) YGZ_HIPCHK(ctx, hipMemcpyAsync(w->poses, poses, (size_t)w->K * 48, hipMemcpyHostToDevice, ctx->stream));
@@ -292,6 +294,7 @@ int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, cons
 // device-pointer variant: the new state is already in HBM (e.g. a torch tensor filled by an RCCL broadcast)
 int ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_poses, const double *d_points)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
     if (d_poses) YGZ_HIPCHK(ctx, hipMemcpyAsync(w->poses, d_poses, (size_t)w->K * 48, hipMemcpyDeviceToDevice, ctx->stream));
@@ -303,6 +306,7 @@ int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
 {
     if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size()) return YGZ_E_INVALID;
     for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i]) return YGZ_E_INVALID;
+    if (ctx->ba_table_dirty) { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     if (ctx->ba_table_dirty) {                       // descriptor table of all windows (changes only at upload time)
         std::vector<BaDev> tab(1024);
         memset(tab.data(), 0, tab.size() * sizeof(BaDev));
@@ -319,6 +323,7 @@ int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
         ctx->ba_table_dirty = false;
     }
     const BaDev *tab = reinterpret_cast<const BaDev *>(ctx->ba_table) + window_begin;
+    YgzAuxScope aux(ctx, 1);
     YGZ_LAUNCH(ctx, KID_BA_POSE_PREP, k_ba_pose_prep, dim3(ygz_div_up(ctx->ba_max_K, 64), n_windows), dim3(64), tab);
     YGZ_LAUNCH(ctx, KID_BA_POINTS, k_ba_points, dim3(ygz_div_up(ctx->ba_max_P, 128), n_windows), dim3(128), tab);
     YGZ_LAUNCH(ctx, KID_BA_POSES, k_ba_poses, dim3(ctx->ba_max_K, n_windows), dim3(256), tab);
@@ -330,6 +335,7 @@ int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
 int ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, double *Hll, double *bl, double *Hpl,
                         double *err, double *chi2_edge, double *chi2)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
     const size_t K = w->K, P = w->P, E = w->E;

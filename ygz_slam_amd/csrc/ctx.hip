@@ -49,6 +49,13 @@ int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out)
     return YGZ_OK;
 }
 
+int ygz_join(ygz_hip_ctx *ctx)
+{
+    for (int i = 0; i < 3; ++i)
+        if (ctx->aux_pending[i]) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); ctx->aux_pending[i] = false; }
+    return YGZ_OK;
+}
+
 int ygz_ensure_levels(ygz_hip_ctx *ctx, int n_levels)
 {
     if (n_levels > YGZ_MAX_LEVELS) return YGZ_E_INVALID;
@@ -128,6 +135,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 3; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ygz_hip_ba_free_all(ctx);
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
@@ -145,14 +153,34 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     for (int i = 0; i < YGZ_N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 3; ++i) { if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); if (ctx->aux[i]) (void)hipStreamDestroy(ctx->aux[i]); }
     for (hipEvent_t e : ctx->probe_ev) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
+int ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    int rc = ygz_join(ctx);
+    if (rc != YGZ_OK) return rc;
+    if (enable && !ctx->aux[0]) {
+        YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) {
+            YGZ_HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+            YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+        }
+    }
+    ctx->overlap = enable ? 1 : 0;
+    return YGZ_OK;
+}
+
 int ygz_hip_synchronize(ygz_hip_ctx *ctx)
 {
     if (!ctx) return YGZ_E_INVALID;
+    int rcj = ygz_join(ctx);
+    if (rcj != YGZ_OK) return rcj;
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }
@@ -167,6 +195,7 @@ int ygz_hip_timer_begin(ygz_hip_ctx *ctx)
 int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
 {
     if (!ctx || !elapsed_ms) return YGZ_E_INVALID;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     YGZ_HIPCHK(ctx, hipEventSynchronize(ctx->ev1));
     YGZ_HIPCHK(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
@@ -196,6 +225,8 @@ int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launc
 int ygz_hip_probe_end(ygz_hip_ctx *ctx, double *total_ms, int *launches)
 {
     if (!ctx || !total_ms || !launches) return YGZ_E_INVALID;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    for (int i = 0; i < 3; ++i) if (ctx->aux[i]) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->aux[i]));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0;
     for (int i = 0; i + 1 < ctx->probe_used; i += 2) {
@@ -218,6 +249,7 @@ int ygz_hip_level_size(const ygz_hip_ctx *ctx, int level, int *w, int *h)
 
 int ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int stride_bytes)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !bgr || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     const int w = ctx->lw[0], h = ctx->lh[0];
     if (stride_bytes < w * 3) return YGZ_E_INVALID;
@@ -231,6 +263,7 @@ int ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int strid
 
 int ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int stride_bytes)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !gray || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     const int w = ctx->lw[0], h = ctx->lh[0];
     if (stride_bytes < w) return YGZ_E_INVALID;
@@ -245,6 +278,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
 {
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     if (from_bgr && !ctx->bgr) return YGZ_E_STATE;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->n_levels_alloc);
     if (rc != YGZ_OK) return rc;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 1;
@@ -253,6 +287,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
 
 int ygz_hip_download_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !dst || slot < 0 || slot >= ctx->prm.max_frames || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
     const size_t n = (size_t)ctx->lw[level] * ctx->lh[level];
     YGZ_HIPCHK(ctx, hipMemcpyAsync(dst, ctx->lvl[level] + (size_t)slot * n, n, hipMemcpyDeviceToHost, ctx->stream));

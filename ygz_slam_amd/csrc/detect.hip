@@ -46,7 +46,7 @@ struct FastArgs {
     unsigned long long *cell_best;
     const uint8_t *occupied;
     uint8_t *dbg_score, *dbg_nms;  // may be null
-    int slot_begin;
+    int slot_begin, n_slots;
 };
 
 __device__ __forceinline__ bool ring10(uint32_t m)
@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
     __shared__ uint16_t list[R1_W * R1_H];
     __shared__ int n_list;
 
-    const int slot = A.slot_begin + blockIdx.z;
+    int bx_, by_, so_;
+    if (!ygz_xcd_remap3(A.n_slots, bx_, by_, so_)) return;          // frame pinned to one XCD's L2 (block-uniform)
+    const int slot = A.slot_begin + so_;
     const size_t npix = (size_t)A.w * A.h;
     const uint8_t *img = A.img + (size_t)slot * npix;
-    const int x0 = blockIdx.x * FT_W, y0 = blockIdx.y * FT_H;
+    const int x0 = bx_ * FT_W, y0 = by_ * FT_H;
     const int tid = threadIdx.x;
 
     if (tid == 0) n_list = 0;
@@ -256,7 +258,7 @@ struct DescArgs {
     int n_levels, cells;
     const double *kp_px; const int32_t *kp_level; const int32_t *n_kp;
     float *kp_angle; uint32_t *kp_desc;
-    int slot_begin;
+    int slot_begin, n_slots;
     int given_angle;               // !=0: kp_angle is an input (FeatureDetector::ComputeDescriptor, :591-594)
 };
 
@@ -285,9 +287,11 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 __global__ __launch_bounds__(256) void k_describe(DescArgs A)
 {
     __shared__ uint8_t patch_all[4][DP_N + 15];
-    const int slot = A.slot_begin + blockIdx.y;
+    int bx, so;
+    if (!ygz_xcd_remap(A.n_slots, bx, so)) return;
+    const int slot = A.slot_begin + so;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int kp = blockIdx.x * 4 + wv;
+    const int kp = bx * 4 + wv;
     if (kp >= A.n_kp[slot]) return;                 // wave-uniform
     uint8_t *patch = patch_all[wv];
     const size_t o = (size_t)slot * A.cells + kp;
@@ -315,8 +319,7 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
             m10 += u * I; m01 += v * I;
         }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    m10 = ygz_wave_sum_i(m10); m01 = ygz_wave_sum_i(m01);
     const float angle = A.given_angle ? A.kp_angle[o] : fast_atan2_deg((float)m01, (float)m10);
     // ComputeOrbDescriptor (:539-578)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
@@ -362,8 +365,8 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
         A.cell_first = ctx->cell_first; A.cell_best = ctx->cell_best; A.occupied = ctx->occupied;
         A.dbg_score = ctx->prm.debug_maps ? ctx->dbg_score[L] : nullptr;
         A.dbg_nms = ctx->prm.debug_maps ? ctx->dbg_nms[L] : nullptr;
-        A.slot_begin = slot_begin;
-        YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), n_slots), dim3(256), A);
+        A.slot_begin = slot_begin; A.n_slots = n_slots;
+        YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), ygz_round_up8(n_slots)), dim3(256), A);
     }
     YGZ_LAUNCH(ctx, KID_COMPACT, k_compact, dim3(n_slots), dim3(1024), ctx->cell_first, ctx->cell_best, ctx->cells,
                        ctx->kp_px, ctx->kp_level, ctx->kp_score, ctx->n_kp, slot_begin);
@@ -377,8 +380,8 @@ static int launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int gi
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { D.lvl[L] = ctx->lvl[L]; D.w[L] = ctx->lw[L]; D.h[L] = ctx->lh[L]; }
     D.n_levels = ctx->prm.pyramid_levels; D.cells = ctx->cells;
     D.kp_px = ctx->kp_px; D.kp_level = ctx->kp_level; D.n_kp = ctx->n_kp;
-    D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin; D.given_angle = given_angle;
-    YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe, dim3(ygz_div_up(ctx->cells, 4), n_slots), dim3(256), D);
+    D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin; D.n_slots = n_slots; D.given_angle = given_angle;
+    YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_slots)), dim3(256), D);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
@@ -389,6 +392,7 @@ extern "C" {
 
 int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *occupied)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) if (!ctx->pyr_valid[s]) return YGZ_E_STATE;
     const size_t Cn = (size_t)ctx->cells;
@@ -408,6 +412,7 @@ int ygz_hip_keypoint_count(ygz_hip_ctx *ctx, int slot, int *n)
 
 int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capacity, int *n_out)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !out || !n_out || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     int n = 0;
     int rc = ygz_hip_keypoint_count(ctx, slot, &n);
@@ -428,6 +433,7 @@ int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capa
 
 static int describe_impl(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, const float *angle, int n)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || n < 0 || (n > 0 && (!px || !level))) return YGZ_E_INVALID;
     if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[slot]) return YGZ_E_STATE;

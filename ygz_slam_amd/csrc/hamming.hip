@@ -128,6 +128,7 @@ extern "C" {
 
 int ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32_t *train_slot, int n_pairs, int cross_check)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !query_slot || !train_slot || n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     if (n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;
     for (int i = 0; i < n_pairs; ++i)
@@ -145,12 +146,14 @@ int ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32
 int ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check)
 {
     if (!ctx || ctx->n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
+    YgzAuxScope aux(ctx, 2);
     return run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->n_pairs, ctx->cells,
                      cross_check, false);
 }
 
 int ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx, int32_t *dist, int capacity, int *nq_out)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || pair < 0 || pair >= ctx->n_pairs || !nq_out) return YGZ_E_INVALID;
     int32_t qslot = 0, nq = 0;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(&qslot, ctx->pair_q + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -171,6 +174,7 @@ int ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx, int32_t 
 int ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int cross_check,
                           int32_t *train_idx, int32_t *dist, int32_t *dist2)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     if (dist2 && cross_check != 0) return YGZ_E_INVALID;
     if (nq > ctx->cells || nt > ctx->cells) return YGZ_E_CAPACITY;        // result rows live in the per-pair buffers

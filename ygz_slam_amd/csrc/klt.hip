@@ -11,8 +11,9 @@
 //             (7 pixels per lane); the previous-image patch and its derivatives (3 x int16 per pixel)
 //             stay in LDS for the whole iteration loop; every iteration gathers the moving 22x22
 //             window of the next image, forms the two mismatch sums and reduces them with wave
-//             shuffles in a FIXED order.  The integer terms are identical to the oracle's; only the
-//             float summation order differs (tree vs raster), well inside the 1e-5 track tolerance.
+//             shuffles in a FIXED order.  The integer terms are identical to the oracle's; each lane adds its 7
+//             terms exactly in integers and the 63 lane sums are combined by a float tree (the oracle adds all 441
+//             terms in float in raster order): same quantities, different rounding, well inside the 1e-5 track tolerance.
 #include "ygz_internal.h"
 #include <vector>
 
@@ -27,11 +28,13 @@ __device__ __forceinline__ int refl101(int i, int n)
 
 // calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1)
 __global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img_base, int16_t *__restrict__ deriv_base,
-                                                const int32_t *__restrict__ pair_t, int w, int h)
+                                                const int32_t *__restrict__ pair_t, int w, int h, int n_pairs)
 {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int bx_, by_, pr_;
+    if (!ygz_xcd_remap3(n_pairs, bx_, by_, pr_)) return;
+    const int x = bx_ * 64 + (threadIdx.x & 63), y = by_ * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const size_t slot = (size_t)pair_t[blockIdx.z];            // reference slot of this pair
+    const size_t slot = (size_t)pair_t[pr_];                   // reference slot of this pair
     const uint8_t *img = img_base + slot * (size_t)w * h;
     int16_t *deriv = deriv_base + slot * (size_t)w * h * 2;
     const int y0 = y > 0 ? y - 1 : (h > 1 ? 1 : 0), y2 = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
@@ -49,7 +52,7 @@ struct KltArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];                            // level images, slot-major
     const int16_t *deriv[YGZ_MAX_LEVELS];                          // Scharr images, slot-major
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
-    int max_level, win, max_count, use_initial_flow, cells;
+    int max_level, win, max_count, use_initial_flow, cells, n_pairs;
     double epsilon;            // already squared
     float min_eig_thr;
     const int32_t *pair_q, *pair_t, *trk_n;                        // cur slot, ref slot, points per pair
@@ -57,12 +60,7 @@ struct KltArgs {
     float *next_pts; uint8_t *status; float *err;                  // [pairs][cells]
 };
 
-__device__ __forceinline__ float wave_sum_f(float v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off));
-    return v;
-}
+#define wave_sum_f ygz_wave_sum_f
 
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
 #define KLT_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
@@ -72,14 +70,19 @@ __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
 __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t *q = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    typedef const __attribute__((address_space(1))) uint32_t *gptr;      // global, not flat: plain global_load
+    gptr q = (gptr)(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3);
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
     lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
 }
 #define KLT_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
-#define KLT_BIL9V(v00, v01, v10, v11) KLT_DESCALE((v00) * iw00 + (v01) * iw01 + (v10) * iw10 + (v11) * iw11, 9)
+// all factors fit 24 bits (pixels 8 bit, derivatives 14 bit, weights 15 bit, differences 14 bit): full-rate v_mad_*24
+// instead of the quarter-rate 32-bit multiply
+#define KLT_MAD(a, b, c) ((int)__mul24((int)(a), (int)(b)) + (int)(c))
+#define KLT_BIL9V(v00, v01, v10, v11) ((KLT_MAD(v00, iw00, KLT_MAD(v01, iw01, KLT_MAD(v10, iw10, KLT_MAD(v11, iw11, 256))))) >> 9)
+#define KLT_BIL14(v00, v01, v10, v11) ((KLT_MAD(v00, iw00, KLT_MAD(v01, iw01, KLT_MAD(v10, iw10, KLT_MAD(v11, iw11, 8192))))) >> 14)
 
 // Lane mapping: 3 lanes per window row, 7 consecutive pixels per lane (21 = 3 x 7; 63 of 64 lanes busy).
 // Interior windows (the common case) fetch their 2 x 8 source bytes per row with 6 dword loads per iteration
@@ -87,8 +90,9 @@ __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32
 __global__ __launch_bounds__(256) void k_klt(KltArgs A)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pair = blockIdx.y;
-    const int pi = blockIdx.x * 4 + wv;
+    int bx, pair;
+    if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
+    const int pi = bx * 4 + wv;
     if (pi >= A.trk_n[pair]) return;               // wave-uniform
     const size_t p = (size_t)pair * A.cells + pi;
     const size_t ref_slot = (size_t)A.pair_t[pair], cur_slot = (size_t)A.pair_q[pair];
@@ -143,10 +147,8 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
                 for (int k = 0; k < 7; ++k) {
                     if (k < npx) {
                         const int ival = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1));
-                        const int ixval = KLT_DESCALE((int)(int16_t)(d0[k] & 0xFFFF) * iw00 + (int)(int16_t)(d0[k + 1] & 0xFFFF) * iw01 +
-                                                      (int)(int16_t)(d1[k] & 0xFFFF) * iw10 + (int)(int16_t)(d1[k + 1] & 0xFFFF) * iw11, 14);
-                        const int iyval = KLT_DESCALE((int)(int16_t)(d0[k] >> 16) * iw00 + (int)(int16_t)(d0[k + 1] >> 16) * iw01 +
-                                                      (int)(int16_t)(d1[k] >> 16) * iw10 + (int)(int16_t)(d1[k + 1] >> 16) * iw11, 14);
+                        const int ixval = KLT_BIL14((int)(int16_t)(d0[k] & 0xFFFF), (int)(int16_t)(d0[k + 1] & 0xFFFF), (int)(int16_t)(d1[k] & 0xFFFF), (int)(int16_t)(d1[k + 1] & 0xFFFF));
+                        const int iyval = KLT_BIL14((int)(int16_t)(d0[k] >> 16), (int)(int16_t)(d0[k + 1] >> 16), (int)(int16_t)(d1[k] >> 16), (int)(int16_t)(d1[k + 1] >> 16));
                         iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
                     }
                 }
@@ -168,12 +170,11 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
                     }
                 }
             }
+            // exact per-lane sums (7 terms < 2^27 each fit int32 only for two... use float of the exact 64-bit sum)
+            long long q11 = 0, q12 = 0, q22 = 0;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                sA11 = __fadd_rn(sA11, (float)(iDx[k] * iDx[k]));
-                sA12 = __fadd_rn(sA12, (float)(iDx[k] * iDy[k]));
-                sA22 = __fadd_rn(sA22, (float)(iDy[k] * iDy[k]));
-            }
+            for (int k = 0; k < 7; ++k) { q11 += __mul24(iDx[k], iDx[k]); q12 += __mul24(iDx[k], iDy[k]); q22 += __mul24(iDy[k], iDy[k]); }
+            sA11 = (float)q11; sA12 = (float)q12; sA22 = (float)q22;
         }
         const float A11 = __fmul_rn(wave_sum_f(sA11), FLT_SCALE), A12 = __fmul_rn(wave_sum_f(sA12), FLT_SCALE),
                     A22 = __fmul_rn(wave_sum_f(sA22), FLT_SCALE);
@@ -207,24 +208,28 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
                     const int o = (iny + row) * w + inx + x0;
                     uint32_t l0, h0, l1, h1;
                     klt_load8(J + o, l0, h0); klt_load8(J + o + w, l1, h1);
+                    // the lane's 7 terms are summed exactly in int32 (|diff*I| < 2^26), converted once; pixels beyond
+                    // the window (k >= npx) carry iDx = iDy = 0
+                    int a1 = 0, a2 = 0;
 #pragma unroll
                     for (int k = 0; k < 7; ++k) {
                         const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
-                        if (k < npx) {
-                            sb1 = __fadd_rn(sb1, (float)(diff * iDx[k]));
-                            sb2 = __fadd_rn(sb2, (float)(diff * iDy[k]));
-                        }
+                        a1 = KLT_MAD(diff, iDx[k], a1);
+                        a2 = KLT_MAD(diff, iDy[k], a2);
                     }
+                    sb1 = (float)a1; sb2 = (float)a2;
                 } else {
+                    int a1 = 0, a2 = 0;
 #pragma unroll
                     for (int k = 0; k < 7; ++k) {
                         if (k < npx) {
                             const int X0 = refl101(inx + x0 + k, w), X1 = refl101(inx + x0 + k + 1, w), Y0 = refl101(iny + row, h), Y1 = refl101(iny + row + 1, h);
                             const int diff = KLT_BIL9V((int)J[Y0 * w + X0], (int)J[Y0 * w + X1], (int)J[Y1 * w + X0], (int)J[Y1 * w + X1]) - iI[k];
-                            sb1 = __fadd_rn(sb1, (float)(diff * iDx[k]));
-                            sb2 = __fadd_rn(sb2, (float)(diff * iDy[k]));
+                            a1 = KLT_MAD(diff, iDx[k], a1);
+                            a2 = KLT_MAD(diff, iDy[k], a2);
                         }
                     }
+                    sb1 = (float)a1; sb2 = (float)a2;
                 }
             }
             const float b1 = __fmul_rn(wave_sum_f(sb1), FLT_SCALE), b2 = __fmul_rn(wave_sum_f(sb2), FLT_SCALE);
@@ -287,10 +292,10 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
         const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
         if (!ctx->deriv[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->deriv[L], (size_t)ctx->prm.max_frames * npix * 4 + 64));
         A.lvl[L] = ctx->lvl[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L];
-        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(A.w[L], 64), ygz_div_up(A.h[L], 4), n_pairs), dim3(256),
-                           ctx->lvl[L], ctx->deriv[L], ctx->pair_t, A.w[L], A.h[L]);
+        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(A.w[L], 64), ygz_div_up(A.h[L], 4), ygz_round_up8(n_pairs)), dim3(256),
+                           ctx->lvl[L], ctx->deriv[L], ctx->pair_t, A.w[L], A.h[L], n_pairs);
     }
-    A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells;
+    A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);
     const double eps = prm->eps < 0 ? 0 : (prm->eps > 10 ? 10 : prm->eps);
     A.epsilon = eps * eps;
@@ -298,7 +303,7 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
     A.use_initial_flow = prm->use_initial_flow;
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.trk_px = ctx->trk_px;
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
-    YGZ_LAUNCH(ctx, KID_KLT, k_klt, dim3(ygz_div_up(ctx->cells, 4), n_pairs), dim3(256), A);
+    YGZ_LAUNCH(ctx, KID_KLT, k_klt, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }

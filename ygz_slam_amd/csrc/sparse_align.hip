@@ -41,7 +41,7 @@ __device__ __forceinline__ double wave_sum_d(double v)
     return v;
 }
 
-__global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
+__global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
 {
     __shared__ double red[SA_THREADS / 64][28];
     __shared__ float stage[SA_CHUNK];
@@ -199,12 +199,12 @@ __global__ __launch_bounds__(SA_THREADS) void k_sparse_align(SaArgs A)
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) {
                         int i = 0;
-                        for (; i + 64 <= cnt; i += 64) {
-                            float4 q[16];
+                        for (; i + 32 <= cnt; i += 32) {
+                            float4 q[8];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) q[k] = *reinterpret_cast<const float4 *>(&stage[i + 4 * k]);
+                            for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const float4 *>(&stage[i + 4 * k]);
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) {
+                            for (int k = 0; k < 8; ++k) {
                                 c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].x, q[k].x), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].y, q[k].y), 1.0f));
                                 c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].z, q[k].z), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].w, q[k].w), 1.0f));
                             }

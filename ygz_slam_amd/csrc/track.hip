@@ -31,6 +31,7 @@ int ygz_track_ensure(ygz_hip_ctx *ctx)
 int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
                         const double *T_ref, int n_pairs)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (n_pairs < 1 || n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;
     for (int i = 0; i < n_pairs; ++i)
         if (cur_slot[i] < 0 || cur_slot[i] >= ctx->prm.max_frames || ref_slot[i] < 0 || ref_slot[i] >= ctx->prm.max_frames) return YGZ_E_INVALID;
@@ -104,6 +105,7 @@ extern "C" {
 
 int ygz_hip_set_keypoint_depths(ygz_hip_ctx *ctx, int slot, const double *depth, const uint8_t *has_mappoint, int n)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || n < 0 || n > ctx->cells || (n > 0 && (!depth || !has_mappoint))) return YGZ_E_INVALID;
     int rc = ygz_track_ensure(ctx);
     if (rc != YGZ_OK) return rc;
@@ -126,6 +128,7 @@ int ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
 
 int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     return launch_load(ctx, predict);
 }
@@ -148,11 +151,13 @@ int ygz_hip_track_sparse_align(ygz_hip_ctx *ctx, int max_level, int min_level, i
 {
     if (!ctx || min_level < 0 || max_level < min_level || max_level >= ctx->prm.pyramid_levels || n_iter < 0) return YGZ_E_INVALID;
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    YgzAuxScope aux(ctx, 0);
     return ygz_launch_sparse_align(ctx, ctx->n_pairs, max_level, min_level, n_iter);
 }
 
 static int pair_count(ygz_hip_ctx *ctx, int pair, int *n)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (pair < 0 || pair >= ctx->n_pairs || !ctx->trk_alloc) return YGZ_E_INVALID;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(n, ctx->trk_n + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -195,6 +200,7 @@ int ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *le
 
 int ygz_hip_track_get_pose(ygz_hip_ctx *ctx, int pair, double T[7], int *n_meas, int *iters)
 {
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || pair < 0 || pair >= ctx->n_pairs || !ctx->trk_alloc) return YGZ_E_INVALID;
     double h[16];
     YGZ_HIPCHK(ctx, hipMemcpyAsync(h, ctx->sa_out + 16 * (size_t)pair, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));

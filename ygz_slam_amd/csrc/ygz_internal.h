@@ -69,6 +69,12 @@ struct ygz_hip_ctx {
     size_t   sa_work_stride = 0;
     int      deriv_slots = 0;                // slots covered by the Scharr buffers
 
+    // optional stage overlap: independent resident stages run on side streams (forked from / joined to `stream`)
+    int overlap = 0;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    bool aux_pending[3] = {false, false, false};
+
     // per-kernel HIP-event probe (bench.py roofline leg): events around every launch of ONE chosen kernel
     int probe_id = -1, probe_used = 0;
     std::vector<hipEvent_t> probe_ev;
@@ -107,6 +113,27 @@ enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR
        SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_GEN_0 = 16 };
 
 int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
+int ygz_join(ygz_hip_ctx *ctx);          // main stream waits for every pending side-stream stage
+
+// RAII: run the enclosed launches on side stream `idx` (sparse-align 0, BA 1, matcher 2) when overlap is enabled.
+// The side stream first waits for everything already enqueued on the main stream (fork), and the main stream waits
+// for it at the next ygz_join (any entry point that reads or overwrites shared state, and ygz_hip_synchronize).
+struct YgzAuxScope {
+    ygz_hip_ctx *c; int idx; hipStream_t saved; bool active;
+    YgzAuxScope(ygz_hip_ctx *ctx, int i) : c(ctx), idx(i), saved(ctx->stream), active(false)
+    {
+        if (!ctx->overlap || !ctx->aux[i]) return;
+        if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess) return;
+        if (hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0) != hipSuccess) return;
+        ctx->stream = ctx->aux[i]; active = true;
+    }
+    ~YgzAuxScope()
+    {
+        if (!active) return;
+        (void)hipEventRecord(c->ev_join[idx], c->aux[idx]);
+        c->stream = saved; c->aux_pending[idx] = true;
+    }
+};
 int ygz_ensure_levels(ygz_hip_ctx *ctx, int n_levels);      // allocates image levels up to n_levels
 
 // launchers implemented in the kernel translation units
@@ -130,6 +157,57 @@ __device__ __forceinline__ uint32_t ygz_f2ord(float f)
 {
     uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// XCD-aware block mapping for 2-D grids (x = work inside one frame / frame pair, y = frame or pair index).
+// MI355X dispatches workgroup L to XCD L % 8 and every XCD has a private 4 MiB L2.  With the natural mapping the 8
+// XCDs all stream the same frame at the same time (8 copies in 8 L2s); here frame/pair y is pinned to XCD y % 8, so
+// each L2 holds only its own frames and a frame's pixels are fetched from HBM once.  Launch with
+// gridDim.y = round_up(n_outer, 8).  Pure performance: any placement gives the same results.
+__device__ __forceinline__ bool ygz_xcd_remap(int n_outer, int &bx, int &outer)
+{
+    const int nbx = (int)gridDim.x;
+    const int L = (int)blockIdx.x + nbx * (int)blockIdx.y;
+    const int xcd = L & 7, j = L >> 3;
+    const int ol = j / nbx;
+    bx = j - ol * nbx;
+    outer = ol * 8 + xcd;
+    return outer < n_outer;
+}
+// same for 3-D grids: (x, y) = tile inside a frame, z = frame / pair index; launch with gridDim.z = round_up(n_outer, 8)
+__device__ __forceinline__ bool ygz_xcd_remap3(int n_outer, int &bx, int &by, int &outer)
+{
+    const int nx = (int)gridDim.x, nb = nx * (int)gridDim.y;
+    const int L = (int)blockIdx.x + nx * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
+    const int xcd = L & 7, j = L >> 3;
+    const int ol = j / nb, r = j - ol * nb;
+    by = r / nx; bx = r - by * nx;
+    outer = ol * 8 + xcd;
+    return outer < n_outer;
+}
+static inline int ygz_round_up8(int n) { return (n + 7) & ~7; }
+
+// Wave64 float sum on the DPP data path (row-local adds + 4 readlanes) instead of 6 rounds of ds_bpermute: the
+// cross-lane latency drops from ~6 x LDS round trips to a few dependent VALU ops.  Fixed order:
+// ((q ^ 1) , (q ^ 2)) inside quads, half-row mirror, row mirror, then rows 0..3 left to right.  Result is uniform.
+__device__ __forceinline__ float ygz_wave_sum_f(float v)
+{
+    v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)));   // quad_perm [1,0,3,2]
+    v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));   // quad_perm [2,3,0,1]
+    v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));  // row_half_mirror
+    v = __fadd_rn(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));  // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return __fadd_rn(__fadd_rn(__fadd_rn(r0, r1), r2), r3);
+}
+__device__ __forceinline__ int ygz_wave_sum_i(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 // correctly rounded float sqrt: the native v_sqrt_f32 path is 1 ulp; sqrt in double then one rounding is
 // exact for float inputs (53 >= 2*24+2 bits)
