@@ -4,20 +4,29 @@
 // the frozen specification in oracle/klt.c (OpenCV generic path: int16 Scharr derivatives, 14-bit
 // fixed-point bilinear weights, int16 patch <<5, float normal equations).
 //
+//  k_klt_pad  the tracker's working images: every pyramid level of the slots in the pair table copied into a
+//             buffer with a 24-pixel BORDER_REFLECT_101 frame (what buildOpticalFlowPyramid does with copyMakeBorder),
+//             so that no window access in k_klt ever needs border logic.
 //  k_scharr   one lane per pixel: 3/10/3 Scharr of the previous image per level (reflect-101 inside
-//             the image exactly as calcSharrDeriv), 2 x int16 per pixel, 4-byte stores.
+//             the image exactly as calcSharrDeriv), 2 x int16 per pixel, written into a zero-framed buffer
+//             (BORDER_CONSTANT 0 around the derivative, as the reference does).
 //  k_klt      one wavefront per point, all pyramid levels inside one launch (points are independent,
-//             so no per-level launch boundary): the 441-pixel window is spread over the 64 lanes
-//             (7 pixels per lane); the previous-image patch and its derivatives (3 x int16 per pixel)
-//             stay in LDS for the whole iteration loop; every iteration gathers the moving 22x22
-//             window of the next image, forms the two mismatch sums and reduces them with wave
-//             shuffles in a FIXED order.  The integer terms are identical to the oracle's; each lane adds its 7
-//             terms exactly in integers and the 63 lane sums are combined by a float tree (the oracle adds all 441
-//             terms in float in raster order): same quantities, different rounding, well inside the 1e-5 track tolerance.
+//             so no per-level launch boundary).  3 lanes per window row x 7 consecutive pixels (21 = 3 x 7):
+//             the previous-image patch and its derivatives stay in registers for the whole level; every iteration
+//             fetches its 2 x 8 source bytes per lane with 3 aligned dword loads + v_alignbyte (a wave-wide byte gather
+//             costs the address unit as much as a dword load), forms the two mismatch sums with full-rate 24-bit
+//             mads, and reduces them on the DPP data path in a FIXED order.  The integer terms are identical to the
+//             oracle's; each lane adds its 7 terms exactly in integers and the 63 lane sums are combined by a float
+//             tree (the oracle adds all 441 terms in float in raster order): same quantities, different rounding,
+//             well inside the 1e-5 track tolerance.
 #include "ygz_internal.h"
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define KLT_MAXWIN 21
+#define KLT_B      24          // reflect-101 frame around every level (>= window + 1, multiple of 4)
+#define KLT_PW(w)  (((w) + 2 * KLT_B + 3) & ~3)      // framed row pitch, 4-byte aligned for any level width
 
 __device__ __forceinline__ int refl101(int i, int n)
 {
@@ -26,7 +35,25 @@ __device__ __forceinline__ int refl101(int i, int n)
     return i;
 }
 
-// calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1)
+// padded copy: out[(y+B)*(w+2B) + x+B] = in[refl101(y)][refl101(x)], 4 output pixels per lane
+__global__ __launch_bounds__(256) void k_klt_pad(const uint8_t *__restrict__ img_base, uint8_t *__restrict__ pad_base,
+                                                 const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
+                                                 int w, int h, int n_pairs)
+{
+    int bx_, by_, z_;
+    if (!ygz_xcd_remap3(2 * n_pairs, bx_, by_, z_)) return;
+    const int pw = KLT_PW(w), ph = h + 2 * KLT_B;
+    const int x4 = (bx_ * 64 + (threadIdx.x & 63)) * 4, y = by_ * 4 + (threadIdx.x >> 6);
+    if (x4 >= pw || y >= ph) return;
+    const size_t slot = (size_t)((z_ & 1) ? pair_q[z_ >> 1] : pair_t[z_ >> 1]);
+    const uint8_t *row = img_base + slot * (size_t)w * h + (size_t)refl101(y - KLT_B, h) * w;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v |= (uint32_t)row[refl101(x4 + k - KLT_B, w)] << (8 * k);
+    *reinterpret_cast<uint32_t *>(pad_base + slot * (size_t)pw * ph + (size_t)y * pw + x4) = v;
+}
+
+// calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1); output zero-framed
 __global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img_base, int16_t *__restrict__ deriv_base,
                                                 const int32_t *__restrict__ pair_t, int w, int h, int n_pairs)
 {
@@ -35,8 +62,9 @@ __global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img_
     const int x = bx_ * 64 + (threadIdx.x & 63), y = by_ * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const size_t slot = (size_t)pair_t[pr_];                   // reference slot of this pair
+    const int pw = KLT_PW(w), ph = h + 2 * KLT_B;
     const uint8_t *img = img_base + slot * (size_t)w * h;
-    int16_t *deriv = deriv_base + slot * (size_t)w * h * 2;
+    uint32_t *deriv = reinterpret_cast<uint32_t *>(deriv_base) + slot * (size_t)pw * ph;
     const int y0 = y > 0 ? y - 1 : (h > 1 ? 1 : 0), y2 = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
     const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
     const uint8_t *r0 = img + (size_t)y0 * w, *r1 = img + (size_t)y * w, *r2 = img + (size_t)y2 * w;
@@ -45,12 +73,12 @@ __global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img_
     const int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
     const int dx = (int16_t)(t0p - t0m);
     const int dy = (int16_t)((t1p + t1m) * 3 + t1c * 10);
-    reinterpret_cast<uint32_t *>(deriv)[(size_t)y * w + x] = ((uint32_t)(uint16_t)dx) | ((uint32_t)(uint16_t)dy << 16);
+    deriv[(size_t)(y + KLT_B) * pw + (x + KLT_B)] = ((uint32_t)(uint16_t)dx) | ((uint32_t)(uint16_t)dy << 16);
 }
 
 struct KltArgs {
-    const uint8_t *lvl[YGZ_MAX_LEVELS];                            // level images, slot-major
-    const int16_t *deriv[YGZ_MAX_LEVELS];                          // Scharr images, slot-major
+    const uint8_t *pad[YGZ_MAX_LEVELS];                            // reflect-framed level images, slot-major
+    const int16_t *deriv[YGZ_MAX_LEVELS];                          // zero-framed Scharr images, slot-major
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
     int max_level, win, max_count, use_initial_flow, cells, n_pairs;
     double epsilon;            // already squared
@@ -58,6 +86,7 @@ struct KltArgs {
     const int32_t *pair_q, *pair_t, *trk_n;                        // cur slot, ref slot, points per pair
     const double *trk_px;                                          // [pairs][cells][2] reference pixels
     float *next_pts; uint8_t *status; float *err;                  // [pairs][cells]
+    long long *dbg;                                                // optional per-point cycle counters [pairs*cells][4]
 };
 
 #define wave_sum_f ygz_wave_sum_f
@@ -65,13 +94,13 @@ struct KltArgs {
 __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
 #define KLT_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
 
-// 8 consecutive bytes from an arbitrary byte address: 3 aligned dword loads + v_alignbyte (a wave-wide byte
-// gather costs the same address-unit time per instruction as a dword load, so bytes are fetched 8 at a time)
+typedef const __attribute__((address_space(1))) uint32_t *klt_gptr;      // global (not flat) loads
+
+// 8 consecutive bytes from an arbitrary byte address: 3 aligned dword loads + v_alignbyte
 __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    typedef const __attribute__((address_space(1))) uint32_t *gptr;      // global, not flat: plain global_load
-    gptr q = (gptr)(a & ~(uintptr_t)3);
+    klt_gptr q = (klt_gptr)(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3);
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
     lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
@@ -83,10 +112,12 @@ __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32
 #define KLT_MAD(a, b, c) ((int)__mul24((int)(a), (int)(b)) + (int)(c))
 #define KLT_BIL9V(v00, v01, v10, v11) ((KLT_MAD(v00, iw00, KLT_MAD(v01, iw01, KLT_MAD(v10, iw10, KLT_MAD(v11, iw11, 256))))) >> 9)
 #define KLT_BIL14(v00, v01, v10, v11) ((KLT_MAD(v00, iw00, KLT_MAD(v01, iw01, KLT_MAD(v10, iw10, KLT_MAD(v11, iw11, 8192))))) >> 14)
+#define KLT_WEIGHTS(a, b)                                                                        \
+    iw00 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), __fsub_rn(1.f, b)), 16384.f));     \
+    iw01 = cv_round_f(__fmul_rn(__fmul_rn(a, __fsub_rn(1.f, b)), 16384.f));                     \
+    iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));                     \
+    iw11 = 16384 - iw00 - iw01 - iw10
 
-// Lane mapping: 3 lanes per window row, 7 consecutive pixels per lane (21 = 3 x 7; 63 of 64 lanes busy).
-// Interior windows (the common case) fetch their 2 x 8 source bytes per row with 6 dword loads per iteration
-// instead of 28 byte gathers; windows that touch the image border take the reflect-101 per-pixel path.
 __global__ __launch_bounds__(256) void k_klt(KltArgs A)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -104,14 +135,17 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
     float outy = A.use_initial_flow ? A.next_pts[2 * p + 1] : ppy;
     bool status = true;
     float errv = 0.f;
+    long long t_start = A.dbg ? clock64() : 0; int n_it = 0;
     const int row = lane / 3, x0 = 7 * (lane - 3 * row);
     const bool act = row < win && x0 < win;
-    const int npx = act ? min(7, win - x0) : 0;
+    const int npx = act ? min(7, win - x0) : 0;    // pixels of this lane (7 for the 21-wide window)
 
     for (int level = A.max_level; level >= 0; --level) {
         const int w = A.w[level], h = A.h[level];
-        const uint8_t *I = A.lvl[level] + ref_slot * (size_t)w * h, *J = A.lvl[level] + cur_slot * (size_t)w * h;
-        const uint32_t *D = reinterpret_cast<const uint32_t *>(A.deriv[level]) + ref_slot * (size_t)w * h;
+        const int pw = KLT_PW(w);
+        const size_t psz = (size_t)pw * (h + 2 * KLT_B), org = (size_t)KLT_B * pw + KLT_B;
+        const uint8_t *I = A.pad[level] + ref_slot * psz + org, *J = A.pad[level] + cur_slot * psz + org;
+        klt_gptr D = (klt_gptr)(reinterpret_cast<const uint32_t *>(A.deriv[level]) + ref_slot * psz + org);
         const float s = (float)(1. / (double)(1 << level));
         float prevx = __fmul_rn(ppx, s), prevy = __fmul_rn(ppy, s);
         float nx, ny;
@@ -125,55 +159,31 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             continue;
         }
         float a = __fsub_rn(prevx, (float)ipx), b = __fsub_rn(prevy, (float)ipy);
-        int iw00 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), __fsub_rn(1.f, b)), 16384.f));
-        int iw01 = cv_round_f(__fmul_rn(__fmul_rn(a, __fsub_rn(1.f, b)), 16384.f));
-        int iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));
-        int iw11 = 16384 - iw00 - iw01 - iw10;
+        int iw00, iw01, iw10, iw11;
+        KLT_WEIGHTS(a, b);
         float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
         // the lane's 7 patch values (int16 image <<5, int16 derivatives) stay in registers for the whole level
         int iI[7], iDx[7], iDy[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) { iI[k] = 0; iDx[k] = 0; iDy[k] = 0; }
-        const bool insideI = ipx >= 0 && ipy >= 0 && ipx + win < w && ipy + win < h;
         if (act) {
-            if (insideI) {
-                const int o = (ipy + row) * w + ipx + x0;
-                uint32_t l0, h0, l1, h1;
-                klt_load8(I + o, l0, h0); klt_load8(I + o + w, l1, h1);
-                uint32_t d0[8], d1[8];
+            const int o = (ipy + row) * pw + ipx + x0;          // inside the framed buffer for every admissible window
+            uint32_t l0, h0, l1, h1;
+            klt_load8(I + o, l0, h0); klt_load8(I + o + pw, l1, h1);
+            uint32_t d0[8], d1[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { d0[k] = D[o + k]; d1[k] = D[o + w + k]; }
+            for (int k = 0; k < 8; ++k) { d0[k] = D[o + k]; d1[k] = D[o + pw + k]; }
+            long long q11 = 0, q12 = 0, q22 = 0;                // exact per-lane sums
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    if (k < npx) {
-                        const int ival = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1));
-                        const int ixval = KLT_BIL14((int)(int16_t)(d0[k] & 0xFFFF), (int)(int16_t)(d0[k + 1] & 0xFFFF), (int)(int16_t)(d1[k] & 0xFFFF), (int)(int16_t)(d1[k + 1] & 0xFFFF));
-                        const int iyval = KLT_BIL14((int)(int16_t)(d0[k] >> 16), (int)(int16_t)(d0[k + 1] >> 16), (int)(int16_t)(d1[k] >> 16), (int)(int16_t)(d1[k + 1] >> 16));
-                        iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    if (k < npx) {
-                        const int X = ipx + x0 + k, Y = ipy + row;
-                        const int X0 = refl101(X, w), X1 = refl101(X + 1, w), Y0 = refl101(Y, h), Y1 = refl101(Y + 1, h);
-                        const int ival = KLT_BIL9V((int)I[Y0 * w + X0], (int)I[Y0 * w + X1], (int)I[Y1 * w + X0], (int)I[Y1 * w + X1]);
-                        const bool x0in = X >= 0 && X < w, x1in = X + 1 >= 0 && X + 1 < w, y0in = Y >= 0 && Y < h, y1in = Y + 1 >= 0 && Y + 1 < h;
-                        const uint32_t d00 = (x0in && y0in) ? D[Y * w + X] : 0u, d01 = (x1in && y0in) ? D[Y * w + X + 1] : 0u;
-                        const uint32_t d10 = (x0in && y1in) ? D[(Y + 1) * w + X] : 0u, d11 = (x1in && y1in) ? D[(Y + 1) * w + X + 1] : 0u;
-                        const int ixval = KLT_DESCALE((int)(int16_t)(d00 & 0xFFFF) * iw00 + (int)(int16_t)(d01 & 0xFFFF) * iw01 +
-                                                      (int)(int16_t)(d10 & 0xFFFF) * iw10 + (int)(int16_t)(d11 & 0xFFFF) * iw11, 14);
-                        const int iyval = KLT_DESCALE((int)(int16_t)(d00 >> 16) * iw00 + (int)(int16_t)(d01 >> 16) * iw01 +
-                                                      (int)(int16_t)(d10 >> 16) * iw10 + (int)(int16_t)(d11 >> 16) * iw11, 14);
-                        iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
-                    }
+            for (int k = 0; k < 7; ++k) {
+                if (k < npx) {
+                    const int ival = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1));
+                    const int ixval = KLT_BIL14((int)(int16_t)(d0[k] & 0xFFFF), (int)(int16_t)(d0[k + 1] & 0xFFFF), (int)(int16_t)(d1[k] & 0xFFFF), (int)(int16_t)(d1[k + 1] & 0xFFFF));
+                    const int iyval = KLT_BIL14((int)(int16_t)(d0[k] >> 16), (int)(int16_t)(d0[k + 1] >> 16), (int)(int16_t)(d1[k] >> 16), (int)(int16_t)(d1[k + 1] >> 16));
+                    iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
+                    q11 += __mul24(iDx[k], iDx[k]); q12 += __mul24(iDx[k], iDy[k]); q22 += __mul24(iDy[k], iDy[k]);
                 }
             }
-            // exact per-lane sums (7 terms < 2^27 each fit int32 only for two... use float of the exact 64-bit sum)
-            long long q11 = 0, q12 = 0, q22 = 0;
-#pragma unroll
-            for (int k = 0; k < 7; ++k) { q11 += __mul24(iDx[k], iDx[k]); q12 += __mul24(iDx[k], iDy[k]); q22 += __mul24(iDy[k], iDy[k]); }
             sA11 = (float)q11; sA12 = (float)q12; sA22 = (float)q22;
         }
         const float A11 = __fmul_rn(wave_sum_f(sA11), FLT_SCALE), A12 = __fmul_rn(wave_sum_f(sA12), FLT_SCALE),
@@ -196,41 +206,24 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
                 if (level == 0) status = false;
                 break;
             }
+            ++n_it;
             a = __fsub_rn(nx, (float)inx); b = __fsub_rn(ny, (float)iny);
-            iw00 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), __fsub_rn(1.f, b)), 16384.f));
-            iw01 = cv_round_f(__fmul_rn(__fmul_rn(a, __fsub_rn(1.f, b)), 16384.f));
-            iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));
-            iw11 = 16384 - iw00 - iw01 - iw10;
+            KLT_WEIGHTS(a, b);
             float sb1 = 0.f, sb2 = 0.f;
-            const bool insideJ = inx >= 0 && iny >= 0 && inx + win < w && iny + win < h;
             if (act) {
-                if (insideJ) {
-                    const int o = (iny + row) * w + inx + x0;
-                    uint32_t l0, h0, l1, h1;
-                    klt_load8(J + o, l0, h0); klt_load8(J + o + w, l1, h1);
-                    // the lane's 7 terms are summed exactly in int32 (|diff*I| < 2^26), converted once; pixels beyond
-                    // the window (k >= npx) carry iDx = iDy = 0
-                    int a1 = 0, a2 = 0;
+                const int o = (iny + row) * pw + inx + x0;
+                uint32_t l0, h0, l1, h1;
+                klt_load8(J + o, l0, h0); klt_load8(J + o + pw, l1, h1);
+                // the lane's 7 terms are summed exactly in int32 (|diff*I| < 2^26), converted once; pixels beyond the
+                // window (k >= npx) carry iDx = iDy = 0, so whatever diff they form is multiplied by 0
+                int a1 = 0, a2 = 0;
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
-                        a1 = KLT_MAD(diff, iDx[k], a1);
-                        a2 = KLT_MAD(diff, iDy[k], a2);
-                    }
-                    sb1 = (float)a1; sb2 = (float)a2;
-                } else {
-                    int a1 = 0, a2 = 0;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        if (k < npx) {
-                            const int X0 = refl101(inx + x0 + k, w), X1 = refl101(inx + x0 + k + 1, w), Y0 = refl101(iny + row, h), Y1 = refl101(iny + row + 1, h);
-                            const int diff = KLT_BIL9V((int)J[Y0 * w + X0], (int)J[Y0 * w + X1], (int)J[Y1 * w + X0], (int)J[Y1 * w + X1]) - iI[k];
-                            a1 = KLT_MAD(diff, iDx[k], a1);
-                            a2 = KLT_MAD(diff, iDy[k], a2);
-                        }
-                    }
-                    sb1 = (float)a1; sb2 = (float)a2;
+                for (int k = 0; k < 7; ++k) {
+                    const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
+                    a1 = KLT_MAD(diff, iDx[k], a1);
+                    a2 = KLT_MAD(diff, iDy[k], a2);
                 }
+                sb1 = (float)a1; sb2 = (float)a2;
             }
             const float b1 = __fmul_rn(wave_sum_f(sb1), FLT_SCALE), b2 = __fmul_rn(wave_sum_f(sb2), FLT_SCALE);
             const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), Dd);
@@ -249,17 +242,18 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             const int inx = (int)floorf(qx), iny = (int)floorf(qy);
             if (inx < -win || inx >= w || iny < -win || iny >= h) { status = false; continue; }
             const float aa = __fsub_rn(qx, (float)inx), bb = __fsub_rn(qy, (float)iny);
-            iw00 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, aa), __fsub_rn(1.f, bb)), 16384.f));
-            iw01 = cv_round_f(__fmul_rn(__fmul_rn(aa, __fsub_rn(1.f, bb)), 16384.f));
-            iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, aa), bb), 16384.f));
-            iw11 = 16384 - iw00 - iw01 - iw10;
+            KLT_WEIGHTS(aa, bb);
             float se = 0.f;
+            if (act) {
+                const int o = (iny + row) * pw + inx + x0;
+                uint32_t l0, h0, l1, h1;
+                klt_load8(J + o, l0, h0); klt_load8(J + o + pw, l1, h1);
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                if (k < npx) {
-                    const int X0 = refl101(inx + x0 + k, w), X1 = refl101(inx + x0 + k + 1, w), Y0 = refl101(iny + row, h), Y1 = refl101(iny + row + 1, h);
-                    const int diff = KLT_BIL9V((int)J[Y0 * w + X0], (int)J[Y0 * w + X1], (int)J[Y1 * w + X0], (int)J[Y1 * w + X1]) - iI[k];
-                    se = __fadd_rn(se, fabsf((float)diff));
+                for (int k = 0; k < 7; ++k) {
+                    if (k < npx) {
+                        const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
+                        se = __fadd_rn(se, fabsf((float)diff));
+                    }
                 }
             }
             errv = __fdiv_rn(__fmul_rn(wave_sum_f(se), 1.f), (float)(32 * win * win));
@@ -268,6 +262,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
     if (lane == 0) {
         A.next_pts[2 * p] = outx; A.next_pts[2 * p + 1] = outy;
         A.status[p] = (uint8_t)status; A.err[p] = errv;
+        if (A.dbg) { A.dbg[4 * p] = clock64() - t_start; A.dbg[4 * p + 3] = n_it; }
     }
 }
 
@@ -287,13 +282,20 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
             if (ctx->pyr_valid[s] && (rc = ygz_launch_gray_pyramid(ctx, s, 1, 0, max_level + 1)) != YGZ_OK) return rc;
     }
     KltArgs A;
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = nullptr; A.deriv[L] = nullptr; A.w[L] = A.h[L] = 0; }
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.pad[L] = nullptr; A.deriv[L] = nullptr; A.w[L] = A.h[L] = 0; }
     for (int L = 0; L <= max_level; ++L) {
-        const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
-        if (!ctx->deriv[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->deriv[L], (size_t)ctx->prm.max_frames * npix * 4 + 64));
-        A.lvl[L] = ctx->lvl[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L];
-        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(A.w[L], 64), ygz_div_up(A.h[L], 4), ygz_round_up8(n_pairs)), dim3(256),
-                           ctx->lvl[L], ctx->deriv[L], ctx->pair_t, A.w[L], A.h[L], n_pairs);
+        const int w = ctx->lw[L], h = ctx->lh[L], pw = KLT_PW(w), ph = h + 2 * KLT_B;
+        const size_t psz = (size_t)pw * ph;
+        if (!ctx->deriv[L]) {
+            YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->deriv[L], (size_t)ctx->prm.max_frames * psz * 4 + 64));
+            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->deriv[L], 0, (size_t)ctx->prm.max_frames * psz * 4 + 64, ctx->stream));   // the zero frame
+        }
+        if (!ctx->klt_pad[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_pad[L], (size_t)ctx->prm.max_frames * psz + 64));
+        A.pad[L] = ctx->klt_pad[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = w; A.h[L] = h;
+        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(pw / 4, 64), ygz_div_up(ph, 4), ygz_round_up8(2 * n_pairs)), dim3(256),
+                   ctx->lvl[L], ctx->klt_pad[L], ctx->pair_q, ctx->pair_t, w, h, n_pairs);
+        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(w, 64), ygz_div_up(h, 4), ygz_round_up8(n_pairs)), dim3(256),
+                   ctx->lvl[L], ctx->deriv[L], ctx->pair_t, w, h, n_pairs);
     }
     A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);
@@ -303,8 +305,19 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
     A.use_initial_flow = prm->use_initial_flow;
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.trk_px = ctx->trk_px;
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
+    A.dbg = nullptr;
+    if (getenv("YGZ_KLT_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_KLT_OUT, (size_t)n_pairs * ctx->cells * 32, &d) == YGZ_OK) { A.dbg = (long long *)d; (void)hipMemsetAsync(d, 0, (size_t)n_pairs * ctx->cells * 32, ctx->stream); } }
     YGZ_LAUNCH(ctx, KID_KLT, k_klt, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
+    if (A.dbg) {
+        const size_t nn = (size_t)n_pairs * ctx->cells;
+        std::vector<long long> h(4 * nn);
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(h.data(), A.dbg, nn * 32, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        double tot = 0, ni = 0, np = 0;
+        for (size_t i = 0; i < nn; ++i) if (h[4 * i] > 0) { tot += h[4 * i]; ni += h[4 * i + 3]; np += 1; }
+        if (np > 0) fprintf(stderr, "[klt-debug] points %.0f: cycles/point %.0f, iterations/point %.1f\n", np, tot / np, ni / np);
+    }
     return YGZ_OK;
 }
 

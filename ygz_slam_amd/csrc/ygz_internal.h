@@ -28,6 +28,7 @@ struct ygz_hip_ctx {
     std::vector<uint8_t> pyr_valid;         // per slot: pyramid built
     // Scharr derivative levels for KLT (int16 x2 per pixel), allocated on first KLT call
     int16_t *deriv[YGZ_MAX_LEVELS] = {nullptr};
+    uint8_t *klt_pad[YGZ_MAX_LEVELS] = {nullptr};       // reflect-101 framed copies of the levels (KLT working images)
 
     // extractor state per slot
     uint32_t *cell_first = nullptr;         // [F][cells]  min over candidates of (visit<<1 | isnan)
@@ -99,7 +100,7 @@ static inline int ygz_div_up(int a, int b) { return (a + b - 1) / b; }
 
 // kernel ids for the probe
 enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIBE, KID_HAMMING_NN, KID_MATCH_FINALIZE,
-       KID_TRACK_LOAD, KID_FDP, KID_ALIGN2D, KID_SPARSE_ALIGN, KID_SCHARR, KID_KLT, KID_BA_POSE_PREP, KID_BA_POINTS,
+       KID_TRACK_LOAD, KID_FDP, KID_ALIGN2D, KID_SPARSE_ALIGN, KID_SCHARR, KID_KLT, KID_KLT_PAD, KID_BA_POSE_PREP, KID_BA_POINTS,
        KID_BA_POSES, KID_BA_CHI2, KID_COUNT };
 
 #define YGZ_LAUNCH(ctx, kid, kern, grid, block, ...)                                                         \
