@@ -118,6 +118,8 @@ __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32
     iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));                     \
     iw11 = 16384 - iw00 - iw01 - iw10
 
+// FULL: the 21-wide window (every active lane owns exactly 7 pixels) -- the per-pixel guards fold away
+template <bool FULL>
 __global__ __launch_bounds__(256) void k_klt(KltArgs A)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
     long long t_start = A.dbg ? clock64() : 0; int n_it = 0;
     const int row = lane / 3, x0 = 7 * (lane - 3 * row);
     const bool act = row < win && x0 < win;
-    const int npx = act ? min(7, win - x0) : 0;    // pixels of this lane (7 for the 21-wide window)
+    const int npx = FULL ? 7 : (act ? min(7, win - x0) : 0);    // pixels of this lane (7 for the 21-wide window)
 
     for (int level = A.max_level; level >= 0; --level) {
         const int w = A.w[level], h = A.h[level];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
         const size_t psz = (size_t)pw * (h + 2 * KLT_B), org = (size_t)KLT_B * pw + KLT_B;
         const uint8_t *I = A.pad[level] + ref_slot * psz + org, *J = A.pad[level] + cur_slot * psz + org;
         klt_gptr D = (klt_gptr)(reinterpret_cast<const uint32_t *>(A.deriv[level]) + ref_slot * psz + org);
-        const float s = (float)(1. / (double)(1 << level));
+        const float s = __int_as_float((127 - level) << 23);       // (float)(1. / (1 << level)), exact
         float prevx = __fmul_rn(ppx, s), prevy = __fmul_rn(ppy, s);
         float nx, ny;
         if (level == A.max_level) { nx = __fmul_rn(outx, s); ny = __fmul_rn(outy, s); }
@@ -173,10 +175,10 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             uint32_t d0[8], d1[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) { d0[k] = D[o + k]; d1[k] = D[o + pw + k]; }
-            long long q11 = 0, q12 = 0, q22 = 0;                // exact per-lane sums
+            int q11 = 0, q12 = 0, q22 = 0;                      // exact per-lane sums: Scharr of u8 is < 2^12, 7 products < 2^27
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
-                if (k < npx) {
+                if (FULL || k < npx) {
                     const int ival = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1));
                     const int ixval = KLT_BIL14((int)(int16_t)(d0[k] & 0xFFFF), (int)(int16_t)(d0[k + 1] & 0xFFFF), (int)(int16_t)(d1[k] & 0xFFFF), (int)(int16_t)(d1[k + 1] & 0xFFFF));
                     const int iyval = KLT_BIL14((int)(int16_t)(d0[k] >> 16), (int)(int16_t)(d0[k + 1] >> 16), (int)(int16_t)(d1[k] >> 16), (int)(int16_t)(d1[k + 1] >> 16));
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
                 klt_load8(J + o, l0, h0); klt_load8(J + o + pw, l1, h1);
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
-                    if (k < npx) {
+                    if (FULL || k < npx) {
                         const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
                         se = __fadd_rn(se, fabsf((float)diff));
                     }
@@ -307,7 +309,8 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
     A.dbg = nullptr;
     if (getenv("YGZ_KLT_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_KLT_OUT, (size_t)n_pairs * ctx->cells * 32, &d) == YGZ_OK) { A.dbg = (long long *)d; (void)hipMemsetAsync(d, 0, (size_t)n_pairs * ctx->cells * 32, ctx->stream); } }
-    YGZ_LAUNCH(ctx, KID_KLT, k_klt, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
+    if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
+    else YGZ_LAUNCH(ctx, KID_KLT, k_klt<false>, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         const size_t nn = (size_t)n_pairs * ctx->cells;
