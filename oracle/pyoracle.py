@@ -83,6 +83,34 @@ class BaProblem(C.Structure):
                 ("huber_delta", C.c_double)]
 
 
+class CeresProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("poses", C.POINTER(C.c_double)), ("pose_fixed", C.POINTER(C.c_uint8)),
+                ("points", C.POINTER(C.c_double)), ("point_fixed", C.POINTER(C.c_uint8)),
+                ("edge_pose", C.POINTER(C.c_int32)), ("edge_point", C.POINTER(C.c_int32)),
+                ("obs_n", C.POINTER(C.c_double)), ("edge_huber", C.POINTER(C.c_double)),
+                ("edge_enable", C.POINTER(C.c_uint8)), ("fail_behind_camera", C.c_int)]
+
+
+class CeresOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int)]
+
+
+class CeresSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("successful_steps", C.c_int), ("unsuccessful_steps", C.c_int),
+                ("termination", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("final_radius", C.c_double)]
+
+
+class LmStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("lm_trials", C.c_int), ("chi2_initial", C.c_double),
+                ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
@@ -407,6 +435,101 @@ class Oracle:
         self.lib.yo_ba_edge_error_norm(_f64(pose_tw), _f64(pt), _f64(obs_n), _f64(err))
         self.lib.yo_ba_edge_jacobians_norm(_f64(pose_tw), _f64(pt), _f64(Jp), _f64(Jx))
         return err, Jp.reshape(2, 3), Jx.reshape(2, 6)
+
+    # ---- ceres-side rows (oracle/ceres_ba.c) ----
+    def ceres_edge(self, pose_taa, pt, obs_n):
+        pose = np.ascontiguousarray(pose_taa, np.float64)
+        pt = np.ascontiguousarray(pt, np.float64)
+        obs_n = np.ascontiguousarray(obs_n, np.float64)
+        r, Jx, Jp, z = np.empty(2), np.empty(12), np.empty(6), C.c_double()
+        self.lib.yo_ceres_edge(_f64(pose), _f64(pt), _f64(obs_n), _f64(r), _f64(Jx), _f64(Jp), C.byref(z))
+        return r, Jp.reshape(2, 3), Jx.reshape(2, 6), z.value
+
+    def ceres_rotate_point(self, aa, p):
+        aa = np.ascontiguousarray(aa, np.float64)
+        p = np.ascontiguousarray(p, np.float64)
+        out = np.empty(3)
+        self.lib.yo_ceres_rotate_point(_f64(aa), _f64(p), _f64(out))
+        return out
+
+    def _ceres_problem(self, poses, pose_fixed, points, point_fixed, edge_pose, edge_point, obs_n, edge_huber,
+                       edge_enable, fail_behind):
+        keep = dict(poses=np.ascontiguousarray(poses, np.float64).reshape(-1, 6).copy(),
+                    points=np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy(),
+                    edge_pose=np.ascontiguousarray(edge_pose, np.int32), edge_point=np.ascontiguousarray(edge_point, np.int32),
+                    obs_n=np.ascontiguousarray(obs_n, np.float64))
+        for k, v in (("pose_fixed", pose_fixed), ("point_fixed", point_fixed), ("edge_enable", edge_enable)):
+            keep[k] = None if v is None else np.ascontiguousarray(v, np.uint8)
+        keep["edge_huber"] = None if edge_huber is None else np.ascontiguousarray(edge_huber, np.float64)
+        nul8, nulf = C.POINTER(C.c_uint8)(), C.POINTER(C.c_double)()
+        pb = CeresProblem(len(keep["poses"]), len(keep["points"]), len(keep["edge_pose"]), _f64(keep["poses"]),
+                          nul8 if keep["pose_fixed"] is None else _u8(keep["pose_fixed"]), _f64(keep["points"]),
+                          nul8 if keep["point_fixed"] is None else _u8(keep["point_fixed"]),
+                          _p(keep["edge_pose"], C.c_int32), _p(keep["edge_point"], C.c_int32), _f64(keep["obs_n"]),
+                          nulf if keep["edge_huber"] is None else _f64(keep["edge_huber"]),
+                          nul8 if keep["edge_enable"] is None else _u8(keep["edge_enable"]), int(bool(fail_behind)))
+        return pb, keep
+
+    def ceres_linearize(self, poses, pose_fixed, points, edge_pose, edge_point, obs_n, point_fixed=None, edge_huber=None,
+                        edge_enable=None, fail_behind=False):
+        pb, keep = self._ceres_problem(poses, pose_fixed, points, point_fixed, edge_pose, edge_point, obs_n, edge_huber,
+                                       edge_enable, fail_behind)
+        K, P, E = pb.n_poses, pb.n_points, pb.n_edges
+        out = dict(Hpp=np.empty((K, 6, 6)), bp=np.empty((K, 6)), Hll=np.empty((P, 3, 3)), bl=np.empty((P, 3)),
+                   Hpl=np.empty((E, 6, 3)), Jx=np.empty((E, 2, 6)), Jp=np.empty((E, 2, 3)), res=np.empty((E, 2)))
+        cost = C.c_double()
+        out["rc"] = self.lib.yo_ceres_linearize(C.byref(pb), _f64(keep["poses"]), _f64(keep["points"]), C.byref(cost),
+                                                _f64(out["Hpp"]), _f64(out["bp"]), _f64(out["Hll"]), _f64(out["bl"]),
+                                                _f64(out["Hpl"]), _f64(out["Jx"]), _f64(out["Jp"]), _f64(out["res"]))
+        out["cost"] = cost.value
+        return out
+
+    def ceres_options(self, **kw):
+        o = CeresOptions()
+        self.lib.yo_ceres_default_options(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def ceres_solve(self, poses, pose_fixed, points, edge_pose, edge_point, obs_n, point_fixed=None, edge_huber=None,
+                    edge_enable=None, fail_behind=False, options=None):
+        """ceres::Solve restatement; returns (poses, points, summary dict)."""
+        pb, keep = self._ceres_problem(poses, pose_fixed, points, point_fixed, edge_pose, edge_point, obs_n, edge_huber,
+                                       edge_enable, fail_behind)
+        opt = options or self.ceres_options()
+        sm = CeresSummary()
+        rc = self.lib.yo_ceres_solve(C.byref(pb), C.byref(opt), C.byref(sm))
+        summary = {k: getattr(sm, k) for k, _ in CeresSummary._fields_}
+        summary["rc"] = rc
+        return keep["poses"], keep["points"], summary
+
+    def g2o_lm(self, poses, pose_fixed, points, edge_pose, edge_point, obs, cam=None, huber_delta=5.991, max_iterations=20):
+        """OptimizationAlgorithmLevenberg restatement around yo_ba_linearize; returns (poses, points, stats dict)."""
+        cam = cam or self.camera()
+        poses = np.ascontiguousarray(poses, np.float64).copy()
+        pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
+        points = np.ascontiguousarray(points, np.float64).copy()
+        edge_pose = np.ascontiguousarray(edge_pose, np.int32)
+        edge_point = np.ascontiguousarray(edge_point, np.int32)
+        obs = np.ascontiguousarray(obs, np.float64)
+        pb = BaProblem(len(poses), len(points), len(edge_pose), _f64(poses), _u8(pose_fixed), _f64(points),
+                       _p(edge_pose, C.c_int32), _p(edge_point, C.c_int32), _f64(obs),
+                       float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), float(huber_delta))
+        st = LmStats()
+        self.lib.yo_g2o_lm(C.byref(pb), _f64(poses), _f64(points), int(max_iterations), C.byref(st))
+        return poses, points, {k: getattr(st, k) for k, _ in LmStats._fields_}
+
+    def optimize_current_pose_only(self, pose_taa, px, pw, cam=None):
+        """ba::OptimizeCurrentPoseOnly; returns (pose [t;aa], bad[n], depth[n], inliers, rounds)."""
+        cam = cam or self.camera()
+        pose = np.ascontiguousarray(pose_taa, np.float64).copy()
+        px = np.ascontiguousarray(px, np.float64)
+        pw = np.ascontiguousarray(pw, np.float64)
+        n = len(px)
+        bad, depth, rounds = np.zeros(max(n, 1), np.uint8), np.full(max(n, 1), np.nan), C.c_int()
+        inl = self.lib.yo_optimize_current_pose_only(C.byref(cam), _f64(pose), n, _f64(px), _f64(pw), _u8(bad), _f64(depth),
+                                                     C.byref(rounds))
+        return pose, bad[:n], depth[:n], int(inl), rounds.value
 
     def ba_pose_oplus(self, pose, upd):
         pose = np.ascontiguousarray(pose, np.float64).copy()

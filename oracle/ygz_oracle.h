@@ -225,6 +225,49 @@ double yo_ba_linearize(const yo_ba_problem *pb, double *Hpp, double *bp, double 
 /* VertexSE3Sophus::oplusImpl G2oTypes.h:38-45 */
 void yo_ba_pose_oplus(double pose[6], const double upd[6]);
 
+/* ---- ceres-side rows (B3, B6, B7) and the two NLLS drivers: oracle/ceres_ba.c ---------------------------- */
+typedef struct {
+    int n_poses, n_points, n_edges;
+    double *poses;              /* [n_poses][6] = [t; angle-axis] (BA.cpp:96-99); yo_ceres_solve updates it */
+    const uint8_t *pose_fixed;  /* constant pose = CeresReprojectionErrorPointOnly's embedded _TCW; NULL: none */
+    double *points;             /* [n_points][3] */
+    const uint8_t *point_fixed; /* constant point = CeresReprojectionErrorPoseOnly's embedded _pt_world; NULL: none */
+    const int32_t *edge_pose, *edge_point;
+    const double *obs_n;        /* [n_edges][2] normalised image coordinates (Camera::Pixel2Camera2D) */
+    const double *edge_huber;   /* [n_edges] ceres::HuberLoss(a); <= 0 or NULL: no loss function */
+    const uint8_t *edge_enable; /* SetEnable; NULL: all enabled */
+    int fail_behind_camera;     /* PoseOnly functor: evaluation fails when p_z < 0 */
+} yo_ceres_problem;
+void yo_ceres_rotate_point(const double aa[3], const double p[3], double out[3]);
+void yo_ceres_edge(const double pose[6], const double pt[3], const double obs_n[2],
+                   double r[2], double Jpose[12], double Jpt[6], double *p_z);
+int  yo_ceres_linearize(const yo_ceres_problem *pb, const double *poses, const double *points, double *cost,
+                        double *Hpp, double *bp, double *Hll, double *bl, double *Hpl,
+                        double *Jx_out, double *Jp_out, double *rc_out);
+int  yo_ba_schur_solve(int K, int P, int E, const int32_t *edge_pose, const int32_t *edge_point,
+                       const uint8_t *pose_free, const uint8_t *point_free,
+                       const double *Hpp, const double *Hll, const double *Hpl, const double *bp, const double *bl,
+                       const double *dp, const double *dl, double *xp, double *xl);
+typedef struct {
+    int max_num_iterations;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
+    double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+    int jacobi_scaling, max_num_consecutive_invalid_steps;
+} yo_ceres_options;
+enum { YO_CERES_FUNCTION_TOLERANCE = 0, YO_CERES_GRADIENT_TOLERANCE, YO_CERES_PARAMETER_TOLERANCE, YO_CERES_MIN_RADIUS,
+       YO_CERES_NO_CONVERGENCE, YO_CERES_FAILURE };
+typedef struct {
+    int iterations, successful_steps, unsuccessful_steps, termination;
+    double initial_cost, final_cost, final_radius;
+} yo_ceres_summary;
+void yo_ceres_default_options(yo_ceres_options *o);
+int  yo_ceres_solve(yo_ceres_problem *pb, const yo_ceres_options *opt, yo_ceres_summary *sum);
+typedef struct { int iterations, lm_trials; double chi2_initial, chi2_final, lambda_final; } yo_lm_stats;
+int  yo_g2o_lm(const yo_ba_problem *pb, double *poses, double *points, int max_iterations, yo_lm_stats *stats);
+int  yo_optimize_current_pose_only(const yo_camera *cam, double pose_io[6], int n, const double *px, const double *pw,
+                                   uint8_t *bad_out, double *depth_out, int *rounds_run);
+
 #ifdef __cplusplus
 }
 #endif

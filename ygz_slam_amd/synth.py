@@ -214,3 +214,35 @@ def ba_window(K=10, P=2000, seed=7, w=640, h=480, sigma_obs=1.0, sigma_pose=0.1,
     fixed[0] = 1
     return dict(poses=est_poses, fixed=fixed, points=est_pts, edge_pose=ep, edge_point=el, obs=obs,
                 true_poses=true_poses, true_points=true_pts)
+
+
+def ba_to_ceres(fx):
+    """The same window in the ceres-side parametrisation (BA.cpp:96-99,336-362): pose = [t; angle-axis] of T_cw,
+    observation in normalised image coordinates (Camera::Pixel2Camera2D with the float intrinsics)."""
+    def conv(poses):
+        out = np.empty_like(poses)
+        for k, p in enumerate(poses):
+            T = se3_exp(np.concatenate([p[3:], p[:3]]))      # [omega; upsilon] -> Sophus [upsilon; omega]
+            out[k, :3], out[k, 3:] = T[4:], p[:3]
+        return out
+    obs_n = np.stack([(fx["obs"][:, 0] - CX) / FX, (fx["obs"][:, 1] - CY) / FY], axis=1)
+    d = dict(fx)
+    d.update(poses=conv(fx["poses"]), obs_n=obs_n, true_poses=conv(fx["true_poses"]))
+    return d
+
+
+def pose_only_fixture(n=400, seed=3, outlier_frac=0.1, sigma_px=0.5, w=640, h=480):
+    """One frame for ba::OptimizeCurrentPoseOnly: n map points seen at pixel noise sigma_px, a fraction of gross
+    outliers, an entry pose a few millimetres off (the first inlier test runs with the ENTRY pose, BA.cpp:233)."""
+    rng = np.random.default_rng(seed)
+    true = np.concatenate([rng.normal(0, 0.05, 3), rng.normal(0, 0.03, 3)])           # [t; aa]
+    T = np.concatenate([se3_exp(np.concatenate([np.zeros(3), true[3:]]))[:4], true[:3]])
+    pw = np.stack([rng.uniform(-2, 2, 4 * n), rng.uniform(-1.5, 1.5, 4 * n), rng.uniform(2, 6, 4 * n)], axis=1)
+    uv, z = project(T, pw)
+    ok = (z > 0.1) & (uv[:, 0] >= 0) & (uv[:, 0] < w) & (uv[:, 1] >= 0) & (uv[:, 1] < h)
+    pw, uv = pw[ok][:n], uv[ok][:n]
+    px = uv + rng.normal(0, sigma_px, uv.shape)
+    out = rng.random(len(px)) < outlier_frac
+    px[out] += rng.uniform(8, 40, (out.sum(), 2)) * rng.choice([-1, 1], (out.sum(), 2))
+    entry = true + np.concatenate([rng.normal(0, 0.002, 3), rng.normal(0, 0.0005, 3)])    # sub-pixel, as after sparse alignment
+    return dict(true=true, entry=entry, px=px, pw=pw, outlier=out)
