@@ -197,7 +197,16 @@ typedef struct {
     double fx, fy, cx, cy;       /* G2oTypes.h:60-66 */
     double huber_delta;          /* BA.cpp:451 (5.991); <= 0: no robust kernel */
     int    formulation;          /* 0: pixel residual (G2oTypes.h); 1: normalised plane, pose order
-                                    [t; omega] (legacy include/ygz/g2o_types.h:33-86, src/optimizer.cpp) */
+                                    [t; omega] (legacy include/ygz/g2o_types.h:33-86, src/optimizer.cpp);
+                                    2: the ceres functors (include/ygz/Ceres/CeresReprojectionError.h:33-69, ...PoseOnly.h:27-58,
+                                    ...PointOnly.h:45-77): pose = [t; angle-axis] with additive update, obs in normalised
+                                    coordinates, Jacobians = what AutoDiffCostFunction<...,2,6,3> returns */
+    /* optional, any formulation (NULL = absent).  They express the ceres problems of src/Algorithm/BA.cpp on one edge
+     * list: a PointOnly functor is an edge to a pose with pose_fixed, a PoseOnly functor an edge to a point with
+     * point_fixed, SetEnable(false) is edge_enable = 0, ceres::HuberLoss(a) is edge_huber = a. */
+    const uint8_t *point_fixed;  /* [n_points] */
+    const double  *edge_huber;   /* [n_edges] per-edge Huber width (<= 0: none); NULL: huber_delta for every edge */
+    const uint8_t *edge_enable;  /* [n_edges] */
 } ygz_ba_problem;
 /* Outputs (host, any may be NULL): Hpp [n_poses][36], bp [n_poses][6], Hll [n_points][9],
  * bl [n_points][3], Hpl [n_edges][18] (6x3 = Jpose^T w Jpoint), err [n_edges][2], chi2_edge [n_edges],
@@ -212,6 +221,10 @@ int  ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_p
 int  ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows);
 int  ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, double *Hll, double *bl,
                          double *Hpl, double *err, double *chi2_edge, double *chi2);
+/* number of enabled edges whose point lay behind the camera (p_z < 0) in the last linearisation -- the condition on which
+ * CeresReprojectionErrorPoseOnly::operator() reports failure (CeresReprojectionErrorPoseOnly.h:48-51) */
+int  ygz_hip_ba_behind_camera(ygz_hip_ctx *ctx, int window, int *n_behind);
+int  ygz_hip_ba_set_enable(ygz_hip_ctx *ctx, int window, const uint8_t *edge_enable);
 
 /* ---- B4: the LM loop of ba::LocalBAG2O (src/Algorithm/BA.cpp:390-395,501-502: g2o OptimizationAlgorithmLevenberg +
  *      BlockSolver_6_3 with marginalised points).  Linearisations run on the GPU, the reduced pose system on the host.
@@ -222,6 +235,38 @@ typedef struct {
 } ygz_ba_stats;
 int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                          int max_iterations, ygz_ba_stats *stats);
+
+
+/* ---- B6/B7: ceres::Solve as the reference configures it (src/Algorithm/BA.cpp:219-226,372-375: default options =
+ *      trust-region Levenberg-Marquardt, Jacobi scaling) around the GPU linearisation of a formulation-2 problem.
+ *      ba::LocalBA, OptimizeCurrent, OptimizeCurrentPointOnly and TwoViewBACeres are this call on different edge lists. */
+typedef struct {
+    int    max_num_iterations;                       /* 50 */
+    double function_tolerance, gradient_tolerance, parameter_tolerance;           /* 1e-6, 1e-10, 1e-8 */
+    double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;   /* 1e4, 1e16, 1e-32 */
+    double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;               /* 1e-3, 1e-6, 1e32 */
+    int    jacobi_scaling, max_num_consecutive_invalid_steps;                     /* 1, 5 */
+    int    fail_behind_camera;                       /* 1: evaluation fails when an enabled edge has p_z < 0 (PoseOnly) */
+} ygz_ceres_options;
+enum { YGZ_CERES_FUNCTION_TOLERANCE = 0, YGZ_CERES_GRADIENT_TOLERANCE, YGZ_CERES_PARAMETER_TOLERANCE, YGZ_CERES_MIN_RADIUS,
+       YGZ_CERES_NO_CONVERGENCE, YGZ_CERES_FAILURE };
+typedef struct {
+    int    iterations, successful_steps, unsuccessful_steps, termination;
+    double initial_cost, final_cost, final_radius;
+} ygz_ceres_summary;
+void ygz_hip_ceres_default_options(ygz_ceres_options *opt);
+int  ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
+                            const ygz_ceres_options *opt, ygz_ceres_summary *summary);
+
+/* ---- B7: ba::OptimizeCurrentPoseOnly (src/Algorithm/BA.cpp:188-264; the per-frame call of
+ *      LocalMapping::OptimizeCurrent, src/Module/LocalMapping.cpp:126) for a batch of frames: one workgroup per frame runs
+ *      the four solve / re-classify rounds entirely on the GPU.  Frame f owns features frame_off[f] .. frame_off[f+1]-1:
+ *      px [n][2] pixels (Feature::_pixel), pw [n][3] world points (MapPoint::_pos_world).  poses_io [n_frames][6] =
+ *      [t; log(so3)] of _TCW in and out; bad [n] (Feature::_bad), depth [n] (Feature::_depth, written for inliers only,
+ *      otherwise left), inliers / rounds [n_frames] (may be NULL).  Intrinsics are the context's camera. */
+int  ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const int32_t *frame_off, const double *px,
+                                const double *pw, double *poses_io, uint8_t *bad, double *depth, int32_t *inliers,
+                                int32_t *rounds);
 
 #ifdef __cplusplus
 }

@@ -475,3 +475,108 @@ def test_ba_batched_windows(hip_lib, oracle):
     for w, f in enumerate(fs):
         _ba_close(ctx.ba_download(w, *dims[w]), oracle.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"]))
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------- B3 / B6 / B7: the ceres side
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_ba_ceres_formulation_blocks(hip_lib, oracle):
+    """formulation 2 = the auto-differentiated ceres functors (Ceres/CeresReprojectionError*.h), closed form on the GPU vs
+    Jets in the oracle, with constant poses / points, disabled edges and per-edge Huber widths.  Bar 1e-5 relative; met 1e-9."""
+    c = synth.ba_to_ceres(synth.ba_window(8, 600, seed=4))
+    c["poses"][0] = 0.0                                            # keyframe 0 at the identity: the first-order rotation branch
+    E, P = len(c["obs_n"]), len(c["points"])
+    rng = np.random.default_rng(0)
+    huber = np.where(rng.random(E) < 0.5, 0.002, 0.0)
+    enable = (rng.random(E) < 0.9).astype(np.uint8)
+    pfix = (rng.random(P) < 0.1).astype(np.uint8)
+    o = oracle.ceres_linearize(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"],
+                               point_fixed=pfix, edge_huber=huber, edge_enable=enable)
+    ctx = make_ctx(hip_lib, max_frames=1)
+    g = ctx.ba_linearize(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], huber_delta=0.0,
+                         formulation=2, point_fixed=pfix, edge_huber=huber, edge_enable=enable)
+    assert g["n_behind"] == 0
+    assert abs(0.5 * g["chi2"] - o["cost"]) <= 1e-12 * o["cost"]
+    for k in ("Hpp", "bp", "Hll", "bl", "Hpl"):
+        assert _rel(g[k], o[k]) < 1e-9, k
+    assert not g["Hll"][pfix == 1].any() and not g["Hpl"][enable == 0].any() and not g["err"][enable == 0].any()
+    # raw residuals of enabled edges (the oracle's `res` carries the sqrt(rho') of the corrector)
+    raw = np.array([oracle.ceres_edge(c["poses"][c["edge_pose"][e]], c["points"][c["edge_point"][e]], c["obs_n"][e])[0]
+                    for e in range(0, E, 37)])
+    assert np.allclose(g["err"][::37][enable[::37] == 1], raw[enable[::37] == 1], atol=1e-13)
+    # behind-the-camera count (what makes the PoseOnly functor fail)
+    pts = c["points"].copy(); pts[:5, 2] = -4.0
+    g2 = ctx.ba_linearize(c["poses"], c["fixed"], pts, c["edge_pose"], c["edge_point"], c["obs_n"], huber_delta=0.0, formulation=2)
+    assert g2["n_behind"] == int(np.isin(c["edge_point"], np.arange(5)).sum())
+    ctx.close()
+
+
+def test_ba_solve_ceres_local_ba(hip_lib, oracle):
+    """ba::LocalBA (BA.cpp:324-384): trust-region LM around the GPU linearisation vs the oracle's restatement: same
+    accept/reject sequence, same termination, final cost and state within 1e-6 relative (bar 1e-5)."""
+    for fx in (synth.ba_to_ceres(synth.ba_window(6, 300, seed=5)), synth.ba_to_ceres(synth.ba_fixture_test_local_ba(noise=True))):
+        po, pt, so = oracle.ceres_solve(fx["poses"], fx["fixed"], fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
+        ctx = make_ctx(hip_lib, max_frames=1)
+        pg, tg, sg = ctx.ba_solve_ceres(fx["poses"], fx["fixed"], fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
+        ctx.close()
+        assert (sg["iterations"], sg["successful_steps"], sg["unsuccessful_steps"], sg["termination"]) == \
+               (so["iterations"], so["successful_steps"], so["unsuccessful_steps"], so["termination"])
+        assert abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-12 * so["initial_cost"]
+        assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"]
+        assert _rel(pg, po) < 1e-6 and _rel(tg, pt) < 1e-6
+        assert sg["final_cost"] < 0.05 * sg["initial_cost"]
+
+
+def test_ba_solve_ceres_variants(hip_lib, oracle):
+    """OptimizeCurrentPointOnly (every pose constant), OptimizeCurrent-like (Huber 0.1 on every edge, one free pose) and a
+    pose-only problem with the behind-camera failure rule -- the other ceres call sites of BA.cpp on the same entry point."""
+    fx = synth.ba_to_ceres(synth.ba_window(5, 200, seed=9))
+    ctx = make_ctx(hip_lib, max_frames=1)
+    allfix = np.ones(len(fx["poses"]), np.uint8)
+    po, pt, so = oracle.ceres_solve(fx["poses"], allfix, fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
+    pg, tg, sg = ctx.ba_solve_ceres(fx["poses"], allfix, fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
+    assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
+    assert np.array_equal(pg, fx["poses"]) and _rel(tg, pt) < 1e-6 and sg["final_cost"] < so["initial_cost"]
+    onefree = np.ones(len(fx["poses"]), np.uint8); onefree[-1] = 0
+    hub = np.full(len(fx["obs_n"]), 0.1)
+    po, pt, so = oracle.ceres_solve(fx["poses"], onefree, fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"], edge_huber=hub)
+    pg, tg, sg = ctx.ba_solve_ceres(fx["poses"], onefree, fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"], edge_huber=hub)
+    assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
+    assert _rel(pg, po) < 1e-6 and _rel(tg, pt) < 1e-6
+    # pose only, a point behind the camera at the start: ceres gives up at iteration zero, state untouched
+    f = synth.pose_only_fixture(n=60, seed=8, outlier_frac=0.0)
+    n = len(f["px"])
+    obs_n = np.stack([(f["px"][:, 0] - synth.CX) / synth.FX, (f["px"][:, 1] - synth.CY) / synth.FY], axis=1)
+    pw = f["pw"].copy(); pw[7, 2] = -3.0
+    args = (f["entry"][None], None, pw, np.zeros(n, np.int32), np.arange(n, dtype=np.int32), obs_n)
+    po, _, so = oracle.ceres_solve(*args, point_fixed=np.ones(n, np.uint8), fail_behind=True)
+    pg, _, sg = ctx.ba_solve_ceres(*args, point_fixed=np.ones(n, np.uint8), options=ctx.ceres_options(fail_behind_camera=1))
+    assert so["termination"] == 5 and sg["termination"] == 5 and np.array_equal(pg[0], f["entry"]) and np.array_equal(po[0], f["entry"])
+    ctx.close()
+
+
+def test_optimize_pose_only_batch(hip_lib, oracle):
+    """ba::OptimizeCurrentPoseOnly for a batch of frames in one launch (one workgroup per frame, four rounds on the device)
+    vs the oracle frame by frame: flags, inlier counts and rounds equal; pose within 1e-7 relative (bar 1e-5), depth 1e-9."""
+    frames = [synth.pose_only_fixture(n=400, seed=3), synth.pose_only_fixture(n=1000, seed=5, outlier_frac=0.3),
+              synth.pose_only_fixture(n=37, seed=6, outlier_frac=0.0), synth.pose_only_fixture(n=12, seed=4, outlier_frac=0.0),
+              dict(entry=np.zeros(6), px=np.zeros((0, 2)), pw=np.zeros((0, 3))), synth.pose_only_fixture(n=257, seed=7)]
+    frames[3]["entry"] = frames[3]["entry"] + np.array([0.5, 0.5, 0, 0, 0, 0])        # < 10 inliers in round 1: no commit
+    frames[5]["pw"][11, 2] = -2.0        # behind the camera: the first solve fails, the re-classification disables the point
+    off = np.concatenate([[0], np.cumsum([len(f["px"]) for f in frames])]).astype(np.int32)
+    ctx = make_ctx(hip_lib, max_frames=1)
+    po, bad, dep, inl, rounds = ctx.optimize_pose_only(off, np.concatenate([f["px"] for f in frames]),
+                                                       np.concatenate([f["pw"] for f in frames]), np.stack([f["entry"] for f in frames]))
+    ctx.close()
+    for i, f in enumerate(frames):
+        o_pose, o_bad, o_dep, o_inl, o_rounds = oracle.optimize_current_pose_only(f["entry"], f["px"], f["pw"])
+        s = slice(off[i], off[i + 1])
+        assert rounds[i] == o_rounds and inl[i] == o_inl, i
+        assert np.array_equal(bad[s], o_bad), i
+        assert np.abs(po[i] - o_pose).max() <= 1e-7 * max(1.0, np.abs(o_pose).max()), i
+        m = o_bad == 0
+        assert np.allclose(dep[s][m], o_dep[m], rtol=1e-9) and np.all(np.isnan(dep[s][~m]) == np.isnan(o_dep[~m])), i
+    assert rounds[3] == 1 and np.array_equal(po[3], frames[3]["entry"]) and rounds[4] == 1 and inl[4] == 0
+    assert rounds[5] == 4 and bad[off[5] + 11] == 1 and not np.array_equal(po[5], frames[5]["entry"])

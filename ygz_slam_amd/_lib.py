@@ -48,7 +48,23 @@ class BaProblem(C.Structure):
                 ("points", C.POINTER(C.c_double)), ("edge_pose", C.POINTER(C.c_int32)),
                 ("edge_point", C.POINTER(C.c_int32)), ("obs", C.POINTER(C.c_double)),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
-                ("huber_delta", C.c_double), ("formulation", C.c_int)]
+                ("huber_delta", C.c_double), ("formulation", C.c_int),
+                ("point_fixed", C.POINTER(C.c_uint8)), ("edge_huber", C.POINTER(C.c_double)),
+                ("edge_enable", C.POINTER(C.c_uint8))]
+
+
+class CeresOptions(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+                ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int), ("fail_behind_camera", C.c_int)]
+
+
+class CeresSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("successful_steps", C.c_int), ("unsuccessful_steps", C.c_int),
+                ("termination", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("final_radius", C.c_double)]
 
 
 class BaStats(C.Structure):
@@ -68,6 +84,7 @@ ABI_SYMBOLS = [
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
+    "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
 ]
 
 _lib = None
@@ -345,28 +362,75 @@ class HipContext:
         return nm.value, np.array(list(T)), list(iters)[:self.levels]
 
     # ---- BA
-    def _ba_problem(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam=None):
-        self._keep = [np.ascontiguousarray(poses, np.float64), np.ascontiguousarray(fixed, np.uint8),
-                      np.ascontiguousarray(points, np.float64), np.ascontiguousarray(edge_pose, np.int32),
-                      np.ascontiguousarray(edge_point, np.int32), np.ascontiguousarray(obs, np.float64)]
+    def _ba_problem(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam=None,
+                    point_fixed=None, edge_huber=None, edge_enable=None):
+        if fixed is None:
+            fixed = np.zeros(len(poses), np.uint8)
+        self._keep = [np.ascontiguousarray(poses, np.float64).reshape(-1, 6), np.ascontiguousarray(fixed, np.uint8),
+                      np.ascontiguousarray(points, np.float64).reshape(-1, 3), np.ascontiguousarray(edge_pose, np.int32),
+                      np.ascontiguousarray(edge_point, np.int32), np.ascontiguousarray(obs, np.float64),
+                      None if point_fixed is None else np.ascontiguousarray(point_fixed, np.uint8),
+                      None if edge_huber is None else np.ascontiguousarray(edge_huber, np.float64),
+                      None if edge_enable is None else np.ascontiguousarray(edge_enable, np.uint8)]
         a = self._keep
         fx, fy, cx, cy = cam if cam else (float(self.params.fx), float(self.params.fy), float(self.params.cx), float(self.params.cy))
+        opt = lambda v, t: C.POINTER(t)() if v is None else _p(v, t)
         return BaProblem(len(a[0]), len(a[2]), len(a[3]), _p(a[0], C.c_double), _p(a[1], C.c_uint8), _p(a[2], C.c_double),
-                         _p(a[3], C.c_int32), _p(a[4], C.c_int32), _p(a[5], C.c_double), fx, fy, cx, cy, float(huber_delta), formulation)
+                         _p(a[3], C.c_int32), _p(a[4], C.c_int32), _p(a[5], C.c_double), fx, fy, cx, cy, float(huber_delta), formulation,
+                         opt(a[6], C.c_uint8), opt(a[7], C.c_double), opt(a[8], C.c_uint8))
 
     @staticmethod
     def _ba_out(K, P, E):
         return dict(Hpp=np.empty((K, 6, 6)), bp=np.empty((K, 6)), Hll=np.empty((P, 3, 3)), bl=np.empty((P, 3)),
                     Hpl=np.empty((E, 6, 3)), err=np.empty((E, 2)), chi2_edge=np.empty(E), chi2=np.empty(1))
 
-    def ba_linearize(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None):
-        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam)
+    def ba_linearize(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None,
+                     point_fixed=None, edge_huber=None, edge_enable=None):
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam, point_fixed,
+                              edge_huber, edge_enable)
         o = self._ba_out(pb.n_poses, pb.n_points, pb.n_edges)
         d = lambda k: _p(o[k], C.c_double)
         self._chk(self.lib.ygz_hip_ba_linearize(self._ctx, C.byref(pb), d("Hpp"), d("bp"), d("Hll"), d("bl"), d("Hpl"), d("err"),
                                                 d("chi2_edge"), d("chi2")), "ba_linearize")
         o["chi2"] = float(o["chi2"][0])
+        nb = C.c_int(0)
+        self._chk(self.lib.ygz_hip_ba_behind_camera(self._ctx, 1023, C.byref(nb)), "ba_behind_camera")
+        o["n_behind"] = nb.value
         return o
+
+    def ceres_options(self, **kw):
+        o = CeresOptions()
+        self.lib.ygz_hip_ceres_default_options(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def ba_solve_ceres(self, poses, fixed, points, edge_pose, edge_point, obs_n, point_fixed=None, edge_huber=None,
+                       edge_enable=None, options=None):
+        """ceres::Solve around the GPU linearisation of a formulation-2 problem; returns (poses, points, summary dict)."""
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs_n, 0.0, 2, None, point_fixed, edge_huber, edge_enable)
+        po = self._keep[0].copy()
+        pt = self._keep[2].copy()
+        sm = CeresSummary()
+        opt = options or self.ceres_options()
+        self._chk(self.lib.ygz_hip_ba_solve_ceres(self._ctx, C.byref(pb), _p(po, C.c_double), _p(pt, C.c_double), C.byref(opt),
+                                                  C.byref(sm)), "ba_solve_ceres")
+        return po, pt, {k: getattr(sm, k) for k, _ in CeresSummary._fields_}
+
+    def optimize_pose_only(self, frame_off, px, pw, poses, depth=None):
+        """ba::OptimizeCurrentPoseOnly for a batch of frames; returns (poses, bad, depth, inliers, rounds)."""
+        off = np.ascontiguousarray(frame_off, np.int32)
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 2)
+        pw = np.ascontiguousarray(pw, np.float64).reshape(-1, 3)
+        po = np.ascontiguousarray(poses, np.float64).reshape(-1, 6).copy()
+        nf, n = len(off) - 1, len(px)
+        bad = np.zeros(max(n, 1), np.uint8)
+        dep = np.full(max(n, 1), np.nan) if depth is None else np.ascontiguousarray(depth, np.float64).copy()
+        inl, rounds = np.zeros(max(nf, 1), np.int32), np.zeros(max(nf, 1), np.int32)
+        self._chk(self.lib.ygz_hip_optimize_pose_only(self._ctx, nf, _p(off, C.c_int32), _p(px, C.c_double), _p(pw, C.c_double),
+                                                      _p(po, C.c_double), _p(bad, C.c_uint8), _p(dep, C.c_double),
+                                                      _p(inl, C.c_int32), _p(rounds, C.c_int32)), "optimize_pose_only")
+        return po, bad[:n], dep[:n], inl[:nf], rounds[:nf]
 
     def ba_optimize(self, poses, fixed, points, edge_pose, edge_point, obs, iterations=20, huber_delta=5.991, cam=None):
         pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, 0, cam)

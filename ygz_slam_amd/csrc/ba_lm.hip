@@ -57,6 +57,83 @@ static bool chol_solve(std::vector<double> &A, std::vector<double> &b, int n)
     return true;
 }
 
+// Solve [Hpp + diag(dp), Hpl; Hpl^T, Hll + diag(dl)] [xp; xl] = [bp; bl], points eliminated first (Schur complement on the
+// pose block, dense Cholesky of the 6Kf x 6Kf reduced system, 3x3 back-substitution per point).  free_idx[k] < 0: constant
+// pose; lfree[l] == 0: constant point.  xp is [Kf][6] (free poses only), xl [P][3].
+struct BlockSystem {
+    int K, P, E, Kf;
+    const int32_t *edge_pose, *edge_point;
+    std::vector<int> free_idx;
+    std::vector<uint8_t> lfree;
+    std::vector<std::vector<int>> pt_edges;
+    std::vector<double> S, bs, Dinv;
+};
+
+static void block_system_init(BlockSystem &B, const ygz_ba_problem *pb)
+{
+    B.K = pb->n_poses; B.P = pb->n_points; B.E = pb->n_edges; B.edge_pose = pb->edge_pose; B.edge_point = pb->edge_point;
+    B.free_idx.assign(B.K, -1); B.Kf = 0;
+    for (int k = 0; k < B.K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) B.free_idx[k] = B.Kf++;
+    B.lfree.assign(B.P, 1);
+    if (pb->point_fixed) for (int l = 0; l < B.P; ++l) B.lfree[l] = pb->point_fixed[l] ? 0 : 1;
+    B.pt_edges.assign(B.P, std::vector<int>());
+    for (int e = 0; e < B.E; ++e) B.pt_edges[pb->edge_point[e]].push_back(e);
+    B.Dinv.assign((size_t)B.P * 9, 0.0);
+}
+
+static bool block_solve(BlockSystem &B, const double *Hpp, const double *Hll, const double *Hpl, const double *bp, const double *bl,
+                        const double *dp /*[K][6]*/, const double *dl /*[P][3]*/, std::vector<double> &xp, std::vector<double> &xl)
+{
+    const int n = 6 * B.Kf;
+    B.S.assign((size_t)n * n, 0.0); B.bs.assign((size_t)n, 0.0);
+    xl.assign((size_t)B.P * 3, 0.0);
+    for (int k = 0; k < B.K; ++k) if (B.free_idx[k] >= 0) {
+        const int a = B.free_idx[k];
+        for (int r = 0; r < 6; ++r) {
+            for (int c = 0; c < 6; ++c) B.S[(size_t)(6 * a + r) * n + 6 * a + c] = Hpp[(size_t)k * 36 + 6 * r + c];
+            B.S[(size_t)(6 * a + r) * n + 6 * a + r] += dp[(size_t)k * 6 + r];
+            B.bs[6 * a + r] = bp[(size_t)k * 6 + r];
+        }
+    }
+    for (int l = 0; l < B.P; ++l) {
+        if (!B.lfree[l]) continue;
+        double D[9]; memcpy(D, &Hll[(size_t)l * 9], sizeof(D));
+        D[0] += dl[(size_t)l * 3]; D[4] += dl[(size_t)l * 3 + 1]; D[8] += dl[(size_t)l * 3 + 2];
+        double *Di = &B.Dinv[(size_t)l * 9];
+        if (!inv3(D, Di)) return false;
+        for (int ei : B.pt_edges[l]) {
+            const int a = B.free_idx[B.edge_pose[ei]];
+            if (a < 0) continue;
+            const double *Bi = &Hpl[(size_t)ei * 18];           // 6x3
+            double BD[18];
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) BD[3 * r + c] = Bi[3 * r] * Di[c] + Bi[3 * r + 1] * Di[3 + c] + Bi[3 * r + 2] * Di[6 + c];
+            for (int r = 0; r < 6; ++r) B.bs[6 * a + r] -= BD[3 * r] * bl[(size_t)l * 3] + BD[3 * r + 1] * bl[(size_t)l * 3 + 1] + BD[3 * r + 2] * bl[(size_t)l * 3 + 2];
+            for (int ej : B.pt_edges[l]) {
+                const int b2 = B.free_idx[B.edge_pose[ej]];
+                if (b2 < 0) continue;
+                const double *Bj = &Hpl[(size_t)ej * 18];
+                for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
+                    B.S[(size_t)(6 * a + r) * n + 6 * b2 + c] -= BD[3 * r] * Bj[3 * c] + BD[3 * r + 1] * Bj[3 * c + 1] + BD[3 * r + 2] * Bj[3 * c + 2];
+            }
+        }
+    }
+    xp = B.bs;
+    if (n > 0 && !chol_solve(B.S, xp, n)) return false;
+    for (int l = 0; l < B.P; ++l) {
+        if (!B.lfree[l]) continue;
+        double r3[3] = { bl[(size_t)l * 3], bl[(size_t)l * 3 + 1], bl[(size_t)l * 3 + 2] };
+        for (int ei : B.pt_edges[l]) {
+            const int a = B.free_idx[B.edge_pose[ei]];
+            if (a < 0) continue;
+            const double *Bi = &Hpl[(size_t)ei * 18];
+            for (int c = 0; c < 3; ++c) for (int r = 0; r < 6; ++r) r3[c] -= Bi[3 * r + c] * xp[6 * a + r];
+        }
+        const double *Di = &B.Dinv[(size_t)l * 9];
+        for (int c = 0; c < 3; ++c) xl[(size_t)l * 3 + c] = Di[3 * c] * r3[0] + Di[3 * c + 1] * r3[1] + Di[3 * c + 2] * r3[2];
+    }
+    return true;
+}
+
 extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                                    int max_iterations, ygz_ba_stats *stats)
 {
@@ -67,17 +144,13 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
     prob.poses = poses_io; prob.points = points_io;
     int rc = ygz_hip_ba_upload(ctx, W, &prob);
     if (rc != YGZ_OK) return rc;
-    std::vector<int> free_idx(K, -1);
-    int Kf = 0;
-    for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) free_idx[k] = Kf++;
-    std::vector<std::vector<int>> pt_edges(P);
-    for (int e = 0; e < E; ++e) pt_edges[pb->edge_point[e]].push_back(e);
-    std::vector<double> Hpp((size_t)K * 36), bp((size_t)K * 6), Hll((size_t)P * 9), bl((size_t)P * 3), Hpl((size_t)E * 18);
+    BlockSystem BS; block_system_init(BS, pb);
+    const std::vector<int> &free_idx = BS.free_idx;
+    std::vector<double> Hpp((size_t)K * 36), bp((size_t)K * 6), Hll((size_t)P * 9), bl((size_t)P * 3), Hpl((size_t)std::max(E, 1) * 18);
     std::vector<double> poses(poses_io, poses_io + (size_t)K * 6), points(points_io, points_io + (size_t)P * 3);
-    std::vector<double> poses_bk, points_bk, xp((size_t)Kf * 6), xl((size_t)P * 3), Dinv((size_t)P * 9);
+    std::vector<double> poses_bk, points_bk, xp, xl, dp((size_t)K * 6), dl((size_t)P * 3);
     double lambda = 0, ni = 2, currentChi = 0;
     ygz_ba_stats st; memset(&st, 0, sizeof(st));
-    const int n = 6 * Kf;
     for (int it = 0; it < max_iterations; ++it) {
         // computeActiveErrors + buildSystem at the current state (GPU)
         if ((rc = ygz_hip_ba_set_state(ctx, W, poses.data(), points.data())) != YGZ_OK) return rc;
@@ -93,49 +166,9 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
         double rho = 0; int qmax = 0;
         do {
             poses_bk = poses; points_bk = points;           // _optimizer->push()
-            // ---- solve (Hpp + lambda I, Hll + lambda I) by Schur complement
-            bool ok2 = true;
-            std::vector<double> S((size_t)n * n, 0.0), bs((size_t)n, 0.0);
-            for (int k = 0; k < K; ++k) if (free_idx[k] >= 0) {
-                const int a = free_idx[k];
-                for (int r = 0; r < 6; ++r) { for (int c = 0; c < 6; ++c) S[(size_t)(6 * a + r) * n + 6 * a + c] = Hpp[(size_t)k * 36 + 6 * r + c]; bs[6 * a + r] = bp[(size_t)k * 6 + r]; }
-                for (int d = 0; d < 6; ++d) S[(size_t)(6 * a + d) * n + 6 * a + d] += lambda;
-            }
-            for (int l = 0; l < P && ok2; ++l) {
-                double D[9]; memcpy(D, &Hll[(size_t)l * 9], sizeof(D));
-                D[0] += lambda; D[4] += lambda; D[8] += lambda;
-                if (!inv3(D, &Dinv[(size_t)l * 9])) { ok2 = false; break; }
-                const double *Di = &Dinv[(size_t)l * 9];
-                for (int ei : pt_edges[l]) {
-                    const int a = free_idx[pb->edge_pose[ei]];
-                    if (a < 0) continue;
-                    const double *Bi = &Hpl[(size_t)ei * 18];           // 6x3
-                    double BD[18];
-                    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) BD[3 * r + c] = Bi[3 * r] * Di[c] + Bi[3 * r + 1] * Di[3 + c] + Bi[3 * r + 2] * Di[6 + c];
-                    for (int r = 0; r < 6; ++r) bs[6 * a + r] -= BD[3 * r] * bl[(size_t)l * 3] + BD[3 * r + 1] * bl[(size_t)l * 3 + 1] + BD[3 * r + 2] * bl[(size_t)l * 3 + 2];
-                    for (int ej : pt_edges[l]) {
-                        const int b2 = free_idx[pb->edge_pose[ej]];
-                        if (b2 < 0) continue;
-                        const double *Bj = &Hpl[(size_t)ej * 18];
-                        for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c)
-                            S[(size_t)(6 * a + r) * n + 6 * b2 + c] -= BD[3 * r] * Bj[3 * c] + BD[3 * r + 1] * Bj[3 * c + 1] + BD[3 * r + 2] * Bj[3 * c + 2];
-                    }
-                }
-            }
-            if (ok2 && n > 0) { xp = bs; ok2 = chol_solve(S, xp, n); }
-            if (ok2) {
-                for (int l = 0; l < P; ++l) {
-                    double r3[3] = { bl[(size_t)l * 3], bl[(size_t)l * 3 + 1], bl[(size_t)l * 3 + 2] };
-                    for (int ei : pt_edges[l]) {
-                        const int a = free_idx[pb->edge_pose[ei]];
-                        if (a < 0) continue;
-                        const double *Bi = &Hpl[(size_t)ei * 18];
-                        for (int c = 0; c < 3; ++c) for (int r = 0; r < 6; ++r) r3[c] -= Bi[3 * r + c] * xp[6 * a + r];
-                    }
-                    const double *Di = &Dinv[(size_t)l * 9];
-                    for (int c = 0; c < 3; ++c) xl[(size_t)l * 3 + c] = Di[3 * c] * r3[0] + Di[3 * c + 1] * r3[1] + Di[3 * c + 2] * r3[2];
-                }
-                // ---- _optimizer->update(x)
+            std::fill(dp.begin(), dp.end(), lambda); std::fill(dl.begin(), dl.end(), lambda);
+            const bool ok2 = block_solve(BS, Hpp.data(), Hll.data(), Hpl.data(), bp.data(), bl.data(), dp.data(), dl.data(), xp, xl);
+            if (ok2) {                                      // _optimizer->update(x)
                 for (int k = 0; k < K; ++k) if (free_idx[k] >= 0) oplus_pose(&poses[(size_t)k * 6], &xp[(size_t)free_idx[k] * 6]);
                 for (size_t i = 0; i < points.size(); ++i) points[i] += xl[i];
             }
@@ -173,5 +206,180 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
     st.chi2_final = currentChi; st.lambda_final = lambda;
     memcpy(poses_io, poses.data(), poses.size() * 8); memcpy(points_io, points.data(), points.size() * 8);
     if (stats) *stats = st;
+    return YGZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// B6/B7 -- ceres::Solve with the reference's (default) options: trust-region Levenberg-Marquardt
+// [frozen spec of ceres-solver 1.13 trust_region_minimizer.cc / levenberg_marquardt_strategy.cc, restated in
+// oracle/ceres_ba.c::yo_ceres_solve, which this mirrors step by step].  Every evaluation (cost, residuals, Jacobians,
+// blocks) is a GPU linearisation of the resident window; the candidate's linearisation becomes the next iterate's when
+// the step is accepted, so an accepted iteration costs exactly one launch group.
+extern "C" void ygz_hip_ceres_default_options(ygz_ceres_options *o)
+{
+    if (!o) return;
+    o->max_num_iterations = 50;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+    o->jacobi_scaling = 1; o->max_num_consecutive_invalid_steps = 5; o->fail_behind_camera = 0;
+}
+
+extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
+                                      const ygz_ceres_options *opt_in, ygz_ceres_summary *summary)
+{
+    if (!ctx || !pb || !poses_io || !points_io) return YGZ_E_INVALID;
+    if (pb->formulation != 2) return YGZ_E_INVALID;
+    ygz_ceres_options opt;
+    if (opt_in) opt = *opt_in; else ygz_hip_ceres_default_options(&opt);
+    const int K = pb->n_poses, P = pb->n_points, E = pb->n_edges, W = 1021;
+    ygz_ba_problem prob = *pb;
+    prob.poses = poses_io; prob.points = points_io;
+    int rc = ygz_hip_ba_upload(ctx, W, &prob);
+    if (rc != YGZ_OK) return rc;
+    BlockSystem BS; block_system_init(BS, pb);
+    const std::vector<int> &fidx = BS.free_idx;
+    std::vector<double> Hpp((size_t)K * 36), bp((size_t)K * 6), Hll((size_t)P * 9), bl((size_t)P * 3), Hpl((size_t)std::max(E, 1) * 18);
+    std::vector<double> sHpp(Hpp.size()), sbp(bp.size()), sHll(Hll.size()), sbl(bl.size()), sHpl(Hpl.size());
+    std::vector<double> scp((size_t)K * 6, 1.0), scl((size_t)P * 3, 1.0), dp((size_t)K * 6), dl((size_t)P * 3), xp, xl;
+    std::vector<double> poses(poses_io, poses_io + (size_t)K * 6), points(points_io, points_io + (size_t)P * 3), cposes, cpoints;
+    std::vector<double> dxp((size_t)K * 6), dxl((size_t)P * 3);
+    ygz_ceres_summary S; memset(&S, 0, sizeof(S));
+    double x_cost = 0, radius = opt.initial_trust_region_radius, decrease_factor = 2.0, x_norm = 0, gmax = 0;
+    int invalid_run = 0, term = YGZ_CERES_NO_CONVERGENCE;
+    bool hard_error = false;
+
+    // evaluate at (ps, ls); cost = chi2 / 2; 0 ok, 1 = the functor reported failure, < 0 = ABI error
+    auto evaluate = [&](const std::vector<double> &ps, const std::vector<double> &ls, double *cost) -> int {
+        int r;
+        if ((r = ygz_hip_ba_set_state(ctx, W, ps.data(), ls.data())) != YGZ_OK) return r;
+        if ((r = ygz_hip_ba_linearize_resident(ctx, W, 1)) != YGZ_OK) return r;
+        double chi2 = 0;
+        if ((r = ygz_hip_ba_download(ctx, W, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &chi2)) != YGZ_OK) return r;
+        *cost = 0.5 * chi2;
+        if (opt.fail_behind_camera) {
+            int nb = 0;
+            if ((r = ygz_hip_ba_behind_camera(ctx, W, &nb)) != YGZ_OK) return r;
+            if (nb > 0) return 1;
+        }
+        return std::isfinite(chi2) ? YGZ_OK : 1;
+    };
+    auto fetch_blocks = [&]() -> int {
+        return ygz_hip_ba_download(ctx, W, Hpp.data(), bp.data(), Hll.data(), bl.data(), Hpl.data(), nullptr, nullptr, nullptr);
+    };
+    auto norm_and_gradient = [&]() {
+        double s2 = 0; gmax = 0;
+        for (int k = 0; k < K; ++k) if (fidx[k] >= 0) for (int d = 0; d < 6; ++d) { const double v = poses[(size_t)k * 6 + d]; s2 += v * v; gmax = std::max(gmax, fabs(bp[(size_t)k * 6 + d])); }
+        for (int l = 0; l < P; ++l) if (BS.lfree[l]) for (int d = 0; d < 3; ++d) { const double v = points[(size_t)l * 3 + d]; s2 += v * v; gmax = std::max(gmax, fabs(bl[(size_t)l * 3 + d])); }
+        x_norm = sqrt(s2);
+    };
+
+    do {   // single-pass block so that every exit path reaches the common epilogue
+        // IterationZero
+        rc = evaluate(poses, points, &x_cost);
+        if (rc < 0) { hard_error = true; break; }
+        if (rc == 1) { term = YGZ_CERES_FAILURE; break; }
+        if ((rc = fetch_blocks()) != YGZ_OK) { hard_error = true; break; }
+        S.initial_cost = x_cost;
+        if (opt.jacobi_scaling) {
+            for (int k = 0; k < K; ++k) for (int d = 0; d < 6; ++d) scp[(size_t)k * 6 + d] = 1.0 / (1.0 + sqrt(Hpp[(size_t)k * 36 + 7 * d]));
+            for (int l = 0; l < P; ++l) for (int d = 0; d < 3; ++d) scl[(size_t)l * 3 + d] = 1.0 / (1.0 + sqrt(Hll[(size_t)l * 9 + 4 * d]));
+        }
+        norm_and_gradient();
+
+        for (;;) {
+            if (S.iterations >= opt.max_num_iterations) { term = YGZ_CERES_NO_CONVERGENCE; break; }
+            if (gmax <= opt.gradient_tolerance) { term = YGZ_CERES_GRADIENT_TOLERANCE; break; }
+            if (radius <= opt.min_trust_region_radius) { term = YGZ_CERES_MIN_RADIUS; break; }
+            ++S.iterations;
+            // LevenbergMarquardtStrategy::ComputeStep on the column-scaled system
+            for (int k = 0; k < K; ++k) for (int r = 0; r < 6; ++r) {
+                for (int c = 0; c < 6; ++c) sHpp[(size_t)k * 36 + 6 * r + c] = Hpp[(size_t)k * 36 + 6 * r + c] * scp[(size_t)k * 6 + r] * scp[(size_t)k * 6 + c];
+                sbp[(size_t)k * 6 + r] = bp[(size_t)k * 6 + r] * scp[(size_t)k * 6 + r];
+                const double dg = std::min(std::max(sHpp[(size_t)k * 36 + 7 * r], opt.min_lm_diagonal), opt.max_lm_diagonal);
+                dp[(size_t)k * 6 + r] = dg / radius;
+            }
+            for (int l = 0; l < P; ++l) for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) sHll[(size_t)l * 9 + 3 * r + c] = Hll[(size_t)l * 9 + 3 * r + c] * scl[(size_t)l * 3 + r] * scl[(size_t)l * 3 + c];
+                sbl[(size_t)l * 3 + r] = bl[(size_t)l * 3 + r] * scl[(size_t)l * 3 + r];
+                const double dg = std::min(std::max(sHll[(size_t)l * 9 + 4 * r], opt.min_lm_diagonal), opt.max_lm_diagonal);
+                dl[(size_t)l * 3 + r] = dg / radius;
+            }
+            for (int e = 0; e < E; ++e) {
+                const int ip = pb->edge_pose[e], il = pb->edge_point[e];
+                for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c)
+                    sHpl[(size_t)e * 18 + 3 * r + c] = Hpl[(size_t)e * 18 + 3 * r + c] * scp[(size_t)ip * 6 + r] * scl[(size_t)il * 3 + c];
+            }
+            bool valid = block_solve(BS, sHpp.data(), sHll.data(), sHpl.data(), sbp.data(), sbl.data(), dp.data(), dl.data(), xp, xl);
+            double model_cost_change = 0;
+            if (valid) {
+                std::fill(dxp.begin(), dxp.end(), 0.0);
+                for (int k = 0; k < K; ++k) if (fidx[k] >= 0) for (int d = 0; d < 6; ++d) {
+                    const double v = xp[(size_t)fidx[k] * 6 + d] * scp[(size_t)k * 6 + d];
+                    if (!std::isfinite(v)) valid = false;
+                    dxp[(size_t)k * 6 + d] = v;
+                }
+                for (int l = 0; l < P; ++l) for (int d = 0; d < 3; ++d) {
+                    const double v = xl[(size_t)l * 3 + d] * scl[(size_t)l * 3 + d];
+                    if (!std::isfinite(v)) valid = false;
+                    dxl[(size_t)l * 3 + d] = v;
+                }
+            }
+            if (valid) {      // model_cost_change = -(J d).(r + J d / 2) = d.b - d.H d / 2, from the blocks
+                for (int k = 0; k < K; ++k) if (fidx[k] >= 0) for (int r = 0; r < 6; ++r) {
+                    double hd = 0;
+                    for (int c = 0; c < 6; ++c) hd += Hpp[(size_t)k * 36 + 6 * r + c] * dxp[(size_t)k * 6 + c];
+                    model_cost_change += dxp[(size_t)k * 6 + r] * (bp[(size_t)k * 6 + r] - 0.5 * hd);
+                }
+                for (int l = 0; l < P; ++l) if (BS.lfree[l]) for (int r = 0; r < 3; ++r) {
+                    double hd = 0;
+                    for (int c = 0; c < 3; ++c) hd += Hll[(size_t)l * 9 + 3 * r + c] * dxl[(size_t)l * 3 + c];
+                    model_cost_change += dxl[(size_t)l * 3 + r] * (bl[(size_t)l * 3 + r] - 0.5 * hd);
+                }
+                for (int e = 0; e < E; ++e) {
+                    const double *h = &Hpl[(size_t)e * 18], *a = &dxp[(size_t)pb->edge_pose[e] * 6], *b = &dxl[(size_t)pb->edge_point[e] * 3];
+                    for (int r = 0; r < 6; ++r) model_cost_change -= a[r] * (h[3 * r] * b[0] + h[3 * r + 1] * b[1] + h[3 * r + 2] * b[2]);
+                }
+                if (!(model_cost_change > 0)) valid = false;
+            }
+            if (!valid) {     // HandleInvalidStep
+                if (++invalid_run >= opt.max_num_consecutive_invalid_steps) { term = YGZ_CERES_FAILURE; break; }
+                radius *= 0.5;
+                ++S.unsuccessful_steps;
+                continue;
+            }
+            invalid_run = 0;
+            cposes = poses; cpoints = points;
+            double step2 = 0;
+            for (size_t i = 0; i < cposes.size(); ++i) { cposes[i] += dxp[i]; step2 += dxp[i] * dxp[i]; }
+            for (size_t i = 0; i < cpoints.size(); ++i) { cpoints[i] += dxl[i]; step2 += dxl[i] * dxl[i]; }
+            double cand_cost = DBL_MAX;
+            rc = evaluate(cposes, cpoints, &cand_cost);
+            if (rc < 0) { hard_error = true; break; }
+            if (rc != YGZ_OK) cand_cost = DBL_MAX;              // evaluation failure = a step of very high cost
+            if (sqrt(step2) <= opt.parameter_tolerance * (x_norm + opt.parameter_tolerance)) { term = YGZ_CERES_PARAMETER_TOLERANCE; break; }
+            const double cost_change = x_cost - cand_cost;
+            if (fabs(cost_change) <= opt.function_tolerance * x_cost) { term = YGZ_CERES_FUNCTION_TOLERANCE; break; }
+            const double relative_decrease = cost_change / model_cost_change;
+            if (relative_decrease > opt.min_relative_decrease) {              // HandleSuccessfulStep
+                poses = cposes; points = cpoints; x_cost = cand_cost;        // the window already holds this state's blocks
+                if ((rc = fetch_blocks()) != YGZ_OK) { hard_error = true; break; }
+                norm_and_gradient();
+                double t = 2.0 * relative_decrease - 1.0;
+                t = 1.0 - t * t * t;
+                radius = std::min(radius / std::max(1.0 / 3.0, t), opt.max_trust_region_radius);
+                decrease_factor = 2.0;
+                ++S.successful_steps;
+            } else {                                                          // StepRejected
+                radius = radius / decrease_factor;
+                decrease_factor *= 2.0;
+                ++S.unsuccessful_steps;
+            }
+        }
+    } while (0);
+    if (hard_error) return rc;
+    S.termination = term; S.final_cost = x_cost; S.final_radius = radius;
+    memcpy(poses_io, poses.data(), poses.size() * 8); memcpy(points_io, points.data(), points.size() * 8);
+    if (summary) *summary = S;
     return YGZ_OK;
 }
