@@ -116,6 +116,64 @@ int main(int argc, char **argv)
         for (int i = 0; i < 8; ++i) { double t[7]; by_id[i]->_TCW.to7(t); fprintf(out, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
         for (int i = 0; i < 16; ++i) fprintf(out, "%.17g %.17g %.17g\n", mpv[i]->_pos_world[0], mpv[i]->_pos_world[1], mpv[i]->_pos_world[2]);
     }
+    // --- the ceres-based entry points of ba:: on the same fixture (rebuilt from the input files)
+    {
+        auto kp = slurp_f64(in + "/ba_poses7.f64"); auto pt = slurp_f64(in + "/ba_points.f64"); auto ob = slurp_f64(in + "/ba_obs.f64");
+        auto build = [&](std::set<Frame *> &frames, std::set<MapPoint *> &map_points, std::vector<Frame *> &by_id, std::vector<MapPoint *> &mpv) {
+            Memory::Clean(); frames.clear(); map_points.clear(); by_id.clear(); mpv.clear();
+            for (int i = 0; i < 8; ++i) { Frame *nf = new Frame(); Memory::RegisterKeyFrame(nf); nf->_TCW = SE3::from7(&kp[7 * i]); frames.insert(nf); by_id.push_back(nf); }
+            for (int i = 0; i < 16; ++i) {
+                MapPoint *mp = new MapPoint; mp->_id = i; mp->_pos_world = Vector3d(pt[3 * i], pt[3 * i + 1], pt[3 * i + 2]);
+                for (int j = 0; j < 8; ++j) { Feature *fea = new Feature(Vector2d(ob[2 * (8 * i + j)], ob[2 * (8 * i + j) + 1])); fea->_frame = by_id[j]; fea->_mappoint = mp; by_id[j]->_features.push_back(fea); mp->_obs[j] = fea; }
+                map_points.insert(mp); mpv.push_back(mp);
+            }
+        };
+        auto reproj = [&](Frame *fr) { double s = 0; for (Feature *fea : fr->_features) { Vector2d d = Frame::_camera->World2Pixel(fea->_mappoint->_pos_world, fr->_TCW) - fea->_pixel; s += d.dot(d); } return s; };
+        std::set<Frame *> frames; std::set<MapPoint *> map_points; std::vector<Frame *> by_id; std::vector<MapPoint *> mpv;
+        build(frames, map_points, by_id, mpv);
+        ba::LocalBA(frames, map_points);
+        fprintf(out, "ba_ceres 0\n");
+        for (int i = 0; i < 8; ++i) { double t[7]; by_id[i]->_TCW.to7(t); fprintf(out, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
+        for (int i = 0; i < 16; ++i) fprintf(out, "%.17g %.17g %.17g\n", mpv[i]->_pos_world[0], mpv[i]->_pos_world[1], mpv[i]->_pos_world[2]);
+        // OptimizeCurrentPointOnly / OptimizeCurrent on keyframe 5 of the noisy scene: the reprojection error over all views must drop
+        build(frames, map_points, by_id, mpv);
+        auto reproj_all = [&]() { double s2 = 0; for (Frame *fr : by_id) s2 += reproj(fr); return s2; };     // the cost both calls minimise
+        const double e0 = reproj_all();
+        ba::OptimizeCurrentPointOnly(by_id[5]);
+        const double e1 = reproj_all();
+        build(frames, map_points, by_id, mpv);
+        ba::OptimizeCurrent(by_id[5]);
+        const double e2 = reproj_all();
+        int nbad = 0; for (Feature *fea : by_id[5]->_features) nbad += fea->_bad;
+        fprintf(out, "opt_current %.17g %.17g %.17g %d\n", e0, e1, e2, nbad);
+        // TwoViewBACeres: keyframes 0 and 7, points 0..15, every correspondence an inlier
+        build(frames, map_points, by_id, mpv);
+        vector<Vector2d> px_ref, px_curr; vector<bool> inl(16, true); vector<Vector3d> pts;
+        for (int i = 0; i < 16; ++i) { px_ref.push_back(mpv[i]->_obs[0]->_pixel); px_curr.push_back(mpv[i]->_obs[7]->_pixel); pts.push_back(mpv[i]->_pos_world); }
+        inl[3] = false;
+        SE3 curr = by_id[7]->_TCW;
+        ba::TwoViewBACeres(by_id[0]->_TCW, curr, px_ref, px_curr, inl, pts);
+        double t7[7]; curr.to7(t7); int ninl = 0; for (bool b : inl) ninl += b;
+        fprintf(out, "two_view %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", ninl, t7[0], t7[1], t7[2], t7[3], t7[4], t7[5], t7[6]);
+        for (int i = 0; i < 16; ++i) fprintf(out, "tv_pt %.17g %.17g %.17g\n", pts[i][0], pts[i][1], pts[i][2]);
+    }
+    // --- ba::OptimizeCurrentPoseOnly on a frame written by the harness: pose [t; aa], px [n][2], pw [n][3]
+    {
+        auto pe = slurp_f64(in + "/po_entry.f64"); auto ppx = slurp_f64(in + "/po_px.f64"); auto ppw = slurp_f64(in + "/po_pw.f64");
+        const int n = (int)(ppx.size() / 2);
+        Frame fr;
+        fr._TCW = SE3(SO3::exp(Vector3d(pe[3], pe[4], pe[5])), Vector3d(pe[0], pe[1], pe[2]));
+        std::vector<MapPoint *> mps;
+        for (int i = 0; i < n; ++i) {
+            MapPoint *mp = new MapPoint; mp->_pos_world = Vector3d(ppw[3 * i], ppw[3 * i + 1], ppw[3 * i + 2]);
+            Feature *fea = new Feature(Vector2d(ppx[2 * i], ppx[2 * i + 1])); fea->_frame = &fr; fea->_mappoint = mp; fea->_depth = -1;
+            fr._features.push_back(fea); mps.push_back(mp);
+        }
+        ba::OptimizeCurrentPoseOnly(&fr);
+        const Vector3d t = fr._TCW.translation(), r = fr._TCW.so3().log();
+        fprintf(out, "pose_only %d %.17g %.17g %.17g %.17g %.17g %.17g\n", n, t[0], t[1], t[2], r[0], r[1], r[2]);
+        for (int i = 0; i < n; ++i) fprintf(out, "po_f %d %.17g %d\n", (int)fr._features[i]->_bad, fr._features[i]->_depth, mps[i]->_cnt_found);
+    }
     fclose(out);
     return 0;
 }

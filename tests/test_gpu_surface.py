@@ -34,6 +34,9 @@ def _parse(path):
             out["ba_hdr"] = [float(x) for x in t[1:]]
             out["ba_poses"] = np.array([lines[i + k].split() for k in range(8)], dtype=np.float64); i += 8
             out["ba_points"] = np.array([lines[i + k].split() for k in range(16)], dtype=np.float64); i += 16
+        elif tag == "ba_ceres":
+            out["bc_poses"] = np.array([lines[i + k].split() for k in range(8)], dtype=np.float64); i += 8
+            out["bc_points"] = np.array([lines[i + k].split() for k in range(16)], dtype=np.float64); i += 16
         else:
             out.setdefault(tag, []).append(t[1:])
     return out
@@ -57,6 +60,8 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     T7 = np.array([oracle.se3_exp(np.concatenate([p[3:], p[:3]])) for p in f["poses"]])
     T7.tofile(os.path.join(d, "ba_poses7.f64")); f["points"].tofile(os.path.join(d, "ba_points.f64"))
     f["obs"].reshape(16, 8, 2).tofile(os.path.join(d, "ba_obs.f64"))
+    pof = synth.pose_only_fixture(n=300, seed=12)
+    pof["entry"].tofile(os.path.join(d, "po_entry.f64")); pof["px"].tofile(os.path.join(d, "po_px.f64")); pof["pw"].tofile(os.path.join(d, "po_pw.f64"))
     outp = os.path.join(d, "out.txt")
     subprocess.check_call([BIN, d, outp], timeout=300)
     r = _parse(outp)
@@ -128,6 +133,38 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     assert outl == int((back["chi2_edge"] > 5.991).sum())
     assert np.allclose(r["ba_poses"][0], T7[0])                      # keyframe 0 fixed
     ctx.close()
+
+    # ba::LocalBA (ceres): the same scene as [t; angle-axis] + normalised observations through the oracle's ceres::Solve.
+    # (block order follows std::set pointer order on the C++ side: compare the optimum, not the bit pattern)
+    def to_taa(T7rows):
+        return np.array([np.concatenate([T[4:], oracle.se3_log(np.concatenate([T[:4], [0, 0, 0]]))[3:]]) for T in T7rows])
+    cam = oracle.camera()
+    obs_n = np.stack([(f["obs"][:, 0] - cam.cx) / cam.fx, (f["obs"][:, 1] - cam.cy) / cam.fy], 1)
+    po_c, pt_c, sm = oracle.ceres_solve(to_taa(T7), f["fixed"], f["points"], f["edge_pose"], f["edge_point"], obs_n)
+    got = oracle.ceres_linearize(to_taa(r["bc_poses"]), f["fixed"], r["bc_points"], f["edge_pose"], f["edge_point"], obs_n)
+    assert sm["termination"] in (0, 1, 2) and abs(got["cost"] - sm["final_cost"]) <= 1e-4 * sm["final_cost"]
+    assert np.abs(to_taa(r["bc_poses"]) - po_c).max() < 1e-3 and np.abs(r["bc_points"] - pt_c).max() < 1e-2
+    assert np.allclose(r["bc_poses"][0], T7[0], atol=1e-15)
+    # OptimizeCurrentPointOnly / OptimizeCurrent: the reprojection error over all views (the cost they minimise) drops
+    e0, e1, e2, nbad = [float(x) for x in r["opt_current"][0]]
+    assert e1 < 0.7 * e0 and e2 < 0.7 * e0
+    # TwoViewBACeres: 15 inliers + 1 flagged outlier (reset to (0,0,1), HuberLoss(0.1)); the result must explain both views
+    tv = [float(x) for x in r["two_view"][0]]
+    tv_pts = np.array(r["tv_pt"], dtype=np.float64)
+    Tc = np.array(tv[1:])
+    uv0, z0 = synth.project(T7[0], tv_pts); uv1, z1 = synth.project(Tc, tv_pts)
+    e_ref = ((uv0 - f["obs"].reshape(16, 8, 2)[:, 0]) ** 2).sum(1); e_cur = ((uv1 - f["obs"].reshape(16, 8, 2)[:, 7]) ** 2).sum(1)
+    assert int(tv[0]) == int(((e_ref <= 5.991) & (e_cur <= 5.991) & (z0 >= 0) & (z1 >= 0)).sum()) and int(tv[0]) >= 14
+    # ba::OptimizeCurrentPoseOnly against the oracle (bar 1e-5 relative on the pose)
+    o_pose, o_bad, o_dep, o_inl, o_rounds = oracle.optimize_current_pose_only(pof["entry"], pof["px"], pof["pw"])
+    hdr = [float(x) for x in r["pose_only"][0]]
+    rows = np.array(r["po_f"], dtype=np.float64)
+    # the C++ surface stores the pose as an SE3 (quaternion) and hands back log(): 1e-12 of round trip
+    assert int(hdr[0]) == len(pof["px"]) and np.abs(np.array(hdr[1:]) - o_pose).max() <= 1e-7 * max(1.0, np.abs(o_pose).max())
+    assert np.array_equal(rows[:, 0].astype(np.uint8), o_bad)
+    m = o_bad == 0
+    assert np.allclose(rows[m, 1], o_dep[m], rtol=1e-9) and np.all(rows[~m, 1] == -1)
+    assert np.array_equal(rows[:, 2].astype(int), (o_bad == 0).astype(int))          # _cnt_found++ for the inliers
 
 
 def test_ba_optimize_converges_to_ground_truth(hip_lib, oracle):

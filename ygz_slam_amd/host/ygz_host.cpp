@@ -613,5 +613,189 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     for (size_t l = 0; l < pts.size(); ++l) pts[l]->_pos_world = Vector3d(points[3 * l], points[3 * l + 1], points[3 * l + 2]);
     if (stats) { stats->iterations = st.iterations; stats->lm_trials = st.lm_trials; stats->outliers = cntOutlier; stats->chi2_initial = st.chi2_initial; stats->chi2_final = st.chi2_final; }
 }
+// ---- the ceres-based entry points (BA.cpp:11-384) ------------------------------------------------------------------
+namespace {
+// one ceres::Problem as arrays: parameter blocks = poses [t; angle-axis] and points, residual blocks = edges
+struct CeresArrays {
+    std::vector<double> poses, points, obs, huber;
+    std::vector<uint8_t> pose_fixed, point_fixed;
+    std::vector<int32_t> edge_pose, edge_point;
+    bool any_huber = false;
+    int add_pose(const SE3 &T, bool fixed)
+    {   // pose.head<3>() = t, pose.tail<3>() = so3().log()  (BA.cpp:96-99)
+        const Vector3d t = T.translation(), r = T.so3().log();
+        for (int i = 0; i < 3; ++i) poses.push_back(t[i]);
+        for (int i = 0; i < 3; ++i) poses.push_back(r[i]);
+        pose_fixed.push_back(fixed ? 1 : 0);
+        return (int)pose_fixed.size() - 1;
+    }
+    int add_point(const Vector3d &p, bool fixed)
+    {
+        for (int i = 0; i < 3; ++i) points.push_back(p[i]);
+        point_fixed.push_back(fixed ? 1 : 0);
+        return (int)point_fixed.size() - 1;
+    }
+    void add_edge(int ip, int il, const Vector2d &obs_n, double huber_a)
+    {
+        edge_pose.push_back(ip); edge_point.push_back(il); obs.push_back(obs_n[0]); obs.push_back(obs_n[1]);
+        huber.push_back(huber_a); any_huber |= huber_a > 0;
+    }
+    SE3 pose(int k) const
+    {   // SE3(SO3::exp(pose.tail<3>()), pose.head<3>())  (BA.cpp:65,146)
+        const double *p = &poses[6 * (size_t)k];
+        return SE3(SO3::exp(Vector3d(p[3], p[4], p[5])), Vector3d(p[0], p[1], p[2]));
+    }
+    bool solve(ygz_ceres_summary *sum = nullptr)
+    {
+        if (edge_pose.empty()) return false;
+        ygz_ba_problem pb; memset(&pb, 0, sizeof(pb));
+        pb.n_poses = (int)pose_fixed.size(); pb.n_points = (int)point_fixed.size(); pb.n_edges = (int)edge_pose.size();
+        pb.poses = poses.data(); pb.pose_fixed = pose_fixed.data(); pb.points = points.data(); pb.point_fixed = point_fixed.data();
+        pb.edge_pose = edge_pose.data(); pb.edge_point = edge_point.data(); pb.obs = obs.data();
+        pb.edge_huber = any_huber ? huber.data() : nullptr; pb.formulation = 2;
+        ygz_ceres_summary s;
+        hip::check(ygz_hip_ba_solve_ceres(hip::Runtime::Get().ctx(), &pb, poses.data(), points.data(), nullptr, &s), "ba_solve_ceres");
+        if (sum) *sum = s;
+        return s.termination != YGZ_CERES_FAILURE;
+    }
+};
+}  // namespace
+
+void TwoViewBACeres(const SE3 &ref, SE3 &curr, const vector<Vector2d> px_ref, const vector<Vector2d> px_curr,
+                    vector<bool> &inlier, vector<Vector3d> &pts_ref)
+{   // BA.cpp:11-89
+    assert(px_ref.size() == px_curr.size());
+    PinholeCamera *cam = Frame::GetCamera();
+    assert(cam != nullptr);
+    CeresArrays A;
+    const int kr = A.add_pose(ref, true), kc = A.add_pose(curr, false);      // ref: PointOnly functor; curr: pose + point
+    for (size_t i = 0; i < px_ref.size(); ++i) {
+        if (inlier[i] == false) pts_ref[i] = Vector3d(0, 0, 1);
+        const int il = A.add_point(pts_ref[i], false);
+        const double a = inlier[i] ? 0.0 : 0.1;                                // HuberLoss(0.1) on the outliers only
+        A.add_edge(kr, il, cam->Pixel2Camera2D(px_ref[i]), a);
+        A.add_edge(kc, il, cam->Pixel2Camera2D(px_curr[i]), a);
+    }
+    A.solve();
+    curr = A.pose(kc);
+    const double ch2 = 5.991;
+    for (size_t i = 0; i < px_ref.size(); ++i) {
+        pts_ref[i] = Vector3d(A.points[3 * i], A.points[3 * i + 1], A.points[3 * i + 2]);
+        const Vector2d e1 = px_ref[i] - cam->World2Pixel(pts_ref[i], ref), e2 = px_curr[i] - cam->World2Pixel(pts_ref[i], curr);
+        const double depth1 = cam->World2Camera(pts_ref[i], ref)[2], depth2 = cam->World2Camera(pts_ref[i], curr)[2];
+        if (e1.dot(e1) > ch2 || e2.dot(e2) > ch2) inlier[i] = false;
+        else if (depth1 < 0 || depth2 < 0) inlier[i] = false;
+        else inlier[i] = true;
+    }
+}
+
+void OptimizeCurrent(Frame *current)
+{   // BA.cpp:91-186: current pose + its map points, every observing keyframe constant, HuberLoss(0.1) everywhere
+    const float chi2Mono = 5.991 * 4;
+    CeresArrays A;
+    const int kc = A.add_pose(current->_TCW, false);
+    std::map<unsigned long, int> kf_index;
+    std::map<MapPoint *, int> pt_index;                  // one parameter block per _pos_world.data()
+    for (Feature *fea : current->_features) {
+        assert(fea->_mappoint != nullptr);
+        auto it = pt_index.find(fea->_mappoint);
+        const int il = it != pt_index.end() ? it->second : (pt_index[fea->_mappoint] = A.add_point(fea->_mappoint->_pos_world, false));
+        A.add_edge(kc, il, Frame::_camera->Pixel2Camera2D(fea->_pixel), 0.1);
+        for (auto &obs_pair : fea->_mappoint->_obs) {
+            Frame *frame = Memory::GetKeyFrame(obs_pair.first);
+            auto kt = kf_index.find(obs_pair.first);
+            const int k = kt != kf_index.end() ? kt->second : (kf_index[obs_pair.first] = A.add_pose(frame->_TCW, true));
+            A.add_edge(k, il, Frame::_camera->Pixel2Camera2D(obs_pair.second->_pixel), 0.1);
+        }
+    }
+    A.solve();
+    current->_TCW = A.pose(kc);
+    for (auto &pi : pt_index) pi.first->_pos_world = Vector3d(A.points[3 * pi.second], A.points[3 * pi.second + 1], A.points[3 * pi.second + 2]);
+    for (Feature *fea : current->_features) {
+        const Vector2d delta = Frame::_camera->World2Pixel(fea->_mappoint->_pos_world, current->_TCW) - fea->_pixel;
+        if (delta.dot(delta) > chi2Mono) fea->_bad = true;
+        else fea->_depth = Frame::_camera->World2Camera(fea->_mappoint->_pos_world, current->_TCW)[2];
+    }
+}
+
+void OptimizeCurrentPoseOnlyBatch(const vector<Frame *> &frames)
+{   // BA.cpp:188-264 for every frame of the batch in one launch
+    std::vector<int32_t> off(1, 0);
+    std::vector<double> px, pw, poses, depth;
+    for (Frame *f : frames) {
+        for (Feature *fea : f->_features) {
+            assert(fea->_mappoint != nullptr);
+            px.push_back(fea->_pixel[0]); px.push_back(fea->_pixel[1]);
+            for (int i = 0; i < 3; ++i) pw.push_back(fea->_mappoint->_pos_world[i]);
+            depth.push_back(fea->_depth);
+        }
+        off.push_back((int32_t)(px.size() / 2));
+        const Vector3d t = f->_TCW.translation(), r = f->_TCW.so3().log();
+        for (int i = 0; i < 3; ++i) poses.push_back(t[i]);
+        for (int i = 0; i < 3; ++i) poses.push_back(r[i]);
+    }
+    std::vector<uint8_t> bad(std::max<size_t>(depth.size(), 1));
+    if (depth.empty()) depth.push_back(0);
+    hip::check(ygz_hip_optimize_pose_only(hip::Runtime::Get().ctx(), (int)frames.size(), off.data(), px.data(), pw.data(), poses.data(),
+                                          bad.data(), depth.data(), nullptr, nullptr), "optimize_pose_only");
+    size_t g = 0;
+    for (size_t fi = 0; fi < frames.size(); ++fi) {
+        Frame *f = frames[fi];
+        const double *p = &poses[6 * fi];
+        f->_TCW = SE3(SO3::exp(Vector3d(p[3], p[4], p[5])), Vector3d(p[0], p[1], p[2]));
+        for (Feature *fea : f->_features) {
+            fea->_bad = bad[g] != 0;
+            if (!fea->_bad) fea->_depth = depth[g];
+            if (fea->_bad == false && fea->_mappoint && fea->_mappoint->_bad == false) fea->_mappoint->_cnt_found++;   // BA.cpp:257-263
+            ++g;
+        }
+    }
+}
+void OptimizeCurrentPoseOnly(Frame *current) { OptimizeCurrentPoseOnlyBatch(vector<Frame *>(1, current)); }
+
+void OptimizeCurrentPointOnly(Frame *current)
+{   // BA.cpp:266-322: the frame's map points against the (constant) current pose and every observing keyframe
+    CeresArrays A;
+    const int kc = A.add_pose(current->_TCW, true);
+    std::map<unsigned long, int> kf_index;
+    std::map<MapPoint *, int> pt_index;
+    for (Feature *fea : current->_features) {
+        if (fea->_bad || fea->_mappoint == nullptr) continue;
+        auto it = pt_index.find(fea->_mappoint);
+        const int il = it != pt_index.end() ? it->second : (pt_index[fea->_mappoint] = A.add_point(fea->_mappoint->_pos_world, false));
+        A.add_edge(kc, il, Frame::_camera->Pixel2Camera2D(fea->_pixel), 0.0);
+        for (auto &obs_pair : fea->_mappoint->_obs) {
+            Frame *frame = Memory::GetKeyFrame(obs_pair.first);
+            auto kt = kf_index.find(obs_pair.first);
+            const int k = kt != kf_index.end() ? kt->second : (kf_index[obs_pair.first] = A.add_pose(frame->_TCW, true));
+            A.add_edge(k, il, Frame::_camera->Pixel2Camera2D(obs_pair.second->_pixel), 0.0);
+        }
+    }
+    if (!A.solve()) return;
+    for (auto &pi : pt_index) pi.first->_pos_world = Vector3d(A.points[3 * pi.second], A.points[3 * pi.second + 1], A.points[3 * pi.second + 2]);
+}
+
+void LocalBA(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points)
+{   // BA.cpp:324-384: keyframe 0 enters through the PointOnly functor (constant), no loss function, default options
+    CeresArrays A;
+    std::map<Frame *, int> pose_index;
+    std::vector<MapPoint *> order;                      // owner of each point block
+    for (MapPoint *mp : local_map_points) {
+        int il = -1;
+        for (auto &obs_pair : mp->_obs) {
+            Frame *frame = Memory::GetKeyFrame(obs_pair.first);
+            assert(frame != nullptr);
+            if (local_keyframes.find(frame) == local_keyframes.end()) continue;
+            if (il < 0) { il = A.add_point(mp->_pos_world, false); order.push_back(mp); }
+            auto it = pose_index.find(frame);
+            const int k = it != pose_index.end() ? it->second : (pose_index[frame] = A.add_pose(frame->_TCW, frame->_keyframe_id == 0));
+            A.add_edge(k, il, Frame::_camera->Pixel2Camera2D(obs_pair.second->_pixel), 0.0);
+        }
+    }
+    if (A.edge_pose.empty()) return;
+    A.solve();
+    for (auto &pp : pose_index) if (pp.first->_keyframe_id != 0) pp.first->_TCW = A.pose(pp.second);      // BA.cpp:378-382
+    for (size_t l = 0; l < order.size(); ++l) order[l]->_pos_world = Vector3d(A.points[3 * l], A.points[3 * l + 1], A.points[3 * l + 2]);
+}
 }  // namespace ba
 }  // namespace ygz
