@@ -210,7 +210,14 @@ def main():
                "k_hamming_nn": a.batch * 72000.0 * 0.5}.get(probe_kernel, 0.0)
         avg_s = (probe_ms / max(probe_n, 1)) * 1e-3
         ach = alg / avg_s / 1e9 if avg_s > 0 else 0.0
-        roofline = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+        # HBM bytes per launch from the PMC passes of this same command (tools/collect_profiles.sh -> profiles/traffic.json)
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("batch") == a.batch and probe_kernel in tj.get("kernels", {}):
+                traffic = tj["kernels"][probe_kernel]["hbm_bytes"]
+        roofline = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                     "kernel": probe_kernel, "launches": probe_n, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg}
         res = {"metric": "frames/sec (extract+match+LK+local-BA), 640x480, 1000 ORB kpts", "value": frames / dt, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
