@@ -19,7 +19,6 @@
 #include <stdio.h>
 
 #define SA_THREADS 512
-#define SA_CHUNK   4096          // floats of res^2 staged in LDS per pass
 
 struct SaArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
@@ -29,7 +28,7 @@ struct SaArgs {
     const int32_t *pair_q, *pair_t, *trk_n;       // cur slot, ref slot, features per pair
     const double *pair_T;                         // [pairs][2][7]; T_ref used here
     const double *trk_px, *trk_depth; const uint8_t *trk_has_mp;     // [pairs][cells]
-    uint8_t *work; size_t work_stride;            // per pair: jac_cache | patch_cache | r2 | visible
+    uint8_t *work; size_t work_stride;            // per pair: jac_cache | patch_cache | r2 | ssq | visible | used
     double *out;                                  // [pairs][16]: pose 7 (in: initial cur->_TCW, out: result), n_meas, iters
     double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
 };
@@ -41,10 +40,34 @@ __device__ __forceinline__ double wave_sum_d(double v)
     return v;
 }
 
+// ---- the reference's chi2: a FLOAT running sum c = fl(c + res*res) over all features / pixels in order
+// (SparseImageAlign.cpp:213), whose value decides when the Gauss-Newton loop stops (NLSSolver_impl.hpp:53) -- so it has to
+// be reproduced bit for bit, and as a dependent chain of n*16 float adds it used to be the critical path of the kernel.
+// It is evaluated here EXACTLY but not sequentially.  While c stays inside one binade [2^E, 2^(E+1)) it is m * ulp with an
+// integer m, and adding x >= 0 rounds to nearest-even on that grid: m += floor(x/ulp) + (frac > 1/2, or frac == 1/2 and the
+// result would be odd).  The only sequential state that influences an increment is therefore the PARITY of m (ties).  A run
+// of consecutive terms is summarised, for a predicted binade E, by two integers: the total increment for incoming parity 0
+// and for incoming parity 1; two such maps compose associatively.  Each lane builds the map of one feature (16 terms,
+// integer ALU only), shuffles compose them into maps of 4 and 16 features, and the wave walks these: if c really is in the
+// predicted binade and the run does not leave it, one integer add replaces 256 (or 64) dependent float adds; otherwise
+// (binade crossings: the first few runs and ~log2(n) later ones) the 64 terms are added one by one in hardware floats.
+// Either way the result is the reference's float, bit for bit.
+__device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &t1, int &bad)
+{   // branch-free: every lane of the wave runs the same ~20 integer instructions per term
+    const uint32_t bex = xb >> 23, mant = xb & 0x7fffffu;
+    const uint32_t mx = bex ? (mant | 0x800000u) : mant;        // x = mx * 2^(ex - 150), ulp of the binade = 2^(E - 150)
+    const int shift = E - (int)max(bex, 1u);                     // denormals share the exponent of the smallest normal
+    bad |= (shift <= 0) & (mx != 0);                             // x >= 2^E (or inf/nan): the sum leaves the binade
+    const int sh = min(max(shift, 1), 31);                       // shift >= 25: x < ulp / 2 -> a = 0, rem = mx < half: no change
+    const uint32_t a = mx >> sh, rem = mx & ((1u << sh) - 1u), half = 1u << (sh - 1);
+    const int up = rem > half, tie = rem == half;
+    t0 += (int)a + (up | (tie & ((t0 + (int)a) & 1)));
+    t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
+}
+
 __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
 {
     __shared__ double red[SA_THREADS / 64][28];
-    __shared__ float stage[SA_CHUNK];
     __shared__ Se3 sT;
     __shared__ int s_ctl;                 // 0 continue, 1 leave level
     __shared__ int s_nmeas_w[SA_THREADS / 64];
@@ -66,7 +89,8 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
     double *jac_cache = (double *)wk;                                   // [16*6][cells]  (entry-major: coalesced over features)
     float *patch_cache = (float *)(jac_cache + 96 * (size_t)A.cells);   // [16][cells]
     float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [cells][16]
-    uint8_t *visible = (uint8_t *)(r2 + 16 * (size_t)A.cells);          // [cells]
+    float *ssq = r2 + 16 * (size_t)A.cells;                             // [cells] sum of the feature's 16 squares (binade prediction only)
+    uint8_t *visible = (uint8_t *)(ssq + A.cells);                      // [cells]
     uint8_t *used = visible + A.cells;                                  // [cells] feature contributes this iteration
     Se3 T_ref;
     for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
@@ -75,7 +99,8 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
     double chi2_ = 1e10; bool stop_ = false;
     Se3 old_model;
     int n_meas_last = 0;
-    long long tph[6] = { 0, 0, 0, 0, 0, 0 }, tlast = clock64();
+    long long tph[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = clock64();
+    __shared__ long long s_acc_cyc;
 #define SA_PHASE(k) do { if (tid == 0) { const long long tn_ = clock64(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 
     if (tid == 0) {
@@ -172,6 +197,10 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                         }
                     }
                 }
+                float sq = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sq += res[k] * res[k];
+                ssq[f] = sq;
                 float4 *dst = reinterpret_cast<float4 *>(r2 + 16 * (size_t)f);        // r2 buffer holds the residuals
                 dst[0] = make_float4(res[0], res[1], res[2], res[3]);     dst[1] = make_float4(res[4], res[5], res[6], res[7]);
                 dst[2] = make_float4(res[8], res[9], res[10], res[11]);   dst[3] = make_float4(res[12], res[13], res[14], res[15]);
@@ -189,37 +218,81 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
             SA_PHASE(1);      // residual pass
             if (wv == 0) {
                 // ---- wave 0: chi2 = the reference's FLOAT sum of res*res in feature/pixel order (a skipped feature
-                // contributes 0.0f + ... exactly).  The wave stages 4096 residuals at a time in LDS with coalesced
-                // 16-byte loads; lane 0 runs the dependent add chain (the squares are off the chain).
-                float c = 0.0f;
-                for (int c0 = 0; c0 < n * 16; c0 += SA_CHUNK) {
-                    const int cnt = min(SA_CHUNK, n * 16 - c0);
-                    for (int i = lane * 4; i < cnt; i += 256)
-                        *reinterpret_cast<float4 *>(&stage[i]) = *reinterpret_cast<const float4 *>(&r2[c0 + i]);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) {
-                        int i = 0;
-                        for (; i + 32 <= cnt; i += 32) {
-                            float4 q[8];
+                // contributes 0.0f + ... exactly), evaluated through the group maps described at sa_chain_term.
+                // lane = feature (64 per pass, coalesced 16-byte loads of the residuals); the 16-term feature maps are composed
+                // along the lanes into quad maps (64 terms) and hex maps (256 terms); the wave then walks hex -> quad -> terms.
+                uint32_t cb = 0u;                                            // bits of c, wave-uniform
+                const int J = (n + 63) >> 6;
+                for (int j = 0; j < J; ++j) {
+                    const int f = 64 * j + lane;
+                    float x[16];
+                    float sq = 0.f;
+                    if (f < n) {
+                        const float4 *src = reinterpret_cast<const float4 *>(r2 + 16 * (size_t)f);
+                        const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
+                        sq = ssq[f];
+                        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+                        x[8] = a2.x; x[9] = a2.y; x[10] = a2.z; x[11] = a2.w; x[12] = a3.x; x[13] = a3.y; x[14] = a3.z; x[15] = a3.w;
+                    } else {
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) q[k] = *reinterpret_cast<const float4 *>(&stage[i + 4 * k]);
+                        for (int k = 0; k < 16; ++k) x[k] = 0.f;
+                    }
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].x, q[k].x), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].y, q[k].y), 1.0f));
-                                c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].z, q[k].z), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q[k].w, q[k].w), 1.0f));
+                    for (int k = 0; k < 16; ++k) x[k] = __fmul_rn(__fmul_rn(x[k], x[k]), 1.0f);      // res*res*weight (:213)
+                    // predicted c at the start of the lane's feature: exact c so far + exclusive scan of the approximate feature sums
+                    float incl = sq;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+                    int E = (int)(__float_as_uint(__uint_as_float(cb) + (incl - sq)) >> 23);
+                    int t0 = 0, t1 = 0, bad = !(E > 0 && E < 255);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
+                    // compose along the lanes: (A then B)(p) = A(p) + B((p + A(p)) & 1); a group is usable only inside one binade
+#define SA_COMPOSE(dist, sel)                                                                                         \
+                    { const int a0_ = __shfl_up(t0, dist), a1_ = __shfl_up(t1, dist), ab_ = __shfl_up(bad, dist), aE_ = __shfl_up(E, dist); \
+                      if (sel) { const int n0_ = a0_ + ((a0_ & 1) ? t1 : t0), n1_ = a1_ + (((1 + a1_) & 1) ? t1 : t0);           \
+                                 bad |= ab_ | (aE_ != E); t0 = n0_; t1 = n1_; E = aE_; } }
+                    SA_COMPOSE(1, (lane & 1) == 1)
+                    SA_COMPOSE(2, (lane & 3) == 3)
+                    const int qt0 = t0, qt1 = t1, qbad = bad, qE = E;         // quad maps live in lanes 4k+3
+                    SA_COMPOSE(4, (lane & 7) == 7)
+                    SA_COMPOSE(8, (lane & 15) == 15)                          // hex maps live in lanes 16h+15
+#undef SA_COMPOSE
+#define SA_TRY(m0_, m1_, mE_, mbad_, taken)                                                                            \
+                    { taken = false;                                                                                   \
+                      if (!(mbad_) && (int)(cb >> 23) == (mE_)) {                                                      \
+                          const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u, mn_ = m_ + (uint32_t)((m_ & 1u) ? (m1_) : (m0_)); \
+                          if (mn_ < 0x1000000u) { cb = (cb & 0xff800000u) | (mn_ & 0x7fffffu); taken = true; } } }
+                    const int nh = min(4, (n - 64 * j + 15) >> 4);
+                    for (int h = 0; h < nh; ++h) {
+                        const int hl = 16 * h + 15;
+                        bool taken;
+                        SA_TRY(__builtin_amdgcn_readlane(t0, hl), __builtin_amdgcn_readlane(t1, hl), __builtin_amdgcn_readlane(E, hl),
+                               __builtin_amdgcn_readlane(bad, hl), taken)
+                        if (taken) continue;
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            const int ql = 16 * h + 4 * k4 + 3;
+                            SA_TRY(__builtin_amdgcn_readlane(qt0, ql), __builtin_amdgcn_readlane(qt1, ql), __builtin_amdgcn_readlane(qE, ql),
+                                   __builtin_amdgcn_readlane(qbad, ql), taken)
+                            if (taken) continue;
+                            if (A.dbg && tid == 0) tph[7] += 1;
+                            float cc = __uint_as_float(cb);                    // binade crossing: the quad term by term, hardware floats
+                            for (int fl_ = ql - 3; fl_ <= ql; ++fl_) {
+#pragma unroll
+                                for (int k = 0; k < 16; ++k)
+                                    cc = __fadd_rn(cc, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[k]), fl_)));
                             }
-                        }
-                        for (; i < cnt; i += 4) {
-                            const float4 q4 = *reinterpret_cast<const float4 *>(&stage[i]);
-                            c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.x, q4.x), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.y, q4.y), 1.0f));
-                            c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.z, q4.z), 1.0f)); c = __fadd_rn(c, __fmul_rn(__fmul_rn(q4.w, q4.w), 1.0f));
+                            cb = __builtin_amdgcn_readfirstlane(__float_as_uint(cc));
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
+#undef SA_TRY
                 }
+                const float c = __uint_as_float(cb);
                 if (lane == 0) s_chi2 = c;
+                if (tid == 0) { tph[2] += clock64() - tlast; tph[5] += 1; }
             } else {
                 // ---- waves 1..: H (21 unique) / Jres (6) in FP64 registers, concurrently with the chain above
+                const long long ta0 = A.dbg ? clock64() : 0;
                 double acc[27];
 #pragma unroll
                 for (int k = 0; k < 27; ++k) acc[k] = 0.0;
@@ -243,9 +316,11 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                 }
 #pragma unroll
                 for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
+                if (A.dbg && tid == 64) s_acc_cyc = clock64() - ta0;
             }
             __syncthreads();
             SA_PHASE(3);      // chain || accumulation
+            if (A.dbg && tid == 0) tph[6] += s_acc_cyc;
             // ---- lane 0: solve, decide, update (NLSSolver_impl.hpp:40-87)
             if (tid == 0) {
                 double Hm[36], Jr[6], x[6];
@@ -287,7 +362,7 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
         for (int k = 0; k < 4; ++k) out[k] = o.q[k];
         for (int k = 0; k < 3; ++k) out[4 + k] = o.t[k];
         out[7] = (double)n_meas_last;
-        if (A.dbg) for (int k = 0; k < 6; ++k) A.dbg[8 * (size_t)pair + k] = (double)tph[k];
+        if (A.dbg) for (int k = 0; k < 16; ++k) A.dbg[16 * (size_t)pair + k] = (double)tph[k];
     }
 }
 
@@ -301,14 +376,14 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
     A.dbg = nullptr;
-    if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 64, &d) == YGZ_OK) A.dbg = (double *)d; }
+    if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
     YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align, dim3(n_pairs), dim3(SA_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
-        double h[8];
+        double h[16];
         YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[sa-debug] pair0 cycles (100MHz ticks): overhead %.0f residual %.0f reduce %.0f chain %.0f solve %.0f\n", h[0], h[1], h[2], h[3], h[4]);
+        fprintf(stderr, "[sa-debug] pair0 shader cycles: overhead %.0f residual %.0f wave0-chain %.0f wave1-accumulate %.0f chain||accumulate %.0f solve %.0f; GN iterations %.0f, chain groups added term by term %.0f\n", h[0], h[1], h[2], h[6], h[3], h[4], h[5], h[7]);
     }
     return YGZ_OK;
 }
