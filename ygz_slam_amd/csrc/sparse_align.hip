@@ -28,7 +28,7 @@ struct SaArgs {
     const int32_t *pair_q, *pair_t, *trk_n;       // cur slot, ref slot, features per pair
     const double *pair_T;                         // [pairs][2][7]; T_ref used here
     const double *trk_px, *trk_depth; const uint8_t *trk_has_mp;     // [pairs][cells]
-    uint8_t *work; size_t work_stride;            // per pair: jac_cache | patch_cache | r2 | ssq | visible | used
+    uint8_t *work; size_t work_stride;            // per pair: Hf, fj, dxy, prev_used (96 doubles/cell) | patch_cache | r2 | ssq | visible | used
     double *out;                                  // [pairs][16]: pose 7 (in: initial cur->_TCW, out: result), n_meas, iters
     double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
 };
@@ -65,7 +65,7 @@ __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &
     t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
 }
 
-__global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
+__global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
 {
     __shared__ double red[SA_THREADS / 64][28];
     __shared__ Se3 sT;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
     __shared__ float s_chi2;
     __shared__ double s_ldlt[36 + 6 + 6];       // lane-0 solver workspace (LDS instead of private scratch)
     __shared__ int s_tr[6];
+    __shared__ double s_H[21];                  // H of the current level (updated by the change per iteration)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pair = blockIdx.x;
     const int n = A.trk_n[pair];
@@ -86,8 +87,15 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
     const double *px = A.trk_px + 2 * (size_t)pair * A.cells, *depth = A.trk_depth + (size_t)pair * A.cells;
     const uint8_t *has_mp = A.trk_has_mp + (size_t)pair * A.cells;
     uint8_t *wk = A.work + (size_t)pair * A.work_stride;
-    double *jac_cache = (double *)wk;                                   // [16*6][cells]  (entry-major: coalesced over features)
-    float *patch_cache = (float *)(jac_cache + 96 * (size_t)A.cells);   // [16][cells]
+    // Per level and feature (entry-major: coalesced over features).  The reference keeps 16 Jacobian columns per feature
+    // (jacobian_cache_, 768 B) and re-reads them every iteration; here the feature's contribution to H = sum J J^T, which does
+    // not depend on the iterate, is summed ONCE per level in the reference's own order (Hf), and what J^T res needs is kept
+    // factored: J = (dx * fj_row0 + dy * fj_row1) * fl  ->  16 x (dx, dy) floats + the 2x6 frame Jacobian.
+    double *Hf = (double *)wk;                                          // [cells][21] upper triangle of sum_px J J^T
+    double *fjc = Hf + 21 * (size_t)A.cells;                            // [cells][12] JacobXYZ2Cam rows
+    float *dxy = (float *)(fjc + 12 * (size_t)A.cells);                 // [cells][32] dx[16], dy[16]
+    uint8_t *prev_used = (uint8_t *)(dxy + 32 * (size_t)A.cells);       // [cells] the feature is part of the running H
+    float *patch_cache = (float *)((double *)wk + 96 * (size_t)A.cells);   // [cells][16]
     float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [cells][16]
     float *ssq = r2 + 16 * (size_t)A.cells;                             // [cells] sum of the feature's 16 squares (binade prediction only)
     uint8_t *visible = (uint8_t *)(ssq + A.cells);                      // [cells]
@@ -99,9 +107,16 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
     double chi2_ = 1e10; bool stop_ = false;
     Se3 old_model;
     int n_meas_last = 0;
+#ifdef YGZ_SA_TIMERS
     long long tph[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = clock64();
-    __shared__ long long s_acc_cyc;
+#endif
+#ifdef YGZ_SA_TIMERS
 #define SA_PHASE(k) do { if (tid == 0) { const long long tn_ = clock64(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
+#define SA_COUNT(k, v) do { if (tid == 0) tph[k] += (v); } while (0)
+#else
+#define SA_PHASE(k) do { } while (0)
+#define SA_COUNT(k, v) do { } while (0)
+#endif
 
     if (tid == 0) {
         Se3 T_cur, Tri;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
     }
     for (int f = tid; f < n; f += SA_THREADS) visible[f] = 0;
     for (int f = tid; f < n; f += SA_THREADS)
-        for (int pc = 0; pc < 16; ++pc) patch_cache[(size_t)pc * A.cells + f] = 0.f;
+        for (int pc = 0; pc < 16; ++pc) patch_cache[16 * (size_t)f + pc] = 0.f;
     __syncthreads();
 
     for (int level = A.max_level; level >= A.min_level; --level) {
@@ -130,8 +145,10 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
             const double pxx = px[2 * f], pxy = px[2 * f + 1];
             const float u_ref = (float)(pxx * scale), v_ref = (float)(pxy * scale);
             const int ui = (int)floorf(u_ref), vi = (int)floorf(v_ref);
+            prev_used[f] = 0;
             if (!has_mp[f] || ui - border < 0 || vi - border < 0 || ui + border >= cols || vi + border >= rows) {
-                for (int k = 0; k < 96; ++k) jac_cache[(size_t)k * A.cells + f] = 0.0;
+                for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = 0.0;       // a zero Jacobian column block (:42)
+                for (int k = 0; k < 12; ++k) fjc[12 * (size_t)f + k] = 0.0;
                 continue;
             }
             visible[f] = 1;
@@ -145,19 +162,53 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
             const float w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv)), w_tr = (float)((double)su * (1.0 - (double)sv));
             const float w_bl = (float)((1.0 - (double)su) * (double)sv), w_br = __fmul_rn(su, sv);
             const double fl = focal / (double)(1 << level);
-            int pc = 0;
-            for (int yy = 0; yy < 4; ++yy) {
-                const uint8_t *p = ref_img + (size_t)(vi + yy - 2) * cols + (ui - 2);
-                for (int xx = 0; xx < 4; ++xx, ++p, ++pc) {
-#define BIL(a, b, c, d) __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w_tl, (float)(a)), __fmul_rn(w_tr, (float)(b))), __fmul_rn(w_bl, (float)(c))), __fmul_rn(w_br, (float)(d)))
-                    patch_cache[(size_t)pc * A.cells + f] = BIL(p[0], p[1], p[cols], p[cols + 1]);
-                    const float dx = __fmul_rn(0.5f, __fsub_rn(BIL(p[1], p[2], p[cols + 1], p[cols + 2]), BIL(p[-1], p[0], p[cols - 1], p[cols])));
-                    const float dy = __fmul_rn(0.5f, __fsub_rn(BIL(p[cols], p[1 + cols], p[cols * 2], p[cols * 2 + 1]), BIL(p[-cols], p[1 - cols], p[0], p[1])));
+            double hf[21];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) jac_cache[(size_t)(6 * pc + k) * A.cells + f] = ((double)dx * fj[k] + (double)dy * fj[6 + k]) * fl;
+            for (int k = 0; k < 21; ++k) hf[k] = 0.0;
+            // the 7x7 reference window rows vi-3..vi+3, columns ui-3..ui+3: W(r, c) = byte c of row r
+            uint32_t wl[7], wh[7];
+#pragma unroll
+            for (int r = 0; r < 7; ++r) ygz_load8(ref_img + (size_t)(vi - 3 + r) * cols + (ui - 3), wl[r], wh[r]);
+#define W(r, c) YGZ_BYTE(wl[r], wh[r], c)
+#define BIL(a, b, c, d) __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w_tl, (float)(a)), __fmul_rn(w_tr, (float)(b))), __fmul_rn(w_bl, (float)(c))), __fmul_rn(w_br, (float)(d)))
+            float pv[16], dxv[16], dyv[16];
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy) {
+#pragma unroll
+                for (int xx = 0; xx < 4; ++xx) {
+                    const int pc = 4 * yy + xx;          // p = &W(yy + 1, xx + 1)
+                    pv[pc] = BIL(W(yy + 1, xx + 1), W(yy + 1, xx + 2), W(yy + 2, xx + 1), W(yy + 2, xx + 2));
+                    const float dx = __fmul_rn(0.5f, __fsub_rn(BIL(W(yy + 1, xx + 2), W(yy + 1, xx + 3), W(yy + 2, xx + 2), W(yy + 2, xx + 3)),
+                                                                BIL(W(yy + 1, xx), W(yy + 1, xx + 1), W(yy + 2, xx), W(yy + 2, xx + 1))));
+                    const float dy = __fmul_rn(0.5f, __fsub_rn(BIL(W(yy + 2, xx + 1), W(yy + 2, xx + 2), W(yy + 3, xx + 1), W(yy + 3, xx + 2)),
+                                                                BIL(W(yy, xx + 1), W(yy, xx + 2), W(yy + 1, xx + 1), W(yy + 1, xx + 2))));
+                    dxv[pc] = dx; dyv[pc] = dy;
+                    double J[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) J[k] = ((double)dx * fj[k] + (double)dy * fj[6 + k]) * fl;      // jacobian_cache_.col (:116-117)
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                        for (int b = a; b < 6; ++b) hf[q++] += J[a] * J[b];                                    // H_ += J J^T (:209), pixel order
+                    }
                 }
             }
+#undef W
+            float4 *o4 = reinterpret_cast<float4 *>(patch_cache + 16 * (size_t)f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o4[k] = make_float4(pv[4 * k], pv[4 * k + 1], pv[4 * k + 2], pv[4 * k + 3]);
+            o4 = reinterpret_cast<float4 *>(dxy + 32 * (size_t)f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { o4[k] = make_float4(dxv[4 * k], dxv[4 * k + 1], dxv[4 * k + 2], dxv[4 * k + 3]);
+                                          o4[4 + k] = make_float4(dyv[4 * k], dyv[4 * k + 1], dyv[4 * k + 2], dyv[4 * k + 3]); }
+            double2 *o2 = reinterpret_cast<double2 *>(fjc + 12 * (size_t)f);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) o2[k] = make_double2(fj[2 * k], fj[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = hf[k];
         }
+        if (tid < 21) s_H[tid] = 0.0;
         __syncthreads();          // caches visible to the whole workgroup (global writes + barrier, same CU)
         if (tid == 0) old_model = sT;
         int it = 0;
@@ -167,6 +218,13 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
             // pass R (all lanes): warp + bilinear + residuals of the lane's features -> res[f][16] (0 when skipped)
             const Se3 T = sT;
             int my_meas = 0;
+            // Jres (6) and the CHANGE of H (21 unique) accumulate in FP64 registers of the lane that owns the feature: H only
+            // changes when a feature enters or leaves the image (first iteration of a level: every used feature enters).
+            double acc[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+            const double fl = (double)((A.fx + A.fy) / 2) / (double)(1 << level);
+#pragma unroll 1
             for (int f = tid; f < n; f += SA_THREADS) {
                 float res[16];
 #pragma unroll
@@ -186,13 +244,19 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                         const float su = __fsub_rn(u_cur, (float)ui), sv = __fsub_rn(v_cur, (float)vi);
                         const float w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv)), w_tr = (float)((double)su * (1.0 - (double)sv));
                         const float w_bl = (float)((1.0 - (double)su) * (double)sv), w_br = __fmul_rn(su, sv);
-                        int pc = 0;
-                        for (int yy = 0; yy < 4; ++yy) {
-                            const uint8_t *p = cur_img + (size_t)(vi + yy - 2) * cols + (ui - 2);
+                        const float4 *pcp = reinterpret_cast<const float4 *>(patch_cache + 16 * (size_t)f);
+                        const float4 c0 = pcp[0], c1 = pcp[1], c2 = pcp[2], c3 = pcp[3];
+                        const float refp[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
+                        uint32_t wl[5], wh[5];            // rows vi-2..vi+2, columns ui-2..ui+2
 #pragma unroll
-                            for (int xx = 0; xx < 4; ++xx, ++pc) {
-                                const float ic = BIL(p[xx], p[xx + 1], p[cols + xx], p[cols + xx + 1]);
-                                res[pc] = __fsub_rn(ic, patch_cache[(size_t)pc * A.cells + f]);
+                        for (int r = 0; r < 5; ++r) ygz_load5(cur_img + (size_t)(vi - 2 + r) * cols + (ui - 2), wl[r], wh[r]);
+#pragma unroll
+                        for (int yy = 0; yy < 4; ++yy) {
+#pragma unroll
+                            for (int xx = 0; xx < 4; ++xx) {
+                                const float ic = BIL(YGZ_BYTE(wl[yy], wh[yy], xx), YGZ_BYTE(wl[yy], wh[yy], xx + 1),
+                                                     YGZ_BYTE(wl[yy + 1], wh[yy + 1], xx), YGZ_BYTE(wl[yy + 1], wh[yy + 1], xx + 1));
+                                res[4 * yy + xx] = __fsub_rn(ic, refp[4 * yy + xx]);
                             }
                         }
                     }
@@ -205,9 +269,28 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                 dst[0] = make_float4(res[0], res[1], res[2], res[3]);     dst[1] = make_float4(res[4], res[5], res[6], res[7]);
                 dst[2] = make_float4(res[8], res[9], res[10], res[11]);   dst[3] = make_float4(res[12], res[13], res[14], res[15]);
                 used[f] = use ? 1 : 0;
-                if (use) my_meas += 16;
+                const bool pu = prev_used[f] != 0;
+                if (use != pu) {
+                    prev_used[f] = use ? 1 : 0;
+#pragma unroll
+                    for (int k = 0; k < 21; ++k) { const double h = Hf[21 * (size_t)f + k]; acc[k] += use ? h : -h; }
+                }
+                if (use) {
+                    my_meas += 16;
+                    double gA = 0.0, gB = 0.0;
+#pragma unroll
+                    for (int pc = 0; pc < 16; ++pc) {
+                        gA += (double)dxy[32 * (size_t)f + pc] * (double)res[pc];
+                        gB += (double)dxy[32 * (size_t)f + 16 + pc] * (double)res[pc];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)                                          // Jres_ -= J * res (:210), J = (dx fj0 + dy fj1) fl
+                        acc[21 + k] -= (fjc[12 * (size_t)f + k] * gA + fjc[12 * (size_t)f + 6 + k] * gB) * fl;
+                }
             }
 #undef BIL
+#pragma unroll
+            for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
             {
                 int m = my_meas;
 #pragma unroll
@@ -223,35 +306,39 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                 // along the lanes into quad maps (64 terms) and hex maps (256 terms); the wave then walks hex -> quad -> terms.
                 uint32_t cb = 0u;                                            // bits of c, wave-uniform
                 const int J = (n + 63) >> 6;
+                float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: pass j + 1 is in flight
+                float nsq = 0.f;
+                if (lane < n) {
+                    const float4 *src = reinterpret_cast<const float4 *>(r2 + 16 * (size_t)lane);
+                    n0 = src[0]; n1 = src[1]; n2 = src[2]; n3 = src[3]; nsq = ssq[lane];
+                }
                 for (int j = 0; j < J; ++j) {
-                    const int f = 64 * j + lane;
-                    float x[16];
-                    float sq = 0.f;
-                    if (f < n) {
-                        const float4 *src = reinterpret_cast<const float4 *>(r2 + 16 * (size_t)f);
-                        const float4 a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3];
-                        sq = ssq[f];
-                        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
-                        x[8] = a2.x; x[9] = a2.y; x[10] = a2.z; x[11] = a2.w; x[12] = a3.x; x[13] = a3.y; x[14] = a3.z; x[15] = a3.w;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) x[k] = 0.f;
+                    SA_PHASE(12);
+                    float x[16] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w };
+                    const float sq = nsq;
+                    {
+                        const int fn = 64 * (j + 1) + lane;
+                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nsq = 0.f;
+                        if (fn < n) {
+                            const float4 *src = reinterpret_cast<const float4 *>(r2 + 16 * (size_t)fn);
+                            n0 = src[0]; n1 = src[1]; n2 = src[2]; n3 = src[3]; nsq = ssq[fn];
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < 16; ++k) x[k] = __fmul_rn(__fmul_rn(x[k], x[k]), 1.0f);      // res*res*weight (:213)
                     // predicted c at the start of the lane's feature: exact c so far + exclusive scan of the approximate feature sums
-                    float incl = sq;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) { const float o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+                    const float incl = ygz_wave_scan_f(sq);
                     int E = (int)(__float_as_uint(__uint_as_float(cb) + (incl - sq)) >> 23);
+                    SA_PHASE(8);
                     int t0 = 0, t1 = 0, bad = !(E > 0 && E < 255);
 #pragma unroll
                     for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
                     // compose along the lanes: (A then B)(p) = A(p) + B((p + A(p)) & 1); a group is usable only inside one binade
 #define SA_COMPOSE(dist, sel)                                                                                         \
-                    { const int a0_ = __shfl_up(t0, dist), a1_ = __shfl_up(t1, dist), ab_ = __shfl_up(bad, dist), aE_ = __shfl_up(E, dist); \
+                    { const int a0_ = YGZ_DPP_SHR(t0, dist), a1_ = YGZ_DPP_SHR(t1, dist), ab_ = YGZ_DPP_SHR(bad, dist), aE_ = YGZ_DPP_SHR(E, dist); \
                       if (sel) { const int n0_ = a0_ + ((a0_ & 1) ? t1 : t0), n1_ = a1_ + (((1 + a1_) & 1) ? t1 : t0);           \
                                  bad |= ab_ | (aE_ != E); t0 = n0_; t1 = n1_; E = aE_; } }
+                    SA_PHASE(9);
                     SA_COMPOSE(1, (lane & 1) == 1)
                     SA_COMPOSE(2, (lane & 3) == 3)
                     const int qt0 = t0, qt1 = t1, qbad = bad, qE = E;         // quad maps live in lanes 4k+3
@@ -263,6 +350,7 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                       if (!(mbad_) && (int)(cb >> 23) == (mE_)) {                                                      \
                           const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u, mn_ = m_ + (uint32_t)((m_ & 1u) ? (m1_) : (m0_)); \
                           if (mn_ < 0x1000000u) { cb = (cb & 0xff800000u) | (mn_ & 0x7fffffu); taken = true; } } }
+                    SA_PHASE(10);
                     const int nh = min(4, (n - 64 * j + 15) >> 4);
                     for (int h = 0; h < nh; ++h) {
                         const int hl = 16 * h + 15;
@@ -275,7 +363,7 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                             SA_TRY(__builtin_amdgcn_readlane(qt0, ql), __builtin_amdgcn_readlane(qt1, ql), __builtin_amdgcn_readlane(qE, ql),
                                    __builtin_amdgcn_readlane(qbad, ql), taken)
                             if (taken) continue;
-                            if (A.dbg && tid == 0) tph[7] += 1;
+                            SA_COUNT(7, 1);
                             float cc = __uint_as_float(cb);                    // binade crossing: the quad term by term, hardware floats
                             for (int fl_ = ql - 3; fl_ <= ql; ++fl_) {
 #pragma unroll
@@ -286,50 +374,24 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
                         }
                     }
 #undef SA_TRY
+                    SA_PHASE(11);
                 }
                 const float c = __uint_as_float(cb);
                 if (lane == 0) s_chi2 = c;
-                if (tid == 0) { tph[2] += clock64() - tlast; tph[5] += 1; }
-            } else {
-                // ---- waves 1..: H (21 unique) / Jres (6) in FP64 registers, concurrently with the chain above
-                const long long ta0 = A.dbg ? clock64() : 0;
-                double acc[27];
-#pragma unroll
-                for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-                for (int f = tid - 64; f < n; f += SA_THREADS - 64) {
-                    if (!used[f]) continue;
-#pragma unroll 1
-                    for (int pc = 0; pc < 16; ++pc) {
-                        double J[6];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) J[k] = jac_cache[(size_t)(6 * pc + k) * A.cells + f];
-                        const double r = (double)r2[16 * (size_t)f + pc];
-                        int q = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                            for (int b = a; b < 6; ++b) acc[q++] += J[a] * J[b];
-                        }
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) acc[21 + a] -= J[a] * r;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
-                if (A.dbg && tid == 64) s_acc_cyc = clock64() - ta0;
+                SA_COUNT(2, clock64() - tlast); SA_COUNT(5, 1);
             }
             __syncthreads();
             SA_PHASE(3);      // chain || accumulation
-            if (A.dbg && tid == 0) tph[6] += s_acc_cyc;
             // ---- lane 0: solve, decide, update (NLSSolver_impl.hpp:40-87)
             if (tid == 0) {
                 double Hm[36], Jr[6], x[6];
                 int q = 0;
                 for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) {
-                    double s = 0; for (int w2 = 1; w2 < SA_THREADS / 64; ++w2) s += red[w2][q];
+                    double s = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) s += red[w2][q];
+                    s = s_H[q] + s; s_H[q] = s;                   // running H of the level
                     Hm[6 * a + b] = s; Hm[6 * b + a] = s; ++q;
                 }
-                for (int a = 0; a < 6; ++a) { double s = 0; for (int w2 = 1; w2 < SA_THREADS / 64; ++w2) s += red[w2][21 + a]; Jr[a] = s; }
+                for (int a = 0; a < 6; ++a) { double s = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) s += red[w2][21 + a]; Jr[a] = s; }
                 int nm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) nm += s_nmeas_w[w2];
                 n_meas_last = nm;
                 const double new_chi2 = (double)__fdiv_rn(s_chi2, (float)nm);
@@ -362,7 +424,9 @@ __global__ __launch_bounds__(SA_THREADS, 4) void k_sparse_align(SaArgs A)
         for (int k = 0; k < 4; ++k) out[k] = o.q[k];
         for (int k = 0; k < 3; ++k) out[4 + k] = o.t[k];
         out[7] = (double)n_meas_last;
+#ifdef YGZ_SA_TIMERS
         if (A.dbg) for (int k = 0; k < 16; ++k) A.dbg[16 * (size_t)pair + k] = (double)tph[k];
+#endif
     }
 }
 
@@ -383,7 +447,7 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
         double h[16];
         YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[sa-debug] pair0 shader cycles: overhead %.0f residual %.0f wave0-chain %.0f wave1-accumulate %.0f chain||accumulate %.0f solve %.0f; GN iterations %.0f, chain groups added term by term %.0f\n", h[0], h[1], h[2], h[6], h[3], h[4], h[5], h[7]);
+        fprintf(stderr, "[sa-debug] pair0 shader cycles: overhead %.0f residual %.0f wave0-chain %.0f (unused %.0f) chain phase %.0f solve %.0f; GN iterations %.0f, chain groups added term by term %.0f; chain: load+scan %.0f terms %.0f compose %.0f walk %.0f other %.0f\n", h[0], h[1], h[2], h[6], h[3], h[4], h[5], h[7], h[8], h[9], h[10], h[11], h[12]);
     }
     return YGZ_OK;
 }

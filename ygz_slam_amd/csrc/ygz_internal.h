@@ -210,9 +210,45 @@ __device__ __forceinline__ int ygz_wave_sum_i(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
+// lane i receives lane i - n of its row of 16 (0 when there is none): one DPP-modified VALU op instead of an LDS round trip
+#define YGZ_DPP_SHR(v, n) __builtin_amdgcn_update_dpp(0, (v), 0x110 + (n), 0xF, 0xF, false)
+// inclusive prefix sum over the 64 lanes (order of the additions is irrelevant to its users: approximate prefixes only)
+__device__ __forceinline__ float ygz_wave_scan_f(float v)
+{
+#define YGZ_SCAN_STEP_(ctrl, rmask) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), 0xF, false))
+    YGZ_SCAN_STEP_(0x111, 0xF); YGZ_SCAN_STEP_(0x112, 0xF); YGZ_SCAN_STEP_(0x114, 0xF); YGZ_SCAN_STEP_(0x118, 0xF);   // row_shr 1, 2, 4, 8
+    YGZ_SCAN_STEP_(0x142, 0xA);                                                                                 // row_bcast:15 -> rows 1, 3
+    YGZ_SCAN_STEP_(0x143, 0xC);                                                                                 // row_bcast:31 -> rows 2, 3
+#undef YGZ_SCAN_STEP_
+    return v;
+}
 // correctly rounded float sqrt: the native v_sqrt_f32 path is 1 ulp; sqrt in double then one rounding is
 // exact for float inputs (53 >= 2*24+2 bits)
 __device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((double)x); }
+
+// 8 (or 5) consecutive bytes from an arbitrary byte address with aligned dword loads + v_alignbyte: a wave-wide byte gather
+// costs the address unit as much as a dword load, so patch windows are fetched row-wise.  May touch up to 11 bytes past p
+// (every image buffer is allocated with 64 bytes of slack).
+typedef const __attribute__((address_space(1))) uint32_t *ygz_gptr32;
+__device__ __forceinline__ void ygz_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+}
+__device__ __forceinline__ void ygz_load5(const uint8_t *p, uint32_t &lo, uint32_t &hi)      // bytes 0..4 valid
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    const uint32_t d0 = q[0], d1 = q[1];
+    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    hi = d1 >> (8 * sh);
+}
+#define YGZ_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
 __device__ __forceinline__ float ygz_ord2f(uint32_t o)
 {
     uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
