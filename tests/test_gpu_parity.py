@@ -580,3 +580,49 @@ def test_optimize_pose_only_batch(hip_lib, oracle):
         assert np.allclose(dep[s][m], o_dep[m], rtol=1e-9) and np.all(np.isnan(dep[s][~m]) == np.isnan(o_dep[~m])), i
     assert rounds[3] == 1 and np.array_equal(po[3], frames[3]["entry"]) and rounds[4] == 1 and inl[4] == 0
     assert rounds[5] == 4 and bad[off[5] + 11] == 1 and not np.array_equal(po[5], frames[5]["entry"])
+
+
+# ------------------------------------------------------------------------------------- config 5 geometry: 1280x720
+def test_pipeline_1280x720(hip_lib, oracle):
+    """SURVEY 8d config 5 frame size (128 x 72 = 9216 grid cells): every stage of one frame pair against the oracle."""
+    W, H = 1280, 720
+    imgs, poses, depths = _frames(2, W, H, seed=17, step=0.3)
+    ctx = make_ctx(hip_lib, width=W, height=H, max_frames=2)
+    assert ctx.cells == 9216
+    for s in range(2):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 2); ctx.detect(0, 2)
+    lv = [oracle.pyramid(imgs[s], 3) for s in range(2)]
+    kps = [ctx.get_keypoints(s) for s in range(2)]
+    for s in range(2):
+        for L in range(3):
+            assert np.array_equal(ctx.download_level(s, L), lv[s][L])
+        _kp_check(kps[s], oracle.detect(lv[s]))
+    assert len(kps[0]["level"]) > 2000
+    # brute-force cross-checked matching of the two descriptor sets
+    idx, dist = ctx.hamming_match(kps[0]["desc"], kps[1]["desc"], cross_check=1)
+    oi, od, _ = oracle.bf_match(kps[0]["desc"], kps[1]["desc"], 1)
+    assert np.array_equal(idx, oi) and np.array_equal(dist[oi >= 0], od[oi >= 0])
+    # tracking stages on the resident pair
+    d = np.array([depths[0][int(p[1]), int(p[0])] for p in kps[0]["px"]])
+    m = np.ones(len(d), np.uint8)
+    ctx.set_keypoint_depths(0, d, m)
+    ctx.track_begin([1], [0], poses[[1]], poses[[0]], predict=False)
+    ctx.track_klt(); ctx.track_direct(); ctx.track_sparse_align()
+    px = kps[0]["px"]
+    sel = np.arange(0, len(px), 5)                      # the oracle's KLT takes ~2 ms per point
+    out, st, err = ctx.track_get_klt(0)
+    pts = px.astype(np.float32)
+    oout, ost, _ = oracle.klt_track(imgs[0], imgs[1], pts[sel], pts[sel])
+    assert np.array_equal(st[sel], ost)
+    mk = ost.astype(bool)
+    assert np.all(np.abs(out[sel][mk] - oout[mk]).max(1) <= 1e-5 * np.maximum(1.0, np.abs(oout[mk]).max(1)))
+    ok, pxo, sl = ctx.track_get_direct(0)
+    for i in range(0, len(px), 25):
+        o_ok, o_px, o_sl = oracle.find_direct_projection(lv[0], poses[0], lv[1], poses[1], px[i], d[i], int(kps[0]["level"][i]), px[i])
+        assert ok[i] == o_ok and sl[i] == o_sl and np.array_equal(pxo[i], o_px, equal_nan=True), i
+    nm, T, iters = ctx.track_get_pose(0)
+    onm, oT, st_ = oracle.sparse_align(lv[0], poses[0], lv[1], poses[0], px, d, m)
+    assert nm == onm and iters == list(st_.iters_per_level)[:3]
+    assert np.allclose(T, oT, rtol=1e-9, atol=1e-11)
+    ctx.close()
