@@ -235,6 +235,13 @@ typedef struct {
 } ygz_ba_stats;
 int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                          int max_iterations, ygz_ba_stats *stats);
+/* The same loop entirely on the GPU for uploaded windows window_begin .. +n_windows-1 (formulation 0, at most 14 free
+ * poses per window): one workgroup per window runs linearisation, Schur complement, Cholesky, back-substitution, update and
+ * the lambda policy in HBM/LDS without a host round trip, all windows concurrently.  The windows' states are updated in
+ * place (ygz_hip_ba_get_state reads them back); stats [n_windows] may be NULL (then the call is asynchronous). */
+int  ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, int max_iterations,
+                                  ygz_ba_stats *stats);
+int  ygz_hip_ba_get_state(ygz_hip_ctx *ctx, int window, double *poses, double *points);
 
 
 /* ---- B6/B7: ceres::Solve as the reference configures it (src/Algorithm/BA.cpp:219-226,372-375: default options =

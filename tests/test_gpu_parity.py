@@ -626,3 +626,39 @@ def test_pipeline_1280x720(hip_lib, oracle):
     assert nm == onm and iters == list(st_.iters_per_level)[:3]
     assert np.allclose(T, oT, rtol=1e-9, atol=1e-11)
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------- LM loop resident on the GPU
+def test_ba_optimize_resident_windows(hip_lib, oracle):
+    """ba::LocalBAG2O's Levenberg-Marquardt loop (g2o LM + Schur + Cholesky) as ONE kernel, several windows per launch, vs the
+    oracle's restatement (yo_g2o_lm) and the host-loop form: same iteration / trial counts, chi2 and state within 1e-6 relative
+    (bar 1e-5; the block reductions sum in a different order than the scalar loops)."""
+    wins = [synth.ba_fixture_test_local_ba(noise=True, seed=5), synth.ba_window(6, 300, seed=5), synth.ba_window(10, 2000, seed=7),
+            synth.ba_window(4, 50, seed=9), synth.ba_window(8, 700, seed=3, sort_by_point=False)]
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for i, w in enumerate(wins):
+        ctx.ba_upload(i, w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
+    stats = ctx.ba_optimize_resident(0, len(wins), iterations=20)
+    for i, w in enumerate(wins):
+        po, pt, so = oracle.g2o_lm(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"], max_iterations=20)
+        pg, tg = ctx.ba_get_state(i, len(w["poses"]), len(w["points"]))
+        st = stats[i]
+        assert 3 <= st.iterations <= 20 and st.lm_trials >= st.iterations, i
+        assert abs(st.chi2_initial - so["chi2_initial"]) <= 1e-10 * so["chi2_initial"], i
+        assert abs(st.chi2_final - so["chi2_final"]) <= 1e-9 * so["chi2_final"], i
+        assert _rel(pg, po) < 1e-6 and _rel(tg, pt) < 1e-6, i
+        assert st.chi2_final < 0.1 * st.chi2_initial and np.array_equal(pg[0], w["poses"][0]), i     # keyframe 0 fixed
+        # the state left in HBM reproduces the reported minimum
+        back = oracle.ba_linearize(pg, w["fixed"], tg, w["edge_pose"], w["edge_point"], w["obs"])
+        assert abs(back["chi2"] - st.chi2_final) <= 1e-9 * st.chi2_final, i
+    # host-loop form (reduced system solved on the CPU) on one of them
+    import os
+    w = wins[1]
+    os.environ["YGZ_BA_HOST_LOOP"] = "1"
+    try:
+        ph, th, sh = ctx.ba_optimize(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
+    finally:
+        del os.environ["YGZ_BA_HOST_LOOP"]
+    assert abs(sh.chi2_final - stats[1].chi2_final) <= 1e-9 * sh.chi2_final
+    assert _rel(ph, ctx.ba_get_state(1, len(w["poses"]), len(w["points"]))[0]) < 1e-6
+    ctx.close()

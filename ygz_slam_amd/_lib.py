@@ -84,7 +84,7 @@ ABI_SYMBOLS = [
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
-    "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
+    "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
 ]
 
 _lib = None
@@ -440,6 +440,17 @@ class HipContext:
         self._chk(self.lib.ygz_hip_ba_optimize(self._ctx, C.byref(pb), _p(po, C.c_double), _p(pt, C.c_double), iterations, C.byref(st)),
                   "ba_optimize")
         return po, pt, st
+
+    def ba_optimize_resident(self, window_begin, n_windows, iterations=20, want_stats=True):
+        st = (BaStats * n_windows)()
+        self._chk(self.lib.ygz_hip_ba_optimize_resident(self._ctx, window_begin, n_windows, iterations, st if want_stats else None),
+                  "ba_optimize_resident")
+        return list(st) if want_stats else None
+
+    def ba_get_state(self, window, K, P):
+        po, pt = np.empty((K, 6)), np.empty((P, 3))
+        self._chk(self.lib.ygz_hip_ba_get_state(self._ctx, window, _p(po, C.c_double), _p(pt, C.c_double)), "ba_get_state")
+        return po, pt
 
     def ba_upload(self, window, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None):
         pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam)

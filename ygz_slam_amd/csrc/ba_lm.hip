@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cfloat>
 #include <string.h>
+#include <stdlib.h>
 
 static void oplus_pose(double pose[6], const double upd[6])
 {   // VertexSE3Sophus::oplusImpl (G2oTypes.h:38-45): estimate order [omega; t], Sophus order [t; omega]
@@ -144,6 +145,19 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
     prob.poses = poses_io; prob.points = points_io;
     int rc = ygz_hip_ba_upload(ctx, W, &prob);
     if (rc != YGZ_OK) return rc;
+    {   // the loop runs entirely on the GPU when the reduced system fits LDS (ba_resident_lm.hip); YGZ_BA_HOST_LOOP=1 forces
+        // the host-side Schur / Cholesky below (kept as the large-window path and as a cross-check)
+        int Kfree = 0;
+        for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
+        const char *force = getenv("YGZ_BA_HOST_LOOP");
+        if (Kfree <= 14 && !(force && force[0] == '1')) {
+            ygz_ba_stats st;
+            if ((rc = ygz_hip_ba_optimize_resident(ctx, W, 1, max_iterations, &st)) != YGZ_OK) return rc;
+            if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;
+            if (stats) *stats = st;
+            return YGZ_OK;
+        }
+    }
     BlockSystem BS; block_system_init(BS, pb);
     const std::vector<int> &free_idx = BS.free_idx;
     std::vector<double> Hpp((size_t)K * 36), bp((size_t)K * 6), Hll((size_t)P * 9), bl((size_t)P * 3), Hpl((size_t)std::max(E, 1) * 18);
