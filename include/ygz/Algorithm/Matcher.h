@@ -1,6 +1,6 @@
 // ygz::Matcher -- same surface as include/ygz/Algorithm/Matcher.h:15-152.  Brute-force matching is offered as
-// BruteForceMatch (what test/test_orb_match.cpp:86-93 does with cv::BFMatcher); the BoW-guided searches need the
-// DBoW3 vocabulary that the reference does not ship (.MISSING_LARGE_BLOBS) and are outside the hot-path scope.
+// BruteForceMatch (what test/test_orb_match.cpp:86-93 does with cv::BFMatcher).  The BoW-guided searches run on the GPU
+// against the vocabulary loaded through ORBVocabulary::loadFromBinaryFile (the reference does not ship vocab/ORBvoc.bin).
 #ifndef YGZ_MATCHER_H_
 #define YGZ_MATCHER_H_
 #include "ygz/Basic/Common.h"
@@ -27,6 +27,9 @@ public:
     void SetTCR(const SE3 &TCR) { _TCR_esti = TCR; }
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);                      // Matcher.cpp:30-43
     int CheckFrameDescriptors(Frame *frame1, Frame *frame2, list<pair<int, int>> &matches);  // Matcher.cpp:45-84
+    int SearchByBoW(Frame *kf1, Frame *kf2, map<int, int> &matches);                          // Matcher.cpp:196-292
+    int SearchForTriangulation(Frame *kf1, Frame *kf2, const Matrix3d &E12, vector<pair<int, int>> &matched_points,
+                               const bool &onlyStereo = false);                               // Matcher.cpp:86-193
     // cv::BFMatcher(NORM_HAMMING, crossCheck).match(frame1 descriptors, frame2 descriptors) on the GPU
     int BruteForceMatch(Frame *frame1, Frame *frame2, vector<DMatch> &matches, bool cross_check = true);
     bool FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector2d &px_curr, int &search_level);   // Matcher.cpp:356-383

@@ -177,6 +177,27 @@ extern int verbosity;      // 0 = errors/warnings only (default), 1 = INFO too
 #define LOG(sev) ygz_log::Sink(ygz_log::sev##_enabled())
 namespace ygz_log { inline bool INFO_enabled() { return verbosity > 0; } inline bool WARNING_enabled() { return true; } inline bool ERROR_enabled() { return true; } }
 
+// ------------------------------------------------------------------------------------------ DBoW3 (the sliver in use)
+// BowVector / FeatureVector with the interface src/ reads (thirdparty/DBoW3/src/{BowVector,FeatureVector}.h); the vocabulary
+// tree itself lives in HBM (ygz_hip_vocab_load), Vocabulary is the handle the reference's call sites hold.
+namespace DBoW3 {
+typedef unsigned int WordId;
+typedef double WordValue;
+typedef unsigned int NodeId;
+class BowVector : public std::map<WordId, WordValue> {};
+class FeatureVector : public std::map<NodeId, std::vector<unsigned int>> {};
+class Vocabulary {
+public:
+    bool loadFromBinaryFile(const std::string &filename);       // Vocabulary.cpp (loadFromBinaryFile), exactly nb_nodes records
+    bool loadFromMemory(const void *blob, size_t bytes);
+    bool empty() const { return n_words_ == 0; }
+    // Vocabulary::transform(features, BowVector, FeatureVector, levelsup), Vocabulary.cpp:706-774
+    void transform(const std::vector<cv::Mat> &features, BowVector &v, FeatureVector &fv, int levelsup) const;
+    int k_ = 0, L_ = 0, n_nodes_ = 0, n_words_ = 0;
+};
+}  // namespace DBoW3
+typedef DBoW3::Vocabulary ORBVocabulary;
+
 // Local mapping patch sizes (Common.h:90-91)
 const int WarpHalfPatchSize = 4;
 const int WarpPatchSize = 8;

@@ -1,5 +1,5 @@
-// ygz::Frame -- the hot-path part of include/ygz/Basic/Frame.h:20-166 (covisibility graph and BoW are out of
-// scope).  InitFrame() uploads the image to an HBM slot of the process-wide ygz_hip context,
+// ygz::Frame -- the hot-path part of include/ygz/Basic/Frame.h:20-166 (the covisibility graph is out of scope,
+// SURVEY 2.1 #1).  InitFrame() uploads the image to an HBM slot of the process-wide ygz_hip context,
 // builds the pyramid on the GPU and mirrors the levels into _pyramid for host readers.
 #ifndef YGZ_FRAME_H_
 #define YGZ_FRAME_H_
@@ -16,6 +16,8 @@ struct Frame {
     ~Frame();
     static void SetCamera(PinholeCamera *camera) { _camera = camera; }
     static PinholeCamera *GetCamera() { return _camera; }
+    static void SetORBVocabulary(ORBVocabulary *orb_vocab) { _vocab = orb_vocab; }      // Frame.h:105-108
+    void ComputeBoW();                                          // src/Basic/Frame.cpp:190-201
     void InitFrame();                                           // src/Basic/Frame.cpp:22-30
     inline Vector3d Pos() const { return _TCW.inverse().translation(); }
     inline bool InFrame(const Vector2d &pixel, const int &boarder = 10) const
@@ -36,6 +38,9 @@ struct Frame {
     Mat    _color, _depth;                  // _color: CV_8UC3 (BGR) or CV_8UC1
     vector<Mat> _pyramid;                   // host mirror of the HBM levels
     static PinholeCamera *_camera;
+    static ORBVocabulary *_vocab;
+    DBoW3::BowVector _bow_vec;
+    DBoW3::FeatureVector _feature_vec;
     Frame *_ref_keyframe = nullptr;
     bool   _bad = false;
     int    _hip_slot = -1;                  // HBM slot of this frame (managed by ygz::hip::Runtime)

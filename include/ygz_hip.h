@@ -275,6 +275,31 @@ int  ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const int32_t *f
                                 const double *pw, double *poses_io, uint8_t *bad, double *depth, int32_t *inliers,
                                 int32_t *rounds);
 
+/* ---- M4 / M5: BoW-guided matching -- replaces Frame::ComputeBoW (src/Basic/Frame.cpp:190-201 ->
+ *      DBoW3::Vocabulary::transform, thirdparty/DBoW3/src/Vocabulary.cpp:706-835), Matcher::SearchByBoW
+ *      (src/Algorithm/Matcher.cpp:196-292) and Matcher::SearchForTriangulation (:86-193, epipolar test :338-354).
+ *      The vocabulary is the file ORBVocabulary::loadFromBinaryFile reads (test/test_orb_match.cpp:72-74): header
+ *      {u32 nb_nodes, u32 size_node, i32 k, i32 L, i32 scoring, i32 weighting}, then per node {i32 parent, u8 desc[32],
+ *      f32 weight, u8 is_leaf}; exactly nb_nodes records are read. */
+int  ygz_hip_vocab_load(ygz_hip_ctx *ctx, const void *blob, size_t bytes);
+int  ygz_hip_vocab_info(ygz_hip_ctx *ctx, int *k, int *L, int *n_nodes, int *n_words);
+/* ComputeBoW over the resident keypoints of a slot range: word id, weight, FeatureVector node (levelsup levels above the leaf;
+ * -1 when the word is stopped, i.e. weight <= 0) per keypoint, kept in HBM */
+int  ygz_hip_compute_bow(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int levelsup);
+int  ygz_hip_get_bow(ygz_hip_ctx *ctx, int slot, int32_t *word, double *weight, int32_t *node, int capacity, int *n);
+/* the same for host descriptors [n][32] */
+int  ygz_hip_bow_transform(ygz_hip_ctx *ctx, const uint8_t *desc, int n, int levelsup, int32_t *word, double *weight,
+                           int32_t *node);
+/* mode 0: SearchByBoW (best < th_low and best < knn_ratio * second best); mode 1: SearchForTriangulation (E12 row-major,
+ * per pair in the slot form).  match12: index in frame 2 or -1 per feature of frame 1 ([n_pairs][max_keypoints] in the slot
+ * form); count(s): number of matches.  Slot form: all pairs in one launch, BoW from ygz_hip_compute_bow. */
+int  ygz_hip_search_by_bow_slots(ygz_hip_ctx *ctx, int mode, int n_pairs, const int32_t *slot1, const int32_t *slot2,
+                                 const double *E12, int th_low, float knn_ratio, double epipolar_dsqr, int32_t *match12,
+                                 int32_t *counts);
+int  ygz_hip_search_by_bow(ygz_hip_ctx *ctx, int mode, const uint8_t *desc1, const int32_t *node1, const double *px1, int n1,
+                           const uint8_t *desc2, const int32_t *node2, const double *px2, int n2, const double *E12,
+                           int th_low, float knn_ratio, double epipolar_dsqr, int32_t *match12, int *count);
+
 #ifdef __cplusplus
 }
 #endif

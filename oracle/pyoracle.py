@@ -83,6 +83,13 @@ class BaProblem(C.Structure):
                 ("huber_delta", C.c_double)]
 
 
+class Vocab(C.Structure):
+    _fields_ = [("k", C.c_int), ("L", C.c_int), ("scoring", C.c_int), ("weighting", C.c_int), ("n_nodes", C.c_int),
+                ("n_words", C.c_int), ("parent", C.POINTER(C.c_int32)), ("desc", C.POINTER(C.c_uint8)),
+                ("weight", C.POINTER(C.c_double)), ("word_id", C.POINTER(C.c_int32)), ("child_off", C.POINTER(C.c_int32)),
+                ("child", C.POINTER(C.c_int32))]
+
+
 class CeresProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
                 ("poses", C.POINTER(C.c_double)), ("pose_fixed", C.POINTER(C.c_uint8)),
@@ -435,6 +442,48 @@ class Oracle:
         self.lib.yo_ba_edge_error_norm(_f64(pose_tw), _f64(pt), _f64(obs_n), _f64(err))
         self.lib.yo_ba_edge_jacobians_norm(_f64(pose_tw), _f64(pt), _f64(Jp), _f64(Jx))
         return err, Jp.reshape(2, 3), Jx.reshape(2, 6)
+
+    # ---- BoW (oracle/bow.c) ----
+    def vocab_parse(self, blob):
+        """blob: bytes of a DBoW3 binary vocabulary (loadFromBinaryFile format).  Returns an opaque handle (keep it)."""
+        v = Vocab()
+        buf = np.frombuffer(blob, np.uint8).copy()
+        if self.lib.yo_vocab_parse(_u8(buf), C.c_size_t(len(buf)), C.byref(v)) != 0:
+            raise ValueError("not a DBoW3 binary vocabulary")
+        return v
+
+    def bow_transform(self, vocab, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word, weight, node = np.empty(max(n, 1), np.int32), np.empty(max(n, 1)), np.empty(max(n, 1), np.int32)
+        bw, bv = np.empty(max(n, 1), np.int32), np.empty(max(n, 1))
+        m = self.lib.yo_bow_transform(C.byref(vocab), _u8(desc), n, levelsup, _p(word, C.c_int32), _f64(weight), _p(node, C.c_int32),
+                                      _p(bw, C.c_int32), _f64(bv))
+        return word[:n], weight[:n], node[:n], bw[:m].copy(), bv[:m].copy()
+
+    def search_by_bow(self, desc1, node1, desc2, node2, th_low=65, knn_ratio=0.7):
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n1a = np.ascontiguousarray(node1, np.int32); n2a = np.ascontiguousarray(node2, np.int32)
+        m = np.empty(max(len(d1), 1), np.int32)
+        self.lib.yo_search_by_bow.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                                              C.c_int, C.c_int, C.c_float, C.POINTER(C.c_int32)]
+        cnt = self.lib.yo_search_by_bow(_u8(d1), _p(n1a, C.c_int32), len(d1), _u8(d2), _p(n2a, C.c_int32), len(d2), int(th_low),
+                                        float(knn_ratio), _p(m, C.c_int32))
+        return m[:len(d1)], cnt
+
+    def search_for_triangulation(self, desc1, node1, px1, desc2, node2, px2, E12, th_low=65, epipolar_dsqr=1e-4, cam=None):
+        cam = cam or self.camera()
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n1a = np.ascontiguousarray(node1, np.int32); n2a = np.ascontiguousarray(node2, np.int32)
+        p1 = np.ascontiguousarray(px1, np.float64); p2 = np.ascontiguousarray(px2, np.float64)
+        E = np.ascontiguousarray(E12, np.float64).reshape(9)
+        m = np.empty(max(len(d1), 1), np.int32)
+        self.lib.yo_search_for_triangulation.argtypes = [C.POINTER(Camera), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                         C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int,
+                                                         C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_int32)]
+        cnt = self.lib.yo_search_for_triangulation(C.byref(cam), _u8(d1), _p(n1a, C.c_int32), _f64(p1), len(d1), _u8(d2), _p(n2a, C.c_int32),
+                                                   _f64(p2), len(d2), _f64(E), int(th_low), float(epipolar_dsqr), _p(m, C.c_int32))
+        return m[:len(d1)], cnt
 
     # ---- ceres-side rows (oracle/ceres_ba.c) ----
     def ceres_edge(self, pose_taa, pt, obs_n):

@@ -225,6 +225,27 @@ double yo_ba_linearize(const yo_ba_problem *pb, double *Hpp, double *bp, double 
 /* VertexSE3Sophus::oplusImpl G2oTypes.h:38-45 */
 void yo_ba_pose_oplus(double pose[6], const double upd[6]);
 
+/* ---- BoW-guided matching (M4, M5): oracle/bow.c ------------------------------------------------------------ */
+typedef struct {
+    int k, L, scoring, weighting;     /* header of the DBoW3 binary vocabulary */
+    int n_nodes, n_words;             /* nodes include the root (id 0) */
+    int32_t *parent;                  /* [n_nodes] */
+    uint8_t *desc;                    /* [n_nodes][32] */
+    double  *weight;                  /* [n_nodes] */
+    int32_t *word_id;                 /* [n_nodes] -1 for inner nodes */
+    int32_t *child_off, *child;       /* CSR of the children, in push_back order */
+} yo_vocab;
+int  yo_vocab_parse(const void *blob, size_t bytes, yo_vocab *v);
+void yo_vocab_free(yo_vocab *v);
+void yo_bow_transform_one(const yo_vocab *v, const uint8_t *d, int levelsup, int32_t *word, double *weight, int32_t *nid);
+int  yo_bow_transform(const yo_vocab *v, const uint8_t *desc, int n, int levelsup, int32_t *word, double *weight, int32_t *node,
+                      int32_t *bow_word, double *bow_value);
+int  yo_search_by_bow(const uint8_t *desc1, const int32_t *node1, int n1, const uint8_t *desc2, const int32_t *node2, int n2,
+                      int th_low, float knn_ratio, int32_t *match12);
+int  yo_search_for_triangulation(const yo_camera *cam, const uint8_t *desc1, const int32_t *node1, const double *px1, int n1,
+                                 const uint8_t *desc2, const int32_t *node2, const double *px2, int n2,
+                                 const double E12[9], int th_low, double epipolar_dsqr, int32_t *match12);
+
 /* ---- ceres-side rows (B3, B6, B7) and the two NLLS drivers: oracle/ceres_ba.c ---------------------------- */
 typedef struct {
     int n_poses, n_points, n_edges;

@@ -48,6 +48,33 @@ int main(int argc, char **argv)
     fprintf(out, "matches %zu\n", matches.size());
     for (auto &m : matches) fprintf(out, "%d %d %d\n", m.queryIdx, m.trainIdx, (int)m.distance);
     fprintf(out, "ddist %d\n", Matcher::DescriptorDistance(f[0]._features[0]->_desc, f[1]._features[0]->_desc));
+    // --- test_orb_match / test_match_for_triangulation: vocabulary, Frame::ComputeBoW, SearchByBoW, SearchForTriangulation
+    {
+        ORBVocabulary vocab;
+        const bool okv = vocab.loadFromBinaryFile(in + "/vocab.bin");
+        Frame::SetORBVocabulary(&vocab);
+        f[0].ComputeBoW(); f[1].ComputeBoW();
+        fprintf(out, "bow %d %d %d %zu %zu %zu %zu\n", (int)okv, vocab.k_, vocab.L_, f[0]._bow_vec.size(), f[0]._feature_vec.size(), f[1]._bow_vec.size(), f[1]._feature_vec.size());
+        double s0 = 0; for (auto &kv : f[0]._bow_vec) s0 += kv.second;
+        fprintf(out, "bow_sum %.17g %u %.17g\n", s0, f[0]._bow_vec.begin()->first, f[0]._bow_vec.begin()->second);
+        map<int, int> bm;
+        const int c_quirk = matcher.SearchByBoW(&f[0], &f[1], bm);      // knnRatio read through Get<int> (Matcher.cpp:17) = 0: nothing can pass
+        matcher._options.knnRatio = 0.7f; bm.clear();
+        const int c = matcher.SearchByBoW(&f[0], &f[1], bm);
+        fprintf(out, "sbow %d %d %zu\n", c_quirk, c, bm.size());
+        for (auto &kv : bm) fprintf(out, "sbow_m %d %d\n", kv.first, kv.second);
+        // E12 of the true relative pose: x2 = R x1 + t, line in frame 2 = pt1^T E12 with E12 = ([t]x R)^T
+        const SE3 T21 = f[1]._TCW * f[0]._TCW.inverse();
+        const Matrix3d R = T21.rotation_matrix(); const Vector3d t = T21.translation();
+        Matrix3d tx; tx(0, 1) = -t[2]; tx(0, 2) = t[1]; tx(1, 0) = t[2]; tx(1, 2) = -t[0]; tx(2, 0) = -t[1]; tx(2, 1) = t[0];
+        Matrix3d E12;
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) { double v = 0; for (int k = 0; k < 3; ++k) v += tx(cc, k) * R(k, r); E12(r, cc) = v; }
+        vector<pair<int, int>> tri;
+        const int ct = matcher.SearchForTriangulation(&f[0], &f[1], E12, tri);
+        fprintf(out, "stri %d %zu %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", ct, tri.size(), E12(0, 0), E12(0, 1), E12(0, 2), E12(1, 0), E12(1, 1), E12(1, 2), E12(2, 0), E12(2, 1), E12(2, 2));
+        for (auto &pr : tri) fprintf(out, "stri_m %d %d\n", pr.first, pr.second);
+        Frame::SetORBVocabulary(nullptr);
+    }
     // Detect(frame, false) keeps the old features and fills only free cells
     {
         const size_t before = f[1]._features.size();

@@ -662,3 +662,62 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
     assert abs(sh.chi2_final - stats[1].chi2_final) <= 1e-9 * sh.chi2_final
     assert _rel(ph, ctx.ba_get_state(1, len(w["poses"]), len(w["points"]))[0]) < 1e-6
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------- M4 / M5: BoW-guided matching
+def test_bow_transform_and_guided_matching(hip_lib, oracle):
+    """Frame::ComputeBoW (DBoW3 tree descent), Matcher::SearchByBoW and Matcher::SearchForTriangulation on extracted frames
+    (slot form, all pairs in one launch) and on host arrays, against the oracle: every index bit-exact."""
+    blob = synth.synthetic_vocabulary(k=10, L=4, seed=5)
+    vo = oracle.vocab_parse(blob)
+    imgs, poses, depths = _frames(3, 640, 480, seed=23, step=0.3)
+    ctx = make_ctx(hip_lib, max_frames=3)
+    assert ctx.vocab_load(blob) == (10, 4, vo.n_nodes, vo.n_words)
+    for s in range(3):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 3); ctx.detect(0, 3)
+    kps = [ctx.get_keypoints(s) for s in range(3)]
+    for levelsup in (2, 4):                                  # Frame.cpp:199 uses 4 (with L = 4: the root); 2 gives 100 nodes
+        ctx.compute_bow(0, 3, levelsup)
+        nodes = []
+        for s in range(3):
+            w, wt, nd = ctx.get_bow(s)
+            ow, owt, ond, _, _ = oracle.bow_transform(vo, kps[s]["desc"], levelsup)
+            assert np.array_equal(w, ow) and np.array_equal(wt, owt) and np.array_equal(nd, ond), (s, levelsup)
+            nodes.append(nd)
+        pairs1, pairs2 = [1, 2, 0], [0, 1, 0]
+        m, cnt = ctx.search_by_bow_slots(pairs1, pairs2, mode=0, th_low=65, knn_ratio=0.7)
+        for p in range(3):
+            a, b = pairs1[p], pairs2[p]
+            om, oc = oracle.search_by_bow(kps[a]["desc"], nodes[a], kps[b]["desc"], nodes[b], 65, 0.7)
+            assert cnt[p] == oc and np.array_equal(m[p, :len(om)], om), (p, levelsup)
+        self_m = m[2, :len(nodes[0])]                          # a frame against itself: whatever matches, matches itself
+        assert cnt[2] > 0.9 * (nodes[0] >= 0).sum() and np.all(self_m[self_m >= 0] == np.nonzero(self_m >= 0)[0])
+        # SearchForTriangulation with E12 of the true relative pose (E = [t]x R, normalised coordinates)
+        Es = []
+        for p in range(3):
+            T12 = oracle.se3_mul(poses[pairs2[p]], oracle.se3_inv(poses[pairs1[p]]))         # x2 = R x1 + t
+            R = synth.quat_to_R(T12[:4]); t = T12[4:]
+            tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+            Es.append((tx @ R).T if False else (tx @ R))
+        # CheckDistEpipolarLine multiplies pt1 from the left: line = pt1^T E12, so E12 maps frame-1 points to frame-2 lines
+        E12 = np.stack([e.T for e in Es])
+        mt, ct = ctx.search_by_bow_slots(pairs1, pairs2, mode=1, E12=E12, th_low=65, epipolar_dsqr=1e-4)
+        for p in range(2):
+            a, b = pairs1[p], pairs2[p]
+            om, oc = oracle.search_for_triangulation(kps[a]["desc"], nodes[a], kps[a]["px"], kps[b]["desc"], nodes[b], kps[b]["px"], E12[p], 65, 1e-4)
+            assert ct[p] == oc and np.array_equal(mt[p, :len(om)], om), (p, levelsup)
+            assert oc > 20
+    # host-array forms (what the class surface calls), incl. ragged / empty sets
+    d1, d2 = kps[1]["desc"], kps[0]["desc"]
+    w, wt, nd1 = ctx.bow_transform(d1, 2); nd2 = ctx.bow_transform(d2, 2)[2]
+    assert np.array_equal(nd1, oracle.bow_transform(vo, d1, 2)[2])
+    m, c = ctx.search_by_bow(d1, nd1, d2, nd2)
+    om, oc = oracle.search_by_bow(d1, nd1, d2, nd2)
+    assert c == oc and np.array_equal(m, om)
+    m, c = ctx.search_by_bow(d1[:300], nd1[:300], d2[:7], nd2[:7], mode=1, px1=kps[1]["px"][:300], px2=kps[0]["px"][:7], E12=E12[0])
+    om, oc = oracle.search_for_triangulation(d1[:300], nd1[:300], kps[1]["px"][:300], d2[:7], nd2[:7], kps[0]["px"][:7], E12[0])
+    assert c == oc and np.array_equal(m, om)
+    m, c = ctx.search_by_bow(d1[:5], nd1[:5], np.zeros((0, 32), np.uint8), np.zeros(0, np.int32))
+    assert c == 0 and np.all(m == -1)
+    ctx.close()

@@ -60,6 +60,8 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     T7 = np.array([oracle.se3_exp(np.concatenate([p[3:], p[:3]])) for p in f["poses"]])
     T7.tofile(os.path.join(d, "ba_poses7.f64")); f["points"].tofile(os.path.join(d, "ba_points.f64"))
     f["obs"].reshape(16, 8, 2).tofile(os.path.join(d, "ba_obs.f64"))
+    vblob = synth.synthetic_vocabulary(k=6, L=6, seed=5)                  # 55 986 nodes, 46 656 words
+    open(os.path.join(d, "vocab.bin"), "wb").write(vblob)
     pof = synth.pose_only_fixture(n=300, seed=12)
     pof["entry"].tofile(os.path.join(d, "po_entry.f64")); pof["px"].tofile(os.path.join(d, "po_px.f64")); pof["pw"].tofile(os.path.join(d, "po_pw.f64"))
     outp = os.path.join(d, "out.txt")
@@ -84,6 +86,26 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     q = np.nonzero(oi >= 0)[0]
     assert np.array_equal(r["matches"][:, 0], q) and np.array_equal(r["matches"][:, 1], oi[q]) and np.array_equal(r["matches"][:, 2], od[q])
     assert int(r["ddist"][0][0]) == oracle.descriptor_distance(ks[0]["desc"][0], ks[1]["desc"][0])
+    # ORBVocabulary + Frame::ComputeBoW + Matcher::SearchByBoW / SearchForTriangulation (levelsup = 4 of L = 6)
+    vo = oracle.vocab_parse(vblob)
+    bows = [oracle.bow_transform(vo, ks[i]["desc"], 4) for i in range(2)]
+    hdr = [int(x) for x in r["bow"][0]]
+    assert hdr[:3] == [1, 6, 6]
+    assert hdr[3:] == [len(bows[0][3]), len(set(bows[0][2][bows[0][2] >= 0])), len(bows[1][3]), len(set(bows[1][2][bows[1][2] >= 0]))]
+    bsum = [float(x) for x in r["bow_sum"][0]]
+    assert abs(bsum[0] - 1.0) < 1e-12 and int(bsum[1]) == bows[0][3][0] and bsum[2] == bows[0][4][0]
+    om, oc = oracle.search_by_bow(ks[0]["desc"], bows[0][2], ks[1]["desc"], bows[1][2], 65, 0.7)
+    sb = [int(x) for x in r["sbow"][0]]
+    assert sb == [0, oc, oc] and oc > 50
+    got = np.array(r["sbow_m"], dtype=int)
+    assert np.array_equal(got[:, 0], np.nonzero(om >= 0)[0]) and np.array_equal(got[:, 1], om[om >= 0])
+    st = [float(x) for x in r["stri"][0]]
+    E12 = np.array(st[2:]).reshape(3, 3)
+    px = [np.stack([ks[i]["px"], ks[i]["py"]], 1) for i in range(2)]
+    omt, oct_ = oracle.search_for_triangulation(ks[0]["desc"], bows[0][2], px[0], ks[1]["desc"], bows[1][2], px[1], E12, 65, 1e-4)
+    assert int(st[0]) == oct_ and int(st[1]) == oct_ and oct_ > 20
+    gott = np.array(r["stri_m"], dtype=int)
+    assert np.array_equal(gott[:, 0], np.nonzero(omt >= 0)[0]) and np.array_equal(gott[:, 1], omt[omt >= 0])
     # Detect(frame, overwrite=false): old features kept, only free cells refilled
     before, kept, after = [int(x) for x in r["redetect"][0]]
     occ = np.zeros(3072, np.uint8)

@@ -85,6 +85,7 @@ ABI_SYMBOLS = [
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
+    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow",
 ]
 
 _lib = None
@@ -360,6 +361,59 @@ class HipContext:
         iters = (C.c_int * MAX_LEVELS)()
         self._chk(self.lib.ygz_hip_track_get_pose(self._ctx, pair, T, C.byref(nm), iters), "track_get_pose")
         return nm.value, np.array(list(T)), list(iters)[:self.levels]
+
+    # ---- BoW
+    def vocab_load(self, blob):
+        buf = np.frombuffer(blob, np.uint8).copy()
+        self._chk(self.lib.ygz_hip_vocab_load(self._ctx, _p(buf, C.c_uint8), C.c_size_t(len(buf))), "vocab_load")
+        k, L, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.ygz_hip_vocab_info(self._ctx, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw)), "vocab_info")
+        return k.value, L.value, nn.value, nw.value
+
+    def compute_bow(self, slot_begin, n_slots, levelsup=4):
+        self._chk(self.lib.ygz_hip_compute_bow(self._ctx, slot_begin, n_slots, levelsup), "compute_bow")
+
+    def get_bow(self, slot):
+        word, weight, node = np.empty(self.cells, np.int32), np.empty(self.cells), np.empty(self.cells, np.int32)
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_get_bow(self._ctx, slot, _p(word, C.c_int32), _p(weight, C.c_double), _p(node, C.c_int32), self.cells,
+                                           C.byref(n)), "get_bow")
+        return word[:n.value].copy(), weight[:n.value].copy(), node[:n.value].copy()
+
+    def bow_transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word, weight, node = np.empty(max(n, 1), np.int32), np.empty(max(n, 1)), np.empty(max(n, 1), np.int32)
+        self._chk(self.lib.ygz_hip_bow_transform(self._ctx, _p(desc, C.c_uint8), n, levelsup, _p(word, C.c_int32), _p(weight, C.c_double),
+                                                 _p(node, C.c_int32)), "bow_transform")
+        return word[:n], weight[:n], node[:n]
+
+    def search_by_bow_slots(self, slot1, slot2, mode=0, E12=None, th_low=65, knn_ratio=0.7, epipolar_dsqr=1e-4):
+        s1 = np.ascontiguousarray(slot1, np.int32); s2 = np.ascontiguousarray(slot2, np.int32)
+        n = len(s1)
+        m = np.empty((n, self.cells), np.int32); cnt = np.empty(n, np.int32)
+        E = None if E12 is None else np.ascontiguousarray(E12, np.float64).reshape(n, 9)
+        self.lib.ygz_hip_search_by_bow_slots.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                         C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        self._chk(self.lib.ygz_hip_search_by_bow_slots(self._ctx, mode, n, _p(s1, C.c_int32), _p(s2, C.c_int32), None if E is None else _p(E, C.c_double),
+                                                       int(th_low), float(knn_ratio), float(epipolar_dsqr), _p(m, C.c_int32), _p(cnt, C.c_int32)),
+                  "search_by_bow_slots")
+        return m, cnt
+
+    def search_by_bow(self, desc1, node1, desc2, node2, mode=0, px1=None, px2=None, E12=None, th_low=65, knn_ratio=0.7, epipolar_dsqr=1e-4):
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n1a = np.ascontiguousarray(node1, np.int32); n2a = np.ascontiguousarray(node2, np.int32)
+        p1 = None if px1 is None else np.ascontiguousarray(px1, np.float64); p2 = None if px2 is None else np.ascontiguousarray(px2, np.float64)
+        E = None if E12 is None else np.ascontiguousarray(E12, np.float64).reshape(9)
+        m = np.empty(max(len(d1), 1), np.int32); cnt = C.c_int(0)
+        f64 = lambda a: None if a is None else _p(a, C.c_double)
+        self.lib.ygz_hip_search_by_bow.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int,
+                                                   C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double),
+                                                   C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int)]
+        self._chk(self.lib.ygz_hip_search_by_bow(self._ctx, mode, _p(d1, C.c_uint8), _p(n1a, C.c_int32), f64(p1), len(d1), _p(d2, C.c_uint8),
+                                                 _p(n2a, C.c_int32), f64(p2), len(d2), f64(E), int(th_low), float(knn_ratio), float(epipolar_dsqr),
+                                                 _p(m, C.c_int32), C.byref(cnt)), "search_by_bow")
+        return m[:len(d1)], cnt.value
 
     # ---- BA
     def _ba_problem(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam=None,

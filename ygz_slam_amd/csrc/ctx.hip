@@ -130,6 +130,7 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
 }
 
 void ygz_hip_ba_free_all(ygz_hip_ctx *ctx);   // ba.hip
+void ygz_hip_vocab_free(ygz_hip_ctx *ctx);    // bow.hip
 
 void ygz_hip_destroy(ygz_hip_ctx *ctx)
 {
@@ -138,6 +139,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     for (int i = 0; i < 3; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ygz_hip_ba_free_all(ctx);
+    ygz_hip_vocab_free(ctx);
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
         if (ctx->lvl[L]) (void)hipFree(ctx->lvl[L]);
         if (ctx->deriv[L]) (void)hipFree(ctx->deriv[L]);
@@ -206,7 +208,7 @@ int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
 static const char *const k_kernel_names[KID_COUNT] = {
     "k_bgr2gray", "k_pyr_down", "k_fast_select", "k_compact", "k_describe", "k_hamming_nn", "k_match_finalize", "k_track_load",
     "k_find_direct_projection", "k_align2d", "k_sparse_align", "k_scharr", "k_klt", "k_klt_pad", "k_ba_pose_prep", "k_ba_points", "k_ba_poses",
-    "k_ba_chi2", "k_pose_only_ba", "k_ba_lm" };
+    "k_ba_chi2", "k_pose_only_ba", "k_ba_lm", "k_bow_transform", "k_bow_match" };
 
 int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launches)
 {

@@ -141,6 +141,7 @@ int Runtime::Resident(Frame *f)
 
 // ------------------------------------------------------------------------------------------ Frame
 PinholeCamera *Frame::_camera = nullptr;
+ORBVocabulary *Frame::_vocab = nullptr;
 Frame::~Frame() { if (!_features.empty()) CleanAllFeatures(); hip::Runtime::Get().Release(this); }
 
 void Frame::InitFrame()
@@ -395,6 +396,54 @@ size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
     return (size_t)n_meas;
 }
 
+// ------------------------------------------------------------------------------------------ DBoW3 surface
+}  // namespace ygz
+namespace DBoW3 {
+bool Vocabulary::loadFromMemory(const void *blob, size_t bytes)
+{
+    ygz::hip::Runtime &rt = ygz::hip::Runtime::Get();
+    if (ygz_hip_vocab_load(rt.ctx(), blob, bytes) != YGZ_OK) return false;
+    return ygz_hip_vocab_info(rt.ctx(), &k_, &L_, &n_nodes_, &n_words_) == YGZ_OK;
+}
+bool Vocabulary::loadFromBinaryFile(const std::string &filename)
+{
+    FILE *f = fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> buf;
+    uint8_t tmp[65536]; size_t n;
+    while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    return loadFromMemory(buf.data(), buf.size());
+}
+void Vocabulary::transform(const std::vector<cv::Mat> &features, BowVector &v, FeatureVector &fv, int levelsup) const
+{   // Vocabulary.cpp:706-774 for TF_IDF / TF weighting with L1 scoring (what an ORB vocabulary file carries)
+    v.clear(); fv.clear();
+    if (empty() || features.empty()) return;
+    const int n = (int)features.size();
+    std::vector<uint8_t> desc((size_t)n * 32);
+    for (int i = 0; i < n; ++i) memcpy(&desc[32 * (size_t)i], features[i].data, 32);
+    std::vector<int32_t> word(n), node(n); std::vector<double> weight(n);
+    ygz::hip::check(ygz_hip_bow_transform(ygz::hip::Runtime::Get().ctx(), desc.data(), n, levelsup, word.data(), weight.data(), node.data()), "bow_transform");
+    for (int i = 0; i < n; ++i) {
+        if (!(weight[i] > 0) || word[i] < 0) continue;          // stopped word
+        v[(WordId)word[i]] += weight[i];                         // BowVector::addWeight
+        fv[(NodeId)node[i]].push_back((unsigned int)i);          // FeatureVector::addFeature
+    }
+    double norm = 0.0;                                           // BowVector::normalize(L1)
+    for (auto &kv : v) norm += fabs(kv.second);
+    if (norm > 0.0) for (auto &kv : v) kv.second /= norm;
+}
+}  // namespace DBoW3
+namespace ygz {
+void Frame::ComputeBoW()
+{   // src/Basic/Frame.cpp:190-201
+    if (_vocab != nullptr && _bow_vec.empty()) {
+        vector<Mat> alldesp;
+        for (Feature *fea : _features) alldesp.push_back(fea->_desc);
+        _vocab->transform(alldesp, _bow_vec, _feature_vec, 4);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ Matcher
 Matcher::Matcher()
 {
@@ -429,6 +478,47 @@ int Matcher::CheckFrameDescriptors(Frame *frame1, Frame *frame2, list<pair<int, 
         else iter = matches.erase(iter);
     }
     return cnt_good;
+}
+
+namespace {
+// descriptors, FeatureVector membership (node id or -1) and pixels of a frame as flat arrays
+void bow_arrays(Frame *kf, std::vector<uint8_t> &desc, std::vector<int32_t> &node, std::vector<double> &px)
+{
+    const size_t n = kf->_features.size();
+    desc.resize(n * 32); node.assign(n, -1); px.resize(n * 2);
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(&desc[32 * i], kf->_features[i]->_desc.data, 32);
+        px[2 * i] = kf->_features[i]->_pixel[0]; px[2 * i + 1] = kf->_features[i]->_pixel[1];
+    }
+    for (auto &kv : kf->_feature_vec) for (unsigned int idx : kv.second) if (idx < n) node[idx] = (int32_t)kv.first;
+}
+}  // namespace
+
+int Matcher::SearchByBoW(Frame *kf1, Frame *kf2, map<int, int> &matches)
+{   // Matcher.cpp:196-292: within equal vocabulary nodes, best < th_low and best < knnRatio * second best
+    std::vector<uint8_t> d1, d2; std::vector<int32_t> n1, n2; std::vector<double> p1, p2;
+    bow_arrays(kf1, d1, n1, p1); bow_arrays(kf2, d2, n2, p2);
+    std::vector<int32_t> m(std::max<size_t>(n1.size(), 1), -1);
+    int cnt = 0;
+    hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 0, d1.data(), n1.data(), nullptr, (int)n1.size(), d2.data(), n2.data(), nullptr,
+                                     (int)n2.size(), nullptr, _options.th_low, _options.knnRatio, 0.0, m.data(), &cnt), "search_by_bow");
+    for (size_t i = 0; i < n1.size(); ++i) if (m[i] >= 0) matches[(int)i] = m[i];
+    return cnt;
+}
+
+int Matcher::SearchForTriangulation(Frame *kf1, Frame *kf2, const Matrix3d &E12, vector<pair<int, int>> &matched_points, const bool &)
+{   // Matcher.cpp:86-193 (+ CheckDistEpipolarLine :338-354)
+    assert(!kf1->_feature_vec.empty() && !kf2->_feature_vec.empty());
+    std::vector<uint8_t> d1, d2; std::vector<int32_t> n1, n2; std::vector<double> p1, p2;
+    bow_arrays(kf1, d1, n1, p1); bow_arrays(kf2, d2, n2, p2);
+    std::vector<int32_t> m(std::max<size_t>(n1.size(), 1), -1);
+    int cnt = 0;
+    hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 1, d1.data(), n1.data(), p1.data(), (int)n1.size(), d2.data(), n2.data(), p2.data(),
+                                     (int)n2.size(), E12.m, _options.th_low, _options.knnRatio, _options._epipolar_dsqr, m.data(), &cnt),
+               "search_for_triangulation");
+    matched_points.clear(); matched_points.reserve(cnt);
+    for (size_t i = 0; i < n1.size(); ++i) if (m[i] >= 0) matched_points.push_back(make_pair((int)i, (int)m[i]));
+    return cnt;
 }
 
 int Matcher::BruteForceMatch(Frame *frame1, Frame *frame2, vector<DMatch> &matches, bool cross_check)

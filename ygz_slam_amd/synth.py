@@ -246,3 +246,34 @@ def pose_only_fixture(n=400, seed=3, outlier_frac=0.1, sigma_px=0.5, w=640, h=48
     px[out] += rng.uniform(8, 40, (out.sum(), 2)) * rng.choice([-1, 1], (out.sum(), 2))
     entry = true + np.concatenate([rng.normal(0, 0.002, 3), rng.normal(0, 0.0005, 3)])    # sub-pixel, as after sparse alignment
     return dict(true=true, entry=entry, px=px, pw=pw, outlier=out)
+
+
+def synthetic_vocabulary(k=10, L=3, seed=5, stop_frac=0.05):
+    """A random vocabulary tree in DBoW3's binary format (Vocabulary::loadFromBinaryFile: header nb_nodes, size_node, k, L,
+    scoring, weighting; per node int parent, 32 descriptor bytes, float weight, byte is_leaf).  Children of a node are
+    perturbed copies of it so that descents are meaningful; a fraction of the words is 'stopped' (weight 0).  Node ids are
+    assigned level by level (breadth first), children of one parent consecutively."""
+    import struct
+    rng = np.random.default_rng(seed)
+    rec = np.dtype([("parent", "<i4"), ("desc", "u1", (32,)), ("weight", "<f4"), ("leaf", "u1")])
+    assert rec.itemsize == 41
+    levels, first_id, prev_desc, prev_ids = [], 1, None, np.array([0])
+    for lev in range(1, L + 1):
+        n = len(prev_ids) * k
+        a = np.zeros(n, rec)
+        a["parent"] = np.repeat(prev_ids, k)
+        if prev_desc is None:
+            a["desc"] = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        else:
+            flip = np.packbits(rng.random((n, 256)) < 0.25 / lev, axis=1)
+            a["desc"] = np.repeat(prev_desc, k, axis=0) ^ flip
+        if lev == L:
+            a["leaf"] = 1
+            w = rng.uniform(0.5, 8.0, n).astype(np.float32)
+            w[rng.random(n) < stop_frac] = 0.0
+            a["weight"] = w
+        levels.append(a)
+        prev_desc, prev_ids = a["desc"], np.arange(first_id, first_id + n)
+        first_id += n
+    body = np.concatenate(levels)
+    return struct.pack("<IIiiii", len(body), 41, k, L, 0, 0) + body.tobytes()          # scoring L1_NORM (0), weighting TF_IDF (0)
