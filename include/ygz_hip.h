@@ -275,6 +275,12 @@ int  ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const int32_t *f
                                 const double *pw, double *poses_io, uint8_t *bad, double *depth, int32_t *inliers,
                                 int32_t *rounds);
 
+/* ---- cvutils::DepthFromTriangulation (include/ygz/Algorithm/CVUtils.h:18-38) for n ray pairs: the step after
+ *      SearchForTriangulation in LocalMapping::CreateNewMapPoints (src/Module/LocalMapping.cpp:430-452).  f_ref / f_cur [n][3]
+ *      normalised rays, T_search_ref = (qx,qy,qz,qw,tx,ty,tz); ok[i] = 0 when det(A^T A) < determinant_th (depths untouched). */
+int  ygz_hip_depth_from_triangulation(ygz_hip_ctx *ctx, const double T_search_ref[7], const double *f_ref, const double *f_cur,
+                                      int n, double determinant_th, double *depth1, double *depth2, uint8_t *ok);
+
 /* ---- M4 / M5: BoW-guided matching -- replaces Frame::ComputeBoW (src/Basic/Frame.cpp:190-201 ->
  *      DBoW3::Vocabulary::transform, thirdparty/DBoW3/src/Vocabulary.cpp:706-835), Matcher::SearchByBoW
  *      (src/Algorithm/Matcher.cpp:196-292) and Matcher::SearchForTriangulation (:86-193, epipolar test :338-354).

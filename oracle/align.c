@@ -187,3 +187,27 @@ int yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, const
         return 0;
     return ok;
 }
+
+/* cvutils::DepthFromTriangulation -- include/ygz/Algorithm/CVUtils.h:18-38, with Eigen's evaluation order
+ * [frozen spec of Eigen: 2x2 inverse = adjugate * (1/det); (-inv * A^T) is formed before it multiplies t].
+ * Returns 1 and |depth| of the ray in the reference / the search frame, or 0 when det(A^T A) < determinant_th. */
+int yo_depth_from_triangulation(const yo_se3 *T_search_ref, const double f_ref[3], const double f_cur[3],
+                                double determinant_th, double *depth1, double *depth2)
+{
+    double R[9], a0[3];
+    yo_quat_to_R(T_search_ref->q, R);
+    for (int i = 0; i < 3; ++i) a0[i] = R[3 * i] * f_ref[0] + R[3 * i + 1] * f_ref[1] + R[3 * i + 2] * f_ref[2];
+    const double a1[3] = { -f_cur[0], -f_cur[1], -f_cur[2] };
+    const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2], m01 = a0[0] * a1[0] + a0[1] * a1[1] + a0[2] * a1[2];
+    const double m10 = a1[0] * a0[0] + a1[1] * a0[1] + a1[2] * a0[2], m11 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
+    const double det = m00 * m11 - m10 * m01;
+    if (det < determinant_th) return 0;
+    const double invdet = 1.0 / det;
+    const double i00 = -(m11 * invdet), i01 = -(-m01 * invdet), i10 = -(-m10 * invdet), i11 = -(m00 * invdet);     /* -AtA.inverse() */
+    double M[6];                                                                                                   /* (-inv) * A^T : 2x3 */
+    for (int c = 0; c < 3; ++c) { M[c] = i00 * a0[c] + i01 * a1[c]; M[3 + c] = i10 * a0[c] + i11 * a1[c]; }
+    const double *t = T_search_ref->t;
+    *depth1 = fabs(M[0] * t[0] + M[1] * t[1] + M[2] * t[2]);
+    *depth2 = fabs(M[3] * t[0] + M[4] * t[1] + M[5] * t[2]);
+    return 1;
+}

@@ -443,6 +443,18 @@ class Oracle:
         self.lib.yo_ba_edge_jacobians_norm(_f64(pose_tw), _f64(pt), _f64(Jp), _f64(Jx))
         return err, Jp.reshape(2, 3), Jx.reshape(2, 6)
 
+    def depth_from_triangulation(self, T_search_ref, f_ref, f_cur, determinant_th=1e-5):
+        T = SE3.from_array(T_search_ref)
+        fr = np.ascontiguousarray(f_ref, np.float64).reshape(-1, 3); fc = np.ascontiguousarray(f_cur, np.float64).reshape(-1, 3)
+        d1, d2, ok = np.full(len(fr), np.nan), np.full(len(fr), np.nan), np.zeros(len(fr), np.uint8)
+        a, b = C.c_double(), C.c_double()
+        self.lib.yo_depth_from_triangulation.argtypes = [C.POINTER(SE3), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        for i in range(len(fr)):
+            if self.lib.yo_depth_from_triangulation(C.byref(T), _f64(fr[i]), _f64(fc[i]), float(determinant_th), C.byref(a), C.byref(b)):
+                d1[i], d2[i], ok[i] = a.value, b.value, 1
+        return d1, d2, ok
+
     # ---- BoW (oracle/bow.c) ----
     def vocab_parse(self, blob):
         """blob: bytes of a DBoW3 binary vocabulary (loadFromBinaryFile format).  Returns an opaque handle (keep it)."""

@@ -154,6 +154,10 @@ int  yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, cons
                                const double px_ref[2], double depth_ref, int level_ref,
                                double px_cur[2], int *search_level);
 
+/* cvutils::DepthFromTriangulation CVUtils.h:18-38 */
+int  yo_depth_from_triangulation(const yo_se3 *T_search_ref, const double f_ref[3], const double f_cur[3],
+                                 double determinant_th, double *depth1, double *depth2);
+
 /* ---- sparse image alignment (SparseImageAlign.cpp, NLSSolver_impl.hpp) --------------- */
 typedef struct {
     int n_iter_total;        /* GN iterations executed over all levels */

@@ -721,3 +721,24 @@ def test_bow_transform_and_guided_matching(hip_lib, oracle):
     m, c = ctx.search_by_bow(d1[:5], nd1[:5], np.zeros((0, 32), np.uint8), np.zeros(0, np.int32))
     assert c == 0 and np.all(m == -1)
     ctx.close()
+
+
+def test_depth_from_triangulation_batch(hip_lib, oracle):
+    """cvutils::DepthFromTriangulation (CVUtils.h:18-38) for a batch of ray pairs: depths within 1e-12 relative, same accept
+    flags (incl. near-parallel rays rejected by the determinant test); exact geometry recovers the true depths."""
+    rng = np.random.default_rng(4)
+    T21 = oracle.se3_exp(np.array([0.3, -0.1, 0.05, 0.02, -0.03, 0.01]))          # search <- ref
+    n = 2000
+    p1 = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), rng.uniform(2, 8, n)], 1)
+    p2 = np.array([oracle.se3_act(T21, p) for p in p1])
+    f1, f2 = p1 / p1[:, 2:3], p2 / p2[:, 2:3]
+    f2[::50] = (synth.quat_to_R(T21[:4]) @ f1[::50].T).T * (1 + 1e-9)           # parallel rays: det ~ 0
+    ctx = make_ctx(hip_lib, max_frames=1)
+    d1, d2, ok = ctx.depth_from_triangulation(T21, f1, f2)
+    o1, o2, ook = oracle.depth_from_triangulation(T21, f1, f2)
+    assert np.array_equal(ok, ook) and ok.sum() == n - len(f1[::50])
+    m = ok == 1
+    assert np.allclose(d1[m], o1[m], rtol=1e-12) and np.allclose(d2[m], o2[m], rtol=1e-12)
+    assert np.allclose(d1[m], p1[m, 2], rtol=1e-9) and np.allclose(d2[m], p2[m, 2], rtol=1e-9)
+    assert ctx.depth_from_triangulation(T21, np.zeros((0, 3)), np.zeros((0, 3)))[2].size == 0
+    ctx.close()

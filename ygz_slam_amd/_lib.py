@@ -85,7 +85,7 @@ ABI_SYMBOLS = [
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
-    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow",
+    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation",
 ]
 
 _lib = None
@@ -361,6 +361,17 @@ class HipContext:
         iters = (C.c_int * MAX_LEVELS)()
         self._chk(self.lib.ygz_hip_track_get_pose(self._ctx, pair, T, C.byref(nm), iters), "track_get_pose")
         return nm.value, np.array(list(T)), list(iters)[:self.levels]
+
+    def depth_from_triangulation(self, T_search_ref, f_ref, f_cur, determinant_th=1e-5):
+        T = (C.c_double * 7)(*T_search_ref)
+        fr = np.ascontiguousarray(f_ref, np.float64).reshape(-1, 3); fc = np.ascontiguousarray(f_cur, np.float64).reshape(-1, 3)
+        n = len(fr)
+        d1, d2, ok = np.full(max(n, 1), np.nan), np.full(max(n, 1), np.nan), np.zeros(max(n, 1), np.uint8)
+        self.lib.ygz_hip_depth_from_triangulation.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                                              C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint8)]
+        self._chk(self.lib.ygz_hip_depth_from_triangulation(self._ctx, T, _p(fr, C.c_double), _p(fc, C.c_double), n, float(determinant_th),
+                                                            _p(d1, C.c_double), _p(d2, C.c_double), _p(ok, C.c_uint8)), "depth_from_triangulation")
+        return d1[:n], d2[:n], ok[:n]
 
     # ---- BoW
     def vocab_load(self, blob):

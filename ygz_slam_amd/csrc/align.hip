@@ -279,3 +279,54 @@ int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pw
 }
 
 }  // extern "C"
+
+// ---- cvutils::DepthFromTriangulation (include/ygz/Algorithm/CVUtils.h:18-38) for a batch of ray pairs,
+// lane = pair, Eigen's evaluation order (2x2 inverse = adjugate / det, (-inv A^T) formed before it multiplies t).
+__global__ __launch_bounds__(256) void k_depth_from_triangulation(const double *__restrict__ T /*q(4) t(3)*/, const double *__restrict__ f_ref,
+                                                                  const double *__restrict__ f_cur, int n, double det_th,
+                                                                  double *__restrict__ depth1, double *__restrict__ depth2, uint8_t *__restrict__ ok)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double R[9];
+    { const double q[4] = { T[0], T[1], T[2], T[3] }; quat_to_R_d(q, R); }
+    const double fr[3] = { f_ref[3 * (size_t)i], f_ref[3 * (size_t)i + 1], f_ref[3 * (size_t)i + 2] };
+    double a0[3];
+    for (int r = 0; r < 3; ++r) a0[r] = R[3 * r] * fr[0] + R[3 * r + 1] * fr[1] + R[3 * r + 2] * fr[2];
+    const double a1[3] = { -f_cur[3 * (size_t)i], -f_cur[3 * (size_t)i + 1], -f_cur[3 * (size_t)i + 2] };
+    const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2], m01 = a0[0] * a1[0] + a0[1] * a1[1] + a0[2] * a1[2];
+    const double m10 = a1[0] * a0[0] + a1[1] * a0[1] + a1[2] * a0[2], m11 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
+    const double det = m00 * m11 - m10 * m01;
+    if (det < det_th) { ok[i] = 0; return; }
+    const double invdet = 1.0 / det;
+    const double i00 = -(m11 * invdet), i01 = -(-m01 * invdet), i10 = -(-m10 * invdet), i11 = -(m00 * invdet);
+    double M[6];
+    for (int c = 0; c < 3; ++c) { M[c] = i00 * a0[c] + i01 * a1[c]; M[3 + c] = i10 * a0[c] + i11 * a1[c]; }
+    depth1[i] = fabs(M[0] * T[4] + M[1] * T[5] + M[2] * T[6]);
+    depth2[i] = fabs(M[3] * T[4] + M[4] * T[5] + M[5] * T[6]);
+    ok[i] = 1;
+}
+
+extern "C" int ygz_hip_depth_from_triangulation(ygz_hip_ctx *ctx, const double T_search_ref[7], const double *f_ref, const double *f_cur, int n,
+                                                double determinant_th, double *depth1, double *depth2, uint8_t *ok)
+{
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || !T_search_ref || n < 0 || (n > 0 && (!f_ref || !f_cur || !depth1 || !depth2 || !ok))) return YGZ_E_INVALID;
+    if (n == 0) return YGZ_OK;
+    const size_t N = (size_t)n;
+    uint8_t *buf = nullptr;
+    int rc = ygz_scratch(ctx, SCR_GEN_0, 64 + N * (24 + 24 + 8 + 8 + 1) + 64, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    double *d_T = (double *)buf, *d_fr = d_T + 8, *d_fc = d_fr + 3 * N, *d_d1 = d_fc + 3 * N, *d_d2 = d_d1 + N;
+    uint8_t *d_ok = (uint8_t *)(d_d2 + N);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_T, T_search_ref, 56, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_fr, f_ref, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_fc, f_cur, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_LAUNCH(ctx, KID_DEPTH_TRI, k_depth_from_triangulation, dim3(ygz_div_up(n, 256)), dim3(256), d_T, d_fr, d_fc, n, determinant_th, d_d1, d_d2, d_ok);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(depth1, d_d1, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(depth2, d_d2, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, d_ok, N, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
