@@ -284,16 +284,18 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+#define DP_P   40          // LDS row pitch of the patch (bytes): rows start dword-aligned
 __global__ __launch_bounds__(256) void k_describe(DescArgs A)
 {
-    __shared__ uint8_t patch_all[4][DP_N + 15];
+    __shared__ uint32_t patch_all[4][DP_W * DP_P / 4 + 4];
     int bx, so;
     if (!ygz_xcd_remap(A.n_slots, bx, so)) return;
     const int slot = A.slot_begin + so;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kp = bx * 4 + wv;
     if (kp >= A.n_kp[slot]) return;                 // wave-uniform
-    uint8_t *patch = patch_all[wv];
+    uint32_t *patch32 = patch_all[wv];
+    const uint8_t *patch = reinterpret_cast<const uint8_t *>(patch32);
     const size_t o = (size_t)slot * A.cells + kp;
     const int L = A.kp_level[o];
     const int w = A.w[L], h = A.h[L];
@@ -301,30 +303,51 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
     const double sc = (double)(1 << L);
     // cvRound(pixel / 2^L): round half to even (FeatureDetector.cpp:514,547)
     const int cx = (int)rint(A.kp_px[2 * o] / sc), cy = (int)rint(A.kp_px[2 * o + 1] / sc);
-    const long long n = (long long)w * h;
-    for (int i = lane; i < DP_N; i += 64) {
-        const int dy = i / DP_W - DP_R, dx = i - (i / DP_W) * DP_W - DP_R;
-        const long long idx = (long long)(cy + dy) * w + (cx + dx);      // linear addressing as center[dy*step+dx]
-        patch[i] = (idx < 0 || idx >= n) ? (uint8_t)0 : img[idx];
+    const int n = w * h;
+    // 39 x 39 neighbourhood, linear addressing as center[dy*step+dx] (reads outside the level buffer are 0): 39 rows x 10
+    // dwords, each from two aligned dword loads + v_alignbyte (a wave-wide byte gather costs as much as a dword load)
+    for (int item = lane; item < DP_W * 10; item += 64) {
+        const int r = item / 10, j = item - 10 * r;
+        const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
+        uint32_t v;
+        if (idx0 >= 0 && idx0 + 4 <= n) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(img + idx0);
+            ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+            v = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3));
+        } else {
+            v = 0;
+            for (int k = 0; k < 4; ++k) { const int idx = idx0 + k; if (idx >= 0 && idx < n) v |= (uint32_t)img[idx] << (8 * k); }
+        }
+        patch32[item] = v;                          // item == r * (DP_P / 4) + j
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    // IC_Angle (:509-537): integer moments over the circular patch
+    // IC_Angle (:509-537): integer moments over the circular patch.  lane = (row v, half of the row): 4 aligned LDS dwords,
+    // u in [-15, 0] or [1, 15]; half-widths umax[|v|] packed as nibbles {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int v = i / 31 - 15, u = i - (i / 31) * 31 - 15;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= c_umax[av]) {
-            const int I = patch[(v + DP_R) * DP_W + (u + DP_R)];
-            m10 += u * I; m01 += v * I;
+    if (lane < 62) {
+        const int v = (lane >> 1) - 15, hh = lane & 1, av = v < 0 ? -v : v;
+        const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15);
+        const uint32_t *rowp = patch32 + (v + DP_R) * (DP_P / 4) + 1 + 4 * hh;        // column 4 (u = -15) or 20 (u = 1)
+        const uint32_t d[4] = { rowp[0], rowp[1], rowp[2], rowp[3] };
+        const int u0 = hh ? 1 : -15;
+        int srow = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int u = u0 + k, au = u < 0 ? -u : u;
+            const int I = (int)((d[k >> 2] >> (8 * (k & 3))) & 255u);
+            if (au <= um && au <= 15) { m10 += u * I; srow += I; }
         }
+        m01 = v * srow;
     }
     m10 = ygz_wave_sum_i(m10); m01 = ygz_wave_sum_i(m01);
     const float angle = A.given_angle ? A.kp_angle[o] : fast_atan2_deg((float)m01, (float)m10);
     // ComputeOrbDescriptor (:539-578)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)ang), b = (float)sin((double)ang);
+    double sn, cs;
+    sincos((double)ang, &sn, &cs);
+    const float a = (float)cs, b = (float)sn;
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -334,8 +357,8 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
         const int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
         const int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int t0 = patch[(dy0 + DP_R) * DP_W + dx0 + DP_R];
-        const int t1 = patch[(dy1 + DP_R) * DP_W + dx1 + DP_R];
+        const int t0 = patch[(dy0 + DP_R) * DP_P + dx0 + DP_R];
+        const int t1 = patch[(dy1 + DP_R) * DP_P + dx1 + DP_R];
         bits[j] = __ballot(t0 < t1);
     }
     if (lane == 0) {
