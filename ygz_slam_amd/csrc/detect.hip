@@ -21,6 +21,8 @@
 //  k_describe     one wavefront per keypoint: 39x39 neighbourhood in LDS, integer moments by
 //                 wave reduction, cv::fastAtan2 polynomial, 256 tests = 4 ballots of 64 lanes.
 #include "ygz_internal.h"
+#include <stdlib.h>
+#include <stdio.h>
 #include "../../include/ygz_orb_pattern.h"
 
 #define FT_W    64
@@ -47,6 +49,7 @@ struct FastArgs {
     const uint8_t *occupied;
     uint8_t *dbg_score, *dbg_nms;  // may be null
     int slot_begin, n_slots;
+    long long *dbg_cyc;            // YGZ_FAST_TIMERS: [level][8] phase cycles
 };
 
 __device__ __forceinline__ bool ring10(uint32_t m)
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH][FT_LW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[R1_H][R1_LW];      // 0 = no corner, else score+1
-    __shared__ uint16_t list[R1_W * R1_H];
-    __shared__ int n_list;
+    __shared__ uint16_t list[R1_W * R1_H], cand[R1_W * R1_H];
+    __shared__ int n_list, n_cand;
 
     int bx_, by_, so_;
     if (!ygz_xcd_remap3(A.n_slots, bx_, by_, so_)) return;          // frame pinned to one XCD's L2 (block-uniform)
@@ -72,8 +75,25 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
     const uint8_t *img = A.img + (size_t)slot * npix;
     const int x0 = bx_ * FT_W, y0 = by_ * FT_H;
     const int tid = threadIdx.x;
+    // a corner outside Frame::InFrame(px, 20, L) can never be selected (step 3): tiles entirely outside that rectangle are
+    // skipped unless the caller asked for the full corner / NMS maps
+    if (!A.dbg_score && !A.dbg_nms) {
+        const int sc_ = 1 << A.level;
+        if (x0 + FT_W <= 20 * sc_ || y0 + FT_H <= 20 * sc_ || x0 >= (A.img_cols - 20) * sc_ || y0 >= (A.img_rows - 20) * sc_) return;
+    }
 
-    if (tid == 0) n_list = 0;
+#ifdef YGZ_FAST_TIMERS
+    long long tq = clock64();
+#define FS_PHASE(k) do { if (tid == 0 && A.dbg_cyc && so_ == 0) { const long long tn = clock64(); A.dbg_cyc[8 * (by_ * 32 + bx_) + k] = tn - tq; tq = tn; } } while (0)
+#else
+#define FS_PHASE(k) do { } while (0)
+#endif
+#ifdef YGZ_FAST_TIMERS
+#define FS_COUNT(n) do { if (A.dbg_cyc && so_ == 0) { A.dbg_cyc[8 * (by_ * 32 + bx_) + 4] = (n); A.dbg_cyc[8 * (by_ * 32 + bx_) + 5] = 1; } } while (0)
+#else
+#define FS_COUNT(n) do { } while (0)
+#endif
+    if (tid == 0) { n_list = 0; n_cand = 0; }
     for (int i = tid; i < R1_H * R1_LW / 4; i += 256) reinterpret_cast<uint32_t *>(&sc[0][0])[i] = 0u;
     const bool aligned = (A.w & 3) == 0;
     for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
@@ -91,19 +111,33 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
         *reinterpret_cast<uint32_t *>(&tile[r][c4]) = v;
     }
     __syncthreads();
+    FS_PHASE(0);
 
-    // ---- 1) FAST-10 segment test on the interior + 1 ring
+    // ---- 1) FAST-10 segment test on the interior + 1 ring, in two passes so that the expensive part runs on dense lanes:
+    //      1a every pixel: the 4 compass pixels.  A 10-arc of the 16-ring always contains two ADJACENT compass pixels, so a
+    //         corner needs an adjacent pair that is brighter than p + t (or darker than p - t); survivors go to an LDS list.
+    //      1b list entries: full 16-pixel ring -> bright / dark masks -> 10 contiguous bits.
     for (int i = tid; i < R1_W * R1_H; i += 256) {
         const int ry = i / R1_W, rx = i - ry * R1_W;
         const int x = x0 - 1 + rx, y = y0 - 1 + ry;
         if (x < 3 || y < 3 || x >= A.w - 3 || y >= A.h - 3) continue;
         const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
         const int p = *c, hi = p + A.thr, lo = p - A.thr;
-        // any 10-arc holds >= 2 of the 4 compass pixels: cheap reject first
         const int v0 = c[3 * FT_LW], v4 = c[3], v8 = c[-3 * FT_LW], v12 = c[-3];
-        const int nb = (v0 > hi) + (v4 > hi) + (v8 > hi) + (v12 > hi);
-        const int nd = (v0 < lo) + (v4 < lo) + (v8 < lo) + (v12 < lo);
-        if (nb < 2 && nd < 2) continue;
+        const bool b0 = v0 > hi, b4 = v4 > hi, b8 = v8 > hi, b12 = v12 > hi;
+        const bool d0 = v0 < lo, d4 = v4 < lo, d8 = v8 < lo, d12 = v12 < lo;
+        if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) {        // some adjacent compass pair agrees
+            const int pos = atomicAdd(&n_cand, 1);
+            cand[pos] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const int nc = n_cand;
+    for (int ci = tid; ci < nc; ci += 256) {
+        const int i = cand[ci];
+        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
+        const int p = *c, hi = p + A.thr, lo = p - A.thr;
         uint32_t bright = 0, dark = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -117,6 +151,7 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
         }
     }
     __syncthreads();
+    FS_PHASE(1);
     const int n = n_list;
 
     // ---- 2) score in closed form: max over 10-arcs of min(v-p) (bright) / min(p-v) (dark), minus 1
@@ -143,6 +178,7 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
         sc[ry][rx] = (uint8_t)(best - 1 + 1);          // score = best-1 in [thr,254]; stored +1
     }
     __syncthreads();
+    FS_PHASE(2);
 
     // ---- 3) NMS + border + Shi-Tomasi + per-cell winner
     const int scale = 1 << A.level;
@@ -173,18 +209,19 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
         // FeatureDetector::ShiTomasiScore (:467-507) on the LDS tile
         float score = 0.0f;
         if (!(x - 4 < 1 || x + 4 >= A.w - 1 || y - 4 < 1 || y + 4 >= A.h - 1)) {
-            float dXX = 0.f, dYY = 0.f, dXY = 0.f;
+            // every partial sum is an integer below 2^24 (|dx| <= 255, 64 terms), so the reference's float accumulation is
+            // exact in any order: accumulate in int32, convert once
+            int iXX = 0, iYY = 0, iXY = 0;
             const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
             for (int yy = -4; yy < 4; ++yy)
 #pragma unroll
                 for (int xx = -4; xx < 4; ++xx) {
                     const uint8_t *q = c + yy * FT_LW + xx;
-                    const float dx = (float)((int)q[1] - (int)q[-1]);
-                    const float dy = (float)((int)q[FT_LW] - (int)q[-FT_LW]);
-                    dXX = __fadd_rn(dXX, __fmul_rn(dx, dx));
-                    dYY = __fadd_rn(dYY, __fmul_rn(dy, dy));
-                    dXY = __fadd_rn(dXY, __fmul_rn(dx, dy));
+                    const int dx = (int)q[1] - (int)q[-1];
+                    const int dy = (int)q[FT_LW] - (int)q[-FT_LW];
+                    iXX += __mul24(dx, dx); iYY += __mul24(dy, dy); iXY += __mul24(dx, dy);
                 }
+            float dXX = (float)iXX, dYY = (float)iYY, dXY = (float)iXY;
             dXX = __fmul_rn(dXX, 1.0f / 128.0f); dYY = __fmul_rn(dYY, 1.0f / 128.0f); dXY = __fmul_rn(dXY, 1.0f / 128.0f);
             const float tr = __fadd_rn(dXX, dYY);
             const float disc = __fsub_rn(__fmul_rn(tr, tr),
@@ -199,6 +236,8 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
             atomicMax(&A.cell_best[(size_t)slot * A.cells + k], key);
         }
     }
+    FS_PHASE(3);
+    if (tid == 0) FS_COUNT(n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,11 +428,30 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
         A.dbg_score = ctx->prm.debug_maps ? ctx->dbg_score[L] : nullptr;
         A.dbg_nms = ctx->prm.debug_maps ? ctx->dbg_nms[L] : nullptr;
         A.slot_begin = slot_begin; A.n_slots = n_slots;
+        A.dbg_cyc = nullptr;
+#ifdef YGZ_FAST_TIMERS
+        { void *dd = nullptr; if (getenv("YGZ_FAST_DEBUG") && ygz_scratch(ctx, SCR_GEN_0 + 1, 3 * 65536, &dd) == YGZ_OK) { if (L == 0) (void)hipMemsetAsync(dd, 0, 3 * 65536, ctx->stream); A.dbg_cyc = (long long *)dd + 8192 * L; } }
+#endif
         YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), ygz_round_up8(n_slots)), dim3(256), A);
     }
     YGZ_LAUNCH(ctx, KID_COMPACT, k_compact, dim3(n_slots), dim3(1024), ctx->cell_first, ctx->cell_best, ctx->cells,
                        ctx->kp_px, ctx->kp_level, ctx->kp_score, ctx->n_kp, slot_begin);
     YGZ_HIPCHK(ctx, hipGetLastError());
+#ifdef YGZ_FAST_TIMERS
+    if (getenv("YGZ_FAST_DEBUG")) {
+        void *dd = nullptr; static long long h[3 * 8192];
+        if (ygz_scratch(ctx, SCR_GEN_0 + 1, 3 * 65536, &dd) == YGZ_OK) {
+            (void)hipMemcpyAsync(h, dd, sizeof(h), hipMemcpyDeviceToHost, ctx->stream); (void)hipStreamSynchronize(ctx->stream);
+            for (int L = 0; L < 3; ++L) {
+                double acc[6] = { 0, 0, 0, 0, 0, 0 };
+                for (int b = 0; b < 1024; ++b) for (int k = 0; k < 6; ++k) acc[k] += (double)h[8192 * L + 8 * b + k];
+                const double nb = acc[5] > 0 ? acc[5] : 1;
+                fprintf(stderr, "[fast-debug] level %d (slot 0): blocks %.0f corners/block %.1f; cycles/block load %.0f test %.0f score %.0f nms+select %.0f\n", L, acc[5], acc[4] / nb,
+                        acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb);
+            }
+        }
+    }
+#endif
     return ygz_launch_describe(ctx, slot_begin, n_slots);
 }
 
