@@ -73,12 +73,22 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
         const float wBL = (float)((1.0 - (double)sx) * (double)sy);
         const float wBR = __fmul_rn(sx, sy);
         float J0 = 0.f, J1 = 0.f, J2 = 0.f;
+        // the 9 x 9 window rows v_r-4..v_r+4, columns u_r-4..u_r+4: three aligned dword loads + v_alignbyte per row instead of
+        // 18 byte gathers (a wave-wide byte gather costs the address unit as much as a dword load)
+        uint32_t wl[9], wh[9], w8[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(cur + (size_t)(v_r + r - 4) * w + (u_r - 4));
+            ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a & 3), d0 = q[0], d1 = q[1], d2 = q[2];
+            wl[r] = __builtin_amdgcn_alignbyte(d1, d0, sh); wh[r] = __builtin_amdgcn_alignbyte(d2, d1, sh); w8[r] = (d2 >> (8 * sh)) & 255u;
+        }
+#define WIN(r, c) ((c) < 8 ? YGZ_BYTE(wl[r], wh[r], (c) & 7) : (int)w8[r])
+#pragma unroll
         for (int y = 0; y < 8; ++y) {
-            const uint8_t *it = cur + (size_t)(v_r + y - 4) * w + (u_r - 4);
-            float tl = (float)it[0], bl = (float)it[w];
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-                const float tr = (float)it[x + 1], br = (float)it[w + x + 1];
+                const float tl = (float)WIN(y, x), tr = (float)WIN(y, x + 1), bl = (float)WIN(y + 1, x), br = (float)WIN(y + 1, x + 1);
                 const float sp = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wTL, tl), __fmul_rn(wTR, tr)), __fmul_rn(wBL, bl)), __fmul_rn(wBR, br));
                 const int k = (y + 1) * 10 + (x + 1);
                 const float refv = (float)pwb[k * 64];
@@ -89,9 +99,9 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
                 J1 = __fsub_rn(J1, __fmul_rn(res, jy));
                 J2 = __fsub_rn(J2, res);
                 chi2 = __fadd_rn(chi2, __fmul_rn(res, res));
-                tl = tr; bl = br;
             }
         }
+#undef WIN
         const float up0 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[0], J0), __fmul_rn(Hinv[1], J1)), __fmul_rn(Hinv[2], J2));
         const float up1 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[3], J0), __fmul_rn(Hinv[4], J1)), __fmul_rn(Hinv[5], J2));
         const float up2 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[6], J0), __fmul_rn(Hinv[7], J1)), __fmul_rn(Hinv[8], J2));
