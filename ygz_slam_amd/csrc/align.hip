@@ -186,7 +186,9 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
                     // cvutils::GetBilateralInterpUchar (CVUtils.h:59-71)
                     const double xx = qx - floor(qx), yy = qy - floor(qy);
                     const uint8_t *d = img + (size_t)((int)qy) * rw + (int)qx;
-                    val = (uint8_t)((1 - xx) * (1 - yy) * d[0] + xx * (1 - yy) * d[1] + (1 - xx) * yy * d[rw] + xx * yy * d[rw + 1]);
+                    const uint32_t top = *reinterpret_cast<const ygz_u16u *>(d), bot = *reinterpret_cast<const ygz_u16u *>(d + rw);   // 2 gathers, not 4
+                    const int d00 = (int)(top & 255u), d01 = (int)(top >> 8), d10 = (int)(bot & 255u), d11 = (int)(bot >> 8);
+                    val = (uint8_t)((1 - xx) * (1 - yy) * d00 + xx * (1 - yy) * d01 + (1 - xx) * yy * d10 + xx * yy * d11);
                 }
                 pwb[(y * 10 + x) * 64] = val;
             }

@@ -110,13 +110,22 @@ __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32
 // all factors fit 24 bits (pixels 8 bit, derivatives 14 bit, weights 15 bit, differences 14 bit): full-rate v_mad_*24
 // instead of the quarter-rate 32-bit multiply
 #define KLT_MAD(a, b, c) ((int)__mul24((int)(a), (int)(b)) + (int)(c))
-#define KLT_BIL9V(v00, v01, v10, v11) ((KLT_MAD(v00, iw00, KLT_MAD(v01, iw01, KLT_MAD(v10, iw10, KLT_MAD(v11, iw11, 256))))) >> 9)
-#define KLT_BIL14(v00, v01, v10, v11) ((KLT_MAD(v00, iw00, KLT_MAD(v01, iw01, KLT_MAD(v10, iw10, KLT_MAD(v11, iw11, 8192))))) >> 14)
+// the 4-tap fixed-point bilinear sums as two v_dot2c_i32_i16 (exact: |tap| < 2^13, weights <= 2^14):
+//   pixels: (byte k, byte k+1) of an 8-byte row -> two zero-extended 16-bit halves with one v_perm_b32
+//   derivatives: the x (low) or y (high) int16 halves of two adjacent Scharr dwords with one v_perm_b32
+typedef short klt_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int klt_dot2(uint32_t a, uint32_t b, int acc)
+{ return __builtin_amdgcn_sdot2(__builtin_bit_cast(klt_s2, a), __builtin_bit_cast(klt_s2, b), acc, false); }
+#define KLT_PAIR(lo, hi, k) __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | ((uint32_t)((k) + 1) << 16) | (uint32_t)(k))
+#define KLT_BIL9P(l0, h0, l1, h1, k) (klt_dot2(KLT_PAIR(l1, h1, k), wbot, klt_dot2(KLT_PAIR(l0, h0, k), wtop, 256)) >> 9)
+#define KLT_DXP(a, b) __builtin_amdgcn_perm((b), (a), 0x05040100u)
+#define KLT_DYP(a, b) __builtin_amdgcn_perm((b), (a), 0x07060302u)
 #define KLT_WEIGHTS(a, b)                                                                        \
     iw00 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), __fsub_rn(1.f, b)), 16384.f));     \
     iw01 = cv_round_f(__fmul_rn(__fmul_rn(a, __fsub_rn(1.f, b)), 16384.f));                     \
     iw10 = cv_round_f(__fmul_rn(__fmul_rn(__fsub_rn(1.f, a), b), 16384.f));                     \
-    iw11 = 16384 - iw00 - iw01 - iw10
+    iw11 = 16384 - iw00 - iw01 - iw10;                                                          \
+    wtop = (uint32_t)iw00 | ((uint32_t)iw01 << 16); wbot = (uint32_t)iw10 | ((uint32_t)iw11 << 16)
 
 // FULL: the 21-wide window (every active lane owns exactly 7 pixels) -- the per-pixel guards fold away
 template <bool FULL>
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
         }
         float a = __fsub_rn(prevx, (float)ipx), b = __fsub_rn(prevy, (float)ipy);
         int iw00, iw01, iw10, iw11;
+        uint32_t wtop, wbot;
         KLT_WEIGHTS(a, b);
         float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
         // the lane's 7 patch values (int16 image <<5, int16 derivatives) stay in registers for the whole level
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
 #pragma unroll
         for (int k = 0; k < 7; ++k) { iI[k] = 0; iDx[k] = 0; iDy[k] = 0; }
         if (act) {
-            const int o = (ipy + row) * pw + ipx + x0;          // inside the framed buffer for every admissible window
+            const int o = __mul24(ipy + row, pw) + ipx + x0;          // inside the framed buffer for every admissible window
             uint32_t l0, h0, l1, h1;
             klt_load8(I + o, l0, h0); klt_load8(I + o + pw, l1, h1);
             uint32_t d0[8], d1[8];
@@ -179,9 +189,9 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 if (FULL || k < npx) {
-                    const int ival = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1));
-                    const int ixval = KLT_BIL14((int)(int16_t)(d0[k] & 0xFFFF), (int)(int16_t)(d0[k + 1] & 0xFFFF), (int)(int16_t)(d1[k] & 0xFFFF), (int)(int16_t)(d1[k + 1] & 0xFFFF));
-                    const int iyval = KLT_BIL14((int)(int16_t)(d0[k] >> 16), (int)(int16_t)(d0[k + 1] >> 16), (int)(int16_t)(d1[k] >> 16), (int)(int16_t)(d1[k + 1] >> 16));
+                    const int ival = KLT_BIL9P(l0, h0, l1, h1, k);
+                    const int ixval = klt_dot2(KLT_DXP(d1[k], d1[k + 1]), wbot, klt_dot2(KLT_DXP(d0[k], d0[k + 1]), wtop, 8192)) >> 14;
+                    const int iyval = klt_dot2(KLT_DYP(d1[k], d1[k + 1]), wbot, klt_dot2(KLT_DYP(d0[k], d0[k + 1]), wtop, 8192)) >> 14;
                     iI[k] = (int)(int16_t)ival; iDx[k] = (int)(int16_t)ixval; iDy[k] = (int)(int16_t)iyval;
                     q11 += __mul24(iDx[k], iDx[k]); q12 += __mul24(iDx[k], iDy[k]); q22 += __mul24(iDy[k], iDy[k]);
                 }
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             KLT_WEIGHTS(a, b);
             float sb1 = 0.f, sb2 = 0.f;
             if (act) {
-                const int o = (iny + row) * pw + inx + x0;
+                const int o = __mul24(iny + row, pw) + inx + x0;
                 uint32_t l0, h0, l1, h1;
                 klt_load8(J + o, l0, h0); klt_load8(J + o + pw, l1, h1);
                 // the lane's 7 terms are summed exactly in int32 (|diff*I| < 2^26), converted once; pixels beyond the
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
                 int a1 = 0, a2 = 0;
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
-                    const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
+                    const int diff = KLT_BIL9P(l0, h0, l1, h1, k) - iI[k];
                     a1 = KLT_MAD(diff, iDx[k], a1);
                     a2 = KLT_MAD(diff, iDy[k], a2);
                 }
@@ -247,13 +257,13 @@ __global__ __launch_bounds__(256) void k_klt(KltArgs A)
             KLT_WEIGHTS(aa, bb);
             float se = 0.f;
             if (act) {
-                const int o = (iny + row) * pw + inx + x0;
+                const int o = __mul24(iny + row, pw) + inx + x0;
                 uint32_t l0, h0, l1, h1;
                 klt_load8(J + o, l0, h0); klt_load8(J + o + pw, l1, h1);
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
                     if (FULL || k < npx) {
-                        const int diff = KLT_BIL9V(KLT_BYTE(l0, h0, k), KLT_BYTE(l0, h0, k + 1), KLT_BYTE(l1, h1, k), KLT_BYTE(l1, h1, k + 1)) - iI[k];
+                        const int diff = KLT_BIL9P(l0, h0, l1, h1, k) - iI[k];
                         se = __fadd_rn(se, fabsf((float)diff));
                     }
                 }

@@ -232,6 +232,7 @@ __device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((dou
 // costs the address unit as much as a dword load, so patch windows are fetched row-wise.  May touch up to 11 bytes past p
 // (every image buffer is allocated with 64 bytes of slack).
 typedef const __attribute__((address_space(1))) uint32_t *ygz_gptr32;
+typedef uint16_t __attribute__((aligned(1))) ygz_u16u;          // 2 adjacent bytes at any address: one (unaligned) global_load_ushort
 __device__ __forceinline__ void ygz_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
