@@ -9,20 +9,20 @@
 //
 // FP64 VALU work; the block contraction has inner dimension 2 (two residual rows), far too thin
 // for MFMA.  The accumulation is organised so that no floating-point atomics are needed and every
-// sum has a fixed order:
+// sum has a fixed order, and the data so that every per-edge access is a contiguous 512-byte row (ba_dev.h):
 //  k_ba_pose_prep  lane = pose: SE3::exp once per pose (q, t, R) instead of once per edge.
-//  k_ba_points     lane = map point: walks the point's edges in edge order (CSR built at upload),
-//                  accumulates Hll / bl in registers exactly in the oracle's order, writes the
-//                  unique 6x3 Hpl block, the residual and chi2 of each edge once (coalesced by edge
-//                  when edges are sorted by point, as BA.cpp:421-493 generates them), and leaves
-//                  (p_cam, rho', r) per edge for the pose pass.
-//  k_ba_poses      workgroup = keyframe pose: lanes stride over the pose's edge list, rebuild the
-//                  2x6 pose Jacobian from the stored camera point (12 values, ~20 flops: cheaper than
-//                  reading it back), accumulate 21+6 sums, fixed-order tree reduction.
-//  k_ba_chi2       fixed-order sum of the robustified chi2.
+//  k_ba_points     lane = map point, wavefront = chunk of 64 points.  Pass 1 walks the point's edges in edge order:
+//                  Hll / bl in registers exactly in the oracle's order, the unique 6x3 Hpl block, residual and chi2 of each
+//                  edge.  Pass 2 runs over the free poses: lanes whose point sees the pose rebuild the 2x6 pose Jacobian
+//                  (cheaper than storing and re-reading it), the 21 + 6 sums are reduced inside the wavefront in a fixed order
+//                  and written as one partial per (chunk, pose).
+//  k_ba_final      Hpp / bp / chi2 = the partials summed over the chunks in chunk order.
+//  k_ba_unpack     edge-order / point-order copies of the chunked arrays for the ABI (download path only).
 #include "ba_dev.h"
 #include <vector>
 #include <string.h>
+
+#define ba_wave_sum ygz_wave_sum_d
 
 __global__ __launch_bounds__(64) void k_ba_pose_prep(const BaDev *__restrict__ wins)
 {
@@ -36,69 +36,55 @@ __global__ __launch_bounds__(64) void k_ba_pose_prep(const BaDev *__restrict__ w
 __global__ __launch_bounds__(128) void k_ba_points(const BaDev *__restrict__ wins)
 {
     const BaDev B = wins[blockIdx.y];
-    const int il = blockIdx.x * 128 + threadIdx.x;
-    if (il >= B.P) return;
-    (void)ba_point_edges(B, il);
-}
-
-__global__ __launch_bounds__(256) void k_ba_poses(const BaDev *__restrict__ wins)
-{
-    __shared__ double red[4][27];
-    const BaDev B = wins[blockIdx.y];
-    if ((int)blockIdx.x >= B.K) return;                // block-uniform
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double acc[27];
+    const int il = blockIdx.x * 128 + threadIdx.x, lane = threadIdx.x & 63, q = il >> 6;
+    if (q >= B.Q) return;                                   // wavefront-uniform
+    const bool live = il < B.P;
+    double chi = live ? ba_point_edges(B, il) : 0.0;
+    chi = ba_wave_sum(chi);
+    if (lane == 0) B.part_chi[q] = chi;
+    for (int a = 0; a < B.Kf; ++a) {
+        double acc[27];
 #pragma unroll
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-    const bool fixed = B.fixed[k] != 0;
-    const double *pd = B.posed + BA_POSED * (size_t)k;
-    if (!fixed) {
-        for (int c = B.pose_off[k] + tid; c < B.pose_off[k + 1]; c += 256) {
-            const int e = B.pose_edges[c];
-            const double *et = B.edge_tmp + 6 * (size_t)e;
-            const double rho1 = et[3], r0 = et[4], r1 = et[5];
-            double Jx[12];
-            ba_pose_jac(B.formulation, et[0], et[1], et[2], B.fx, B.fy, pd, Jx);
-            int q = 0;
+        for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+        if (live) ba_pose_contrib(B, il, a, acc);
+        double *out = B.part_pose + ((size_t)q * B.Kf + a) * 27;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[q++] += rho1 * (Jx[a] * Jx[b] + Jx[6 + a] * Jx[6 + b]);
-            }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] += -rho1 * (Jx[a] * r0 + Jx[6 + a] * r1);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 27; ++i) {
-        double v = acc[i];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) red[wv][i] = v;
-    }
-    __syncthreads();
-    if (tid < 27) {
-        const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        if (tid < 21) {
-            int a = 0, rem = tid;                      // unpack upper-triangular index
-            while (rem >= 6 - a) { rem -= 6 - a; ++a; }
-            const int b = a + rem;
-            B.Hpp[36 * (size_t)k + 6 * a + b] = s; B.Hpp[36 * (size_t)k + 6 * b + a] = s;
-        } else B.bp[6 * (size_t)k + (tid - 21)] = s;
+        for (int i = 0; i < 27; ++i) { const double v = ba_wave_sum(acc[i]); if (lane == 0) out[i] = v; }
     }
 }
 
-__global__ __launch_bounds__(1024) void k_ba_chi2(const BaDev *__restrict__ wins)
+__global__ __launch_bounds__(256) void k_ba_final(const BaDev *__restrict__ wins)
 {
-    __shared__ double red[16];
-    const double *rho0 = wins[blockIdx.x].rho0; const int E = wins[blockIdx.x].E; double *out = wins[blockIdx.x].chi2;
-    double v = 0.0;
-    for (int e = threadIdx.x; e < E; e += 1024) v += rho0[e];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) { double s = 0; for (int i = 0; i < 16; ++i) s += red[i]; *out = s; }
+    const BaDev B = wins[blockIdx.x];
+    for (int t = threadIdx.x; t < B.Kf * 27; t += 256) {
+        const int a = t / 27, i = t - 27 * a, k = B.free_pose[a];
+        double s = 0.0;
+        for (int q = 0; q < B.Q; ++q) s += B.part_pose[((size_t)q * B.Kf + a) * 27 + i];
+        if (i < 21) {
+            int u = 0, rem = i;                                // unpack upper-triangular index
+            while (rem >= 6 - u) { rem -= 6 - u; ++u; }
+            const int v = u + rem;
+            B.Hpp[36 * (size_t)k + 6 * u + v] = s; B.Hpp[36 * (size_t)k + 6 * v + u] = s;
+        } else B.bp[6 * (size_t)k + (i - 21)] = s;
+    }
+    if (threadIdx.x == 0) { double s = 0.0; for (int q = 0; q < B.Q; ++q) s += B.part_chi[q]; *B.chi2 = s; }
+}
+
+// out[e][k] = chunked[(row_e * NC + k) * 64 + lane_e]   (edge order for the ABI)
+__global__ __launch_bounds__(256) void k_ba_unpack_edges(const double *__restrict__ src, const int32_t *__restrict__ edge_rl, int E, int NC,
+                                                         double *__restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= E * NC) return;
+    const int e = t / NC, k = t - e * NC, rl = edge_rl[e];
+    out[t] = src[((size_t)(rl >> 6) * NC + k) * 64 + (rl & 63)];
+}
+__global__ __launch_bounds__(256) void k_ba_unpack_points(const double *__restrict__ src, int P, int NC, double *__restrict__ out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= P * NC) return;
+    const int l = t / NC, k = t - l * NC;
+    out[t] = src[((size_t)(l >> 6) * NC + k) * 64 + (l & 63)];
 }
 
 static void ba_free(ygz_hip_ctx::BaWindow *w) { if (w) { if (w->blob) (void)hipFree(w->blob); delete w; } }
@@ -113,15 +99,16 @@ extern "C" void ygz_hip_ba_free_all(ygz_hip_ctx *ctx)
 static BaDev ba_dev(const ygz_hip_ctx::BaWindow *w)
 {
     BaDev B;
-    B.K = w->K; B.P = w->P; B.E = w->E; B.formulation = w->formulation;
+    B.K = w->K; B.P = w->P; B.E = w->E; B.formulation = w->formulation; B.Kf = w->Kf; B.R = w->R; B.Q = w->Q;
     B.fx = w->fx; B.fy = w->fy; B.cx = w->cx; B.cy = w->cy; B.huber = w->huber;
-    B.poses = w->poses; B.points = w->points; B.obs = w->obs; B.posed = w->posed; B.edge_tmp = w->edge_tmp; B.rho0 = w->rho0;
-    B.edge_huber = w->edge_huber; B.n_behind = w->n_behind; B.point_fixed = w->point_fixed; B.edge_enable = w->edge_enable;
-    B.Hpp = w->Hpp; B.bp = w->bp; B.Hll = w->Hll; B.bl = w->bl; B.Hpl = w->Hpl; B.err = w->err; B.chi2_edge = w->chi2_edge; B.chi2 = w->chi2;
-    B.edge_pose = w->edge_pose; B.edge_point = w->edge_point; B.pt_off = w->pt_off; B.pt_edges = w->pt_edges;
-    B.pose_off = w->pose_off; B.pose_edges = w->pose_edges; B.fixed = w->fixed;
-    B.Kf = w->Kf; B.poses_w = w->poses; B.points_w = w->points; B.poses_bk = w->poses_bk; B.points_bk = w->points_bk;
-    B.Y = w->Y; B.Dinv = w->Dinv; B.xl = w->xl; B.free_idx = w->free_idx; B.free_pose = w->free_pose; B.pt_pose_edge = w->pt_pose_edge;
+    B.poses = w->poses; B.points = w->points; B.posed = w->posed;
+    B.obs_c = w->obs_c; B.huber_c = w->huber_c; B.pose_c = w->pose_c; B.enable_c = w->enable_c; B.slot_off = w->slot_off; B.ppc = w->ppc;
+    B.edge_rl = w->edge_rl; B.fixed = w->fixed; B.point_fixed = w->point_fixed; B.free_idx = w->free_idx; B.free_pose = w->free_pose;
+    B.n_behind = w->n_behind;
+    B.Hpp = w->Hpp; B.bp = w->bp; B.chi2 = w->chi2; B.Hll_c = w->Hll_c; B.bl_c = w->bl_c; B.Hpl_c = w->Hpl_c; B.err_c = w->err_c;
+    B.chi2e_c = w->chi2e_c; B.part_pose = w->part_pose; B.part_chi = w->part_chi;
+    B.poses_w = w->poses; B.points_w = w->points; B.poses_bk = w->poses_bk; B.points_bk = w->points_bk;
+    B.Y_c = w->Y_c; B.Dinv = w->Dinv; B.xl = w->xl;
     return B;
 }
 
@@ -167,70 +154,81 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     auto *w = new ygz_hip_ctx::BaWindow();
     w->K = K; w->P = P; w->E = E; w->formulation = pb->formulation;
     w->fx = pb->fx; w->fy = pb->fy; w->cx = pb->cx; w->cy = pb->cy; w->huber = pb->huber_delta;
-    // CSR by point and by pose, edges in ascending edge order inside each row
-    std::vector<int32_t> pt_off(P + 1, 0), pose_off(K + 1, 0), pt_edges(E > 0 ? E : 1), pose_edges(E > 0 ? E : 1);
-    for (int e = 0; e < E; ++e) { pt_off[pb->edge_point[e] + 1]++; pose_off[pb->edge_pose[e] + 1]++; }
-    for (int i = 0; i < P; ++i) pt_off[i + 1] += pt_off[i];
-    for (int i = 0; i < K; ++i) pose_off[i + 1] += pose_off[i];
-    { std::vector<int32_t> c1(pt_off.begin(), pt_off.end() - 1), c2(pose_off.begin(), pose_off.end() - 1);
-      for (int e = 0; e < E; ++e) { pt_edges[c1[pb->edge_point[e]]++] = e; pose_edges[c2[pb->edge_pose[e]]++] = e; } }
-    // one blob: doubles first, then int32, then bytes
-    const size_t Ez = (size_t)(E > 0 ? E : 1);
+    // ---- rows: the c-th edge (ascending edge order) of every point of a 64-point chunk
+    const int Q = (P + 63) / 64;
+    std::vector<int32_t> cnt(P, 0), slot_off(Q + 1, 0);
+    for (int e = 0; e < E; ++e) cnt[pb->edge_point[e]]++;
+    for (int q = 0; q < Q; ++q) {
+        int mx = 0;
+        for (int l = 64 * q; l < std::min(P, 64 * q + 64); ++l) mx = std::max(mx, cnt[l]);
+        if (mx > 32767) { delete w; return YGZ_E_CAPACITY; }
+        slot_off[q + 1] = slot_off[q] + mx;
+    }
+    const int R = slot_off[Q];
+    const size_t Rz = (size_t)(R > 0 ? R : 1), Ez = (size_t)(E > 0 ? E : 1);
     std::vector<int32_t> free_idx(K, -1), free_pose(K, -1);
     int Kf = 0;
     for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) { free_idx[k] = Kf; free_pose[Kf] = k; ++Kf; }
     const size_t Kfz = (size_t)(Kf > 0 ? Kf : 1);
-    const size_t nd = (size_t)K * 6 + (size_t)P * 3 + Ez * 2 + (size_t)K * BA_POSED + Ez * 6 + Ez + Ez
-                    + (size_t)K * 36 + (size_t)K * 6 + (size_t)P * 9 + (size_t)P * 3 + Ez * 18 + Ez * 2 + Ez + 1
-                    + (size_t)K * 6 + (size_t)P * 3 + Ez * 18 + (size_t)P * 9 + (size_t)P * 3;          // LM: backups, Y, Dinv, xl
-    const size_t ni = Ez * 4 + (size_t)P + 1 + (size_t)K + 1 + 1 + 2 * (size_t)K + (size_t)P * Kfz;
-    const size_t bytes = nd * 8 + ni * 4 + (size_t)K + (size_t)P + Ez + 64;
+    w->Kf = Kf; w->R = R; w->Q = Q;
+    std::vector<int32_t> pose_c(Rz * 64, -1), edge_rl(Ez, 0);
+    std::vector<double> obs_c(Rz * 128, 0.0), huber_c(Rz * 64, 0.0);
+    std::vector<uint8_t> enable_c(Rz * 64, 0);
+    std::vector<int16_t> ppc((size_t)P * Kfz, -1);
+    std::fill(cnt.begin(), cnt.end(), 0);
+    for (int e = 0; e < E; ++e) {
+        const int l = pb->edge_point[e], c = cnt[l]++, row = slot_off[l >> 6] + c, lane = l & 63, ip = pb->edge_pose[e];
+        edge_rl[e] = row * 64 + lane;
+        pose_c[(size_t)row * 64 + lane] = ip;
+        obs_c[((size_t)row * 2) * 64 + lane] = pb->obs[2 * (size_t)e]; obs_c[((size_t)row * 2 + 1) * 64 + lane] = pb->obs[2 * (size_t)e + 1];
+        huber_c[(size_t)row * 64 + lane] = pb->edge_huber ? pb->edge_huber[e] : pb->huber_delta;
+        enable_c[(size_t)row * 64 + lane] = pb->edge_enable ? (pb->edge_enable[e] ? 1 : 0) : 1;
+        const int a = free_idx[ip];
+        if (a >= 0 && ppc[(size_t)l * Kfz + a] < 0) ppc[(size_t)l * Kfz + a] = (int16_t)c;
+    }
+    w->h_edge_rl = edge_rl;
+    // ---- one blob: doubles, then int32, then int16, then bytes
+    const size_t nd = (size_t)K * 6 + (size_t)P * 3 + (size_t)K * BA_POSED                      // poses, points, posed
+                    + Rz * 128 + Rz * 64                                                          // obs_c, huber_c
+                    + (size_t)K * 36 + (size_t)K * 6 + 1 + (size_t)Q * 9 * 64 + (size_t)Q * 3 * 64  // Hpp, bp, chi2, Hll_c, bl_c
+                    + Rz * 18 * 64 + Rz * 2 * 64 + Rz * 64                                        // Hpl_c, err_c, chi2e_c
+                    + (size_t)Q * Kfz * 27 + (size_t)Q                                            // partials
+                    + (size_t)K * 6 + (size_t)P * 3 + Rz * 18 * 64 + (size_t)P * 9 + (size_t)P * 3;   // LM: backups, Y_c, Dinv, xl
+    const size_t ni = Rz * 64 + (size_t)Q + 1 + Ez + 2 * (size_t)K + 1;
+    const size_t ns = (size_t)P * Kfz + 1;
+    const size_t bytes = nd * 8 + ni * 4 + ((ns * 2 + 3) & ~(size_t)3) + (size_t)K + (size_t)P + Rz * 64 + 64;
     hipError_t he = hipMalloc(&w->blob, bytes);
     if (he != hipSuccess) { ctx->last_hip_error = (int)he; delete w; return YGZ_E_HIP; }
     double *d = (double *)w->blob;
-    w->poses = d; d += (size_t)K * 6; w->points = d; d += (size_t)P * 3; w->obs = d; d += Ez * 2;
-    w->posed = d; d += (size_t)K * BA_POSED; w->edge_tmp = d; d += Ez * 6; w->rho0 = d; d += Ez; w->edge_huber = d; d += Ez;
-    w->Hpp = d; d += (size_t)K * 36; w->bp = d; d += (size_t)K * 6; w->Hll = d; d += (size_t)P * 9; w->bl = d; d += (size_t)P * 3;
-    w->Hpl = d; d += Ez * 18; w->err = d; d += Ez * 2; w->chi2_edge = d; d += Ez; w->chi2 = d; d += 1;
-    w->poses_bk = d; d += (size_t)K * 6; w->points_bk = d; d += (size_t)P * 3; w->Y = d; d += Ez * 18; w->Dinv = d; d += (size_t)P * 9;
-    w->xl = d; d += (size_t)P * 3;
+    w->poses = d; d += (size_t)K * 6; w->points = d; d += (size_t)P * 3; w->posed = d; d += (size_t)K * BA_POSED;
+    w->obs_c = d; d += Rz * 128; w->huber_c = d; d += Rz * 64;
+    w->Hpp = d; d += (size_t)K * 36; w->bp = d; d += (size_t)K * 6; w->chi2 = d; d += 1;
+    w->Hll_c = d; d += (size_t)Q * 9 * 64; w->bl_c = d; d += (size_t)Q * 3 * 64;
+    w->Hpl_c = d; d += Rz * 18 * 64; w->err_c = d; d += Rz * 2 * 64; w->chi2e_c = d; d += Rz * 64;
+    w->part_pose = d; d += (size_t)Q * Kfz * 27; w->part_chi = d; d += (size_t)Q;
+    w->poses_bk = d; d += (size_t)K * 6; w->points_bk = d; d += (size_t)P * 3; w->Y_c = d; d += Rz * 18 * 64;
+    w->Dinv = d; d += (size_t)P * 9; w->xl = d; d += (size_t)P * 3;
     int32_t *ii = (int32_t *)d;
-    w->edge_pose = ii; ii += Ez; w->edge_point = ii; ii += Ez; w->pt_edges = ii; ii += Ez; w->pose_edges = ii; ii += Ez;
-    w->pt_off = ii; ii += (size_t)P + 1; w->pose_off = ii; ii += (size_t)K + 1; w->n_behind = ii; ii += 1;
-    w->free_idx = ii; ii += K; w->free_pose = ii; ii += K; w->pt_pose_edge = ii; ii += (size_t)P * Kfz;
-    w->Kf = Kf;
-    w->fixed = (uint8_t *)ii; w->point_fixed = w->fixed + K; w->edge_enable = w->point_fixed + P;
+    w->pose_c = ii; ii += Rz * 64; w->slot_off = ii; ii += (size_t)Q + 1; w->edge_rl = ii; ii += Ez;
+    w->free_idx = ii; ii += K; w->free_pose = ii; ii += K; w->n_behind = ii; ii += 1;
+    w->ppc = (int16_t *)ii;
+    uint8_t *bb = (uint8_t *)ii + ((ns * 2 + 3) & ~(size_t)3);
+    w->fixed = bb; bb += K; w->point_fixed = bb; bb += P; w->enable_c = bb;
     ctx->ba[window] = w;
     ctx->ba_table_dirty = true;
-    std::vector<uint8_t> fixed(K, 0), pfixed(P, 0), enable(Ez, 1);
-    std::vector<double> hub(Ez, pb->huber_delta);
+    std::vector<uint8_t> fixed(K, 0), pfixed(P, 0);
     if (pb->pose_fixed) memcpy(fixed.data(), pb->pose_fixed, K);
     if (pb->point_fixed) memcpy(pfixed.data(), pb->point_fixed, P);
-    if (pb->edge_enable && E > 0) memcpy(enable.data(), pb->edge_enable, E);
-    if (pb->edge_huber && E > 0) memcpy(hub.data(), pb->edge_huber, (size_t)E * 8);
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->poses, pb->poses, (size_t)K * 48, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->points, pb->points, (size_t)P * 24, hipMemcpyHostToDevice, ctx->stream));
-    if (E > 0) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->obs, pb->obs, (size_t)E * 16, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->edge_pose, pb->edge_pose, (size_t)E * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->edge_point, pb->edge_point, (size_t)E * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->pt_edges, pt_edges.data(), (size_t)E * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->pose_edges, pose_edges.data(), (size_t)E * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    {   // edge of (point, free pose): first such edge if a pair is observed twice
-        std::vector<int32_t> ppe((size_t)P * Kfz, -1);
-        for (int e = E - 1; e >= 0; --e) { const int a = free_idx[pb->edge_pose[e]]; if (a >= 0) ppe[(size_t)pb->edge_point[e] * Kfz + a] = e; }
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->pt_pose_edge, ppe.data(), ppe.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->free_idx, free_idx.data(), (size_t)K * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(w->free_pose, free_pose.data(), (size_t)K * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->pt_off, pt_off.data(), ((size_t)P + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->pose_off, pose_off.data(), ((size_t)K + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->fixed, fixed.data(), (size_t)K, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->point_fixed, pfixed.data(), (size_t)P, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->edge_enable, enable.data(), Ez, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->edge_huber, hub.data(), Ez * 8, hipMemcpyHostToDevice, ctx->stream));
+#define UP_(dst, src, n) YGZ_HIPCHK(ctx, hipMemcpyAsync((void *)(dst), (src), (n), hipMemcpyHostToDevice, ctx->stream))
+    UP_(w->poses, pb->poses, (size_t)K * 48); UP_(w->points, pb->points, (size_t)P * 24);
+    UP_(w->obs_c, obs_c.data(), Rz * 128 * 8); UP_(w->huber_c, huber_c.data(), Rz * 64 * 8);
+    UP_(w->pose_c, pose_c.data(), Rz * 64 * 4); UP_(w->slot_off, slot_off.data(), ((size_t)Q + 1) * 4); UP_(w->edge_rl, edge_rl.data(), Ez * 4);
+    UP_(w->free_idx, free_idx.data(), (size_t)K * 4); UP_(w->free_pose, free_pose.data(), (size_t)K * 4);
+    UP_(w->ppc, ppc.data(), ppc.size() * 2);
+    UP_(w->fixed, fixed.data(), (size_t)K); UP_(w->point_fixed, pfixed.data(), (size_t)P); UP_(w->enable_c, enable_c.data(), Rz * 64);
+#undef UP_
+    // blocks of constant poses / padding lanes are never written by the kernels: zero once
+    YGZ_HIPCHK(ctx, hipMemsetAsync(w->Hpp, 0, ((size_t)K * 42 + 1 + (size_t)Q * 12 * 64 + Rz * 21 * 64) * 8, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // host vectors go out of scope
     return YGZ_OK;
 }
@@ -268,8 +266,7 @@ int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
     YgzAuxScope aux(ctx, 1);
     YGZ_LAUNCH(ctx, KID_BA_POSE_PREP, k_ba_pose_prep, dim3(ygz_div_up(ctx->ba_max_K, 64), n_windows), dim3(64), tab);
     YGZ_LAUNCH(ctx, KID_BA_POINTS, k_ba_points, dim3(ygz_div_up(ctx->ba_max_P, 128), n_windows), dim3(128), tab);
-    YGZ_LAUNCH(ctx, KID_BA_POSES, k_ba_poses, dim3(ctx->ba_max_K, n_windows), dim3(256), tab);
-    YGZ_LAUNCH(ctx, KID_BA_CHI2, k_ba_chi2, dim3(n_windows), dim3(1024), tab);
+    YGZ_LAUNCH(ctx, KID_BA_POSES, k_ba_final, dim3(n_windows), dim3(256), tab);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
@@ -282,9 +279,26 @@ int ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, d
     auto *w = ctx->ba[window];
     const size_t K = w->K, P = w->P, E = w->E;
 #define DL_(dst, src, n) if ((dst) && (n) > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync((dst), (src), (n) * 8, hipMemcpyDeviceToHost, ctx->stream))
-    DL_(Hpp, w->Hpp, K * 36); DL_(bp, w->bp, K * 6); DL_(Hll, w->Hll, P * 9); DL_(bl, w->bl, P * 3);
-    DL_(Hpl, w->Hpl, E * 18); DL_(err, w->err, E * 2); DL_(chi2_edge, w->chi2_edge, E); DL_(chi2, w->chi2, (size_t)1);
+    DL_(Hpp, w->Hpp, K * 36); DL_(bp, w->bp, K * 6); DL_(chi2, w->chi2, (size_t)1);
+    // chunked -> ABI order through a staging buffer
+    const size_t need = std::max(E * 18, P * 9);
+    double *stage = nullptr;
+    if ((Hll || bl || Hpl || err || chi2_edge) && need > 0) {
+        int rc = ygz_scratch(ctx, SCR_BA_0, need * 8, (void **)&stage);
+        if (rc != YGZ_OK) return rc;
+    }
+#define EDGE_(dst, src, NC) if ((dst) && E > 0) { k_ba_unpack_edges<<<dim3(ygz_div_up((int)(E * (NC)), 256)), dim3(256), 0, ctx->stream>>>((src), w->edge_rl, (int)E, (NC), stage); \
+                                                  YGZ_HIPCHK(ctx, hipMemcpyAsync((dst), stage, E * (NC) * 8, hipMemcpyDeviceToHost, ctx->stream)); \
+                                                  YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+#define POINT_(dst, src, NC) if (dst) { k_ba_unpack_points<<<dim3(ygz_div_up((int)(P * (NC)), 256)), dim3(256), 0, ctx->stream>>>((src), (int)P, (NC), stage); \
+                                        YGZ_HIPCHK(ctx, hipMemcpyAsync((dst), stage, P * (NC) * 8, hipMemcpyDeviceToHost, ctx->stream)); \
+                                        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+    POINT_(Hll, w->Hll_c, 9) POINT_(bl, w->bl_c, 3)
+    EDGE_(Hpl, w->Hpl_c, 18) EDGE_(err, w->err_c, 2) EDGE_(chi2_edge, w->chi2e_c, 1)
+#undef EDGE_
+#undef POINT_
 #undef DL_
+    YGZ_HIPCHK(ctx, hipGetLastError());
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }
@@ -305,7 +319,9 @@ int ygz_hip_ba_set_enable(ygz_hip_ctx *ctx, int window, const uint8_t *edge_enab
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !edge_enable || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
-    if (w->E > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(w->edge_enable, edge_enable, (size_t)w->E, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint8_t> en((size_t)(w->R > 0 ? w->R : 1) * 64, 0);
+    for (int e = 0; e < w->E; ++e) en[w->h_edge_rl[e]] = edge_enable[e] ? 1 : 0;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(w->enable_c, en.data(), en.size(), hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }

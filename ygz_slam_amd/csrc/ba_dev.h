@@ -1,38 +1,61 @@
 // Device-side building blocks of the local-BA edge stack, shared by the linearisation kernels (ba.hip) and the resident
 // Levenberg-Marquardt kernel (ba_resident_lm.hip).  See ba.hip for the reference citations.
+//
+// HBM layout of a window.  The unit of parallelism is the map point (lane = point), so every per-edge array is stored the way
+// the lanes touch it: points are taken 64 at a time (a chunk = a wavefront), the c-th edge of every point of a chunk forms
+// a ROW, and a row keeps each of its NC components as 64 consecutive doubles:
+//     element(l, c, k) = base[((slot_off[l >> 6] + c) * NC + k) * 64 + (l & 63)]
+// A store of component k by the 64 lanes is one contiguous 512-byte write and a load one contiguous read -- the edge-major
+// AoS form ([E][18] doubles written 8 bytes at a time with a ~1.3 KB lane stride) cost 1.6x write amplification plus a
+// read-for-ownership of the same size in HBM.  Per-point arrays (Hll, bl) use the same idea with c = 0: [chunk][NC][64].
+// The ABI keeps edge order: ygz_hip_ba_download gathers through the (row, lane) of every edge.
 #ifndef YGZ_BA_DEV_H_
 #define YGZ_BA_DEV_H_
 #include "ygz_internal.h"
 #include "se3_dev.h"
+#include <vector>
 
 struct ygz_hip_ctx::BaWindow {
-    int K = 0, P = 0, E = 0, formulation = 0;
+    int K = 0, P = 0, E = 0, formulation = 0, Kf = 0, R = 0, Q = 0;       // R rows, Q = ceil(P / 64) chunks
     double fx = 0, fy = 0, cx = 0, cy = 0, huber = 0;
     void *blob = nullptr;            // one allocation
-    double *poses, *points, *obs, *posed, *edge_tmp, *rho0, *edge_huber;
-    double *Hpp, *bp, *Hll, *bl, *Hpl, *err, *chi2_edge, *chi2;
-    int32_t *edge_pose, *edge_point, *pt_off, *pt_edges, *pose_off, *pose_edges, *n_behind;
-    uint8_t *fixed, *point_fixed, *edge_enable;
+    double *poses, *points, *posed;
+    double *obs_c, *huber_c;         // [R][2][64], [R][64]
+    int32_t *pose_c;                 // [R][64] pose of the c-th edge of the lane's point, -1: no such edge
+    uint8_t *enable_c;               // [R][64]
+    int32_t *slot_off;               // [Q + 1] first row of each chunk
+    int16_t *ppc;                    // [P][Kf] c of the (first) edge from point l to free pose a, or -1
+    int32_t *edge_rl;                // [E] row * 64 + lane of edge e (gather / scatter between ABI order and rows)
+    uint8_t *fixed, *point_fixed;
+    int32_t *free_idx, *free_pose, *n_behind;
+    double *Hpp, *bp, *chi2;         // [K][36], [K][6], [1]
+    double *Hll_c, *bl_c;            // [Q][9][64], [Q][3][64]
+    double *Hpl_c, *err_c, *chi2e_c; // [R][18][64], [R][2][64], [R][64]
+    double *part_pose, *part_chi;    // [Q][Kf][27], [Q]: per-wavefront partial sums of the pose blocks / chi2
     // work space of the resident Levenberg-Marquardt kernel (ba_resident_lm.hip)
-    int Kf = 0;                      // free poses
-    double *poses_bk, *points_bk, *Y, *Dinv, *xl;
-    int32_t *free_idx, *free_pose, *pt_pose_edge;
+    double *poses_bk, *points_bk, *Y_c, *Dinv, *xl;       // Y_c [R][18][64]
+    // host side: where each edge lives (for ygz_hip_ba_set_enable)
+    std::vector<int32_t> h_edge_rl;
 };
 #define BA_POSED 32      // doubles per prepared pose: q(4) t(3) R(9) J_l(9)
 
 struct BaDev {
-    int K, P, E, formulation;
+    int K, P, E, formulation, Kf, R, Q;
     double fx, fy, cx, cy, huber;
-    const double *poses, *points, *obs; double *posed, *edge_tmp, *rho0; const double *edge_huber;
-    double *Hpp, *bp, *Hll, *bl, *Hpl, *err, *chi2_edge, *chi2;
-    const int32_t *edge_pose, *edge_point, *pt_off, *pt_edges, *pose_off, *pose_edges; int32_t *n_behind;
-    const uint8_t *fixed, *point_fixed, *edge_enable;
-    int Kf;
+    const double *poses, *points; double *posed;
+    const double *obs_c, *huber_c; const int32_t *pose_c; const uint8_t *enable_c; const int32_t *slot_off; const int16_t *ppc;
+    const int32_t *edge_rl;
+    const uint8_t *fixed, *point_fixed; const int32_t *free_idx, *free_pose; int32_t *n_behind;
+    double *Hpp, *bp, *chi2, *Hll_c, *bl_c, *Hpl_c, *err_c, *chi2e_c, *part_pose, *part_chi;
     double *poses_w, *points_w;      // the same state arrays, writable (LM update / restore)
-    double *poses_bk, *points_bk, *Y, *Dinv, *xl;
-    const int32_t *free_idx, *free_pose, *pt_pose_edge;     // pose -> free index or -1; free index -> pose; [P][Kf] edge of (point, free pose) or -1
+    double *poses_bk, *points_bk, *Y_c, *Dinv, *xl;
 };
 const BaDev *ygz_ba_table(ygz_hip_ctx *ctx, int *rc);        // device table of all uploaded windows, rebuilt when dirty
+
+// element k of row `row` for lane `lane` in a chunked per-edge array with NC components
+#define BA_EC(base, row, NC, k, lane) ((base)[(((size_t)(row) * (NC)) + (k)) * 64 + (lane)])
+// element k of point l in a chunked per-point array with NC components
+#define BA_PC(base, l, NC, k) ((base)[((size_t)((l) >> 6) * (NC) + (k)) * 64 + ((l) & 63)])
 
 // SE3::exp once per pose instead of once per edge: (q, t, R) and, for the ceres formulation, J_l
 __device__ __forceinline__ void ba_pose_prep_one(const BaDev &B, int k)
@@ -100,10 +123,11 @@ __device__ __forceinline__ void ba_pose_jac(int formulation, double x, double y,
     }
 }
 
-// camera-frame point and residual of one edge (computeError)
-__device__ __forceinline__ void ba_edge_residual(const BaDev &B, int e, const double pt[3], double p[3], double r[2])
+
+// camera-frame point of map point pt seen from prepared pose pd, and the residual against obs (computeError)
+__device__ __forceinline__ void ba_project(const BaDev &B, const double *__restrict__ pd, const double pt[3], double ox, double oy,
+                                           double p[3], double r[2])
 {
-    const double *pd = B.posed + BA_POSED * (size_t)B.edge_pose[e];
     const double *R = pd + 7;
     if (B.formulation == 2) {
         for (int i = 0; i < 3; ++i) p[i] = R[3 * i] * pt[0] + R[3 * i + 1] * pt[1] + R[3 * i + 2] * pt[2];
@@ -114,107 +138,121 @@ __device__ __forceinline__ void ba_edge_residual(const BaDev &B, int e, const do
     p[0] += pd[4]; p[1] += pd[5]; p[2] += pd[6];
     if (B.formulation == 0) {
         const double proj0 = p[0] / p[2], proj1 = p[1] / p[2];             // camProject, G2oTypes.h:134-144
-        r[0] = B.obs[2 * (size_t)e] - (proj0 * B.fx + B.cx);
-        r[1] = B.obs[2 * (size_t)e + 1] - (proj1 * B.fy + B.cy);
-    } else {
-        r[0] = B.obs[2 * (size_t)e] - p[0] / p[2];
-        r[1] = B.obs[2 * (size_t)e + 1] - p[1] / p[2];
+        r[0] = ox - (proj0 * B.fx + B.cx);
+        r[1] = oy - (proj1 * B.fy + B.cy);
+    } else {                                                               // formulations 1 and 2 share the residual
+        r[0] = ox - p[0] / p[2];
+        r[1] = oy - p[1] / p[2];
     }
+}
+
+// RobustKernelHuber::robustify == ceres::HuberLoss + Corrector
+__device__ __forceinline__ void ba_robust(double e2, double hub, double *rho0, double *rho1)
+{
+    *rho0 = e2; *rho1 = 1.0;
+    const double dsqr = hub * hub;
+    if (hub > 0 && e2 > dsqr) { const double sqrte = sqrt(e2); *rho0 = 2 * sqrte * hub - dsqr; *rho1 = hub / sqrte; }
 }
 
 // computeActiveErrors for the edges of map point il: the point's share of the robustified chi2, nothing is written
 __device__ __forceinline__ double ba_point_chi2(const BaDev &B, int il)
 {
+    const int lane = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
     double sum = 0.0;
-    for (int c = B.pt_off[il]; c < B.pt_off[il + 1]; ++c) {
-        const int e = B.pt_edges[c];
-        if (!B.edge_enable[e]) continue;
-        double p[3], r[2];
-        ba_edge_residual(B, e, pt, p, r);
-        const double e2 = r[0] * r[0] + r[1] * r[1], hub = B.edge_huber[e], dsqr = hub * hub;
-        sum += (hub > 0 && e2 > dsqr) ? 2 * sqrt(e2) * hub - dsqr : e2;
+    for (int c = 0; c < rows; ++c) {
+        const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + lane];
+        if (ip < 0 || !B.enable_c[(size_t)row * 64 + lane]) continue;
+        double p[3], r[2], rho0, rho1;
+        ba_project(B, B.posed + BA_POSED * (size_t)ip, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
+        ba_robust(r[0] * r[0] + r[1] * r[1], B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
+        sum += rho0;
     }
     return sum;
 }
 
-// all edges of map point il, in edge order: residual, robust weight, Hll / bl (registers), the 6x3 Hpl block per edge,
-// (p_cam, rho', r) for the pose pass.  Returns the point's share of the robustified chi2.
+// all edges of map point il, in edge order: residual, robust weight, Hll / bl (registers), the 6x3 Hpl block per edge.
+// Returns the point's share of the robustified chi2.
 __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
 {
+    const int lane = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
     double chi_sum = 0.0;
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
     double hl[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, gl[3] = { 0, 0, 0 };
     const bool lfree = B.point_fixed[il] == 0;
-    for (int c = B.pt_off[il]; c < B.pt_off[il + 1]; ++c) {
-        const int e = B.pt_edges[c];
-        const int ip = B.edge_pose[e];
+    for (int c = 0; c < rows; ++c) {
+        const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + lane];
+        if (ip < 0) continue;                                                // this point has fewer edges than the chunk's longest
         const double *pd = B.posed + BA_POSED * (size_t)ip;
         const double *R = pd + 7;
-        double p[3];
-        if (B.formulation == 2) {
-            for (int i = 0; i < 3; ++i) p[i] = R[3 * i] * pt[0] + R[3 * i + 1] * pt[1] + R[3 * i + 2] * pt[2];
-        } else {
-            const double q[4] = { pd[0], pd[1], pd[2], pd[3] };
-            quat_rotate_d(q, pt, p);
-        }
-        p[0] += pd[4]; p[1] += pd[5]; p[2] += pd[6];
+        double p[3], r[2], Jp[6];
+        ba_project(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
         const double x = p[0], y = p[1], z = p[2];
-        double r[2], Jp[6];
         if (B.formulation == 0) {
-            const double proj0 = x / z, proj1 = y / z;                       // camProject, G2oTypes.h:134-144
-            r[0] = B.obs[2 * (size_t)e] - (proj0 * B.fx + B.cx);
-            r[1] = B.obs[2 * (size_t)e + 1] - (proj1 * B.fy + B.cy);
             const double tmp[6] = { B.fx, 0, -x / z * B.fx, 0, B.fy, -y / z * B.fy };
             double s[6];
             for (int i = 0; i < 6; ++i) s[i] = -1. / z * tmp[i];
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b)
                 Jp[3 * a + b] = s[3 * a] * R[b] + s[3 * a + 1] * R[3 + b] + s[3 * a + 2] * R[6 + b];
-        } else {                                                             // formulations 1 and 2 share residual and point Jacobian
-            r[0] = B.obs[2 * (size_t)e] - x / z;
-            r[1] = B.obs[2 * (size_t)e + 1] - y / z;
+        } else {                                                             // formulations 1 and 2 share the point Jacobian
             const double z_inv = 1. / z, z_inv_2 = z_inv * z_inv;
             const double tmp[6] = { z_inv, 0, -x * z_inv_2, 0, z_inv, -y * z_inv_2 };
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b)
                 Jp[3 * a + b] = -tmp[3 * a] * R[b] + -tmp[3 * a + 1] * R[3 + b] + -tmp[3 * a + 2] * R[6 + b];
         }
-        double *et = B.edge_tmp + 6 * (size_t)e;
-        double *hpl = B.Hpl + 18 * (size_t)e;
-        if (!B.edge_enable[e]) {                                             // SetEnable(false): residual and Jacobians are zero
-            B.err[2 * (size_t)e] = 0.0; B.err[2 * (size_t)e + 1] = 0.0; B.chi2_edge[e] = 0.0; B.rho0[e] = 0.0;
-            et[0] = x; et[1] = y; et[2] = z; et[3] = 0.0; et[4] = 0.0; et[5] = 0.0;
-            for (int i = 0; i < 18; ++i) hpl[i] = 0.0;
+        if (!B.enable_c[(size_t)row * 64 + lane]) {                          // SetEnable(false): residual and Jacobians are zero
+            BA_EC(B.err_c, row, 2, 0, lane) = 0.0; BA_EC(B.err_c, row, 2, 1, lane) = 0.0; B.chi2e_c[(size_t)row * 64 + lane] = 0.0;
+            for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0;
             continue;
         }
         if (z < 0) atomicAdd(B.n_behind, 1);
         const double e2 = r[0] * r[0] + r[1] * r[1];
-        double rho0 = e2, rho1 = 1.0;
-        const double hub = B.edge_huber[e], dsqr = hub * hub;
-        if (hub > 0 && e2 > dsqr) {                                          // RobustKernelHuber::robustify == ceres::HuberLoss + Corrector
-            const double sqrte = sqrt(e2);
-            rho0 = 2 * sqrte * hub - dsqr;
-            rho1 = hub / sqrte;
-        }
-        B.err[2 * (size_t)e] = r[0]; B.err[2 * (size_t)e + 1] = r[1];
-        B.chi2_edge[e] = e2; B.rho0[e] = rho0; chi_sum += rho0;
-        et[0] = x; et[1] = y; et[2] = z; et[3] = rho1; et[4] = r[0]; et[5] = r[1];
-        if (!lfree) { for (int i = 0; i < 18; ++i) hpl[i] = 0.0; continue; }   // constant point: no point block, no cross block
+        double rho0, rho1;
+        ba_robust(e2, B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
+        BA_EC(B.err_c, row, 2, 0, lane) = r[0]; BA_EC(B.err_c, row, 2, 1, lane) = r[1];
+        B.chi2e_c[(size_t)row * 64 + lane] = e2; chi_sum += rho0;
+        if (!lfree) { for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0; continue; }   // constant point: no point / cross block
         for (int a = 0; a < 3; ++a) {
             for (int b = 0; b < 3; ++b) hl[3 * a + b] += rho1 * (Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b]);
             gl[a] += -rho1 * (Jp[a] * r[0] + Jp[3 + a] * r[1]);
         }
-        if (B.fixed[ip]) { for (int i = 0; i < 18; ++i) hpl[i] = 0.0; }
+        if (B.fixed[ip]) { for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0; }
         else {
             double Jx[12];
             ba_pose_jac(B.formulation, x, y, z, B.fx, B.fy, pd, Jx);
             for (int a = 0; a < 6; ++a) for (int b = 0; b < 3; ++b)
-                hpl[3 * a + b] = rho1 * (Jx[a] * Jp[b] + Jx[6 + a] * Jp[3 + b]);
+                BA_EC(B.Hpl_c, row, 18, 3 * a + b, lane) = rho1 * (Jx[a] * Jp[b] + Jx[6 + a] * Jp[3 + b]);
         }
     }
-    for (int i = 0; i < 9; ++i) B.Hll[9 * (size_t)il + i] = hl[i];
-    for (int i = 0; i < 3; ++i) B.bl[3 * (size_t)il + i] = gl[i];
+    for (int i = 0; i < 9; ++i) BA_PC(B.Hll_c, il, 9, i) = hl[i];
+    for (int i = 0; i < 3; ++i) BA_PC(B.bl_c, il, 3, i) = gl[i];
     return chi_sum;
 }
 
+// contribution of map point il to the blocks of free pose a (Hpp upper triangle 21 + bp 6), added to acc; the edge's camera
+// point, residual and weight are recomputed exactly as in ba_point_edges (cheaper than storing 48 bytes per edge and reading
+// them back through a pose-major gather).
+__device__ __forceinline__ void ba_pose_contrib(const BaDev &B, int il, int a, double acc[27])
+{
+    const int c = B.ppc[(size_t)il * B.Kf + a];
+    if (c < 0) return;
+    const int lane = il & 63, row = B.slot_off[il >> 6] + c;
+    if (!B.enable_c[(size_t)row * 64 + lane]) return;
+    const int k = B.free_pose[a];
+    const double *pd = B.posed + BA_POSED * (size_t)k;
+    const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
+    double p[3], r[2], rho0, rho1, Jx[12];
+    ba_project(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
+    ba_robust(r[0] * r[0] + r[1] * r[1], B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
+    ba_pose_jac(B.formulation, p[0], p[1], p[2], B.fx, B.fy, pd, Jx);
+    int q = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+#pragma unroll
+        for (int v = u; v < 6; ++v) acc[q++] += rho1 * (Jx[u] * Jx[v] + Jx[6 + u] * Jx[6 + v]);
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc[21 + u] += -rho1 * (Jx[u] * r[0] + Jx[6 + u] * r[1]);
+}
 
 #endif

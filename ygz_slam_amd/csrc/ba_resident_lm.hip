@@ -23,12 +23,7 @@
 #define LM_MAXKF   14
 #define LM_MAXN    (6 * LM_MAXKF)
 
-__device__ __forceinline__ double lm_wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+#define lm_wave_sum ygz_wave_sum_d
 // block-wide sum in a fixed order (xor tree inside the wavefronts, then the wavefronts left to right); result on every lane
 __device__ __forceinline__ double lm_block_sum(double v, double *red /*[LM_WAVES]*/)
 {
@@ -88,27 +83,12 @@ __device__ double lm_linearize(const BaDev &B, double (*red27)[28], double *red)
     double chi = 0.0;
     for (int il = tid; il < B.P; il += LM_THREADS) chi += ba_point_edges(B, il);
     chi = lm_block_sum(chi, red);                        // (barriers inside: the per-edge records are visible below)
-    for (int a = 0; a < B.Kf; ++a) {                     // pose blocks, as k_ba_poses
+    for (int a = 0; a < B.Kf; ++a) {                     // pose blocks: every point that sees free pose a contributes
         const int k = B.free_pose[a];
-        const double *pd = B.posed + BA_POSED * (size_t)k;
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-        for (int c = B.pose_off[k] + tid; c < B.pose_off[k + 1]; c += LM_THREADS) {
-            const int e = B.pose_edges[c];
-            const double *et = B.edge_tmp + 6 * (size_t)e;
-            const double rho1 = et[3], r0 = et[4], r1 = et[5];
-            double Jx[12];
-            ba_pose_jac(B.formulation, et[0], et[1], et[2], B.fx, B.fy, pd, Jx);
-            int q = 0;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-#pragma unroll
-                for (int v = u; v < 6; ++v) acc[q++] += rho1 * (Jx[u] * Jx[v] + Jx[6 + u] * Jx[6 + v]);
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) acc[21 + u] += -rho1 * (Jx[u] * r0 + Jx[6 + u] * r1);
-        }
+        for (int il = tid; il < B.P; il += LM_THREADS) ba_pose_contrib(B, il, a, acc);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 27; ++i) { const double v = lm_wave_sum(acc[i]); if (lane == 0) red27[wv][i] = v; }
@@ -158,7 +138,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm(const BaDev *__restrict__ 
             chi_initial = currentChi;
             double mx = 0.0;                                        // computeLambdaInit: tau * max |diag| over the active vertices
             for (int i = tid; i < 6 * Kf; i += LM_THREADS) mx = fmax(mx, fabs(B.Hpp[36 * (size_t)B.free_pose[i / 6] + 7 * (i % 6)]));
-            for (int i = tid; i < 3 * P; i += LM_THREADS) mx = fmax(mx, fabs(B.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+            for (int i = tid; i < 3 * P; i += LM_THREADS) mx = fmax(mx, fabs(BA_PC(B.Hll_c, i / 3, 9, 4 * (i % 3))));
             lambda = 1e-5 * lm_block_max(mx, red); ni = 2.0;
         }
         double rho = 0.0; int qmax = 0;
@@ -173,17 +153,19 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm(const BaDev *__restrict__ 
                 double *Di = B.Dinv + 9 * (size_t)il;
                 if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; continue; }
                 double D[9];
-                for (int i = 0; i < 9; ++i) D[i] = B.Hll[9 * (size_t)il + i];
+                for (int i = 0; i < 9; ++i) D[i] = BA_PC(B.Hll_c, il, 9, i);
                 D[0] += lambda; D[4] += lambda; D[8] += lambda;
                 double Dv[9];
                 if (!lm_inv3(D, Dv)) { s_fail = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
                 for (int i = 0; i < 9; ++i) Di[i] = Dv[i];
-                for (int c = B.pt_off[il]; c < B.pt_off[il + 1]; ++c) {
-                    const int e = B.pt_edges[c];
-                    const double *W = B.Hpl + 18 * (size_t)e;
-                    double *Y = B.Y + 18 * (size_t)e;
+                const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                for (int c = 0; c < rows; ++c) {
+                    const int row = row0 + c;
+                    if (B.pose_c[(size_t)row * 64 + ln] < 0) continue;
+                    double W[18];
+                    for (int i = 0; i < 18; ++i) W[i] = BA_EC(B.Hpl_c, row, 18, i, ln);
                     for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc)
-                        Y[3 * r + cc] = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
+                        BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
                 }
             }
             // ---- 2. S = blockdiag(Hpp + lambda I), bs = bp
@@ -207,18 +189,19 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm(const BaDev *__restrict__ 
 #pragma unroll
                 for (int i = 0; i < 6; ++i) accb[i] = 0.0;
                 for (int l = lane; l < P; l += 64) {
-                    const int ea = B.pt_pose_edge[(size_t)l * Kf + a], eb = B.pt_pose_edge[(size_t)l * Kf + b];
-                    if (ea < 0 || eb < 0) continue;
+                    const int ca = B.ppc[(size_t)l * Kf + a], cb = B.ppc[(size_t)l * Kf + b];
+                    if (ca < 0 || cb < 0) continue;
+                    const int row0 = B.slot_off[l >> 6], ln = l & 63;
                     double Ya[18], Wb[18];
 #pragma unroll
-                    for (int i = 0; i < 18; ++i) { Ya[i] = B.Y[18 * (size_t)ea + i]; Wb[i] = B.Hpl[18 * (size_t)eb + i]; }
+                    for (int i = 0; i < 18; ++i) { Ya[i] = BA_EC(B.Y_c, row0 + ca, 18, i, ln); Wb[i] = BA_EC(B.Hpl_c, row0 + cb, 18, i, ln); }
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
 #pragma unroll
                         for (int c = 0; c < 6; ++c) acc[6 * r + c] += Ya[3 * r] * Wb[3 * c] + Ya[3 * r + 1] * Wb[3 * c + 1] + Ya[3 * r + 2] * Wb[3 * c + 2];
                     }
                     if (a == b) {
-                        const double g0 = B.bl[3 * (size_t)l], g1 = B.bl[3 * (size_t)l + 1], g2 = B.bl[3 * (size_t)l + 2];
+                        const double g0 = BA_PC(B.bl_c, l, 3, 0), g1 = BA_PC(B.bl_c, l, 3, 1), g2 = BA_PC(B.bl_c, l, 3, 2);
 #pragma unroll
                         for (int r = 0; r < 6; ++r) accb[r] += Ya[3 * r] * g0 + Ya[3 * r + 1] * g1 + Ya[3 * r + 2] * g2;
                     }
@@ -276,19 +259,21 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm(const BaDev *__restrict__ 
                 // ---- 4. x_l, then _optimizer->update(x)
                 for (int il = tid; il < P; il += LM_THREADS) {
                     if (B.point_fixed[il]) { B.xl[3 * (size_t)il] = B.xl[3 * (size_t)il + 1] = B.xl[3 * (size_t)il + 2] = 0.0; continue; }
-                    double r3[3] = { B.bl[3 * (size_t)il], B.bl[3 * (size_t)il + 1], B.bl[3 * (size_t)il + 2] };
-                    for (int c = B.pt_off[il]; c < B.pt_off[il + 1]; ++c) {
-                        const int e = B.pt_edges[c], a = B.free_idx[B.edge_pose[e]];
+                    double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
+                    const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                    for (int c = 0; c < rows; ++c) {
+                        const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + ln];
+                        if (ip < 0) continue;
+                        const int a = B.free_idx[ip];
                         if (a < 0) continue;
-                        const double *W = B.Hpl + 18 * (size_t)e;
-                        for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= W[3 * r + cc] * xp[6 * a + r];
+                        for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= BA_EC(B.Hpl_c, row, 18, 3 * r + cc, ln) * xp[6 * a + r];
                     }
                     const double *Di = B.Dinv + 9 * (size_t)il;
                     double x3[3];
                     for (int cc = 0; cc < 3; ++cc) x3[cc] = Di[3 * cc] * r3[0] + Di[3 * cc + 1] * r3[1] + Di[3 * cc + 2] * r3[2];
                     for (int cc = 0; cc < 3; ++cc) {
                         B.xl[3 * (size_t)il + cc] = x3[cc];
-                        scale += x3[cc] * (lambda * x3[cc] + B.bl[3 * (size_t)il + cc]);          // computeScale
+                        scale += x3[cc] * (lambda * x3[cc] + BA_PC(B.bl_c, il, 3, cc));             // computeScale
                         B.points_w[3 * (size_t)il + cc] += x3[cc];
                     }
                 }

@@ -90,9 +90,7 @@ __device__ bool po_eval(const PoArgs &A, int beg, int n, const double *pose /*LD
     }
     const int first = full ? 0 : 27;
     for (int i = first; i < PO_NV; ++i) {
-        double v = acc[i];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        const double v = ygz_wave_sum_d(acc[i]);
         if (lane == 0) red[wv][i] = v;
     }
     const int any_behind = __syncthreads_or(behind);

@@ -33,12 +33,7 @@ struct SaArgs {
     double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
 };
 
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+#define wave_sum_d ygz_wave_sum_d
 
 // ---- the reference's chi2: a FLOAT running sum c = fl(c + res*res) over all features / pixels in order
 // (SparseImageAlign.cpp:213), whose value decides when the Gauss-Newton loop stops (NLSSolver_impl.hpp:53) -- so it has to

@@ -224,6 +224,22 @@ __device__ __forceinline__ float ygz_wave_scan_f(float v)
 #undef YGZ_SCAN_STEP_
     return v;
 }
+// FP64 sum over the 64 lanes, same fixed order as ygz_wave_sum_f: two DPP moves (the halves) + one v_add_f64 per step instead
+// of two LDS-crossbar permutes; result is uniform.
+__device__ __forceinline__ double ygz_wave_sum_d(double v)
+{
+#define YGZ_DSTEP_(ctrl) { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), (ctrl), 0xF, 0xF, false);            \
+                           const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), (ctrl), 0xF, 0xF, false);            \
+                           v += __hiloint2double(hi_, lo_); }
+    YGZ_DSTEP_(0xB1) YGZ_DSTEP_(0x4E) YGZ_DSTEP_(0x141) YGZ_DSTEP_(0x140)
+#undef YGZ_DSTEP_
+    const int l = __double2loint(v), h = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(h, 0), __builtin_amdgcn_readlane(l, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(h, 16), __builtin_amdgcn_readlane(l, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(h, 32), __builtin_amdgcn_readlane(l, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(h, 48), __builtin_amdgcn_readlane(l, 48));
+    return ((r0 + r1) + r2) + r3;
+}
 // correctly rounded float sqrt: the native v_sqrt_f32 path is 1 ulp; sqrt in double then one rounding is
 // exact for float inputs (53 >= 2*24+2 bits)
 __device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((double)x); }
