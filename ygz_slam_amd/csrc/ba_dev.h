@@ -180,13 +180,21 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
     double hl[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, gl[3] = { 0, 0, 0 };
     const bool lfree = B.point_fixed[il] == 0;
+    // the inputs of row c + 1 are in flight while row c is computed (the loop is a chain of dependent loads otherwise)
+    int n_ip = -1, n_en = 0; double n_ox = 0, n_oy = 0, n_hub = 0;
+#define BA_FETCH_(row_)                                                                                          \
+    { n_ip = B.pose_c[(size_t)(row_) * 64 + lane]; n_en = B.enable_c[(size_t)(row_) * 64 + lane];                \
+      n_ox = BA_EC(B.obs_c, row_, 2, 0, lane); n_oy = BA_EC(B.obs_c, row_, 2, 1, lane); n_hub = B.huber_c[(size_t)(row_) * 64 + lane]; }
+    if (rows > 0) BA_FETCH_(row0)
     for (int c = 0; c < rows; ++c) {
-        const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + lane];
+        const int row = row0 + c, ip = n_ip, en = n_en;
+        const double ox = n_ox, oy = n_oy, hub = n_hub;
+        if (c + 1 < rows) BA_FETCH_(row + 1)
         if (ip < 0) continue;                                                // this point has fewer edges than the chunk's longest
         const double *pd = B.posed + BA_POSED * (size_t)ip;
         const double *R = pd + 7;
         double p[3], r[2], Jp[6];
-        ba_project(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
+        ba_project(B, pd, pt, ox, oy, p, r);
         const double x = p[0], y = p[1], z = p[2];
         if (B.formulation == 0) {
             const double tmp[6] = { B.fx, 0, -x / z * B.fx, 0, B.fy, -y / z * B.fy };
@@ -200,7 +208,7 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b)
                 Jp[3 * a + b] = -tmp[3 * a] * R[b] + -tmp[3 * a + 1] * R[3 + b] + -tmp[3 * a + 2] * R[6 + b];
         }
-        if (!B.enable_c[(size_t)row * 64 + lane]) {                          // SetEnable(false): residual and Jacobians are zero
+        if (!en) {                                                           // SetEnable(false): residual and Jacobians are zero
             BA_EC(B.err_c, row, 2, 0, lane) = 0.0; BA_EC(B.err_c, row, 2, 1, lane) = 0.0; B.chi2e_c[(size_t)row * 64 + lane] = 0.0;
             for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0;
             continue;
@@ -208,7 +216,7 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
         if (z < 0) atomicAdd(B.n_behind, 1);
         const double e2 = r[0] * r[0] + r[1] * r[1];
         double rho0, rho1;
-        ba_robust(e2, B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
+        ba_robust(e2, hub, &rho0, &rho1);
         BA_EC(B.err_c, row, 2, 0, lane) = r[0]; BA_EC(B.err_c, row, 2, 1, lane) = r[1];
         B.chi2e_c[(size_t)row * 64 + lane] = e2; chi_sum += rho0;
         if (!lfree) { for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0; continue; }   // constant point: no point / cross block
@@ -224,6 +232,7 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
                 BA_EC(B.Hpl_c, row, 18, 3 * a + b, lane) = rho1 * (Jx[a] * Jp[b] + Jx[6 + a] * Jp[3 + b]);
         }
     }
+#undef BA_FETCH_
     for (int i = 0; i < 9; ++i) BA_PC(B.Hll_c, il, 9, i) = hl[i];
     for (int i = 0; i < 3; ++i) BA_PC(B.bl_c, il, 3, i) = gl[i];
     return chi_sum;
