@@ -11,9 +11,9 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -- $CMD > $OUT/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/bench_write.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $CMD > $OUT/bench_stats.log 2>&1
+timeout 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/bench_fetch.log 2>&1
+timeout 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/bench_write.log 2>&1
 DB=$(find $OUT/stats -name '*.db' | head -1)
 [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $OUT/kernel_stats.md > /dev/null
 python $R/tools/pmc_summary.py $OUT/fetch > $OUT/pmc_fetch.md
