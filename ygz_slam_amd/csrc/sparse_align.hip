@@ -91,9 +91,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
     float *dxy = (float *)(fjc + 12 * (size_t)A.cells);                 // [cells][32] dx[16], dy[16]
     uint8_t *prev_used = (uint8_t *)(dxy + 32 * (size_t)A.cells);       // [cells] the feature is part of the running H
     float *patch_cache = (float *)((double *)wk + 96 * (size_t)A.cells);   // [cells][16]
-    float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [cells][16]
+    float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [4][cells] float4: the squared residuals (chain terms)
     float *ssq = r2 + 16 * (size_t)A.cells;                             // [cells] sum of the feature's 16 squares (binade prediction only)
-    uint8_t *visible = (uint8_t *)(ssq + A.cells);                      // [cells]
+    float *pre = ssq + A.cells;                                         // [cells] predicted chain value at the start of the feature
+    int4 *fmap = reinterpret_cast<int4 *>(pre + A.cells);               // [cells] 16-term parity map of the feature: t0, t1, E, bad
+    uint8_t *visible = (uint8_t *)(fmap + A.cells);                     // [cells]
     uint8_t *used = visible + A.cells;                                  // [cells] feature contributes this iteration
     Se3 T_ref;
     for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
@@ -256,13 +258,13 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
                         }
                     }
                 }
-                float sq = 0.f;
+                float xs[16], sq = 0.f;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) sq += res[k] * res[k];
+                for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
                 ssq[f] = sq;
-                float4 *dst = reinterpret_cast<float4 *>(r2 + 16 * (size_t)f);        // r2 buffer holds the residuals
-                dst[0] = make_float4(res[0], res[1], res[2], res[3]);     dst[1] = make_float4(res[4], res[5], res[6], res[7]);
-                dst[2] = make_float4(res[8], res[9], res[10], res[11]);   dst[3] = make_float4(res[12], res[13], res[14], res[15]);
+                float4 *dst = reinterpret_cast<float4 *>(r2);          // the chain terms, quarter-major: lanes write 1 KB contiguous per store
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dst[(size_t)k * A.cells + f] = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
                 used[f] = use ? 1 : 0;
                 const bool pu = prev_used[f] != 0;
                 if (use != pu) {
@@ -294,6 +296,32 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
             }
             __syncthreads();
             SA_PHASE(1);      // residual pass
+            // ---- chain, step 1 (wave 0): predicted value of the chi2 chain at the start of every feature = exclusive prefix of the
+            // approximate per-feature sums (only the binade is taken from it; a wrong guess costs a term-by-term fallback)
+            if (wv == 0) {
+                float base = 0.f;
+                for (int j = 0; j < ((n + 63) >> 6); ++j) {
+                    const int f = 64 * j + lane;
+                    const float v = f < n ? ssq[f] : 0.f;
+                    const float incl = ygz_wave_scan_f(v);
+                    if (f < n) pre[f] = base + (incl - v);
+                    base += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(incl), 63));
+                }
+            }
+            __syncthreads();
+            // ---- chain, step 2 (all lanes): the 16-term map of every feature for its predicted binade, integer ALU only
+            for (int f = tid; f < n; f += SA_THREADS) {
+                const float4 *src = reinterpret_cast<const float4 *>(r2) + f;
+                const float4 a0 = src[0], a1 = src[A.cells], a2 = src[2 * (size_t)A.cells], a3 = src[3 * (size_t)A.cells];
+                const float x[16] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
+                const int E = (int)(__float_as_uint(pre[f]) >> 23);
+                int t0 = 0, t1 = 0, bad = !(E > 0 && E < 255);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
+                fmap[f] = make_int4(t0, t1, E, bad);
+            }
+            __syncthreads();
+            SA_PHASE(13);     // prefix + maps
             if (wv == 0) {
                 // ---- wave 0: chi2 = the reference's FLOAT sum of res*res in feature/pixel order (a skipped feature
                 // contributes 0.0f + ... exactly), evaluated through the group maps described at sa_chain_term.
@@ -302,32 +330,29 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
                 uint32_t cb = 0u;                                            // bits of c, wave-uniform
                 const int J = (n + 63) >> 6;
                 float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: pass j + 1 is in flight
-                float nsq = 0.f;
+                int4 nm = make_int4(0, 0, 0, 0);
                 if (lane < n) {
-                    const float4 *src = reinterpret_cast<const float4 *>(r2 + 16 * (size_t)lane);
-                    n0 = src[0]; n1 = src[1]; n2 = src[2]; n3 = src[3]; nsq = ssq[lane];
+                    const float4 *src = reinterpret_cast<const float4 *>(r2) + lane;
+                    n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells]; nm = fmap[lane];
                 }
                 for (int j = 0; j < J; ++j) {
                     SA_PHASE(12);
                     float x[16] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w };
-                    const float sq = nsq;
                     {
                         const int fn = 64 * (j + 1) + lane;
-                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nsq = 0.f;
+                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0;
                         if (fn < n) {
-                            const float4 *src = reinterpret_cast<const float4 *>(r2 + 16 * (size_t)fn);
-                            n0 = src[0]; n1 = src[1]; n2 = src[2]; n3 = src[3]; nsq = ssq[fn];
+                            const float4 *src = reinterpret_cast<const float4 *>(r2) + fn;
+                            n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells];
                         }
                     }
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) x[k] = __fmul_rn(__fmul_rn(x[k], x[k]), 1.0f);      // res*res*weight (:213)
-                    // predicted c at the start of the lane's feature: exact c so far + exclusive scan of the approximate feature sums
-                    const float incl = ygz_wave_scan_f(sq);
-                    int E = (int)(__float_as_uint(__uint_as_float(cb) + (incl - sq)) >> 23);
-                    SA_PHASE(8);
-                    int t0 = 0, t1 = 0, bad = !(E > 0 && E < 255);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
+                    int t0 = nm.x, t1 = nm.y, E = nm.z, bad = nm.w;      // the feature's map (lanes past the end: the empty map of any binade)
+                    {
+                        const int fn = 64 * (j + 1) + lane;
+                        nm = make_int4(0, 0, 0, 0);
+                        if (fn < n) nm = fmap[fn];
+                    }
+                    if (64 * j + lane >= n) E = __builtin_amdgcn_readlane(E, (n - 1) & 63);      // only in the last pass: the binade of the last feature
                     // compose along the lanes: (A then B)(p) = A(p) + B((p + A(p)) & 1); a group is usable only inside one binade
 #define SA_COMPOSE(dist, sel)                                                                                         \
                     { const int a0_ = YGZ_DPP_SHR(t0, dist), a1_ = YGZ_DPP_SHR(t1, dist), ab_ = YGZ_DPP_SHR(bad, dist), aE_ = YGZ_DPP_SHR(E, dist); \
@@ -442,7 +467,7 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
         double h[16];
         YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[sa-debug] pair0 shader cycles: overhead %.0f residual %.0f wave0-chain %.0f (unused %.0f) chain phase %.0f solve %.0f; GN iterations %.0f, chain groups added term by term %.0f; chain: load+scan %.0f terms %.0f compose %.0f walk %.0f other %.0f\n", h[0], h[1], h[2], h[6], h[3], h[4], h[5], h[7], h[8], h[9], h[10], h[11], h[12]);
+        fprintf(stderr, "[sa-debug] pair0 shader cycles: overhead %.0f residual %.0f wave0-chain %.0f (unused %.0f) chain phase %.0f solve %.0f; GN iterations %.0f, chain groups added term by term %.0f; chain: prefix+maps %.0f, per pass: unpack %.0f compose %.0f walk %.0f loop %.0f\n", h[0], h[1], h[2], h[6], h[3], h[4], h[5], h[7], h[13], h[9], h[10], h[11], h[12]);
     }
     return YGZ_OK;
 }
