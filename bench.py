@@ -226,7 +226,7 @@ def main():
                                       "FindDirectProjection + SparseImgAlign + local-BA 10x2000 linearise, per frame",
                           "frames_per_gpu_per_step": a.batch, "keypoints_per_frame": n_kp, "parallelism": "frames sharded x%d" % world},
                "stage_ms_per_batch": stages, "roofline": roofline}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe)
         print(json.dumps(res))
     if dist is not None:
