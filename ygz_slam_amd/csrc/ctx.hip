@@ -144,6 +144,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
         if (ctx->lvl[L]) (void)hipFree(ctx->lvl[L]);
         if (ctx->deriv[L]) (void)hipFree(ctx->deriv[L]);
         if (ctx->klt_pad[L]) (void)hipFree(ctx->klt_pad[L]);
+        if (L == 0 && ctx->klt_slots) (void)hipFree(ctx->klt_slots);
         if (ctx->dbg_score[L]) (void)hipFree(ctx->dbg_score[L]);
         if (ctx->dbg_nms[L]) (void)hipFree(ctx->dbg_nms[L]);
     }

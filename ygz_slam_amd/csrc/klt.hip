@@ -35,45 +35,62 @@ __device__ __forceinline__ int refl101(int i, int n)
     return i;
 }
 
-// padded copy: out[(y+B)*(w+2B) + x+B] = in[refl101(y)][refl101(x)], 4 output pixels per lane
+#define KLT_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
+typedef uint32_t __attribute__((aligned(1))) klt_u32u;      // 4 adjacent bytes at any address: one (unaligned) global_load_dword
+
+// padded copy: out[(y+B)*pw + x+B] = in[refl101(y)][refl101(x)], 4 output pixels per lane, once per distinct slot
 __global__ __launch_bounds__(256) void k_klt_pad(const uint8_t *__restrict__ img_base, uint8_t *__restrict__ pad_base,
-                                                 const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
-                                                 int w, int h, int n_pairs)
+                                                 const int32_t *__restrict__ slots, int w, int h, int n_slots)
 {
     int bx_, by_, z_;
-    if (!ygz_xcd_remap3(2 * n_pairs, bx_, by_, z_)) return;
+    if (!ygz_xcd_remap3(n_slots, bx_, by_, z_)) return;
     const int pw = KLT_PW(w), ph = h + 2 * KLT_B;
     const int x4 = (bx_ * 64 + (threadIdx.x & 63)) * 4, y = by_ * 4 + (threadIdx.x >> 6);
     if (x4 >= pw || y >= ph) return;
-    const size_t slot = (size_t)((z_ & 1) ? pair_q[z_ >> 1] : pair_t[z_ >> 1]);
+    const size_t slot = (size_t)slots[z_];
     const uint8_t *row = img_base + slot * (size_t)w * h + (size_t)refl101(y - KLT_B, h) * w;
+    const int sx = x4 - KLT_B;
     uint32_t v = 0;
+    if (sx >= 0 && sx + 3 < w) v = *reinterpret_cast<const klt_u32u *>(row + sx);
+    else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v |= (uint32_t)row[refl101(x4 + k - KLT_B, w)] << (8 * k);
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)row[refl101(sx + k, w)] << (8 * k);
+    }
     *reinterpret_cast<uint32_t *>(pad_base + slot * (size_t)pw * ph + (size_t)y * pw + x4) = v;
 }
 
-// calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1); output zero-framed
-__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ img_base, int16_t *__restrict__ deriv_base,
-                                                const int32_t *__restrict__ pair_t, int w, int h, int n_pairs)
+// calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1); output zero-framed.
+// Reads the framed copy (its BORDER_REFLECT_101 frame is exactly the border rule of the derivative), 4 pixels per lane:
+// three rows of 6 bytes as two unaligned dword loads each, one 16-byte store.
+__global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ pad_base, int16_t *__restrict__ deriv_base,
+                                                const int32_t *__restrict__ slots, int w, int h, int n_slots)
 {
-    int bx_, by_, pr_;
-    if (!ygz_xcd_remap3(n_pairs, bx_, by_, pr_)) return;
-    const int x = bx_ * 64 + (threadIdx.x & 63), y = by_ * 4 + (threadIdx.x >> 6);
+    int bx_, by_, z_;
+    if (!ygz_xcd_remap3(n_slots, bx_, by_, z_)) return;
+    const int x = (bx_ * 64 + (threadIdx.x & 63)) * 4, y = by_ * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const size_t slot = (size_t)pair_t[pr_];                   // reference slot of this pair
+    const size_t slot = (size_t)slots[z_];
     const int pw = KLT_PW(w), ph = h + 2 * KLT_B;
-    const uint8_t *img = img_base + slot * (size_t)w * h;
-    uint32_t *deriv = reinterpret_cast<uint32_t *>(deriv_base) + slot * (size_t)pw * ph;
-    const int y0 = y > 0 ? y - 1 : (h > 1 ? 1 : 0), y2 = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-    const int xm = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xp = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
-    const uint8_t *r0 = img + (size_t)y0 * w, *r1 = img + (size_t)y * w, *r2 = img + (size_t)y2 * w;
-    // trow0 = (s0+s2)*3 + s1*10 ; trow1 = s2 - s0   (as int16 in the reference; values fit)
-    const int t0m = (r0[xm] + r2[xm]) * 3 + r1[xm] * 10, t0p = (r0[xp] + r2[xp]) * 3 + r1[xp] * 10;
-    const int t1m = r2[xm] - r0[xm], t1c = r2[x] - r0[x], t1p = r2[xp] - r0[xp];
-    const int dx = (int16_t)(t0p - t0m);
-    const int dy = (int16_t)((t1p + t1m) * 3 + t1c * 10);
-    deriv[(size_t)(y + KLT_B) * pw + (x + KLT_B)] = ((uint32_t)(uint16_t)dx) | ((uint32_t)(uint16_t)dy << 16);
+    const uint8_t *p = pad_base + slot * (size_t)pw * ph + (size_t)(y + KLT_B - 1) * pw + (x + KLT_B - 1);
+    uint32_t *deriv = reinterpret_cast<uint32_t *>(deriv_base) + slot * (size_t)pw * ph + (size_t)(y + KLT_B) * pw + (x + KLT_B);
+    uint32_t lo[3], hi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { lo[r] = *reinterpret_cast<const klt_u32u *>(p + (size_t)r * pw); hi[r] = *reinterpret_cast<const klt_u32u *>(p + (size_t)r * pw + 4); }
+    int t0[6], t1[6];            // trow0 = (s0+s2)*3 + s1*10 ; trow1 = s2 - s0 for columns x-1 .. x+4
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int s0 = KLT_BYTE(lo[0], hi[0], c), s1 = KLT_BYTE(lo[1], hi[1], c), s2 = KLT_BYTE(lo[2], hi[2], c);
+        t0[c] = (s0 + s2) * 3 + s1 * 10; t1[c] = s2 - s0;
+    }
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int dx = (int16_t)(t0[k + 2] - t0[k]);
+        const int dy = (int16_t)((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10);
+        out[k] = ((uint32_t)(uint16_t)dx) | ((uint32_t)(uint16_t)dy << 16);
+    }
+    if (x + 3 < w) *reinterpret_cast<uint4 *>(deriv) = make_uint4(out[0], out[1], out[2], out[3]);
+    else { for (int k = 0; k < 4; ++k) if (x + k < w) deriv[k] = out[k]; }       // the zero frame stays zero
 }
 
 struct KltArgs {
@@ -106,7 +123,6 @@ __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32
     lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
 }
-#define KLT_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
 // all factors fit 24 bits (pixels 8 bit, derivatives 14 bit, weights 15 bit, differences 14 bit): full-rate v_mad_*24
 // instead of the quarter-rate 32-bit multiply
 #define KLT_MAD(a, b, c) ((int)__mul24((int)(a), (int)(b)) + (int)(c))
@@ -304,10 +320,10 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
         }
         if (!ctx->klt_pad[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_pad[L], (size_t)ctx->prm.max_frames * psz + 64));
         A.pad[L] = ctx->klt_pad[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = w; A.h[L] = h;
-        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(pw / 4, 64), ygz_div_up(ph, 4), ygz_round_up8(2 * n_pairs)), dim3(256),
-                   ctx->lvl[L], ctx->klt_pad[L], ctx->pair_q, ctx->pair_t, w, h, n_pairs);
-        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(w, 64), ygz_div_up(h, 4), ygz_round_up8(n_pairs)), dim3(256),
-                   ctx->lvl[L], ctx->deriv[L], ctx->pair_t, w, h, n_pairs);
+        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(pw / 4, 64), ygz_div_up(ph, 4), ygz_round_up8(ctx->n_klt_slots)), dim3(256),
+                   ctx->lvl[L], ctx->klt_pad[L], ctx->klt_slots, w, h, ctx->n_klt_slots);
+        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(ygz_div_up(w, 4), 64), ygz_div_up(h, 4), ygz_round_up8(ctx->n_klt_refs)), dim3(256),
+                   ctx->klt_pad[L], ctx->deriv[L], ctx->klt_slots + ctx->n_klt_slots, w, h, ctx->n_klt_refs);
     }
     A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);

@@ -43,6 +43,19 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, cur_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, ref_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_T, T.data(), T.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    {   // distinct slots of the table (a frame is usually the current frame of one pair and the reference of the next): the
+        // tracker prepares its working images once per slot
+        const int F = ctx->prm.max_frames;
+        std::vector<uint8_t> any(F, 0), isref(F, 0);
+        for (int i = 0; i < n_pairs; ++i) { any[cur_slot[i]] = 1; any[ref_slot[i]] = 1; isref[ref_slot[i]] = 1; }
+        std::vector<int32_t> lst;
+        for (int s = 0; s < F; ++s) if (any[s]) lst.push_back(s);
+        ctx->n_klt_slots = (int)lst.size();
+        for (int s = 0; s < F; ++s) if (isref[s]) lst.push_back(s);
+        ctx->n_klt_refs = (int)lst.size() - ctx->n_klt_slots;
+        if (!ctx->klt_slots) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_slots, (size_t)F * 8));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_slots, lst.data(), lst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_pairs = n_pairs;
     return YGZ_OK;

@@ -29,6 +29,7 @@ struct ygz_hip_ctx {
     // Scharr derivative levels for KLT (int16 x2 per pixel), allocated on first KLT call
     int16_t *deriv[YGZ_MAX_LEVELS] = {nullptr};
     uint8_t *klt_pad[YGZ_MAX_LEVELS] = {nullptr};       // reflect-101 framed copies of the levels (KLT working images)
+    int32_t *klt_slots = nullptr; int n_klt_slots = 0, n_klt_refs = 0;   // distinct slots of the pair table: [0, n_klt_slots) all, then the reference slots
 
     // extractor state per slot
     uint32_t *cell_first = nullptr;         // [F][cells]  min over candidates of (visit<<1 | isnan)
