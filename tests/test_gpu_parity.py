@@ -742,3 +742,35 @@ def test_depth_from_triangulation_batch(hip_lib, oracle):
     assert np.allclose(d1[m], p1[m, 2], rtol=1e-9) and np.allclose(d2[m], p2[m, 2], rtol=1e-9)
     assert ctx.depth_from_triangulation(T21, np.zeros((0, 3)), np.zeros((0, 3)))[2].size == 0
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------- degenerate inputs through the ABI
+def test_degenerate_inputs(hip_lib, oracle):
+    """empty / minimal inputs of every batched entry point: status codes instead of crashes, results equal to the oracle's"""
+    ctx = make_ctx(hip_lib, max_frames=2)
+    black = np.zeros((480, 640), np.uint8)
+    for s in range(2):
+        ctx.upload_gray(s, black)
+    ctx.build_pyramid(0, 2); ctx.detect(0, 2)
+    assert len(ctx.get_keypoints(0)["level"]) == 0 and len(oracle.detect(oracle.pyramid(black, 3))) == 0      # no corner in a flat image
+    idx, dist = ctx.hamming_match(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8))
+    assert len(idx) == 0
+    # tracking stages on a pair without keypoints
+    I7 = np.array([[0, 0, 0, 1, 0, 0, 0.0]])
+    ctx.track_begin([1], [0], I7, I7, predict=False)
+    ctx.track_klt(); ctx.track_direct(); ctx.track_sparse_align()
+    out, st, err = ctx.track_get_klt(0)
+    assert len(st) == 0
+    nm, T, iters = ctx.track_get_pose(0)
+    assert nm == 0 and np.allclose(T, I7[0])
+    # BA window without a single edge, one pose, one point
+    g = ctx.ba_linearize(np.zeros((1, 6)), np.zeros(1, np.uint8), np.array([[0.0, 0.0, 3.0]]), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
+    assert g["chi2"] == 0.0 and not g["Hpp"].any() and not g["Hll"].any()
+    po, pt, stt = ctx.ba_optimize(np.zeros((1, 6)), np.zeros(1, np.uint8), np.array([[0.0, 0.0, 3.0]]), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2)))
+    assert np.array_equal(pt, [[0.0, 0.0, 3.0]]) and stt.chi2_final == 0.0
+    # pose-only BA with no frame / a frame without features; BoW without a vocabulary is a state error, not a crash
+    p, bad, dep, inl, rounds = ctx.optimize_pose_only(np.array([0, 0], np.int32), np.zeros((0, 2)), np.zeros((0, 3)), np.zeros((1, 6)))
+    assert inl[0] == 0 and rounds[0] == 1
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.bow_transform(np.zeros((4, 32), np.uint8))
+    ctx.close()
