@@ -69,6 +69,9 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
     __shared__ float s_chi2;
     __shared__ double s_ldlt[36 + 6 + 6];       // lane-0 solver workspace (LDS instead of private scratch)
     __shared__ int s_tr[6];
+    __shared__ Se3 s_Tn;                        // candidate model of the iteration
+    __shared__ double s_nmx;
+    __shared__ int s_solve_ok;
     __shared__ double s_H[21];                  // H of the current level (updated by the change per iteration)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pair = blockIdx.x;
@@ -399,34 +402,39 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
                 const float c = __uint_as_float(cb);
                 if (lane == 0) s_chi2 = c;
                 SA_COUNT(2, clock64() - tlast); SA_COUNT(5, 1);
-            }
-            __syncthreads();
-            SA_PHASE(3);      // chain || accumulation
-            // ---- lane 0: solve, decide, update (NLSSolver_impl.hpp:40-87)
-            if (tid == 0) {
+            } else if (tid == 64) {
+                // ---- meanwhile, one lane of wave 1: the 6x6 solve and the candidate model (NLSSolver_impl.hpp:40-52, 66-75).  The
+                // Gauss-Newton step does not depend on chi2; only the accept / stop decision below does.
                 double Hm[36], Jr[6], x[6];
                 int q = 0;
                 for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) {
-                    double s = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) s += red[w2][q];
-                    s = s_H[q] + s; s_H[q] = s;                   // running H of the level
-                    Hm[6 * a + b] = s; Hm[6 * b + a] = s; ++q;
+                    double sm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) sm += red[w2][q];
+                    sm = s_H[q] + sm; s_H[q] = sm;                // running H of the level
+                    Hm[6 * a + b] = sm; Hm[6 * b + a] = sm; ++q;
                 }
-                for (int a = 0; a < 6; ++a) { double s = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) s += red[w2][21 + a]; Jr[a] = s; }
+                for (int a = 0; a < 6; ++a) { double sm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) sm += red[w2][21 + a]; Jr[a] = sm; }
+                const bool okx = ldlt6_solve_ws(Hm, Jr, x, s_ldlt, s_ldlt + 36, s_ldlt + 42, s_tr);
+                double mx[6]; for (int k = 0; k < 6; ++k) mx[k] = -x[k];
+                Se3 E, Tn;
+                se3_exp_d(mx, &E);
+                se3_mul_d(&T, &E, &Tn);
+                double nmx = -1; for (int k = 0; k < 6; ++k) if (fabs(x[k]) > nmx) nmx = fabs(x[k]);
+                s_Tn = Tn; s_nmx = nmx; s_solve_ok = okx ? 1 : 0;
+            }
+            __syncthreads();
+            SA_PHASE(3);      // chain || accumulation
+            // ---- lane 0: accept / stop decision (NLSSolver_impl.hpp:53-63, 85-87)
+            if (tid == 0) {
                 int nm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) nm += s_nmeas_w[w2];
                 n_meas_last = nm;
                 const double new_chi2 = (double)__fdiv_rn(s_chi2, (float)nm);
-                if (!ldlt6_solve_ws(Hm, Jr, x, s_ldlt, s_ldlt + 36, s_ldlt + 42, s_tr)) stop_ = true;
+                if (!s_solve_ok) stop_ = true;
                 int ctl = 0;
                 if ((it > 0 && new_chi2 > chi2_) || stop_) { sT = old_model; ctl = 1; }
                 else {
-                    double mx[6]; for (int k = 0; k < 6; ++k) mx[k] = -x[k];
-                    Se3 E, Tn;
-                    se3_exp_d(mx, &E);
-                    se3_mul_d(&T, &E, &Tn);
-                    old_model = T; sT = Tn;
+                    old_model = T; sT = s_Tn;
                     chi2_ = new_chi2;
-                    double nmx = -1; for (int k = 0; k < 6; ++k) if (fabs(x[k]) > nmx) nmx = fabs(x[k]);
-                    if (nmx <= 0.000001) ctl = 2;          // eps_ (SparseImageAlign.cpp:18)
+                    if (s_nmx <= 0.000001) ctl = 2;        // eps_ (SparseImageAlign.cpp:18)
                 }
                 s_ctl = ctl;
             }
