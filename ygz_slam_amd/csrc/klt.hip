@@ -145,12 +145,13 @@ __device__ __forceinline__ int klt_dot2(uint32_t a, uint32_t b, int acc)
 
 // FULL: the 21-wide window (every active lane owns exactly 7 pixels) -- the per-pixel guards fold away
 template <bool FULL>
-__global__ __launch_bounds__(256) void k_klt(KltArgs A)
+#define KLT_WPB 4          // wavefronts (points) per workgroup: points finish after very different iteration counts, small groups retire early
+__global__ __launch_bounds__(64 * KLT_WPB) void k_klt(KltArgs A)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int bx, pair;
     if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
-    const int pi = bx * 4 + wv;
+    const int pi = bx * KLT_WPB + wv;
     if (pi >= A.trk_n[pair]) return;               // wave-uniform
     const size_t p = (size_t)pair * A.cells + pi;
     const size_t ref_slot = (size_t)A.pair_t[pair], cur_slot = (size_t)A.pair_q[pair];
@@ -335,8 +336,8 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
     A.dbg = nullptr;
     if (getenv("YGZ_KLT_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_KLT_OUT, (size_t)n_pairs * ctx->cells * 32, &d) == YGZ_OK) { A.dbg = (long long *)d; (void)hipMemsetAsync(d, 0, (size_t)n_pairs * ctx->cells * 32, ctx->stream); } }
-    if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
-    else YGZ_LAUNCH(ctx, KID_KLT, k_klt<false>, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_pairs)), dim3(256), A);
+    if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
+    else YGZ_LAUNCH(ctx, KID_KLT, k_klt<false>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         const size_t nn = (size_t)n_pairs * ctx->cells;
