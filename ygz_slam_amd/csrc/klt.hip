@@ -295,6 +295,182 @@ __global__ __launch_bounds__(64 * KLT_WPB) void k_klt(KltArgs A)
     }
 }
 
+// ---- three points per wavefront (the default 21 x 21 window).  In k_klt<> two thirds of every iteration are per-point
+// bookkeeping (weights, window address, bounds, the 2x2 solve, convergence tests) executed by all 64 lanes for ONE point.
+// Here a point owns 21 lanes (7 row-triples x 3 column-thirds, 3 rows x 7 pixels per lane), so the same bookkeeping
+// instructions serve three points, consecutive window rows share their image row (4 loads and 28 byte-pair permutes for 3
+// rows instead of 6 and 42), and the lanes of a point reduce with a fixed-order 21-lane tree.  Points of a wavefront iterate
+// until the slowest has converged; finished ones idle (their lanes are masked).  Integer terms are those of k_klt<> and the
+// oracle; float sums differ in order only.
+__device__ __forceinline__ float klt_seg21_sum(float v, int lane, int q, int seg)
+{
+    float t;
+    t = __shfl(v, lane + 16 < 63 ? lane + 16 : 63); if (q < 5) v = __fadd_rn(v, t);
+    t = __shfl(v, lane + 8 < 63 ? lane + 8 : 63);   if (q < 8) v = __fadd_rn(v, t);
+    t = __shfl(v, lane + 4 < 63 ? lane + 4 : 63);   if (q < 4) v = __fadd_rn(v, t);
+    t = __shfl(v, lane + 2 < 63 ? lane + 2 : 63);   if (q < 2) v = __fadd_rn(v, t);
+    t = __shfl(v, lane + 1 < 63 ? lane + 1 : 63);   if (q < 1) v = __fadd_rn(v, t);
+    return __shfl(v, seg);
+}
+
+__global__ __launch_bounds__(256) void k_klt3(KltArgs A)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int bx, pair;
+    if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
+    const int n = A.trk_n[pair];
+    const int first = (bx * 4 + wv) * 3;
+    if (first >= n) return;                                  // wave-uniform
+    const int sub = lane / 21, q = lane - 21 * sub, rt = q / 3, x0 = 7 * (q - 3 * rt), row0 = 3 * rt, seg = sub < 3 ? 21 * sub : 63;
+    const int pi = first + sub;
+    const bool live = sub < 3 && pi < n;                     // lane 63 and the lanes of points past the end idle
+    const size_t p = (size_t)pair * A.cells + (live ? pi : first);
+    const size_t ref_slot = (size_t)A.pair_t[pair], cur_slot = (size_t)A.pair_q[pair];
+    const int win = KLT_MAXWIN;
+    const float half = (float)(win - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const float ppx = (float)A.trk_px[2 * p], ppy = (float)A.trk_px[2 * p + 1];   // cv::Point2f(fea->_pixel) (Tracker.cpp:85)
+    float outx = A.use_initial_flow ? A.next_pts[2 * p] : ppx;
+    float outy = A.use_initial_flow ? A.next_pts[2 * p + 1] : ppy;
+    bool status = true;
+    float errv = 0.f;
+
+    for (int level = A.max_level; level >= 0; --level) {
+        const int w = A.w[level], h = A.h[level];
+        const int pw = KLT_PW(w);
+        const size_t psz = (size_t)pw * (h + 2 * KLT_B), org = (size_t)KLT_B * pw + KLT_B;
+        const uint8_t *I = A.pad[level] + ref_slot * psz + org, *J = A.pad[level] + cur_slot * psz + org;
+        klt_gptr D = (klt_gptr)(reinterpret_cast<const uint32_t *>(A.deriv[level]) + ref_slot * psz + org);
+        const float s = __int_as_float((127 - level) << 23);       // (float)(1. / (1 << level)), exact
+        float prevx = __fmul_rn(ppx, s), prevy = __fmul_rn(ppy, s);
+        float nx, ny;
+        if (level == A.max_level) { nx = __fmul_rn(outx, s); ny = __fmul_rn(outy, s); }
+        else { nx = __fmul_rn(outx, 2.f); ny = __fmul_rn(outy, 2.f); }
+        outx = nx; outy = ny;
+        prevx = __fsub_rn(prevx, half); prevy = __fsub_rn(prevy, half);
+        const int ipx = (int)floorf(prevx), ipy = (int)floorf(prevy);
+        const bool in_lv = live && !(ipx < -win || ipx >= w || ipy < -win || ipy >= h);
+        if (live && !in_lv && level == 0) { status = false; errv = 0.f; }
+        float a = __fsub_rn(prevx, (float)ipx), b = __fsub_rn(prevy, (float)ipy);
+        int iw00, iw01, iw10, iw11;
+        uint32_t wtop, wbot;
+        KLT_WEIGHTS(a, b);
+        // the lane's 3 x 7 patch values stay in registers for the whole level: image << 5, (dx | dy << 16)
+        int iI[21]; uint32_t iD[21];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { iI[k] = 0; iD[k] = 0u; }
+        float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
+        if (in_lv) {
+            const int o = __mul24(ipy + row0, pw) + ipx + x0;
+            uint32_t il[4], ih[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) klt_load8(I + o + r * pw, il[r], ih[r]);
+            int q11 = 0, q12 = 0, q22 = 0;                      // exact: |Scharr| < 2^12, 21 products < 2^29
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                uint32_t d0[8], d1[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) { d0[kk] = D[o + r * pw + kk]; d1[kk] = D[o + (r + 1) * pw + kk]; }
+#pragma unroll
+                for (int kk = 0; kk < 7; ++kk) {
+                    const int ival = KLT_BIL9P(il[r], ih[r], il[r + 1], ih[r + 1], kk);
+                    const int ixval = klt_dot2(KLT_DXP(d1[kk], d1[kk + 1]), wbot, klt_dot2(KLT_DXP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
+                    const int iyval = klt_dot2(KLT_DYP(d1[kk], d1[kk + 1]), wbot, klt_dot2(KLT_DYP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
+                    const int sx = (int)(int16_t)ixval, sy = (int)(int16_t)iyval;
+                    iI[7 * r + kk] = (int)(int16_t)ival;
+                    iD[7 * r + kk] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+                    q11 += __mul24(sx, sx); q12 += __mul24(sx, sy); q22 += __mul24(sy, sy);
+                }
+            }
+            sA11 = (float)q11; sA12 = (float)q12; sA22 = (float)q22;
+        }
+        const float A11 = __fmul_rn(klt_seg21_sum(sA11, lane, q, seg), FLT_SCALE), A12 = __fmul_rn(klt_seg21_sum(sA12, lane, q, seg), FLT_SCALE),
+                    A22 = __fmul_rn(klt_seg21_sum(sA22, lane, q, seg), FLT_SCALE);
+        float Dd = __fsub_rn(__fmul_rn(A11, A22), __fmul_rn(A12, A12));
+        const float dif = __fsub_rn(A11, A22);
+        const float minEig = __fdiv_rn(__fsub_rn(__fadd_rn(A22, A11),
+                                                 ygz_sqrtf_cr(__fadd_rn(__fmul_rn(dif, dif), __fmul_rn(__fmul_rn(4.f, A12), A12)))),
+                                       (float)(2 * win * win));
+        const bool it_ok = in_lv && !(minEig < A.min_eig_thr || Dd < 1.192092896e-07f);
+        if (in_lv && !it_ok && level == 0) status = false;
+        Dd = __fdiv_rn(1.f, Dd);
+        nx = it_ok ? __fsub_rn(nx, half) : nx; ny = it_ok ? __fsub_rn(ny, half) : ny;
+        float pdx = 0.f, pdy = 0.f;
+        bool done = !it_ok;
+        for (int j = 0; j < A.max_count; ++j) {
+            if (__ballot(!done) == 0ull) break;
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (!done && (inx < -win || inx >= w || iny < -win || iny >= h)) {
+                if (level == 0) status = false;
+                done = true;
+            }
+            const bool act = !done;
+            a = __fsub_rn(nx, (float)inx); b = __fsub_rn(ny, (float)iny);
+            KLT_WEIGHTS(a, b);
+            float sb1 = 0.f, sb2 = 0.f;
+            if (act) {
+                const int o = __mul24(iny + row0, pw) + inx + x0;
+                uint32_t jl[4], jh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) klt_load8(J + o + r * pw, jl[r], jh[r]);
+                int a1 = 0, a2 = 0;                                  // 21 terms, |diff * I| < 2^26: exact in int32
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) {
+                        const int diff = KLT_BIL9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk) - iI[7 * r + kk];
+                        a1 = KLT_MAD(diff, (int)(int16_t)(iD[7 * r + kk] & 0xffffu), a1);
+                        a2 = KLT_MAD(diff, (int)iD[7 * r + kk] >> 16, a2);
+                    }
+                }
+                sb1 = (float)a1; sb2 = (float)a2;
+            }
+            const float b1 = __fmul_rn(klt_seg21_sum(sb1, lane, q, seg), FLT_SCALE), b2 = __fmul_rn(klt_seg21_sum(sb2, lane, q, seg), FLT_SCALE);
+            if (act) {
+                const float dx = __fmul_rn(__fsub_rn(__fmul_rn(A12, b2), __fmul_rn(A22, b1)), Dd);
+                const float dy = __fmul_rn(__fsub_rn(__fmul_rn(A12, b1), __fmul_rn(A11, b2)), Dd);
+                nx = __fadd_rn(nx, dx); ny = __fadd_rn(ny, dy);
+                outx = __fadd_rn(nx, half); outy = __fadd_rn(ny, half);
+                if ((double)dx * (double)dx + (double)dy * (double)dy <= A.epsilon) done = true;
+                else if (j > 0 && (double)fabsf(__fadd_rn(dx, pdx)) < 0.01 && (double)fabsf(__fadd_rn(dy, pdy)) < 0.01) {
+                    outx = __fsub_rn(outx, __fmul_rn(dx, 0.5f)); outy = __fsub_rn(outy, __fmul_rn(dy, 0.5f));
+                    done = true;
+                }
+                pdx = dx; pdy = dy;
+            }
+        }
+        if (level == 0) {
+            bool want = it_ok && status;
+            const float qx = __fsub_rn(outx, half), qy = __fsub_rn(outy, half);
+            const int inx = (int)floorf(qx), iny = (int)floorf(qy);
+            if (want && (inx < -win || inx >= w || iny < -win || iny >= h)) { status = false; want = false; }
+            const float aa = __fsub_rn(qx, (float)inx), bb = __fsub_rn(qy, (float)iny);
+            KLT_WEIGHTS(aa, bb);
+            float se = 0.f;
+            if (want) {
+                const int o = __mul24(iny + row0, pw) + inx + x0;
+                uint32_t jl[4], jh[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) klt_load8(J + o + r * pw, jl[r], jh[r]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int kk = 0; kk < 7; ++kk) {
+                        const int diff = KLT_BIL9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk) - iI[7 * r + kk];
+                        se = __fadd_rn(se, fabsf((float)diff));
+                    }
+                }
+            }
+            const float tot = klt_seg21_sum(se, lane, q, seg);
+            if (want) errv = __fdiv_rn(__fmul_rn(tot, 1.f), (float)(32 * win * win));
+        }
+    }
+    if (live && q == 0) {
+        A.next_pts[2 * p] = outx; A.next_pts[2 * p + 1] = outy;
+        A.status[p] = (uint8_t)status; A.err[p] = errv;
+    }
+}
+
 int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
 {
     if (prm->win < 3 || prm->win > KLT_MAXWIN || prm->max_level < 0 || prm->max_level >= YGZ_MAX_LEVELS) return YGZ_E_INVALID;
@@ -336,7 +512,8 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
     A.dbg = nullptr;
     if (getenv("YGZ_KLT_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_KLT_OUT, (size_t)n_pairs * ctx->cells * 32, &d) == YGZ_OK) { A.dbg = (long long *)d; (void)hipMemsetAsync(d, 0, (size_t)n_pairs * ctx->cells * 32, ctx->stream); } }
-    if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
+    if (A.win == KLT_MAXWIN && !A.dbg && !getenv("YGZ_KLT_ONE_POINT")) YGZ_LAUNCH(ctx, KID_KLT, k_klt3, dim3(ygz_div_up(ctx->cells, 12), ygz_round_up8(n_pairs)), dim3(256), A);
+    else if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
     else YGZ_LAUNCH(ctx, KID_KLT, k_klt<false>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
