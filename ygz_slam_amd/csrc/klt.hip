@@ -355,10 +355,13 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
         int iw00, iw01, iw10, iw11;
         uint32_t wtop, wbot;
         KLT_WEIGHTS(a, b);
-        // the lane's 3 x 7 patch values stay in registers for the whole level: image << 5, (dx | dy << 16)
-        int iI[21]; uint32_t iD[21];
+        // the lane's 3 x 7 patch values stay in registers for the whole level: image << 5, and the derivatives of two
+        // consecutive pixels per register (dx_k | dx_k+1 << 16, same for dy) -- the layout v_dot2 wants for the mismatch sums
+        int iI[21]; uint32_t pDx[11], pDy[11];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) { iI[k] = 0; iD[k] = 0u; }
+        for (int k = 0; k < 21; ++k) iI[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { pDx[k] = 0u; pDy[k] = 0u; }
         float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
         if (in_lv) {
             const int o = __mul24(ipy + row0, pw) + ipx + x0;
@@ -377,8 +380,10 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
                     const int ixval = klt_dot2(KLT_DXP(d1[kk], d1[kk + 1]), wbot, klt_dot2(KLT_DXP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
                     const int iyval = klt_dot2(KLT_DYP(d1[kk], d1[kk + 1]), wbot, klt_dot2(KLT_DYP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
                     const int sx = (int)(int16_t)ixval, sy = (int)(int16_t)iyval;
-                    iI[7 * r + kk] = (int)(int16_t)ival;
-                    iD[7 * r + kk] = ((uint32_t)sx & 0xffffu) | ((uint32_t)sy << 16);
+                    const int li = 7 * r + kk;
+                    iI[li] = (int)(int16_t)ival;
+                    if (li & 1) { pDx[li >> 1] |= (uint32_t)sx << 16; pDy[li >> 1] |= (uint32_t)sy << 16; }
+                    else { pDx[li >> 1] = (uint32_t)sx & 0xffffu; pDy[li >> 1] = (uint32_t)sy & 0xffffu; }
                     q11 += __mul24(sx, sx); q12 += __mul24(sx, sy); q22 += __mul24(sy, sy);
                 }
             }
@@ -414,14 +419,18 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) klt_load8(J + o + r * pw, jl[r], jh[r]);
                 int a1 = 0, a2 = 0;                                  // 21 terms, |diff * I| < 2^26: exact in int32
+                int df[22];
+                df[21] = 0;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                    for (int kk = 0; kk < 7; ++kk) {
-                        const int diff = KLT_BIL9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk) - iI[7 * r + kk];
-                        a1 = KLT_MAD(diff, (int)(int16_t)(iD[7 * r + kk] & 0xffffu), a1);
-                        a2 = KLT_MAD(diff, (int)iD[7 * r + kk] >> 16, a2);
-                    }
+                    for (int kk = 0; kk < 7; ++kk) df[7 * r + kk] = KLT_BIL9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk) - iI[7 * r + kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 11; ++kk) {                    // (diff_2k, diff_2k+1) . (dx_2k, dx_2k+1): |diff| < 2^14 fits int16
+                    const uint32_t dp = __builtin_amdgcn_perm((uint32_t)df[2 * kk + 1], (uint32_t)df[2 * kk], 0x05040100u);
+                    a1 = klt_dot2(dp, pDx[kk], a1);
+                    a2 = klt_dot2(dp, pDy[kk], a2);
                 }
                 sb1 = (float)a1; sb2 = (float)a2;
             }
