@@ -37,6 +37,12 @@ public:
     // the same for many features of `ref` in one launch (what LocalMapping::ProjectMapPoints loops over)
     int FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Feature *> &fea_ref, vector<Vector2d> &px_curr,
                                   vector<int> &search_level, vector<bool> &ok);
+    // LocalMapping::FindCandidates + ProjectMapPoints (src/Module/LocalMapping.cpp:47-120) in one launch: projects the local map
+    // points into `current`, refines every co-visible observation with FindDirectProjection (MapPoint overload) and appends one
+    // new Feature per matched map point to current->_features; side effects as the reference (_track_in_view = false when out
+    // of view, _cnt_visible++ when in view).  Candidates are visited per map point in _obs (keyframe id) order -- the
+    // reference's order is the heap-address order of a std::map<Feature*, ...>.  Returns the number of matched points.
+    int ProjectMapPoints(Frame *current, const std::set<Frame *> &local_keyframes, const std::set<MapPoint *> &local_map_points);
     bool SparseImageAlignment(Frame *ref, Frame *current);                                  // Matcher.cpp:468-492
     SE3 GetTCR() const { return _TCR_esti; }
 private:

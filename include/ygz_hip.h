@@ -135,6 +135,22 @@ typedef struct {
 int  ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair,
                                     const double *px_ref, const double *depth_ref, const int32_t *level_ref,
                                     double *px_cur, int32_t *search_level, uint8_t *ok, int n);
+/* ---- LocalMapping::FindCandidates + ProjectMapPoints (src/Module/LocalMapping.cpp:47-120) in one call.
+ * FindCandidates: each non-bad local map point is projected into the current frame (World2Camera, Camera2Pixel); behind the
+ * camera or outside InFrame(px,20) -> in_view = 0.  ProjectMapPoints: every candidate (an observation of a point in one of
+ * the K resident local keyframes: pixel and pyramid level of that observation) is refined by the MapPoint overload of
+ * Matcher::FindDirectProjection (Matcher.cpp:356-383, depth = z of the point in that keyframe); per point the FIRST success
+ * in candidate order is kept (the reference iterates a std::map<Feature*,...>, i.e. heap-address order; the order here is
+ * the caller's).  Outputs per point: in_view, px_proj [P][2], match_cand (candidate index or -1), px_match [P][2]
+ * (Feature::_pixel of the new feature), match_level (its _level).  Host arrays; synchronises. */
+typedef struct {
+    int n_points;      const double *pos_world /*[P][3]*/; const uint8_t *point_bad /*[P] or NULL*/;
+    int n_keyframes;   const int32_t *kf_slot /*[K]*/;     const double *kf_T /*[K][7] Frame::_TCW*/;
+    int n_candidates;  const int32_t *cand_point, *cand_kf, *cand_level /*[C]*/; const double *cand_px_ref /*[C][2]*/;
+} ygz_local_map;
+int  ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
+                             uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level,
+                             int32_t *n_matched);
 /* bare cvutils::Align2D on host-provided patches against level `level` of `cur_slot`:
  * pwb [n][100], patch [n][64], uv [n][2] in/out (level pixels), ok [n], chi2 [n] (may be NULL) */
 int  ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pwb, const uint8_t *patch,

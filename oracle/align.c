@@ -160,12 +160,11 @@ void yo_warp_affine(const double A[4], const uint8_t *img_ref, int w, int h,
 
 /* Matcher::FindDirectProjection(Frame*,Frame*,Feature*,...) -- Matcher.cpp:385-417.
  * The MapPoint overload (:356-383) differs only in how the depth is obtained. */
-int yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
-                              const yo_pyramid *cur, const yo_se3 *T_cur,
-                              const double px_ref[2], double depth_ref, int level_ref,
-                              double px_cur[2], int *search_level_out)
+static int fdp_body(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
+                    const yo_pyramid *cur, const yo_se3 *T_cur,
+                    const double px_ref[2], double depth_ref, int level_ref,
+                    double px_cur[2], int *search_level_out)
 {
-    if (depth_ref < 0) return 0;
     double pt_ref[3], A[4];
     yo_se3 Tri, TCR;
     pixel2camera(cam, px_ref, depth_ref, pt_ref);
@@ -186,6 +185,68 @@ int yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, const
     if (!(px_cur[0] >= 10 && px_cur[0] < cur->w[0] - 10 && px_cur[1] >= 10 && px_cur[1] < cur->h[0] - 10))
         return 0;
     return ok;
+}
+
+int yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
+                              const yo_pyramid *cur, const yo_se3 *T_cur,
+                              const double px_ref[2], double depth_ref, int level_ref,
+                              double px_cur[2], int *search_level_out)
+{
+    if (depth_ref < 0) return 0;                                   /* Matcher.cpp:388-392 */
+    return fdp_body(cam, ref, T_ref, cur, T_cur, px_ref, depth_ref, level_ref, px_cur, search_level_out);
+}
+
+/* Matcher::FindDirectProjection(Frame*,Frame*,MapPoint*,...) -- Matcher.cpp:356-383: the depth is the z of the map point in
+ * the reference keyframe, World2Camera(mp->_pos_world, ref->_TCW)[2] (:362), and is NOT tested for its sign;
+ * px_ref / level_ref are those of the map point's observation in that keyframe (:360-361). */
+int yo_find_direct_projection_mp(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
+                                 const yo_pyramid *cur, const yo_se3 *T_cur, const double pos_world[3],
+                                 const double px_ref[2], int level_ref, double px_cur[2], int *search_level_out)
+{
+    double pc[3];
+    yo_se3_act(T_ref, pos_world, pc);
+    return fdp_body(cam, ref, T_ref, cur, T_cur, px_ref, pc[2], level_ref, px_cur, search_level_out);
+}
+
+/* LocalMapping::FindCandidates + ProjectMapPoints -- src/Module/LocalMapping.cpp:47-120.
+ * FindCandidates (:47-79): every non-bad local map point is projected into the current frame; behind the camera or outside
+ * InFrame(px,20) -> not in view; otherwise each of its observations in a local keyframe becomes a candidate carrying the
+ * projected pixel.  ProjectMapPoints (:81-120): candidates are visited in order; a map point that already matched is skipped;
+ * FindDirectProjection (MapPoint overload) refines the projection; the first success of a point wins.
+ * The reference visits candidates in std::map<Feature*,...> order, i.e. by heap address; here the order is the caller's
+ * (cand_* arrays), which is the only reproducible statement of it.
+ * Inputs: K local keyframes (pyramid + pose), P points (pos_world [P][3], point_bad [P]), C candidates
+ * (cand_point, cand_kf, cand_px_ref [C][2], cand_level).  Outputs per point: in_view, px_proj [P][2] (valid when in view),
+ * match_cand (candidate index or -1), px_match [P][2], match_level.  Returns the number of matched points. */
+int yo_track_local_map(const yo_camera *cam, const yo_pyramid *kf_pyr, const yo_se3 *kf_T, int K,
+                       const yo_pyramid *cur, const yo_se3 *T_cur,
+                       const double *pos_world, const uint8_t *point_bad, int P,
+                       const int32_t *cand_point, const int32_t *cand_kf, const double *cand_px_ref, const int32_t *cand_level, int C,
+                       uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level)
+{
+    int matched = 0;
+    for (int p = 0; p < P; ++p) {
+        in_view[p] = 0; match_cand[p] = -1; match_level[p] = 0;
+        px_proj[2 * p] = px_proj[2 * p + 1] = px_match[2 * p] = px_match[2 * p + 1] = 0.0;
+        if (point_bad && point_bad[p]) continue;
+        double pc[3], px[2];
+        yo_se3_act(T_cur, pos_world + 3 * (size_t)p, pc);               /* World2Camera, Camera.h:41-43 */
+        camera2pixel(cam, pc, px);
+        px_proj[2 * p] = px[0]; px_proj[2 * p + 1] = px[1];
+        if (pc[2] < 0 || !(px[0] >= 20 && px[0] < cur->w[0] - 20 && px[1] >= 20 && px[1] < cur->h[0] - 20)) continue;   /* :59 */
+        in_view[p] = 1;
+    }
+    for (int c = 0; c < C; ++c) {
+        const int p = cand_point[c], kf = cand_kf[c];
+        if (p < 0 || p >= P || kf < 0 || kf >= K || !in_view[p] || match_cand[p] >= 0) continue;
+        double px[2] = { px_proj[2 * p], px_proj[2 * p + 1] };
+        int level = 0;
+        if (yo_find_direct_projection_mp(cam, &kf_pyr[kf], &kf_T[kf], cur, T_cur, pos_world + 3 * (size_t)p,
+                                         cand_px_ref + 2 * (size_t)c, cand_level[c], px, &level)) {
+            match_cand[p] = c; px_match[2 * p] = px[0]; px_match[2 * p + 1] = px[1]; match_level[p] = level; ++matched;
+        }
+    }
+    return matched;
 }
 
 /* cvutils::DepthFromTriangulation -- include/ygz/Algorithm/CVUtils.h:18-38, with Eigen's evaluation order

@@ -350,6 +350,39 @@ class Oracle:
                                                 _f64(pxr), float(depth), int(level_ref), _f64(pxc), C.byref(sl))
         return bool(ok), pxc, sl.value
 
+    def find_direct_projection_mp(self, ref_levels, T_ref, cur_levels, T_cur, pos_world, px_ref, level_ref, px_cur, cam=None):
+        cam = cam or self.camera()
+        pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)
+        Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
+        pw = np.ascontiguousarray(pos_world, np.float64)
+        pxr = np.ascontiguousarray(px_ref, np.float64)
+        pxc = np.ascontiguousarray(px_cur, np.float64).copy()
+        sl = C.c_int(0)
+        ok = self.lib.yo_find_direct_projection_mp(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc), _f64(pw),
+                                                   _f64(pxr), int(level_ref), _f64(pxc), C.byref(sl))
+        return bool(ok), pxc, sl.value
+
+    def track_local_map(self, kf_levels, kf_T, cur_levels, T_cur, pos_world, point_bad, cand_point, cand_kf, cand_px_ref,
+                        cand_level, cam=None):
+        """yo_track_local_map: LocalMapping::FindCandidates + ProjectMapPoints (LocalMapping.cpp:47-120)"""
+        cam = cam or self.camera()
+        K = len(kf_levels)
+        pyrs = (Pyramid * max(K, 1))(*[self._pyr_struct(l) for l in kf_levels])
+        Ts = (SE3 * max(K, 1))(*[SE3.from_array(t) for t in kf_T])
+        pc, Tc = self._pyr_struct(cur_levels), SE3.from_array(T_cur)
+        pw = np.ascontiguousarray(pos_world, np.float64).reshape(-1, 3)
+        P = pw.shape[0]
+        bad = np.ascontiguousarray(point_bad if point_bad is not None else np.zeros(P), np.uint8)
+        cp = np.ascontiguousarray(cand_point, np.int32); ck = np.ascontiguousarray(cand_kf, np.int32)
+        cx = np.ascontiguousarray(cand_px_ref, np.float64).reshape(-1, 2); cl = np.ascontiguousarray(cand_level, np.int32)
+        Cn = cp.shape[0]
+        in_view = np.zeros(P, np.uint8); px_proj = np.zeros((P, 2)); match = np.zeros(P, np.int32)
+        px_match = np.zeros((P, 2)); lvl = np.zeros(P, np.int32)
+        n = self.lib.yo_track_local_map(C.byref(cam), pyrs, Ts, K, C.byref(pc), C.byref(Tc), _f64(pw), _u8(bad), P,
+                                        _p(cp, C.c_int32), _p(ck, C.c_int32), _f64(cx), _p(cl, C.c_int32), Cn,
+                                        _u8(in_view), _f64(px_proj), _p(match, C.c_int32), _f64(px_match), _p(lvl, C.c_int32))
+        return int(n), in_view, px_proj, match, px_match, lvl
+
     def sparse_align(self, ref_levels, T_ref, cur_levels, T_cur, px, depth, has_mp, max_level=2, min_level=0,
                      n_iter=30, cam=None):
         cam = cam or self.camera()

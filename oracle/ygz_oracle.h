@@ -154,6 +154,17 @@ int  yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, cons
                                const double px_ref[2], double depth_ref, int level_ref,
                                double px_cur[2], int *search_level);
 
+/* MapPoint overload, Matcher.cpp:356-383 (depth = z of the point in the reference keyframe, no sign test) */
+int  yo_find_direct_projection_mp(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
+                                  const yo_pyramid *cur, const yo_se3 *T_cur, const double pos_world[3],
+                                  const double px_ref[2], int level_ref, double px_cur[2], int *search_level);
+/* LocalMapping::FindCandidates + ProjectMapPoints, LocalMapping.cpp:47-120 (candidates in caller order); see align.c */
+int  yo_track_local_map(const yo_camera *cam, const yo_pyramid *kf_pyr, const yo_se3 *kf_T, int K,
+                        const yo_pyramid *cur, const yo_se3 *T_cur,
+                        const double *pos_world, const uint8_t *point_bad, int P,
+                        const int32_t *cand_point, const int32_t *cand_kf, const double *cand_px_ref, const int32_t *cand_level, int C,
+                        uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level);
+
 /* cvutils::DepthFromTriangulation CVUtils.h:18-38 */
 int  yo_depth_from_triangulation(const yo_se3 *T_search_ref, const double f_ref[3], const double f_cur[3],
                                  double determinant_th, double *depth1, double *depth2);

@@ -108,6 +108,26 @@ int main(int argc, char **argv)
     { Vector2d p1 = f[0]._features[3]->_pixel + Vector2d(1.5, -1.0); int l1 = 0;
       bool o1 = matcher.FindDirectProjection(&f[0], &f[1], f[0]._features[3], p1, l1);
       fprintf(out, "fdp1 %d %d %.17g %.17g\n", (int)o1, l1, p1[0], p1[1]); }
+    // --- LocalMapping::FindCandidates + ProjectMapPoints through Matcher::ProjectMapPoints
+    {
+        std::set<Frame *> kfs; kfs.insert(&f[0]);
+        std::set<MapPoint *> mpset;
+        for (Feature *fe : f[0]._features) if (fe->_mappoint) { fe->_mappoint->_obs[f[0]._keyframe_id] = fe; fe->_frame = &f[0]; mpset.insert(fe->_mappoint); }
+        mps[2]->_bad = true;
+        const size_t n_before = f[1]._features.size();
+        const int nm = matcher.ProjectMapPoints(&f[1], kfs, mpset);
+        fprintf(out, "lmap %zu\n", mps.size());
+        for (MapPoint *mp : mps) {
+            Feature *found = nullptr;
+            for (size_t i = n_before; i < f[1]._features.size(); ++i) if (f[1]._features[i]->_mappoint == mp) found = f[1]._features[i];
+            fprintf(out, "%d %d %d %.17g %.17g %.17g %.17g %.17g\n", mp->_cnt_visible, found ? 1 : 0, found ? found->_level : 0, found ? found->_pixel[0] : 0.0,
+                    found ? found->_pixel[1] : 0.0, mp->_pos_world[0], mp->_pos_world[1], mp->_pos_world[2]);
+        }
+        fprintf(out, "lmap_n %d %zu\n", nm, f[1]._features.size() - n_before);
+        for (size_t i = n_before; i < f[1]._features.size(); ++i) delete f[1]._features[i];
+        f[1]._features.resize(n_before);
+        mps[2]->_bad = false;
+    }
     // cvutils::Align2D on a host patch against a pyramid level of frame 1
     { uint8_t pwb[100], patch[64];
       const cv::Mat &img = f[0]._pyramid[0];

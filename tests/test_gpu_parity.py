@@ -232,6 +232,69 @@ def test_find_direct_projection_bit_exact(hip_lib, oracle):
         ctx.close()
 
 
+def _local_map_fixture(oracle, imgs, poses, depths, n_kf, per_kf, rng):
+    """map points from the first n_kf frames; every point gets an observation in each keyframe that sees it"""
+    pos, cand = [], []
+    for kf in range(n_kf):
+        kps = oracle.detect(oracle.pyramid(imgs[kf], 3))
+        sel = rng.permutation(len(kps))[:per_kf]
+        Twc = oracle.se3_inv(poses[kf])
+        R = synth.quat_to_R(Twc[:4])
+        for i in sel:
+            x, y = kps["px"][i], kps["py"][i]
+            d = depths[kf][int(y), int(x)]
+            pc = np.array([(x - synth.CX) / synth.FX * d, (y - synth.CY) / synth.FY * d, d])
+            pw = R @ pc + Twc[4:] + rng.normal(0, 0.002, 3)
+            p = len(pos); pos.append(pw)
+            cand.append((p, kf, x, y, int(kps["level"][i])))
+            for o in range(n_kf):                                  # co-visible observations (sub-pixel positions, other levels)
+                if o == kf:
+                    continue
+                q = synth.project(poses[o], pw[None])[0][0]
+                if 30 < q[0] < 610 and 30 < q[1] < 450 and rng.random() < 0.7:
+                    cand.append((p, o, q[0] + rng.uniform(-0.5, 0.5), q[1] + rng.uniform(-0.5, 0.5), int(rng.integers(0, 3))))
+    pos = np.array(pos)
+    cand = [cand[i] for i in rng.permutation(len(cand))]          # the reference's order is heap-address order: any order must work
+    cp = np.array([c[0] for c in cand], np.int32); ck = np.array([c[1] for c in cand], np.int32)
+    cx = np.array([[c[2], c[3]] for c in cand]); cl = np.array([c[4] for c in cand], np.int32)
+    return pos, cp, ck, cx, cl
+
+
+def test_track_local_map(hip_lib, oracle):
+    """SURVEY 8f-3: LocalMapping::FindCandidates + ProjectMapPoints in one launch vs the oracle's sequential restatement"""
+    imgs, poses, depths = _frames(4, 640, 480, seed=8, step=0.5)
+    rng = np.random.default_rng(4)
+    pos, cp, ck, cx, cl = _local_map_fixture(oracle, imgs, poses, depths, 3, 300, rng)
+    P = len(pos)
+    bad = (rng.random(P) < 0.05).astype(np.uint8)
+    pos[3] = [0.0, 0.0, -5.0]                               # behind the current camera
+    pos[4] = [50.0, 0.0, 2.0]                               # far outside the image
+    pos[6] = oracle.se3_inv(poses[3])[4:]                   # at the camera centre: z = 0 -> inf / nan pixel -> not in view
+    T_cur = oracle.se3_mul(synth.se3_exp([0.004, -0.003, 0.002, 0.001, -0.001, 0.0015]), poses[3])     # prediction a little off
+    ctx = make_ctx(hip_lib, max_frames=4)
+    for s in range(4):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 4)
+    lv = [oracle.pyramid(imgs[s], 3) for s in range(4)]
+    n, vis, proj, match, pxm, lvl = ctx.track_local_map(3, T_cur, [0, 1, 2], [poses[0], poses[1], poses[2]], pos, bad, cp, ck, cx, cl)
+    on, ovis, oproj, omatch, opxm, olvl = oracle.track_local_map(lv[:3], poses[:3], lv[3], T_cur, pos, bad, cp, ck, cx, cl)
+    assert np.array_equal(vis, ovis) and vis[3] == 0 and vis[4] == 0 and vis[6] == 0
+    inv = vis.astype(bool)
+    assert np.array_equal(proj[inv], oproj[inv])                               # bit-exact doubles
+    assert np.array_equal(match, omatch) and n == on
+    assert np.array_equal(pxm, opxm) and np.array_equal(lvl, olvl)
+    assert n > 0.5 * inv.sum() and (match[~inv] == -1).all() and (match[bad.astype(bool)] == -1).all()
+    # some point's first candidate failed and a later one matched: the "first success in order" rule is exercised
+    first = {}
+    for c, p_ in enumerate(cp):
+        first.setdefault(int(p_), c)
+    assert any(match[p_] >= 0 and match[p_] != first[p_] for p_ in first)
+    # empty inputs
+    n0, v0, *_ = ctx.track_local_map(3, T_cur, [0], [poses[0]], pos[:5], None, [], [], np.zeros((0, 2)), [])
+    assert n0 == 0 and len(v0) == 5
+    ctx.close()
+
+
 def test_align2d_patches_bit_exact(hip_lib, oracle):
     imgs, _, _ = _frames(2, 640, 480, seed=7, step=0.2)
     rng = np.random.default_rng(2)

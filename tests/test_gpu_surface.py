@@ -24,7 +24,7 @@ def _parse(path):
         if tag == "kp":
             n = int(t[2]); rows = [lines[i + k].split() for k in range(n)]; i += n
             out["kp%s" % t[1]] = np.array(rows, dtype=np.float64)
-        elif tag in ("matches", "fdp"):
+        elif tag in ("matches", "fdp", "lmap"):
             n = int(t[1]); rows = [lines[i + k].split() for k in range(n)]; i += n
             out[tag] = np.array(rows, dtype=np.float64).reshape(n, -1)
         elif tag == "klt":
@@ -126,6 +126,17 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
         o_ok, o_px, o_sl = oracle.find_direct_projection(lv[0], poses[0], lv[1], poses[1], px0[i], depth[i], int(ks[0]["level"][i]), px0[i] + [1.5, -1.0])
         assert int(r["fdp"][i, 0]) == int(o_ok) and int(r["fdp"][i, 1]) == o_sl and np.array_equal(r["fdp"][i, 2:], o_px)
     assert [float(x) for x in r["fdp1"][0]] == list(r["fdp"][3])
+    # Matcher::ProjectMapPoints = LocalMapping::FindCandidates + ProjectMapPoints (one observation per point, keyframe 0)
+    lm = r["lmap"]
+    mp_idx = np.array([i for i in range(len(px0)) if i % 9 != 0])
+    assert len(lm) == len(mp_idx)
+    bad = np.zeros(len(lm), np.uint8); bad[2] = 1
+    on, ovis, _, omatch, opx, olvl = oracle.track_local_map([lv[0]], [poses[0]], lv[1], poses[1], lm[:, 5:8], bad, np.arange(len(lm)),
+                                                            np.zeros(len(lm), int), px0[mp_idx], ks[0]["level"][mp_idx])
+    assert [int(x) for x in r["lmap_n"][0]] == [on, on] and on > 0.5 * len(lm)
+    assert np.array_equal(lm[:, 0].astype(int), ovis.astype(int))                   # _cnt_visible went 0 -> 1 exactly for the in-view points
+    assert np.array_equal(lm[:, 1].astype(int), (omatch >= 0).astype(int))
+    assert np.array_equal(lm[:, 2].astype(int), olvl) and np.array_equal(lm[:, 3:5], opx)
     pwb = lv[0][0][195:205, 295:305].copy()
     o_ok, u, v, _, _ = oracle.align2d(lv[0][0], pwb, pwb[1:9, 1:9].copy(), 301.2, 199.1)
     assert [float(x) for x in r["align2d"][0]] == [float(o_ok), u, v]

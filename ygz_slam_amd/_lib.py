@@ -37,6 +37,13 @@ class AlignPair(C.Structure):
     _fields_ = [("ref_slot", C.c_int), ("cur_slot", C.c_int), ("T_ref", C.c_double * 7), ("T_cur", C.c_double * 7)]
 
 
+class LocalMap(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("pos_world", C.POINTER(C.c_double)), ("point_bad", C.POINTER(C.c_uint8)),
+                ("n_keyframes", C.c_int), ("kf_slot", C.POINTER(C.c_int32)), ("kf_T", C.POINTER(C.c_double)),
+                ("n_candidates", C.c_int), ("cand_point", C.POINTER(C.c_int32)), ("cand_kf", C.POINTER(C.c_int32)),
+                ("cand_level", C.POINTER(C.c_int32)), ("cand_px_ref", C.POINTER(C.c_double))]
+
+
 class KltParams(C.Structure):
     _fields_ = [("win", C.c_int), ("max_level", C.c_int), ("max_iter", C.c_int), ("eps", C.c_double),
                 ("min_eig_threshold", C.c_double), ("use_initial_flow", C.c_int)]
@@ -85,7 +92,7 @@ ABI_SYMBOLS = [
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
-    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation",
+    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map",
 ]
 
 _lib = None
@@ -268,6 +275,27 @@ class HipContext:
                                                           _p(level_ref, C.c_int32), _p(px_cur, C.c_double), _p(sl, C.c_int32),
                                                           _p(ok, C.c_uint8), n), "find_direct_projection")
         return ok.astype(bool), px_cur, sl
+
+    def track_local_map(self, cur_slot, T_cur, kf_slot, kf_T, pos_world, point_bad, cand_point, cand_kf, cand_px_ref, cand_level):
+        """LocalMapping::FindCandidates + ProjectMapPoints (LocalMapping.cpp:47-120) -> n, in_view, px_proj, match_cand, px_match, level"""
+        pw = np.ascontiguousarray(pos_world, np.float64).reshape(-1, 3)
+        P = pw.shape[0]
+        bad = None if point_bad is None else np.ascontiguousarray(point_bad, np.uint8)
+        ks = np.ascontiguousarray(kf_slot, np.int32); kT = np.ascontiguousarray(kf_T, np.float64).reshape(-1, 7)
+        cp = np.ascontiguousarray(cand_point, np.int32); ck = np.ascontiguousarray(cand_kf, np.int32)
+        cl = np.ascontiguousarray(cand_level, np.int32); cx = np.ascontiguousarray(cand_px_ref, np.float64).reshape(-1, 2)
+        m = LocalMap(P, _p(pw, C.c_double), _p(bad, C.c_uint8) if bad is not None else None, len(ks), _p(ks, C.c_int32), _p(kT, C.c_double),
+                     len(cp), _p(cp, C.c_int32), _p(ck, C.c_int32), _p(cl, C.c_int32), _p(cx, C.c_double))
+        in_view = np.zeros(P, np.uint8); px_proj = np.zeros((P, 2)); match = np.full(P, -1, np.int32)
+        px_match = np.zeros((P, 2)); lvl = np.zeros(P, np.int32)
+        n = C.c_int32(0)
+        T = (C.c_double * 7)(*[float(x) for x in T_cur])
+        self.lib.ygz_hip_track_local_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(LocalMap), C.POINTER(C.c_uint8),
+                                                     C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                                     C.POINTER(C.c_int32)]
+        self._chk(self.lib.ygz_hip_track_local_map(self._ctx, int(cur_slot), T, C.byref(m), _p(in_view, C.c_uint8), _p(px_proj, C.c_double),
+                                                   _p(match, C.c_int32), _p(px_match, C.c_double), _p(lvl, C.c_int32), C.byref(n)), "track_local_map")
+        return int(n.value), in_view, px_proj, match, px_match, lvl
 
     def align2d(self, cur_slot, level, pwb, uv, n_iter=10):
         pwb = np.ascontiguousarray(pwb, np.uint8).reshape(-1, 100)

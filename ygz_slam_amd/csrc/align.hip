@@ -124,26 +124,17 @@ struct FdpArgs {
     double *px_cur; int32_t *search_level; uint8_t *ok;      // [pairs][cells]
 };
 
-// Matcher::FindDirectProjection (Feature* overload, Matcher.cpp:385-417)
-__global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
+// the body shared by both Matcher::FindDirectProjection overloads (Matcher.cpp:356-417) from Pixel2Camera(px_ref, depth) on:
+// GetWarpAffineMatrix, GetBestSearchLevel, WarpAffine into the lane's LDS column, Align2D, rescale.  px_cur in (prediction) /
+// out (refined, level-0 pixels); returns success && InFrame(px_cur, 10).
+static __device__ __forceinline__ bool fdp_core(const FdpArgs &A, int ref_slot, int cur_slot, const double *Tr7, const double *Tc7,
+                                                const double px_ref[2], double depth, int Lr, uint8_t *pwb, double px_cur[2], int *sl_out)
 {
-    __shared__ uint8_t pwb_all[100 * 64];
-    int bx, pair;
-    if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
-    const int ii = bx * 64 + threadIdx.x;
-    if (ii >= A.trk_n[pair]) return;
-    const size_t i = (size_t)pair * A.cells + ii;
-    const int ref_slot = A.pair_t[pair], cur_slot = A.pair_q[pair];
-    uint8_t *pwb = pwb_all + threadIdx.x;
-    const double depth = A.trk_depth[i];
-    if (depth < 0) { A.ok[i] = 0; A.search_level[i] = 0; return; }
-    const int Lr = A.trk_level[i];
-    const double px_ref[2] = { A.trk_px[2 * i], A.trk_px[2 * i + 1] };
     double pt_ref[3];
     pixel2camera_d(A.cam, px_ref, depth, pt_ref);
     Se3 T_ref, T_cur, Tri, TCR;
-    for (int k = 0; k < 4; ++k) { T_ref.q[k] = A.pair_T[14 * (size_t)pair + k]; T_cur.q[k] = A.pair_T[14 * (size_t)pair + 7 + k]; }
-    for (int k = 0; k < 3; ++k) { T_ref.t[k] = A.pair_T[14 * (size_t)pair + 4 + k]; T_cur.t[k] = A.pair_T[14 * (size_t)pair + 11 + k]; }
+    for (int k = 0; k < 4; ++k) { T_ref.q[k] = Tr7[k]; T_cur.q[k] = Tc7[k]; }
+    for (int k = 0; k < 3; ++k) { T_ref.t[k] = Tr7[4 + k]; T_cur.t[k] = Tc7[4 + k]; }
     se3_inv_d(&T_ref, &Tri);
     se3_mul_d(&T_cur, &Tri, &TCR);
     // GetWarpAffineMatrix (Matcher.cpp:420-436)
@@ -195,13 +186,106 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
     }
     const int cw = A.w[sl], ch = A.h[sl];
     const uint8_t *cur = A.lvl[sl] + (size_t)cur_slot * cw * ch;
-    double u = A.px_cur[2 * i] / (double)(1 << sl), v = A.px_cur[2 * i + 1] / (double)(1 << sl);
+    double u = px_cur[0] / (double)(1 << sl), v = px_cur[1] / (double)(1 << sl);
     const bool good = align2d_core(cur, cw, ch, pwb, 10, &u, &v, nullptr);
     const double ox = u * (double)(1 << sl), oy = v * (double)(1 << sl);
-    A.px_cur[2 * i] = ox; A.px_cur[2 * i + 1] = oy;
-    A.search_level[i] = sl;
+    px_cur[0] = ox; px_cur[1] = oy;
+    *sl_out = sl;
     const bool inframe = ox >= 10 && ox < A.w[0] - 10 && oy >= 10 && oy < A.h[0] - 10;     // Frame::InFrame(px,10)
-    A.ok[i] = (uint8_t)(inframe && good);
+    return inframe && good;
+}
+
+// Matcher::FindDirectProjection (Feature* overload, Matcher.cpp:385-417)
+__global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    int bx, pair;
+    if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
+    const int ii = bx * 64 + threadIdx.x;
+    if (ii >= A.trk_n[pair]) return;
+    const size_t i = (size_t)pair * A.cells + ii;
+    const double depth = A.trk_depth[i];
+    if (depth < 0) { A.ok[i] = 0; A.search_level[i] = 0; return; }
+    const double px_ref[2] = { A.trk_px[2 * i], A.trk_px[2 * i + 1] };
+    double px_cur[2] = { A.px_cur[2 * i], A.px_cur[2 * i + 1] };
+    int sl;
+    const bool ok = fdp_core(A, A.pair_t[pair], A.pair_q[pair], A.pair_T + 14 * (size_t)pair, A.pair_T + 14 * (size_t)pair + 7,
+                             px_ref, depth, A.trk_level[i], pwb_all + threadIdx.x, px_cur, &sl);
+    A.px_cur[2 * i] = px_cur[0]; A.px_cur[2 * i + 1] = px_cur[1];
+    A.search_level[i] = sl;
+    A.ok[i] = (uint8_t)ok;
+}
+
+// ---- LocalMapping::FindCandidates + ProjectMapPoints (src/Module/LocalMapping.cpp:47-120) ----
+struct LmapArgs {
+    FdpArgs F;                                     // levels, sizes, camera (the pair / track members are unused)
+    int cur_slot, P, C, K;
+    const double *T_cur;                           // [7]
+    const double *pos_world; const uint8_t *point_bad;              // [P][3], [P]
+    const int32_t *kf_slot; const double *kf_T;                      // [K], [K][7]
+    const int32_t *cand_point, *cand_kf, *cand_level; const double *cand_px_ref;      // [C]
+    uint8_t *in_view; double *px_proj; int32_t *match_cand; double *px_match; int32_t *match_level;   // [P]
+    double *cand_px; int32_t *cand_sl; uint8_t *cand_ok;             // [C]
+};
+
+// FindCandidates (:47-79), lane = map point: World2Camera, Camera2Pixel, z < 0 or !InFrame(px, 20) -> not in view
+__global__ __launch_bounds__(256) void k_lmap_project(LmapArgs A)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= A.P) return;
+    A.match_cand[p] = 0x7fffffff; A.match_level[p] = 0;
+    A.px_match[2 * p] = 0.0; A.px_match[2 * p + 1] = 0.0;
+    double px[2] = { 0.0, 0.0 };
+    bool vis = false;
+    if (!(A.point_bad && A.point_bad[p])) {
+        Se3 T;
+        for (int k = 0; k < 4; ++k) T.q[k] = A.T_cur[k];
+        for (int k = 0; k < 3; ++k) T.t[k] = A.T_cur[4 + k];
+        const double pw[3] = { A.pos_world[3 * (size_t)p], A.pos_world[3 * (size_t)p + 1], A.pos_world[3 * (size_t)p + 2] };
+        double pc[3];
+        se3_act_d(&T, pw, pc);
+        camera2pixel_d(A.F.cam, pc, px);
+        vis = !(pc[2] < 0) && px[0] >= 20 && px[0] < A.F.w[0] - 20 && px[1] >= 20 && px[1] < A.F.h[0] - 20;
+    }
+    A.px_proj[2 * p] = px[0]; A.px_proj[2 * p + 1] = px[1];
+    A.in_view[p] = (uint8_t)vis;
+}
+
+// ProjectMapPoints (:81-120), lane = candidate: every candidate of an in-view point is refined (the reference skips the
+// candidates that follow a point's first success -- their result is never used, so evaluating them changes nothing);
+// the first success in candidate order is kept with an integer atomicMin on the candidate index.
+__global__ __launch_bounds__(64) void k_lmap_match(LmapArgs A)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= A.C) return;
+    const int p = A.cand_point[c], kf = A.cand_kf[c];
+    A.cand_ok[c] = 0; A.cand_sl[c] = 0;
+    if (p < 0 || p >= A.P || kf < 0 || kf >= A.K || !A.in_view[p]) return;
+    const double *Tr7 = A.kf_T + 7 * (size_t)kf;
+    Se3 T;
+    for (int k = 0; k < 4; ++k) T.q[k] = Tr7[k];
+    for (int k = 0; k < 3; ++k) T.t[k] = Tr7[4 + k];
+    const double pw[3] = { A.pos_world[3 * (size_t)p], A.pos_world[3 * (size_t)p + 1], A.pos_world[3 * (size_t)p + 2] };
+    double pr[3];
+    se3_act_d(&T, pw, pr);                                   // depth = World2Camera(mp->_pos_world, ref->_TCW)[2] (Matcher.cpp:362), sign not tested
+    const double px_ref[2] = { A.cand_px_ref[2 * (size_t)c], A.cand_px_ref[2 * (size_t)c + 1] };
+    double px_cur[2] = { A.px_proj[2 * p], A.px_proj[2 * p + 1] };
+    int sl;
+    const bool ok = fdp_core(A.F, A.kf_slot[kf], A.cur_slot, Tr7, A.T_cur, px_ref, pr[2], A.cand_level[c], pwb_all + threadIdx.x, px_cur, &sl);
+    A.cand_px[2 * (size_t)c] = px_cur[0]; A.cand_px[2 * (size_t)c + 1] = px_cur[1];
+    A.cand_sl[c] = sl; A.cand_ok[c] = (uint8_t)ok;
+    if (ok) atomicMin(&A.match_cand[p], c);
+}
+
+__global__ __launch_bounds__(256) void k_lmap_gather(LmapArgs A)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= A.P) return;
+    const int c = A.match_cand[p];
+    if (c == 0x7fffffff) { A.match_cand[p] = -1; return; }
+    A.px_match[2 * p] = A.cand_px[2 * (size_t)c]; A.px_match[2 * p + 1] = A.cand_px[2 * (size_t)c + 1];
+    A.match_level[p] = A.cand_sl[c];
 }
 
 __global__ __launch_bounds__(64) void k_align2d(const uint8_t *__restrict__ cur, int w, int h,
@@ -287,6 +371,72 @@ int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pw
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, d_ok, N, hipMemcpyDeviceToHost, ctx->stream));
     if (chi2) YGZ_HIPCHK(ctx, hipMemcpyAsync(chi2, d_chi, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+// one call = LocalMapping::FindCandidates + ProjectMapPoints for the current frame against K resident keyframes
+int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
+                            uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level, int32_t *n_matched)
+{
+    if (!ctx || !T_cur || !m || m->n_points < 0 || m->n_keyframes < 0 || m->n_candidates < 0) return YGZ_E_INVALID;
+    if (cur_slot < 0 || cur_slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (!ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
+    const int P = m->n_points, K = m->n_keyframes, Cn = m->n_candidates;
+    if (n_matched) *n_matched = 0;
+    if (P == 0) return YGZ_OK;
+    if (!m->pos_world || !in_view || !px_proj || !match_cand || !px_match || !match_level) return YGZ_E_INVALID;
+    if (K > 0 && (!m->kf_slot || !m->kf_T)) return YGZ_E_INVALID;
+    if (Cn > 0 && (!m->cand_point || !m->cand_kf || !m->cand_level || !m->cand_px_ref || K == 0)) return YGZ_E_INVALID;
+    for (int i = 0; i < K; ++i) {
+        if (m->kf_slot[i] < 0 || m->kf_slot[i] >= ctx->prm.max_frames) return YGZ_E_INVALID;
+        if (!ctx->pyr_valid[m->kf_slot[i]]) return YGZ_E_STATE;
+    }
+    for (int i = 0; i < Cn; ++i) if (m->cand_level[i] < 0 || m->cand_level[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
+    const size_t Ps = (size_t)P, Ks = (size_t)K, Cs = (size_t)Cn;
+    const size_t nd = 8 + 3 * Ps + 7 * Ks + 2 * Cs + 2 * Ps + 2 * Ps + 2 * Cs, ni = Ks + 3 * Cs + 2 * Ps + Cs, nb = 2 * Ps + Cs;
+    uint8_t *buf = nullptr;
+    int rc = ygz_scratch(ctx, SCR_LMAP, nd * 8 + ni * 4 + nb + 64, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    double *d_T = (double *)buf, *d_pw = d_T + 8, *d_kfT = d_pw + 3 * Ps, *d_cpx = d_kfT + 7 * Ks, *d_proj = d_cpx + 2 * Cs,
+           *d_pm = d_proj + 2 * Ps, *d_candpx = d_pm + 2 * Ps;
+    int32_t *d_kfs = (int32_t *)(d_candpx + 2 * Cs), *d_cp = d_kfs + Ks, *d_ck = d_cp + Cs, *d_cl = d_ck + Cs, *d_mc = d_cl + Cs,
+            *d_ml = d_mc + Ps, *d_csl = d_ml + Ps;
+    uint8_t *d_bad = (uint8_t *)(d_csl + Cs), *d_vis = d_bad + Ps, *d_cok = d_vis + Ps;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_T, T_cur, 56, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pw, m->pos_world, Ps * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (m->point_bad) YGZ_HIPCHK(ctx, hipMemcpyAsync(d_bad, m->point_bad, Ps, hipMemcpyHostToDevice, ctx->stream));
+    if (K) {
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_kfT, m->kf_T, Ks * 56, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_kfs, m->kf_slot, Ks * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (Cn) {
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cpx, m->cand_px_ref, Cs * 16, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cp, m->cand_point, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_ck, m->cand_kf, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cl, m->cand_level, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    LmapArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
+    A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 0;
+    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr;
+    A.F.px_cur = nullptr; A.F.search_level = nullptr; A.F.ok = nullptr;
+    A.cur_slot = cur_slot; A.P = P; A.C = Cn; A.K = K; A.T_cur = d_T;
+    A.pos_world = d_pw; A.point_bad = m->point_bad ? d_bad : nullptr; A.kf_slot = d_kfs; A.kf_T = d_kfT;
+    A.cand_point = d_cp; A.cand_kf = d_ck; A.cand_level = d_cl; A.cand_px_ref = d_cpx;
+    A.in_view = d_vis; A.px_proj = d_proj; A.match_cand = d_mc; A.px_match = d_pm; A.match_level = d_ml;
+    A.cand_px = d_candpx; A.cand_sl = d_csl; A.cand_ok = d_cok;
+    YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_project, dim3(ygz_div_up(P, 256)), dim3(256), A);
+    if (Cn) YGZ_LAUNCH(ctx, KID_LMAP_MATCH, k_lmap_match, dim3(ygz_div_up(Cn, 64)), dim3(64), A);
+    YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_gather, dim3(ygz_div_up(P, 256)), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(in_view, d_vis, Ps, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_proj, d_proj, Ps * 16, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(match_cand, d_mc, Ps * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_match, d_pm, Ps * 16, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(match_level, d_ml, Ps * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_matched) { int n = 0; for (int p = 0; p < P; ++p) n += match_cand[p] >= 0; *n_matched = n; }
     return YGZ_OK;
 }
 

@@ -209,7 +209,7 @@ int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
 static const char *const k_kernel_names[KID_COUNT] = {
     "k_bgr2gray", "k_pyr_down", "k_fast_select", "k_compact", "k_describe", "k_hamming_nn", "k_match_finalize", "k_track_load",
     "k_find_direct_projection", "k_align2d", "k_sparse_align", "k_scharr", "k_klt", "k_klt_pad", "k_ba_pose_prep", "k_ba_points", "k_ba_final",
-    "k_ba_chi2", "k_pose_only_ba", "k_ba_lm", "k_bow_transform", "k_bow_match", "k_depth_from_triangulation" };
+    "k_ba_chi2", "k_pose_only_ba", "k_ba_lm", "k_bow_transform", "k_bow_match", "k_depth_from_triangulation", "k_lmap_match", "k_lmap_aux" };
 
 int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launches)
 {

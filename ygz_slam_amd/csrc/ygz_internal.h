@@ -104,7 +104,7 @@ static inline int ygz_div_up(int a, int b) { return (a + b - 1) / b; }
 // kernel ids for the probe
 enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIBE, KID_HAMMING_NN, KID_MATCH_FINALIZE,
        KID_TRACK_LOAD, KID_FDP, KID_ALIGN2D, KID_SPARSE_ALIGN, KID_SCHARR, KID_KLT, KID_KLT_PAD, KID_BA_POSE_PREP, KID_BA_POINTS,
-       KID_BA_POSES, KID_BA_CHI2, KID_POSE_ONLY, KID_BA_LM, KID_BOW_TRANSFORM, KID_BOW_MATCH, KID_DEPTH_TRI, KID_COUNT };
+       KID_BA_POSES, KID_BA_CHI2, KID_POSE_ONLY, KID_BA_LM, KID_BOW_TRANSFORM, KID_BOW_MATCH, KID_DEPTH_TRI, KID_LMAP_MATCH, KID_LMAP_AUX, KID_COUNT };
 
 #define YGZ_LAUNCH(ctx, kid, kern, grid, block, ...)                                                         \
     do { const bool pr_ = (ctx)->probe_id == (kid) && (ctx)->probe_used + 2 <= (int)(ctx)->probe_ev.size();    \
@@ -114,7 +114,7 @@ enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIB
 
 // scratch ids
 enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR_SA_OUT, SCR_SA_WORK,
-       SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_GEN_0 = 16 };
+       SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_LMAP, SCR_GEN_0 = 16 };
 
 int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
 int ygz_join(ygz_hip_ctx *ctx);          // main stream waits for every pending side-stream stage

@@ -585,6 +585,59 @@ bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector
     return ok[0];
 }
 
+int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_keyframes, const std::set<MapPoint *> &local_map_points)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    vector<Frame *> kfs(local_keyframes.begin(), local_keyframes.end());
+    map<Frame *, int> kf_index;
+    vector<int32_t> kf_slot; vector<double> kf_T;
+    for (Frame *f : kfs) {
+        kf_index[f] = (int)kf_slot.size();
+        kf_slot.push_back(rt.Resident(f));
+        double t7[7]; f->_TCW.to7(t7); kf_T.insert(kf_T.end(), t7, t7 + 7);
+    }
+    vector<MapPoint *> mps(local_map_points.begin(), local_map_points.end());
+    vector<double> pos; vector<uint8_t> bad;
+    vector<int32_t> cp, ck, cl; vector<double> cpx; vector<Feature *> cfea;
+    for (size_t p = 0; p < mps.size(); ++p) {
+        MapPoint *mp = mps[p];
+        pos.push_back(mp->_pos_world[0]); pos.push_back(mp->_pos_world[1]); pos.push_back(mp->_pos_world[2]);
+        bad.push_back(mp->_bad ? 1 : 0);
+        if (mp->_bad) continue;
+        for (auto &obs : mp->_obs) {                                   // LocalMapping.cpp:66-75
+            Feature *fea = obs.second;
+            auto it = fea ? kf_index.find(fea->_frame) : kf_index.end();
+            if (it == kf_index.end()) continue;
+            cp.push_back((int32_t)p); ck.push_back(it->second); cl.push_back(fea->_level);
+            cpx.push_back(fea->_pixel[0]); cpx.push_back(fea->_pixel[1]); cfea.push_back(fea);
+        }
+    }
+    const int P = (int)mps.size();
+    if (P == 0) return 0;
+    ygz_local_map m;
+    m.n_points = P; m.pos_world = pos.data(); m.point_bad = bad.data();
+    m.n_keyframes = (int)kf_slot.size(); m.kf_slot = kf_slot.data(); m.kf_T = kf_T.data();
+    m.n_candidates = (int)cp.size(); m.cand_point = cp.data(); m.cand_kf = ck.data(); m.cand_level = cl.data(); m.cand_px_ref = cpx.data();
+    vector<uint8_t> in_view(P); vector<double> px_proj(2 * (size_t)P), px_match(2 * (size_t)P); vector<int32_t> match(P), level(P);
+    double Tc[7]; current->_TCW.to7(Tc);
+    int32_t n = 0;
+    hip::check(ygz_hip_track_local_map(rt.ctx(), rt.Resident(current), Tc, &m, in_view.data(), px_proj.data(), match.data(), px_match.data(),
+                                       level.data(), &n), "track_local_map");
+    for (int p = 0; p < P; ++p) {
+        MapPoint *mp = mps[p];
+        if (mp->_bad) continue;
+        if (!in_view[p]) { mp->_track_in_view = false; continue; }     // :59-62
+        mp->_cnt_visible++;                                            // :64
+        if (match[p] < 0) continue;
+        Feature *src = cfea[match[p]];
+        Feature *feature = new Feature(Vector2d(px_match[2 * p], px_match[2 * p + 1]), level[p], src->_score);   // :104-111
+        feature->_frame = current;
+        feature->_mappoint = mp;
+        current->_features.push_back(feature);
+    }
+    return (int)n;
+}
+
 bool Matcher::SparseImageAlignment(Frame *ref, Frame *current)
 {
     current->_TCW = ref->_TCW;
