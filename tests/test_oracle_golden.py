@@ -269,6 +269,51 @@ def test_align_golden(oracle):
     assert np.array_equal(kp, g["klt_pts"]) and np.array_equal(kst, g["klt_status"]) and np.array_equal(kerr, g["klt_err"])
 
 
+def test_track_local_map_structure(oracle):
+    """yo_track_local_map (LocalMapping.cpp:47-120) = frustum filter + per-candidate MapPoint-overload FindDirectProjection with
+    the first success per point; checked against single calls, and the MapPoint overload against the Feature overload."""
+    g = golden("align")
+    e = golden("extract")
+    lv0, lv1 = oracle.pyramid(e["imgs"][0], 3), oracle.pyramid(e["imgs"][1], 3)
+    T_ref, T_cur = e["poses"][0], e["poses"][1]
+    n = 120
+    px_ref, depth, level = g["px_ref"][:n], g["depth"][:n], g["level"][:n].astype(np.int32)
+    keep = depth > 0
+    px_ref, depth, level = px_ref[keep], depth[keep], level[keep]
+    n = len(depth)
+    Twc = oracle.se3_inv(T_ref)
+    pc = np.stack([(px_ref[:, 0] - synth.CX) / synth.FX * depth, (px_ref[:, 1] - synth.CY) / synth.FY * depth, depth], 1)
+    pos = pc @ synth.quat_to_R(Twc[:4]).T + Twc[4:]
+    bad = np.zeros(n, np.uint8); bad[1] = 1
+    # two candidates per point: a deliberately wrong observation first (pixel far from the true one), then the right one
+    cp = np.repeat(np.arange(n), 2).astype(np.int32)
+    cx = np.repeat(px_ref, 2, axis=0); cx[0::2] += [37.0, -23.0]
+    cl = np.repeat(level, 2).astype(np.int32)
+    cnt, vis, proj, match, pxm, lvl = oracle.track_local_map([lv0], [T_ref], lv1, T_cur, pos, bad, cp, np.zeros(2 * n, np.int32), cx, cl)
+    assert vis[1] == 0 and match[1] == -1 and cnt == (match >= 0).sum() and cnt > 0.4 * n
+    second = 0
+    for p in range(n):
+        if not vis[p]:
+            assert match[p] == -1
+            continue
+        want = -1
+        for c in (2 * p, 2 * p + 1):
+            ok, px, sl = oracle.find_direct_projection_mp(lv0, T_ref, lv1, T_cur, pos[p], cx[c], int(cl[c]), proj[p])
+            if ok:
+                want = c
+                assert np.array_equal(px, pxm[p]) and sl == lvl[p]
+                break
+        assert match[p] == want
+        second += want == 2 * p + 1
+    assert second > 0.3 * n                                  # the wrong observation fails, the right one is taken
+    # MapPoint overload == Feature overload given the same depth (z of the point in the reference keyframe)
+    for p in range(0, n, 5):
+        z = (synth.quat_to_R(np.asarray(T_ref)[:4]) @ pos[p] + np.asarray(T_ref)[4:])[2]
+        a = oracle.find_direct_projection_mp(lv0, T_ref, lv1, T_cur, pos[p], px_ref[p], int(level[p]), proj[p])
+        b = oracle.find_direct_projection(lv0, T_ref, lv1, T_cur, px_ref[p], z, int(level[p]), proj[p])
+        assert a[0] == b[0] and a[2] == b[2] and np.allclose(a[1], b[1], rtol=0, atol=1e-6)
+
+
 def test_align2d_recovers_known_shift(oracle):
     rng = np.random.default_rng(9)
     yy, xx = np.mgrid[0:80, 0:96]
