@@ -134,6 +134,14 @@ __device__ __forceinline__ int klt_dot2(uint32_t a, uint32_t b, int acc)
 { return __builtin_amdgcn_sdot2(__builtin_bit_cast(klt_s2, a), __builtin_bit_cast(klt_s2, b), acc, false); }
 #define KLT_PAIR(lo, hi, k) __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | ((uint32_t)((k) + 1) << 16) | (uint32_t)(k))
 #define KLT_BIL9P(l0, h0, l1, h1, k) (klt_dot2(KLT_PAIR(l1, h1, k), wbot, klt_dot2(KLT_PAIR(l0, h0, k), wtop, 256)) >> 9)
+// the same minus a patch value, with the subtraction folded into the accumulator: c = 256 - (I << 9), and
+// (S + 256 - 512 I) >> 9 == ((S + 256) >> 9) - I for the arithmetic shift
+// (the compiler only selects the two-address v_dot2c, which would need a copy of c first: the three-address VOP3P form by hand)
+__device__ __forceinline__ int klt_dot2_keep(uint32_t a, uint32_t b, int acc)
+{ int d; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc)); return d; }
+__device__ __forceinline__ int klt_dot2_sacc(uint32_t a, uint32_t b, int acc /* wave-uniform */)
+{ int d; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(acc)); return d; }
+#define KLT_DIFF9P(l0, h0, l1, h1, k, c) (klt_dot2(KLT_PAIR(l1, h1, k), wbot, klt_dot2_keep(KLT_PAIR(l0, h0, k), wtop, (c))) >> 9)
 #define KLT_DXP(a, b) __builtin_amdgcn_perm((b), (a), 0x05040100u)
 #define KLT_DYP(a, b) __builtin_amdgcn_perm((b), (a), 0x07060302u)
 #define KLT_WEIGHTS(a, b)                                                                        \
@@ -357,9 +365,9 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
         KLT_WEIGHTS(a, b);
         // the lane's 3 x 7 patch values stay in registers for the whole level: image << 5, and the derivatives of two
         // consecutive pixels per register (dx_k | dx_k+1 << 16, same for dy) -- the layout v_dot2 wants for the mismatch sums
-        int iI[21]; uint32_t pDx[11], pDy[11];
+        int cI[21]; uint32_t pDx[11], pDy[11];                      // cI = 256 - (patch value << 9), see KLT_DIFF9P
 #pragma unroll
-        for (int k = 0; k < 21; ++k) iI[k] = 0;
+        for (int k = 0; k < 21; ++k) cI[k] = 256;
 #pragma unroll
         for (int k = 0; k < 11; ++k) { pDx[k] = 0u; pDy[k] = 0u; }
         float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
@@ -376,12 +384,12 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
                 for (int kk = 0; kk < 8; ++kk) { d0[kk] = D[o + r * pw + kk]; d1[kk] = D[o + (r + 1) * pw + kk]; }
 #pragma unroll
                 for (int kk = 0; kk < 7; ++kk) {
-                    const int ival = KLT_BIL9P(il[r], ih[r], il[r + 1], ih[r + 1], kk);
-                    const int ixval = klt_dot2(KLT_DXP(d1[kk], d1[kk + 1]), wbot, klt_dot2(KLT_DXP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
-                    const int iyval = klt_dot2(KLT_DYP(d1[kk], d1[kk + 1]), wbot, klt_dot2(KLT_DYP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
+                    const int ival = klt_dot2(KLT_PAIR(il[r + 1], ih[r + 1], kk), wbot, klt_dot2_sacc(KLT_PAIR(il[r], ih[r], kk), wtop, 256)) >> 9;
+                    const int ixval = klt_dot2(KLT_DXP(d1[kk], d1[kk + 1]), wbot, klt_dot2_sacc(KLT_DXP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
+                    const int iyval = klt_dot2(KLT_DYP(d1[kk], d1[kk + 1]), wbot, klt_dot2_sacc(KLT_DYP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
                     const int sx = (int)(int16_t)ixval, sy = (int)(int16_t)iyval;
                     const int li = 7 * r + kk;
-                    iI[li] = (int)(int16_t)ival;
+                    cI[li] = 256 - ((int)(int16_t)ival << 9);
                     if (li & 1) { pDx[li >> 1] |= (uint32_t)sx << 16; pDy[li >> 1] |= (uint32_t)sy << 16; }
                     else { pDx[li >> 1] = (uint32_t)sx & 0xffffu; pDy[li >> 1] = (uint32_t)sy & 0xffffu; }
                     q11 += __mul24(sx, sx); q12 += __mul24(sx, sy); q22 += __mul24(sy, sy);
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                    for (int kk = 0; kk < 7; ++kk) df[7 * r + kk] = KLT_BIL9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk) - iI[7 * r + kk];
+                    for (int kk = 0; kk < 7; ++kk) df[7 * r + kk] = KLT_DIFF9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk, cI[7 * r + kk]);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 11; ++kk) {                    // (diff_2k, diff_2k+1) . (dx_2k, dx_2k+1): |diff| < 2^14 fits int16
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
                     for (int kk = 0; kk < 7; ++kk) {
-                        const int diff = KLT_BIL9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk) - iI[7 * r + kk];
+                        const int diff = KLT_DIFF9P(jl[r], jh[r], jl[r + 1], jh[r + 1], kk, cI[7 * r + kk]);
                         se = __fadd_rn(se, fabsf((float)diff));
                     }
                 }
