@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("stage")
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--probe", default="", help="comma-separated kernel names: HIP-event time of each kernel's launches in one run of the stage")
 a = ap.parse_args()
 p = bench.Pipeline(a.batch, 0, 0)
 p.setup()
@@ -24,3 +25,7 @@ ts = []
 for _ in range(a.reps):
     c.timer_begin(); fn(); ts.append(c.timer_end())
 print("%s batch %d: %s ms  (min %.3f)" % (a.stage, a.batch, " ".join("%.3f" % t for t in ts), min(ts)))
+for name in [x for x in a.probe.split(",") if x]:
+    c.probe_begin(name); fn(); c.synchronize()
+    ms, n = c.probe_end()
+    print("  %s: %d launches, %.3f ms total" % (name, n, ms))
