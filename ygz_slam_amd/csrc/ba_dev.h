@@ -55,6 +55,14 @@ const BaDev *ygz_ba_table(ygz_hip_ctx *ctx, int *rc);        // device table of 
 // element k of row `row` for lane `lane` in a chunked per-edge array with NC components
 #define BA_EC(base, row, NC, k, lane) ((base)[(((size_t)(row) * (NC)) + (k)) * 64 + (lane)])
 // element k of point l in a chunked per-point array with NC components
+// the per-edge outputs are written once and read by a later kernel: streaming stores
+#ifdef YGZ_BA_PLAIN_STORES
+#define BA_ST(p, v) (*(p) = (v))
+#define BA_LD(p) (*(p))
+#else
+#define BA_LD(p) (*(p))      /* the inputs are read again by the pose pass: streaming loads measured 15 % slower */
+#define BA_ST(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 #define BA_PC(base, l, NC, k) ((base)[((size_t)((l) >> 6) * (NC) + (k)) * 64 + ((l) & 63)])
 
 // SE3::exp once per pose instead of once per edge: (q, t, R) and, for the ceres formulation, J_l
@@ -183,8 +191,8 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
     // the inputs of row c + 1 are in flight while row c is computed (the loop is a chain of dependent loads otherwise)
     int n_ip = -1, n_en = 0; double n_ox = 0, n_oy = 0, n_hub = 0;
 #define BA_FETCH_(row_)                                                                                          \
-    { n_ip = B.pose_c[(size_t)(row_) * 64 + lane]; n_en = B.enable_c[(size_t)(row_) * 64 + lane];                \
-      n_ox = BA_EC(B.obs_c, row_, 2, 0, lane); n_oy = BA_EC(B.obs_c, row_, 2, 1, lane); n_hub = B.huber_c[(size_t)(row_) * 64 + lane]; }
+    { n_ip = BA_LD(&B.pose_c[(size_t)(row_) * 64 + lane]); n_en = BA_LD(&B.enable_c[(size_t)(row_) * 64 + lane]);  \
+      n_ox = BA_LD(&BA_EC(B.obs_c, row_, 2, 0, lane)); n_oy = BA_LD(&BA_EC(B.obs_c, row_, 2, 1, lane)); n_hub = BA_LD(&B.huber_c[(size_t)(row_) * 64 + lane]); }
     if (rows > 0) BA_FETCH_(row0)
     for (int c = 0; c < rows; ++c) {
         const int row = row0 + c, ip = n_ip, en = n_en;
@@ -217,7 +225,7 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
         const double e2 = r[0] * r[0] + r[1] * r[1];
         double rho0, rho1;
         ba_robust(e2, hub, &rho0, &rho1);
-        BA_EC(B.err_c, row, 2, 0, lane) = r[0]; BA_EC(B.err_c, row, 2, 1, lane) = r[1];
+        BA_ST(&BA_EC(B.err_c, row, 2, 0, lane), r[0]); BA_ST(&BA_EC(B.err_c, row, 2, 1, lane), r[1]);
         B.chi2e_c[(size_t)row * 64 + lane] = e2; chi_sum += rho0;
         if (!lfree) { for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0; continue; }   // constant point: no point / cross block
         for (int a = 0; a < 3; ++a) {
@@ -229,7 +237,7 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
             double Jx[12];
             ba_pose_jac(B.formulation, x, y, z, B.fx, B.fy, pd, Jx);
             for (int a = 0; a < 6; ++a) for (int b = 0; b < 3; ++b)
-                BA_EC(B.Hpl_c, row, 18, 3 * a + b, lane) = rho1 * (Jx[a] * Jp[b] + Jx[6 + a] * Jp[3 + b]);
+                BA_ST(&BA_EC(B.Hpl_c, row, 18, 3 * a + b, lane), rho1 * (Jx[a] * Jp[b] + Jx[6 + a] * Jp[3 + b]));
         }
     }
 #undef BA_FETCH_
