@@ -95,10 +95,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
     uint8_t *prev_used = (uint8_t *)(dxy + 32 * (size_t)A.cells);       // [cells] the feature is part of the running H
     float *patch_cache = (float *)((double *)wk + 96 * (size_t)A.cells);   // [cells][16]
     float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [4][cells] float4: the squared residuals (chain terms)
-    float *ssq = r2 + 16 * (size_t)A.cells;                             // [cells] sum of the feature's 16 squares (binade prediction only)
-    float *pre = ssq + A.cells;                                         // [cells] predicted chain value at the start of the feature
-    int4 *fmap = reinterpret_cast<int4 *>(pre + A.cells);               // [cells] 16-term parity map of the feature: t0, t1, E, bad
-    uint8_t *visible = (uint8_t *)(fmap + A.cells);                     // [cells]
+    float *ctot = r2 + 16 * (size_t)A.cells;                            // [cells / 64] sum of the squares of a chunk of 64 features (binade prediction only)
+    float *pre = ctot + A.cells;                                        // [cells] the same for the features before f in its chunk
+    int4 *fmap = reinterpret_cast<int4 *>(pre + A.cells);               // [cells] 16-term parity map of the feature: t0, t1, E, bad | head << 1
+    int2 *pmap = reinterpret_cast<int2 *>(fmap + A.cells);              // [cells] map of the features from the head of f's segment to f
+    uint8_t *visible = (uint8_t *)(pmap + A.cells);                     // [cells]
     uint8_t *used = visible + A.cells;                                  // [cells] feature contributes this iteration
     Se3 T_ref;
     for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
@@ -225,7 +226,10 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
             for (int k = 0; k < 27; ++k) acc[k] = 0.0;
             const double fl = (double)((A.fx + A.fy) / 2) / (double)(1 << level);
 #pragma unroll 1
-            for (int f = tid; f < n; f += SA_THREADS) {
+            for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {             // uniform trip count: the chunk scan below needs whole wavefronts
+                const int f = f0_ + tid;
+                float sq = 0.f;
+                if (f < n) {
                 float res[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) res[k] = 0.f;
@@ -261,10 +265,9 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
                         }
                     }
                 }
-                float xs[16], sq = 0.f;
+                float xs[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
-                ssq[f] = sq;
                 float4 *dst = reinterpret_cast<float4 *>(r2);          // the chain terms, quarter-major: lanes write 1 KB contiguous per store
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dst[(size_t)k * A.cells + f] = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
@@ -287,6 +290,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
                     for (int k = 0; k < 6; ++k)                                          // Jres_ -= J * res (:210), J = (dx fj0 + dy fj1) fl
                         acc[21 + k] -= (fjc[12 * (size_t)f + k] * gA + fjc[12 * (size_t)f + 6 + k] * gB) * fl;
                 }
+                }   // f < n
+                // approximate value of the chi2 chain at the start of the feature, relative to its chunk of 64 (= this wavefront)
+                const float incl = ygz_wave_scan_f(sq);
+                if (f < n) pre[f] = incl - sq;
+                if (lane == 63) ctot[f >> 6] = incl;
             }
 #undef BIL
 #pragma unroll
@@ -299,106 +307,121 @@ __global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
             }
             __syncthreads();
             SA_PHASE(1);      // residual pass
-            // ---- chain, step 1 (wave 0): predicted value of the chi2 chain at the start of every feature = exclusive prefix of the
-            // approximate per-feature sums (only the binade is taken from it; a wrong guess costs a term-by-term fallback)
-            if (wv == 0) {
-                float base = 0.f;
-                for (int j = 0; j < ((n + 63) >> 6); ++j) {
-                    const int f = 64 * j + lane;
-                    const float v = f < n ? ssq[f] : 0.f;
-                    const float incl = ygz_wave_scan_f(v);
-                    if (f < n) pre[f] = base + (incl - v);
-                    base += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(incl), 63));
-                }
-            }
-            __syncthreads();
-            // ---- chain, step 2 (all lanes): the 16-term map of every feature for its predicted binade, integer ALU only
-            for (int f = tid; f < n; f += SA_THREADS) {
-                const float4 *src = reinterpret_cast<const float4 *>(r2) + f;
-                const float4 a0 = src[0], a1 = src[A.cells], a2 = src[2 * (size_t)A.cells], a3 = src[3 * (size_t)A.cells];
-                const float x[16] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
-                const int E = (int)(__float_as_uint(pre[f]) >> 23);
-                int t0 = 0, t1 = 0, bad = !(E > 0 && E < 255);
+            // ---- chain, step 1 (all lanes, lane = feature, wavefront = chunk of 64): the 16-term map of every feature for its
+            // predicted binade (integer ALU only), then a SEGMENTED scan of the maps along the chunk: a segment = a run of
+            // features with the same predicted binade and usable maps; after the scan a lane holds the map of everything from
+            // the head of its segment up to itself ((A then B)(p) = A(p) + B((p + A(p)) & 1), associative).
+            for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {
+                const int chunk = (f0_ >> 6) + wv;
+                if (64 * chunk >= n) continue;                                // wave-uniform
+                const int f = f0_ + tid, cnt = min(64, n - 64 * chunk);
+                float part = 0.f;
+                for (int c2 = lane; c2 < chunk; c2 += 64) part += ctot[c2];
+                const float base = ygz_wave_sum_f(part);
+                int t0 = 0, t1 = 0, bad = 0, E = 0;
+                if (f < n) {
+                    const float4 *src = reinterpret_cast<const float4 *>(r2) + f;
+                    const float4 a0 = src[0], a1 = src[A.cells], a2 = src[2 * (size_t)A.cells], a3 = src[3 * (size_t)A.cells];
+                    const float x[16] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
+                    E = (int)(__float_as_uint(base + pre[f]) >> 23);
+                    bad = !(E > 0 && E < 255);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
-                fmap[f] = make_int4(t0, t1, E, bad);
+                    for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
+                }
+                if (lane >= cnt) E = __builtin_amdgcn_readlane(E, cnt - 1);   // past the end: the empty map in the last feature's binade
+                const int prev = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, E | (bad << 16));
+                const int head = (lane == 0) | (prev != (E | (bad << 16))) | bad;      // bad features stand alone
+                int p0 = t0, p1 = t1, hd = head;
+#define SA_SCAN(ctrl, rmask, valid)                                                                                  \
+                { const int l0_ = __builtin_amdgcn_update_dpp(0, p0, (ctrl), (rmask), 0xF, false),                   \
+                            l1_ = __builtin_amdgcn_update_dpp(0, p1, (ctrl), (rmask), 0xF, false),                   \
+                            lh_ = __builtin_amdgcn_update_dpp(0, hd, (ctrl), (rmask), 0xF, false);                   \
+                  if (valid) { if (!hd) { const int n0_ = l0_ + ((l0_ & 1) ? p1 : p0), n1_ = l1_ + (((1 + l1_) & 1) ? p1 : p0); \
+                                          p0 = min(n0_, 0x10000000); p1 = min(n1_, 0x10000000); }                    \
+                               hd |= lh_; } }
+                SA_SCAN(0x111, 0xF, (lane & 15) >= 1) SA_SCAN(0x112, 0xF, (lane & 15) >= 2)
+                SA_SCAN(0x114, 0xF, (lane & 15) >= 4) SA_SCAN(0x118, 0xF, (lane & 15) >= 8)
+                SA_SCAN(0x142, 0xA, (lane & 16) != 0)                          // row_bcast:15 -> rows 1, 3
+                SA_SCAN(0x143, 0xC, lane >= 32)                                // row_bcast:31 -> rows 2, 3
+#undef SA_SCAN
+                if (f < n) { fmap[f] = make_int4(t0, t1, E, bad | (head << 1)); pmap[f] = make_int2(p0, p1); }
             }
             __syncthreads();
-            SA_PHASE(13);     // prefix + maps
+            SA_PHASE(13);     // maps + scan
             if (wv == 0) {
-                // ---- wave 0: chi2 = the reference's FLOAT sum of res*res in feature/pixel order (a skipped feature
-                // contributes 0.0f + ... exactly), evaluated through the group maps described at sa_chain_term.
-                // lane = feature (64 per pass, coalesced 16-byte loads of the residuals); the 16-term feature maps are composed
-                // along the lanes into quad maps (64 terms) and hex maps (256 terms); the wave then walks hex -> quad -> terms.
+                // ---- wave 0: chi2 = the reference's FLOAT sum of res*res in feature/pixel order (a skipped feature contributes
+                // 0.0f + ... exactly), walked segment by segment: if c is in the segment's binade and the whole segment stays in it,
+                // ONE integer add replaces 16 x (features of the segment) dependent float adds; if the segment leaves the binade the
+                // crossing feature is found with one ballot (increments are monotone), the features before it are taken at once,
+                // and only its own 16 terms are added one by one in hardware floats.  Either way the result is the reference's float.
                 uint32_t cb = 0u;                                            // bits of c, wave-uniform
                 const int J = (n + 63) >> 6;
-                float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: pass j + 1 is in flight
-                int4 nm = make_int4(0, 0, 0, 0);
+                float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: chunk j + 1 is in flight
+                int4 nm = make_int4(0, 0, 0, 0); int2 np = make_int2(0, 0);
                 if (lane < n) {
                     const float4 *src = reinterpret_cast<const float4 *>(r2) + lane;
-                    n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells]; nm = fmap[lane];
+                    n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells]; nm = fmap[lane]; np = pmap[lane];
                 }
-                for (int j = 0; j < J; ++j) {
-                    SA_PHASE(12);
-                    float x[16] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w };
-                    {
-                        const int fn = 64 * (j + 1) + lane;
-                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0;
-                        if (fn < n) {
-                            const float4 *src = reinterpret_cast<const float4 *>(r2) + fn;
-                            n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells];
-                        }
-                    }
-                    int t0 = nm.x, t1 = nm.y, E = nm.z, bad = nm.w;      // the feature's map (lanes past the end: the empty map of any binade)
-                    {
-                        const int fn = 64 * (j + 1) + lane;
-                        nm = make_int4(0, 0, 0, 0);
-                        if (fn < n) nm = fmap[fn];
-                    }
-                    if (64 * j + lane >= n) E = __builtin_amdgcn_readlane(E, (n - 1) & 63);      // only in the last pass: the binade of the last feature
-                    // compose along the lanes: (A then B)(p) = A(p) + B((p + A(p)) & 1); a group is usable only inside one binade
-#define SA_COMPOSE(dist, sel)                                                                                         \
-                    { const int a0_ = YGZ_DPP_SHR(t0, dist), a1_ = YGZ_DPP_SHR(t1, dist), ab_ = YGZ_DPP_SHR(bad, dist), aE_ = YGZ_DPP_SHR(E, dist); \
-                      if (sel) { const int n0_ = a0_ + ((a0_ & 1) ? t1 : t0), n1_ = a1_ + (((1 + a1_) & 1) ? t1 : t0);           \
-                                 bad |= ab_ | (aE_ != E); t0 = n0_; t1 = n1_; E = aE_; } }
-                    SA_PHASE(9);
-                    SA_COMPOSE(1, (lane & 1) == 1)
-                    SA_COMPOSE(2, (lane & 3) == 3)
-                    const int qt0 = t0, qt1 = t1, qbad = bad, qE = E;         // quad maps live in lanes 4k+3
-                    SA_COMPOSE(4, (lane & 7) == 7)
-                    SA_COMPOSE(8, (lane & 15) == 15)                          // hex maps live in lanes 16h+15
-#undef SA_COMPOSE
 #define SA_TRY(m0_, m1_, mE_, mbad_, taken)                                                                            \
                     { taken = false;                                                                                   \
                       if (!(mbad_) && (int)(cb >> 23) == (mE_)) {                                                      \
                           const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u, mn_ = m_ + (uint32_t)((m_ & 1u) ? (m1_) : (m0_)); \
                           if (mn_ < 0x1000000u) { cb = (cb & 0xff800000u) | (mn_ & 0x7fffffu); taken = true; } } }
-                    SA_PHASE(10);
-                    const int nh = min(4, (n - 64 * j + 15) >> 4);
-                    for (int h = 0; h < nh; ++h) {
-                        const int hl = 16 * h + 15;
-                        bool taken;
-                        SA_TRY(__builtin_amdgcn_readlane(t0, hl), __builtin_amdgcn_readlane(t1, hl), __builtin_amdgcn_readlane(E, hl),
-                               __builtin_amdgcn_readlane(bad, hl), taken)
-                        if (taken) continue;
-                        for (int k4 = 0; k4 < 4; ++k4) {
-                            const int ql = 16 * h + 4 * k4 + 3;
-                            SA_TRY(__builtin_amdgcn_readlane(qt0, ql), __builtin_amdgcn_readlane(qt1, ql), __builtin_amdgcn_readlane(qE, ql),
-                                   __builtin_amdgcn_readlane(qbad, ql), taken)
-                            if (taken) continue;
-                            SA_COUNT(7, 1);
-                            float cc = __uint_as_float(cb);                    // binade crossing: the quad term by term, hardware floats
-                            for (int fl_ = ql - 3; fl_ <= ql; ++fl_) {
-#pragma unroll
-                                for (int k = 0; k < 16; ++k)
-                                    cc = __fadd_rn(cc, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[k]), fl_)));
-                            }
-                            cb = __builtin_amdgcn_readfirstlane(__float_as_uint(cc));
+                for (int j = 0; j < J; ++j) {
+                    SA_PHASE(12);
+                    const float x[16] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w };
+                    const int f0 = nm.x, f1 = nm.y, E = nm.z, bad = nm.w & 1, p0 = np.x, p1 = np.y;
+                    const int cnt = min(64, n - 64 * j);
+                    const unsigned long long H = __ballot(((nm.w >> 1) & 1) && lane < cnt);
+                    {
+                        const int fn = 64 * (j + 1) + lane;
+                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nm = make_int4(0, 0, 0, 0); np = make_int2(0, 0);
+                        if (fn < n) {
+                            const float4 *src = reinterpret_cast<const float4 *>(r2) + fn;
+                            n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells]; nm = fmap[fn]; np = pmap[fn];
                         }
                     }
-#undef SA_TRY
+                    SA_PHASE(9);
+                    int pos = 0;
+                    while (pos < cnt) {
+                        bool taken;
+                        if ((H >> pos) & 1ull) {
+                            const unsigned long long rest = pos < 63 ? (H >> (pos + 1)) : 0ull;
+                            const int e = rest ? pos + (int)__builtin_ctzll(rest) : cnt - 1;        // last feature of the segment
+                            const int sE = __builtin_amdgcn_readlane(E, pos), sbad = __builtin_amdgcn_readlane(bad, pos);
+                            SA_TRY(__builtin_amdgcn_readlane(p0, e), __builtin_amdgcn_readlane(p1, e), sE, sbad, taken)
+                            if (taken) { pos = e + 1; continue; }
+                            if (!sbad && (int)(cb >> 23) == sE) {
+                                // the segment leaves the binade: the first feature whose prefix does (the prefixes are monotone)
+                                const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u;
+                                const int inc = (m_ & 1u) ? p1 : p0;
+                                unsigned long long over = __ballot(m_ + (uint32_t)inc >= 0x1000000u);
+                                over &= (~0ull << pos) & (e < 63 ? ((2ull << e) - 1ull) : ~0ull);
+                                if (over) {
+                                    const int jx = (int)__builtin_ctzll(over);
+                                    if (jx > pos) {
+                                        SA_TRY(__builtin_amdgcn_readlane(p0, jx - 1), __builtin_amdgcn_readlane(p1, jx - 1), sE, 0, taken)
+                                        pos = jx;
+                                    }
+                                }
+                            }
+                        }
+                        // one feature: its own map if c is in its binade and stays there, else its 16 terms in hardware floats
+                        SA_TRY(__builtin_amdgcn_readlane(f0, pos), __builtin_amdgcn_readlane(f1, pos), __builtin_amdgcn_readlane(E, pos),
+                               __builtin_amdgcn_readlane(bad, pos), taken)
+                        if (!taken) {
+                            SA_COUNT(7, 1);
+                            float cc = __uint_as_float(cb);
+#pragma unroll
+                            for (int k = 0; k < 16; ++k)
+                                cc = __fadd_rn(cc, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[k]), pos)));
+                            cb = __builtin_amdgcn_readfirstlane(__float_as_uint(cc));
+                        }
+                        ++pos;
+                    }
                     SA_PHASE(11);
                 }
+#undef SA_TRY
                 const float c = __uint_as_float(cb);
                 if (lane == 0) s_chi2 = c;
                 SA_COUNT(2, clock64() - tlast); SA_COUNT(5, 1);

@@ -17,7 +17,7 @@ int ygz_track_ensure(ygz_hip_ctx *ctx)
     A_(ctx->klt_pts, F * Cn * 8); A_(ctx->klt_err, F * Cn * 4); A_(ctx->klt_status, F * Cn);
     A_(ctx->fdp_px, F * Cn * 16); A_(ctx->fdp_level, F * Cn * 4); A_(ctx->fdp_ok, F * Cn); A_(ctx->sa_out, F * 16 * 8);
     // sparse-align work per pair: jac_cache 768 B + patch_cache 64 B + r2 64 B + visible 1 B per feature
-    ctx->sa_work_stride = ((Cn * (768 + 64 + 64 + 4 + 4 + 16 + 2) + 255) / 256) * 256;      // caches | patch | chain terms | ssq | pre | fmap | visible, used
+    ctx->sa_work_stride = ((Cn * (768 + 64 + 64 + 4 + 4 + 16 + 8 + 2) + 255) / 256) * 256;  // caches | patch | chain terms | ctot | pre | fmap | pmap | visible, used
     A_(ctx->sa_work, F * ctx->sa_work_stride);
 #undef A_
     if (e != hipSuccess) { ctx->last_hip_error = (int)e; return YGZ_E_HIP; }
