@@ -157,8 +157,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # test hook for a 1-GPU box (the N > 1 control flow without RCCL): YGZ_BENCH_ONE_DEVICE=1 puts every rank on device 0
+        # and uses gloo; RCCL refuses two ranks on one device
+        if os.environ.get("YGZ_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
