@@ -116,26 +116,48 @@ def cpu_baseline(pipe, budget_s=12.0):
     except Exception:
         o = Oracle()
     f = pipe.ba
-    n, t0 = 0, time.perf_counter()
-    while n < pipe.B and (time.perf_counter() - t0) < budget_s:
-        i, p = n, (n - 1) % pipe.B
-        gray = o.bgr2gray(pipe.frames[i])
-        lv = o.pyramid(gray, LEVELS)
+
+    last = {}
+
+    def one_frame(i, keep=False):
+        p = (i - 1) % pipe.B
+        lv = o.pyramid(o.bgr2gray(pipe.frames[i]), LEVELS)
         k = o.detect(lv)
         kp_ = pipe.kps[p]
-        lvp = o.pyramid(o.bgr2gray(pipe.frames[p]), LEVELS) if n == 0 else prev_lv
+        lvp = last.get(p) if keep else None                       # sequential run: the predecessor's pyramid is kept, as in the reference
+        if lvp is None:
+            lvp = o.pyramid(o.bgr2gray(pipe.frames[p]), LEVELS)
+        if keep:
+            last.clear(); last[i] = lv
         o.bf_match(k["desc"], kp_["desc"], 1)
         pts = kp_["px"].astype(np.float32)
         o.klt_track(lvp[0], lv[0], pts, pts)
-        for j in range(len(kp_["level"])):
-            o.find_direct_projection(lvp, pipe.poses[p], lv, pipe.poses[i], kp_["px"][j], pipe.kp_depth[p][j], int(kp_["level"][j]), kp_["px"][j])
+        o.find_direct_projection_n(lvp, pipe.poses[p], lv, pipe.poses[i], kp_["px"], pipe.kp_depth[p], kp_["level"], kp_["px"])
         o.sparse_align(lvp, pipe.poses[p], lv, pipe.poses[p], kp_["px"], pipe.kp_depth[p], np.ones(len(pipe.kp_depth[p]), np.uint8))
         o.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
-        prev_lv = lv
+
+    n, t0 = 0, time.perf_counter()
+    while n < pipe.B and (time.perf_counter() - t0) < budget_s:
+        one_frame(n, keep=True)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d whole frames of the same batch (oracle/, gcc -O3, single thread)" % n}
+    res = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d whole frames of the same batch (oracle/, gcc -O3, single thread)" % n}
+    # the whole host -- the same frames handed to one thread per core (the C calls release the GIL)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        cores = max(1, min(len(os.sched_getaffinity(0)), 128))
+        if cores > 1:
+            m = int(min(pipe.B, max(cores, (n / dt) * cores * 6.0)))           # ~6 s if it scaled perfectly
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(one_frame, range(m)))
+            dt2 = time.perf_counter() - t1
+            res["all_cores"] = {"value": m / dt2, "unit": "frames/s", "cores": cores,
+                                "sample": "%d whole frames, one thread per host core" % m}
+    except Exception as e:       # the 1-core number is the contract; the whole-host number is extra
+        res["all_cores"] = {"error": str(e)}
+    return res
 
 
 def main():

@@ -196,6 +196,24 @@ int yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, const
     return fdp_body(cam, ref, T_ref, cur, T_cur, px_ref, depth_ref, level_ref, px_cur, search_level_out);
 }
 
+/* the same for n features of one reference frame (the loop of LocalMapping::ProjectMapPoints / the bench's CPU leg, kept in C
+ * so that the timing is the algorithm's and not the binding's) */
+int yo_find_direct_projection_n(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
+                                const yo_pyramid *cur, const yo_se3 *T_cur, int n,
+                                const double *px_ref, const double *depth_ref, const int32_t *level_ref,
+                                double *px_cur, int32_t *search_level, uint8_t *ok)
+{
+    int good = 0;
+    for (int i = 0; i < n; ++i) {
+        int sl = 0;
+        ok[i] = (uint8_t)yo_find_direct_projection(cam, ref, T_ref, cur, T_cur, px_ref + 2 * (size_t)i, depth_ref[i], level_ref[i],
+                                                   px_cur + 2 * (size_t)i, &sl);
+        search_level[i] = sl;
+        good += ok[i];
+    }
+    return good;
+}
+
 /* Matcher::FindDirectProjection(Frame*,Frame*,MapPoint*,...) -- Matcher.cpp:356-383: the depth is the z of the map point in
  * the reference keyframe, World2Camera(mp->_pos_world, ref->_TCW)[2] (:362), and is NOT tested for its sign;
  * px_ref / level_ref are those of the map point's observation in that keyframe (:360-361). */

@@ -350,6 +350,19 @@ class Oracle:
                                                 _f64(pxr), float(depth), int(level_ref), _f64(pxc), C.byref(sl))
         return bool(ok), pxc, sl.value
 
+    def find_direct_projection_n(self, ref_levels, T_ref, cur_levels, T_cur, px_ref, depth, level_ref, px_cur, cam=None):
+        cam = cam or self.camera()
+        pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)
+        Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
+        pxr = np.ascontiguousarray(px_ref, np.float64).reshape(-1, 2)
+        dep = np.ascontiguousarray(depth, np.float64); lvl = np.ascontiguousarray(level_ref, np.int32)
+        pxc = np.ascontiguousarray(px_cur, np.float64).reshape(-1, 2).copy()
+        n = len(dep)
+        sl = np.zeros(n, np.int32); ok = np.zeros(n, np.uint8)
+        self.lib.yo_find_direct_projection_n(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc), n, _f64(pxr), _f64(dep),
+                                             _p(lvl, C.c_int32), _f64(pxc), _p(sl, C.c_int32), _u8(ok))
+        return ok.astype(bool), pxc, sl
+
     def find_direct_projection_mp(self, ref_levels, T_ref, cur_levels, T_cur, pos_world, px_ref, level_ref, px_cur, cam=None):
         cam = cam or self.camera()
         pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)

@@ -154,6 +154,10 @@ int  yo_find_direct_projection(const yo_camera *cam, const yo_pyramid *ref, cons
                                const double px_ref[2], double depth_ref, int level_ref,
                                double px_cur[2], int *search_level);
 
+int  yo_find_direct_projection_n(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
+                                 const yo_pyramid *cur, const yo_se3 *T_cur, int n,
+                                 const double *px_ref, const double *depth_ref, const int32_t *level_ref,
+                                 double *px_cur, int32_t *search_level, uint8_t *ok);
 /* MapPoint overload, Matcher.cpp:356-383 (depth = z of the point in the reference keyframe, no sign test) */
 int  yo_find_direct_projection_mp(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref,
                                   const yo_pyramid *cur, const yo_se3 *T_cur, const double pos_world[3],

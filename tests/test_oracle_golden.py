@@ -258,6 +258,8 @@ def test_align_golden(oracle):
         ok, px, sl = oracle.find_direct_projection(lv0, T_ref, lv1, T_cur, g["px_ref"][i], g["depth"][i], int(g["level"][i]), g["pred"][i])
         assert ok == g["fdp_ok"][i] and sl == g["fdp_sl"][i]
         assert np.array_equal(px, g["fdp_px"][i], equal_nan=True)
+    ok_n, px_n, sl_n = oracle.find_direct_projection_n(lv0, T_ref, lv1, T_cur, g["px_ref"], g["depth"], g["level"], g["pred"])
+    assert np.array_equal(ok_n, g["fdp_ok"].astype(bool)) and np.array_equal(px_n, g["fdp_px"], equal_nan=True)       # the batched form (bench CPU leg)
     assert g["fdp_ok"].mean() > 0.5                        # the synthetic pair is trackable
     nm, T, st = oracle.sparse_align(lv0, T_ref, lv1, g["T_init"], g["px_ref"], g["depth"], g["has_mp"])
     assert nm == int(g["sa_nmeas"]) and np.array_equal(T, g["sa_T"])
