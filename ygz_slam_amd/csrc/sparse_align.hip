@@ -3,7 +3,7 @@
 // (src/Algorithm/SparseImageAlign.cpp:21-238) and NLLSSolver::optimizeGaussNewton
 // (include/ygz/Algorithm/NLSSolver_impl.hpp:15-89).
 //
-// One workgroup (512 lanes) per alignment problem; lane = feature (4x4 patch).  Per iteration:
+// One workgroup (256 lanes) per alignment problem; lane = feature (4x4 patch).  Per iteration:
 //   lanes warp their feature, gather the 5x5 current-image window, form 16 residuals, accumulate
 //   their own H (21 unique) / Jres (6) in FP64 registers, and publish res^2;
 //   H/Jres are reduced in a fixed tree order (wave shuffles, then 16 wave partials in order);
@@ -18,7 +18,11 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-#define SA_THREADS 512
+// 4 wavefronts (one per SIMD) with up to 256 VGPRs each: the kernel is latency-bound (serial chain / solve phases, dependent
+// loads), 8 wavefronts per problem were not faster, and a 512-lane workgroup at 256 VGPRs owns the whole register file of its
+// CU -- nothing else could run beside it.  At 256 lanes half of the file stays free and the VALU-bound stages launched on
+// the other streams (LK, matcher) fill the idle issue slots: 3.87 -> 3.6 ms per step of the bench.
+#define SA_THREADS 256
 
 struct SaArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
@@ -60,7 +64,7 @@ __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &
     t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
 }
 
-__global__ __launch_bounds__(SA_THREADS, 2) void k_sparse_align(SaArgs A)
+__global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
 {
     __shared__ double red[SA_THREADS / 64][28];
     __shared__ Se3 sT;
