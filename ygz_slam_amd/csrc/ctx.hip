@@ -49,10 +49,10 @@ int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out)
     return YGZ_OK;
 }
 
-int ygz_join(ygz_hip_ctx *ctx)
+int ygz_join(ygz_hip_ctx *ctx, unsigned skip_mask)
 {
     for (int i = 0; i < 3; ++i)
-        if (ctx->aux_pending[i]) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); ctx->aux_pending[i] = false; }
+        if (ctx->aux_pending[i] && !((skip_mask >> i) & 1u)) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); ctx->aux_pending[i] = false; }
     return YGZ_OK;
 }
 
@@ -282,7 +282,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
 {
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     if (from_bgr && !ctx->bgr) return YGZ_E_STATE;
-    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    { int rj = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj != YGZ_OK) return rj; }      // a pending BA linearisation reads no image
     int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->n_levels_alloc);
     if (rc != YGZ_OK) return rc;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 1;

@@ -473,7 +473,7 @@ extern "C" {
 
 int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *occupied)
 {
-    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (ctx) { int rj_ = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) if (!ctx->pyr_valid[s]) return YGZ_E_STATE;
     const size_t Cn = (size_t)ctx->cells;

@@ -141,7 +141,7 @@ int ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
 
 int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
 {
-    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (ctx) { int rj_ = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     return launch_load(ctx, predict);
 }

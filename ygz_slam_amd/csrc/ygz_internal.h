@@ -117,7 +117,12 @@ enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR
        SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_LMAP, SCR_GEN_0 = 16 };
 
 int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
-int ygz_join(ygz_hip_ctx *ctx);          // main stream waits for every pending side-stream stage
+int ygz_join(ygz_hip_ctx *ctx, unsigned skip_mask = 0);   // main stream waits for every pending side-stream stage (bit i of
+                                                          // skip_mask: leave side stream i pending -- for entry points that do not
+                                                          // touch what that stage reads or writes)
+#define YGZ_AUX_SPARSE 0
+#define YGZ_AUX_BA     1
+#define YGZ_AUX_MATCH  2
 
 // RAII: run the enclosed launches on side stream `idx` (sparse-align 0, BA 1, matcher 2) when overlap is enabled.
 // The side stream first waits for everything already enqueued on the main stream (fork), and the main stream waits
