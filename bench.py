@@ -169,7 +169,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run every stage on one stream")
     ap.add_argument("--probe", default="k_klt", help="kernel timed with HIP events for the roofline leg")
+    ap.add_argument("--size", default="vga", choices=["vga", "720p"],
+                    help="vga = BASELINE.json's metric (640x480, the default); 720p = its configs[4] frame size (1280x720, --batch 128 per GPU)")
     a = ap.parse_args()
+    global W, H
+    if a.size == "720p":
+        W, H = 1280, 720
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -232,9 +237,10 @@ def main():
         stages = pipe.stage_times()
         n_kp = float(np.mean([len(k["level"]) for k in pipe.kps]))
         # dominant kernel (see profiles/): algorithmic bytes per launch (DESIGN.md "Measurement") / HIP-event duration
+        n_px = sum((W >> L) * (H >> L) for L in range(LEVELS))
         alg = {"k_klt": a.batch * n_kp * 5 * 2 * 23 * 23,                  # 23x23 B window, 2 images, 5 levels per point
                "k_sparse_align": a.batch * n_kp * 3 * 80.0,               # ~80 B per feature-level
-               "k_fast_select": a.batch * (403200 + 8 * 3000 + 100 * 3000),
+               "k_fast_select": a.batch * (n_px + 8 * 3000 + 100 * 3000),
                "k_find_direct_projection": a.batch * n_kp * 220.0,
                "k_hamming_nn": a.batch * 72000.0 * 0.5}.get(probe_kernel, 0.0)
         avg_s = (probe_ms / max(probe_n, 1)) * 1e-3
@@ -251,11 +257,12 @@ def main():
                 traffic = tj["kernels"][tname]["hbm_bytes"]
         roofline = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                     "kernel": {"k_klt": "k_klt3"}.get(probe_kernel, probe_kernel), "launches": probe_n, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg}
-        res = {"metric": "frames/sec (extract+match+LK+local-BA), 640x480, 1000 ORB kpts", "value": frames / dt, "unit": "frames/s",
+        res = {"metric": "frames/sec (extract+match+LK+local-BA), %dx%d, %d ORB kpts" % (W, H, int(round(n_kp, -3)) if n_kp >= 500 else int(n_kp)),
+               "value": frames / dt, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
-               "config": {"workload": "2x640x480-pair pipeline: ORB extract + 256-bit Hamming BF cross-check + KLT 21x21x5 + "
-                                      "FindDirectProjection + SparseImgAlign + local-BA 10x2000 linearise, per frame",
+               "config": {"workload": "2x%dx%d-pair pipeline: ORB extract + 256-bit Hamming BF cross-check + KLT 21x21x5 + "
+                                      "FindDirectProjection + SparseImgAlign + local-BA 10x2000 linearise, per frame" % (W, H),
                           "frames_per_gpu_per_step": a.batch, "keypoints_per_frame": n_kp, "parallelism": "frames sharded x%d" % world},
                "stage_ms_per_batch": stages, "roofline": roofline}
         if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
