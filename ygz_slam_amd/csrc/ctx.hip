@@ -85,6 +85,7 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
     if (!ctx) return YGZ_E_INVALID;
     ctx->prm = *prm;
     ctx->device = device;
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->n_cu = ncu; }
     int rc = YGZ_OK;
     do {
         if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }

@@ -22,7 +22,8 @@
 // loads), 8 wavefronts per problem were not faster, and a 512-lane workgroup at 256 VGPRs owns the whole register file of its
 // CU -- nothing else could run beside it.  At 256 lanes half of the file stays free and the VALU-bound stages launched on
 // the other streams (LK, matcher) fill the idle issue slots: 3.87 -> 3.6 ms per step of the bench.
-#define SA_THREADS 256
+// (With few problems per launch -- fewer than half the CUs -- nothing competes for the registers and the 512-lane form is
+// used: more lanes per problem shorten the residual pass.)
 
 struct SaArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
@@ -64,6 +65,7 @@ __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &
     t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
 }
 
+template <int SA_THREADS>
 __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
 {
     __shared__ double red[SA_THREADS / 64][28];
@@ -496,7 +498,10 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
     A.dbg = nullptr;
     if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
-    YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align, dim3(n_pairs), dim3(SA_THREADS), A);
+    const char *env_t = getenv("YGZ_SA_THREADS");
+    const int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
+    if (threads == 512) YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align<512>, dim3(n_pairs), dim3(512), A);
+    else YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align<256>, dim3(n_pairs), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         double h[16];

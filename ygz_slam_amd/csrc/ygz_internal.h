@@ -12,6 +12,7 @@
 struct ygz_hip_ctx {
     ygz_hip_params prm;
     int device = 0;
+    int n_cu = 256;                          // compute units of the device (launch-shape decisions)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int last_hip_error = 0;
