@@ -176,6 +176,24 @@ def test_hamming_edge_cases_and_golden(hip_lib, oracle):
     ctx.close()
 
 
+def test_hamming_more_than_65535_rows(hip_lib, oracle):
+    """sets larger than 65535 rows (a 4K frame has 82944 grid cells): the kernel that packs (distance, row) into one 32-bit key
+    must not be used; cross-check and second-best paths stay exact"""
+    ctx = make_ctx(hip_lib, width=3840, height=2160, levels=3, max_frames=1)
+    q = synth.random_descriptors(70000, 5)
+    t = synth.random_descriptors(700, 6)
+    t[650] = q[69990]; q[66000] = q[65999]                  # an exact match and a duplicate beyond row 65535
+    for cc in (0, 1, 2):
+        idx, d = ctx.hamming_match(t, q, cc)                # the 70000-row set is scanned: indices up to 69999
+        oi, od, _ = oracle.bf_match(t, q, cc)
+        assert np.array_equal(idx, oi) and np.array_equal(d, od), cc
+    assert idx[650] == 69990
+    idx, d = ctx.hamming_match(q, t, 1)                     # and the other way round (70000 query rows)
+    oi, od, _ = oracle.bf_match(q, t, 1)
+    assert np.array_equal(idx, oi) and np.array_equal(d, od)
+    ctx.close()
+
+
 def test_match_slots_on_extracted_frames(hip_lib, oracle):
     imgs, _, _ = _frames(4, 640, 480, seed=5, step=0.3)
     ctx = make_ctx(hip_lib, max_frames=4)
@@ -292,6 +310,22 @@ def test_track_local_map(hip_lib, oracle):
     # empty inputs
     n0, v0, *_ = ctx.track_local_map(3, T_cur, [0], [poses[0]], pos[:5], None, [], [], np.zeros((0, 2)), [])
     assert n0 == 0 and len(v0) == 5
+    n0, v0, *_ = ctx.track_local_map(3, T_cur, [0], [poses[0]], np.zeros((0, 3)), None, [], [], np.zeros((0, 2)), [])
+    assert n0 == 0 and len(v0) == 0
+    # candidates that name no point / no keyframe are ignored by both; an impossible pyramid level is refused
+    cp2, ck2 = cp[:50].copy(), ck[:50].copy()
+    cp2[3] = -1; cp2[4] = P + 7; ck2[5] = 9; ck2[6] = -2
+    r_g = ctx.track_local_map(3, T_cur, [0, 1, 2], [poses[0], poses[1], poses[2]], pos, bad, cp2, ck2, cx[:50], cl[:50])
+    r_o = oracle.track_local_map(lv[:3], poses[:3], lv[3], T_cur, pos, bad, cp2, ck2, cx[:50], cl[:50])
+    assert r_g[0] == r_o[0] and np.array_equal(r_g[3], r_o[3]) and np.array_equal(r_g[4], r_o[4])
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.track_local_map(3, T_cur, [0], [poses[0]], pos[:5], None, [0], [0], [[100.0, 100.0]], [7])
+    with pytest.raises(hip_lib.YgzHipError):                # a keyframe slot whose pyramid was never built
+        ctx2 = make_ctx(hip_lib, max_frames=2)
+        try:
+            ctx2.track_local_map(0, T_cur, [1], [poses[0]], pos[:5], None, [0], [0], [[100.0, 100.0]], [0])
+        finally:
+            ctx2.close()
     ctx.close()
 
 
