@@ -323,6 +323,30 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
+// sin and cos of |x| < 8 (an angle in [0, 2 pi)) in double, ~1e-16 absolute: quadrant reduction with a two-part pi/2 and the
+// fdlibm kernel polynomials.  The results are rounded to float by the caller (oracle: (float)cos((double)angle)); the library
+// sincos carries the huge-argument reduction and costs ~4x the instructions.
+__device__ __forceinline__ void ygz_sincos_small(double x, double *sn, double *cs)
+{
+    const double kq = rint(x * 0.63661977236758134308);                 // 2 / pi
+    double r = fma(-kq, 1.57079632679489655800e+00, x);                 // pi/2 high part (exact product by fma)
+    r = fma(-kq, 6.12323399573676603587e-17, r);                        // pi/2 low part
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08); ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04); ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09); pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05); pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)kq & 3;
+    *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
 #define DP_P   40          // LDS row pitch of the patch (bytes): rows start dword-aligned
 __global__ __launch_bounds__(256) void k_describe(DescArgs A)
 {
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float ang = __fmul_rn(angle, factorPI);
     double sn, cs;
-    sincos((double)ang, &sn, &cs);
+    ygz_sincos_small((double)ang, &sn, &cs);
     const float a = (float)cs, b = (float)sn;
     unsigned long long bits[4];
 #pragma unroll
