@@ -358,7 +358,10 @@ def test_fdp_golden(hip_lib):
 
 
 # ------------------------------------------------------------------------------------- L3
-def test_sparse_align(hip_lib, oracle):
+@pytest.mark.parametrize("lanes", ["256", "512"])
+def test_sparse_align(hip_lib, oracle, lanes, monkeypatch):
+    # both workgroup shapes of the kernel (the launcher picks by the number of problems; YGZ_SA_THREADS pins one)
+    monkeypatch.setenv("YGZ_SA_THREADS", lanes)
     for (w, h, n, seed) in ((320, 240, 200, 3), (640, 480, 1000, 8)):
         imgs, poses, depths = _frames(2, w, h, seed=seed, step=0.4)
         k0 = oracle.detect(oracle.pyramid(imgs[0], 3), oracle.default_params(w, h, 3))[:n]
