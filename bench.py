@@ -82,8 +82,8 @@ class Pipeline:
         c.track_sparse_align()                                # L3  SparseImgAlign::run
         c.ba_linearize_resident(0, self.B)                    # B1-B5 one Jacobian/JtJ build per frame
         c.match_slots_again(1)                                # M1-M3 BFMatcher(crossCheck) vs predecessor
+        c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D (side stream, beside LK)
         c.track_klt()                                         # L4  Tracker::TrackKLT
-        c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D
 
     def stage_times(self, reps=3):
         """per-stage HIP-event times (ms per batch), outside the timed region"""

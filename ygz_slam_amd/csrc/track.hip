@@ -157,6 +157,7 @@ int ygz_hip_track_direct(ygz_hip_ctx *ctx)
 {
     if (!ctx) return YGZ_E_INVALID;
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    YgzAuxScope aux(ctx, YGZ_AUX_MATCH);                     // independent of LK: shares the matcher's side stream
     return ygz_launch_fdp(ctx, ctx->n_pairs);
 }
 
