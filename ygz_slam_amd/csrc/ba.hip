@@ -298,7 +298,8 @@ int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, cons
 // device-pointer variant: the new state is already in HBM (e.g. a torch tensor filled by an RCCL broadcast)
 int ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_poses, const double *d_points)
 {
-    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    // only a pending BA stage reads what this overwrites; sparse alignment / matcher stages of the last step keep running
+    if (ctx) { int rj_ = ygz_join(ctx, ~(1u << YGZ_AUX_BA)); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
     if (d_poses) YGZ_HIPCHK(ctx, hipMemcpyAsync(w->poses, d_poses, (size_t)w->K * 48, hipMemcpyDeviceToDevice, ctx->stream));
