@@ -96,8 +96,7 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
     // not depend on the iterate, is summed ONCE per level in the reference's own order (Hf), and what J^T res needs is kept
     // factored: J = (dx * fj_row0 + dy * fj_row1) * fl  ->  16 x (dx, dy) floats + the 2x6 frame Jacobian.
     double *Hf = (double *)wk;                                          // [cells][21] upper triangle of sum_px J J^T
-    double *fjc = Hf + 21 * (size_t)A.cells;                            // [cells][12] JacobXYZ2Cam rows
-    float *dxy = (float *)(fjc + 12 * (size_t)A.cells);                 // [cells][32] dx[16], dy[16]
+    float *dxy = (float *)(Hf + 33 * (size_t)A.cells);                  // [cells][32] dx[16], dy[16] (the 12 doubles per cell before it are unused)
     uint8_t *prev_used = (uint8_t *)(dxy + 32 * (size_t)A.cells);       // [cells] the feature is part of the running H
     float *patch_cache = (float *)((double *)wk + 96 * (size_t)A.cells);   // [cells][16]
     float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [4][cells] float4: the squared residuals (chain terms)
@@ -155,7 +154,6 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
             prev_used[f] = 0;
             if (!has_mp[f] || ui - border < 0 || vi - border < 0 || ui + border >= cols || vi + border >= rows) {
                 for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = 0.0;       // a zero Jacobian column block (:42)
-                for (int k = 0; k < 12; ++k) fjc[12 * (size_t)f + k] = 0.0;
                 continue;
             }
             visible[f] = 1;
@@ -209,9 +207,6 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
 #pragma unroll
             for (int k = 0; k < 4; ++k) { o4[k] = make_float4(dxv[4 * k], dxv[4 * k + 1], dxv[4 * k + 2], dxv[4 * k + 3]);
                                           o4[4 + k] = make_float4(dyv[4 * k], dyv[4 * k + 1], dyv[4 * k + 2], dyv[4 * k + 3]); }
-            double2 *o2 = reinterpret_cast<double2 *>(fjc + 12 * (size_t)f);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) o2[k] = make_double2(fj[2 * k], fj[2 * k + 1]);
 #pragma unroll
             for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = hf[k];
         }
@@ -292,9 +287,17 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                         gA += (double)dxy[32 * (size_t)f + pc] * (double)res[pc];
                         gB += (double)dxy[32 * (size_t)f + 16 + pc] * (double)res[pc];
                     }
+                    // the 2x6 frame Jacobian is recomputed (a dozen FP64 operations from the values above, the same expressions
+                    // as in the set-up) instead of fetched: 96 bytes less per feature and iteration
+                    const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
+                    const double jx = (pxx - A.cx) * dep / A.fx, jy = (pxy - A.cy) * dep / A.fy;
+                    const double z_inv = 1. / dep, z_inv_2 = z_inv * z_inv;
+                    double fj[12];      // cvutils::JacobXYZ2Cam (CVUtils.h:77-99)
+                    fj[0] = -z_inv; fj[1] = 0.0; fj[2] = jx * z_inv_2; fj[3] = jy * fj[2]; fj[4] = -(1.0 + jx * fj[2]); fj[5] = jy * z_inv;
+                    fj[6] = 0.0; fj[7] = -z_inv; fj[8] = jy * z_inv_2; fj[9] = 1.0 + jy * fj[8]; fj[10] = -fj[3]; fj[11] = -jx * z_inv;
 #pragma unroll
                     for (int k = 0; k < 6; ++k)                                          // Jres_ -= J * res (:210), J = (dx fj0 + dy fj1) fl
-                        acc[21 + k] -= (fjc[12 * (size_t)f + k] * gA + fjc[12 * (size_t)f + 6 + k] * gB) * fl;
+                        acc[21 + k] -= (fj[k] * gA + fj[6 + k] * gB) * fl;
                 }
                 }   // f < n
                 // approximate value of the chi2 chain at the start of the feature, relative to its chunk of 64 (= this wavefront)
