@@ -3,14 +3,14 @@
 // (src/Algorithm/SparseImageAlign.cpp:21-238) and NLLSSolver::optimizeGaussNewton
 // (include/ygz/Algorithm/NLSSolver_impl.hpp:15-89).
 //
-// One workgroup (256 lanes) per alignment problem; lane = feature (4x4 patch).  Per iteration:
-//   lanes warp their feature, gather the 5x5 current-image window, form 16 residuals, accumulate
-//   their own H (21 unique) / Jres (6) in FP64 registers, and publish res^2;
-//   H/Jres are reduced in a fixed tree order (wave shuffles, then 16 wave partials in order);
-//   chi2 is the reference's FLOAT sum in feature/pixel order: it decides "error increased ->
-//   rollback" (NLSSolver_impl.hpp:53-63), so it is reproduced exactly -- res^2 staged through LDS
-//   and summed by one lane in raster order (adding the 0.0f of a skipped feature is exact);
-//   lane 0 solves the 6x6 LDLT, applies T <- T * exp(-x), and broadcasts the loop decision.
+// One workgroup (256 or 512 lanes) per alignment problem; lane = feature (4x4 patch).  Per iteration:
+//   residual pass: lanes warp their features, load the 5x5 current-image window row-wise, form 16 residuals, accumulate
+//   J^T res (and the change of H when a feature enters / leaves) in FP64 registers, publish res^2 and an approximate prefix;
+//   H / Jres are reduced in a fixed order (DPP wave sums, then the wavefront partials in order);
+//   chi2 is the reference's FLOAT sum in feature/pixel order: it decides "error increased -> rollback"
+//   (NLSSolver_impl.hpp:53-63), so it is reproduced bit for bit -- but evaluated through per-feature parity maps, a segmented
+//   scan and a segment walk instead of n*16 dependent float adds (see sa_chain_term below and DESIGN.md);
+//   one lane of wave 1 solves the 6x6 LDLT and forms T * exp(-x) meanwhile; lane 0 takes the accept / stop decision.
 // No host round trip per iteration (the reference solves ~30 6x6 systems per frame pair).
 #include "ygz_internal.h"
 #include "se3_dev.h"
@@ -33,7 +33,7 @@ struct SaArgs {
     const int32_t *pair_q, *pair_t, *trk_n;       // cur slot, ref slot, features per pair
     const double *pair_T;                         // [pairs][2][7]; T_ref used here
     const double *trk_px, *trk_depth; const uint8_t *trk_has_mp;     // [pairs][cells]
-    uint8_t *work; size_t work_stride;            // per pair: Hf, fj, dxy, prev_used (96 doubles/cell) | patch_cache | r2 | ssq | visible | used
+    uint8_t *work; size_t work_stride;            // per pair: Hf, (unused), dxy, prev_used (96 doubles/cell) | patch_cache | r2 | ctot | pre | fmap | pmap | visible | used
     double *out;                                  // [pairs][16]: pose 7 (in: initial cur->_TCW, out: result), n_meas, iters
     double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
 };
@@ -48,9 +48,11 @@ struct SaArgs {
 // result would be odd).  The only sequential state that influences an increment is therefore the PARITY of m (ties).  A run
 // of consecutive terms is summarised, for a predicted binade E, by two integers: the total increment for incoming parity 0
 // and for incoming parity 1; two such maps compose associatively.  Each lane builds the map of one feature (16 terms,
-// integer ALU only), shuffles compose them into maps of 4 and 16 features, and the wave walks these: if c really is in the
-// predicted binade and the run does not leave it, one integer add replaces 256 (or 64) dependent float adds; otherwise
-// (binade crossings: the first few runs and ~log2(n) later ones) the 64 terms are added one by one in hardware floats.
+// integer ALU only) for the binade predicted by an approximate prefix sum; a segmented DPP scan composes the maps of every run
+// of features with the same predicted binade; wave 0 then walks the segments: if c really is in the segment's binade and the
+// segment does not leave it, ONE integer add replaces 16 x (features of the segment) dependent float adds; if it does, a
+// ballot finds the crossing feature (prefix increments are monotone), the features before it are taken at once and only its
+// 16 terms are added in hardware floats (the first few features and ~log2(n) later ones per iteration).
 // Either way the result is the reference's float, bit for bit.
 __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &t1, int &bad)
 {   // branch-free: every lane of the wave runs the same ~20 integer instructions per term
