@@ -3,10 +3,11 @@
 // cv::BFMatcher(NORM_HAMMING, crossCheck).match() (test/test_orb_match.cpp:86-93).
 // Bit-exact with oracle/hamming.c (integer arithmetic; first minimum wins ties).
 //
-// k_hamming_nn: lane = one row of set A with its 256-bit descriptor in 8 VGPRs; set B streams
+// k_hamming_nn: lane = one or two rows of set A with their 256-bit descriptors in 8 / 16 VGPRs; set B streams
 // through LDS in 256-row tiles (two 16-byte coalesced loads per lane to stage, then every lane
 // reads the SAME tile row -> LDS broadcast, conflict-free); per pair 8 x (v_xor + v_bcnt with
-// accumulate) and a 3-5 op running (min, 2nd min, argmin).  The kernel is VALU-bound by two
+// accumulate) and a running minimum (a packed (distance, row) key, or (min, 2nd min, argmin) when the second-best distance
+// is wanted).  The kernel is VALU-bound by two
 // orders of magnitude (72 KB per 1000x1000 pair vs 1.6e7 lane-ops), so the layout
 // goal is only that the 64 KB of descriptors are read from HBM exactly once per workgroup column.
 // Cross-check (OpenCV batchDistance semantics) = the same kernel run train->query with a fused

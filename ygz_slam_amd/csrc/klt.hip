@@ -19,6 +19,10 @@
 //             oracle's; each lane adds its 7 terms exactly in integers and the 63 lane sums are combined by a float
 //             tree (the oracle adds all 441 terms in float in raster order): same quantities, different rounding,
 //             well inside the 1e-5 track tolerance.
+//  k_klt3     the 21 x 21 window of the reference: THREE points per wavefront, 21 lanes per point, a lane owns 3 rows x 7
+//             pixels; bilinear taps and mismatch sums as v_dot2_i32_i16 on pixel pairs, patch subtraction folded into the dot
+//             accumulator, 21-lane segment sums; the wavefront iterates while any of its points is live (see the kernel).
+//             k_klt stays for other window sizes and for the debug taps.
 #include "ygz_internal.h"
 #include <vector>
 #include <stdio.h>
