@@ -18,8 +18,9 @@ DB=$(find $OUT/stats -name '*.db' | head -1)
 [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $OUT/kernel_stats.md > /dev/null
 python $R/tools/pmc_summary.py $OUT/fetch > $OUT/pmc_fetch.md
 python $R/tools/pmc_summary.py $OUT/write > $OUT/pmc_write.md
-python $R/tools/make_traffic.py $OUT/pmc_fetch.md $OUT/pmc_write.md $OUT/traffic.json
 grep -h '^{' $OUT/bench_stats.log | tail -1 > $OUT/bench.json
+BATCH=$(python -c "import json; print(json.load(open('$OUT/bench.json'))['config']['frames_per_gpu_per_step'])")
+python $R/tools/make_traffic.py $OUT/pmc_fetch.md $OUT/pmc_write.md $OUT/traffic.json $BATCH
 # keep the merge-back small: the raw traces stay on the box
 rm -rf $OUT/stats $OUT/fetch $OUT/write
 ls -la $OUT
