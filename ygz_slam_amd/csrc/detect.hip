@@ -180,8 +180,12 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
     __syncthreads();
     FS_PHASE(2);
 
-    // ---- 3) NMS + border + Shi-Tomasi + per-cell winner
+    // ---- 3) NMS + border + Shi-Tomasi + per-cell winner, in two passes so that the 64-pixel Shi-Tomasi window runs on dense
+    //         lanes: 3a (lane = corner) keeps the corners that survive NMS, the InFrame test and the occupied-cell test in an LDS
+    //         list; 3b gives every survivor 4 lanes (2 window rows each), sums in exact int32 and reduces inside the quad.
     const int scale = 1 << A.level;
+    if (tid == 0) n_cand = 0;                                   // the candidate list of step 1 is free: reuse it for the survivors
+    __syncthreads();
     for (int li = tid; li < n; li += 256) {
         const int i = list[li];
         const int ry = i / R1_W, rx = i - ry * R1_W;
@@ -206,21 +210,36 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
         const int k = gy * A.grid_cols + gx;
         if (k < 0 || k >= A.cells) continue;
         if (A.occupied[(size_t)slot * A.cells + k]) continue;
-        // FeatureDetector::ShiTomasiScore (:467-507) on the LDS tile
-        float score = 0.0f;
-        if (!(x - 4 < 1 || x + 4 >= A.w - 1 || y - 4 < 1 || y + 4 >= A.h - 1)) {
-            // every partial sum is an integer below 2^24 (|dx| <= 255, 64 terms), so the reference's float accumulation is
-            // exact in any order: accumulate in int32, convert once
-            int iXX = 0, iYY = 0, iXY = 0;
+        cand[atomicAdd(&n_cand, 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    const int n_sel = n_cand;
+    for (int t = tid; t < 4 * n_sel; t += 256) {
+        const int i = cand[t >> 2], part = t & 3;
+        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const int x = x0 - 1 + rx, y = y0 - 1 + ry;
+        // FeatureDetector::ShiTomasiScore (:467-507) on the LDS tile.  Every partial sum is an integer below 2^24 (|dx| <= 255,
+        // 64 terms), so the reference's float accumulation is exact in any order: accumulate in int32, convert once
+        const bool inside = !(x - 4 < 1 || x + 4 >= A.w - 1 || y - 4 < 1 || y + 4 >= A.h - 1);
+        int iXX = 0, iYY = 0, iXY = 0;
+        if (inside) {
             const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
-            for (int yy = -4; yy < 4; ++yy)
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
                 for (int xx = -4; xx < 4; ++xx) {
-                    const uint8_t *q = c + yy * FT_LW + xx;
+                    const uint8_t *q = c + (2 * part - 4 + yy) * FT_LW + xx;
                     const int dx = (int)q[1] - (int)q[-1];
                     const int dy = (int)q[FT_LW] - (int)q[-FT_LW];
                     iXX += __mul24(dx, dx); iYY += __mul24(dy, dy); iXY += __mul24(dx, dy);
                 }
+        }
+#define FS_QUAD_SUM(v) { v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false); v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false); }
+        FS_QUAD_SUM(iXX) FS_QUAD_SUM(iYY) FS_QUAD_SUM(iXY)
+#undef FS_QUAD_SUM
+        if (part != 0) continue;
+        float score = 0.0f;
+        if (inside) {
             float dXX = (float)iXX, dYY = (float)iYY, dXY = (float)iXY;
             dXX = __fmul_rn(dXX, 1.0f / 128.0f); dYY = __fmul_rn(dYY, 1.0f / 128.0f); dXY = __fmul_rn(dXY, 1.0f / 128.0f);
             const float tr = __fadd_rn(dXX, dYY);
@@ -228,6 +247,8 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
                                          __fmul_rn(4.0f, __fsub_rn(__fmul_rn(dXX, dYY), __fmul_rn(dXY, dXY))));
             score = __fmul_rn(0.5f, __fsub_rn(tr, ygz_sqrtf_cr(disc)));
         }
+        const int gy = (y * scale) / A.cell, gx = (x * scale) / A.cell;
+        const int k = gy * A.grid_cols + gx;
         const uint32_t visit = ((uint32_t)A.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
         const bool isnan_ = score != score;
         atomicMin(&A.cell_first[(size_t)slot * A.cells + k], (visit << 1) | (isnan_ ? 1u : 0u));
