@@ -123,6 +123,24 @@ int  ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx /*[nq]*/
 int  ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt,
                            int cross_check, int32_t *train_idx, int32_t *dist, int32_t *dist2);
 
+/* ---- M3: the "good match" filter of test/test_orb_match.cpp:97-104 on the matcher's output: min_dis = the smallest distance
+ *      among the matches, clamped to [min_floor, min_ceil] (20, 50); a match is good iff distance < factor * min_dis (3).
+ *      Resident form: every pair of the current pair table in one launch, flags stay in HBM (ygz_hip_get_good_matches). */
+int  ygz_hip_match_postfilter(ygz_hip_ctx *ctx, double min_floor, double min_ceil, double factor);
+int  ygz_hip_get_good_matches(ygz_hip_ctx *ctx, int pair, uint8_t *good /*[nq]*/, int capacity, int *nq, int *n_good, double *min_dis);
+/* the same on host arrays as ygz_hip_hamming_match returned them (train_idx < 0: no match).  nq == 0 (the reference dereferences
+ * end() there) is defined as "nothing kept". */
+int  ygz_hip_match_postfilter_host(ygz_hip_ctx *ctx, const int32_t *train_idx, const int32_t *dist, int nq, double min_floor,
+                                   double min_ceil, double factor, uint8_t *good, int *n_good, double *min_dis);
+/* ---- M6: Matcher::CheckFrameDescriptors (src/Algorithm/Matcher.cpp:45-84): Hamming distance of n given (index1, index2) feature
+ *      pairs of two frames, best_dist = min clamped to [init_low, init_high] (Matcher.h:27-28), keep[i] = dist[i] < ratio * best_dist
+ *      (initMatchRatio 3.0).  Slot form: resident descriptors of the two slots; pair form: host descriptors [n][32] row by row.
+ *      n == 0 (UB in the reference) returns n_good = 0. */
+int  ygz_hip_check_frame_descriptors(ygz_hip_ctx *ctx, int slot1, int slot2, const int32_t *idx1, const int32_t *idx2, int n,
+                                     int init_low, int init_high, float ratio, int32_t *dist, uint8_t *keep, int *n_good, int *best_dist);
+int  ygz_hip_check_descriptor_pairs(ygz_hip_ctx *ctx, const uint8_t *desc1, const uint8_t *desc2, int n, int init_low, int init_high,
+                                    float ratio, int32_t *dist, uint8_t *keep, int *n_good, int *best_dist);
+
 /* ---- L1-L2: patch alignment -- replaces Matcher::FindDirectProjection (Matcher.cpp:356-417:
  *      GetWarpAffineMatrix, GetBestSearchLevel, WarpAffine, cvutils::Align2D CVUtils.cpp:186-318) -- */
 typedef struct {
@@ -194,6 +212,19 @@ int  ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict);       /* device-side r
 int  ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm);
 int  ygz_hip_track_direct(ygz_hip_ctx *ctx);
 int  ygz_hip_track_sparse_align(ygz_hip_ctx *ctx, int max_level, int min_level, int n_iter);
+/* VisualOdometry::TrackRefFrame -> TrackLocalMap hand-over (src/Module/VisualOdometry.cpp:281-302, src/Module/LocalMapping.cpp:47-80)
+ * on the device for every pair: the pose the sparse alignment left becomes the pair's current pose and every reference feature's
+ * map point (Pixel2Camera(px, depth) taken to the world with T_ref) is re-projected with it -- the start pixel of the direct
+ * projection; features without depth, behind the camera or outside InFrame(px, 20) stop being candidates (ok = 0 afterwards). */
+int  ygz_hip_track_adopt_pose(ygz_hip_ctx *ctx);
+/* LocalMapping::OptimizeCurrent -> ba::OptimizeCurrentPoseOnly (src/Module/LocalMapping.cpp:122-127, src/Algorithm/BA.cpp:188-264) for
+ * every pair, on the features ProjectMapPoints created (the direct-projection successes: pixel = refined pixel, map point = the
+ * reference feature's), starting from the pair's current pose.  Results stay in HBM. */
+int  ygz_hip_track_pose_only(ygz_hip_ctx *ctx);
+/* pose [6] = [t; log(so3)], T [7] = SE3(SO3::exp(.), t) (BA.cpp:254); bad/depth [n] per reference feature (bad = 1 also for
+ * features that were not projected); any output may be NULL */
+int  ygz_hip_track_get_pose_only(ygz_hip_ctx *ctx, int pair, double pose[6], double T[7], int *inliers, int *rounds, uint8_t *bad,
+                                 double *depth, int capacity, int *n);
 int  ygz_hip_track_get_klt(ygz_hip_ctx *ctx, int pair, float *pts, uint8_t *status, float *err, int capacity, int *n);
 int  ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *level, uint8_t *ok, int capacity, int *n);
 int  ygz_hip_track_get_pose(ygz_hip_ctx *ctx, int pair, double T[7], int *n_meas, int *iters /*[levels] or NULL*/);

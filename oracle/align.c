@@ -267,6 +267,34 @@ int yo_track_local_map(const yo_camera *cam, const yo_pyramid *kf_pyr, const yo_
     return matched;
 }
 
+/* The hand-over between VisualOdometry::TrackRefFrame and LocalMapping::TrackLocalMap for the features of ONE reference frame
+ * (src/Module/VisualOdometry.cpp:293, src/Module/LocalMapping.cpp:47-79): the map point of feature i is its back-projection
+ * Camera2World(Pixel2Camera(px, depth), T_ref) (Camera.h:45-62,70-72 -- what the reference stores in MapPoint::_pos_world when the
+ * point is created); FindCandidates projects it with the current pose and drops it when it lies behind the camera or outside
+ * InFrame(px, 20).  Features without depth (<= 0) have no map point.  Returns the number of candidates. */
+int yo_track_candidates(const yo_camera *cam, const yo_se3 *T_ref, const yo_se3 *T_cur, const double *px_ref, const double *depth,
+                        int n, int w, int h, double *pos_world, double *px_pred, uint8_t *cand)
+{
+    yo_se3 Tri;
+    yo_se3_inv(T_ref, &Tri);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        cand[i] = 0;
+        px_pred[2 * i] = px_ref[2 * i]; px_pred[2 * i + 1] = px_ref[2 * i + 1];
+        pos_world[3 * i] = pos_world[3 * i + 1] = pos_world[3 * i + 2] = 0.0;
+        if (!(depth[i] > 0)) continue;
+        double pr[3], pc[3], px[2];
+        pixel2camera(cam, px_ref + 2 * (size_t)i, depth[i], pr);
+        yo_se3_act(&Tri, pr, pos_world + 3 * (size_t)i);
+        yo_se3_act(T_cur, pos_world + 3 * (size_t)i, pc);
+        camera2pixel(cam, pc, px);
+        px_pred[2 * i] = px[0]; px_pred[2 * i + 1] = px[1];
+        if (pc[2] < 0 || !(px[0] >= 20 && px[0] < w - 20 && px[1] >= 20 && px[1] < h - 20)) continue;
+        cand[i] = 1; ++cnt;
+    }
+    return cnt;
+}
+
 /* cvutils::DepthFromTriangulation -- include/ygz/Algorithm/CVUtils.h:18-38, with Eigen's evaluation order
  * [frozen spec of Eigen: 2x2 inverse = adjugate * (1/det); (-inv * A^T) is formed before it multiplies t].
  * Returns 1 and |depth| of the ray in the reference / the search frame, or 0 when det(A^T A) < determinant_th. */

@@ -84,3 +84,27 @@ int yo_good_match_filter(const int32_t *train_idx, const int32_t *dist, int nq, 
     }
     return n;
 }
+
+/* Matcher::CheckFrameDescriptors -- src/Algorithm/Matcher.cpp:45-84.  Distances of the (idx1[i], idx2[i]) feature pairs,
+ * best clamped to [init_low, init_high] (Matcher.h:27-28: 30, 80; the YAML values are read at Matcher.cpp:15-16), keep[i] =
+ * distance[i] < initMatchRatio * best_dist (float x int -> float, :72).  Returns cnt_good; *best_out = the clamped best.
+ * n == 0 is undefined in the reference (min_element of an empty vector is dereferenced): defined here as 0 / init_low. */
+int yo_check_frame_descriptors(const uint8_t *desc1, const uint8_t *desc2, const int32_t *idx1, const int32_t *idx2, int n,
+                               int init_low, int init_high, float ratio, int32_t *dist, uint8_t *keep, int *best_out)
+{
+    if (n <= 0) { if (best_out) *best_out = init_low; return 0; }
+    int best_dist = INT_MAX;
+    for (int i = 0; i < n; ++i) {
+        dist[i] = yo_descriptor_distance(desc1 + 32 * (size_t)idx1[i], desc2 + 32 * (size_t)idx2[i]);
+        if (dist[i] < best_dist) best_dist = dist[i];
+    }
+    best_dist = best_dist > init_low ? best_dist : init_low;
+    best_dist = best_dist < init_high ? best_dist : init_high;
+    int cnt_good = 0;
+    for (int i = 0; i < n; ++i) {
+        keep[i] = (uint8_t)((float)dist[i] < ratio * (float)best_dist);
+        cnt_good += keep[i];
+    }
+    if (best_out) *best_out = best_dist;
+    return cnt_good;
+}

@@ -293,6 +293,15 @@ class Oracle:
         n = self.lib.yo_good_match_filter(_p(idx, C.c_int32), _p(dist, C.c_int32), len(idx), _u8(keep))
         return keep.astype(bool), n
 
+    def check_frame_descriptors(self, desc1, desc2, idx1, idx2, init_low=30, init_high=80, ratio=3.0):
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        i1 = np.ascontiguousarray(idx1, np.int32); i2 = np.ascontiguousarray(idx2, np.int32)
+        n = len(i1)
+        dist = np.zeros(max(n, 1), np.int32); keep = np.zeros(max(n, 1), np.uint8); best = C.c_int(0)
+        cnt = self.lib.yo_check_frame_descriptors(_u8(d1), _u8(d2), _p(i1, C.c_int32), _p(i2, C.c_int32), n, int(init_low), int(init_high),
+                                                  C.c_float(ratio), _p(dist, C.c_int32), _u8(keep), C.byref(best))
+        return dist[:n].copy(), keep[:n].astype(bool), cnt, best.value
+
     # ---- SE3 ----
     def se3_exp(self, v):
         v = np.ascontiguousarray(v, np.float64)
@@ -362,6 +371,18 @@ class Oracle:
         self.lib.yo_find_direct_projection_n(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc), n, _f64(pxr), _f64(dep),
                                              _p(lvl, C.c_int32), _f64(pxc), _p(sl, C.c_int32), _u8(ok))
         return ok.astype(bool), pxc, sl
+
+    def track_candidates(self, T_ref, T_cur, px_ref, depth, w, h, cam=None):
+        """yo_track_candidates: map points of the reference features + LocalMapping::FindCandidates with the current pose"""
+        cam = cam or self.camera()
+        Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
+        pxr = np.ascontiguousarray(px_ref, np.float64).reshape(-1, 2)
+        dep = np.ascontiguousarray(depth, np.float64)
+        n = len(dep)
+        pw = np.zeros((max(n, 1), 3)); pred = np.zeros((max(n, 1), 2)); cand = np.zeros(max(n, 1), np.uint8)
+        self.lib.yo_track_candidates(C.byref(cam), C.byref(Tr), C.byref(Tc), _f64(pxr), _f64(dep), n, int(w), int(h), _f64(pw), _f64(pred),
+                                     _u8(cand))
+        return pw[:n], pred[:n], cand[:n].astype(bool)
 
     def find_direct_projection_mp(self, ref_levels, T_ref, cur_levels, T_cur, pos_world, px_ref, level_ref, px_cur, cam=None):
         cam = cam or self.camera()

@@ -116,6 +116,9 @@ int  yo_bf_match(const uint8_t *q, int nq, const uint8_t *t, int nt, int cross_c
 /* test_orb_match.cpp:97-104 post filter: min_dis clamped to [20,50], keep d < 3*min_dis.
  * keep[i] set for kept matches; returns count */
 int  yo_good_match_filter(const int32_t *train_idx, const int32_t *dist, int nq, uint8_t *keep);
+/* Matcher::CheckFrameDescriptors (src/Algorithm/Matcher.cpp:45-84) */
+int  yo_check_frame_descriptors(const uint8_t *desc1, const uint8_t *desc2, const int32_t *idx1, const int32_t *idx2, int n,
+                                int init_low, int init_high, float ratio, int32_t *dist, uint8_t *keep, int *best_out);
 
 /* ---- SE3 / SO3 (thirdparty/Sophus/sophus/{so3,se3}.cpp) --------------------------- */
 typedef struct { double q[4]; /* x,y,z,w */ double t[3]; } yo_se3;
@@ -163,6 +166,8 @@ int  yo_find_direct_projection_mp(const yo_camera *cam, const yo_pyramid *ref, c
                                   const yo_pyramid *cur, const yo_se3 *T_cur, const double pos_world[3],
                                   const double px_ref[2], int level_ref, double px_cur[2], int *search_level);
 /* LocalMapping::FindCandidates + ProjectMapPoints, LocalMapping.cpp:47-120 (candidates in caller order); see align.c */
+int  yo_track_candidates(const yo_camera *cam, const yo_se3 *T_ref, const yo_se3 *T_cur, const double *px_ref, const double *depth,
+                         int n, int w, int h, double *pos_world, double *px_pred, uint8_t *cand);
 int  yo_track_local_map(const yo_camera *cam, const yo_pyramid *kf_pyr, const yo_se3 *kf_T, int K,
                         const yo_pyramid *cur, const yo_se3 *T_cur,
                         const double *pos_world, const uint8_t *point_bad, int P,

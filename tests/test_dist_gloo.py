@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 from ygz_slam_amd import dist as ydist
-from ygz_slam_amd import synth
+from ygz_slam_amd import synth, offline
 
 
 def test_shards_partition_frames_and_pairs():
@@ -80,3 +80,77 @@ def test_world_size_2_gloo(oracle):
     ks = [oracle.detect(oracle.pyramid(synth.render(tex, m, tr[i], 160, 120, 1.0, 40 + i)[0], 3), prm) for i in range(n_frames)]
     exp = [int((oracle.bf_match(ks[i]["desc"], ks[i - 1]["desc"], 1)[0] >= 0).sum()) for i in range(1, n_frames)]
     assert list(ret["nmatch"]) == exp
+
+
+# ---- host logic of the offline run (ygz_slam_amd/offline.py); its GPU half is tests/test_gpu_offline.py ------------------
+def test_offline_windows_and_owners():
+    assert offline.keyframes(17, 8) == [0, 8, 16]
+    assert offline.ba_windows(1024, 8, 8) == [list(range(64 * w, 64 * w + 64, 8)) for w in range(16)]
+    assert offline.ba_windows(16, 2, 4) == [[0, 2, 4, 6], [8, 10, 12, 14]]
+    assert offline.ba_windows(18, 2, 4) == [[0, 2, 4, 6], [8, 10, 12, 14]]          # a trailing window needs two keyframes
+    assert offline.ba_windows(20, 2, 4)[-1] == [16, 18]
+    for n, world in ((1024, 8), (16, 2), (17, 3)):
+        own = [offline.frame_owner(f, n, world) for f in range(n)]
+        assert own == sorted(own) and set(own) == set(range(world))
+        for r in range(world):
+            s, c, _ = ydist.shard_frames(n, r, world)
+            assert own[s:s + c] == [r] * c
+    # 1024 frames / 8 ranks / stride 8 / 8 keyframes per window: every rank owns exactly two whole windows
+    wins = offline.ba_windows(1024, 8, 8)
+    assert [offline.frame_owner(w[0], 1024, 8) for w in wins] == [w // 2 for w in range(16)]
+
+
+def test_offline_se3_helpers_match_the_oracle(oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        a = synth.se3_exp(rng.normal(0, 0.4, 6)); b = synth.se3_exp(rng.normal(0, 0.4, 6))
+        assert np.allclose(offline.se3_mul(a, b), oracle.se3_mul(a, b), rtol=0, atol=1e-15)
+        assert np.allclose(offline.se3_inv(a), oracle.se3_inv(a), rtol=0, atol=1e-15)
+        p = rng.normal(0, 2, 3)
+        assert np.allclose(offline.se3_act(a, p), oracle.se3_act(a, p), rtol=0, atol=1e-14)
+        assert np.allclose(offline.se3_act(a, np.stack([p, 2 * p])), np.stack([oracle.se3_act(a, p), oracle.se3_act(a, 2 * p)]), atol=1e-14)
+        lg = oracle.se3_log(a)                                   # Sophus order [upsilon; omega]
+        g = offline.se3_log_g2o(a)
+        assert np.allclose(g, np.concatenate([lg[3:], lg[:3]]), rtol=0, atol=1e-13)
+        assert np.allclose(offline.se3_exp_g2o(g), a, rtol=0, atol=1e-13)
+    T_rel = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(9)])
+    tr = offline.chain(T_rel)
+    ref = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    assert np.array_equal(tr[0], ref)
+    for i in range(1, 9):
+        ref = oracle.se3_mul(T_rel[i], ref)
+        assert np.allclose(tr[i], ref, rtol=0, atol=1e-14)
+
+
+def _exchange_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owner = [0, 0, 1, 1, 1]                                      # 5 BA windows, contiguous ownership
+    buf = torch.zeros((5, 7), dtype=torch.float64)
+    for i, o in enumerate(owner):
+        if o == rank:
+            buf[i] = torch.arange(7, dtype=torch.float64) + 10 * i + 0.5
+    offline.exchange_rows(buf, owner, world)
+    # trajectory gather of ragged shards (5 frames: 3 + 2) followed by the chain, as OfflineVO.gather does
+    n = 5
+    rng = np.random.default_rng(9)
+    T_rel_all = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(n)])
+    s, c, _ = ydist.shard_frames(n, rank, world)
+    got = ydist.gather_trajectories(T_rel_all[s:s + c], n, rank, world)
+    ret[rank] = (buf.numpy().copy(), got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_offline_exchange_world_size_2_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_exchange_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    exp = np.stack([np.arange(7) + 10 * i + 0.5 for i in range(5)])
+    rng = np.random.default_rng(9)
+    T_rel_all = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(5)])
+    for r in range(2):
+        buf, got = ret[r]
+        assert np.array_equal(buf, exp)                          # every rank holds every owner's rows
+        assert np.array_equal(got, T_rel_all)
+        assert np.array_equal(offline.chain(got), offline.chain(T_rel_all))

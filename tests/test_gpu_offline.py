@@ -1,0 +1,213 @@
+"""GPU tests (pytest -m gpu) of the offline run of BASELINE configs[4] (ygz_slam_amd/offline.py) and of the stages it adds
+to the C ABI: the M3 / M6 match filters, the TrackRefFrame -> TrackLocalMap hand-over on the device, pose-only BA on resident
+tracks.  The sharded run (2 ranks, gloo, both on the one GPU of the test box) must reproduce the unsharded run exactly."""
+import os
+import pickle
+import socket
+import numpy as np
+import pytest
+from conftest import make_ctx, ROOT
+from ygz_slam_amd import synth, offline
+
+pytestmark = pytest.mark.gpu
+I7 = np.array([0, 0, 0, 1.0, 0, 0, 0])
+
+
+def test_match_postfilter_and_check_frame_descriptors(hip_lib, oracle):
+    """M3 (test_orb_match.cpp:97-104) and M6 (Matcher.cpp:45-84) through the ABI vs the oracle: resident pairs, host arrays,
+    clamp at both ends, no match at all, a single pair"""
+    seq = synth.Sequence(3, 640, 480, seed=5, step=0.3)
+    ctx = make_ctx(hip_lib, max_frames=3)
+    for s in range(3):
+        ctx.upload_bgr(s, seq.frame(s))
+    ctx.build_pyramid(0, 3, from_bgr=True); ctx.detect(0, 3)
+    kps = [ctx.get_keypoints(s) for s in range(3)]
+    ctx.match_slots([1, 2, 0], [0, 1, 2], 1)
+    ctx.match_postfilter()
+    for p, (q, t) in enumerate([(1, 0), (2, 1), (0, 2)]):
+        idx, dist = ctx.get_matches(p)
+        good, ng, md = ctx.get_good_matches(p)
+        okeep, on = oracle.good_match_filter(idx, dist)
+        assert ng == on and np.array_equal(good, okeep) and 20 <= md <= 50
+        g2, ng2, md2 = ctx.match_postfilter_host(idx, dist)
+        assert ng2 == on and np.array_equal(g2, okeep) and md2 == md
+    rng = np.random.default_rng(3)
+    for lo_d, hi_d in ((0, 15), (60, 200), (25, 40)):                       # clamp to the floor / to the ceiling / inside
+        n = 700
+        idx = rng.integers(-1, 900, n).astype(np.int32); dist = rng.integers(lo_d, hi_d, n).astype(np.int32)
+        dist[idx < 0] = 0x7FFFFFFF
+        g, ng, md = ctx.match_postfilter_host(idx, dist)
+        ok_, on = oracle.good_match_filter(idx, dist)
+        assert ng == on and np.array_equal(g, ok_)
+    g, ng, md = ctx.match_postfilter_host(np.full(5, -1, np.int32), np.full(5, 0x7FFFFFFF, np.int32))
+    assert ng == 0 and not g.any() and md == 50.0
+    g, ng, md = ctx.match_postfilter_host(np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert ng == 0
+    # M6 on the resident descriptors of two slots and on host rows
+    n1, n2 = len(kps[0]["level"]), len(kps[1]["level"])
+    for n in (1, 63, 500, 1400):
+        i1 = rng.integers(0, n1, n).astype(np.int32); i2 = rng.integers(0, n2, n).astype(np.int32)
+        if n >= 63:
+            i2[:20] = ctx.get_matches(0)[0][:20].clip(0)                     # some true matches: small distances -> the floor clamp
+            i1[:20] = np.arange(20)
+        for lo, hi, ratio in ((30, 80, 3.0), (30, 100, 3.0), (150, 200, 0.9), (1, 2, 50.0)):
+            d, keep, ng, best = ctx.check_frame_descriptors(0, 1, i1, i2, lo, hi, ratio)
+            od, okeep, ong, obest = oracle.check_frame_descriptors(kps[0]["desc"], kps[1]["desc"], i1, i2, lo, hi, ratio)
+            assert np.array_equal(d, od) and np.array_equal(keep, okeep) and ng == ong and best == obest
+            d2, keep2, ng2, best2 = ctx.check_descriptor_pairs(kps[0]["desc"][i1], kps[1]["desc"][i2], lo, hi, ratio)
+            assert np.array_equal(d2, od) and np.array_equal(keep2, okeep) and ng2 == ong and best2 == obest
+    d, keep, ng, best = ctx.check_frame_descriptors(0, 1, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert ng == 0 and len(d) == 0
+    ctx.close()
+
+
+def _oracle_pair(oracle, seq, ref, cur, T_sa=None):
+    """the oracle's composition of one frame pair of the offline run (T_ref = identity)"""
+    w, h = seq.w, seq.h
+    lv_r = oracle.pyramid(oracle.bgr2gray(seq.frame(ref)), 3)
+    lv_c = oracle.pyramid(oracle.bgr2gray(seq.frame(cur)), 3)
+    prm = oracle.default_params(w, h, 3)
+    kr, kc = oracle.detect(lv_r, prm), oracle.detect(lv_c, prm)
+    px = np.stack([kr["px"], kr["py"]], axis=1).astype(np.float64)
+    dep = seq.depth(ref)[px[:, 1].astype(np.int64), px[:, 0].astype(np.int64)].astype(np.float64)
+    out = dict(kr=kr, kc=kc, px=px, depth=dep)
+    out["m_idx"], out["m_dist"], _ = oracle.bf_match(kc["desc"], kr["desc"], 1)
+    out["m_good"], out["n_good"] = oracle.good_match_filter(out["m_idx"], out["m_dist"])
+    pts = px.astype(np.float32)
+    out["klt"] = oracle.klt_track(lv_r[0], lv_c[0], pts, pts)
+    n_meas, T, st = oracle.sparse_align(lv_r, I7, lv_c, I7, px, dep, (dep > 0).astype(np.uint8))
+    out["sa"] = (n_meas, T, list(st.iters_per_level)[:3])
+    T_use = T if T_sa is None else T_sa                  # downstream stages are checked on the GPU's own pose (they branch on floats)
+    pw, pred, cand = oracle.track_candidates(I7, T_use, px, dep, w, h)
+    ok = np.zeros(len(px), bool); pxo = pred.copy(); sl = np.zeros(len(px), np.int32)
+    ci = np.nonzero(cand)[0]
+    ok[ci], pxo[ci], sl[ci] = oracle.find_direct_projection_n(lv_r, I7, lv_c, T_use, px[ci], dep[ci], kr["level"][ci], pred[ci])
+    out.update(pw=pw, pred=pred, cand=cand, fdp_ok=ok, fdp_px=pxo, fdp_level=sl)
+    th = oracle.se3_log(T_use)                           # [upsilon; omega]
+    entry = np.concatenate([T_use[4:], th[3:]])
+    out["po"] = oracle.optimize_current_pose_only(entry, pxo[ok], pw[ok])
+    return out
+
+
+def _check_pair(rec, o):
+    """record of the offline run (keep=True) vs the oracle composition"""
+    assert rec["n_kp"] == len(o["kc"]["level"])
+    assert np.array_equal(rec["m_idx"], o["m_idx"]) and np.array_equal(rec["m_dist"], o["m_dist"])
+    assert np.array_equal(rec["m_good"], o["m_good"]) and rec["n_good"] == o["n_good"]
+    oout, ost, oerr = o["klt"]
+    assert np.array_equal(rec["klt_status"], ost)
+    m = ost.astype(bool)
+    assert np.all(np.abs(rec["klt_pts"][m] - oout[m]).max(1) <= 1e-5 * np.maximum(1.0, np.abs(oout[m]).max(1)))       # north_star: 1e-5 relative
+    n_meas, T, iters = o["sa"]
+    assert rec["sa_n_meas"] == n_meas and rec["sa_iters"] == iters
+    assert np.allclose(rec["T_sa"], T, rtol=1e-9, atol=1e-11)
+    assert np.array_equal(rec["fdp_ok"], o["fdp_ok"])
+    c = o["cand"]
+    assert np.array_equal(rec["fdp_px"][c], o["fdp_px"][c]) and np.array_equal(rec["fdp_level"][c], o["fdp_level"][c])
+    assert np.array_equal(rec["fdp_px"][~c], o["pred"][~c])
+    pose, bad, depth, inl, rounds = o["po"]
+    assert rec["po_inliers"] == inl and rec["po_rounds"] == rounds
+    full_bad = np.ones(len(c), bool); full_bad[np.nonzero(o["fdp_ok"])[0]] = bad.astype(bool)
+    assert np.array_equal(rec["po_bad"], full_bad)
+    assert np.allclose(rec["po_pose"], pose, rtol=1e-7, atol=1e-9)
+
+
+def test_track_handover_and_pose_only_vga(hip_lib, oracle):
+    """the device-side chain sparse alignment -> adopt pose -> FindDirectProjection -> OptimizeCurrentPoseOnly of 3 VGA pairs
+    against the oracle's composition (bit-exact candidates / pixels / flags on the GPU's own alignment pose)"""
+    seq = synth.Sequence(4, 640, 480, seed=7, step=0.25)
+    vo = offline.OfflineVO(640, 480, 4, chunk=4, kf_stride=2, window_kfs=2, keep=True)
+    rec = vo.track_shard(seq.frame, seq.depth)
+    for cur in (1, 2, 3):
+        o = _oracle_pair(oracle, seq, cur - 1, cur, T_sa=rec[cur]["T_sa"])
+        _check_pair(rec[cur], o)
+        assert rec[cur]["po_inliers"] > 100
+        # the refined relative pose is close to the ground truth of the synthetic sequence
+        gt = offline.se3_mul(seq.poses[cur], offline.se3_inv(seq.poses[cur - 1]))
+        assert np.abs(rec[cur]["T_rel"] - gt).max() < 5e-3
+    vo.close()
+
+
+N_SEQ = 16
+
+
+def _run_offline(rank, world, port, outdir, chunk):
+    import sys
+    sys.path.insert(0, ROOT)
+    pg = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)         # RCCL refuses two ranks on one device; gloo carries the same calls
+    seq = synth.Sequence(N_SEQ, 1280, 720, seed=11, step=0.05)
+    vo = offline.OfflineVO(1280, 720, N_SEQ, rank=rank, world=world, device=0, chunk=chunk, kf_stride=2, window_kfs=4,
+                           max_points=2000, keep=True, exchange_on_device=False)
+    res = vo.run(seq.frame, seq.depth)
+    vo.close()
+    res.pop("built")
+    with open(os.path.join(outdir, "r%d_of_%d.pkl" % (rank, world)), "wb") as f:
+        pickle.dump(res, f)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _same(a, b, path=""):
+    if isinstance(a, dict):
+        assert set(a) == set(b), path
+        for k in a:
+            _same(a[k], b[k], path + "/" + str(k))
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, path + "/%d" % i)
+    elif isinstance(a, np.ndarray):
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), path
+    else:
+        assert a == b or (a != a and b != b), path
+
+
+def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path):
+    """BASELINE configs[4] at test size: a 16-frame 1280x720 sequence (a) unsharded in one chunk, (b) unsharded in chunks of 5
+    frames (halo between chunks), (c) as 2 shards in 2 processes (gloo, both on this box's GPU): keypoints, matches, tracks,
+    poses, BA windows and the gathered trajectory are IDENTICAL; two pairs are checked against the oracle."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    _run_offline(0, 1, 0, out, N_SEQ)
+    full = pickle.load(open(os.path.join(out, "r0_of_1.pkl"), "rb"))
+    os.rename(os.path.join(out, "r0_of_1.pkl"), os.path.join(out, "full.pkl"))
+    _run_offline(0, 1, 0, out, 5)
+    chunked = pickle.load(open(os.path.join(out, "r0_of_1.pkl"), "rb"))
+    _same(full, chunked)
+    mp.spawn(_run_offline, args=(2, _free_port(), out, N_SEQ), nprocs=2, join=True)
+    parts = [pickle.load(open(os.path.join(out, "r%d_of_2.pkl" % r), "rb")) for r in range(2)]
+    # every rank ends with the same global trajectory, relative poses, windows and keyframe poses as the unsharded run
+    for part in parts:
+        for k in ("T_rel", "trajectory", "windows", "keyframe_pose"):
+            _same(full[k], part[k], k)
+    merged = {}
+    for part in parts:
+        merged.update(part["records"])
+    assert sorted(merged) == list(range(N_SEQ))
+    assert sorted(parts[0]["records"]) == list(range(8)) and sorted(parts[1]["records"]) == list(range(8, 16))
+    _same(full["records"], merged, "records")
+    # sanity of the run itself
+    assert len(full["windows"]) == 2 and [w["owner"] for w in parts[0]["windows"]] == [0, 1]
+    for w in full["windows"]:
+        chi0, chi1, its, n_edges = w["stats"]
+        assert n_edges > 1000 and chi1 < chi0 and its >= 1
+    seq = synth.Sequence(N_SEQ, 1280, 720, seed=11, step=0.05)
+    gt = np.stack([offline.se3_mul(seq.poses[i], offline.se3_inv(seq.poses[0])) for i in range(N_SEQ)])
+    assert np.abs(full["trajectory"] - gt).max() < 2e-2
+    # oracle parity on a subset: one pair inside shard 0 and the pair that straddles the shard boundary (cur = 8, ref = 7: the halo)
+    for cur in (3, 8):
+        o = _oracle_pair(oracle, seq, cur - 1, cur, T_sa=full["records"][cur]["T_sa"])
+        _check_pair(full["records"][cur], o)

@@ -93,6 +93,8 @@ ABI_SYMBOLS = [
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
     "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map",
+    "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_check_frame_descriptors",
+    "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
 ]
 
 _lib = None
@@ -261,6 +263,46 @@ class HipContext:
                                                  _p(d2, C.c_int32) if want_second else None), "hamming_match")
         return (idx, dist, d2) if want_second else (idx, dist)
 
+    # ---- M3 / M6 filters
+    def match_postfilter(self, min_floor=20.0, min_ceil=50.0, factor=3.0):
+        self._chk(self.lib.ygz_hip_match_postfilter(self._ctx, C.c_double(min_floor), C.c_double(min_ceil), C.c_double(factor)), "match_postfilter")
+
+    def get_good_matches(self, pair):
+        good = np.zeros(self.cells, np.uint8)
+        n, ng, md = C.c_int(0), C.c_int(0), C.c_double(0)
+        self._chk(self.lib.ygz_hip_get_good_matches(self._ctx, pair, _p(good, C.c_uint8), self.cells, C.byref(n), C.byref(ng), C.byref(md)),
+                  "get_good_matches")
+        return good[:n.value].astype(bool), ng.value, md.value
+
+    def match_postfilter_host(self, train_idx, dist, min_floor=20.0, min_ceil=50.0, factor=3.0):
+        ti = np.ascontiguousarray(train_idx, np.int32); di = np.ascontiguousarray(dist, np.int32)
+        good = np.zeros(max(len(ti), 1), np.uint8)
+        ng, md = C.c_int(0), C.c_double(0)
+        self._chk(self.lib.ygz_hip_match_postfilter_host(self._ctx, _p(ti, C.c_int32), _p(di, C.c_int32), len(ti), C.c_double(min_floor),
+                                                         C.c_double(min_ceil), C.c_double(factor), _p(good, C.c_uint8), C.byref(ng), C.byref(md)),
+                  "match_postfilter_host")
+        return good[:len(ti)].astype(bool), ng.value, md.value
+
+    def check_frame_descriptors(self, slot1, slot2, idx1, idx2, init_low=30, init_high=80, ratio=3.0):
+        i1 = np.ascontiguousarray(idx1, np.int32); i2 = np.ascontiguousarray(idx2, np.int32)
+        n = len(i1)
+        dist = np.zeros(max(n, 1), np.int32); keep = np.zeros(max(n, 1), np.uint8)
+        ng, best = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.ygz_hip_check_frame_descriptors(self._ctx, slot1, slot2, _p(i1, C.c_int32), _p(i2, C.c_int32), n, init_low, init_high,
+                                                           C.c_float(ratio), _p(dist, C.c_int32), _p(keep, C.c_uint8), C.byref(ng), C.byref(best)),
+                  "check_frame_descriptors")
+        return dist[:n].copy(), keep[:n].astype(bool), ng.value, best.value
+
+    def check_descriptor_pairs(self, desc1, desc2, init_low=30, init_high=80, ratio=3.0):
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n = len(d1)
+        dist = np.zeros(max(n, 1), np.int32); keep = np.zeros(max(n, 1), np.uint8)
+        ng, best = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.ygz_hip_check_descriptor_pairs(self._ctx, _p(d1, C.c_uint8), _p(d2, C.c_uint8), n, init_low, init_high, C.c_float(ratio),
+                                                          _p(dist, C.c_int32), _p(keep, C.c_uint8), C.byref(ng), C.byref(best)),
+                  "check_descriptor_pairs")
+        return dist[:n].copy(), keep[:n].astype(bool), ng.value, best.value
+
     # ---- alignment
     def find_direct_projection(self, ref_slot, T_ref, cur_slot, T_cur, px_ref, depth_ref, level_ref, px_cur):
         pair = AlignPair(ref_slot, cur_slot, (C.c_double * 7)(*T_ref), (C.c_double * 7)(*T_cur))
@@ -364,6 +406,21 @@ class HipContext:
 
     def track_sparse_align(self, max_level=2, min_level=0, n_iter=30):
         self._chk(self.lib.ygz_hip_track_sparse_align(self._ctx, max_level, min_level, n_iter), "track_sparse_align")
+
+    def track_adopt_pose(self):
+        self._chk(self.lib.ygz_hip_track_adopt_pose(self._ctx), "track_adopt_pose")
+
+    def track_pose_only(self):
+        self._chk(self.lib.ygz_hip_track_pose_only(self._ctx), "track_pose_only")
+
+    def track_get_pose_only(self, pair):
+        pose = (C.c_double * 6)(); T = (C.c_double * 7)()
+        inl, rnd, n = C.c_int(0), C.c_int(0), C.c_int(0)
+        bad = np.zeros(self.cells, np.uint8); depth = np.zeros(self.cells, np.float64)
+        self._chk(self.lib.ygz_hip_track_get_pose_only(self._ctx, pair, pose, T, C.byref(inl), C.byref(rnd), _p(bad, C.c_uint8),
+                                                       _p(depth, C.c_double), self.cells, C.byref(n)), "track_get_pose_only")
+        return dict(pose=np.array(list(pose)), T=np.array(list(T)), inliers=inl.value, rounds=rnd.value,
+                    bad=bad[:n.value].astype(bool), depth=depth[:n.value].copy())
 
     def track_get_klt(self, pair):
         pts = np.empty((self.cells, 2), np.float32)

@@ -122,6 +122,7 @@ struct FdpArgs {
     const double *pair_T;                         // [pairs][2][7] (T_ref, T_cur)
     const double *trk_px, *trk_depth; const int32_t *trk_level;
     double *px_cur; int32_t *search_level; uint8_t *ok;      // [pairs][cells]
+    const uint8_t *cand;                                     // [pairs][cells] or nullptr: 0 = not a candidate (FindCandidates dropped it)
 };
 
 // the body shared by both Matcher::FindDirectProjection overloads (Matcher.cpp:356-417) from Pixel2Camera(px_ref, depth) on:
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
     if (ii >= A.trk_n[pair]) return;
     const size_t i = (size_t)pair * A.cells + ii;
     const double depth = A.trk_depth[i];
-    if (depth < 0) { A.ok[i] = 0; A.search_level[i] = 0; return; }
+    if (depth < 0 || (A.cand && !A.cand[i])) { A.ok[i] = 0; A.search_level[i] = 0; return; }
     const double px_ref[2] = { A.trk_px[2 * i], A.trk_px[2 * i + 1] };
     double px_cur[2] = { A.px_cur[2 * i], A.px_cur[2 * i + 1] };
     int sl;
@@ -311,7 +312,7 @@ int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs)
     A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_level = ctx->trk_level;
-    A.px_cur = ctx->fdp_px; A.search_level = ctx->fdp_level; A.ok = ctx->fdp_ok;
+    A.px_cur = ctx->fdp_px; A.search_level = ctx->fdp_level; A.ok = ctx->fdp_ok; A.cand = ctx->fdp_cand;
     YGZ_LAUNCH(ctx, KID_FDP, k_find_direct_projection, dim3(ygz_div_up(ctx->cells, 64), ygz_round_up8(n_pairs)), dim3(64), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
@@ -323,6 +324,7 @@ extern "C" {
 int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair, const double *px_ref, const double *depth_ref,
                                    const int32_t *level_ref, double *px_cur, int32_t *search_level, uint8_t *ok, int n)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !pair || n < 0) return YGZ_E_INVALID;
     if (n == 0) return YGZ_OK;
     if (!px_ref || !depth_ref || !level_ref || !px_cur || !search_level || !ok) return YGZ_E_INVALID;
@@ -337,6 +339,7 @@ int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair,
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, depth_ref, N * 8, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_level, level_ref, N * 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->fdp_px, px_cur, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->fdp_cand, 1, N, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = ygz_launch_fdp(ctx, 1)) != YGZ_OK) return rc;
@@ -350,6 +353,7 @@ int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair,
 int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pwb, const uint8_t *patch, double *uv,
                     uint8_t *ok, float *chi2, int n, int n_iter)
 {
+    YgzDeviceGuard dg_(ctx);
     (void)patch;     // the 8x8 patch is the interior of the 10x10 one (Matcher.cpp:369-375); kept for signature parity
     if (!ctx || n < 0 || cur_slot < 0 || cur_slot >= ctx->prm.max_frames || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
     if (n == 0) return YGZ_OK;
@@ -378,6 +382,7 @@ int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pw
 int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
                             uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level, int32_t *n_matched)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !T_cur || !m || m->n_points < 0 || m->n_keyframes < 0 || m->n_candidates < 0) return YGZ_E_INVALID;
     if (cur_slot < 0 || cur_slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     if (!ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
@@ -419,7 +424,7 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 0;
     A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
-    A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr;
+    A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;
     A.F.px_cur = nullptr; A.F.search_level = nullptr; A.F.ok = nullptr;
     A.cur_slot = cur_slot; A.P = P; A.C = Cn; A.K = K; A.T_cur = d_T;
     A.pos_world = d_pw; A.point_bad = m->point_bad ? d_bad : nullptr; A.kf_slot = d_kfs; A.kf_T = d_kfT;
@@ -472,6 +477,7 @@ __global__ __launch_bounds__(256) void k_depth_from_triangulation(const double *
 extern "C" int ygz_hip_depth_from_triangulation(ygz_hip_ctx *ctx, const double T_search_ref[7], const double *f_ref, const double *f_cur, int n,
                                                 double determinant_th, double *depth1, double *depth2, uint8_t *ok)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !T_search_ref || n < 0 || (n > 0 && (!f_ref || !f_cur || !depth1 || !depth2 || !ok))) return YGZ_E_INVALID;
     if (n == 0) return YGZ_OK;

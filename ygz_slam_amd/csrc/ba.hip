@@ -142,6 +142,7 @@ static void ba_free(ygz_hip_ctx::BaWindow *w) { if (w) { if (w->blob) (void)hipF
 
 extern "C" void ygz_hip_ba_free_all(ygz_hip_ctx *ctx)
 {
+    YgzDeviceGuard dg_(ctx);
     for (auto *w : ctx->ba) ba_free(w);
     ctx->ba.clear();
     if (ctx->ba_table) { (void)hipFree(ctx->ba_table); ctx->ba_table = nullptr; }
@@ -192,6 +193,7 @@ extern "C" {
 
 int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !pb || window < 0 || window > 1023) return YGZ_E_INVALID;
     const int K = pb->n_poses, P = pb->n_points, E = pb->n_edges;
@@ -286,6 +288,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
 
 int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, const double *points)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
@@ -298,6 +301,7 @@ int ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, cons
 // device-pointer variant: the new state is already in HBM (e.g. a torch tensor filled by an RCCL broadcast)
 int ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_poses, const double *d_points)
 {
+    YgzDeviceGuard dg_(ctx);
     // only a pending BA stage reads what this overwrites; sparse alignment / matcher stages of the last step keep running
     if (ctx) { int rj_ = ygz_join(ctx, ~(1u << YGZ_AUX_BA)); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
@@ -309,6 +313,7 @@ int ygz_hip_ba_set_state_device(ygz_hip_ctx *ctx, int window, const double *d_po
 
 int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size()) return YGZ_E_INVALID;
     for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i]) return YGZ_E_INVALID;
     int trc = YGZ_OK;
@@ -326,6 +331,7 @@ int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
 int ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, double *Hll, double *bl, double *Hpl,
                         double *err, double *chi2_edge, double *chi2)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
@@ -357,6 +363,7 @@ int ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, d
 
 int ygz_hip_ba_behind_camera(ygz_hip_ctx *ctx, int window, int *n_behind)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !n_behind || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     int32_t v = 0;
@@ -368,6 +375,7 @@ int ygz_hip_ba_behind_camera(ygz_hip_ctx *ctx, int window, int *n_behind)
 
 int ygz_hip_ba_set_enable(ygz_hip_ctx *ctx, int window, const uint8_t *edge_enable)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !edge_enable || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
@@ -381,6 +389,7 @@ int ygz_hip_ba_set_enable(ygz_hip_ctx *ctx, int window, const uint8_t *edge_enab
 int ygz_hip_ba_linearize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *Hpp, double *bp, double *Hll, double *bl,
                          double *Hpl, double *err, double *chi2_edge, double *chi2)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx) return YGZ_E_INVALID;
     const int window = 1023;          // private slot for the one-shot form
     int rc = ygz_hip_ba_upload(ctx, window, pb);

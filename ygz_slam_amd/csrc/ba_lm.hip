@@ -138,6 +138,7 @@ static bool block_solve(BlockSystem &B, const double *Hpp, const double *Hll, co
 extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                                    int max_iterations, ygz_ba_stats *stats)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !pb || !poses_io || !points_io || max_iterations < 0) return YGZ_E_INVALID;
     if (pb->formulation != 0) return YGZ_E_INVALID;       // the g2o path of the live tree
     const int K = pb->n_poses, P = pb->n_points, E = pb->n_edges, W = 1022;
@@ -242,6 +243,7 @@ extern "C" void ygz_hip_ceres_default_options(ygz_ceres_options *o)
 extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                                       const ygz_ceres_options *opt_in, ygz_ceres_summary *summary)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !pb || !poses_io || !points_io) return YGZ_E_INVALID;
     if (pb->formulation != 2) return YGZ_E_INVALID;
     ygz_ceres_options opt;

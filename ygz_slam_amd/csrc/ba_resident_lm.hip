@@ -320,6 +320,7 @@ extern "C" {
 
 int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, int max_iterations, ygz_ba_stats *stats)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size() || max_iterations < 0) return YGZ_E_INVALID;
     for (int i = window_begin; i < window_begin + n_windows; ++i) {
         if (!ctx->ba[i]) return YGZ_E_INVALID;
@@ -343,6 +344,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
 
 int ygz_hip_ba_get_state(ygz_hip_ctx *ctx, int window, double *poses, double *points)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const BowPair *__restrict__ p
 
 extern "C" void ygz_hip_vocab_free(ygz_hip_ctx *ctx)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx->vocab) return;
     if (ctx->vocab->blob) (void)hipFree(ctx->vocab->blob);
     if (ctx->vocab->kp_word) (void)hipFree(ctx->vocab->kp_word);
@@ -151,6 +152,7 @@ extern "C" {
 
 int ygz_hip_vocab_load(ygz_hip_ctx *ctx, const void *blob, size_t bytes)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !blob || bytes < 24) return YGZ_E_INVALID;
     const uint8_t *p = (const uint8_t *)blob;
@@ -199,6 +201,7 @@ int ygz_hip_vocab_load(ygz_hip_ctx *ctx, const void *blob, size_t bytes)
 
 int ygz_hip_vocab_info(ygz_hip_ctx *ctx, int *k, int *L, int *n_nodes, int *n_words)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !ctx->vocab) return YGZ_E_STATE;
     if (k) *k = ctx->vocab->k; if (L) *L = ctx->vocab->L; if (n_nodes) *n_nodes = ctx->vocab->n_nodes; if (n_words) *n_words = ctx->vocab->n_words;
     return YGZ_OK;
@@ -207,6 +210,7 @@ int ygz_hip_vocab_info(ygz_hip_ctx *ctx, int *k, int *L, int *n_nodes, int *n_wo
 // Frame::ComputeBoW for the resident keypoints of slots slot_begin .. +n_slots-1
 int ygz_hip_compute_bow(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int levelsup)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames || levelsup < 0) return YGZ_E_INVALID;
     if (!ctx->vocab) return YGZ_E_STATE;
     auto *v = ctx->vocab;
@@ -219,6 +223,7 @@ int ygz_hip_compute_bow(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int level
 
 int ygz_hip_get_bow(ygz_hip_ctx *ctx, int slot, int32_t *word, double *weight, int32_t *node, int capacity, int *n)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || capacity < 0) return YGZ_E_INVALID;
     if (!ctx->vocab) return YGZ_E_STATE;
@@ -240,6 +245,7 @@ int ygz_hip_get_bow(ygz_hip_ctx *ctx, int slot, int32_t *word, double *weight, i
 // host descriptors in, host BoW out (what the class surface uses: Feature::_desc lives on the host)
 int ygz_hip_bow_transform(ygz_hip_ctx *ctx, const uint8_t *desc, int n, int levelsup, int32_t *word, double *weight, int32_t *node)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || n < 0 || levelsup < 0 || (n > 0 && !desc)) return YGZ_E_INVALID;
     if (!ctx->vocab) return YGZ_E_STATE;
@@ -283,6 +289,7 @@ static int bow_match_launch(ygz_hip_ctx *ctx, int mode, const std::vector<BowPai
 int ygz_hip_search_by_bow_slots(ygz_hip_ctx *ctx, int mode, int n_pairs, const int32_t *slot1, const int32_t *slot2, const double *E12,
                                 int th_low, float knn_ratio, double epipolar_dsqr, int32_t *match12, int32_t *counts)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || n_pairs < 1 || !slot1 || !slot2 || (mode != 0 && mode != 1) || (mode == 1 && !E12)) return YGZ_E_INVALID;
     if (!ctx->vocab) return YGZ_E_STATE;
@@ -318,6 +325,7 @@ int ygz_hip_search_by_bow(ygz_hip_ctx *ctx, int mode, const uint8_t *desc1, cons
                           const uint8_t *desc2, const int32_t *node2, const double *px2, int n2, const double *E12,
                           int th_low, float knn_ratio, double epipolar_dsqr, int32_t *match12, int *count)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || n1 < 0 || n2 < 0 || (mode != 0 && mode != 1) || (mode == 1 && (!E12 || (n1 > 0 && !px1) || (n2 > 0 && !px2)))) return YGZ_E_INVALID;
     if (count) *count = 0;

@@ -80,7 +80,10 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
         return YGZ_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return YGZ_E_NO_DEVICE;
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     if (hipSetDevice(device) != hipSuccess) return YGZ_E_NO_DEVICE;
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore_{ prev_dev == device ? -1 : prev_dev };
     ygz_hip_ctx *ctx = new (std::nothrow) ygz_hip_ctx();
     if (!ctx) return YGZ_E_INVALID;
     ctx->prm = *prm;
@@ -135,6 +138,7 @@ void ygz_hip_vocab_free(ygz_hip_ctx *ctx);    // bow.hip
 
 void ygz_hip_destroy(ygz_hip_ctx *ctx)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < 3; ++i) if (ctx->aux[i]) (void)hipStreamSynchronize(ctx->aux[i]);
@@ -151,9 +155,9 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     }
     void *ptrs[] = { ctx->bgr, ctx->cell_first, ctx->cell_best, ctx->occupied, ctx->kp_px, ctx->kp_level, ctx->kp_score,
                      ctx->kp_angle, ctx->kp_desc, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->m_tq, ctx->m_td, ctx->m_key,
-                     ctx->m_idx, ctx->m_dist, ctx->m_dist2, ctx->trk_n, ctx->trk_px, ctx->trk_level, ctx->trk_depth, ctx->trk_has_mp,
+                     ctx->m_idx, ctx->m_dist, ctx->m_dist2, ctx->m_good, ctx->m_good_n, ctx->m_min_dis, ctx->trk_n, ctx->trk_px, ctx->trk_level, ctx->trk_depth, ctx->trk_has_mp,
                      ctx->pair_T, ctx->kp_depth, ctx->kp_has_mp, ctx->klt_pts, ctx->klt_err, ctx->klt_status, ctx->fdp_px,
-                     ctx->fdp_level, ctx->fdp_ok, ctx->sa_out, ctx->sa_work };
+                     ctx->fdp_level, ctx->fdp_ok, ctx->sa_out, ctx->sa_work, ctx->fdp_cand, ctx->po_pw, ctx->po_pose, ctx->po_depth, ctx->po_bad, ctx->po_cnt };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < YGZ_N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -167,6 +171,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
 
 int ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx) return YGZ_E_INVALID;
     int rc = ygz_join(ctx);
     if (rc != YGZ_OK) return rc;
@@ -183,6 +188,7 @@ int ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable)
 
 int ygz_hip_synchronize(ygz_hip_ctx *ctx)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx) return YGZ_E_INVALID;
     int rcj = ygz_join(ctx);
     if (rcj != YGZ_OK) return rcj;
@@ -192,6 +198,7 @@ int ygz_hip_synchronize(ygz_hip_ctx *ctx)
 
 int ygz_hip_timer_begin(ygz_hip_ctx *ctx)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx) return YGZ_E_INVALID;
     YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     return YGZ_OK;
@@ -199,6 +206,7 @@ int ygz_hip_timer_begin(ygz_hip_ctx *ctx)
 
 int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !elapsed_ms) return YGZ_E_INVALID;
     { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -210,10 +218,12 @@ int ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms)
 static const char *const k_kernel_names[KID_COUNT] = {
     "k_bgr2gray", "k_pyr_down", "k_fast_select", "k_compact", "k_describe", "k_hamming_nn", "k_match_finalize", "k_track_load",
     "k_find_direct_projection", "k_align2d", "k_sparse_align", "k_scharr", "k_klt", "k_klt_pad", "k_ba_pose_prep", "k_ba_points", "k_ba_final",
-    "k_ba_chi2", "k_pose_only_ba", "k_ba_lm", "k_bow_transform", "k_bow_match", "k_depth_from_triangulation", "k_lmap_match", "k_lmap_aux" };
+    "k_ba_chi2", "k_pose_only_ba", "k_ba_lm", "k_bow_transform", "k_bow_match", "k_depth_from_triangulation", "k_lmap_match", "k_lmap_aux",
+    "k_match_postfilter", "k_track_aux", "k_depth_filter" };
 
 int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launches)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !kernel_name || max_launches < 1 || max_launches > 65536) return YGZ_E_INVALID;
     int id = -1;
     for (int i = 0; i < KID_COUNT; ++i) if (strcmp(kernel_name, k_kernel_names[i]) == 0) id = i;
@@ -229,6 +239,7 @@ int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launc
 
 int ygz_hip_probe_end(ygz_hip_ctx *ctx, double *total_ms, int *launches)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !total_ms || !launches) return YGZ_E_INVALID;
     { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     for (int i = 0; i < 3; ++i) if (ctx->aux[i]) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->aux[i]));
@@ -254,6 +265,7 @@ int ygz_hip_level_size(const ygz_hip_ctx *ctx, int level, int *w, int *h)
 
 int ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int stride_bytes)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !bgr || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     const int w = ctx->lw[0], h = ctx->lh[0];
@@ -268,6 +280,7 @@ int ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int strid
 
 int ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int stride_bytes)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !gray || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     const int w = ctx->lw[0], h = ctx->lh[0];
@@ -281,6 +294,7 @@ int ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int str
 
 int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     if (from_bgr && !ctx->bgr) return YGZ_E_STATE;
     { int rj = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj != YGZ_OK) return rj; }      // a pending BA linearisation reads no image
@@ -292,6 +306,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
 
 int ygz_hip_download_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !dst || slot < 0 || slot >= ctx->prm.max_frames || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
     const size_t n = (size_t)ctx->lw[level] * ctx->lh[level];

@@ -518,6 +518,7 @@ extern "C" {
 
 int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *occupied)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) if (!ctx->pyr_valid[s]) return YGZ_E_STATE;
@@ -530,6 +531,7 @@ int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t 
 
 int ygz_hip_keypoint_count(ygz_hip_ctx *ctx, int slot, int *n)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !n || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(n, ctx->n_kp + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -538,6 +540,7 @@ int ygz_hip_keypoint_count(ygz_hip_ctx *ctx, int slot, int *n)
 
 int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capacity, int *n_out)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !out || !n_out || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
     int n = 0;
@@ -577,17 +580,20 @@ static int describe_impl(ygz_hip_ctx *ctx, int slot, const double *px, const int
 
 int ygz_hip_describe(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, int n)
 {
+    YgzDeviceGuard dg_(ctx);
     return describe_impl(ctx, slot, px, level, nullptr, n);
 }
 
 int ygz_hip_describe_given_angle(ygz_hip_ctx *ctx, int slot, const double *px, const int32_t *level, const float *angle, int n)
 {
+    YgzDeviceGuard dg_(ctx);
     if (n > 0 && !angle) return YGZ_E_INVALID;
     return describe_impl(ctx, slot, px, level, angle, n);
 }
 
 int ygz_hip_get_fast_maps(ygz_hip_ctx *ctx, int slot, int level, uint8_t *score, uint8_t *nms)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || level < 0 || level >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
     if (!ctx->prm.debug_maps) return YGZ_E_STATE;
     const size_t npix = (size_t)ctx->lw[level] * ctx->lh[level];

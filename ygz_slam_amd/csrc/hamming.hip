@@ -134,6 +134,7 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
                      const int32_t *pair_q, const int32_t *pair_t, int n_pairs, int max_rows, int cross_check, bool want_second)
 {
     const size_t Cn = (size_t)ctx->cells;
+    ctx->pf_valid = false;                            // the M3 flags of the previous result are stale
     HamArgs A;
     A.desc = desc; A.set_stride = set_stride; A.set_count = set_count; A.out_stride = Cn;
     const dim3 grid(n_pairs, ygz_div_up(max_rows, 256)), block(256), grid_f(ygz_div_up(max_rows, 256), n_pairs);
@@ -165,6 +166,7 @@ extern "C" {
 
 int ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32_t *train_slot, int n_pairs, int cross_check)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !query_slot || !train_slot || n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     if (n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;
@@ -182,6 +184,7 @@ int ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32
 // resident variant for pipelines: pair tables already uploaded by a previous ygz_hip_match_slots call
 int ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || ctx->n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     YgzAuxScope aux(ctx, 2);
     return run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->n_pairs, ctx->cells,
@@ -190,6 +193,7 @@ int ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check)
 
 int ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx, int32_t *dist, int capacity, int *nq_out)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || pair < 0 || pair >= ctx->n_pairs || !nq_out) return YGZ_E_INVALID;
     int32_t qslot = 0, nq = 0;
@@ -211,6 +215,7 @@ int ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx, int32_t 
 int ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int cross_check,
                           int32_t *train_idx, int32_t *dist, int32_t *dist2)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     if (dist2 && cross_check != 0) return YGZ_E_INVALID;

@@ -570,6 +570,7 @@ void ygz_hip_default_klt_params(ygz_klt_params *p)
 int ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
                       const ygz_klt_params *prm, uint8_t *status, float *err)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !prm || n < 0 || prev_slot < 0 || prev_slot >= ctx->prm.max_frames || cur_slot < 0 || cur_slot >= ctx->prm.max_frames)
         return YGZ_E_INVALID;
     if (n == 0) return YGZ_OK;

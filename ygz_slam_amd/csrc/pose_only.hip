@@ -20,7 +20,7 @@
 #define PO_NV 28
 
 struct PoArgs {
-    const int32_t *off; const double *px, *pw; double *poses; uint8_t *bad; double *depth; int32_t *inliers, *rounds;
+    YgzPoDev d;               // off (or cnt + stride), use, px, pw, poses, bad, depth, inliers, rounds
     double fx, fy, cx, cy;
     ygz_ceres_options opt;
 };
@@ -59,12 +59,12 @@ __device__ bool po_eval(const PoArgs &A, int beg, int n, const double *pose /*LD
     int behind = 0;
     for (int i = tid; i < n; i += PO_THREADS) {
         const size_t g = (size_t)(beg + i);
-        if (A.bad[g]) continue;                                   // SetEnable(false)
-        const double X = A.pw[3 * g], Y = A.pw[3 * g + 1], Z = A.pw[3 * g + 2];
+        if (A.d.bad[g]) continue;                                   // SetEnable(false)
+        const double X = A.d.pw[3 * g], Y = A.d.pw[3 * g + 1], Z = A.d.pw[3 * g + 2];
         const double a = R[0] * X + R[1] * Y + R[2] * Z, b = R[3] * X + R[4] * Y + R[5] * Z, c = R[6] * X + R[7] * Y + R[8] * Z;
         const double x = a + t0, y = b + t1, z = c + t2;
         if (z < 0) { behind = 1; continue; }
-        const double obx = (A.px[2 * g] - A.cx) / A.fx, oby = (A.px[2 * g + 1] - A.cy) / A.fy;      // Pixel2Camera2D, Camera.h:64-69
+        const double obx = (A.d.px[2 * g] - A.cx) / A.fx, oby = (A.d.px[2 * g + 1] - A.cy) / A.fy;      // Pixel2Camera2D, Camera.h:64-69
         const double r0 = obx - x / z, r1 = oby - y / z;
         acc[27] += 0.5 * (r0 * r0 + r1 * r1);
         if (!full) continue;
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
     __shared__ double lin[PO_NV], tmp[PO_NV];       // the iterate's linearisation; the candidate's cost
     __shared__ PoState S;
     const int f = blockIdx.x, tid = threadIdx.x;
-    const int beg = A.off[f], n = A.off[f + 1] - beg;
+    const int beg = A.d.cnt ? f * A.d.stride : A.d.off[f], n = A.d.cnt ? A.d.cnt[f] : A.d.off[f + 1] - beg;
     const ygz_ceres_options &o = A.opt;
-    if (tid < 6) { const double v = A.poses[6 * (size_t)f + tid]; S.backup[tid] = v; S.tcw[tid] = v; }
-    for (int i = tid; i < n; i += PO_THREADS) A.bad[beg + i] = 0;
+    if (tid < 6) { const double v = A.d.poses[6 * (size_t)f + tid]; S.backup[tid] = v; S.tcw[tid] = v; }
+    for (int i = tid; i < n; i += PO_THREADS) A.d.bad[beg + i] = (uint8_t)(A.d.use ? !A.d.use[beg + i] : 0);   // features that do not exist in this frame
     __syncthreads();
 
     int it = 0, cntInlier = 0;
@@ -241,14 +241,15 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
             int mine = 0;
             for (int i = tid; i < n; i += PO_THREADS) {
                 const size_t g = (size_t)(beg + i);
-                const double pw[3] = { A.pw[3 * g], A.pw[3 * g + 1], A.pw[3 * g + 2] };
+                if (A.d.use && !A.d.use[g]) continue;
+                const double pw[3] = { A.d.pw[3 * g], A.d.pw[3 * g + 1], A.d.pw[3 * g + 2] };
                 double pc[3];
                 quat_rotate_d(q, pw, pc);
                 pc[0] += S.tcw[0]; pc[1] += S.tcw[1]; pc[2] += S.tcw[2];
                 const double u = A.fx * pc[0] / pc[2] + A.cx, v = A.fy * pc[1] / pc[2] + A.cy;     // Camera2Pixel, Camera.h:48-53
-                const double dx = u - A.px[2 * g], dy = v - A.px[2 * g + 1], error2 = dx * dx + dy * dy;
-                if (error2 > (double)5.991f) A.bad[g] = 1;       // const float chi2Mono = 5.991, BA.cpp:195
-                else { A.depth[g] = pc[2]; A.bad[g] = 0; ++mine; }
+                const double dx = u - A.d.px[2 * g], dy = v - A.d.px[2 * g + 1], error2 = dx * dx + dy * dy;
+                if (error2 > (double)5.991f) A.d.bad[g] = 1;       // const float chi2Mono = 5.991, BA.cpp:195
+                else { A.d.depth[g] = pc[2]; A.d.bad[g] = 0; ++mine; }
             }
             if (mine) atomicAdd(&S.cnt, mine);
         }
@@ -258,14 +259,29 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
         if (tid < 6) S.tcw[tid] = S.pose[tid];
         __syncthreads();
     }
-    if (tid < 6) A.poses[6 * (size_t)f + tid] = S.tcw[tid];
-    if (tid == 0) { if (A.inliers) A.inliers[f] = cntInlier; if (A.rounds) A.rounds[f] = it; }
+    if (tid < 6) A.d.poses[6 * (size_t)f + tid] = S.tcw[tid];
+    if (tid == 0) { if (A.d.inliers) A.d.inliers[f] = cntInlier; if (A.d.rounds) A.d.rounds[f] = it; }
+}
+
+// device-array form (resident tracking, track.hip): frame f owns rows [f * stride, f * stride + cnt[f]), `use` masks the rows
+// that are features of the frame; everything stays in HBM, asynchronous on the context's stream
+int ygz_launch_pose_only(ygz_hip_ctx *ctx, int n_frames, const YgzPoDev &d)
+{
+    PoArgs A;
+    A.d = d;
+    A.fx = (double)ctx->prm.fx; A.fy = (double)ctx->prm.fy; A.cx = (double)ctx->prm.cx; A.cy = (double)ctx->prm.cy;
+    ygz_hip_ceres_default_options(&A.opt);
+    A.opt.fail_behind_camera = 1;
+    YGZ_LAUNCH(ctx, KID_POSE_ONLY, k_pose_only_ba, dim3(n_frames), dim3(PO_THREADS), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
 }
 
 extern "C" int ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const int32_t *frame_off, const double *px,
                                           const double *pw, double *poses_io, uint8_t *bad, double *depth, int32_t *inliers,
                                           int32_t *rounds)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || n_frames < 0 || !frame_off || !poses_io) return YGZ_E_INVALID;
     if (n_frames == 0) return YGZ_OK;
@@ -280,33 +296,34 @@ extern "C" int ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const 
     if (rc != YGZ_OK) return rc;
     uint8_t *base = (uint8_t *)blob;
     PoArgs A;
-    A.off = (const int32_t *)base; base += (b_off + 7) & ~(size_t)7;
+    A.d.cnt = nullptr; A.d.stride = 0; A.d.use = nullptr;
+    A.d.off = (const int32_t *)base; base += (b_off + 7) & ~(size_t)7;
     double *d_px = (double *)base; base += b_px;
     double *d_pw = (double *)base; base += b_pw;
-    A.poses = (double *)base; base += b_pose;
-    A.depth = (double *)base; base += b_depth;
-    A.inliers = (int32_t *)base; A.rounds = A.inliers + n_frames; base += b_cnt;
-    A.bad = base;
-    A.px = d_px; A.pw = d_pw;
+    A.d.poses = (double *)base; base += b_pose;
+    A.d.depth = (double *)base; base += b_depth;
+    A.d.inliers = (int32_t *)base; A.d.rounds = A.d.inliers + n_frames; base += b_cnt;
+    A.d.bad = base;
+    A.d.px = d_px; A.d.pw = d_pw;
     A.fx = (double)ctx->prm.fx; A.fy = (double)ctx->prm.fy; A.cx = (double)ctx->prm.cx; A.cy = (double)ctx->prm.cy;
     ygz_hip_ceres_default_options(&A.opt);
     A.opt.fail_behind_camera = 1;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync((void *)A.off, frame_off, b_off, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync((void *)A.d.off, frame_off, b_off, hipMemcpyHostToDevice, ctx->stream));
     if (n > 0) {
         YGZ_HIPCHK(ctx, hipMemcpyAsync(d_px, px, n * 16, hipMemcpyHostToDevice, ctx->stream));
         YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pw, pw, n * 24, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(A.depth, depth, n * 8, hipMemcpyHostToDevice, ctx->stream));     // outliers keep their value
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(A.d.depth, depth, n * 8, hipMemcpyHostToDevice, ctx->stream));     // outliers keep their value
     }
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(A.poses, poses_io, b_pose, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(A.d.poses, poses_io, b_pose, hipMemcpyHostToDevice, ctx->stream));
     YGZ_LAUNCH(ctx, KID_POSE_ONLY, k_pose_only_ba, dim3(n_frames), dim3(PO_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(poses_io, A.poses, b_pose, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(poses_io, A.d.poses, b_pose, hipMemcpyDeviceToHost, ctx->stream));
     if (n > 0) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(bad, A.bad, n, hipMemcpyDeviceToHost, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(depth, A.depth, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(bad, A.d.bad, n, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(depth, A.d.depth, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (inliers) YGZ_HIPCHK(ctx, hipMemcpyAsync(inliers, A.inliers, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (rounds) YGZ_HIPCHK(ctx, hipMemcpyAsync(rounds, A.rounds, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (inliers) YGZ_HIPCHK(ctx, hipMemcpyAsync(inliers, A.d.inliers, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (rounds) YGZ_HIPCHK(ctx, hipMemcpyAsync(rounds, A.d.rounds, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }

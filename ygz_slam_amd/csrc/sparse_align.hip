@@ -522,6 +522,7 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
                                     const double *px, const double *depth, const uint8_t *has_mappoint, int n,
                                     int max_level, int min_level, int n_iter, int *n_meas_out, int *iters_out)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !T_ref || !T_cur || n < 0 || ref_slot < 0 || ref_slot >= ctx->prm.max_frames || cur_slot < 0 ||
         cur_slot >= ctx->prm.max_frames || min_level < 0 || max_level < min_level || max_level >= ctx->prm.pyramid_levels || n_iter < 0)
         return YGZ_E_INVALID;

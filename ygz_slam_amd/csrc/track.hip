@@ -19,11 +19,14 @@ int ygz_track_ensure(ygz_hip_ctx *ctx)
     // sparse-align work per pair: jac_cache 768 B + patch_cache 64 B + r2 64 B + visible 1 B per feature
     ctx->sa_work_stride = ((Cn * (768 + 64 + 64 + 4 + 4 + 16 + 8 + 2) + 255) / 256) * 256;  // caches | patch | chain terms | ctot | pre | fmap | pmap | visible, used
     A_(ctx->sa_work, F * ctx->sa_work_stride);
+    A_(ctx->fdp_cand, F * Cn); A_(ctx->po_pw, F * Cn * 24); A_(ctx->po_pose, F * 48); A_(ctx->po_depth, F * Cn * 8);
+    A_(ctx->po_bad, F * Cn); A_(ctx->po_cnt, F * 8);
 #undef A_
     if (e != hipSuccess) { ctx->last_hip_error = (int)e; return YGZ_E_HIP; }
     YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->trk_n, 0, F * 4, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->kp_depth, 0, F * Cn * 8, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->kp_has_mp, 0, F * Cn, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->fdp_cand, 1, F * Cn, ctx->stream));
     ctx->trk_alloc = true;
     return YGZ_OK;
 }
@@ -66,7 +69,7 @@ struct LoadArgs {
     const double *kp_px; const int32_t *kp_level; const double *kp_depth; const uint8_t *kp_has_mp;
     const double *pair_T;
     int32_t *trk_n; double *trk_px; int32_t *trk_level; double *trk_depth; uint8_t *trk_has_mp;
-    float *klt_pts; double *fdp_px; double *sa_out;
+    float *klt_pts; double *fdp_px; double *sa_out; uint8_t *fdp_cand;
     float fx, fy, cx, cy; int predict;
 };
 
@@ -98,6 +101,72 @@ __global__ __launch_bounds__(256) void k_track_load(LoadArgs A)
         ox = A.fx * pc[0] / pc[2] + A.cx; oy = A.fy * pc[1] / pc[2] + A.cy;
     }
     A.fdp_px[2 * d] = ox; A.fdp_px[2 * d + 1] = oy;
+    A.fdp_cand[d] = 1;
+}
+
+// VisualOdometry::TrackRefFrame -> TrackLocalMap hand-over for every pair: the pose sparse alignment left in sa_out becomes the
+// pair's current pose (_curr_frame->_TCW = _TCR_estimated * _ref_frame->_TCW, VisualOdometry.cpp:293) and each reference feature's
+// map point is projected with it (LocalMapping::FindCandidates, LocalMapping.cpp:47-79: World2Camera, Camera2Pixel; behind the
+// camera or outside InFrame(px, 20) -> no candidate).  lane = feature.
+struct AdoptArgs {
+    const int32_t *trk_n; int cells, w, h;
+    double *pair_T; const double *sa_out;
+    const double *trk_px, *trk_depth; double *fdp_px; uint8_t *fdp_cand;
+    double fx, fy, cx, cy;
+};
+__global__ __launch_bounds__(256) void k_track_adopt_pose(AdoptArgs A)
+{
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) for (int k = 0; k < 7; ++k) A.pair_T[14 * (size_t)p + 7 + k] = A.sa_out[16 * (size_t)p + k];
+    if (i >= A.trk_n[p]) return;
+    const size_t d = (size_t)p * A.cells + i;
+    const double x = A.trk_px[2 * d], y = A.trk_px[2 * d + 1], dep = A.trk_depth[d];
+    bool cand = false;
+    double ox = x, oy = y;
+    if (dep > 0) {
+        Se3 Tr, Tc, Tri;
+        for (int k = 0; k < 4; ++k) { Tr.q[k] = A.pair_T[14 * (size_t)p + k]; Tc.q[k] = A.sa_out[16 * (size_t)p + k]; }
+        for (int k = 0; k < 3; ++k) { Tr.t[k] = A.pair_T[14 * (size_t)p + 4 + k]; Tc.t[k] = A.sa_out[16 * (size_t)p + 4 + k]; }
+        se3_inv_d(&Tr, &Tri);
+        const double pr[3] = { (x - A.cx) * dep / A.fx, (y - A.cy) * dep / A.fy, dep };          // Pixel2Camera, Camera.h:56-62
+        double pw[3], pc[3];
+        se3_act_d(&Tri, pr, pw);                      // the feature's map point (world)
+        se3_act_d(&Tc, pw, pc);                       // World2Camera(_pos_world, current->_TCW)
+        ox = A.fx * pc[0] / pc[2] + A.cx; oy = A.fy * pc[1] / pc[2] + A.cy;
+        cand = !(pc[2] < 0) && ox >= 20 && ox < A.w - 20 && oy >= 20 && oy < A.h - 20;
+    }
+    A.fdp_px[2 * d] = ox; A.fdp_px[2 * d + 1] = oy;
+    A.fdp_cand[d] = (uint8_t)cand;
+}
+
+// inputs of ba::OptimizeCurrentPoseOnly for every pair: pose = [t; so3.log()] of the pair's current pose (BA.cpp:190-193), the
+// map point of every reference feature, and the mask of the features ProjectMapPoints created (direct-projection successes)
+struct PoPrepArgs {
+    const int32_t *trk_n; int cells;
+    const double *pair_T, *trk_px, *trk_depth; const uint8_t *fdp_ok;
+    double *po_pw, *po_pose, *po_depth;
+    double fx, fy, cx, cy;
+};
+__global__ __launch_bounds__(256) void k_track_po_prep(PoPrepArgs A)
+{
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        double th, w[3];
+        so3_log_d(A.pair_T + 14 * (size_t)p + 7, w, &th);
+        for (int k = 0; k < 3; ++k) { A.po_pose[6 * (size_t)p + k] = A.pair_T[14 * (size_t)p + 11 + k]; A.po_pose[6 * (size_t)p + 3 + k] = w[k]; }
+    }
+    if (i >= A.trk_n[p]) return;
+    const size_t d = (size_t)p * A.cells + i;
+    const double x = A.trk_px[2 * d], y = A.trk_px[2 * d + 1], dep = A.trk_depth[d];
+    Se3 Tr, Tri;
+    for (int k = 0; k < 4; ++k) Tr.q[k] = A.pair_T[14 * (size_t)p + k];
+    for (int k = 0; k < 3; ++k) Tr.t[k] = A.pair_T[14 * (size_t)p + 4 + k];
+    se3_inv_d(&Tr, &Tri);
+    const double pr[3] = { (x - A.cx) * dep / A.fx, (y - A.cy) * dep / A.fy, dep };
+    double pw[3];
+    se3_act_d(&Tri, pr, pw);
+    A.po_pw[3 * d] = pw[0]; A.po_pw[3 * d + 1] = pw[1]; A.po_pw[3 * d + 2] = pw[2];
+    A.po_depth[d] = 0.0;
 }
 
 static int launch_load(ygz_hip_ctx *ctx, int predict)
@@ -107,7 +176,7 @@ static int launch_load(ygz_hip_ctx *ctx, int predict)
     A.kp_px = ctx->kp_px; A.kp_level = ctx->kp_level; A.kp_depth = ctx->kp_depth; A.kp_has_mp = ctx->kp_has_mp;
     A.pair_T = ctx->pair_T;
     A.trk_n = ctx->trk_n; A.trk_px = ctx->trk_px; A.trk_level = ctx->trk_level; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
-    A.klt_pts = ctx->klt_pts; A.fdp_px = ctx->fdp_px; A.sa_out = ctx->sa_out;
+    A.klt_pts = ctx->klt_pts; A.fdp_px = ctx->fdp_px; A.sa_out = ctx->sa_out; A.fdp_cand = ctx->fdp_cand;
     A.fx = ctx->prm.fx; A.fy = ctx->prm.fy; A.cx = ctx->prm.cx; A.cy = ctx->prm.cy; A.predict = predict;
     YGZ_LAUNCH(ctx, KID_TRACK_LOAD, k_track_load, dim3(ygz_div_up(ctx->cells, 256), ctx->n_pairs), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
@@ -118,6 +187,7 @@ extern "C" {
 
 int ygz_hip_set_keypoint_depths(ygz_hip_ctx *ctx, int slot, const double *depth, const uint8_t *has_mappoint, int n)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || slot < 0 || slot >= ctx->prm.max_frames || n < 0 || n > ctx->cells || (n > 0 && (!depth || !has_mappoint))) return YGZ_E_INVALID;
     int rc = ygz_track_ensure(ctx);
@@ -133,6 +203,7 @@ int ygz_hip_set_keypoint_depths(ygz_hip_ctx *ctx, int slot, const double *depth,
 int ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
                         const double *T_ref, int n_pairs, int predict)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !cur_slot || !ref_slot || !T_cur || !T_ref) return YGZ_E_INVALID;
     int rc = ygz_track_set_pairs(ctx, cur_slot, ref_slot, T_cur, T_ref, n_pairs);
     if (rc != YGZ_OK) return rc;
@@ -141,6 +212,7 @@ int ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
 
 int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     return launch_load(ctx, predict);
@@ -148,6 +220,7 @@ int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
 
 int ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !prm) return YGZ_E_INVALID;
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     return ygz_launch_klt(ctx, ctx->n_pairs, prm);
@@ -155,6 +228,7 @@ int ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm)
 
 int ygz_hip_track_direct(ygz_hip_ctx *ctx)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx) return YGZ_E_INVALID;
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     YgzAuxScope aux(ctx, YGZ_AUX_MATCH);                     // independent of LK: shares the matcher's side stream
@@ -163,10 +237,46 @@ int ygz_hip_track_direct(ygz_hip_ctx *ctx)
 
 int ygz_hip_track_sparse_align(ygz_hip_ctx *ctx, int max_level, int min_level, int n_iter)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || min_level < 0 || max_level < min_level || max_level >= ctx->prm.pyramid_levels || n_iter < 0) return YGZ_E_INVALID;
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     YgzAuxScope aux(ctx, 0);
     return ygz_launch_sparse_align(ctx, ctx->n_pairs, max_level, min_level, n_iter);
+}
+
+int ygz_hip_track_adopt_pose(ygz_hip_ctx *ctx)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }           // waits for the sparse alignment (and a running direct projection)
+    if (!ctx) return YGZ_E_INVALID;
+    if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    AdoptArgs A;
+    A.trk_n = ctx->trk_n; A.cells = ctx->cells; A.w = ctx->lw[0]; A.h = ctx->lh[0];
+    A.pair_T = ctx->pair_T; A.sa_out = ctx->sa_out; A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth;
+    A.fdp_px = ctx->fdp_px; A.fdp_cand = ctx->fdp_cand;
+    A.fx = ctx->prm.fx; A.fy = ctx->prm.fy; A.cx = ctx->prm.cx; A.cy = ctx->prm.cy;
+    YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_track_adopt_pose, dim3(ygz_div_up(ctx->cells, 256), ctx->n_pairs), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+int ygz_hip_track_pose_only(ygz_hip_ctx *ctx)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }           // the direct projection runs on a side stream
+    if (!ctx) return YGZ_E_INVALID;
+    if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    PoPrepArgs P;
+    P.trk_n = ctx->trk_n; P.cells = ctx->cells; P.pair_T = ctx->pair_T; P.trk_px = ctx->trk_px; P.trk_depth = ctx->trk_depth;
+    P.fdp_ok = ctx->fdp_ok; P.po_pw = ctx->po_pw; P.po_pose = ctx->po_pose; P.po_depth = ctx->po_depth;
+    P.fx = ctx->prm.fx; P.fy = ctx->prm.fy; P.cx = ctx->prm.cx; P.cy = ctx->prm.cy;
+    YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_track_po_prep, dim3(ygz_div_up(ctx->cells, 256), ctx->n_pairs), dim3(256), P);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YgzPoDev d;
+    d.off = nullptr; d.cnt = ctx->trk_n; d.stride = ctx->cells; d.use = ctx->fdp_ok;
+    d.px = ctx->fdp_px; d.pw = ctx->po_pw; d.poses = ctx->po_pose; d.bad = ctx->po_bad; d.depth = ctx->po_depth;
+    d.inliers = ctx->po_cnt; d.rounds = ctx->po_cnt + ctx->prm.max_frames;
+    return ygz_launch_pose_only(ctx, ctx->n_pairs, d);
 }
 
 static int pair_count(ygz_hip_ctx *ctx, int pair, int *n)
@@ -180,6 +290,7 @@ static int pair_count(ygz_hip_ctx *ctx, int pair, int *n)
 
 int ygz_hip_track_get_klt(ygz_hip_ctx *ctx, int pair, float *pts, uint8_t *status, float *err, int capacity, int *n_out)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !n_out) return YGZ_E_INVALID;
     int n = 0, rc = pair_count(ctx, pair, &n);
     if (rc != YGZ_OK) return rc;
@@ -197,6 +308,7 @@ int ygz_hip_track_get_klt(ygz_hip_ctx *ctx, int pair, float *pts, uint8_t *statu
 
 int ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *level, uint8_t *ok, int capacity, int *n_out)
 {
+    YgzDeviceGuard dg_(ctx);
     if (!ctx || !n_out) return YGZ_E_INVALID;
     int n = 0, rc = pair_count(ctx, pair, &n);
     if (rc != YGZ_OK) return rc;
@@ -212,8 +324,33 @@ int ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *le
     return YGZ_OK;
 }
 
+int ygz_hip_track_get_pose_only(ygz_hip_ctx *ctx, int pair, double pose[6], double T[7], int *inliers, int *rounds, uint8_t *bad,
+                                double *depth, int capacity, int *n_out)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !n_out) return YGZ_E_INVALID;
+    int n = 0, rc = pair_count(ctx, pair, &n);
+    if (rc != YGZ_OK) return rc;
+    *n_out = n;
+    if (n > capacity && (bad || depth)) return YGZ_E_CAPACITY;
+    double h[6]; int32_t c[2];
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(h, ctx->po_pose + 6 * (size_t)pair, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(&c[0], ctx->po_cnt + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(&c[1], ctx->po_cnt + ctx->prm.max_frames + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t o = (size_t)pair * ctx->cells;
+    if (n > 0 && bad) YGZ_HIPCHK(ctx, hipMemcpyAsync(bad, ctx->po_bad + o, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (n > 0 && depth) YGZ_HIPCHK(ctx, hipMemcpyAsync(depth, ctx->po_depth + o, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (pose) for (int k = 0; k < 6; ++k) pose[k] = h[k];
+    if (T) { double th; so3_exp_d(h + 3, T, &th); T[4] = h[0]; T[5] = h[1]; T[6] = h[2]; }      // SE3(SO3::exp(pose.tail<3>()), pose.head<3>()), BA.cpp:254
+    if (inliers) *inliers = c[0];
+    if (rounds) *rounds = c[1];
+    return YGZ_OK;
+}
+
 int ygz_hip_track_get_pose(ygz_hip_ctx *ctx, int pair, double T[7], int *n_meas, int *iters)
 {
+    YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || pair < 0 || pair >= ctx->n_pairs || !ctx->trk_alloc) return YGZ_E_INVALID;
     double h[16];

@@ -49,6 +49,8 @@ struct ygz_hip_ctx {
     unsigned long long *m_key = nullptr;            // [F][cells] (dist<<32 | train) per query
     int32_t *m_idx = nullptr, *m_dist = nullptr, *m_dist2 = nullptr;   // [F][cells] final per query
     int n_pairs = 0;
+    uint8_t *m_good = nullptr; int32_t *m_good_n = nullptr; double *m_min_dis = nullptr;   // M3 post-filter per pair (postfilter.hip)
+    bool pf_valid = false;
 
     // resident tracking state: one "track set" per pair (capacity max_frames pairs), filled either from the
     // keypoints of the pair's reference slot (device-to-device) or from host arrays (single-pair APIs)
@@ -68,6 +70,12 @@ struct ygz_hip_ctx {
     int32_t *fdp_level = nullptr;            // [F][cells]
     uint8_t *fdp_ok = nullptr;               // [F][cells]
     double  *sa_out = nullptr;               // [F][16]: pose 7, n_meas, iters per level
+    uint8_t *fdp_cand = nullptr;             // [F][cells] candidate in view (LocalMapping::FindCandidates); 1 unless ygz_hip_track_adopt_pose cleared it
+    double  *po_pw = nullptr;                // [F][cells][3] map point of each reference feature (world), pose-only stage
+    double  *po_pose = nullptr;              // [F][6] [t; log(so3)] in/out
+    double  *po_depth = nullptr;             // [F][cells]
+    uint8_t *po_bad = nullptr;               // [F][cells] 1: not a feature of the current frame, or outlier
+    int32_t *po_cnt = nullptr;               // [F][2] inliers, rounds
     uint8_t *sa_work = nullptr;              // [F][sa_work_stride]
     size_t   sa_work_stride = 0;
     int      deriv_slots = 0;                // slots covered by the Scharr buffers
@@ -102,10 +110,24 @@ struct ygz_hip_ctx {
 
 static inline int ygz_div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Every entry point that may allocate or launch makes the context's device current for its duration and restores the
+// caller's device afterwards (a process may hold contexts on several GPUs, and torch may have switched device since create).
+struct YgzDeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit YgzDeviceGuard(const ygz_hip_ctx *c)
+    {
+        if (!c) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = (hipSetDevice(c->device) == hipSuccess);
+    }
+    ~YgzDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    YgzDeviceGuard(const YgzDeviceGuard &) = delete;
+    YgzDeviceGuard &operator=(const YgzDeviceGuard &) = delete;
+};
+
 // kernel ids for the probe
 enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIBE, KID_HAMMING_NN, KID_MATCH_FINALIZE,
        KID_TRACK_LOAD, KID_FDP, KID_ALIGN2D, KID_SPARSE_ALIGN, KID_SCHARR, KID_KLT, KID_KLT_PAD, KID_BA_POSE_PREP, KID_BA_POINTS,
-       KID_BA_POSES, KID_BA_CHI2, KID_POSE_ONLY, KID_BA_LM, KID_BOW_TRANSFORM, KID_BOW_MATCH, KID_DEPTH_TRI, KID_LMAP_MATCH, KID_LMAP_AUX, KID_COUNT };
+       KID_BA_POSES, KID_BA_CHI2, KID_POSE_ONLY, KID_BA_LM, KID_BOW_TRANSFORM, KID_BOW_MATCH, KID_DEPTH_TRI, KID_LMAP_MATCH, KID_LMAP_AUX, KID_MATCH_POSTFILTER, KID_TRACK_AUX, KID_DEPTH_FILTER, KID_COUNT };
 
 #define YGZ_LAUNCH(ctx, kid, kern, grid, block, ...)                                                         \
     do { const bool pr_ = (ctx)->probe_id == (kid) && (ctx)->probe_used + 2 <= (int)(ctx)->probe_ev.size();    \
@@ -156,6 +178,14 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
 int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm);
 int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs);
 int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int min_level, int n_iter);
+// ba::OptimizeCurrentPoseOnly on device arrays (pose_only.hip): rows of frame f = [off[f], off[f+1]) or, when cnt != nullptr,
+// [f * stride, f * stride + cnt[f]); use (nullable) masks rows that are not features of the frame
+struct YgzPoDev {
+    const int32_t *off, *cnt; int stride; const uint8_t *use;
+    const double *px, *pw; double *poses; uint8_t *bad; double *depth; int32_t *inliers, *rounds;
+};
+int ygz_launch_pose_only(ygz_hip_ctx *ctx, int n_frames, const YgzPoDev &d);
+int ygz_pf_ensure(ygz_hip_ctx *ctx);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -277,3 +277,27 @@ def synthetic_vocabulary(k=10, L=3, seed=5, stop_frac=0.05):
         first_id += n
     body = np.concatenate(levels)
     return struct.pack("<IIiiii", len(body), 41, k, L, 0, 0) + body.tobytes()          # scoring L1_NORM (0), weighting TF_IDF (0)
+
+
+class Sequence:
+    """Procedural RGB-D sequence for the offline run (BASELINE configs[4]): frame(i) -> BGR uint8 [h, w, 3],
+    depth(i) -> float64 [h, w].  Every frame depends on (seed, i) only, so any rank renders exactly the frames it owns."""
+
+    def __init__(self, n, w=1280, h=720, seed=11, step=0.02, noise_sigma=1.0):
+        self.n, self.w, self.h, self.seed, self.noise = n, w, h, seed, noise_sigma
+        self.tex, self.margin = make_texture(seed, w, h, margin=max(160, w // 4))
+        self.poses = trajectory(n, seed + 10, step)
+        self.poses[0] = [0, 0, 0, 1, 0, 0, 0]
+        self._last = (None, None, None)
+
+    def _render(self, i):
+        if self._last[0] != i:
+            im, d = render(self.tex, self.margin, self.poses[i], self.w, self.h, self.noise, self.seed * 100003 + i)
+            self._last = (i, gray_to_bgr(im, i), d)
+        return self._last
+
+    def frame(self, i):
+        return self._render(i)[1]
+
+    def depth(self, i):
+        return self._render(i)[2]
