@@ -190,6 +190,8 @@ def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path):
     mp.spawn(_run_offline, args=(2, _free_port(), out, N_SEQ), nprocs=2, join=True)
     parts = [pickle.load(open(os.path.join(out, "r%d_of_2.pkl" % r), "rb")) for r in range(2)]
     # every rank ends with the same global trajectory, relative poses, windows and keyframe poses as the unsharded run
+    owners = [[w.pop("owner") for w in r["windows"]] for r in [full] + parts]
+    assert owners == [[0, 0], [0, 1], [0, 1]]                  # the second window belongs to the rank that owns frame 8
     for part in parts:
         for k in ("T_rel", "trajectory", "windows", "keyframe_pose"):
             _same(full[k], part[k], k)
@@ -200,7 +202,7 @@ def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path):
     assert sorted(parts[0]["records"]) == list(range(8)) and sorted(parts[1]["records"]) == list(range(8, 16))
     _same(full["records"], merged, "records")
     # sanity of the run itself
-    assert len(full["windows"]) == 2 and [w["owner"] for w in parts[0]["windows"]] == [0, 1]
+    assert len(full["windows"]) == 2
     for w in full["windows"]:
         chi0, chi1, its, n_edges = w["stats"]
         assert n_edges > 1000 and chi1 < chi0 and its >= 1
