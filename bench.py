@@ -49,6 +49,53 @@ class Pipeline:
         self.B = batch
         self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device, stream=stream)
         self.frames, self.poses, self.depths, self.ba = build_inputs(batch, rank)
+        self.from_bgr = True
+
+    def setup_stream(self, upload):
+        """stream mode: the batch lives in page-locked host memory and crosses PCIe every step; so do the results"""
+        _lib, B, c = self.lib, self.B, self.ctx
+        self.upload = upload
+        if upload == "gray":                                  # the caller converts on the host side of the ABI
+            self.from_bgr = False
+            self.pin = _lib.PinnedArray((B, H, W), np.uint8)
+            for s in range(B):
+                self.pin.array[s] = c.download_level(s, 0)
+        else:
+            self.pin = _lib.PinnedArray((B, H, W, 3), np.uint8)
+            self.pin.array[:] = self.frames
+        cells = c.cells
+        self.kp_pin = {k: _lib.PinnedArray(sh, dt) for k, sh, dt in (("px", (B, cells, 2), np.float64), ("level", (B, cells), np.int32),
+                       ("score", (B, cells), np.float32), ("angle", (B, cells), np.float32), ("desc", (B, cells, 32), np.uint8),
+                       ("count", (B,), np.int32))}
+        self.kp_out = {k: v.array for k, v in self.kp_pin.items()}
+        self.sum_pin = _lib.PinnedArray((B, _lib.SUMMARY_FIELDS), np.float64)
+        self.h2d_bytes = self.pin.nbytes
+        self.d2h_bytes = sum(v.nbytes for v in self.kp_pin.values()) + self.sum_pin.nbytes
+        self.consumed = 0.0
+        self.in_flight = False
+
+    def stream_step(self):
+        c = self.ctx
+        if self.in_flight:                                    # the step issued on this buffer two steps ago: wait, then the host reads its results
+            c.synchronize()
+            self.consume()
+        if self.upload == "gray":
+            c.upload_gray_batch(0, self.pin.array, wait=False)
+        else:
+            c.upload_bgr_batch(0, self.pin.array, wait=False)
+        self.step()
+        c.match_postfilter()
+        c.get_keypoints_batch(0, self.B, out=self.kp_out, wait=False)
+        c.track_get_summary(out=self.sum_pin.array, wait=False)
+        self.in_flight = True
+
+    def consume(self):
+        """host-side use of a finished step: keypoint counts, a checksum of the descriptors that exist, tracked / matched totals"""
+        cnt = self.kp_out["count"]
+        S = self.sum_pin.array
+        self.consumed += float(cnt.sum()) + float(S[:, 16].sum()) + float(S[:, 19].sum()) + float(S[:, 20].sum()) + float(S[:, 7].sum())
+        self.consumed += float(self.kp_out["desc"][0, :int(cnt[0])].sum())
+        self.last_counts = (int(cnt.sum()), int(S[:, 16].sum()), int(S[:, 19].sum()), int(S[:, 20].sum()))
 
     def setup(self):
         c = self.ctx
@@ -76,7 +123,7 @@ class Pipeline:
         # with overlap enabled the ABI forks sparse alignment, BA and the matcher onto side streams: the latency-bound sparse
         # alignment and the HBM / FP64-bound BA build then share the CUs with the VALU-bound extractor, LK and matcher.
         # (Issuing the BA build -- it depends on no image -- before the extractor was measured slower: 3.64 against 3.55 ms.)
-        c.build_pyramid(0, self.B, from_bgr=True)             # A1  InitFrame
+        c.build_pyramid(0, self.B, from_bgr=self.from_bgr)    # A1  InitFrame
         c.detect(0, self.B)                                   # A2-A7 FeatureDetector::Detect
         c.track_reload(True)                                  # track sets from the fresh keypoints
         c.track_sparse_align()                                # L3  SparseImgAlign::run
@@ -136,13 +183,20 @@ def cpu_baseline(pipe, budget_s=12.0):
         o.sparse_align(lvp, pipe.poses[p], lv, pipe.poses[p], kp_["px"], pipe.kp_depth[p], np.ones(len(pipe.kp_depth[p]), np.uint8))
         o.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
 
-    n, t0 = 0, time.perf_counter()
-    while n < pipe.B and (time.perf_counter() - t0) < budget_s:
-        one_frame(n, keep=True)
+    one_frame(0, keep=True)                                  # warm-up (page-in, first-touch), not timed
+    n, t0, per = 0, time.perf_counter(), []
+    while n < pipe.B and ((time.perf_counter() - t0) < budget_s or n < 30):      # BASELINE.md protocol: >= 30 repetitions after warm-up
+        t1 = time.perf_counter()
+        one_frame((n + 1) % pipe.B, keep=True)
+        per.append(time.perf_counter() - t1)
         n += 1
     dt = time.perf_counter() - t0
+    per = np.array(per) * 1e3
     res = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d whole frames of the same batch (oracle/, gcc -O3, single thread)" % n}
+           "sample": "%d whole frames of the same batch (oracle/, gcc -O3 -march=native, single thread), one warm-up frame before" % n,
+           "per_frame_ms": {"median": float(np.median(per)), "p10": float(np.percentile(per, 10)), "p90": float(np.percentile(per, 90)), "reps": n},
+           "what_it_is": "scalar restatement of the reference path (no SSE2 FAST / OpenCV SIMD as the reference's libraries have): "
+                         "a lower bound of what the reference would do on this host, not a tuned CPU implementation"}
     # the whole host -- the same frames handed to one thread per core (the C calls release the GIL)
     try:
         from concurrent.futures import ThreadPoolExecutor
@@ -160,6 +214,154 @@ def cpu_baseline(pipe, budget_s=12.0):
     return res
 
 
+# ---------------------------------------------------------------------------------------------- offline mode (configs[4])
+_SEQ = None
+
+
+def _render_one(i):
+    return i, _SEQ.frame(i).copy(), _SEQ.depth(i).astype(np.float32)
+
+
+def cpu_offline_baseline(bgr, depth, first_frame, budget_s=12.0):
+    """the oracle's composition of the offline per-pair path (what tests/test_gpu_offline.py checks the GPU against) on a
+    bounded sample of this rank's pairs, one core"""
+    from oracle.pyoracle import Oracle
+    try:
+        o = Oracle(variant="o3")
+    except Exception:
+        o = Oracle()
+    I7 = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    prm = o.default_params(W, H, LEVELS)
+    n, t0, prev = 0, time.perf_counter(), None
+    for k in range(len(bgr)):
+        lv = o.pyramid(o.bgr2gray(bgr[k]), LEVELS)
+        kp = o.detect(lv, prm)
+        px = np.stack([kp["px"], kp["py"]], axis=1).astype(np.float64)
+        dep = depth[k][px[:, 1].astype(np.int64), px[:, 0].astype(np.int64)].astype(np.float64)
+        if prev is not None:
+            plv, pkp, ppx, pdep = prev
+            idx, dist_, _ = o.bf_match(kp["desc"], pkp["desc"], 1)
+            o.good_match_filter(idx, dist_)
+            pts = ppx.astype(np.float32)
+            o.klt_track(plv[0], lv[0], pts, pts)
+            _, T, _ = o.sparse_align(plv, I7, lv, I7, ppx, pdep, (pdep > 0).astype(np.uint8))
+            pw, pred, cand = o.track_candidates(I7, T, ppx, pdep, W, H)
+            ci = np.nonzero(cand)[0]
+            ok, pxo, _ = o.find_direct_projection_n(plv, I7, lv, T, ppx[ci], pdep[ci], pkp["level"][ci], pred[ci])
+            th = o.se3_log(T)
+            o.optimize_current_pose_only(np.concatenate([T[4:], th[3:]]), pxo[ok], pw[ci][ok])
+            n += 1
+        prev = (lv, kp, px, dep)
+        if time.perf_counter() - t0 > budget_s and n > 0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d consecutive %dx%d frame pairs of the sequence (oracle/, gcc -O3, single thread; the BA round is not included)" % (n, W, H)}
+
+
+def main_offline(a):
+    """BASELINE configs[4]: one sequence of a.frames frames, sharded over the ranks (strong scaling).  A step = one complete
+    offline run; the timed region holds every upload, kernel, result copy, collective and the BA round."""
+    global _SEQ
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    from ygz_slam_amd import synth, offline, dist as ydist
+    start, count, halo = ydist.shard_frames(a.frames, rank, world)
+    need = list(range(start - halo, start + count))
+    # render this rank's frames on the host cores BEFORE the GPU runtime is touched (fork-based pool)
+    import multiprocessing as mp
+    _SEQ = synth.Sequence(a.frames, W, H, seed=11, step=0.02)
+    workers = max(1, min(len(os.sched_getaffinity(0)) // max(1, min(world, 8)), 32))
+    t_r = time.perf_counter()
+    with mp.get_context("fork").Pool(workers) as pool:
+        rendered = pool.map(_render_one, need, chunksize=max(1, len(need) // (4 * workers)))
+    t_render = time.perf_counter() - t_r
+    import torch
+    dist = None
+    one_dev = os.environ.get("YGZ_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world)
+    from ygz_slam_amd import _lib
+    pin = _lib.PinnedArray((len(need), H, W, 3), np.uint8)
+    dmap = np.empty((len(need), H, W), np.float32)
+    for k, (i, b, d) in enumerate(rendered):
+        assert i == need[k]
+        pin.array[k] = b; dmap[k] = d
+    del rendered
+    base = need[0]
+
+    def block(frames):
+        i0 = frames[0] - base
+        return pin.array[i0:i0 + len(frames)], dmap[i0:i0 + len(frames)]
+
+    chunk = a.batch if a.batch != 512 else 128
+    vo = offline.OfflineVO(W, H, a.frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
+                           exchange_on_device=not one_dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        vo.ctx.synchronize()
+
+    res = None
+    for _ in range(a.warmup):
+        res = vo.run(None, None, block)
+    barrier()
+    vo.ctx.probe_begin(a.probe, 64 * (a.steps + 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = vo.run(None, None, block)
+    barrier()
+    dt = time.perf_counter() - t0
+    probe_ms, probe_n = vo.ctx.probe_end()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        recs = res["records"]
+        n_kp = float(np.mean([r["n_kp"] for r in recs.values()]))
+        pairs = [r for r in recs.values() if "T_rel" in r]
+        gt = np.stack([offline.se3_mul(_SEQ.poses[i], offline.se3_inv(_SEQ.poses[0])) for i in range(a.frames)])
+        traj_err = float(np.abs(res["trajectory"] - gt).max())
+        alg = {"k_klt": count * n_kp * 5 * 2 * 23 * 23 / max(1, -(-count // chunk))}.get(a.probe, 0.0)       # per launch = per chunk
+        avg_s = (probe_ms / max(probe_n, 1)) * 1e-3
+        ach = alg / avg_s / 1e9 if avg_s > 0 else 0.0
+        out = {"metric": "frames/sec (extract+match+LK+local-BA), %dx%d offline VO, %d frames sharded over the GPUs" % (W, H, a.frames),
+               "value": a.frames * a.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "u8/f32/f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[4]: %d synthetic %dx%d frames, contiguous shards with a one-frame halo, per pair ORB extract + "
+                                      "BF cross-check match + good-match filter + KLT 21x21x5 + SparseImgAlign + FindCandidates/FindDirectProjection + "
+                                      "pose-only BA; BA round: windows of 8 keyframes (stride 8) x <= 2000 points, 20 LM iterations resident; "
+                                      "map exchange + trajectory all-gather; H2D of every frame and D2H of the results inside the timed region"
+                                      % (a.frames, W, H),
+                          "frames_total": a.frames, "frames_per_gpu": count, "chunk": chunk, "keypoints_per_frame": n_kp,
+                          "parallelism": "frames sharded x%d" % world},
+               "phases_ms": vo.timing, "render_s_outside_timed_region": t_render,
+               "result_check": {"pairs": len(pairs), "mean_pose_only_inliers": float(np.mean([r["po_inliers"] for r in pairs])),
+                                "max_abs_trajectory_error_vs_ground_truth": traj_err,
+                                "ba_windows": len(res["windows"]),
+                                "ba_chi2_initial_final": [[float(w["stats"][0]), float(w["stats"][1])] for w in res["windows"][:4]]},
+               "roofline": {"bound": "valu", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                            "kernel": {"k_klt": "k_klt3"}.get(a.probe, a.probe), "launches": probe_n, "avg_launch_us": avg_s * 1e6,
+                            "algorithmic_bytes_per_launch": alg,
+                            "note": "HBM fraction of the dominant kernel; it is VALU-issue bound, see roofline_valu in the default mode"}}
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_offline_baseline(pin.array, dmap, base)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    vo.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,12 +375,23 @@ def main():
                     help="two resident batches per GPU, consecutive steps alternate between them so that the latency-bound tail of "
                          "one step overlaps the extraction of the next (+4.5 %% frames/s; off by default because the probed kernel "
                          "then shares the GPU with the other batch and its launch duration no longer measures the kernel alone)")
-    ap.add_argument("--size", default="vga", choices=["vga", "720p"],
+    ap.add_argument("--mode", default="step", choices=["step", "stream", "offline"],
+                    help="step (default): the hot path over a batch resident in HBM = BASELINE.json's metric; stream: the same step with the "
+                         "frames coming from page-locked host memory every step (double-buffered H2D under compute) and the keypoints + per-pair "
+                         "results copied back and read by the host; offline: BASELINE configs[4], a --frames long 1280x720 sequence sharded over "
+                         "the ranks (strong scaling) through ygz_slam_amd/offline.py, uploads, result copies, collectives and the BA round included")
+    ap.add_argument("--frames", type=int, default=1024, help="offline mode: length of the sequence (all ranks together)")
+    ap.add_argument("--upload", default="bgr", choices=["bgr", "gray"], help="stream mode: what crosses PCIe per frame (3 or 1 byte per pixel)")
+    ap.add_argument("--size", default=None, choices=["vga", "720p"],
                     help="vga = BASELINE.json's metric (640x480, the default); 720p = its configs[4] frame size (1280x720, --batch 128 per GPU)")
     a = ap.parse_args()
     global W, H
+    if a.size is None:
+        a.size = "720p" if a.mode == "offline" else "vga"
     if a.size == "720p":
         W, H = 1280, 720
+    if a.mode == "offline":
+        return main_offline(a)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -204,12 +417,14 @@ def main():
     # --double-buffer: two resident batches per GPU, each behind its own ABI context and streams: step k runs on batch k % 2,
     # so the next step's extraction does not wait for the latency-bound tail (sparse alignment, BA) of this one.  Every step is
     # still one full pass of the hot path over one batch of a.batch frames.
-    n_buf = 2 if a.double_buffer else 1
+    n_buf = 2 if (a.double_buffer or a.mode == "stream") else 1
     streams = [torch.cuda.Stream() for _ in range(n_buf)]
     torch.cuda.set_stream(streams[0])
     pipes = [Pipeline(a.batch, local_rank, rank, stream=streams[b].cuda_stream, overlap=not a.no_overlap) for b in range(n_buf)]
     for q in pipes:
         q.setup()
+        if a.mode == "stream":
+            q.setup_stream(a.upload)
     pipe = pipes[0]
     n_pts = pipe.ba["points"].size
     map_buf = torch.from_numpy(np.concatenate([pipe.ba["points"].ravel(), pipe.ba["poses"].ravel()])).cuda()
@@ -229,7 +444,10 @@ def main():
             with torch.cuda.stream(streams[pipes.index(q)]):     # the stream the batch's kernels are ordered on
                 dist.broadcast(map_buf, src=0)                   # RCCL over xGMI, ~50 KB, once per BA round
             q.ctx.ba_set_state_device(0, map_buf.data_ptr() + 8 * n_pts, map_buf.data_ptr())
-        q.step()
+        if a.mode == "stream":
+            q.stream_step()
+        else:
+            q.step()
 
     for _ in range(a.warmup):
         one_step()
@@ -241,6 +459,10 @@ def main():
     for _ in range(a.steps):
         one_step()
     barrier()
+    if a.mode == "stream":                                   # the last steps' results are read inside the timed region too
+        for q in pipes:
+            if q.in_flight:
+                q.consume(); q.in_flight = False
     dt = time.perf_counter() - t0
     probe_ms, probe_n = pipe.ctx.probe_end()
     if dist is not None:
@@ -282,6 +504,13 @@ def main():
                           "frames_per_gpu_per_step": a.batch, "resident_batches_per_gpu": n_buf, "keypoints_per_frame": n_kp,
                           "parallelism": "frames sharded x%d" % world},
                "stage_ms_per_batch": stages, "roofline": roofline}
+        if a.mode == "stream":
+            res["metric"] += ", frames streamed from host memory"
+            res["stream"] = {"upload": a.upload, "h2d_bytes_per_step": pipe.h2d_bytes, "d2h_bytes_per_step": pipe.d2h_bytes,
+                             "h2d_GBps": pipe.h2d_bytes / (dt / a.steps) / 1e9, "d2h_GBps": pipe.d2h_bytes / (dt / a.steps) / 1e9,
+                             "host_read_totals_last_step": list(getattr(pipes[(step_no[0] - 1) % n_buf], "last_counts", ())),
+                             "note": "every step: H2D of the batch from page-locked memory, the 8-call hot path + good-match filter, D2H of all keypoint "
+                                     "fields and the per-pair summary, host reads them; two batches in flight (upload of one under the kernels of the other)"}
         if not a.no_cpu_baseline and world == 1:          # reported on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(pipe)
         print(json.dumps(res))

@@ -229,6 +229,28 @@ int  ygz_hip_track_get_klt(ygz_hip_ctx *ctx, int pair, float *pts, uint8_t *stat
 int  ygz_hip_track_get_direct(ygz_hip_ctx *ctx, int pair, double *px, int32_t *level, uint8_t *ok, int capacity, int *n);
 int  ygz_hip_track_get_pose(ygz_hip_ctx *ctx, int pair, double T[7], int *n_meas, int *iters /*[levels] or NULL*/);
 
+/* ---- bulk traffic for pipelines that stream frames through the context (offline run, bench.py --stream).  wait == 0: the
+ *      copy is only enqueued on the context's stream -- host buffers must then be page-locked (ygz_hip_pinned_alloc) and stay
+ *      valid until the next synchronising call; wait != 0: synchronises.  Layouts are the resident ones: [n_slots][cells][...]. */
+int  ygz_hip_pinned_alloc(void **out, size_t bytes);
+int  ygz_hip_pinned_free(void *p);
+/* Frame::_color of n consecutive slots in one copy: bgr [n_slots][h][w][3], contiguous (src/Basic/Frame.cpp:22-30 input) */
+int  ygz_hip_upload_bgr_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *bgr, int wait);
+/* the same for frames that are already gray (level 0 of the pyramid): gray [n_slots][h][w] */
+int  ygz_hip_upload_gray_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t *gray, int wait);
+/* Feature::_pixel of every keypoint of n slots: px [n_slots][cells][2], count [n_slots] */
+int  ygz_hip_get_keypoint_pixels_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, double *px, int32_t *count, int wait);
+/* all keypoint fields of n slots (members of *out may be NULL): arrays [n_slots][cells][...] */
+int  ygz_hip_get_keypoints_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, ygz_kpt_soa *out, int32_t *count, int wait);
+/* Feature::_depth / _mappoint != nullptr of n slots: depth [n_slots][cells], has_mappoint [n_slots][cells] */
+int  ygz_hip_set_keypoint_depths_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const double *depth, const uint8_t *has_mappoint,
+                                       int wait);
+/* per pair of the resident pair table 32 doubles, reduced on the device: [0..6] pose after sparse alignment, [7] its n_meas / 16,
+ * [8..13] pose after pose-only BA [t; log so3], [14] inliers, [15] rounds, [16] cross-checked matches, [17] good matches (M3),
+ * [18] min_dis, [19] KLT tracks with status 1, [20] direct-projection successes, [21] reference features, [22] query keypoints, [23] 0,
+ * [24..30] the pose-only pose as (qx,qy,qz,qw,tx,ty,tz), [31] 0 */
+int  ygz_hip_track_get_summary(ygz_hip_ctx *ctx, double *out /*[capacity_pairs][32]*/, int capacity_pairs, int *n_pairs, int wait);
+
 /* ---- B1-B5: local-BA edge stack -- replaces the per-iteration work g2o does for
  *      EdgeSophusSE3ProjectXYZ (include/ygz/G2oTypes.h:84-132: computeError, linearizeOplus) plus
  *      BaseBinaryEdge::constructQuadraticForm with RobustKernelHuber, as driven by

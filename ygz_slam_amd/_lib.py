@@ -95,7 +95,11 @@ ABI_SYMBOLS = [
     "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map",
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
+    "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
+    "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary",
 ]
+
+SUMMARY_FIELDS = 32
 
 _lib = None
 
@@ -114,6 +118,34 @@ def load():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (ygz_hip_pinned_alloc) -- asynchronous copies need it"""
+
+    def __init__(self, shape, dtype):
+        lib = load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = C.c_void_p()
+        lib.ygz_hip_pinned_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        rc = lib.ygz_hip_pinned_alloc(C.byref(self._ptr), max(self.nbytes, 64))
+        if rc != OK:
+            raise YgzHipError(rc, "ygz_hip_pinned_alloc")
+        buf = (C.c_uint8 * max(self.nbytes, 64)).from_address(self._ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._ptr:
+            self.array = None
+            load().ygz_hip_pinned_free.argtypes = [C.c_void_p]
+            load().ygz_hip_pinned_free(self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class HipContext:
@@ -183,6 +215,45 @@ class HipContext:
         bgr = np.ascontiguousarray(bgr, np.uint8)
         assert bgr.shape == (self.height, self.width, 3)
         self._chk(self.lib.ygz_hip_upload_bgr(self._ctx, slot, _p(bgr, C.c_uint8), self.width * 3), "upload_bgr")
+
+    # ---- bulk traffic (arrays must be C-contiguous; wait=False needs page-locked memory, see PinnedArray)
+    def upload_bgr_batch(self, slot_begin, bgr, wait=True):
+        assert bgr.dtype == np.uint8 and bgr.flags["C_CONTIGUOUS"] and bgr.shape[1:] == (self.height, self.width, 3)
+        self._chk(self.lib.ygz_hip_upload_bgr_batch(self._ctx, slot_begin, len(bgr), _p(bgr, C.c_uint8), int(wait)), "upload_bgr_batch")
+
+    def upload_gray_batch(self, slot_begin, gray, wait=True):
+        assert gray.dtype == np.uint8 and gray.flags["C_CONTIGUOUS"] and gray.shape[1:] == (self.height, self.width)
+        self._chk(self.lib.ygz_hip_upload_gray_batch(self._ctx, slot_begin, len(gray), _p(gray, C.c_uint8), int(wait)), "upload_gray_batch")
+
+    def get_keypoint_pixels_batch(self, slot_begin, n_slots, px=None, count=None, wait=True):
+        px = np.empty((n_slots, self.cells, 2), np.float64) if px is None else px
+        count = np.empty(n_slots, np.int32) if count is None else count
+        self._chk(self.lib.ygz_hip_get_keypoint_pixels_batch(self._ctx, slot_begin, n_slots, _p(px, C.c_double), _p(count, C.c_int32), int(wait)),
+                  "get_keypoint_pixels_batch")
+        return px, count
+
+    def get_keypoints_batch(self, slot_begin, n_slots, out=None, wait=True):
+        if out is None:
+            out = dict(px=np.empty((n_slots, self.cells, 2), np.float64), level=np.empty((n_slots, self.cells), np.int32),
+                       score=np.empty((n_slots, self.cells), np.float32), angle=np.empty((n_slots, self.cells), np.float32),
+                       desc=np.empty((n_slots, self.cells, 32), np.uint8), count=np.empty(n_slots, np.int32))
+        f = lambda k, t: _p(out[k], t) if out.get(k) is not None else None
+        soa = KptSoa(f("px", C.c_double), f("level", C.c_int32), f("score", C.c_float), f("angle", C.c_float), f("desc", C.c_uint8))
+        self._chk(self.lib.ygz_hip_get_keypoints_batch(self._ctx, slot_begin, n_slots, C.byref(soa), _p(out["count"], C.c_int32), int(wait)),
+                  "get_keypoints_batch")
+        return out
+
+    def set_keypoint_depths_batch(self, slot_begin, depth, has_mp, wait=True):
+        assert depth.dtype == np.float64 and has_mp.dtype == np.uint8 and depth.shape[1] == self.cells and has_mp.shape == depth.shape
+        self._chk(self.lib.ygz_hip_set_keypoint_depths_batch(self._ctx, slot_begin, len(depth), _p(depth, C.c_double), _p(has_mp, C.c_uint8),
+                                                             int(wait)), "set_keypoint_depths_batch")
+
+    def track_get_summary(self, out=None, wait=True):
+        if out is None:
+            out = np.empty((self.max_frames, SUMMARY_FIELDS), np.float64)
+        n = C.c_int(0)
+        self._chk(self.lib.ygz_hip_track_get_summary(self._ctx, _p(out, C.c_double), len(out), C.byref(n), int(wait)), "track_get_summary")
+        return out[:n.value]
 
     def build_pyramid(self, slot_begin=0, n_slots=1, from_bgr=False):
         self._chk(self.lib.ygz_hip_build_pyramid(self._ctx, slot_begin, n_slots, int(from_bgr)), "build_pyramid")

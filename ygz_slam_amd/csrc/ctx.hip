@@ -157,7 +157,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
                      ctx->kp_angle, ctx->kp_desc, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->m_tq, ctx->m_td, ctx->m_key,
                      ctx->m_idx, ctx->m_dist, ctx->m_dist2, ctx->m_good, ctx->m_good_n, ctx->m_min_dis, ctx->trk_n, ctx->trk_px, ctx->trk_level, ctx->trk_depth, ctx->trk_has_mp,
                      ctx->pair_T, ctx->kp_depth, ctx->kp_has_mp, ctx->klt_pts, ctx->klt_err, ctx->klt_status, ctx->fdp_px,
-                     ctx->fdp_level, ctx->fdp_ok, ctx->sa_out, ctx->sa_work, ctx->fdp_cand, ctx->po_pw, ctx->po_pose, ctx->po_depth, ctx->po_bad, ctx->po_cnt };
+                     ctx->fdp_level, ctx->fdp_ok, ctx->sa_out, ctx->sa_work, ctx->fdp_cand, ctx->po_pw, ctx->po_pose, ctx->po_T, ctx->po_depth, ctx->po_bad, ctx->po_cnt };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < YGZ_N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -260,6 +260,12 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
         __syncthreads();
     }
     if (tid < 6) A.d.poses[6 * (size_t)f + tid] = S.tcw[tid];
+    if (tid == 0 && A.d.T_out) {
+        double q[4], th;
+        so3_exp_d(S.tcw + 3, q, &th);
+        for (int k = 0; k < 4; ++k) A.d.T_out[7 * (size_t)f + k] = q[k];
+        for (int k = 0; k < 3; ++k) A.d.T_out[7 * (size_t)f + 4 + k] = S.tcw[k];
+    }
     if (tid == 0) { if (A.d.inliers) A.d.inliers[f] = cntInlier; if (A.d.rounds) A.d.rounds[f] = it; }
 }
 
@@ -296,7 +302,7 @@ extern "C" int ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const 
     if (rc != YGZ_OK) return rc;
     uint8_t *base = (uint8_t *)blob;
     PoArgs A;
-    A.d.cnt = nullptr; A.d.stride = 0; A.d.use = nullptr;
+    A.d.cnt = nullptr; A.d.stride = 0; A.d.use = nullptr; A.d.T_out = nullptr;
     A.d.off = (const int32_t *)base; base += (b_off + 7) & ~(size_t)7;
     double *d_px = (double *)base; base += b_px;
     double *d_pw = (double *)base; base += b_pw;

@@ -19,7 +19,7 @@ int ygz_track_ensure(ygz_hip_ctx *ctx)
     // sparse-align work per pair: jac_cache 768 B + patch_cache 64 B + r2 64 B + visible 1 B per feature
     ctx->sa_work_stride = ((Cn * (768 + 64 + 64 + 4 + 4 + 16 + 8 + 2) + 255) / 256) * 256;  // caches | patch | chain terms | ctot | pre | fmap | pmap | visible, used
     A_(ctx->sa_work, F * ctx->sa_work_stride);
-    A_(ctx->fdp_cand, F * Cn); A_(ctx->po_pw, F * Cn * 24); A_(ctx->po_pose, F * 48); A_(ctx->po_depth, F * Cn * 8);
+    A_(ctx->fdp_cand, F * Cn); A_(ctx->po_pw, F * Cn * 24); A_(ctx->po_pose, F * 48); A_(ctx->po_T, F * 56); A_(ctx->po_depth, F * Cn * 8);
     A_(ctx->po_bad, F * Cn); A_(ctx->po_cnt, F * 8);
 #undef A_
     if (e != hipSuccess) { ctx->last_hip_error = (int)e; return YGZ_E_HIP; }
@@ -27,6 +27,9 @@ int ygz_track_ensure(ygz_hip_ctx *ctx)
     YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->kp_depth, 0, F * Cn * 8, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->kp_has_mp, 0, F * Cn, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->fdp_cand, 1, F * Cn, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->po_pose, 0, F * 48, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->po_T, 0, F * 56, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->po_cnt, 0, F * 8, ctx->stream));
     ctx->trk_alloc = true;
     return YGZ_OK;
 }
@@ -276,6 +279,7 @@ int ygz_hip_track_pose_only(ygz_hip_ctx *ctx)
     d.off = nullptr; d.cnt = ctx->trk_n; d.stride = ctx->cells; d.use = ctx->fdp_ok;
     d.px = ctx->fdp_px; d.pw = ctx->po_pw; d.poses = ctx->po_pose; d.bad = ctx->po_bad; d.depth = ctx->po_depth;
     d.inliers = ctx->po_cnt; d.rounds = ctx->po_cnt + ctx->prm.max_frames;
+    d.T_out = ctx->po_T;
     return ygz_launch_pose_only(ctx, ctx->n_pairs, d);
 }
 
@@ -333,8 +337,9 @@ int ygz_hip_track_get_pose_only(ygz_hip_ctx *ctx, int pair, double pose[6], doub
     if (rc != YGZ_OK) return rc;
     *n_out = n;
     if (n > capacity && (bad || depth)) return YGZ_E_CAPACITY;
-    double h[6]; int32_t c[2];
+    double h[6], hT[7]; int32_t c[2];
     YGZ_HIPCHK(ctx, hipMemcpyAsync(h, ctx->po_pose + 6 * (size_t)pair, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(hT, ctx->po_T + 7 * (size_t)pair, sizeof(hT), hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(&c[0], ctx->po_cnt + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(&c[1], ctx->po_cnt + ctx->prm.max_frames + pair, 4, hipMemcpyDeviceToHost, ctx->stream));
     const size_t o = (size_t)pair * ctx->cells;
@@ -342,7 +347,7 @@ int ygz_hip_track_get_pose_only(ygz_hip_ctx *ctx, int pair, double pose[6], doub
     if (n > 0 && depth) YGZ_HIPCHK(ctx, hipMemcpyAsync(depth, ctx->po_depth + o, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (pose) for (int k = 0; k < 6; ++k) pose[k] = h[k];
-    if (T) { double th; so3_exp_d(h + 3, T, &th); T[4] = h[0]; T[5] = h[1]; T[6] = h[2]; }      // SE3(SO3::exp(pose.tail<3>()), pose.head<3>()), BA.cpp:254
+    if (T) for (int k = 0; k < 7; ++k) T[k] = hT[k];          // SE3(SO3::exp(pose.tail<3>()), pose.head<3>()), BA.cpp:254, formed on the device
     if (inliers) *inliers = c[0];
     if (rounds) *rounds = c[1];
     return YGZ_OK;

@@ -73,6 +73,7 @@ struct ygz_hip_ctx {
     uint8_t *fdp_cand = nullptr;             // [F][cells] candidate in view (LocalMapping::FindCandidates); 1 unless ygz_hip_track_adopt_pose cleared it
     double  *po_pw = nullptr;                // [F][cells][3] map point of each reference feature (world), pose-only stage
     double  *po_pose = nullptr;              // [F][6] [t; log(so3)] in/out
+    double  *po_T = nullptr;                 // [F][7] the same pose as quaternion + translation
     double  *po_depth = nullptr;             // [F][cells]
     uint8_t *po_bad = nullptr;               // [F][cells] 1: not a feature of the current frame, or outlier
     int32_t *po_cnt = nullptr;               // [F][2] inliers, rounds
@@ -183,6 +184,7 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
 struct YgzPoDev {
     const int32_t *off, *cnt; int stride; const uint8_t *use;
     const double *px, *pw; double *poses; uint8_t *bad; double *depth; int32_t *inliers, *rounds;
+    double *T_out;            // nullable: [n_frames][7] SE3(SO3::exp(pose.tail<3>()), pose.head<3>()) of the final pose (BA.cpp:254)
 };
 int ygz_launch_pose_only(ygz_hip_ctx *ctx, int n_frames, const YgzPoDev &d);
 int ygz_pf_ensure(ygz_hip_ctx *ctx);

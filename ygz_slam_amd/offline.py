@@ -171,31 +171,38 @@ class OfflineVO:
         self.ctx.close()
 
     # ------------------------------------------------------------------ phase 1: the hot path over this shard
-    def track_shard(self, frame_source, depth_source):
-        """returns per-frame records of the owned frames (and the keyframe tables of the owned keyframes)"""
+    def track_shard(self, frame_source, depth_source, block_source=None):
+        """The hot path over the frames this rank owns, chunk by chunk; returns per-frame records (+ the keyframe tables of the
+        owned keyframes).  block_source(frames) -> (bgr [n, h, w, 3] uint8 C-contiguous, depth maps [n, h, w]) replaces the
+        per-frame sources when the caller holds the sequence in (page-locked) memory.  Per chunk: one upload, the batched
+        kernels, one download of the keypoint pixels (the depth look-up is the stand-in for the map, see the module text), one
+        upload of the depths, and one download of the per-pair summary."""
         c = self.ctx
         rec = {}                      # frame -> dict
         first, last = self.start, self.start + self.count
+        cells = c.cells
         for c0 in range(first, last, self.chunk):
             c1 = min(c0 + self.chunk, last)
             frames = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))      # one-frame halo: the predecessor of the chunk
             slot_of = {f: k for k, f in enumerate(frames)}
-            depth_maps = {}
-            for f in frames:
-                c.upload_bgr(slot_of[f], frame_source(f))
-                depth_maps[f] = depth_source(f)
             n = len(frames)
+            if block_source is not None:
+                bgr, dmaps = block_source(frames)
+            else:
+                bgr = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
+                dmaps = [depth_source(f) for f in frames]
+            c.upload_bgr_batch(0, bgr)
             c.build_pyramid(0, n, from_bgr=True)
             c.detect(0, n)
-            kps = {}
-            for f in frames:
-                k = c.get_keypoints(slot_of[f])
-                px = k["px"]
-                d = depth_maps[f][px[:, 1].astype(np.int64), px[:, 0].astype(np.int64)].astype(np.float64) if len(px) else np.zeros(0)
-                k["depth"] = d
-                c.set_keypoint_depths(slot_of[f], d, (d > 0).astype(np.uint8))
-                kps[f] = k
+            px, cnt = c.get_keypoint_pixels_batch(0, n)
+            depth = np.zeros((n, cells), np.float64)
+            for k in range(n):
+                m = int(cnt[k])
+                if m:
+                    depth[k, :m] = dmaps[k][px[k, :m, 1].astype(np.int64), px[k, :m, 0].astype(np.int64)]
+            c.set_keypoint_depths_batch(0, depth, (depth > 0).astype(np.uint8))
             pairs = [(f, f - 1) for f in frames if f - 1 in slot_of and f >= c0]
+            S = None
             if pairs:
                 q = [slot_of[a] for a, _ in pairs]
                 t = [slot_of[b] for _, b in pairs]
@@ -208,31 +215,34 @@ class OfflineVO:
                 c.track_adopt_pose()
                 c.track_direct()
                 c.track_pose_only()
+                S = c.track_get_summary().copy()
             for f in range(c0, c1):
-                r = dict(n_kp=len(kps[f]["level"]))
-                if self.keep:
-                    r["kp"] = kps[f]
-                if f % self.kf_stride == 0:
-                    r["kf"] = {k: kps[f][k] for k in ("px", "level", "desc", "depth")}
+                k = slot_of[f]
+                r = dict(n_kp=int(cnt[k]))
+                if self.keep or f % self.kf_stride == 0:
+                    kp = c.get_keypoints(k)
+                    kp["depth"] = depth[k, :int(cnt[k])].copy()
+                    if self.keep:
+                        r["kp"] = kp
+                    if f % self.kf_stride == 0:
+                        r["kf"] = {key: kp[key] for key in ("px", "level", "desc", "depth")}
                 rec[f] = r
             for p, (cur, ref) in enumerate(pairs):
                 r = rec[cur]
-                n_meas, T_sa, iters = c.track_get_pose(p)
-                po = c.track_get_pose_only(p)
-                r["T_sa"], r["sa_n_meas"], r["sa_iters"] = T_sa, n_meas, iters
-                r["T_rel"], r["po_inliers"], r["po_rounds"] = po["T"], po["inliers"], po["rounds"]
-                good, n_good, min_dis = c.get_good_matches(p)
-                r["n_good"], r["min_dis"] = n_good, min_dis
-                if self.keep:
+                r.update(T_sa=S[p, 0:7].copy(), sa_n_meas=int(S[p, 7]), T_rel=S[p, 24:31].copy(), po_inliers=int(S[p, 14]),
+                         po_rounds=int(S[p, 15]), n_match=int(S[p, 16]), n_good=int(S[p, 17]), min_dis=float(S[p, 18]),
+                         n_klt=int(S[p, 19]), n_fdp=int(S[p, 20]))
+                if self.keep:                      # everything a parity test wants to look at
+                    n_meas, T_sa, iters = c.track_get_pose(p)
+                    po = c.track_get_pose_only(p)
+                    good, n_good, min_dis = c.get_good_matches(p)
                     idx, dist_ = c.get_matches(p)
                     pts, st, err = c.track_get_klt(p)
-                    ok, px, lvl = c.track_get_direct(p)
-                    r.update(m_idx=idx, m_dist=dist_, m_good=good, klt_pts=pts, klt_status=st, klt_err=err,
-                             fdp_ok=ok, fdp_px=px, fdp_level=lvl, po_bad=po["bad"], po_pose=po["pose"])
-                else:
-                    _, st, _ = c.track_get_klt(p)
-                    ok, _, _ = c.track_get_direct(p)
-                    r["n_klt"], r["n_fdp"] = int(st.astype(bool).sum()), int(ok.sum())
+                    ok, pxd, lvl = c.track_get_direct(p)
+                    assert np.array_equal(T_sa, r["T_sa"]) and np.array_equal(po["T"], r["T_rel"]) and n_good == r["n_good"]
+                    assert int(st.astype(bool).sum()) == r["n_klt"] and int(ok.sum()) == r["n_fdp"] and int((idx >= 0).sum()) == r["n_match"]
+                    r.update(sa_iters=iters, m_idx=idx, m_dist=dist_, m_good=good, klt_pts=pts, klt_status=st, klt_err=err,
+                             fdp_ok=ok, fdp_px=pxd, fdp_level=lvl, po_bad=po["bad"], po_pose=po["pose"])
         return rec
 
     # ------------------------------------------------------------------ phase 2: trajectory all-gather
@@ -347,12 +357,18 @@ class OfflineVO:
         exchange_rows(buf, owner, self.world, self.pg)
 
     # ------------------------------------------------------------------ whole run
-    def run(self, frame_source, depth_source):
-        rec = self.track_shard(frame_source, depth_source)
+    def run(self, frame_source, depth_source, block_source=None):
+        import time
+        t0 = time.perf_counter()
+        rec = self.track_shard(frame_source, depth_source, block_source)
         self.ctx.synchronize()
+        t1 = time.perf_counter()
         T_rel, traj = self.gather(rec)
         kf_tab = self.gather_keyframes(rec)
+        t2 = time.perf_counter()
         windows, built = self.ba_round(kf_tab, traj)
+        t3 = time.perf_counter()
+        self.timing = {"track_shard": (t1 - t0) * 1e3, "gather": (t2 - t1) * 1e3, "ba_round": (t3 - t2) * 1e3}
         kf_pose = {}
         for w in windows:
             for k, f in enumerate(w["kfs"]):
