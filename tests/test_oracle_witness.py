@@ -1,0 +1,228 @@
+"""Second sources for the oracle's FROZEN SPECS (third-party code that is absent from the reference tree and
+therefore restated from its published behaviour).  Every check here is written with numpy / scipy only -- no line of it shares code
+with oracle/*.c -- and derives the expected value from the textbook definition of the operation:
+
+  cv::cvtColor(BGR2GRAY)       fixed-point luma  (B*1868 + G*9617 + R*4899 + 8192) >> 14                     (OpenCV 3.1 color.cpp)
+  cv::pyrDown                  5x5 binomial [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8, even samples (OpenCV 3.1 pyramids.cpp)
+  uzh-rpg/fast (Rosten FAST)   segment test on the 16-pixel Bresenham ring, 10 contiguous; score = largest threshold that still
+                               passes; 3x3 non-maximum suppression on the score
+  cv::fastAtan2                degrees in [0, 360), documented accuracy ~0.3 deg
+  cv::BFMatcher(crossCheck)    OpenCV 3.1 batchDistance semantics
+  cv::calcOpticalFlowPyrLK     known answer: a pure translation of a smooth image is recovered
+  g2o LM / ceres trust region  the optimum they converge to is the least-squares optimum: scipy.optimize.least_squares
+
+They pin the restatements against a mistake of transcription; they cannot prove bit-equality with the binaries of the libraries
+(those are not in the image), which is why DESIGN.md keeps the words "parity unpinned" for these rows."""
+import numpy as np
+import pytest
+from scipy import ndimage, optimize
+from ygz_slam_amd import synth
+
+
+# ---------------------------------------------------------------------------------------- cvtColor / pyrDown
+def test_witness_bgr2gray(oracle):
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    b, g, r = (bgr[..., i].astype(np.int64) for i in range(3))
+    want = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(oracle.bgr2gray(bgr), want)
+    # the three weights are round(2^14 * (0.114, 0.587, 0.299)) and a gray input maps to itself
+    assert (1868, 9617, 4899) == tuple(int(round(c * 16384)) for c in (0.114, 0.587, 0.299)) and 1868 + 9617 + 4899 == 16384
+    flat = np.repeat(rng.integers(0, 256, (8, 8, 1), dtype=np.uint8), 3, axis=2)
+    assert np.array_equal(oracle.bgr2gray(flat), flat[..., 0])
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (67, 45), (33, 34), (640, 480)])
+def test_witness_pyr_down(oracle, w, h):
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    s = ndimage.correlate1d(img.astype(np.int64), k, axis=1, mode="mirror")       # 'mirror' = d c b | a b c d | c b a = BORDER_REFLECT_101
+    s = ndimage.correlate1d(s, k, axis=0, mode="mirror")
+    want = ((s + 128) >> 8)[::2, ::2].astype(np.uint8)
+    got = oracle.pyr_down(img)
+    assert got.shape == ((h + 1) // 2, (w + 1) // 2) and np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------- FAST-10
+RING = [(0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3), (0, 3), (-1, 3), (-2, 2), (-3, 1), (-3, 0), (-3, -1), (-2, -2), (-1, -3)]
+
+
+def _is_corner(img, x, y, t, n=10):
+    c = int(img[y, x])
+    ring = [int(img[y + dy, x + dx]) for dx, dy in RING]
+    for sign in (1, -1):
+        flags = [(v > c + t) if sign > 0 else (v < c - t) for v in ring]
+        for s in range(16):
+            if all(flags[(s + k) % 16] for k in range(n)):
+                return True
+    return False
+
+
+def _fast_bruteforce(img, thr):
+    h, w = img.shape
+    corners, scores = [], []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if _is_corner(img, x, y, thr):
+                t = thr
+                while t < 255 and _is_corner(img, x, y, t + 1):     # threshold sweep: the largest threshold that still passes
+                    t += 1
+                corners.append((x, y)); scores.append(t)
+    return np.array(corners, np.int16).reshape(-1, 2), np.array(scores, np.int32)
+
+
+@pytest.mark.parametrize("seed,thr", [(1, 15), (2, 15), (3, 40), (4, 5)])
+def test_witness_fast10(oracle, seed, thr):
+    rng = np.random.default_rng(seed)
+    # random blocks + noise: plenty of corners, ties and near-threshold pixels on a 64 x 48 image
+    img = np.kron(rng.integers(0, 256, (12, 16)), np.ones((4, 4))).astype(np.int64) + rng.integers(-12, 13, (48, 64))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    xy, sc = _fast_bruteforce(img, thr)
+    assert len(xy) > 20
+    oxy = oracle.fast_detect(img, thr)
+    assert np.array_equal(oxy, xy)                                   # same corners in the same raster order
+    assert np.array_equal(oracle.fast_score(img, oxy, thr), sc)     # bisection == threshold sweep
+    # 3x3 non-maximum suppression from its definition: a corner survives iff no corner among its 8 neighbours scores strictly higher
+    smap = -np.ones(img.shape, np.int64)
+    smap[xy[:, 1], xy[:, 0]] = sc
+    keep = [i for i, (x, y) in enumerate(xy) if not (smap[y - 1:y + 2, x - 1:x + 2] > sc[i]).any()]
+    assert np.array_equal(oracle.fast_nonmax(oxy, sc, 0), np.array(keep, np.int32))
+
+
+# ---------------------------------------------------------------------------------------- fastAtan2
+def test_witness_fast_atan2(oracle):
+    rng = np.random.default_rng(5)
+    yx = rng.normal(0, 100, (4000, 2))
+    yx = np.concatenate([yx, rng.integers(-50000, 50000, (2000, 2)).astype(np.float64)])      # IC_Angle passes integer moments
+    got = np.array([oracle.fast_atan2(y, x) for y, x in yx])
+    want = np.degrees(np.arctan2(yx[:, 0], yx[:, 1])) % 360.0
+    err = np.abs((got - want + 180.0) % 360.0 - 180.0)
+    assert err.max() < 0.3 and np.all((got >= 0) & (got < 360.0 + 1e-4))
+    for (y, x), a in [((0, 1), 0.0), ((1, 0), 90.0), ((0, -1), 180.0), ((-1, 0), 270.0)]:
+        assert oracle.fast_atan2(y, x) == a                            # exact on the axes
+    for (y, x), a in [((1, 1), 45.0), ((1, -1), 135.0), ((-1, -1), 225.0), ((-1, 1), 315.0)]:
+        assert abs(oracle.fast_atan2(y, x) - a) < 0.02                 # diagonals: the polynomial's end point
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+
+
+# ---------------------------------------------------------------------------------------- BFMatcher(crossCheck)
+def test_witness_bfmatcher_cross_check(oracle):
+    lut = np.array([bin(i).count("1") for i in range(256)])
+    rng = np.random.default_rng(6)
+    for nq, nt in ((300, 280), (5, 40), (40, 5), (1, 1)):
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8); t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+        t[: min(nq, nt) // 2] = q[: min(nq, nt) // 2] ^ (rng.random((min(nq, nt) // 2, 32)) < 0.1).astype(np.uint8)     # true matches + ties
+        D = lut[q[:, None, :] ^ t[None, :, :]].sum(2)
+        # OpenCV 3.1 batchDistance(crosscheck): every train row votes for its nearest query (first minimum); a query keeps the
+        # closest of the train rows that voted for it, the earliest on ties
+        tq = D.argmin(0)
+        idx = -np.ones(nq, np.int64); dist = np.full(nq, np.iinfo(np.int32).max, np.int64)
+        for j in range(nt):
+            i = tq[j]
+            if D[i, j] < dist[i]:
+                dist[i], idx[i] = D[i, j], j
+        oi, od, on = oracle.bf_match(q, t, 1)
+        assert np.array_equal(oi, idx) and np.array_equal(od[idx >= 0], dist[idx >= 0]) and on == int((idx >= 0).sum())
+        # every reported match is a mutual best in the weak sense OpenCV documents: query i is the nearest query of train j
+        for i in np.nonzero(idx >= 0)[0]:
+            assert D[i, idx[i]] == D[:, idx[i]].min()
+
+
+# ---------------------------------------------------------------------------------------- calcOpticalFlowPyrLK
+def test_witness_klt_recovers_translations(oracle):
+    rng = np.random.default_rng(7)
+    base = ndimage.gaussian_filter(rng.normal(0, 1, (300, 400)), 3.0)
+    base = np.clip(128 + 70 * base / np.abs(base).max(), 0, 255)
+    pts = np.stack([rng.uniform(60, 340, 150), rng.uniform(60, 240, 150)], axis=1).astype(np.float32)
+    for dx, dy in ((3, 2), (-5, 4), (0, 0), (7, -6)):
+        prev = base.astype(np.uint8)
+        nxt = np.roll(np.roll(base, dy, axis=0), dx, axis=1).astype(np.uint8)         # nxt(x, y) = prev(x - dx, y - dy)
+        out, st, err = oracle.klt_track(prev, nxt, pts, pts)
+        assert st.all()
+        d = out - pts
+        assert np.abs(d[:, 0] - dx).max() < 0.05 and np.abs(d[:, 1] - dy).max() < 0.05
+        assert err.max() < 1.0                                        # mean absolute patch difference after convergence
+    # sub-pixel: shift by (0.5, 0.25) with bilinear resampling -> recovered to a few hundredths of a pixel on average
+    sh = ndimage.shift(base, (0.25, 0.5), order=1, mode="nearest")
+    out, st, _ = oracle.klt_track(base.astype(np.uint8), np.clip(np.rint(sh), 0, 255).astype(np.uint8), pts, pts)
+    e = np.abs((out - pts) - np.array([0.5, 0.25]))                    # the resampled image is smoothed and re-quantised: a small bias remains
+    assert st.all() and e.max() < 0.15 and e.mean() < 0.05
+
+
+# ---------------------------------------------------------------------------------------- LM / trust-region optimum
+def _reproj_residuals(x, f, free, K):
+    """pixel residuals of the g2o edge (G2oTypes.h:84-91) for the stacked free poses [omega; upsilon] and all points"""
+    poses = f["poses"].copy()
+    poses[free] = x[:6 * len(free)].reshape(-1, 6)
+    pts = x[6 * len(free):].reshape(-1, 3)
+    T = [synth.se3_exp(np.concatenate([p[3:], p[:3]])) for p in poses]
+    r = np.empty((len(f["edge_pose"]), 2))
+    for k in range(K):
+        m = f["edge_pose"] == k
+        uv, _ = synth.project(T[k], pts[f["edge_point"][m]])
+        r[m] = f["obs"][m] - uv
+    return r.ravel()
+
+
+def test_witness_g2o_lm_reaches_the_least_squares_optimum(oracle):
+    """test/test_local_ba.cpp's problem (8 keyframes x 16 points, noisy): the oracle's g2o-LM restatement, run to convergence without
+    the robust kernel, and scipy's trust-region solver started from the same state end in the same minimum"""
+    f = synth.ba_fixture_test_local_ba(noise=True, seed=7)
+    K = len(f["poses"])
+    free = np.nonzero(f["fixed"] == 0)[0]
+    x0 = np.concatenate([f["poses"][free].ravel(), f["points"].ravel()])
+    sol = optimize.least_squares(_reproj_residuals, x0, args=(f, free, K), method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=400)
+    po, pt, st = oracle.g2o_lm(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"], huber_delta=0.0, max_iterations=200)
+    chi2_scipy = float(np.sum(sol.fun ** 2))
+    assert st["chi2_final"] < st["chi2_initial"] * 0.5
+    assert abs(st["chi2_final"] - chi2_scipy) <= 1e-6 * chi2_scipy
+    # the same stationary point, not just the same cost.  Monocular BA with one fixed keyframe (BA.cpp:404-405) leaves the scale of
+    # the map free, so the minimum is a one-parameter family: rotations must agree, translations and points up to ONE common factor
+    ps = f["poses"].copy(); ps[free] = sol.x[:6 * len(free)].reshape(-1, 6)
+    To = np.stack([synth.se3_exp(np.concatenate([po[k, 3:], po[k, :3]])) for k in range(K)])
+    Ts = np.stack([synth.se3_exp(np.concatenate([ps[k, 3:], ps[k, :3]])) for k in range(K)])
+    assert np.allclose(To[:, :4], Ts[:, :4], atol=2e-5)
+    pts_s = sol.x[6 * len(free):].reshape(-1, 3)
+    scale = float(np.sum(pts_s * pt) / np.sum(pt * pt))
+    assert np.allclose(pts_s, scale * pt, atol=2e-4 * max(1.0, scale)) and np.allclose(Ts[:, 4:], scale * To[:, 4:], atol=2e-5 * max(1.0, scale))
+
+
+def _ceres_residuals(x, c, free, K):
+    """CeresReprojectionError (Ceres/CeresReprojectionError.h:33-69): pose = [t; angle-axis], residual = u_n - p / p_z"""
+    poses = c["poses"].copy()
+    poses[free] = x[:6 * len(free)].reshape(-1, 6)
+    pts = x[6 * len(free):].reshape(-1, 3)
+    r = np.empty((len(c["edge_pose"]), 2))
+    for k in range(K):
+        m = c["edge_pose"] == k
+        aa, t = poses[k, 3:], poses[k, :3]
+        th = np.linalg.norm(aa)
+        p = pts[c["edge_point"][m]]
+        if th > 1e-12:
+            w = aa / th
+            pr = p * np.cos(th) + np.cross(w, p) * np.sin(th) + np.outer(p @ w, w) * (1 - np.cos(th))     # Rodrigues
+        else:
+            pr = p + np.cross(aa, p)
+        pc = pr + t
+        r[m] = c["obs_n"][m] - pc[:, :2] / pc[:, 2:3]
+    return r.ravel()
+
+
+def test_witness_ceres_solve_reaches_the_least_squares_optimum(oracle):
+    f = synth.ba_fixture_test_local_ba(noise=True, seed=9)
+    c = synth.ba_to_ceres(f)
+    K = len(c["poses"])
+    free = np.nonzero(c["fixed"] == 0)[0]
+    x0 = np.concatenate([c["poses"][free].ravel(), c["points"].ravel()])
+    sol = optimize.least_squares(_ceres_residuals, x0, args=(c, free, K), method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-14, max_nfev=400)
+    opt = oracle.ceres_options(max_num_iterations=200, function_tolerance=1e-14, parameter_tolerance=1e-14, gradient_tolerance=1e-16)
+    po, pt, sm = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], options=opt)
+    cost_scipy = 0.5 * float(np.sum(sol.fun ** 2))                       # ceres reports 1/2 sum r^2
+    assert sm["final_cost"] < sm["initial_cost"] * 0.5
+    assert abs(sm["final_cost"] - cost_scipy) <= 1e-6 * cost_scipy
+    ps = c["poses"].copy(); ps[free] = sol.x[:6 * len(free)].reshape(-1, 6)
+    pts_s = sol.x[6 * len(free):].reshape(-1, 3)
+    scale = float(np.sum(pts_s * pt) / np.sum(pt * pt))                  # free scale, as above
+    assert np.allclose(po[:, 3:], ps[:, 3:], atol=2e-5)
+    assert np.allclose(ps[:, :3], scale * po[:, :3], atol=2e-5 * max(1.0, scale)) and np.allclose(pts_s, scale * pt, atol=2e-4 * max(1.0, scale))
