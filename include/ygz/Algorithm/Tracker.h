@@ -21,8 +21,9 @@ public:
 private:
     void TrackKLT();
     Frame *_ref = nullptr, *_curr = nullptr;
-    list<Feature *> _tracked_features;
-    vector<cv::Point2f> _px_curr;
+    // the live tracks as parallel arrays (the reference keeps a std::list<Feature*> next to a vector<cv::Point2f>, Tracker.h:68-69):
+    // row i = reference feature, its pixel (what LK starts from in the reference image) and its current position
+    struct Tracks { vector<Feature *> feature; vector<float> ref_px, cur_px; size_t size() const { return feature.size(); } } _tracks;
     TrackerStatusType _status = TrackerStatusType::TRACK_NOT_READY;
 };
 }

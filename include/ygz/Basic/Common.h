@@ -52,6 +52,7 @@ template <int N> struct Vec {
     double squaredNorm() const { return dot(*this); }
     double norm() const { return std::sqrt(squaredNorm()); }
     static Vec Zero() { return Vec(); }
+    const Vec &transpose() const { return *this; }             // only ever streamed (LOG << v.transpose()): prints as a row already
     template <int M> Vec<M> head() const { Vec<M> r; for (int i = 0; i < M; ++i) r.d[i] = d[i]; return r; }
     template <int M> Vec<M> tail() const { Vec<M> r; for (int i = 0; i < M; ++i) r.d[i] = d[N - M + i]; return r; }
     const double *data() const { return d; }
@@ -68,9 +69,21 @@ struct Matrix3d {
     const double &operator()(int r, int c) const { return m[3 * r + c]; }
     Vec<3> operator*(const Vec<3> &v) const
     { return Vec<3>(m[0] * v[0] + m[1] * v[1] + m[2] * v[2], m[3] * v[0] + m[4] * v[1] + m[5] * v[2], m[6] * v[0] + m[7] * v[1] + m[8] * v[2]); }
+    Matrix3d operator*(const Matrix3d &o) const
+    { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double v = 0; for (int k = 0; k < 3; ++k) v += (*this)(i, k) * o(k, j); r(i, j) = v; } return r; }
     Matrix3d transpose() const { Matrix3d r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r(i, j) = (*this)(j, i); return r; }
     static Matrix3d Identity() { Matrix3d r; r(0, 0) = r(1, 1) = r(2, 2) = 1; return r; }
 };
+struct Matrix4d {                     // what SE3::matrix() returns; the callers only print it
+    double m[16];
+    Matrix4d() { for (double &v : m) v = 0; }
+    double &operator()(int r, int c) { return m[4 * r + c]; }
+    const double &operator()(int r, int c) const { return m[4 * r + c]; }
+};
+inline std::ostream &operator<<(std::ostream &os, const Matrix3d &M)
+{ for (int r = 0; r < 3; ++r) os << M(r, 0) << " " << M(r, 1) << " " << M(r, 2) << (r < 2 ? "\n" : ""); return os; }
+inline std::ostream &operator<<(std::ostream &os, const Matrix4d &M)
+{ for (int r = 0; r < 4; ++r) os << M(r, 0) << " " << M(r, 1) << " " << M(r, 2) << " " << M(r, 3) << (r < 3 ? "\n" : ""); return os; }
 struct Matrix2d {
     double m[4];
     Matrix2d() { for (double &v : m) v = 0; }
@@ -85,6 +98,11 @@ using Vector3d = ygz_math::Vec<3>;
 typedef ygz_math::Vec<6> Vector6d;
 using Matrix2d = ygz_math::Matrix2d;
 using Matrix3d = ygz_math::Matrix3d;
+using Matrix4d = ygz_math::Matrix4d;
+namespace Eigen {                     // the spellings src/Module uses with the namespace written out (LocalMapping.cpp:406)
+using Vector2d = ygz_math::Vec<2>; using Vector3d = ygz_math::Vec<3>; using Matrix2d = ygz_math::Matrix2d;
+using Matrix3d = ygz_math::Matrix3d; using Matrix4d = ygz_math::Matrix4d;
+}
 
 // ------------------------------------------------------------------------------------------ Sophus (non-template)
 namespace Sophus {
@@ -97,6 +115,8 @@ public:
     SO3 operator*(const SO3 &o) const;
     Vector3d operator*(const Vector3d &p) const;
     Matrix3d matrix() const;
+    static Matrix3d hat(const Vector3d &v)                      // so3.cpp:204-211
+    { Matrix3d O; O(0, 1) = -v[2]; O(0, 2) = v[1]; O(1, 0) = v[2]; O(1, 2) = -v[0]; O(2, 0) = -v[1]; O(2, 1) = v[0]; return O; }
     const double *quat() const { return q_; }                   // x,y,z,w
     double q_[4];
 };
@@ -111,6 +131,8 @@ public:
     Vector3d operator*(const Vector3d &p) const;                // se3.cpp:92-96
     Vector3d translation() const { return Vector3d(t_[0], t_[1], t_[2]); }
     Matrix3d rotation_matrix() const { return so3_.matrix(); }
+    Matrix4d matrix() const                                     // se3.cpp:98-106: [R t; 0 1]
+    { Matrix4d M; const Matrix3d R = so3_.matrix(); for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) M(r, c) = R(r, c); M(r, 3) = t_[r]; } M(3, 3) = 1; return M; }
     const SO3 &so3() const { return so3_; }
     void to7(double out[7]) const { for (int i = 0; i < 4; ++i) out[i] = so3_.q_[i]; for (int i = 0; i < 3; ++i) out[4 + i] = t_[i]; }
     static SE3 from7(const double in[7]) { SE3 T; for (int i = 0; i < 4; ++i) T.so3_.q_[i] = in[i]; for (int i = 0; i < 3; ++i) T.t_[i] = in[4 + i]; return T; }
@@ -166,6 +188,8 @@ private:
 }  // namespace cv
 using cv::Mat;
 typedef unsigned char uchar;
+typedef unsigned short ushort;
+inline int cvRound(double v) { return (int)lrint(v); }        // OpenCV: round half to even (SSE2 cvtsd2si / lrint)
 
 // ------------------------------------------------------------------------------------------ glog-shaped logging
 namespace ygz_log {

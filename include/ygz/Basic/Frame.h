@@ -28,6 +28,7 @@ struct Frame {
     { return pixel[0] / (1 << level) >= boarder && pixel[0] / (1 << level) < _color.cols - boarder
           && pixel[1] / (1 << level) >= boarder && pixel[1] / (1 << level) < _color.rows - boarder; }
     Vector3d GetCamCenter() const { return _TCW.inverse().translation(); }
+    bool GetMeanAndMinDepth(double &mean_depth, double &min_depth);      // src/Basic/Frame.cpp:42-72
     cv::Mat GetAllDescriptors();                                // src/Basic/Frame.cpp:178-188
     void CleanAllFeatures();                                    // src/Basic/Frame.cpp:203-210
     unsigned long _id = 0, _keyframe_id = 0;

@@ -10,6 +10,7 @@ class Memory {
 public:
     static Frame *RegisterKeyFrame(Frame *frame, bool overwrite = false);   // assigns _keyframe_id
     static MapPoint *RegisterMapPoint(MapPoint *mp);                        // assigns _id
+    static MapPoint *CreateMapPoint();                                      // src/Basic/Memory.cpp:45-52
     static Frame *GetKeyFrame(const unsigned long &keyframe_id);
     static MapPoint *GetMapPoint(const unsigned long &id);
     static void Clean();                                                    // forgets (does not delete)

@@ -196,6 +196,11 @@ void ygz_hip_default_klt_params(ygz_klt_params *p);
 int  ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts,
                        int n, const ygz_klt_params *prm, uint8_t *status, float *err);
 
+/* the same plus Tracker::TrackKLT's survivor rule (Tracker.cpp:100-112) evaluated on the device: keep[i] = status[i] != 0 and
+ * InFrame(next_pts[i], border) (20 in the reference); n_keep = number of survivors */
+int  ygz_hip_klt_track_filtered(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
+                                const ygz_klt_params *prm, int border, uint8_t *status, float *err, uint8_t *keep, int *n_keep);
+
 /* ---- resident batched tracking: the same L1-L4 kernels over MANY frame pairs per launch, inputs taken from
  *      the keypoints the extractor left in HBM, no host round trip between stages.  This is the per-frame path
  *      of VisualOdometry::AddFrame (src/Module/VisualOdometry.cpp:38-107: Tracker::Track -> TrackRefFrame ->

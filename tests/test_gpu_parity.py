@@ -4,6 +4,7 @@ Integer / byte / index stages: bit-exact.  Float stages: the tolerance is writte
 (north_star: LK tracks and BA residuals within 1e-5 relative)."""
 import numpy as np
 import pytest
+import fixtures
 from conftest import golden, make_ctx
 from ygz_slam_amd import synth
 
@@ -139,8 +140,8 @@ def test_describe_arbitrary_pixels(hip_lib, oracle):
 # ------------------------------------------------------------------------------------- M1-M3
 @pytest.mark.parametrize("nq,nt", [(1000, 1000), (70, 53), (1, 1), (257, 3), (3, 700), (3072, 3072)])
 def test_hamming_bit_exact_indices(hip_lib, oracle, nq, nt):
-    q = synth.random_descriptors(nq, 42 + nq)
-    t = synth.random_descriptors(nt, 43 + nt)
+    q = fixtures.random_descriptors(nq, 42 + nq)
+    t = fixtures.random_descriptors(nt, 43 + nt)
     if nq > 30 and nt > 12:
         t[10] = q[3]; t[11] = q[3]; q[20] = q[21]
     ctx = make_ctx(hip_lib, max_frames=1)
@@ -169,7 +170,7 @@ def test_hamming_edge_cases_and_golden(hip_lib, oracle):
     idx, d = ctx.hamming_match(e, g["t"], 1)
     assert len(idx) == 0
     with pytest.raises(hip_lib.YgzHipError):             # capacity: more rows than grid cells
-        ctx.hamming_match(synth.random_descriptors(4000, 1), g["t"], 0)
+        ctx.hamming_match(fixtures.random_descriptors(4000, 1), g["t"], 0)
     z = np.zeros((5, 32), np.uint8); f = np.full((4, 32), 255, np.uint8)
     idx, d = ctx.hamming_match(z, f, 0)
     assert np.all(d == 256) and np.all(idx == 0)         # maximum distance, first index on ties
@@ -180,8 +181,8 @@ def test_hamming_more_than_65535_rows(hip_lib, oracle):
     """sets larger than 65535 rows (a 4K frame has 82944 grid cells): the kernel that packs (distance, row) into one 32-bit key
     must not be used; cross-check and second-best paths stay exact"""
     ctx = make_ctx(hip_lib, width=3840, height=2160, levels=3, max_frames=1)
-    q = synth.random_descriptors(70000, 5)
-    t = synth.random_descriptors(700, 6)
+    q = fixtures.random_descriptors(70000, 5)
+    t = fixtures.random_descriptors(700, 6)
     t[650] = q[69990]; q[66000] = q[65999]                  # an exact match and a duplicate beyond row 65535
     for cc in (0, 1, 2):
         idx, d = ctx.hamming_match(t, q, cc)                # the 70000-row set is scanned: indices up to 69999
@@ -585,7 +586,7 @@ def _rel(a, b):
 def test_ba_ceres_formulation_blocks(hip_lib, oracle):
     """formulation 2 = the auto-differentiated ceres functors (Ceres/CeresReprojectionError*.h), closed form on the GPU vs
     Jets in the oracle, with constant poses / points, disabled edges and per-edge Huber widths.  Bar 1e-5 relative; met 1e-9."""
-    c = synth.ba_to_ceres(synth.ba_window(8, 600, seed=4))
+    c = fixtures.ba_to_ceres(synth.ba_window(8, 600, seed=4))
     c["poses"][0] = 0.0                                            # keyframe 0 at the identity: the first-order rotation branch
     E, P = len(c["obs_n"]), len(c["points"])
     rng = np.random.default_rng(0)
@@ -616,7 +617,7 @@ def test_ba_ceres_formulation_blocks(hip_lib, oracle):
 def test_ba_solve_ceres_local_ba(hip_lib, oracle):
     """ba::LocalBA (BA.cpp:324-384): trust-region LM around the GPU linearisation vs the oracle's restatement: same
     accept/reject sequence, same termination, final cost and state within 1e-6 relative (bar 1e-5)."""
-    for fx in (synth.ba_to_ceres(synth.ba_window(6, 300, seed=5)), synth.ba_to_ceres(synth.ba_fixture_test_local_ba(noise=True))):
+    for fx in (fixtures.ba_to_ceres(synth.ba_window(6, 300, seed=5)), fixtures.ba_to_ceres(fixtures.ba_fixture_test_local_ba(noise=True))):
         po, pt, so = oracle.ceres_solve(fx["poses"], fx["fixed"], fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
         ctx = make_ctx(hip_lib, max_frames=1)
         pg, tg, sg = ctx.ba_solve_ceres(fx["poses"], fx["fixed"], fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
@@ -632,7 +633,7 @@ def test_ba_solve_ceres_local_ba(hip_lib, oracle):
 def test_ba_solve_ceres_variants(hip_lib, oracle):
     """OptimizeCurrentPointOnly (every pose constant), OptimizeCurrent-like (Huber 0.1 on every edge, one free pose) and a
     pose-only problem with the behind-camera failure rule -- the other ceres call sites of BA.cpp on the same entry point."""
-    fx = synth.ba_to_ceres(synth.ba_window(5, 200, seed=9))
+    fx = fixtures.ba_to_ceres(synth.ba_window(5, 200, seed=9))
     ctx = make_ctx(hip_lib, max_frames=1)
     allfix = np.ones(len(fx["poses"]), np.uint8)
     po, pt, so = oracle.ceres_solve(fx["poses"], allfix, fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
@@ -646,7 +647,7 @@ def test_ba_solve_ceres_variants(hip_lib, oracle):
     assert sg["termination"] == so["termination"] and sg["iterations"] == so["iterations"]
     assert _rel(pg, po) < 1e-6 and _rel(tg, pt) < 1e-6
     # pose only, a point behind the camera at the start: ceres gives up at iteration zero, state untouched
-    f = synth.pose_only_fixture(n=60, seed=8, outlier_frac=0.0)
+    f = fixtures.pose_only_fixture(n=60, seed=8, outlier_frac=0.0)
     n = len(f["px"])
     obs_n = np.stack([(f["px"][:, 0] - synth.CX) / synth.FX, (f["px"][:, 1] - synth.CY) / synth.FY], axis=1)
     pw = f["pw"].copy(); pw[7, 2] = -3.0
@@ -660,9 +661,9 @@ def test_ba_solve_ceres_variants(hip_lib, oracle):
 def test_optimize_pose_only_batch(hip_lib, oracle):
     """ba::OptimizeCurrentPoseOnly for a batch of frames in one launch (one workgroup per frame, four rounds on the device)
     vs the oracle frame by frame: flags, inlier counts and rounds equal; pose within 1e-7 relative (bar 1e-5), depth 1e-9."""
-    frames = [synth.pose_only_fixture(n=400, seed=3), synth.pose_only_fixture(n=1000, seed=5, outlier_frac=0.3),
-              synth.pose_only_fixture(n=37, seed=6, outlier_frac=0.0), synth.pose_only_fixture(n=12, seed=4, outlier_frac=0.0),
-              dict(entry=np.zeros(6), px=np.zeros((0, 2)), pw=np.zeros((0, 3))), synth.pose_only_fixture(n=257, seed=7)]
+    frames = [fixtures.pose_only_fixture(n=400, seed=3), fixtures.pose_only_fixture(n=1000, seed=5, outlier_frac=0.3),
+              fixtures.pose_only_fixture(n=37, seed=6, outlier_frac=0.0), fixtures.pose_only_fixture(n=12, seed=4, outlier_frac=0.0),
+              dict(entry=np.zeros(6), px=np.zeros((0, 2)), pw=np.zeros((0, 3))), fixtures.pose_only_fixture(n=257, seed=7)]
     frames[3]["entry"] = frames[3]["entry"] + np.array([0.5, 0.5, 0, 0, 0, 0])        # < 10 inliers in round 1: no commit
     frames[5]["pw"][11, 2] = -2.0        # behind the camera: the first solve fails, the re-classification disables the point
     off = np.concatenate([[0], np.cumsum([len(f["px"]) for f in frames])]).astype(np.int32)
@@ -733,7 +734,7 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
     """ba::LocalBAG2O's Levenberg-Marquardt loop (g2o LM + Schur + Cholesky) as ONE kernel, several windows per launch, vs the
     oracle's restatement (yo_g2o_lm) and the host-loop form: same iteration / trial counts, chi2 and state within 1e-6 relative
     (bar 1e-5; the block reductions sum in a different order than the scalar loops)."""
-    wins = [synth.ba_fixture_test_local_ba(noise=True, seed=5), synth.ba_window(6, 300, seed=5), synth.ba_window(10, 2000, seed=7),
+    wins = [fixtures.ba_fixture_test_local_ba(noise=True, seed=5), synth.ba_window(6, 300, seed=5), synth.ba_window(10, 2000, seed=7),
             synth.ba_window(4, 50, seed=9), synth.ba_window(8, 700, seed=3, sort_by_point=False)]
     ctx = make_ctx(hip_lib, max_frames=1)
     for i, w in enumerate(wins):
@@ -768,7 +769,7 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
 def test_bow_transform_and_guided_matching(hip_lib, oracle):
     """Frame::ComputeBoW (DBoW3 tree descent), Matcher::SearchByBoW and Matcher::SearchForTriangulation on extracted frames
     (slot form, all pairs in one launch) and on host arrays, against the oracle: every index bit-exact."""
-    blob = synth.synthetic_vocabulary(k=10, L=4, seed=5)
+    blob = fixtures.synthetic_vocabulary(k=10, L=4, seed=5)
     vo = oracle.vocab_parse(blob)
     imgs, poses, depths = _frames(3, 640, 480, seed=23, step=0.3)
     ctx = make_ctx(hip_lib, max_frames=3)

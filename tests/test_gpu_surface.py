@@ -5,6 +5,7 @@ import os
 import subprocess
 import numpy as np
 import pytest
+import fixtures
 from conftest import ROOT
 from ygz_slam_amd import synth
 
@@ -56,13 +57,13 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     deps[0].astype(np.float64).tofile(os.path.join(d, "depth0.f64"))
     open(os.path.join(d, "default.yaml"), "w").write("%YAML:1.0\nimage.width: 640\nimage.height: 480\nframe.pyramid: 3\nfeature.cell: 10\n"
                                                      "feature.detection_threshold: 15.0\ncamera.fx: 520.9\ncamera.fy: 521.0\ncamera.cx: 325.1\ncamera.cy: 249.7\n")
-    f = synth.ba_fixture_test_local_ba(noise=True, seed=5)
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=5)
     T7 = np.array([oracle.se3_exp(np.concatenate([p[3:], p[:3]])) for p in f["poses"]])
     T7.tofile(os.path.join(d, "ba_poses7.f64")); f["points"].tofile(os.path.join(d, "ba_points.f64"))
     f["obs"].reshape(16, 8, 2).tofile(os.path.join(d, "ba_obs.f64"))
-    vblob = synth.synthetic_vocabulary(k=6, L=6, seed=5)                  # 55 986 nodes, 46 656 words
+    vblob = fixtures.synthetic_vocabulary(k=6, L=6, seed=5)                  # 55 986 nodes, 46 656 words
     open(os.path.join(d, "vocab.bin"), "wb").write(vblob)
-    pof = synth.pose_only_fixture(n=300, seed=12)
+    pof = fixtures.pose_only_fixture(n=300, seed=12)
     pof["entry"].tofile(os.path.join(d, "po_entry.f64")); pof["px"].tofile(os.path.join(d, "po_px.f64")); pof["pw"].tofile(os.path.join(d, "po_pw.f64"))
     outp = os.path.join(d, "out.txt")
     subprocess.check_call([BIN, d, outp], timeout=300)
@@ -203,7 +204,7 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
 def test_ba_optimize_converges_to_ground_truth(hip_lib, oracle):
     """LocalBA on the transcribed test_local_ba fixture with small noise recovers the true structure (up to the
     monocular scale gauge, removed by comparing reprojection errors)"""
-    f = synth.ba_fixture_test_local_ba(noise=True, seed=9)
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=9)
     ctx = hip_lib.HipContext(max_frames=1)
     po, pt, st = ctx.ba_optimize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])
     r0 = oracle.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])

@@ -4,6 +4,7 @@ format (the reference does not ship vocab/ORBvoc.bin)."""
 import struct
 import numpy as np
 from ygz_slam_amd import synth
+import fixtures
 
 LUT = np.array([bin(i).count("1") for i in range(256)])
 
@@ -38,11 +39,11 @@ def _descend(nodes, L, d, levelsup):
 
 
 def test_vocab_parse_and_transform(oracle):
-    blob = synth.synthetic_vocabulary(k=7, L=4, seed=2)
+    blob = fixtures.synthetic_vocabulary(k=7, L=4, seed=2)
     k, L, nodes = _parse(blob)
     v = oracle.vocab_parse(blob)
     assert (v.k, v.L, v.n_nodes) == (7, 4, len(nodes)) and v.n_words == 7 ** 4
-    desc = synth.random_descriptors(300, 8)
+    desc = fixtures.random_descriptors(300, 8)
     for levelsup in (0, 1, 2, 4, 6):
         word, weight, node, bw, bv = oracle.bow_transform(v, desc, levelsup)
         acc = {}
@@ -64,14 +65,14 @@ def test_vocab_parse_and_transform(oracle):
 
 
 def test_search_by_bow_and_triangulation(oracle):
-    blob = synth.synthetic_vocabulary(k=10, L=3, seed=5)
+    blob = fixtures.synthetic_vocabulary(k=10, L=3, seed=5)
     v = oracle.vocab_parse(blob)
     rng = np.random.default_rng(3)
-    d1 = synth.random_descriptors(400, 11)
+    d1 = fixtures.random_descriptors(400, 11)
     d2 = d1[rng.permutation(400)].copy()
     flip = rng.random((400, 256)) < 0.04
     d2 ^= np.packbits(flip, axis=1)
-    d2 = np.concatenate([d2, synth.random_descriptors(100, 12)])
+    d2 = np.concatenate([d2, fixtures.random_descriptors(100, 12)])
     n1 = oracle.bow_transform(v, d1, 1)[2]; n2 = oracle.bow_transform(v, d2, 1)[2]
     m, cnt = oracle.search_by_bow(d1, n1, d2, n2, th_low=65, knn_ratio=0.7)
     D = LUT[d1[:, None, :] ^ d2[None, :, :]].sum(-1)

@@ -6,6 +6,7 @@ the zero-noise known-answer fixture of test/test_local_ba.cpp:9-37 -- plus the c
 ba::OptimizeCurrentPoseOnly as written (BA.cpp:188-264)."""
 import numpy as np
 import pytest
+import fixtures
 
 from ygz_slam_amd import synth
 
@@ -53,7 +54,7 @@ def test_ceres_residual_equals_legacy_normalised_plane_residual(oracle):
 
 
 def test_ceres_linearize_blocks_flags_and_loss(oracle):
-    fx = synth.ba_to_ceres(synth.ba_fixture_test_local_ba(noise=True))
+    fx = fixtures.ba_to_ceres(fixtures.ba_fixture_test_local_ba(noise=True))
     E, K, P = len(fx["obs_n"]), len(fx["poses"]), len(fx["points"])
     rng = np.random.default_rng(0)
     huber = np.where(rng.random(E) < 0.5, 0.002, 0.0)
@@ -95,7 +96,7 @@ def test_ceres_linearize_blocks_flags_and_loss(oracle):
 def test_schur_solve_against_dense(oracle):
     import ctypes as C
     from oracle.pyoracle import _f64, _u8, _p
-    fx = synth.ba_to_ceres(synth.ba_fixture_test_local_ba(noise=True))
+    fx = fixtures.ba_to_ceres(fixtures.ba_fixture_test_local_ba(noise=True))
     r = oracle.ceres_linearize(fx["poses"], fx["fixed"], fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs_n"])
     K, P, E = len(fx["poses"]), len(fx["points"]), len(fx["obs_n"])
     rng = np.random.default_rng(1)
@@ -126,10 +127,10 @@ def test_schur_solve_against_dense(oracle):
 
 def test_ceres_solve_local_ba_zero_noise_converges(oracle):
     """ba::LocalBA (BA.cpp:324-384) on the reference's own fixture: exact observations, perturbed estimate -> cost 0."""
-    fx = synth.ba_fixture_test_local_ba(noise=True)
-    exact = synth.ba_fixture_test_local_ba(noise=False)
+    fx = fixtures.ba_fixture_test_local_ba(noise=True)
+    exact = fixtures.ba_fixture_test_local_ba(noise=False)
     fx["obs"] = exact["obs"]
-    c = synth.ba_to_ceres(fx)
+    c = fixtures.ba_to_ceres(fx)
     poses, points, s = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"])
     assert s["rc"] == 0 and s["initial_cost"] > 1e-3
     assert s["final_cost"] < 1e-12 * s["initial_cost"] + 1e-16
@@ -141,7 +142,7 @@ def test_ceres_solve_local_ba_zero_noise_converges(oracle):
 
 
 def test_ceres_solve_noisy_window_decreases_and_terminates(oracle):
-    c = synth.ba_to_ceres(synth.ba_window(K=6, P=300, seed=5))
+    c = fixtures.ba_to_ceres(synth.ba_window(K=6, P=300, seed=5))
     poses, points, s = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"])
     assert s["rc"] == 0 and s["final_cost"] < 0.05 * s["initial_cost"]
     assert s["termination"] in (0, 1, 2)                                  # a convergence criterion, not the iteration cap
@@ -152,8 +153,8 @@ def test_ceres_solve_noisy_window_decreases_and_terminates(oracle):
 
 
 def test_g2o_lm_restatement(oracle):
-    fx = synth.ba_fixture_test_local_ba(noise=True)
-    fx["obs"] = synth.ba_fixture_test_local_ba(noise=False)["obs"]
+    fx = fixtures.ba_fixture_test_local_ba(noise=True)
+    fx["obs"] = fixtures.ba_fixture_test_local_ba(noise=False)["obs"]
     poses, points, st = oracle.g2o_lm(fx["poses"], fx["fixed"], fx["points"], fx["edge_pose"], fx["edge_point"], fx["obs"],
                                       max_iterations=20)
     assert st["chi2_initial"] > 1.0 and st["chi2_final"] < 1e-8 * st["chi2_initial"]
@@ -166,7 +167,7 @@ def test_g2o_lm_restatement(oracle):
 
 
 def test_optimize_current_pose_only(oracle):
-    f = synth.pose_only_fixture(n=400, seed=3)
+    f = fixtures.pose_only_fixture(n=400, seed=3)
     pose, bad, depth, inl, rounds = oracle.optimize_current_pose_only(f["entry"], f["px"], f["pw"])
     assert rounds == 4 and inl == int((bad == 0).sum())
     assert np.abs(pose[:3] - f["true"][:3]).max() < 5e-3 and np.abs(pose[3:] - f["true"][3:]).max() < 2e-3
@@ -188,7 +189,7 @@ def test_optimize_current_pose_only(oracle):
         tcw = sol[0].copy()
     assert np.array_equal(pose, tcw) and np.array_equal(bad, 1 - enable)
     # fewer than 10 inliers in round 1 -> break before the pose is committed: _TCW unchanged
-    g = synth.pose_only_fixture(n=12, seed=4, outlier_frac=0.0)
+    g = fixtures.pose_only_fixture(n=12, seed=4, outlier_frac=0.0)
     far = g["entry"] + np.array([0.5, 0.5, 0, 0, 0, 0])
     pose2, bad2, _, inl2, rounds2 = oracle.optimize_current_pose_only(far, g["px"], g["pw"])
     assert rounds2 == 1 and inl2 < 10 and np.array_equal(pose2, far)

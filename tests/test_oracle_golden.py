@@ -7,6 +7,7 @@ import os
 import zlib
 import numpy as np
 import pytest
+import fixtures
 from conftest import golden, ROOT
 from ygz_slam_amd import synth
 
@@ -192,9 +193,9 @@ def test_local_ba_known_answer(oracle):
     # the projection itself against an independent numpy pinhole model
     for e in range(0, 128, 17):
         j, i = g["edge_pose"][e], g["edge_point"][e]
-        om, t = synth.TEST_LOCAL_BA_POSES[j]
+        om, t = fixtures.TEST_LOCAL_BA_POSES[j]
         T = np.concatenate([synth.se3_exp([0, 0, 0, *om])[:4], t])
-        uv, _ = synth.project(T, np.array([synth.TEST_LOCAL_BA_POINTS[i]], float))
+        uv, _ = synth.project(T, np.array([fixtures.TEST_LOCAL_BA_POINTS[i]], float))
         assert np.allclose(uv[0], g["obs"][e], atol=1e-9)
 
 

@@ -15,6 +15,7 @@ They pin the restatements against a mistake of transcription; they cannot prove 
 (those are not in the image), which is why DESIGN.md keeps the words "parity unpinned" for these rows."""
 import numpy as np
 import pytest
+import fixtures
 from scipy import ndimage, optimize
 from ygz_slam_amd import synth
 
@@ -168,7 +169,7 @@ def _reproj_residuals(x, f, free, K):
 def test_witness_g2o_lm_reaches_the_least_squares_optimum(oracle):
     """test/test_local_ba.cpp's problem (8 keyframes x 16 points, noisy): the oracle's g2o-LM restatement, run to convergence without
     the robust kernel, and scipy's trust-region solver started from the same state end in the same minimum"""
-    f = synth.ba_fixture_test_local_ba(noise=True, seed=7)
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=7)
     K = len(f["poses"])
     free = np.nonzero(f["fixed"] == 0)[0]
     x0 = np.concatenate([f["poses"][free].ravel(), f["points"].ravel()])
@@ -210,8 +211,8 @@ def _ceres_residuals(x, c, free, K):
 
 
 def test_witness_ceres_solve_reaches_the_least_squares_optimum(oracle):
-    f = synth.ba_fixture_test_local_ba(noise=True, seed=9)
-    c = synth.ba_to_ceres(f)
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=9)
+    c = fixtures.ba_to_ceres(f)
     K = len(c["poses"])
     free = np.nonzero(c["fixed"] == 0)[0]
     x0 = np.concatenate([c["poses"][free].ravel(), c["points"].ravel()])

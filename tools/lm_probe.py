@@ -1,9 +1,11 @@
 import sys, numpy as np, time
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ygz_slam_amd import synth, _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import fixtures
 from oracle import pyoracle
 oracle = pyoracle.Oracle()
-wins = [synth.ba_fixture_test_local_ba(noise=True, seed=5), synth.ba_window(6, 300, seed=5), synth.ba_window(10, 2000, seed=7),
+wins = [fixtures.ba_fixture_test_local_ba(noise=True, seed=5), synth.ba_window(6, 300, seed=5), synth.ba_window(10, 2000, seed=7),
         synth.ba_window(4, 50, seed=9), synth.ba_window(8, 700, seed=3, sort_by_point=False)]
 ctx = _lib.HipContext(max_frames=1)
 for i, w in enumerate(wins):

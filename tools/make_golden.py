@@ -12,6 +12,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.pyoracle import Oracle
 from ygz_slam_amd import synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import fixtures
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -54,7 +56,7 @@ k0occ = o.detect(lv0, prm, occ)
 np.savez_compressed(os.path.join(OUT, "extract.npz"), imgs=imgs, poses=poses, k0=k0, k1=k1, occ=occ, k0occ=k0occ, **fx)
 
 # 3 Hamming
-q = synth.random_descriptors(70, 5); t = synth.random_descriptors(53, 6)
+q = fixtures.random_descriptors(70, 5); t = fixtures.random_descriptors(53, 6)
 t[10] = q[3]; t[11] = q[3]; q[20] = q[21]         # exact ties
 hm = dict(q=q, t=t)
 for cc in (0, 1, 2):
@@ -95,7 +97,7 @@ np.savez_compressed(os.path.join(OUT, "align.npz"), px_ref=px_ref, depth=depth, 
 
 # 5 BA: transcription of test/test_local_ba.cpp (zero-noise = known answer) + noisy + outliers
 for name, noise in (("ba_exact", False), ("ba_noisy", True)):
-    f = synth.ba_fixture_test_local_ba(noise=noise)
+    f = fixtures.ba_fixture_test_local_ba(noise=noise)
     if noise:
         f["obs"][5] += 40.0          # beyond the Huber delta
     r = o.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"])

@@ -6,6 +6,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from ygz_slam_amd import synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import fixtures
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 p = bench.Pipeline(B, 0, 0)
@@ -24,7 +26,7 @@ def timed(name, kernel, fn, reps=3):
     return best
 
 # ---- BoW: vocabulary k = 10, L = 4 (10^4 words, DBoW3 binary format), Frame::ComputeBoW of every frame, then the two matchers
-voc = synth.synthetic_vocabulary(k=10, L=4, seed=5)
+voc = fixtures.synthetic_vocabulary(k=10, L=4, seed=5)
 c.vocab_load(voc)
 timed("ComputeBoW, %d frames x ~970 features" % B, "k_bow_transform", lambda: c.compute_bow(0, B, 4))
 s1 = list(range(B)); s2 = [(i - 1) % B for i in range(B)]

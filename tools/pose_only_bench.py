@@ -3,9 +3,11 @@ import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ygz_slam_amd import synth, _lib
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import fixtures
 
 ctx = _lib.HipContext(max_frames=1)
-fr = [synth.pose_only_fixture(n=1000, seed=100 + i, outlier_frac=0.1) for i in range(16)] * 16
+fr = [fixtures.pose_only_fixture(n=1000, seed=100 + i, outlier_frac=0.1) for i in range(16)] * 16
 off = np.concatenate([[0], np.cumsum([len(f["px"]) for f in fr])]).astype(np.int32)
 px = np.concatenate([f["px"] for f in fr]); pw = np.concatenate([f["pw"] for f in fr]); en = np.stack([f["entry"] for f in fr])
 for k in range(4):

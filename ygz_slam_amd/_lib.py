@@ -87,7 +87,7 @@ ABI_SYMBOLS = [
     "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_describe_given_angle", "ygz_hip_get_fast_maps",
     "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
     "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
-    "ygz_hip_default_klt_params", "ygz_hip_klt_track",
+    "ygz_hip_default_klt_params", "ygz_hip_klt_track", "ygz_hip_klt_track_filtered",
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
@@ -449,6 +449,17 @@ class HipContext:
         self._chk(self.lib.ygz_hip_klt_track(self._ctx, prev_slot, cur_slot, _p(pp, C.c_float), _p(npts, C.c_float), len(pp),
                                              C.byref(prm), _p(st, C.c_uint8), _p(err, C.c_float)), "klt_track")
         return npts, st, err
+
+    def klt_track_filtered(self, prev_slot, cur_slot, prev_pts, next_pts_init, border=20, params=None):
+        prm = params or self.klt_params()
+        pp = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        npts = np.ascontiguousarray(next_pts_init, np.float32).reshape(-1, 2).copy()
+        n = len(pp)
+        st = np.empty(max(n, 1), np.uint8); err = np.empty(max(n, 1), np.float32); keep = np.zeros(max(n, 1), np.uint8); nk = C.c_int(0)
+        self._chk(self.lib.ygz_hip_klt_track_filtered(self._ctx, prev_slot, cur_slot, _p(pp, C.c_float), _p(npts, C.c_float), n, C.byref(prm),
+                                                      int(border), _p(st, C.c_uint8), _p(err, C.c_float), _p(keep, C.c_uint8), C.byref(nk)),
+                  "klt_track_filtered")
+        return npts, st[:n], err[:n], keep[:n].astype(bool), nk.value
 
     # ---- resident batched tracking
     def set_keypoint_depths(self, slot, depth, has_mp):

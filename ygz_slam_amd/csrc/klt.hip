@@ -566,13 +566,31 @@ void ygz_hip_default_klt_params(ygz_klt_params *p)
     p->use_initial_flow = 1;
 }
 
-// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
-int ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
-                      const ygz_klt_params *prm, uint8_t *status, float *err)
+}  // extern "C"
+
+// Tracker::TrackKLT's survivor rule (src/Algorithm/Tracker.cpp:100-112): a track is kept iff status != 0 and the new position is
+// InFrame(pt, border) -- evaluated where the results are, one flag per point
+__global__ __launch_bounds__(256) void k_klt_keep(const float *__restrict__ pts, const uint8_t *__restrict__ status, int n, int w, int h,
+                                                  int border, uint8_t *__restrict__ keep, int32_t *__restrict__ n_keep)
 {
-    YgzDeviceGuard dg_(ctx);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool k = false;
+    if (i < n) {
+        const float x = pts[2 * i], y = pts[2 * i + 1];
+        k = status[i] != 0 && x >= border && x < w - border && y >= border && y < h - border;      // Frame::InFrame(cv::Point2f, boarder), Frame.h:60-65
+        keep[i] = (uint8_t)k;
+    }
+    const int c = __popcll(__ballot(k));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_keep, c);
+}
+
+// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
+static int klt_track_host(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
+                          const ygz_klt_params *prm, uint8_t *status, float *err, int border, uint8_t *keep, int *n_keep)
+{
     if (!ctx || !prm || n < 0 || prev_slot < 0 || prev_slot >= ctx->prm.max_frames || cur_slot < 0 || cur_slot >= ctx->prm.max_frames)
         return YGZ_E_INVALID;
+    if (n_keep) *n_keep = 0;
     if (n == 0) return YGZ_OK;
     if (!prev_pts || !next_pts || !status) return YGZ_E_INVALID;
     if (n > ctx->cells) return YGZ_E_CAPACITY;
@@ -588,11 +606,39 @@ int ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if ((rc = ygz_launch_klt(ctx, 1, prm)) != YGZ_OK) return rc;
+    if (keep) {
+        uint8_t *d_keep = nullptr;
+        if ((rc = ygz_scratch(ctx, SCR_KLT_OUT, N + 64, (void **)&d_keep)) != YGZ_OK) return rc;
+        int32_t *d_cnt = reinterpret_cast<int32_t *>(d_keep + ((N + 15) & ~(size_t)15));
+        YGZ_HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+        YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_klt_keep, dim3(ygz_div_up(n, 256)), dim3(256), ctx->klt_pts, ctx->klt_status, n, ctx->lw[0], ctx->lh[0],
+                   border, d_keep, d_cnt);
+        YGZ_HIPCHK(ctx, hipGetLastError());
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(keep, d_keep, N, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_keep) YGZ_HIPCHK(ctx, hipMemcpyAsync(n_keep, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     YGZ_HIPCHK(ctx, hipMemcpyAsync(next_pts, ctx->klt_pts, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(status, ctx->klt_status, N, hipMemcpyDeviceToHost, ctx->stream));
     if (err) YGZ_HIPCHK(ctx, hipMemcpyAsync(err, ctx->klt_err, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
+}
+
+extern "C" {
+
+int ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
+                      const ygz_klt_params *prm, uint8_t *status, float *err)
+{
+    YgzDeviceGuard dg_(ctx);
+    return klt_track_host(ctx, prev_slot, cur_slot, prev_pts, next_pts, n, prm, status, err, 0, nullptr, nullptr);
+}
+
+int ygz_hip_klt_track_filtered(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
+                               const ygz_klt_params *prm, int border, uint8_t *status, float *err, uint8_t *keep, int *n_keep)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!keep && n > 0) return YGZ_E_INVALID;
+    return klt_track_host(ctx, prev_slot, cur_slot, prev_pts, next_pts, n, prm, status, err, border, keep, n_keep);
 }
 
 }  // extern "C"

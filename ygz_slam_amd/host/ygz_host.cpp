@@ -179,17 +179,32 @@ void Frame::CreateImagePyramid()
 }
 
 Mat Frame::GetAllDescriptors()
-{
-    Mat alldesp((int)_features.size(), 32, CV_8U);
-    int index = 0;
-    for (Feature *fea : _features) { memcpy(alldesp.ptr<uchar>(index), fea->_desc.data, 32); index++; }
-    return alldesp;
+{   // Frame.cpp:178-188: one 32-byte row per feature, feature order
+    const int n = (int)_features.size();
+    Mat rows(n, 32, CV_8U);
+    for (int r = 0; r < n; ++r) std::copy_n(_features[r]->_desc.data, 32, rows.ptr<uchar>(r));
+    return rows;
 }
 
 void Frame::CleanAllFeatures()
-{
-    for (size_t i = 0; i < _features.size(); i++) delete _features[i];
-    _features.clear();
+{   // Frame.cpp:203-210: the frame owns its features
+    for (Feature *f : _features) delete f;
+    vector<Feature *>().swap(_features);
+}
+
+bool Frame::GetMeanAndMinDepth(double &mean_depth, double &min_depth)
+{   // Frame.cpp:42-72: depth statistics of the features that have a good map point in front of the camera
+    double sum = 0, lo = 9999;
+    int n = 0;
+    for (const Feature *f : _features) {
+        if (!f->_mappoint || f->_mappoint->_bad) continue;
+        const double z = (_TCW * f->_mappoint->_pos_world)[2];
+        if (z < 0) continue;
+        sum += z; lo = std::min(lo, z); ++n;
+    }
+    mean_depth = n ? sum / n : 0.0;
+    min_depth = n ? lo : 0.0;
+    return n > 0;
 }
 
 // ------------------------------------------------------------------------------------------ Memory
@@ -204,6 +219,7 @@ Frame *Memory::RegisterKeyFrame(Frame *frame, bool overwrite)
     return frame;
 }
 MapPoint *Memory::RegisterMapPoint(MapPoint *mp) { mp->_id = g_pt_id++; g_points[mp->_id] = mp; return mp; }
+MapPoint *Memory::CreateMapPoint() { return RegisterMapPoint(new MapPoint); }      // Memory.cpp:45-52
 Frame *Memory::GetKeyFrame(const unsigned long &id) { auto it = g_keyframes.find(id); return it == g_keyframes.end() ? nullptr : it->second; }
 MapPoint *Memory::GetMapPoint(const unsigned long &id) { auto it = g_points.find(id); return it == g_points.end() ? nullptr : it->second; }
 void Memory::Clean() { g_keyframes.clear(); g_points.clear(); g_kf_id = g_pt_id = 0; }
@@ -299,73 +315,81 @@ void FeatureDetector::ComputeDescriptor(Feature *fea) { describe_features(fea->_
 Tracker::Tracker() { _option._min_feature_tracking = Config::Get<int>("tracker.min_features"); }
 
 void Tracker::SetReference(Frame *ref)
-{
-    if ((int)ref->_features.size() < _option._min_feature_tracking) {
-        LOG(WARNING) << "Track a reference with little features: " << ref->_features.size() << ", abort." << endl;
+{   // Tracker.cpp:13-32
+    const size_t n = ref->_features.size();
+    if ((int)n < _option._min_feature_tracking) {
+        LOG(WARNING) << "Tracker::SetReference: only " << n << " features in the reference frame (need " << _option._min_feature_tracking << ")" << endl;
         _status = TRACK_NOT_READY;
         return;
     }
-    _ref = ref; _curr = ref; _status = TRACK_GOOD;
-    for (Feature *fea : ref->_features) {
-        _tracked_features.push_back(fea);
-        _px_curr.push_back(cv::Point2f((float)fea->_pixel[0], (float)fea->_pixel[1]));
+    _ref = _curr = ref;
+    _status = TRACK_GOOD;
+    _tracks.feature.reserve(_tracks.size() + n);
+    for (Feature *fea : ref->_features) {                    // appended, as the reference does when called twice
+        const float x = (float)fea->_pixel[0], y = (float)fea->_pixel[1];
+        _tracks.feature.push_back(fea);
+        _tracks.ref_px.push_back(x); _tracks.ref_px.push_back(y);
+        _tracks.cur_px.push_back(x); _tracks.cur_px.push_back(y);
     }
 }
 
 void Tracker::Track(Frame *curr)
-{
-    if (_status == TRACK_NOT_READY) { LOG(WARNING) << "reference is not ready, please set reference first! " << endl; return; }
-    else if (_status == TRACK_LOST) { LOG(WARNING) << "track is lost, please reset it" << endl; return; }
+{   // Tracker.cpp:34-53
+    if (_status != TRACK_GOOD) {
+        LOG(WARNING) << (_status == TRACK_NOT_READY ? "Tracker::Track: no reference set" : "Tracker::Track: tracking was lost, set a new reference") << endl;
+        return;
+    }
     _curr = curr;
     TrackKLT();
-    if ((int)_px_curr.size() < _option._min_feature_tracking) {
+    if ((int)_tracks.size() < _option._min_feature_tracking) {
         _status = TRACK_LOST;
-        LOG(WARNING) << "Track with little features, set it as lost." << endl;
+        LOG(WARNING) << "Tracker::Track: " << _tracks.size() << " tracks left, lost" << endl;
     }
 }
 
 void Tracker::GetTrackedPixel(vector<Feature *> &feature1, vector<Vector2d> &pixels2) const
 {
-    for (Feature *fea : _tracked_features) feature1.push_back(fea);
-    for (auto px : _px_curr) pixels2.push_back(Vector2d(px.x, px.y));
+    feature1.insert(feature1.end(), _tracks.feature.begin(), _tracks.feature.end());
+    for (size_t i = 0; i < _tracks.size(); ++i) pixels2.push_back(Vector2d(_tracks.cur_px[2 * i], _tracks.cur_px[2 * i + 1]));
 }
 
 void Tracker::TrackKLT()
-{   // cv::calcOpticalFlowPyrLK(ref, cur, pt_ref, pt_curr, ..., Size(21,21), 4, COUNT+EPS(30,1e-3), USE_INITIAL_FLOW)  (Tracker.cpp:92-98)
+{   // cv::calcOpticalFlowPyrLK(ref, cur, pt_ref, pt_curr, ..., Size(21,21), 4, COUNT+EPS(30,1e-3), USE_INITIAL_FLOW) and the survivor rule
+    // status && InFrame(pt, 20) (Tracker.cpp:92-112), both on the GPU; the host only compacts the rows that were kept
     hip::Runtime &rt = hip::Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
-    const int cells = rt.cells();
-    vector<float> pt_ref, pt_curr;
-    for (Feature *fea : _tracked_features) { pt_ref.push_back((float)fea->_pixel[0]); pt_ref.push_back((float)fea->_pixel[1]); }
-    for (cv::Point2f &p : _px_curr) { pt_curr.push_back(p.x); pt_curr.push_back(p.y); }
-    const int n = (int)_tracked_features.size();
-    vector<uint8_t> status(n); vector<float> err(n);
+    const int cells = rt.cells(), n = (int)_tracks.size();
     ygz_klt_params prm;
     ygz_hip_default_klt_params(&prm);
     prm.win = (int)_option.klt_win_size; prm.max_iter = _option.klt_max_iter; prm.eps = _option.klt_eps;
     const int rs = rt.Resident(_ref), cs = rt.Resident(_curr);
+    vector<uint8_t> status(n), keep(n); vector<float> err(n);
     for (int base = 0; base < n; base += cells) {
         const int m = std::min(cells, n - base);
-        hip::check(ygz_hip_klt_track(c, rs, cs, &pt_ref[2 * base], &pt_curr[2 * base], m, &prm, &status[base], &err[base]), "klt_track");
+        int kept = 0;
+        hip::check(ygz_hip_klt_track_filtered(c, rs, cs, &_tracks.ref_px[2 * base], &_tracks.cur_px[2 * base], m, &prm, 20, &status[base], &err[base],
+                                              &keep[base], &kept), "klt_track_filtered");
     }
-    _px_curr.clear();
-    size_t iStatus = 0;
-    for (auto iter = _tracked_features.begin(); iter != _tracked_features.end(); iStatus++) {
-        const cv::Point2f p(pt_curr[2 * iStatus], pt_curr[2 * iStatus + 1]);
-        if (!status[iStatus] || !_curr->InFrame(p, 20)) iter = _tracked_features.erase(iter);
-        else { iter++; _px_curr.push_back(p); }
+    size_t w = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!keep[i]) continue;
+        _tracks.feature[w] = _tracks.feature[i];
+        _tracks.ref_px[2 * w] = _tracks.ref_px[2 * i]; _tracks.ref_px[2 * w + 1] = _tracks.ref_px[2 * i + 1];
+        _tracks.cur_px[2 * w] = _tracks.cur_px[2 * i]; _tracks.cur_px[2 * w + 1] = _tracks.cur_px[2 * i + 1];
+        ++w;
     }
+    _tracks.feature.resize(w); _tracks.ref_px.resize(2 * w); _tracks.cur_px.resize(2 * w);
 }
 
 float Tracker::MeanDisparity() const
-{
-    assert(_tracked_features.size() == _px_curr.size());
-    float mean_disparity = 0;
-    auto iter_ref = _tracked_features.begin();
-    size_t iCur = 0;
-    for (; iter_ref != _tracked_features.end(); iter_ref++, iCur++)
-        mean_disparity += (float)((*iter_ref)->_pixel - Vector2d(_px_curr[iCur].x, _px_curr[iCur].y)).norm();
-    return mean_disparity / _tracked_features.size();
+{   // Tracker.cpp:115-127: a float accumulator over |feature pixel (double) - current position| in track order
+    float acc = 0;
+    for (size_t i = 0; i < _tracks.size(); ++i) {
+        const Vector2d &p = _tracks.feature[i]->_pixel;
+        const double dx = p[0] - (double)_tracks.cur_px[2 * i], dy = p[1] - (double)_tracks.cur_px[2 * i + 1];
+        acc += std::sqrt(dx * dx + dy * dy);              // float += double: the sum is formed in double and rounded, as in the reference
+    }
+    return acc / _tracks.size();
 }
 
 // ------------------------------------------------------------------------------------------ SparseImgAlign
@@ -465,19 +489,24 @@ int Matcher::DescriptorDistance(const Mat &a, const Mat &b)
 }
 
 int Matcher::CheckFrameDescriptors(Frame *frame1, Frame *frame2, list<pair<int, int>> &matches)
-{
-    vector<int> distance;
-    for (auto &m : matches) distance.push_back(DescriptorDistance(frame1->_features[m.first]->_desc, frame2->_features[m.second]->_desc));
-    int cnt_good = 0;
-    int best_dist = *std::min_element(distance.begin(), distance.end());
-    best_dist = best_dist > _options.init_low ? best_dist : _options.init_low;
-    best_dist = best_dist < _options.init_high ? best_dist : _options.init_high;
-    int i = 0;
-    for (auto iter = matches.begin(); iter != matches.end(); i++) {
-        if (distance[i] < _options.initMatchRatio * best_dist) { cnt_good++; iter++; }
-        else iter = matches.erase(iter);
+{   // Matcher.cpp:45-84 through ygz_hip_check_descriptor_pairs: distances, clamped best and keep flags come back from the GPU,
+    // the list is filtered with them
+    const size_t n = matches.size();
+    if (n == 0) return 0;
+    vector<uint8_t> d1(32 * n), d2(32 * n), keep(n);
+    size_t r = 0;
+    for (const auto &m : matches) {
+        memcpy(&d1[32 * r], frame1->_features[m.first]->_desc.data, 32);
+        memcpy(&d2[32 * r], frame2->_features[m.second]->_desc.data, 32);
+        ++r;
     }
-    return cnt_good;
+    int n_good = 0, best = 0;
+    hip::check(ygz_hip_check_descriptor_pairs(hip::Runtime::Get().ctx(), d1.data(), d2.data(), (int)n, _options.init_low, _options.init_high,
+                                              _options.initMatchRatio, nullptr, keep.data(), &n_good, &best), "check_descriptor_pairs");
+    LOG(INFO) << "best dist = " << best << ", kept " << n_good << " of " << n << endl;
+    r = 0;
+    matches.remove_if([&](const pair<int, int> &) { return keep[r++] == 0; });
+    return n_good;
 }
 
 namespace {
