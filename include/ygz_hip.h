@@ -287,6 +287,10 @@ typedef struct {
  * chi2 = sum of robustified chi2.  Uploads the problem, runs the kernels, downloads. */
 int  ygz_hip_ba_linearize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *Hpp, double *bp, double *Hll,
                           double *bl, double *Hpl, double *err, double *chi2_edge, double *chi2);
+/* An edge list may hold the same (point, pose) pair more than once (two features of one frame that share a map point, as
+ * ba::OptimizeCurrent can produce): every edge contributes to chi2, Hll, bl, Hpp, bp and has its own Hpl block, as ceres / g2o count
+ * every residual block.  Only ygz_hip_ba_optimize_resident refuses such a window (YGZ_E_INVALID); ygz_hip_ba_optimize then runs
+ * the reduced system on the host. */
 /* resident form: upload structure once, then re-linearise for new states without host copies */
 int  ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb);
 int  ygz_hip_ba_set_state(ygz_hip_ctx *ctx, int window, const double *poses, const double *points);

@@ -568,6 +568,51 @@ def test_resident_batched_tracking(hip_lib, oracle, overlap):
     ctx.close()
 
 
+def test_ba_repeated_point_pose_edges(hip_lib, oracle):
+    """the same (map point, free pose) pair observed twice -- two features of one frame sharing a map point, as ba::OptimizeCurrent can
+    build (BA.cpp:91-186): every residual block counts, in Hpp / bp too.  Linearisation vs the oracle, the LM loop (falls back to the
+    host-side reduced system), the ceres solver, and the resident LM kernel refusing such a window."""
+    f = synth.ba_window(6, 300, seed=21)
+    rng = np.random.default_rng(4)
+    dup = rng.choice(len(f["obs"]), 90, replace=False)
+    ep = np.concatenate([f["edge_pose"], f["edge_pose"][dup], f["edge_pose"][dup[:10]]]).astype(np.int32)        # some pairs three times
+    el = np.concatenate([f["edge_point"], f["edge_point"][dup], f["edge_point"][dup[:10]]]).astype(np.int32)
+    obs = np.concatenate([f["obs"], f["obs"][dup] + rng.normal(0, 1.5, (90, 2)), f["obs"][dup[:10]] + rng.normal(0, 1.5, (10, 2))])
+    perm = rng.permutation(len(ep))                                                                              # unsorted edge list
+    ep, el, obs = ep[perm], el[perm], obs[perm]
+    ctx = make_ctx(hip_lib, max_frames=2)
+    for form in (0, 1):
+        g = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], ep, el, obs, formulation=form)
+        if form == 0:
+            r = oracle.ba_linearize(f["poses"], f["fixed"], f["points"], ep, el, obs)
+            for k in ("err", "chi2_edge", "Hpp", "bp", "Hll", "bl", "Hpl"):
+                assert np.allclose(g[k], r[k], rtol=1e-9, atol=1e-7), k
+            assert abs(g["chi2"] - r["chi2"]) <= 1e-9 * r["chi2"]
+        # the blocks of a free pose are the sums over ALL its edges: rebuild Hpp from single-edge problems
+        k = 3
+        sel = np.nonzero(ep == k)[0]
+        Hk = np.zeros(36); bk = np.zeros(6)
+        for e in sel[:40]:
+            one = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], ep[e:e + 1], el[e:e + 1], obs[e:e + 1], formulation=form)
+            Hk += one["Hpp"][k].ravel(); bk += one["bp"][k]
+        part = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], ep[sel[:40]], el[sel[:40]], obs[sel[:40]], formulation=form)
+        assert np.allclose(part["Hpp"][k].ravel(), Hk, rtol=1e-10, atol=1e-6) and np.allclose(part["bp"][k], bk, rtol=1e-10, atol=1e-6)
+    ctx.ba_upload(0, f["poses"], f["fixed"], f["points"], ep, el, obs)
+    with pytest.raises(hip_lib.YgzHipError) as ei:
+        ctx.ba_optimize_resident(0, 1, 5)
+    assert ei.value.code == hip_lib.E_INVALID
+    po, pt, st = ctx.ba_optimize(f["poses"], f["fixed"], f["points"], ep, el, obs, iterations=10)
+    opo, opt_, ost = oracle.g2o_lm(f["poses"], f["fixed"], f["points"], ep, el, obs, max_iterations=10)
+    assert st.iterations == ost["iterations"] and abs(st.chi2_final - ost["chi2_final"]) <= 1e-8 * ost["chi2_final"]
+    assert np.allclose(po, opo, rtol=1e-6, atol=1e-8) and np.allclose(pt, opt_, rtol=1e-6, atol=1e-8)
+    c = fixtures.ba_to_ceres(dict(f, obs=obs, edge_pose=ep, edge_point=el))
+    gpo, gpt, gsm = ctx.ba_solve_ceres(c["poses"], c["fixed"], c["points"], ep, el, c["obs_n"])
+    cpo, cpt, csm = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], ep, el, c["obs_n"])
+    assert gsm["iterations"] == csm["iterations"] and gsm["termination"] == csm["termination"]
+    assert abs(gsm["final_cost"] - csm["final_cost"]) <= 1e-6 * csm["final_cost"]
+    ctx.close()
+
+
 def test_ba_batched_windows(hip_lib, oracle):
     ctx = make_ctx(hip_lib, max_frames=1)
     fs = [synth.ba_window(10, 500, seed=20 + i) for i in range(3)] + [synth.ba_window(6, 200, seed=30)]

@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void k_ba_unpack_points(const double *__restri
     out[t] = src[((size_t)(l >> 6) * NC + k) * 64 + (l & 63)];
 }
 
+bool ygz_ba_window_has_dup(const ygz_hip_ctx *ctx, int window)
+{ return window >= 0 && window < (int)ctx->ba.size() && ctx->ba[window] && ctx->ba[window]->has_dup; }
+
 static void ba_free(ygz_hip_ctx::BaWindow *w) { if (w) { if (w->blob) (void)hipFree(w->blob); delete w; } }
 
 extern "C" void ygz_hip_ba_free_all(ygz_hip_ctx *ctx)
@@ -154,7 +157,7 @@ static BaDev ba_dev(const ygz_hip_ctx::BaWindow *w)
     B.K = w->K; B.P = w->P; B.E = w->E; B.formulation = w->formulation; B.Kf = w->Kf; B.R = w->R; B.Q = w->Q;
     B.fx = w->fx; B.fy = w->fy; B.cx = w->cx; B.cy = w->cy; B.huber = w->huber;
     B.poses = w->poses; B.points = w->points; B.posed = w->posed;
-    B.obs_c = w->obs_c; B.huber_c = w->huber_c; B.pose_c = w->pose_c; B.enable_c = w->enable_c; B.slot_off = w->slot_off; B.ppc = w->ppc;
+    B.obs_c = w->obs_c; B.huber_c = w->huber_c; B.pose_c = w->pose_c; B.enable_c = w->enable_c; B.slot_off = w->slot_off; B.ppc = w->ppc; B.dupn = w->dupn;
     B.edge_rl = w->edge_rl; B.fixed = w->fixed; B.point_fixed = w->point_fixed; B.free_idx = w->free_idx; B.free_pose = w->free_pose;
     B.n_behind = w->n_behind;
     B.Hpp = w->Hpp; B.bp = w->bp; B.chi2 = w->chi2; B.Hll_c = w->Hll_c; B.bl_c = w->bl_c; B.Hpl_c = w->Hpl_c; B.err_c = w->err_c;
@@ -227,7 +230,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     std::vector<int32_t> pose_c(Rz * 64, -1), edge_rl(Ez, 0);
     std::vector<double> obs_c(Rz * 128, 0.0), huber_c(Rz * 64, 0.0);
     std::vector<uint8_t> enable_c(Rz * 64, 0);
-    std::vector<int16_t> ppc((size_t)P * Kfz, -1);
+    std::vector<int16_t> ppc((size_t)P * Kfz, -1), dupn(Rz * 64, -1), last_c((size_t)P * Kfz, -1);
     std::fill(cnt.begin(), cnt.end(), 0);
     for (int e = 0; e < E; ++e) {
         const int l = pb->edge_point[e], c = cnt[l]++, row = slot_off[l >> 6] + c, lane = l & 63, ip = pb->edge_pose[e];
@@ -237,7 +240,12 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
         huber_c[(size_t)row * 64 + lane] = pb->edge_huber ? pb->edge_huber[e] : pb->huber_delta;
         enable_c[(size_t)row * 64 + lane] = pb->edge_enable ? (pb->edge_enable[e] ? 1 : 0) : 1;
         const int a = free_idx[ip];
-        if (a >= 0 && ppc[(size_t)l * Kfz + a] < 0) ppc[(size_t)l * Kfz + a] = (int16_t)c;
+        if (a >= 0) {
+            const size_t pa = (size_t)l * Kfz + a;
+            if (ppc[pa] < 0) ppc[pa] = (int16_t)c;
+            else { dupn[(size_t)(slot_off[l >> 6] + last_c[pa]) * 64 + lane] = (int16_t)c; w->has_dup = true; }    // a repeated (point, free pose) pair
+            last_c[pa] = (int16_t)c;
+        }
     }
     w->h_edge_rl = edge_rl;
     // ---- one blob: doubles, then int32, then int16, then bytes
@@ -248,7 +256,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
                     + (size_t)Q * Kfz * 27 + (size_t)Q                                            // partials
                     + (size_t)K * 6 + (size_t)P * 3 + Rz * 18 * 64 + (size_t)P * 9 + (size_t)P * 3;   // LM: backups, Y_c, Dinv, xl
     const size_t ni = Rz * 64 + (size_t)Q + 1 + Ez + 2 * (size_t)K + 1;
-    const size_t ns = (size_t)P * Kfz + 1;
+    const size_t ns = (size_t)P * Kfz + 1 + Rz * 64;
     const size_t bytes = nd * 8 + ni * 4 + ((ns * 2 + 3) & ~(size_t)3) + (size_t)K + (size_t)P + Rz * 64 + 64;
     hipError_t he = hipMalloc(&w->blob, bytes);
     if (he != hipSuccess) { ctx->last_hip_error = (int)he; delete w; return YGZ_E_HIP; }
@@ -264,7 +272,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     int32_t *ii = (int32_t *)d;
     w->pose_c = ii; ii += Rz * 64; w->slot_off = ii; ii += (size_t)Q + 1; w->edge_rl = ii; ii += Ez;
     w->free_idx = ii; ii += K; w->free_pose = ii; ii += K; w->n_behind = ii; ii += 1;
-    w->ppc = (int16_t *)ii;
+    w->ppc = (int16_t *)ii; w->dupn = w->ppc + (size_t)P * Kfz + 1;
     uint8_t *bb = (uint8_t *)ii + ((ns * 2 + 3) & ~(size_t)3);
     w->fixed = bb; bb += K; w->point_fixed = bb; bb += P; w->enable_c = bb;
     ctx->ba[window] = w;
@@ -277,7 +285,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     UP_(w->obs_c, obs_c.data(), Rz * 128 * 8); UP_(w->huber_c, huber_c.data(), Rz * 64 * 8);
     UP_(w->pose_c, pose_c.data(), Rz * 64 * 4); UP_(w->slot_off, slot_off.data(), ((size_t)Q + 1) * 4); UP_(w->edge_rl, edge_rl.data(), Ez * 4);
     UP_(w->free_idx, free_idx.data(), (size_t)K * 4); UP_(w->free_pose, free_pose.data(), (size_t)K * 4);
-    UP_(w->ppc, ppc.data(), ppc.size() * 2);
+    UP_(w->ppc, ppc.data(), ppc.size() * 2); UP_(w->dupn, dupn.data(), dupn.size() * 2);
     UP_(w->fixed, fixed.data(), (size_t)K); UP_(w->point_fixed, pfixed.data(), (size_t)P); UP_(w->enable_c, enable_c.data(), Rz * 64);
 #undef UP_
     // blocks of constant poses / padding lanes are never written by the kernels: zero once

@@ -25,6 +25,9 @@ struct ygz_hip_ctx::BaWindow {
     uint8_t *enable_c;               // [R][64]
     int32_t *slot_off;               // [Q + 1] first row of each chunk
     int16_t *ppc;                    // [P][Kf] c of the (first) edge from point l to free pose a, or -1
+    int16_t *dupn;                   // [R][64] c of the NEXT edge of the lane's point to the same pose, or -1 (two features of one frame
+                                     // observing one map point: ceres / g2o count both residual blocks)
+    bool has_dup = false;
     int32_t *edge_rl;                // [E] row * 64 + lane of edge e (gather / scatter between ABI order and rows)
     uint8_t *fixed, *point_fixed;
     int32_t *free_idx, *free_pose, *n_behind;
@@ -43,7 +46,7 @@ struct BaDev {
     int K, P, E, formulation, Kf, R, Q;
     double fx, fy, cx, cy, huber;
     const double *poses, *points; double *posed;
-    const double *obs_c, *huber_c; const int32_t *pose_c; const uint8_t *enable_c; const int32_t *slot_off; const int16_t *ppc;
+    const double *obs_c, *huber_c; const int32_t *pose_c; const uint8_t *enable_c; const int32_t *slot_off; const int16_t *ppc, *dupn;
     const int32_t *edge_rl;
     const uint8_t *fixed, *point_fixed; const int32_t *free_idx, *free_pose; int32_t *n_behind;
     double *Hpp, *bp, *chi2, *Hll_c, *bl_c, *Hpl_c, *err_c, *chi2e_c, *part_pose, *part_chi;
@@ -251,25 +254,28 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
 // them back through a pose-major gather).
 __device__ __forceinline__ void ba_pose_contrib(const BaDev &B, int il, int a, double acc[27])
 {
-    const int c = B.ppc[(size_t)il * B.Kf + a];
+    int c = B.ppc[(size_t)il * B.Kf + a];
     if (c < 0) return;
-    const int lane = il & 63, row = B.slot_off[il >> 6] + c;
-    if (!B.enable_c[(size_t)row * 64 + lane]) return;
+    const int lane = il & 63, row0 = B.slot_off[il >> 6];
     const int k = B.free_pose[a];
     const double *pd = B.posed + BA_POSED * (size_t)k;
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
-    double p[3], r[2], rho0, rho1, Jx[12];
-    ba_project(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
-    ba_robust(r[0] * r[0] + r[1] * r[1], B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
-    ba_pose_jac(B.formulation, p[0], p[1], p[2], B.fx, B.fy, pd, Jx);
-    int q = 0;
+    for (; c >= 0; c = B.dupn[(size_t)(row0 + c) * 64 + lane]) {            // almost always one edge; the chain holds repeated (point, pose) pairs
+        const int row = row0 + c;
+        if (!B.enable_c[(size_t)row * 64 + lane]) continue;
+        double p[3], r[2], rho0, rho1, Jx[12];
+        ba_project(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
+        ba_robust(r[0] * r[0] + r[1] * r[1], B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
+        ba_pose_jac(B.formulation, p[0], p[1], p[2], B.fx, B.fy, pd, Jx);
+        int q = 0;
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
+        for (int u = 0; u < 6; ++u) {
 #pragma unroll
-        for (int v = u; v < 6; ++v) acc[q++] += rho1 * (Jx[u] * Jx[v] + Jx[6 + u] * Jx[6 + v]);
+            for (int v = u; v < 6; ++v) acc[q++] += rho1 * (Jx[u] * Jx[v] + Jx[6 + u] * Jx[6 + v]);
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) acc[21 + u] += -rho1 * (Jx[u] * r[0] + Jx[6 + u] * r[1]);
     }
-#pragma unroll
-    for (int u = 0; u < 6; ++u) acc[21 + u] += -rho1 * (Jx[u] * r[0] + Jx[6 + u] * r[1]);
 }
 
 #endif

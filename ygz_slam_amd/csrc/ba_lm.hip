@@ -151,7 +151,7 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
         int Kfree = 0;
         for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
         const char *force = getenv("YGZ_BA_HOST_LOOP");
-        if (Kfree <= 14 && !(force && force[0] == '1')) {
+        if (Kfree <= 14 && !(force && force[0] == '1') && !ygz_ba_window_has_dup(ctx, W)) {      // repeated (point, pose) pairs: host-side Schur sums them per edge
             ygz_ba_stats st;
             if ((rc = ygz_hip_ba_optimize_resident(ctx, W, 1, max_iterations, &st)) != YGZ_OK) return rc;
             if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;

@@ -326,6 +326,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
         if (!ctx->ba[i]) return YGZ_E_INVALID;
         if (ctx->ba[i]->formulation != 0) return YGZ_E_INVALID;      // the g2o path of the live tree
         if (ctx->ba[i]->Kf > LM_MAXKF || ctx->ba[i]->K > LM_THREADS) return YGZ_E_CAPACITY;   // reduced system must fit LDS
+        if (ctx->ba[i]->has_dup) return YGZ_E_INVALID;            // the pair sweep of the Schur step takes ONE edge per (point, pose): use ygz_hip_ba_optimize
     }
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);

@@ -156,6 +156,10 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
             prev_used[f] = 0;
             if (!has_mp[f] || ui - border < 0 || vi - border < 0 || ui + border >= cols || vi + border >= rows) {
                 for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = 0.0;       // a zero Jacobian column block (:42)
+                if (visible[f]) {                                                 // visible from a coarser level (visible_fts_ is never reset, :35):
+                    float4 *z4 = reinterpret_cast<float4 *>(dxy + 32 * (size_t)f);   // the residual pass still visits it, so its gradients must be
+                    for (int k = 0; k < 8; ++k) z4[k] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero columns setZero() left, not the previous level's
+                }
                 continue;
             }
             visible[f] = 1;

@@ -188,6 +188,7 @@ struct YgzPoDev {
 };
 int ygz_launch_pose_only(ygz_hip_ctx *ctx, int n_frames, const YgzPoDev &d);
 int ygz_pf_ensure(ygz_hip_ctx *ctx);
+bool ygz_ba_window_has_dup(const ygz_hip_ctx *ctx, int window);    // an uploaded BA window repeats a (point, free pose) pair (ba.hip)
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

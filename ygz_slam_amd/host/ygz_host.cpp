@@ -917,7 +917,7 @@ void OptimizeCurrentPoseOnlyBatch(const vector<Frame *> &frames)
         f->_TCW = SE3(SO3::exp(Vector3d(p[3], p[4], p[5])), Vector3d(p[0], p[1], p[2]));
         for (Feature *fea : f->_features) {
             fea->_bad = bad[g] != 0;
-            if (!fea->_bad) fea->_depth = depth[g];
+            fea->_depth = depth[g];               // the depth of the LAST round in which the feature was an inlier (BA.cpp:236-240); never an inlier: unchanged
             if (fea->_bad == false && fea->_mappoint && fea->_mappoint->_bad == false) fea->_mappoint->_cnt_found++;   // BA.cpp:257-263
             ++g;
         }
