@@ -533,3 +533,149 @@ int yo_optimize_current_pose_only(const yo_camera *cam, double pose_io[6], int n
     free(obs); free(ep); free(el); free(enable); free(pfix); free(pts);
     return cntInlier;
 }
+
+/* ---- the other ceres-based entry points of src/Algorithm/BA.cpp on plain arrays (B7) --------------------------------------
+ * Each function builds the residual blocks in the order the reference adds them, solves with yo_ceres_solve (default options =
+ * trust-region Levenberg-Marquardt) and applies the reference's write-back.  Poses are [t; log(so3)] 6-vectors. */
+static void se3_to_taa(const yo_se3 *T, double p[6])
+{
+    double th;
+    p[0] = T->t[0]; p[1] = T->t[1]; p[2] = T->t[2];
+    yo_so3_log(T->q, p + 3, &th);                         /* pose.head<3>() = translation, pose.tail<3>() = so3().log() */
+}
+static void taa_to_se3(const double p[6], yo_se3 *T)
+{
+    double th;
+    yo_so3_exp(p + 3, T->q, &th); T->t[0] = p[0]; T->t[1] = p[1]; T->t[2] = p[2];   /* SE3(SO3::exp(tail), head) */
+}
+static void world2pixel(const yo_camera *cam, const yo_se3 *T, const double pw[3], double px[2], double *z)
+{   /* Camera::World2Pixel / World2Camera, Camera.h:41-52,73-75 */
+    double pc[3];
+    yo_se3_act(T, pw, pc);
+    px[0] = (double)cam->fx * pc[0] / pc[2] + (double)cam->cx; px[1] = (double)cam->fy * pc[1] / pc[2] + (double)cam->cy;
+    if (z) *z = pc[2];
+}
+static void pixel2camera2d(const yo_camera *cam, const double px[2], double out[2])
+{   /* Camera.h:64-69 */
+    out[0] = (px[0] - (double)cam->cx) / (double)cam->fx; out[1] = (px[1] - (double)cam->cy) / (double)cam->fy;
+}
+
+/* ba::TwoViewBACeres -- BA.cpp:11-89.  ref is constant (CeresReprojectionErrorPointOnly), curr is optimised together with the
+ * points; outlier points restart from (0,0,1) and their two residual blocks get HuberLoss(0.1).  The reference asks for
+ * options.trust_region_strategy_type = DOGLEG (:59); [frozen spec, divergence] the restated solver has the Levenberg-Marquardt
+ * strategy only -- both strategies stop at a stationary point of the same cost, which tests/test_oracle_ceres.py checks against
+ * scipy's dogbox solver.  inlier [n] in/out, pts_ref [n][3] in/out. */
+int yo_two_view_ba_ceres(const yo_camera *cam, const yo_se3 *ref, yo_se3 *curr, int n, const double *px_ref, const double *px_curr,
+                         uint8_t *inlier, double *pts_ref, yo_ceres_summary *sum)
+{
+    const size_t nz = (size_t)(n > 0 ? n : 1);
+    double poses[12];
+    se3_to_taa(ref, poses); se3_to_taa(curr, poses + 6);
+    const uint8_t pose_fixed[2] = { 1, 0 };
+    int32_t *ep = (int32_t *)malloc(8 * nz), *el = (int32_t *)malloc(8 * nz);
+    double *obs = (double *)malloc(32 * nz), *hub = (double *)malloc(16 * nz);
+    for (int i = 0; i < n; ++i) {
+        if (!inlier[i]) { pts_ref[3 * i] = 0; pts_ref[3 * i + 1] = 0; pts_ref[3 * i + 2] = 1; }      /* :36-38 */
+        const double a = inlier[i] ? 0.0 : 0.1;
+        ep[2 * i] = 0; el[2 * i] = i; pixel2camera2d(cam, px_ref + 2 * i, obs + 4 * i); hub[2 * i] = a;            /* :41-45 */
+        ep[2 * i + 1] = 1; el[2 * i + 1] = i; pixel2camera2d(cam, px_curr + 2 * i, obs + 4 * i + 2); hub[2 * i + 1] = a;   /* :48-55 */
+    }
+    yo_ceres_problem pb; memset(&pb, 0, sizeof(pb));
+    pb.n_poses = 2; pb.n_points = n; pb.n_edges = 2 * n; pb.poses = poses; pb.pose_fixed = pose_fixed; pb.points = pts_ref;
+    pb.edge_pose = ep; pb.edge_point = el; pb.obs_n = obs; pb.edge_huber = hub;
+    yo_ceres_options opt; yo_ceres_default_options(&opt);
+    if (n > 0) yo_ceres_solve(&pb, &opt, sum);
+    taa_to_se3(poses + 6, curr);                                                        /* :65 */
+    const double ch2 = 5.991;
+    int n_in = 0;
+    for (int i = 0; i < n; ++i) {                                                        /* :68-84 */
+        double p1[2], p2[2], d1, d2;
+        world2pixel(cam, ref, pts_ref + 3 * i, p1, &d1); world2pixel(cam, curr, pts_ref + 3 * i, p2, &d2);
+        const double e1x = px_ref[2 * i] - p1[0], e1y = px_ref[2 * i + 1] - p1[1], e2x = px_curr[2 * i] - p2[0], e2y = px_curr[2 * i + 1] - p2[1];
+        if (e1x * e1x + e1y * e1y > ch2 || e2x * e2x + e2y * e2y > ch2) inlier[i] = 0;
+        else if (d1 < 0 || d2 < 0) inlier[i] = 0;
+        else { inlier[i] = 1; ++n_in; }
+    }
+    free(ep); free(el); free(obs); free(hub);
+    return n_in;
+}
+
+/* the residual blocks shared by OptimizeCurrent / OptimizeCurrentPointOnly: per feature one block to the current frame, then one
+ * PointOnly block per keyframe observation of ITS map point (so a map point shared by two features brings its keyframe
+ * observations twice, as the reference's loops do).  Keyframes are constant poses 1..K, the current frame is pose 0. */
+static int current_frame_problem(const yo_camera *cam, int n, const double *px, const int32_t *feat_point, const uint8_t *skip,
+                                 const int32_t *obs_off, const int32_t *obs_kf, const double *obs_px, double huber_a,
+                                 int32_t **ep_out, int32_t **el_out, double **obs_out, double **hub_out)
+{
+    int E = 0;
+    for (int i = 0; i < n; ++i) if (!(skip && skip[i])) E += 1 + (obs_off[feat_point[i] + 1] - obs_off[feat_point[i]]);
+    const size_t Ez = (size_t)(E > 0 ? E : 1);
+    int32_t *ep = (int32_t *)malloc(4 * Ez), *el = (int32_t *)malloc(4 * Ez);
+    double *obs = (double *)malloc(16 * Ez), *hub = (double *)malloc(8 * Ez);
+    int e = 0;
+    for (int i = 0; i < n; ++i) {
+        if (skip && skip[i]) continue;
+        const int l = feat_point[i];
+        ep[e] = 0; el[e] = l; pixel2camera2d(cam, px + 2 * i, obs + 2 * e); hub[e] = huber_a; ++e;
+        for (int o = obs_off[l]; o < obs_off[l + 1]; ++o) {
+            ep[e] = 1 + obs_kf[o]; el[e] = l; pixel2camera2d(cam, obs_px + 2 * o, obs + 2 * e); hub[e] = huber_a; ++e;
+        }
+    }
+    *ep_out = ep; *el_out = el; *obs_out = obs; *hub_out = hub;
+    return E;
+}
+
+/* ba::OptimizeCurrent -- BA.cpp:91-186: the current pose and the map points of its features, every observing keyframe constant,
+ * HuberLoss(0.1) on every block; then Feature::_bad where the reprojection error^2 exceeds 4 * 5.991 (float), else _depth.
+ * feat_point [n] = map point of each feature (index into points [P][3]); keyframe observations in CSR form per map point. */
+int yo_optimize_current(const yo_camera *cam, yo_se3 *T_cur, int n, const double *px, const int32_t *feat_point, int P, double *points,
+                        int K, const yo_se3 *kf_T, const int32_t *obs_off, const int32_t *obs_kf, const double *obs_px,
+                        uint8_t *bad, double *depth, yo_ceres_summary *sum)
+{
+    const float chi2Mono = 5.991 * 4;
+    double *poses = (double *)malloc(48 * (size_t)(K + 1));
+    uint8_t *pfix = (uint8_t *)malloc((size_t)(K + 1));
+    se3_to_taa(T_cur, poses); pfix[0] = 0;
+    for (int k = 0; k < K; ++k) { se3_to_taa(&kf_T[k], poses + 6 * (k + 1)); pfix[k + 1] = 1; }
+    int32_t *ep, *el; double *obs, *hub;
+    const int E = current_frame_problem(cam, n, px, feat_point, NULL, obs_off, obs_kf, obs_px, 0.1, &ep, &el, &obs, &hub);
+    yo_ceres_problem pb; memset(&pb, 0, sizeof(pb));
+    pb.n_poses = K + 1; pb.n_points = P; pb.n_edges = E; pb.poses = poses; pb.pose_fixed = pfix; pb.points = points;
+    pb.edge_pose = ep; pb.edge_point = el; pb.obs_n = obs; pb.edge_huber = hub;
+    yo_ceres_options opt; yo_ceres_default_options(&opt);
+    if (E > 0) yo_ceres_solve(&pb, &opt, sum);
+    taa_to_se3(poses, T_cur);                                                            /* :144-146 */
+    int cntInlier = 0;
+    for (int i = 0; i < n; ++i) {                                                        /* :148-158 */
+        double p[2], z;
+        world2pixel(cam, T_cur, points + 3 * (size_t)feat_point[i], p, &z);
+        const double dx = p[0] - px[2 * i], dy = p[1] - px[2 * i + 1], error2 = dx * dx + dy * dy;
+        if (error2 > chi2Mono) bad[i] = 1;
+        else { depth[i] = z; ++cntInlier; }
+    }
+    free(poses); free(pfix); free(ep); free(el); free(obs); free(hub);
+    return cntInlier;
+}
+
+/* ba::OptimizeCurrentPointOnly -- BA.cpp:266-322: only the map points move; features that are bad or have no map point are
+ * skipped (feat_point < 0 = no map point); no loss function. */
+int yo_optimize_current_point_only(const yo_camera *cam, const yo_se3 *T_cur, int n, const double *px, const int32_t *feat_point,
+                                   const uint8_t *feat_bad, int P, double *points, int K, const yo_se3 *kf_T, const int32_t *obs_off,
+                                   const int32_t *obs_kf, const double *obs_px, yo_ceres_summary *sum)
+{
+    double *poses = (double *)malloc(48 * (size_t)(K + 1));
+    uint8_t *pfix = (uint8_t *)malloc((size_t)(K + 1)), *skip = (uint8_t *)malloc((size_t)(n > 0 ? n : 1));
+    se3_to_taa(T_cur, poses); pfix[0] = 1;
+    for (int k = 0; k < K; ++k) { se3_to_taa(&kf_T[k], poses + 6 * (k + 1)); pfix[k + 1] = 1; }
+    for (int i = 0; i < n; ++i) skip[i] = (uint8_t)((feat_bad && feat_bad[i]) || feat_point[i] < 0);    /* :272-273 */
+    int32_t *ep, *el; double *obs, *hub;
+    const int E = current_frame_problem(cam, n, px, feat_point, skip, obs_off, obs_kf, obs_px, 0.0, &ep, &el, &obs, &hub);
+    yo_ceres_problem pb; memset(&pb, 0, sizeof(pb));
+    pb.n_poses = K + 1; pb.n_points = P; pb.n_edges = E; pb.poses = poses; pb.pose_fixed = pfix; pb.points = points;
+    pb.edge_pose = ep; pb.edge_point = el; pb.obs_n = obs;
+    yo_ceres_options opt; yo_ceres_default_options(&opt);
+    int rc = 0;
+    if (E > 0) rc = yo_ceres_solve(&pb, &opt, sum);
+    free(poses); free(pfix); free(skip); free(ep); free(el); free(obs); free(hub);
+    return rc;
+}

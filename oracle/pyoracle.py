@@ -659,6 +659,47 @@ class Oracle:
                                                      C.byref(rounds))
         return pose, bad[:n], depth[:n], int(inl), rounds.value
 
+    def two_view_ba_ceres(self, T_ref, T_cur, px_ref, px_cur, inlier, pts_ref, cam=None):
+        """ba::TwoViewBACeres; returns (T_cur, inlier, pts_ref, summary dict)"""
+        cam = cam or self.camera()
+        Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
+        pr = np.ascontiguousarray(px_ref, np.float64).reshape(-1, 2); pc = np.ascontiguousarray(px_cur, np.float64).reshape(-1, 2)
+        inl = np.ascontiguousarray(inlier, np.uint8).copy(); pts = np.ascontiguousarray(pts_ref, np.float64).reshape(-1, 3).copy()
+        sm = CeresSummary()
+        self.lib.yo_two_view_ba_ceres(C.byref(cam), C.byref(Tr), C.byref(Tc), len(pr), _f64(pr), _f64(pc), _u8(inl), _f64(pts), C.byref(sm))
+        return Tc.to_array(), inl.astype(bool), pts, {k: getattr(sm, k) for k, _ in CeresSummary._fields_}
+
+    def _kf_obs(self, kf_T, obs_off, obs_kf, obs_px):
+        Ts = (SE3 * max(len(kf_T), 1))(*[SE3.from_array(t) for t in kf_T])
+        return (Ts, np.ascontiguousarray(obs_off, np.int32), np.ascontiguousarray(obs_kf, np.int32),
+                np.ascontiguousarray(obs_px, np.float64).reshape(-1, 2))
+
+    def optimize_current(self, T_cur, px, feat_point, points, kf_T, obs_off, obs_kf, obs_px, cam=None):
+        """ba::OptimizeCurrent; returns (T_cur, points, bad, depth, inliers)"""
+        cam = cam or self.camera()
+        Tc = SE3.from_array(T_cur)
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 2); fp = np.ascontiguousarray(feat_point, np.int32)
+        pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy()
+        Ts, oo, ok, op = self._kf_obs(kf_T, obs_off, obs_kf, obs_px)
+        n = len(px)
+        bad = np.zeros(max(n, 1), np.uint8); depth = np.full(max(n, 1), np.nan); sm = CeresSummary()
+        inl = self.lib.yo_optimize_current(C.byref(cam), C.byref(Tc), n, _f64(px), _p(fp, C.c_int32), len(pts), _f64(pts), len(kf_T), Ts,
+                                           _p(oo, C.c_int32), _p(ok, C.c_int32), _f64(op), _u8(bad), _f64(depth), C.byref(sm))
+        return Tc.to_array(), pts, bad[:n].astype(bool), depth[:n], int(inl)
+
+    def optimize_current_point_only(self, T_cur, px, feat_point, feat_bad, points, kf_T, obs_off, obs_kf, obs_px, cam=None):
+        """ba::OptimizeCurrentPointOnly; returns the points"""
+        cam = cam or self.camera()
+        Tc = SE3.from_array(T_cur)
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 2); fp = np.ascontiguousarray(feat_point, np.int32)
+        fb = np.ascontiguousarray(feat_bad, np.uint8)
+        pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy()
+        Ts, oo, ok, op = self._kf_obs(kf_T, obs_off, obs_kf, obs_px)
+        sm = CeresSummary()
+        self.lib.yo_optimize_current_point_only(C.byref(cam), C.byref(Tc), len(px), _f64(px), _p(fp, C.c_int32), _u8(fb), len(pts), _f64(pts),
+                                                len(kf_T), Ts, _p(oo, C.c_int32), _p(ok, C.c_int32), _f64(op), C.byref(sm))
+        return pts
+
     def ba_pose_oplus(self, pose, upd):
         pose = np.ascontiguousarray(pose, np.float64).copy()
         upd = np.ascontiguousarray(upd, np.float64)

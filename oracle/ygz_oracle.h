@@ -310,6 +310,15 @@ void yo_ceres_default_options(yo_ceres_options *o);
 int  yo_ceres_solve(yo_ceres_problem *pb, const yo_ceres_options *opt, yo_ceres_summary *sum);
 typedef struct { int iterations, lm_trials; double chi2_initial, chi2_final, lambda_final; } yo_lm_stats;
 int  yo_g2o_lm(const yo_ba_problem *pb, double *poses, double *points, int max_iterations, yo_lm_stats *stats);
+/* ba::TwoViewBACeres (BA.cpp:11-89), ba::OptimizeCurrent (:91-186), ba::OptimizeCurrentPointOnly (:266-322) on plain arrays */
+int  yo_two_view_ba_ceres(const yo_camera *cam, const yo_se3 *ref, yo_se3 *curr, int n, const double *px_ref, const double *px_curr,
+                          uint8_t *inlier, double *pts_ref, yo_ceres_summary *sum);
+int  yo_optimize_current(const yo_camera *cam, yo_se3 *T_cur, int n, const double *px, const int32_t *feat_point, int P, double *points,
+                         int K, const yo_se3 *kf_T, const int32_t *obs_off, const int32_t *obs_kf, const double *obs_px,
+                         uint8_t *bad, double *depth, yo_ceres_summary *sum);
+int  yo_optimize_current_point_only(const yo_camera *cam, const yo_se3 *T_cur, int n, const double *px, const int32_t *feat_point,
+                                    const uint8_t *feat_bad, int P, double *points, int K, const yo_se3 *kf_T, const int32_t *obs_off,
+                                    const int32_t *obs_kf, const double *obs_px, yo_ceres_summary *sum);
 int  yo_optimize_current_pose_only(const yo_camera *cam, double pose_io[6], int n, const double *px, const double *pw,
                                    uint8_t *bad_out, double *depth_out, int *rounds_run);
 

@@ -188,11 +188,16 @@ int main(int argc, char **argv)
         const double e0 = reproj_all();
         ba::OptimizeCurrentPointOnly(by_id[5]);
         const double e1 = reproj_all();
+        for (int i = 0; i < 16; ++i) fprintf(out, "ocpo_pt %.17g %.17g %.17g\n", mpv[i]->_pos_world[0], mpv[i]->_pos_world[1], mpv[i]->_pos_world[2]);
         build(frames, map_points, by_id, mpv);
+        by_id[5]->_features[2]->_pixel = by_id[5]->_features[2]->_pixel + Vector2d(40.0, -25.0);     // one gross outlier: must come back _bad
         ba::OptimizeCurrent(by_id[5]);
         const double e2 = reproj_all();
         int nbad = 0; for (Feature *fea : by_id[5]->_features) nbad += fea->_bad;
         fprintf(out, "opt_current %.17g %.17g %.17g %d\n", e0, e1, e2, nbad);
+        { double t[7]; by_id[5]->_TCW.to7(t); fprintf(out, "oc_pose %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6]); }
+        for (int i = 0; i < 16; ++i) fprintf(out, "oc_pt %.17g %.17g %.17g %d %.17g\n", mpv[i]->_pos_world[0], mpv[i]->_pos_world[1], mpv[i]->_pos_world[2],
+                                             (int)by_id[5]->_features[i]->_bad, by_id[5]->_features[i]->_depth);
         // TwoViewBACeres: keyframes 0 and 7, points 0..15, every correspondence an inlier
         build(frames, map_points, by_id, mpv);
         vector<Vector2d> px_ref, px_curr; vector<bool> inl(16, true); vector<Vector3d> pts;
@@ -202,7 +207,7 @@ int main(int argc, char **argv)
         ba::TwoViewBACeres(by_id[0]->_TCW, curr, px_ref, px_curr, inl, pts);
         double t7[7]; curr.to7(t7); int ninl = 0; for (bool b : inl) ninl += b;
         fprintf(out, "two_view %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", ninl, t7[0], t7[1], t7[2], t7[3], t7[4], t7[5], t7[6]);
-        for (int i = 0; i < 16; ++i) fprintf(out, "tv_pt %.17g %.17g %.17g\n", pts[i][0], pts[i][1], pts[i][2]);
+        for (int i = 0; i < 16; ++i) fprintf(out, "tv_pt %.17g %.17g %.17g %d\n", pts[i][0], pts[i][1], pts[i][2], (int)inl[i]);
     }
     // --- ba::OptimizeCurrentPoseOnly on a frame written by the harness: pose [t; aa], px [n][2], pw [n][3]
     {

@@ -227,3 +227,35 @@ def test_witness_ceres_solve_reaches_the_least_squares_optimum(oracle):
     scale = float(np.sum(pts_s * pt) / np.sum(pt * pt))                  # free scale, as above
     assert np.allclose(po[:, 3:], ps[:, 3:], atol=2e-5)
     assert np.allclose(ps[:, :3], scale * po[:, :3], atol=2e-5 * max(1.0, scale)) and np.allclose(pts_s, scale * pt, atol=2e-4 * max(1.0, scale))
+
+
+def test_witness_two_view_ba_lm_vs_dogleg_optimum(oracle):
+    """ba::TwoViewBACeres asks ceres for the DOGLEG trust-region strategy (BA.cpp:58-62); the restated solver (and the GPU path behind
+    it) has Levenberg-Marquardt only.  Both are descent methods on the same cost: what LM returns must be a minimum that a
+    dogleg-type solver (scipy 'dogbox') accepts -- zero gradient, no further decrease from there, and no lower cost from the same start
+    (all correspondences inliers -> no loss function)."""
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=13)
+    T = np.array([synth.se3_exp(np.concatenate([p[3:], p[:3]])) for p in f["poses"]])
+    obs8 = f["obs"].reshape(16, 8, 2)
+    Tc, inl, pts, sm = oracle.two_view_ba_ceres(T[0], T[7], obs8[:, 0], obs8[:, 7], np.ones(16, np.uint8), f["points"])
+    # the same problem for scipy: pose 0 = ref (constant), pose 1 = curr, 32 edges, [t; angle-axis] parametrisation
+    c = fixtures.ba_to_ceres(dict(poses=f["poses"][[0, 7]], fixed=np.array([1, 0], np.uint8), points=f["points"],
+                                  edge_pose=np.tile([0, 1], 16).astype(np.int32), edge_point=np.repeat(np.arange(16), 2).astype(np.int32),
+                                  obs=np.stack([obs8[:, 0], obs8[:, 7]], 1).reshape(-1, 2), true_poses=f["true_poses"][[0, 7]]))
+    free = np.array([1])
+    # (1) the LM result is a stationary point: the gradient J^T r vanishes there ...
+    x_lm = np.concatenate([Tc[4:], oracle.se3_log(Tc)[3:], pts.ravel()])
+    r_lm = _ceres_residuals(x_lm, c, free, 2)
+    assert abs(0.5 * float(r_lm @ r_lm) - sm["final_cost"]) <= 1e-9 * max(sm["final_cost"], 1e-12) + 1e-15
+    J = optimize.approx_fprime(x_lm, lambda x: 0.5 * float(np.sum(_ceres_residuals(x, c, free, 2) ** 2)), 1e-7)
+    assert np.abs(J).max() < 1e-5
+    # (2) ... and a dogleg-type trust-region solver started THERE cannot lower the cost (it is a minimum, not a saddle)
+    sol = optimize.least_squares(_ceres_residuals, x_lm, args=(c, free, 2), method="dogbox", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=200)
+    assert 0.5 * float(np.sum(sol.fun ** 2)) >= sm["final_cost"] * (1 - 1e-3) - 1e-12
+    # (3) started from the same noisy state as ceres, the dogleg solver ends no lower than LM did (64 equations for 53 effective
+    #     unknowns: both fit almost exactly; the valley is flat, so states are compared through the cost only)
+    x0 = np.concatenate([c["poses"][1], c["points"].ravel()])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sol0 = optimize.least_squares(_ceres_residuals, x0, args=(c, free, 2), method="dogbox", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=2000)
+    assert sm["final_cost"] <= sm["initial_cost"] * 1e-3 and sm["final_cost"] <= 0.5 * float(np.sum(sol0.fun ** 2)) * 1.001 + 1e-9
+    assert inl.sum() >= 14
