@@ -190,7 +190,7 @@ int main(int argc, char **argv)
         const double e1 = reproj_all();
         for (int i = 0; i < 16; ++i) fprintf(out, "ocpo_pt %.17g %.17g %.17g\n", mpv[i]->_pos_world[0], mpv[i]->_pos_world[1], mpv[i]->_pos_world[2]);
         build(frames, map_points, by_id, mpv);
-        by_id[5]->_features[2]->_pixel = by_id[5]->_features[2]->_pixel + Vector2d(40.0, -25.0);     // one gross outlier: must come back _bad
+        by_id[5]->_features[2]->_pixel = by_id[5]->_features[2]->_pixel + Vector2d(40.0, -25.0);     // a gross error on one feature (which is also MapPoint 2's observation in keyframe 5)
         ba::OptimizeCurrent(by_id[5]);
         const double e2 = reproj_all();
         int nbad = 0; for (Feature *fea : by_id[5]->_features) nbad += fea->_bad;

@@ -190,12 +190,13 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     o_pts = oracle.optimize_current_point_only(T7[5], obs8[:, 5], np.arange(16), np.zeros(16, np.uint8), f["points"], T7, obs_off, obs_kf, obs8.reshape(-1, 2))
     g_pts = np.array(r["ocpo_pt"], dtype=np.float64)
     assert np.allclose(g_pts, o_pts, rtol=1e-6, atol=1e-8)
-    px5 = obs8[:, 5].copy(); px5[2] += [40.0, -25.0]
-    o_T, o_pts2, o_bad, o_dep, o_inl = oracle.optimize_current(T7[5], px5, np.arange(16), f["points"], T7, obs_off, obs_kf, obs8.reshape(-1, 2))
+    obs8b = obs8.copy(); obs8b[2, 5] += [40.0, -25.0]        # the shifted Feature is both the current frame's feature and MapPoint 2's _obs[5]
+    px5 = obs8b[:, 5].copy()
+    o_T, o_pts2, o_bad, o_dep, o_inl = oracle.optimize_current(T7[5], px5, np.arange(16), f["points"], T7, obs_off, obs_kf, obs8b.reshape(-1, 2))
     g_T = np.array([float(x) for x in r["oc_pose"][0]])
     g_rows = np.array(r["oc_pt"], dtype=np.float64)
     assert np.allclose(g_T, o_T, rtol=1e-6, atol=1e-8) and np.allclose(g_rows[:, :3], o_pts2, rtol=1e-6, atol=1e-8)
-    assert np.array_equal(g_rows[:, 3].astype(bool), o_bad) and o_bad[2] and int(nbad) == int(o_bad.sum()) and o_inl == 16 - int(nbad)
+    assert np.array_equal(g_rows[:, 3].astype(bool), o_bad) and o_bad.any() and int(nbad) == int(o_bad.sum()) and o_inl == 16 - int(nbad)
     assert np.allclose(g_rows[~o_bad, 4], o_dep[~o_bad], rtol=1e-6)
     # TwoViewBACeres: 15 inliers + 1 flagged outlier (reset to (0,0,1), HuberLoss(0.1)); the result must explain both views
     tv = [float(x) for x in r["two_view"][0]]
