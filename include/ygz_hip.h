@@ -359,6 +359,17 @@ int  ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const int32_t *f
 int  ygz_hip_depth_from_triangulation(ygz_hip_ctx *ctx, const double T_search_ref[7], const double *f_ref, const double *f_cur,
                                       int n, double determinant_th, double *depth1, double *depth2, uint8_t *ok);
 
+/* ---- the triangulation loop of LocalMapping::CreateNewMapPoints (src/Module/LocalMapping.cpp:416-495, the branch where neither
+ *      feature has a map point yet), for n matched pairs (SearchForTriangulation's output) of keyframes in slot1 (current keyframe,
+ *      pose T1) and slot2 (neighbour, T2): parallax test, DepthFromTriangulation, Matcher::FindDirectProjection of feature 1 into
+ *      frame 2 with the triangulated depth, second triangulation with the refined pixel, reprojection test (5.991 px), map point.
+ *      px1 [n][2] / level1 [n]: Feature::_pixel / _level in frame 1; px2 [n][2] in/out: fea2->_pixel (overwritten once the direct
+ *      projection succeeded, as the reference does); code [n]: 0 map point created, 1 parallel rays, 2 / 4 first / second
+ *      triangulation rejected, 3 direct projection failed, 5 reprojection error; depth1 / depth2 / pos_world [n][3] for code 0. */
+int  ygz_hip_create_map_points(ygz_hip_ctx *ctx, int slot1, const double T1[7], int slot2, const double T2[7], int n, const double *px1,
+                               const int32_t *level1, double *px2, int32_t *code, double *depth1, double *depth2, double *pos_world,
+                               int32_t *search_level, int *n_created);
+
 /* ---- M4 / M5: BoW-guided matching -- replaces Frame::ComputeBoW (src/Basic/Frame.cpp:190-201 ->
  *      DBoW3::Vocabulary::transform, thirdparty/DBoW3/src/Vocabulary.cpp:706-835), Matcher::SearchByBoW
  *      (src/Algorithm/Matcher.cpp:196-292) and Matcher::SearchForTriangulation (:86-193, epipolar test :338-354).

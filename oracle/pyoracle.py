@@ -384,6 +384,20 @@ class Oracle:
                                      _u8(cand))
         return pw[:n], pred[:n], cand[:n].astype(bool)
 
+    def create_map_points(self, lv1, T1, lv2, T2, px1, level1, px2, cam=None):
+        """yo_create_map_points: the triangulation loop of LocalMapping::CreateNewMapPoints"""
+        cam = cam or self.camera()
+        p1s, p2s = self._pyr_struct(lv1), self._pyr_struct(lv2)
+        Ta, Tb = SE3.from_array(T1), SE3.from_array(T2)
+        p1 = np.ascontiguousarray(px1, np.float64).reshape(-1, 2); l1 = np.ascontiguousarray(level1, np.int32)
+        p2 = np.ascontiguousarray(px2, np.float64).reshape(-1, 2).copy()
+        n = len(l1)
+        code = np.zeros(max(n, 1), np.int32); d1 = np.zeros(max(n, 1)); d2 = np.zeros(max(n, 1)); pw = np.zeros((max(n, 1), 3))
+        sl = np.zeros(max(n, 1), np.int32)
+        created = self.lib.yo_create_map_points(C.byref(cam), C.byref(p1s), C.byref(Ta), C.byref(p2s), C.byref(Tb), n, _f64(p1), _p(l1, C.c_int32),
+                                                _f64(p2), _p(code, C.c_int32), _f64(d1), _f64(d2), _f64(pw), _p(sl, C.c_int32))
+        return dict(px2=p2, code=code[:n], depth1=d1[:n], depth2=d2[:n], pos_world=pw[:n], search_level=sl[:n], created=int(created))
+
     def find_direct_projection_mp(self, ref_levels, T_ref, cur_levels, T_cur, pos_world, px_ref, level_ref, px_cur, cam=None):
         cam = cam or self.camera()
         pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)

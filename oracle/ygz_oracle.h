@@ -166,6 +166,10 @@ int  yo_find_direct_projection_mp(const yo_camera *cam, const yo_pyramid *ref, c
                                   const yo_pyramid *cur, const yo_se3 *T_cur, const double pos_world[3],
                                   const double px_ref[2], int level_ref, double px_cur[2], int *search_level);
 /* LocalMapping::FindCandidates + ProjectMapPoints, LocalMapping.cpp:47-120 (candidates in caller order); see align.c */
+/* LocalMapping::CreateNewMapPoints, triangulation loop (src/Module/LocalMapping.cpp:416-495): oracle/mapping.c */
+int  yo_create_map_points(const yo_camera *cam, const yo_pyramid *pyr1, const yo_se3 *T1, const yo_pyramid *pyr2, const yo_se3 *T2, int n,
+                          const double *px1, const int32_t *level1, double *px2, int32_t *code, double *depth1, double *depth2,
+                          double *pos_world, int32_t *search_level);
 int  yo_track_candidates(const yo_camera *cam, const yo_se3 *T_ref, const yo_se3 *T_cur, const double *px_ref, const double *depth,
                          int n, int w, int h, double *pos_world, double *px_pred, uint8_t *cand);
 int  yo_track_local_map(const yo_camera *cam, const yo_pyramid *kf_pyr, const yo_se3 *kf_T, int K,

@@ -213,3 +213,44 @@ def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path):
     for cur in (3, 8):
         o = _oracle_pair(oracle, seq, cur - 1, cur, T_sa=full["records"][cur]["T_sa"])
         _check_pair(full["records"][cur], o)
+
+
+def test_create_map_points_triangulation_loop(hip_lib, oracle):
+    """the triangulation loop of LocalMapping::CreateNewMapPoints (LocalMapping.cpp:416-495) for ~900 matched pairs of two keyframes:
+    every exit of the loop is hit (parallel rays, rejected triangulations, failed direct projection, reprojection error, success);
+    codes, refined pixels and search levels bit-exact, depths and map points to 1e-12"""
+    seq = synth.Sequence(6, 640, 480, seed=9, step=0.6)
+    ctx = make_ctx(hip_lib, max_frames=2)
+    f1, f2 = 0, 5
+    for s, f in enumerate((f1, f2)):
+        ctx.upload_bgr(s, seq.frame(f))
+    ctx.build_pyramid(0, 2, from_bgr=True); ctx.detect(0, 2)
+    k1 = ctx.get_keypoints(0)
+    T1, T2 = seq.poses[f1], seq.poses[f2]
+    px1 = k1["px"]; lv1 = k1["level"]
+    z = seq.depth(f1)[px1[:, 1].astype(int), px1[:, 0].astype(int)]
+    cam = oracle.camera()
+    fx, fy, cx, cy = float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)
+    pc1 = np.stack([(px1[:, 0] - cx) * z / fx, (px1[:, 1] - cy) * z / fy, z], 1)
+    pc2 = offline.se3_act(offline.se3_mul(T2, offline.se3_inv(T1)), pc1)
+    px2 = np.stack([fx * pc2[:, 0] / pc2[:, 2] + cx, fy * pc2[:, 1] / pc2[:, 2] + cy], 1)
+    rng = np.random.default_rng(1)
+    px2 += rng.normal(0, 0.7, px2.shape)                         # what a descriptor match gives: the right corner, roughly
+    n = len(px2)
+    px2[::17] += rng.uniform(15, 40, (len(px2[::17]), 2))       # wrong matches: direct projection fails or the reprojection test does
+    px2[5::23] = px1[5::23] + rng.normal(0, 0.05, px1[5::23].shape)      # (almost) the same ray in both frames -> cos >= 0.9998 for most
+    lv = [oracle.pyramid(oracle.bgr2gray(seq.frame(f)), 3) for f in (f1, f2)]
+    o = oracle.create_map_points(lv[0], T1, lv[1], T2, px1, lv1, px2)
+    g = ctx.create_map_points(0, T1, 1, T2, px1, lv1, px2)
+    assert np.array_equal(g["code"], o["code"]) and g["created"] == o["created"]
+    assert np.array_equal(g["px2"], o["px2"]) and np.array_equal(g["search_level"], o["search_level"])
+    m = o["code"] == 0
+    assert np.allclose(g["depth1"][m], o["depth1"][m], rtol=1e-12) and np.allclose(g["depth2"][m], o["depth2"][m], rtol=1e-12)
+    assert np.allclose(g["pos_world"][m], o["pos_world"][m], rtol=1e-12, atol=1e-13)
+    hist = np.bincount(o["code"], minlength=6)
+    assert hist[0] > 0.5 * n and hist[1] > 0 and hist[3] > 0 and (hist[4] + hist[5] + hist[2]) > 0, hist
+    # the new map points are where the scene is: depth of the triangulated point vs the rendered depth
+    assert np.median(np.abs(g["depth1"][m] - z[m]) / z[m]) < 0.05
+    e = ctx.create_map_points(0, T1, 1, T2, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros((0, 2)))
+    assert e["created"] == 0 and len(e["code"]) == 0
+    ctx.close()

@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
-    "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary",
+    "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points",
 ]
 
 SUMMARY_FIELDS = 32
@@ -528,6 +528,17 @@ class HipContext:
         iters = (C.c_int * MAX_LEVELS)()
         self._chk(self.lib.ygz_hip_track_get_pose(self._ctx, pair, T, C.byref(nm), iters), "track_get_pose")
         return nm.value, np.array(list(T)), list(iters)[:self.levels]
+
+    def create_map_points(self, slot1, T1, slot2, T2, px1, level1, px2):
+        p1 = np.ascontiguousarray(px1, np.float64).reshape(-1, 2); l1 = np.ascontiguousarray(level1, np.int32)
+        p2 = np.ascontiguousarray(px2, np.float64).reshape(-1, 2).copy()
+        n = len(l1)
+        code = np.zeros(max(n, 1), np.int32); d1 = np.zeros(max(n, 1)); d2 = np.zeros(max(n, 1)); pw = np.zeros((max(n, 1), 3))
+        sl = np.zeros(max(n, 1), np.int32); nc = C.c_int(0)
+        self._chk(self.lib.ygz_hip_create_map_points(self._ctx, slot1, (C.c_double * 7)(*T1), slot2, (C.c_double * 7)(*T2), n, _p(p1, C.c_double),
+                                                     _p(l1, C.c_int32), _p(p2, C.c_double), _p(code, C.c_int32), _p(d1, C.c_double),
+                                                     _p(d2, C.c_double), _p(pw, C.c_double), _p(sl, C.c_int32), C.byref(nc)), "create_map_points")
+        return dict(px2=p2, code=code[:n], depth1=d1[:n], depth2=d2[:n], pos_world=pw[:n], search_level=sl[:n], created=nc.value)
 
     def depth_from_triangulation(self, T_search_ref, f_ref, f_cur, determinant_th=1e-5):
         T = (C.c_double * 7)(*T_search_ref)

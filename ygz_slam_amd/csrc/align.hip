@@ -32,8 +32,17 @@ __device__ __forceinline__ float cof3(const float m[9], int i, int j)
     return __fsub_rn(__fmul_rn(m[3 * i1 + j1], m[3 * i2 + j2]), __fmul_rn(m[3 * i1 + j2], m[3 * i2 + j1]));
 }
 
-// cvutils::Align2D core.  pwb: LDS, element k of this lane at pwb[k * 64].
-__device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, const uint8_t *pwb, int n_iter,
+// The neighbourhood of the start pixel is staged ONCE per candidate: STG_ROWS rows x 16 bytes of the current level image around
+// floor(u0, v0) go into the lane's LDS column (dword e of the lane at stg[e * 64]: consecutive lanes hit consecutive banks), and the
+// Gauss-Newton iterations read their 9 x 9 windows from there as long as the window stays inside (+-3 px in x, +-2 px in y; Align2D
+// converges at 0.03 px or bails out).  Before, every iteration gathered 27 dwords per lane from L2 / HBM -- 64 different cache lines
+// per load -- and the counters showed 10.7 x the algorithmic bytes (profiles/traffic.json, r01).  A window that leaves the staged
+// block falls back to the global loads, so the arithmetic and the results are unchanged.
+#define STG_ROWS 13
+#define STG_DWORDS (STG_ROWS * 4)
+
+// cvutils::Align2D core.  pwb: LDS, element k of this lane at pwb[k * 64]; stg: the lane's staging column (or nullptr).
+__device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, const uint8_t *pwb, uint32_t *stg, int n_iter,
                              double *pu, double *pv, float *chi2_out)
 {
     // gradient Hessian: J = (0.5*(I[x+1]-I[x-1]), 0.5*(I[y+1]-I[y-1]), 1); every partial sum is a
@@ -59,6 +68,22 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
     }
     float mean_diff = 0.f;
     float u = (float)*pu, v = (float)*pv;
+    bool stg_ok = false;
+    int sx0 = 0, sy0 = 0;
+    if (stg && u == u && v == v && w >= 16 && h >= STG_ROWS) {
+        const int u0 = (int)floorf(u), v0 = (int)floorf(v);
+        if (!(u0 < 4 || v0 < 4 || u0 >= w - 4 || v0 >= h - 4)) {                 // otherwise the first iteration bails out anyway
+            sx0 = min(max(u0 - 7, 0), w - 16); sy0 = min(max(v0 - 6, 0), h - STG_ROWS);
+            const uint8_t *p0 = cur + (size_t)sy0 * w + sx0;
+#pragma unroll
+            for (int r = 0; r < STG_ROWS; ++r) {
+                ygz_gptr32u q = (ygz_gptr32u)(p0 + (size_t)r * w);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) stg[(r * 4 + d) * 64] = q[d];
+            }
+            stg_ok = true;
+        }
+    }
     const float min_update_squared = (float)(0.03 * 0.03);
     float chi2 = 0.f;
     bool converged = false;
@@ -76,12 +101,23 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
         // the 9 x 9 window rows v_r-4..v_r+4, columns u_r-4..u_r+4: three aligned dword loads + v_alignbyte per row instead of
         // 18 byte gathers (a wave-wide byte gather costs the address unit as much as a dword load)
         uint32_t wl[9], wh[9], w8[9];
+        const int ox = u_r - 4 - sx0, oy = v_r - 4 - sy0;
+        if (stg_ok && ox >= 0 && ox <= 7 && oy >= 0 && oy <= STG_ROWS - 9) {       // the window lies inside the staged block
+            const uint32_t sh = (uint32_t)(ox & 3);
+            const uint32_t *sp = stg + (oy * 4 + (ox >> 2)) * 64;
 #pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(cur + (size_t)(v_r + r - 4) * w + (u_r - 4));
-            ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
-            const uint32_t sh = (uint32_t)(a & 3), d0 = q[0], d1 = q[1], d2 = q[2];
-            wl[r] = __builtin_amdgcn_alignbyte(d1, d0, sh); wh[r] = __builtin_amdgcn_alignbyte(d2, d1, sh); w8[r] = (d2 >> (8 * sh)) & 255u;
+            for (int r = 0; r < 9; ++r) {
+                const uint32_t d0 = sp[(r * 4) * 64], d1 = sp[(r * 4 + 1) * 64], d2 = sp[(r * 4 + 2) * 64];
+                wl[r] = __builtin_amdgcn_alignbyte(d1, d0, sh); wh[r] = __builtin_amdgcn_alignbyte(d2, d1, sh); w8[r] = (d2 >> (8 * sh)) & 255u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const uintptr_t a = reinterpret_cast<uintptr_t>(cur + (size_t)(v_r + r - 4) * w + (u_r - 4));
+                ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(a & 3), d0 = q[0], d1 = q[1], d2 = q[2];
+                wl[r] = __builtin_amdgcn_alignbyte(d1, d0, sh); wh[r] = __builtin_amdgcn_alignbyte(d2, d1, sh); w8[r] = (d2 >> (8 * sh)) & 255u;
+            }
         }
 #define WIN(r, c) ((c) < 8 ? YGZ_BYTE(wl[r], wh[r], (c) & 7) : (int)w8[r])
 #pragma unroll
@@ -129,7 +165,8 @@ struct FdpArgs {
 // GetWarpAffineMatrix, GetBestSearchLevel, WarpAffine into the lane's LDS column, Align2D, rescale.  px_cur in (prediction) /
 // out (refined, level-0 pixels); returns success && InFrame(px_cur, 10).
 static __device__ __forceinline__ bool fdp_core(const FdpArgs &A, int ref_slot, int cur_slot, const double *Tr7, const double *Tc7,
-                                                const double px_ref[2], double depth, int Lr, uint8_t *pwb, double px_cur[2], int *sl_out)
+                                                const double px_ref[2], double depth, int Lr, uint8_t *pwb, uint32_t *stg, double px_cur[2],
+                                                int *sl_out)
 {
     double pt_ref[3];
     pixel2camera_d(A.cam, px_ref, depth, pt_ref);
@@ -188,7 +225,7 @@ static __device__ __forceinline__ bool fdp_core(const FdpArgs &A, int ref_slot, 
     const int cw = A.w[sl], ch = A.h[sl];
     const uint8_t *cur = A.lvl[sl] + (size_t)cur_slot * cw * ch;
     double u = px_cur[0] / (double)(1 << sl), v = px_cur[1] / (double)(1 << sl);
-    const bool good = align2d_core(cur, cw, ch, pwb, 10, &u, &v, nullptr);
+    const bool good = align2d_core(cur, cw, ch, pwb, stg, 10, &u, &v, nullptr);
     const double ox = u * (double)(1 << sl), oy = v * (double)(1 << sl);
     px_cur[0] = ox; px_cur[1] = oy;
     *sl_out = sl;
@@ -200,6 +237,7 @@ static __device__ __forceinline__ bool fdp_core(const FdpArgs &A, int ref_slot, 
 __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
 {
     __shared__ uint8_t pwb_all[100 * 64];
+    __shared__ uint32_t stg_all[STG_DWORDS * 64];
     int bx, pair;
     if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
     const int ii = bx * 64 + threadIdx.x;
@@ -211,7 +249,7 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
     double px_cur[2] = { A.px_cur[2 * i], A.px_cur[2 * i + 1] };
     int sl;
     const bool ok = fdp_core(A, A.pair_t[pair], A.pair_q[pair], A.pair_T + 14 * (size_t)pair, A.pair_T + 14 * (size_t)pair + 7,
-                             px_ref, depth, A.trk_level[i], pwb_all + threadIdx.x, px_cur, &sl);
+                             px_ref, depth, A.trk_level[i], pwb_all + threadIdx.x, stg_all + threadIdx.x, px_cur, &sl);
     A.px_cur[2 * i] = px_cur[0]; A.px_cur[2 * i + 1] = px_cur[1];
     A.search_level[i] = sl;
     A.ok[i] = (uint8_t)ok;
@@ -258,6 +296,7 @@ __global__ __launch_bounds__(256) void k_lmap_project(LmapArgs A)
 __global__ __launch_bounds__(64) void k_lmap_match(LmapArgs A)
 {
     __shared__ uint8_t pwb_all[100 * 64];
+    __shared__ uint32_t stg_all[STG_DWORDS * 64];
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= A.C) return;
     const int p = A.cand_point[c], kf = A.cand_kf[c];
@@ -273,7 +312,7 @@ __global__ __launch_bounds__(64) void k_lmap_match(LmapArgs A)
     const double px_ref[2] = { A.cand_px_ref[2 * (size_t)c], A.cand_px_ref[2 * (size_t)c + 1] };
     double px_cur[2] = { A.px_proj[2 * p], A.px_proj[2 * p + 1] };
     int sl;
-    const bool ok = fdp_core(A.F, A.kf_slot[kf], A.cur_slot, Tr7, A.T_cur, px_ref, pr[2], A.cand_level[c], pwb_all + threadIdx.x, px_cur, &sl);
+    const bool ok = fdp_core(A.F, A.kf_slot[kf], A.cur_slot, Tr7, A.T_cur, px_ref, pr[2], A.cand_level[c], pwb_all + threadIdx.x, stg_all + threadIdx.x, px_cur, &sl);
     A.cand_px[2 * (size_t)c] = px_cur[0]; A.cand_px[2 * (size_t)c + 1] = px_cur[1];
     A.cand_sl[c] = sl; A.cand_ok[c] = (uint8_t)ok;
     if (ok) atomicMin(&A.match_cand[p], c);
@@ -294,13 +333,14 @@ __global__ __launch_bounds__(64) void k_align2d(const uint8_t *__restrict__ cur,
                                                 uint8_t *__restrict__ ok, float *__restrict__ chi2, int n, int n_iter)
 {
     __shared__ uint8_t pwb_all[100 * 64];
+    __shared__ uint32_t stg_all[STG_DWORDS * 64];
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     uint8_t *pwb = pwb_all + threadIdx.x;
     for (int k = 0; k < 100; ++k) pwb[k * 64] = pwb_in[(size_t)i * 100 + k];
     double u = uv[2 * i], v = uv[2 * i + 1];
     float c2 = 0.f;
-    const bool good = align2d_core(cur, w, h, pwb, n_iter, &u, &v, &c2);
+    const bool good = align2d_core(cur, w, h, pwb, stg_all + threadIdx.x, n_iter, &u, &v, &c2);
     uv[2 * i] = u; uv[2 * i + 1] = v; ok[i] = (uint8_t)good; chi2[i] = c2;
 }
 
@@ -447,31 +487,149 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
 
 }  // extern "C"
 
-// ---- cvutils::DepthFromTriangulation (include/ygz/Algorithm/CVUtils.h:18-38) for a batch of ray pairs,
-// lane = pair, Eigen's evaluation order (2x2 inverse = adjugate / det, (-inv A^T) formed before it multiplies t).
+// ---- cvutils::DepthFromTriangulation (include/ygz/Algorithm/CVUtils.h:18-38), Eigen's evaluation order (2x2 inverse =
+// adjugate / det, (-inv A^T) formed before it multiplies t).  T7 = (qx,qy,qz,qw,tx,ty,tz) of T_search_ref.
+__device__ __forceinline__ bool tri_depth_d(const double *T7, const double fr[3], const double fc[3], double det_th, double *depth1, double *depth2)
+{
+    double R[9];
+    { const double q[4] = { T7[0], T7[1], T7[2], T7[3] }; quat_to_R_d(q, R); }
+    double a0[3];
+    for (int r = 0; r < 3; ++r) a0[r] = R[3 * r] * fr[0] + R[3 * r + 1] * fr[1] + R[3 * r + 2] * fr[2];
+    const double a1[3] = { -fc[0], -fc[1], -fc[2] };
+    const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2], m01 = a0[0] * a1[0] + a0[1] * a1[1] + a0[2] * a1[2];
+    const double m10 = a1[0] * a0[0] + a1[1] * a0[1] + a1[2] * a0[2], m11 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
+    const double det = m00 * m11 - m10 * m01;
+    if (det < det_th) return false;
+    const double invdet = 1.0 / det;
+    const double i00 = -(m11 * invdet), i01 = -(-m01 * invdet), i10 = -(-m10 * invdet), i11 = -(m00 * invdet);
+    double M[6];
+    for (int c = 0; c < 3; ++c) { M[c] = i00 * a0[c] + i01 * a1[c]; M[3 + c] = i10 * a0[c] + i11 * a1[c]; }
+    *depth1 = fabs(M[0] * T7[4] + M[1] * T7[5] + M[2] * T7[6]);
+    *depth2 = fabs(M[3] * T7[4] + M[4] * T7[5] + M[5] * T7[6]);
+    return true;
+}
+
+// batch of ray pairs, lane = pair
 __global__ __launch_bounds__(256) void k_depth_from_triangulation(const double *__restrict__ T /*q(4) t(3)*/, const double *__restrict__ f_ref,
                                                                   const double *__restrict__ f_cur, int n, double det_th,
                                                                   double *__restrict__ depth1, double *__restrict__ depth2, uint8_t *__restrict__ ok)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double R[9];
-    { const double q[4] = { T[0], T[1], T[2], T[3] }; quat_to_R_d(q, R); }
     const double fr[3] = { f_ref[3 * (size_t)i], f_ref[3 * (size_t)i + 1], f_ref[3 * (size_t)i + 2] };
-    double a0[3];
-    for (int r = 0; r < 3; ++r) a0[r] = R[3 * r] * fr[0] + R[3 * r + 1] * fr[1] + R[3 * r + 2] * fr[2];
-    const double a1[3] = { -f_cur[3 * (size_t)i], -f_cur[3 * (size_t)i + 1], -f_cur[3 * (size_t)i + 2] };
-    const double m00 = a0[0] * a0[0] + a0[1] * a0[1] + a0[2] * a0[2], m01 = a0[0] * a1[0] + a0[1] * a1[1] + a0[2] * a1[2];
-    const double m10 = a1[0] * a0[0] + a1[1] * a0[1] + a1[2] * a0[2], m11 = a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2];
-    const double det = m00 * m11 - m10 * m01;
-    if (det < det_th) { ok[i] = 0; return; }
-    const double invdet = 1.0 / det;
-    const double i00 = -(m11 * invdet), i01 = -(-m01 * invdet), i10 = -(-m10 * invdet), i11 = -(m00 * invdet);
-    double M[6];
-    for (int c = 0; c < 3; ++c) { M[c] = i00 * a0[c] + i01 * a1[c]; M[3 + c] = i10 * a0[c] + i11 * a1[c]; }
-    depth1[i] = fabs(M[0] * T[4] + M[1] * T[5] + M[2] * T[6]);
-    depth2[i] = fabs(M[3] * T[4] + M[4] * T[5] + M[5] * T[6]);
-    ok[i] = 1;
+    const double fc[3] = { f_cur[3 * (size_t)i], f_cur[3 * (size_t)i + 1], f_cur[3 * (size_t)i + 2] };
+    double d1, d2;
+    if (!tri_depth_d(T, fr, fc, det_th, &d1, &d2)) { ok[i] = 0; return; }
+    depth1[i] = d1; depth2[i] = d2; ok[i] = 1;
+}
+
+// ---- the triangulation loop of LocalMapping::CreateNewMapPoints (src/Module/LocalMapping.cpp:416-495, first branch: neither feature has
+// a map point), lane = matched feature pair of (frame 1 = current keyframe, frame 2 = neighbour): parallax test, DepthFromTriangulation,
+// FindDirectProjection of feature 1 into frame 2 with that depth (the Feature overload: fdp_core), second triangulation with the
+// refined pixel, reprojection test, map point.  The reference's loop is sequential only because it appends to lists; the pairs are
+// independent.
+struct CmpArgs {
+    FdpArgs F;
+    int slot1, slot2, n;
+    const double *T;                 // T1 (7), T2 (7), T12.inverse() (7), T1.inverse() (7)
+    const double *px1; const int32_t *level1; double *px2;
+    int32_t *code; double *depth1, *depth2, *pos_world; int32_t *search_level;
+};
+__global__ __launch_bounds__(64) void k_create_map_points(CmpArgs A)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    __shared__ uint32_t stg_all[STG_DWORDS * 64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.n) return;
+    const double *T1 = A.T, *T2 = A.T + 7, *T21 = A.T + 14, *T1i = A.T + 21;
+    const double p1[2] = { A.px1[2 * (size_t)i], A.px1[2 * (size_t)i + 1] };
+    double p2[2] = { A.px2[2 * (size_t)i], A.px2[2 * (size_t)i + 1] };
+    double pt1[3], pt2[3], d1 = 0, d2 = 0;
+    pixel2camera_d(A.F.cam, p1, 1.0, pt1); pixel2camera_d(A.F.cam, p2, 1.0, pt2);
+    int code = 0, sl = 0;
+    do {
+        const double dot = pt1[0] * pt2[0] + pt1[1] * pt2[1] + pt1[2] * pt2[2];
+        const double n1 = sqrt(pt1[0] * pt1[0] + pt1[1] * pt1[1] + pt1[2] * pt1[2]), n2 = sqrt(pt2[0] * pt2[0] + pt2[1] * pt2[1] + pt2[2] * pt2[2]);
+        if (dot / (n1 * n2) >= 0.9998) { code = 1; break; }                       // :433-435
+        if (!tri_depth_d(T21, pt1, pt2, 1e-5, &d1, &d2) || d1 < 0 || d2 < 0) { code = 2; break; }
+        const bool ok = fdp_core(A.F, A.slot1, A.slot2, T1, T2, p1, d1, A.level1[i], pwb_all + threadIdx.x, stg_all + threadIdx.x, p2, &sl);
+        if (!ok) { code = 3; break; }
+        A.px2[2 * (size_t)i] = p2[0]; A.px2[2 * (size_t)i + 1] = p2[1];           // fea2->_pixel = px_curr (:453)
+        pixel2camera_d(A.F.cam, p2, 1.0, pt2);
+        if (!tri_depth_d(T21, pt1, pt2, 1e-5, &d1, &d2) || d1 < 0 || d2 < 0) { code = 4; break; }
+        const double ptt[3] = { pt1[0] * d1, pt1[1] * d1, pt1[2] * d1 };
+        Se3 S;
+        for (int k = 0; k < 4; ++k) S.q[k] = T21[k];
+        for (int k = 0; k < 3; ++k) S.t[k] = T21[4 + k];
+        double pc[3], pr[2];
+        se3_act_d(&S, ptt, pc);
+        camera2pixel_d(A.F.cam, pc, pr);
+        const double rx = pr[0] - p2[0], ry = pr[1] - p2[1];
+        if (sqrt(rx * rx + ry * ry) > 5.991) { code = 5; break; }                  // :460-466
+        for (int k = 0; k < 4; ++k) S.q[k] = T1i[k];
+        for (int k = 0; k < 3; ++k) S.t[k] = T1i[4 + k];
+        double pw[3];
+        se3_act_d(&S, ptt, pw);                                                    // Camera2World(pt1 * depth1, _current_kf->_TCW) (:478)
+        A.depth1[i] = d1; A.depth2[i] = d2;
+        A.pos_world[3 * (size_t)i] = pw[0]; A.pos_world[3 * (size_t)i + 1] = pw[1]; A.pos_world[3 * (size_t)i + 2] = pw[2];
+    } while (0);
+    A.code[i] = code; A.search_level[i] = sl;
+}
+
+extern "C" int ygz_hip_create_map_points(ygz_hip_ctx *ctx, int slot1, const double T1[7], int slot2, const double T2[7], int n, const double *px1,
+                                         const int32_t *level1, double *px2, int32_t *code, double *depth1, double *depth2, double *pos_world,
+                                         int32_t *search_level, int *n_created)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || !T1 || !T2 || n < 0 || slot1 < 0 || slot1 >= ctx->prm.max_frames || slot2 < 0 || slot2 >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (n_created) *n_created = 0;
+    if (n == 0) return YGZ_OK;
+    if (!px1 || !level1 || !px2 || !code || !depth1 || !depth2 || !pos_world || !search_level) return YGZ_E_INVALID;
+    if (!ctx->pyr_valid[slot1] || !ctx->pyr_valid[slot2]) return YGZ_E_STATE;
+    for (int i = 0; i < n; ++i) if (level1[i] < 0 || level1[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
+    const size_t N = (size_t)n;
+    double hT[28];
+    {   // T12 = T1 * T2^-1 (LocalMapping.cpp:402); DepthFromTriangulation and the reprojection take T12.inverse(); the map point T1^-1
+        Se3 a, b, bi, t12, t21, ai;
+        for (int k = 0; k < 4; ++k) { a.q[k] = T1[k]; b.q[k] = T2[k]; }
+        for (int k = 0; k < 3; ++k) { a.t[k] = T1[4 + k]; b.t[k] = T2[4 + k]; }
+        se3_inv_d(&b, &bi); se3_mul_d(&a, &bi, &t12); se3_inv_d(&t12, &t21); se3_inv_d(&a, &ai);
+        for (int k = 0; k < 7; ++k) { hT[k] = T1[k]; hT[7 + k] = T2[k]; }
+        for (int k = 0; k < 4; ++k) { hT[14 + k] = t21.q[k]; hT[21 + k] = ai.q[k]; }
+        for (int k = 0; k < 3; ++k) { hT[18 + k] = t21.t[k]; hT[25 + k] = ai.t[k]; }
+    }
+    uint8_t *buf = nullptr;
+    const size_t o_px1 = 256, o_px2 = o_px1 + N * 16, o_d1 = o_px2 + N * 16, o_d2 = o_d1 + N * 8, o_pw = o_d2 + N * 8, o_lv = o_pw + N * 24,
+                 o_code = o_lv + N * 4, o_sl = o_code + N * 4, total = o_sl + N * 4 + 64;
+    int rc = ygz_scratch(ctx, SCR_GEN_0, total, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf, hT, sizeof(hT), hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf + o_px1, px1, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf + o_px2, px2, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf + o_lv, level1, N * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(buf + o_d1, 0, N * 40, ctx->stream));
+    CmpArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
+    A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 1;
+    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;
+    A.F.px_cur = nullptr; A.F.search_level = nullptr; A.F.ok = nullptr;
+    A.slot1 = slot1; A.slot2 = slot2; A.n = n; A.T = (const double *)buf;
+    A.px1 = (const double *)(buf + o_px1); A.level1 = (const int32_t *)(buf + o_lv); A.px2 = (double *)(buf + o_px2);
+    A.code = (int32_t *)(buf + o_code); A.depth1 = (double *)(buf + o_d1); A.depth2 = (double *)(buf + o_d2); A.pos_world = (double *)(buf + o_pw);
+    A.search_level = (int32_t *)(buf + o_sl);
+    YGZ_LAUNCH(ctx, KID_DEPTH_TRI, k_create_map_points, dim3(ygz_div_up(n, 64)), dim3(64), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(px2, buf + o_px2, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(code, buf + o_code, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(depth1, buf + o_d1, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(depth2, buf + o_d2, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(pos_world, buf + o_pw, N * 24, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(search_level, buf + o_sl, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_created) { int c = 0; for (int i = 0; i < n; ++i) c += code[i] == 0; *n_created = c; }
+    return YGZ_OK;
 }
 
 extern "C" int ygz_hip_depth_from_triangulation(ygz_hip_ctx *ctx, const double T_search_ref[7], const double *f_ref, const double *f_cur, int n,

@@ -289,6 +289,8 @@ __device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((dou
 // (every image buffer is allocated with 64 bytes of slack).
 typedef const __attribute__((address_space(1))) uint32_t *ygz_gptr32;
 typedef uint16_t __attribute__((aligned(1))) ygz_u16u;          // 2 adjacent bytes at any address: one (unaligned) global_load_ushort
+typedef uint32_t __attribute__((aligned(1))) ygz_u32u;          // 4 adjacent bytes at any address: one (unaligned) global_load_dword
+typedef const __attribute__((address_space(1))) ygz_u32u *ygz_gptr32u;
 __device__ __forceinline__ void ygz_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
 {
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
