@@ -370,6 +370,20 @@ int  ygz_hip_create_map_points(ygz_hip_ctx *ctx, int slot1, const double T1[7], 
                                const int32_t *level1, double *px2, int32_t *code, double *depth1, double *depth2, double *pos_world,
                                int32_t *search_level, int *n_created);
 
+/* ---- the depth filter of the legacy tree: DepthFilter::UpdateSeeds / UpdateSeed / ComputeTau (src/optimizer.cpp:537-735) with
+ *      utils::FindEpipolarMatchDirect (src/utils.cpp:330-661: epipolar ZMSSD search + the legacy Align2D + DepthFromTriangulation),
+ *      for n seeds against ONE new frame (cur_slot, T_cur).  Seed i belongs to reference frame seed_ref[i] (ref_slot / T_refs
+ *      [n_refs]) whose id for the age test is seed_frame_id[i]; kp [n][2] = cv::KeyPoint::pt, octave [n]; a, b, mu, sigma2 [n] are
+ *      updated in place (Seed's Beta / Gaussian parameters, float), z_range [n].  state [n]: 0 updated and kept; 1 behind the camera,
+ *      2 outside the frame, 3 no epipolar match (kept unchanged); 4 erased, older than max_n_kfs (5); 5 erased, converged
+ *      (sqrt(sigma2) < z_range / convergence_sigma2_thresh (100)): pos_world [n][3] = the new map point; 6 erased, NaN.
+ *      z [n] = matched depth, matched_px [n][2].  Needs >= 3 pyramid levels. */
+int  ygz_hip_depth_filter_update(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], int n_refs, const int32_t *ref_slot,
+                                 const double *T_refs, int batch_counter, int max_n_kfs, double convergence_sigma2_thresh, int n,
+                                 const float *kp, const int32_t *octave, const int32_t *seed_ref, const uint64_t *seed_frame_id,
+                                 float *a, float *b, float *mu, const float *z_range, float *sigma2, int32_t *state, double *z,
+                                 double *matched_px, double *pos_world, int *n_updated);
+
 /* ---- M4 / M5: BoW-guided matching -- replaces Frame::ComputeBoW (src/Basic/Frame.cpp:190-201 ->
  *      DBoW3::Vocabulary::transform, thirdparty/DBoW3/src/Vocabulary.cpp:706-835), Matcher::SearchByBoW
  *      (src/Algorithm/Matcher.cpp:196-292) and Matcher::SearchForTriangulation (:86-193, epipolar test :338-354).

@@ -384,6 +384,24 @@ class Oracle:
                                      _u8(cand))
         return pw[:n], pred[:n], cand[:n].astype(bool)
 
+    def depth_filter_update(self, cur_levels, T_cur, ref_levels_list, T_refs, seeds, batch_counter, max_n_kfs=5, conv_thresh=100.0, cam=None):
+        """yo_depth_filter_update: legacy DepthFilter::UpdateSeeds for the seeds (dict as in _lib.HipContext.depth_filter_update)"""
+        cam = cam or self.camera()
+        R = len(ref_levels_list)
+        pyrs = (Pyramid * max(R, 1))(*[self._pyr_struct(l) for l in ref_levels_list])
+        Ts = (SE3 * max(R, 1))(*[SE3.from_array(t) for t in T_refs])
+        pc, Tc = self._pyr_struct(cur_levels), SE3.from_array(T_cur)
+        kp = np.ascontiguousarray(seeds["kp"], np.float32).reshape(-1, 2); n = len(kp)
+        oc = np.ascontiguousarray(seeds["octave"], np.int32); sr = np.ascontiguousarray(seeds["ref"], np.int32)
+        fid = np.ascontiguousarray(seeds["frame_id"], np.uint64)
+        f = {k: np.ascontiguousarray(seeds[k], np.float32).copy() for k in ("a", "b", "mu", "z_range", "sigma2")}
+        st = np.zeros(max(n, 1), np.int32); z = np.zeros(max(n, 1)); mp = np.zeros((max(n, 1), 2)); pw = np.zeros((max(n, 1), 3))
+        fp = lambda k: _p(f[k], C.c_float)
+        nu = self.lib.yo_depth_filter_update(C.byref(cam), pyrs, Ts, _p(sr, C.c_int32), _p(fid, C.c_uint64), int(batch_counter), int(max_n_kfs),
+                                             C.c_double(conv_thresh), C.byref(pc), C.byref(Tc), n, _p(kp, C.c_float), _p(oc, C.c_int32),
+                                             fp("a"), fp("b"), fp("mu"), fp("z_range"), fp("sigma2"), _p(st, C.c_int32), _f64(z), _f64(mp), _f64(pw))
+        return dict(a=f["a"], b=f["b"], mu=f["mu"], sigma2=f["sigma2"], state=st[:n], z=z[:n], matched_px=mp[:n], pos_world=pw[:n], updated=int(nu))
+
     def create_map_points(self, lv1, T1, lv2, T2, px1, level1, px2, cam=None):
         """yo_create_map_points: the triangulation loop of LocalMapping::CreateNewMapPoints"""
         cam = cam or self.camera()

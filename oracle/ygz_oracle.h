@@ -170,6 +170,12 @@ int  yo_find_direct_projection_mp(const yo_camera *cam, const yo_pyramid *ref, c
 int  yo_create_map_points(const yo_camera *cam, const yo_pyramid *pyr1, const yo_se3 *T1, const yo_pyramid *pyr2, const yo_se3 *T2, int n,
                           const double *px1, const int32_t *level1, double *px2, int32_t *code, double *depth1, double *depth2,
                           double *pos_world, int32_t *search_level);
+/* legacy DepthFilter::UpdateSeeds (src/optimizer.cpp:537-735) + utils::FindEpipolarMatchDirect (src/utils.cpp:330-661): oracle/mapping.c */
+int  yo_depth_filter_update(const yo_camera *cam, const yo_pyramid *refs, const yo_se3 *T_refs, const int32_t *frame_idx,
+                            const uint64_t *frame_id, int batch_counter, int max_n_kfs, double convergence_sigma2_thresh,
+                            const yo_pyramid *cur, const yo_se3 *T_cur, int n, const float *kp, const int32_t *octave,
+                            float *a, float *b, float *mu, const float *z_range, float *sigma2,
+                            int32_t *state, double *z_out, double *matched_px, double *pos_world);
 int  yo_track_candidates(const yo_camera *cam, const yo_se3 *T_ref, const yo_se3 *T_cur, const double *px_ref, const double *depth,
                          int n, int w, int h, double *pos_world, double *px_pred, uint8_t *cand);
 int  yo_track_local_map(const yo_camera *cam, const yo_pyramid *kf_pyr, const yo_se3 *kf_T, int K,

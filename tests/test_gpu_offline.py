@@ -254,3 +254,56 @@ def test_create_map_points_triangulation_loop(hip_lib, oracle):
     e = ctx.create_map_points(0, T1, 1, T2, np.zeros((0, 2)), np.zeros(0, np.int32), np.zeros((0, 2)))
     assert e["created"] == 0 and len(e["code"]) == 0
     ctx.close()
+
+
+def test_depth_filter_update_seeds(hip_lib, oracle):
+    """the legacy SVO depth filter (DepthFilter::UpdateSeeds + FindEpipolarMatchDirect, src/optimizer.cpp:537-735, src/utils.cpp:330-661):
+    seeds of one keyframe updated by four later frames.  Every update runs on identical inputs on both sides (the oracle's carried
+    seed list): states, matched pixels and depths are equal (integer ZMSSD search and float Align2D chains are reproduced exactly); the
+    Bayesian parameters agree to 1e-5 relative (expf / acos differ in the last ulp between libm and the device -- which is also why
+    the carried state is the oracle's: one ulp in mu moves the next frame's search interval)."""
+    seq = synth.Sequence(6, 640, 480, seed=4, step=0.45)
+    ctx = make_ctx(hip_lib, max_frames=6)
+    for s in range(6):
+        ctx.upload_bgr(s, seq.frame(s))
+    ctx.build_pyramid(0, 6, from_bgr=True); ctx.detect(0, 1)
+    k0 = ctx.get_keypoints(0)
+    lv = [oracle.pyramid(oracle.bgr2gray(seq.frame(f)), 3) for f in range(6)]
+    n = len(k0["level"])
+    zt = seq.depth(0)[k0["px"][:, 1].astype(int), k0["px"][:, 0].astype(int)]
+    rng = np.random.default_rng(2)
+    depth_mean, depth_min = float(zt.mean()), float(zt.min()) * 0.6
+    mu0 = (1.0 / (zt * rng.uniform(0.75, 1.3, n))).astype(np.float32)            # Seed::Seed uses 1 / depth_mean; spread it so that long and short
+    z_range = np.full(n, 1.0 / depth_min, np.float32)                             # epipolar segments both occur
+    seeds = dict(kp=k0["px"].astype(np.float32), octave=k0["level"], ref=np.zeros(n, np.int32), frame_id=np.zeros(n, np.uint64),
+                 a=np.full(n, 10, np.float32), b=np.full(n, 10, np.float32), mu=mu0, z_range=z_range, sigma2=(z_range * z_range / 36).astype(np.float32))
+    seeds["frame_id"][::97] = 9                                                   # seeds of a frame "from the future": int - unsigned wraps -> erased as too old
+    og = dict(seeds)
+    seen = set()
+    total_conv = 0
+    err0 = np.abs(1.0 / og["mu"] - zt)
+    for f in (1, 2, 3, 5):
+        o = oracle.depth_filter_update(lv[f], seq.poses[f], [lv[0]], [seq.poses[0]], og, batch_counter=1)
+        g = ctx.depth_filter_update(f, seq.poses[f], [0], [seq.poses[0]], og, batch_counter=1)
+        assert np.array_equal(g["state"], o["state"]), np.nonzero(g["state"] != o["state"])
+        assert g["updated"] == o["updated"]
+        assert np.array_equal(g["matched_px"], o["matched_px"]) and np.allclose(g["z"], o["z"], rtol=1e-12)
+        assert np.allclose(g["mu"], o["mu"], rtol=1e-5, atol=1e-9)
+        for k in ("a", "b", "sigma2"):                   # differences of nearly equal float terms (sigma2 = E[x^2] - mu^2; a, b from (e - f) / (f - e / f)):
+            assert np.allclose(g[k], o[k], rtol=2e-4, atol=1e-9), k      # one ulp of expf is amplified ~10-100 x
+        m = o["state"] == 5
+        assert np.allclose(g["pos_world"][m], o["pos_world"][m], rtol=1e-6)
+        seen |= set(np.unique(o["state"]).tolist())
+        total_conv += int(m.sum())
+        keep = np.isin(o["state"], (0, 1, 2, 3))                                  # erased seeds leave the list
+        for k in ("a", "b", "mu", "sigma2"):
+            og[k] = o[k][keep]
+        for k in ("kp", "octave", "ref", "frame_id", "z_range"):
+            og[k] = og[k][keep]
+        zt, err0 = zt[keep], err0[keep]
+    assert {0, 3, 4}.issubset(seen), seen
+    # the filter does its job: after four frames the depth of the surviving seeds is closer to the rendered depth than the prior was
+    assert np.median(np.abs(1.0 / og["mu"] - zt)) < 0.5 * np.median(err0)
+    e = ctx.depth_filter_update(1, seq.poses[1], [0], [seq.poses[0]], {k: v[:0] for k, v in og.items()}, batch_counter=1)
+    assert e["updated"] == 0
+    ctx.close()

@@ -96,7 +96,7 @@ ABI_SYMBOLS = [
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
-    "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points",
+    "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
 ]
 
 SUMMARY_FIELDS = 32
@@ -528,6 +528,23 @@ class HipContext:
         iters = (C.c_int * MAX_LEVELS)()
         self._chk(self.lib.ygz_hip_track_get_pose(self._ctx, pair, T, C.byref(nm), iters), "track_get_pose")
         return nm.value, np.array(list(T)), list(iters)[:self.levels]
+
+    def depth_filter_update(self, cur_slot, T_cur, ref_slot, T_refs, seeds, batch_counter, max_n_kfs=5, conv_thresh=100.0):
+        """seeds: dict of kp [n,2] f32, octave, ref (index into ref_slot), frame_id (u64), a, b, mu, z_range, sigma2 (f32); a/b/mu/sigma2 come
+        back updated (copies) together with state, z, matched_px, pos_world"""
+        rs = np.ascontiguousarray(ref_slot, np.int32); Tr = np.ascontiguousarray(T_refs, np.float64).reshape(-1, 7)
+        kp = np.ascontiguousarray(seeds["kp"], np.float32).reshape(-1, 2); n = len(kp)
+        oc = np.ascontiguousarray(seeds["octave"], np.int32); sr = np.ascontiguousarray(seeds["ref"], np.int32)
+        fid = np.ascontiguousarray(seeds["frame_id"], np.uint64)
+        f = {k: np.ascontiguousarray(seeds[k], np.float32).copy() for k in ("a", "b", "mu", "z_range", "sigma2")}
+        st = np.zeros(max(n, 1), np.int32); z = np.zeros(max(n, 1)); mp = np.zeros((max(n, 1), 2)); pw = np.zeros((max(n, 1), 3)); nu = C.c_int(0)
+        fp = lambda k: _p(f[k], C.c_float)
+        self._chk(self.lib.ygz_hip_depth_filter_update(self._ctx, cur_slot, (C.c_double * 7)(*T_cur), len(rs), _p(rs, C.c_int32), _p(Tr, C.c_double),
+                                                       int(batch_counter), int(max_n_kfs), C.c_double(conv_thresh), n, _p(kp, C.c_float), _p(oc, C.c_int32),
+                                                       _p(sr, C.c_int32), _p(fid, C.c_uint64), fp("a"), fp("b"), fp("mu"), fp("z_range"), fp("sigma2"),
+                                                       _p(st, C.c_int32), _p(z, C.c_double), _p(mp, C.c_double), _p(pw, C.c_double), C.byref(nu)),
+                  "depth_filter_update")
+        return dict(a=f["a"], b=f["b"], mu=f["mu"], sigma2=f["sigma2"], state=st[:n], z=z[:n], matched_px=mp[:n], pos_world=pw[:n], updated=nu.value)
 
     def create_map_points(self, slot1, T1, slot2, T2, px1, level1, px2):
         p1 = np.ascontiguousarray(px1, np.float64).reshape(-1, 2); l1 = np.ascontiguousarray(level1, np.int32)

@@ -149,6 +149,33 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
     return converged && chi2 < 20000.f;
 }
 
+// Matcher::WarpAffine (Matcher.cpp:438-466; the legacy utils::WarpAffine, src/utils.cpp:66-98, is the same code) with half_patch_size 5:
+// the 10 x 10 affine-warped reference patch into the lane's LDS column, bilinear samples truncated to uchar (GetBilateralInterpUchar)
+static __device__ __forceinline__ void warp_affine_lds(const double Am[4], const uint8_t *img, int rw, int rh, const double px_ref[2], int Lr, int sl,
+                                                       uint8_t *pwb)
+{
+    const double det = Am[0] * Am[3] - Am[2] * Am[1];
+    const double invdet = 1.0 / det;
+    const double R0 = Am[3] * invdet, R1 = -Am[1] * invdet, R2 = -Am[2] * invdet, R3 = Am[0] * invdet;
+    const double rx = px_ref[0] / (double)(1 << Lr), ry = px_ref[1] / (double)(1 << Lr);
+    for (int y = 0; y < 10; ++y)
+        for (int x = 0; x < 10; ++x) {
+            double ppx = (double)(x - 5), ppy = (double)(y - 5);
+            ppx *= (double)(1 << sl); ppy *= (double)(1 << sl);
+            const double qx = (R0 * ppx + R1 * ppy) + rx, qy = (R2 * ppx + R3 * ppy) + ry;
+            uint8_t val = 0;
+            if (!(qx < 0 || qy < 0 || qx >= rw - 1 || qy >= rh - 1)) {
+                // cvutils::GetBilateralInterpUchar (CVUtils.h:59-71)
+                const double xx = qx - floor(qx), yy = qy - floor(qy);
+                const uint8_t *d = img + (size_t)((int)qy) * rw + (int)qx;
+                const uint32_t top = *reinterpret_cast<const ygz_u16u *>(d), bot = *reinterpret_cast<const ygz_u16u *>(d + rw);   // 2 gathers, not 4
+                const int d00 = (int)(top & 255u), d01 = (int)(top >> 8), d10 = (int)(bot & 255u), d11 = (int)(bot >> 8);
+                val = (uint8_t)((1 - xx) * (1 - yy) * d00 + xx * (1 - yy) * d01 + (1 - xx) * yy * d10 + xx * yy * d11);
+            }
+            pwb[(y * 10 + x) * 64] = val;
+        }
+}
+
 struct FdpArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
@@ -198,30 +225,7 @@ static __device__ __forceinline__ bool fdp_core(const FdpArgs &A, int ref_slot, 
         while (D > 3.0 && sl < A.n_levels - 1) { sl += 1; D *= 0.25; }
     }
     // WarpAffine (Matcher.cpp:438-466), half_patch_size 5
-    {
-        const int rw = A.w[Lr], rh = A.h[Lr];
-        const uint8_t *img = A.lvl[Lr] + (size_t)ref_slot * rw * rh;
-        const double det = Am[0] * Am[3] - Am[2] * Am[1];
-        const double invdet = 1.0 / det;
-        const double R0 = Am[3] * invdet, R1 = -Am[1] * invdet, R2 = -Am[2] * invdet, R3 = Am[0] * invdet;
-        const double rx = px_ref[0] / (double)(1 << Lr), ry = px_ref[1] / (double)(1 << Lr);
-        for (int y = 0; y < 10; ++y)
-            for (int x = 0; x < 10; ++x) {
-                double ppx = (double)(x - 5), ppy = (double)(y - 5);
-                ppx *= (double)(1 << sl); ppy *= (double)(1 << sl);
-                const double qx = (R0 * ppx + R1 * ppy) + rx, qy = (R2 * ppx + R3 * ppy) + ry;
-                uint8_t val = 0;
-                if (!(qx < 0 || qy < 0 || qx >= rw - 1 || qy >= rh - 1)) {
-                    // cvutils::GetBilateralInterpUchar (CVUtils.h:59-71)
-                    const double xx = qx - floor(qx), yy = qy - floor(qy);
-                    const uint8_t *d = img + (size_t)((int)qy) * rw + (int)qx;
-                    const uint32_t top = *reinterpret_cast<const ygz_u16u *>(d), bot = *reinterpret_cast<const ygz_u16u *>(d + rw);   // 2 gathers, not 4
-                    const int d00 = (int)(top & 255u), d01 = (int)(top >> 8), d10 = (int)(bot & 255u), d11 = (int)(bot >> 8);
-                    val = (uint8_t)((1 - xx) * (1 - yy) * d00 + xx * (1 - yy) * d01 + (1 - xx) * yy * d10 + xx * yy * d11);
-                }
-                pwb[(y * 10 + x) * 64] = val;
-            }
-    }
+    warp_affine_lds(Am, A.lvl[Lr] + (size_t)ref_slot * A.w[Lr] * A.h[Lr], A.w[Lr], A.h[Lr], px_ref, Lr, sl, pwb);
     const int cw = A.w[sl], ch = A.h[sl];
     const uint8_t *cur = A.lvl[sl] + (size_t)cur_slot * cw * ch;
     double u = px_cur[0] / (double)(1 << sl), v = px_cur[1] / (double)(1 << sl);
@@ -654,5 +658,361 @@ extern "C" int ygz_hip_depth_from_triangulation(ygz_hip_ctx *ctx, const double T
     YGZ_HIPCHK(ctx, hipMemcpyAsync(depth2, d_d2, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, d_ok, N, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+// =====================================================================================================================================
+// the SVO depth filter of the legacy tree -- DepthFilter::UpdateSeeds / UpdateSeed / ComputeTau (src/optimizer.cpp:537-735)
+// with utils::FindEpipolarMatchDirect, utils::GetWarpAffineMatrix, ZMSSD<4> and the legacy utils::Align2D (src/utils.cpp:37-98,102-281,
+// 330-661; include/ygz/utils.h:185-196,288-465).  lane = seed: the seeds of one new frame are independent (the reference walks a
+// std::list only to erase from it).  What the legacy tree takes from headers that no longer exist (Frame::InFrame, PinholeCamera::focal)
+// comes from their live successors, and the two undefined spots (ZMSSD patches outside a level image, matched_px on paths that never
+// assign it) are defined as in oracle/mapping.c -- the kernel follows that restatement decision by decision.
+
+// legacy utils::Align2D (src/utils.cpp:102-281, convergence_condition = false): same float chains as cvutils::Align2D, other stop rules
+// (update^2 < 0.001, stop when chi2 grows, accept below 15000)
+static __device__ bool align2d_legacy_core(const uint8_t *__restrict__ cur, int w, int h, const uint8_t *pwb, int n_iter, double *pu, double *pv)
+{
+    float H[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) {
+            const int k = (y + 1) * 10 + (x + 1);
+            const float jx = 0.5f * (float)((int)pwb[(k + 1) * 64] - (int)pwb[(k - 1) * 64]);
+            const float jy = 0.5f * (float)((int)pwb[(k + 10) * 64] - (int)pwb[(k - 10) * 64]);
+            H[0] = __fadd_rn(H[0], __fmul_rn(jx, jx)); H[1] = __fadd_rn(H[1], __fmul_rn(jx, jy)); H[2] = __fadd_rn(H[2], jx);
+            H[4] = __fadd_rn(H[4], __fmul_rn(jy, jy)); H[5] = __fadd_rn(H[5], jy); H[8] = __fadd_rn(H[8], 1.0f);
+        }
+    H[3] = H[1]; H[6] = H[2]; H[7] = H[5];
+    float Hinv[9];
+    {
+        const float c0 = cof3(H, 0, 0), c1 = cof3(H, 1, 0), c2 = cof3(H, 2, 0);
+        const float det = __fadd_rn(__fadd_rn(__fmul_rn(c0, H[0]), __fmul_rn(c1, H[3])), __fmul_rn(c2, H[6]));
+        const float invdet = __fdiv_rn(1.0f, det);
+        Hinv[0] = __fmul_rn(c0, invdet); Hinv[1] = __fmul_rn(c1, invdet); Hinv[2] = __fmul_rn(c2, invdet);
+        Hinv[3] = __fmul_rn(cof3(H, 0, 1), invdet); Hinv[4] = __fmul_rn(cof3(H, 1, 1), invdet); Hinv[5] = __fmul_rn(cof3(H, 2, 1), invdet);
+        Hinv[6] = __fmul_rn(cof3(H, 0, 2), invdet); Hinv[7] = __fmul_rn(cof3(H, 1, 2), invdet); Hinv[8] = __fmul_rn(cof3(H, 2, 2), invdet);
+    }
+    double first_u = *pu, first_v = *pv;
+    float mean_diff = 0.f, u = (float)*pu, v = (float)*pv, last_chi2 = 0.f;
+    const float min_update_squared = 0.001f;
+    int n_chi2 = 0;
+    bool converged = false, error_increased = false;
+    for (int iter = 0; iter < n_iter; ++iter) {
+        float chi2 = 0.f;
+        if (u != u || v != v) return false;
+        const int u_r = (int)floorf(u), v_r = (int)floorf(v);
+        if (u_r < 4 || v_r < 4 || u_r >= w - 4 || v_r >= h - 4) break;
+        const float sx = __fsub_rn(u, (float)u_r), sy = __fsub_rn(v, (float)v_r);
+        const float wTL = (float)((1.0 - (double)sx) * (1.0 - (double)sy)), wTR = (float)((double)sx * (1.0 - (double)sy));
+        const float wBL = (float)((1.0 - (double)sx) * (double)sy), wBR = __fmul_rn(sx, sy);
+        float J0 = 0.f, J1 = 0.f, J2 = 0.f;
+        uint32_t wl[9], wh[9], w8[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(cur + (size_t)(v_r + r - 4) * w + (u_r - 4));
+            ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(a & 3), d0 = q[0], d1 = q[1], d2 = q[2];
+            wl[r] = __builtin_amdgcn_alignbyte(d1, d0, sh); wh[r] = __builtin_amdgcn_alignbyte(d2, d1, sh); w8[r] = (d2 >> (8 * sh)) & 255u;
+        }
+#define WINL(r, c) ((c) < 8 ? YGZ_BYTE(wl[r], wh[r], (c) & 7) : (int)w8[r])
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float tl = (float)WINL(y, x), tr = (float)WINL(y, x + 1), bl = (float)WINL(y + 1, x), br = (float)WINL(y + 1, x + 1);
+                const float sp = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(wTL, tl), __fmul_rn(wTR, tr)), __fmul_rn(wBL, bl)), __fmul_rn(wBR, br));
+                const int k = (y + 1) * 10 + (x + 1);
+                const float res = __fadd_rn(__fsub_rn(sp, (float)pwb[k * 64]), mean_diff);
+                const float jx = 0.5f * (float)((int)pwb[(k + 1) * 64] - (int)pwb[(k - 1) * 64]);
+                const float jy = 0.5f * (float)((int)pwb[(k + 10) * 64] - (int)pwb[(k - 10) * 64]);
+                J0 = __fsub_rn(J0, __fmul_rn(res, jx)); J1 = __fsub_rn(J1, __fmul_rn(res, jy)); J2 = __fsub_rn(J2, res);
+                chi2 = __fadd_rn(chi2, __fmul_rn(res, res));
+            }
+        }
+#undef WINL
+        const float up0 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[0], J0), __fmul_rn(Hinv[1], J1)), __fmul_rn(Hinv[2], J2));
+        const float up1 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[3], J0), __fmul_rn(Hinv[4], J1)), __fmul_rn(Hinv[5], J2));
+        const float up2 = __fadd_rn(__fadd_rn(__fmul_rn(Hinv[6], J0), __fmul_rn(Hinv[7], J1)), __fmul_rn(Hinv[8], J2));
+        u = __fadd_rn(u, up0); v = __fadd_rn(v, up1); mean_diff = __fadd_rn(mean_diff, up2);
+        if (iter > 0 && chi2 > last_chi2) { error_increased = true; break; }
+        last_chi2 = chi2; ++n_chi2;
+        if (__fadd_rn(__fmul_rn(up0, up0), __fmul_rn(up1, up1)) < min_update_squared) { first_u = (double)u; first_v = (double)v; converged = true; break; }
+    }
+    *pu = (double)u; *pv = (double)v;
+    if (converged) return true;
+    if (n_chi2 == 0) return false;
+    if (error_increased) {
+        if (last_chi2 < 15000.f) { *pu = first_u; *pv = first_v; return true; }
+        return false;
+    }
+    return last_chi2 < 15000.f;
+}
+
+struct DfArgs {
+    const uint8_t *lvl[YGZ_MAX_LEVELS];
+    int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
+    Cam cam;
+    int cur_slot, n, batch_counter, max_n_kfs;
+    double conv_thresh, px_error_angle;
+    const double *T_cur;                          // T_cur (7), T_cur.inverse() (7)
+    const int32_t *ref_slot; const double *T_refs;        // [n_refs], [n_refs][7]
+    const float *kp; const int32_t *octave, *seed_ref; const unsigned long long *frame_id;
+    float *a, *b, *mu, *sigma2; const float *z_range;
+    int32_t *state; double *z_out, *matched_px, *pos_world;
+};
+
+__device__ __forceinline__ void df_cam2px_unit(const Cam &c, const double uv[2], double px[2])
+{ px[0] = (double)c.fx * uv[0] / 1.0 + (double)c.cx; px[1] = (double)c.fy * uv[1] / 1.0 + (double)c.cy; }
+
+// utils::FindEpipolarMatchDirect (src/utils.cpp:330-661)
+static __device__ bool df_epipolar_match(const DfArgs &A, int ref_slot, const Se3 &T_ref, const Se3 &T_cur, const double px_ref[2], int octave,
+                                         double d_estimate, double d_min, double d_max, uint8_t *pwb, double *depth, double matched_px[2])
+{
+    Se3 Tri, T_cur_ref;
+    se3_inv_d(&T_ref, &Tri); se3_mul_d(&T_cur, &Tri, &T_cur_ref);
+    double pt_ref[3], t[3], q[3], Ae[2], Be[2];
+    pixel2camera_d(A.cam, px_ref, 1.0, pt_ref);
+    for (int k = 0; k < 3; ++k) t[k] = pt_ref[k] * d_min;
+    se3_act_d(&T_cur_ref, t, q); Ae[0] = q[0] / q[2]; Ae[1] = q[1] / q[2];
+    for (int k = 0; k < 3; ++k) t[k] = pt_ref[k] * d_max;
+    se3_act_d(&T_cur_ref, t, q); Be[0] = q[0] / q[2]; Be[1] = q[1] / q[2];
+    const double ep0 = Ae[0] - Be[0], ep1 = Ae[1] - Be[1];
+    double Am[4];
+    {   // utils::GetWarpAffineMatrix (src/utils.cpp:37-64)
+        double p3[3], pw[3], pdu[3], pdv[3], pc[2], pu[2], pv[2], c3[3];
+        for (int k = 0; k < 3; ++k) p3[k] = pt_ref[k] * d_estimate;
+        se3_act_d(&Tri, p3, pw);
+        const double s = (double)(1 << octave);
+        const double pxu[2] = { px_ref[0] + 4.0 * s, px_ref[1] + 0.0 * s }, pxv[2] = { px_ref[0] + 0.0 * s, px_ref[1] + 4.0 * s };
+        double cu[3], cv[3];
+        pixel2camera_d(A.cam, pxu, p3[2], cu); pixel2camera_d(A.cam, pxv, p3[2], cv);
+        se3_act_d(&Tri, cu, pdu); se3_act_d(&Tri, cv, pdv);
+        se3_act_d(&T_cur, pw, c3); camera2pixel_d(A.cam, c3, pc);
+        se3_act_d(&T_cur, pdu, c3); camera2pixel_d(A.cam, c3, pu);
+        se3_act_d(&T_cur, pdv, c3); camera2pixel_d(A.cam, c3, pv);
+        Am[0] = (pu[0] - pc[0]) / 4; Am[2] = (pu[1] - pc[1]) / 4; Am[1] = (pv[0] - pc[0]) / 4; Am[3] = (pv[1] - pc[1]) / 4;
+    }
+    int sl = 0;
+    { double D = Am[0] * Am[3] - Am[2] * Am[1]; while (D > 3.0 && sl < 2) { sl += 1; D *= 0.25; } }            // GetBestSearchLevel(A, 2)
+    double px_A[2], px_B[2];
+    df_cam2px_unit(A.cam, Ae, px_A); df_cam2px_unit(A.cam, Be, px_B);
+    const double dxl = px_A[0] - px_B[0], dyl = px_A[1] - px_B[1];
+    const double epi_length = sqrt(dxl * dxl + dyl * dyl) / (double)(1 << sl);
+    warp_affine_lds(Am, A.lvl[octave] + (size_t)ref_slot * A.w[octave] * A.h[octave], A.w[octave], A.h[octave], px_ref, octave, sl, pwb);
+    const int cw = A.w[sl], ch = A.h[sl];
+    const uint8_t *cimg = A.lvl[sl] + (size_t)A.cur_slot * cw * ch;
+    const double T7[7] = { T_cur_ref.q[0], T_cur_ref.q[1], T_cur_ref.q[2], T_cur_ref.q[3], T_cur_ref.t[0], T_cur_ref.t[1], T_cur_ref.t[2] };
+    double px_cur[2];
+    if (epi_length < 2.0) {
+        px_cur[0] = (px_A[0] + px_B[0]) / 2.0; px_cur[1] = (px_A[1] + px_B[1]) / 2.0;
+        double su = px_cur[0] / (double)(1 << sl), sv = px_cur[1] / (double)(1 << sl);
+        const bool res = align2d_legacy_core(cimg, cw, ch, pwb, 10, &su, &sv);
+        if (res) {
+            px_cur[0] = su * (double)(1 << sl); px_cur[1] = sv * (double)(1 << sl);
+            double fc[3], d2;
+            pixel2camera_d(A.cam, px_cur, 1.0, fc);
+            matched_px[0] = px_cur[0]; matched_px[1] = px_cur[1];
+            return tri_depth_d(T7, pt_ref, fc, 1e-5, depth, &d2);
+        }
+        matched_px[0] = px_cur[0]; matched_px[1] = px_cur[1];
+        return false;
+    }
+    unsigned long long n_steps = (unsigned long long)(epi_length / 0.7);
+    const double st0 = ep0 / (double)n_steps, st1 = ep1 / (double)n_steps;
+    if (n_steps > 1000) return false;
+    int sumA = 0, sumAA = 0;                                   // ZMSSD<4> of the warped reference patch (rows 1..8, columns 1..8 of pwb)
+    for (int y = 0; y < 8; ++y) for (int x = 0; x < 8; ++x) { const int p = pwb[((y + 1) * 10 + x + 1) * 64]; sumA += p; sumAA += p * p; }
+    int zmssd_best = 2000 * 64;
+    double uv[2] = { Be[0] - st0, Be[1] - st1 }, uv_best[2] = { 0, 0 };
+    int last_x = 0, last_y = 0;
+    ++n_steps;
+    for (unsigned long long i = 0; i < n_steps; ++i, uv[0] += st0, uv[1] += st1) {
+        double px[2];
+        df_cam2px_unit(A.cam, uv, px);
+        const int pxi_x = (int)(px[0] / (double)(1 << sl) + 0.5), pxi_y = (int)(px[1] / (double)(1 << sl) + 0.5);
+        if (pxi_x == last_x && pxi_y == last_y) continue;
+        last_x = pxi_x; last_y = pxi_y;
+        const double xx = (double)pxi_x / (double)(1 << sl), yy = (double)pxi_y / (double)(1 << sl);
+        if (!(xx >= 8 && xx < A.w[0] - 8 && yy >= 8 && yy < A.h[0] - 8)) continue;
+        if (pxi_x - 4 < 0 || pxi_y - 4 < 0 || pxi_x + 4 > cw || pxi_y + 4 > ch) continue;
+        const uint8_t *cp = cimg + (size_t)(pxi_y - 4) * cw + (pxi_x - 4);
+        int sumB = 0, sumBB = 0, sumAB = 0;
+        for (int y = 0; y < 8; ++y) {
+            uint32_t lo, hi;
+            ygz_load8(cp + (size_t)y * cw, lo, hi);
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int c = YGZ_BYTE(lo, hi, x), p = pwb[((y + 1) * 10 + x + 1) * 64];
+                sumB += c; sumBB += c * c; sumAB += c * p;
+            }
+        }
+        const int zmssd = sumAA - 2 * sumAB + sumBB - (sumA * sumA - 2 * sumA * sumB + sumB * sumB) / 64;
+        if (zmssd < zmssd_best) { zmssd_best = zmssd; uv_best[0] = uv[0]; uv_best[1] = uv[1]; }
+    }
+    if (zmssd_best < 2000 * 64) {
+        df_cam2px_unit(A.cam, uv_best, px_cur);
+        double su = px_cur[0] / (double)(1 << sl), sv = px_cur[1] / (double)(1 << sl);
+        const bool res = align2d_legacy_core(cimg, cw, ch, pwb, 10, &su, &sv);
+        if (res) {
+            px_cur[0] = su * (double)(1 << sl); px_cur[1] = sv * (double)(1 << sl);
+            double fc[3], d2;
+            pixel2camera_d(A.cam, px_cur, 1.0, fc);
+            matched_px[0] = px_cur[0]; matched_px[1] = px_cur[1];
+            return tri_depth_d(T7, pt_ref, fc, 1e-5, depth, &d2);
+        }
+        matched_px[0] = px_cur[0]; matched_px[1] = px_cur[1];
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_depth_filter(DfArgs A)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= A.n) return;
+    A.z_out[i] = 0.0; A.matched_px[2 * (size_t)i] = 0.0; A.matched_px[2 * (size_t)i + 1] = 0.0;
+    if (((unsigned long long)(long long)A.batch_counter - A.frame_id[i]) > (unsigned long long)(long long)A.max_n_kfs) { A.state[i] = 4; return; }
+    const int r = A.seed_ref[i];
+    Se3 T_ref, T_cur, T_cur_inv, T_ref_cur, T_ref_cur_inv;
+    for (int k = 0; k < 4; ++k) { T_ref.q[k] = A.T_refs[7 * (size_t)r + k]; T_cur.q[k] = A.T_cur[k]; T_cur_inv.q[k] = A.T_cur[7 + k]; }
+    for (int k = 0; k < 3; ++k) { T_ref.t[k] = A.T_refs[7 * (size_t)r + 4 + k]; T_cur.t[k] = A.T_cur[4 + k]; T_cur_inv.t[k] = A.T_cur[11 + k]; }
+    se3_mul_d(&T_ref, &T_cur_inv, &T_ref_cur); se3_inv_d(&T_ref_cur, &T_ref_cur_inv);
+    const double px_ref[2] = { (double)A.kp[2 * (size_t)i], (double)A.kp[2 * (size_t)i + 1] };
+    float a = A.a[i], b = A.b[i], mu = A.mu[i], sigma2 = A.sigma2[i];
+    const float z_range = A.z_range[i];
+    double pt_ref[3], sc[3], xyz_f[3];
+    pixel2camera_d(A.cam, px_ref, 1.0, pt_ref);
+    for (int k = 0; k < 3; ++k) sc[k] = 1.0 / (double)mu * pt_ref[k];
+    se3_act_d(&T_ref_cur_inv, sc, xyz_f);
+    if (xyz_f[2] < 0.0) { A.state[i] = 1; return; }
+    {
+        double uvp[2];
+        camera2pixel_d(A.cam, xyz_f, uvp);
+        if (!(uvp[0] >= 10 && uvp[0] < A.w[0] - 10 && uvp[1] >= 10 && uvp[1] < A.h[0] - 10)) { A.state[i] = 2; return; }
+    }
+    const float ssig = ygz_sqrtf_cr(sigma2);
+    const float z_inv_min = __fadd_rn(mu, ssig);
+    const float z_inv_max = fmaxf(__fsub_rn(mu, ssig), 0.00000001f);
+    double z = 0.0, mpx[2] = { 0.0, 0.0 };
+    if (!df_epipolar_match(A, A.ref_slot[r], T_ref, T_cur, px_ref, A.octave[i], 0.9 / (double)mu, 1.1 / (double)z_inv_min, 1.0 / (double)z_inv_max,
+                           pwb_all + threadIdx.x, &z, mpx)) {
+        A.matched_px[2 * (size_t)i] = mpx[0]; A.matched_px[2 * (size_t)i + 1] = mpx[1];
+        A.state[i] = 3; return;
+    }
+    A.matched_px[2 * (size_t)i] = mpx[0]; A.matched_px[2 * (size_t)i + 1] = mpx[1];
+    A.z_out[i] = z;
+    double tau;
+    {   // DepthFilter::ComputeTau (src/optimizer.cpp:711-726)
+        const double *t = T_ref_cur.t;
+        const double av[3] = { pt_ref[0] * z - t[0], pt_ref[1] * z - t[1], pt_ref[2] * z - t[2] };
+        const double t_norm = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]), a_norm = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+        const double alpha = acos((pt_ref[0] * t[0] + pt_ref[1] * t[1] + pt_ref[2] * t[2]) / t_norm);
+        const double beta = acos((av[0] * -t[0] + av[1] * -t[1] + av[2] * -t[2]) / (t_norm * a_norm));
+        const double beta_plus = beta + A.px_error_angle;
+        const double gamma_plus = 3.14159265358979323846 - alpha - beta_plus;
+        tau = t_norm * sin(beta_plus) / sin(gamma_plus) - z;
+    }
+    const double tau_inverse = 0.5 * (1.0 / fmax(0.0000001, z - tau) - 1.0 / (z + tau));
+    {   // DepthFilter::UpdateSeed (src/optimizer.cpp:683-708), float throughout
+        const float x = (float)(1. / z), tau2 = (float)(tau_inverse * tau_inverse);
+        const float norm_scale = ygz_sqrtf_cr(__fadd_rn(sigma2, tau2));
+        if (!(norm_scale != norm_scale)) {
+            float e_ = __fsub_rn(x, mu); e_ = __fmul_rn(e_, -e_); e_ = __fdiv_rn(e_, __fmul_rn(__fmul_rn(2.f, norm_scale), norm_scale));
+            const float pdf = __fdiv_rn(expf(e_), __fmul_rn(norm_scale, ygz_sqrtf_cr(__fmul_rn(2.f, 3.14159265358979323846f))));
+            const float s2 = (float)(1. / (1. / (double)sigma2 + 1. / (double)tau2));
+            const float m = __fmul_rn(s2, __fadd_rn(__fdiv_rn(mu, sigma2), __fdiv_rn(x, tau2)));
+            float C1 = __fmul_rn(__fdiv_rn(a, __fadd_rn(a, b)), pdf);
+            float C2 = (float)((double)__fdiv_rn(b, __fadd_rn(a, b)) * 1. / (double)z_range);
+            const float nc = __fadd_rn(C1, C2);
+            C1 = __fdiv_rn(C1, nc); C2 = __fdiv_rn(C2, nc);
+            const float ab = __fadd_rn(a, b);
+            const float f = (float)((double)C1 * ((double)a + 1.) / ((double)ab + 1.) + (double)__fmul_rn(C2, a) / ((double)ab + 1.));
+            const float e = (float)((double)C1 * ((double)a + 1.) * ((double)a + 2.) / (((double)ab + 1.) * ((double)ab + 2.))
+                                    + (double)__fdiv_rn(__fmul_rn(__fmul_rn(C2, a), __fadd_rn(a, 1.0f)), __fmul_rn(__fadd_rn(ab, 1.0f), __fadd_rn(ab, 2.0f))));
+            const float mu_new = __fadd_rn(__fmul_rn(C1, m), __fmul_rn(C2, mu));
+            sigma2 = __fsub_rn(__fadd_rn(__fmul_rn(C1, __fadd_rn(s2, __fmul_rn(m, m))), __fmul_rn(C2, __fadd_rn(sigma2, __fmul_rn(mu, mu)))), __fmul_rn(mu_new, mu_new));
+            mu = mu_new;
+            a = __fdiv_rn(__fsub_rn(e, f), __fsub_rn(f, __fdiv_rn(e, f)));
+            b = __fdiv_rn(__fmul_rn(a, __fsub_rn(1.0f, f)), f);
+        }
+    }
+    A.a[i] = a; A.b[i] = b; A.mu[i] = mu; A.sigma2[i] = sigma2;
+    if ((double)ygz_sqrtf_cr(sigma2) < (double)z_range / A.conv_thresh) {
+        double p[3], pw[3];
+        for (int k = 0; k < 3; ++k) p[k] = pt_ref[k] * (1.0 / (double)mu);
+        se3_act_d(&T_cur_inv, p, pw);                       // frame->_T_c_w.inverse() * (pt_ref / mu), src/optimizer.cpp:628 as written
+        A.pos_world[3 * (size_t)i] = pw[0]; A.pos_world[3 * (size_t)i + 1] = pw[1]; A.pos_world[3 * (size_t)i + 2] = pw[2];
+        A.state[i] = 5;
+    } else if (z_inv_min != z_inv_min) A.state[i] = 6;
+    else A.state[i] = 0;
+}
+
+extern "C" int ygz_hip_depth_filter_update(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], int n_refs, const int32_t *ref_slot,
+                                           const double *T_refs, int batch_counter, int max_n_kfs, double convergence_sigma2_thresh, int n,
+                                           const float *kp, const int32_t *octave, const int32_t *seed_ref, const uint64_t *seed_frame_id,
+                                           float *a, float *b, float *mu, const float *z_range, float *sigma2, int32_t *state, double *z,
+                                           double *matched_px, double *pos_world, int *n_updated)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || !T_cur || n < 0 || n_refs < 0 || cur_slot < 0 || cur_slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (n_updated) *n_updated = 0;
+    if (n == 0) return YGZ_OK;
+    if (n_refs < 1 || !ref_slot || !T_refs || !kp || !octave || !seed_ref || !seed_frame_id || !a || !b || !mu || !z_range || !sigma2 || !state || !z ||
+        !matched_px || !pos_world) return YGZ_E_INVALID;
+    if (!ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
+    for (int r = 0; r < n_refs; ++r) {
+        if (ref_slot[r] < 0 || ref_slot[r] >= ctx->prm.max_frames) return YGZ_E_INVALID;
+        if (!ctx->pyr_valid[ref_slot[r]]) return YGZ_E_STATE;
+    }
+    for (int i = 0; i < n; ++i)
+        if (seed_ref[i] < 0 || seed_ref[i] >= n_refs || octave[i] < 0 || octave[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
+    if (ctx->prm.pyramid_levels < 3) return YGZ_E_STATE;              // GetBestSearchLevel(A, 2) may pick level 2
+    const size_t N = (size_t)n, R = (size_t)n_refs;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) & ~(size_t)15; return o; };
+    const size_t o_T = take(14 * 8), o_rs = take(R * 4), o_Tr = take(R * 56), o_kp = take(N * 8), o_oc = take(N * 4), o_sr = take(N * 4), o_fid = take(N * 8),
+                 o_a = take(N * 4), o_b = take(N * 4), o_mu = take(N * 4), o_zr = take(N * 4), o_s2 = take(N * 4), o_st = take(N * 4), o_z = take(N * 8),
+                 o_mp = take(N * 16), o_pw = take(N * 24);
+    uint8_t *buf = nullptr;
+    int rc = ygz_scratch(ctx, SCR_GEN_0, off + 64, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    double hT[14];
+    {
+        Se3 c, ci;
+        for (int k = 0; k < 4; ++k) c.q[k] = T_cur[k];
+        for (int k = 0; k < 3; ++k) c.t[k] = T_cur[4 + k];
+        se3_inv_d(&c, &ci);
+        for (int k = 0; k < 7; ++k) hT[k] = T_cur[k];
+        for (int k = 0; k < 4; ++k) hT[7 + k] = ci.q[k];
+        for (int k = 0; k < 3; ++k) hT[11 + k] = ci.t[k];
+    }
+#define UPD_(o, src, bytes) YGZ_HIPCHK(ctx, hipMemcpyAsync(buf + (o), (src), (bytes), hipMemcpyHostToDevice, ctx->stream))
+    UPD_(o_T, hT, sizeof(hT)); UPD_(o_rs, ref_slot, R * 4); UPD_(o_Tr, T_refs, R * 56); UPD_(o_kp, kp, N * 8); UPD_(o_oc, octave, N * 4);
+    UPD_(o_sr, seed_ref, N * 4); UPD_(o_fid, seed_frame_id, N * 8); UPD_(o_a, a, N * 4); UPD_(o_b, b, N * 4); UPD_(o_mu, mu, N * 4);
+    UPD_(o_zr, z_range, N * 4); UPD_(o_s2, sigma2, N * 4);
+#undef UPD_
+    YGZ_HIPCHK(ctx, hipMemsetAsync(buf + o_pw, 0, N * 24, ctx->stream));
+    DfArgs A;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
+    A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.cur_slot = cur_slot; A.n = n; A.batch_counter = batch_counter; A.max_n_kfs = max_n_kfs; A.conv_thresh = convergence_sigma2_thresh;
+    {   // px_error_angle = atan(px_noise / (2 focal)) * 2, focal = float (fx + fy) / 2 (Camera.h:24)
+        const double focal_length = (double)((ctx->prm.fx + ctx->prm.fy) / 2);
+        A.px_error_angle = atan(1.0 / (2.0 * focal_length)) * 2.0;
+    }
+    A.T_cur = (const double *)(buf + o_T); A.ref_slot = (const int32_t *)(buf + o_rs); A.T_refs = (const double *)(buf + o_Tr);
+    A.kp = (const float *)(buf + o_kp); A.octave = (const int32_t *)(buf + o_oc); A.seed_ref = (const int32_t *)(buf + o_sr);
+    A.frame_id = (const unsigned long long *)(buf + o_fid);
+    A.a = (float *)(buf + o_a); A.b = (float *)(buf + o_b); A.mu = (float *)(buf + o_mu); A.z_range = (const float *)(buf + o_zr); A.sigma2 = (float *)(buf + o_s2);
+    A.state = (int32_t *)(buf + o_st); A.z_out = (double *)(buf + o_z); A.matched_px = (double *)(buf + o_mp); A.pos_world = (double *)(buf + o_pw);
+    YGZ_LAUNCH(ctx, KID_DEPTH_FILTER, k_depth_filter, dim3(ygz_div_up(n, 64)), dim3(64), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+#define DNL_(dst, o, bytes) YGZ_HIPCHK(ctx, hipMemcpyAsync((dst), buf + (o), (bytes), hipMemcpyDeviceToHost, ctx->stream))
+    DNL_(a, o_a, N * 4); DNL_(b, o_b, N * 4); DNL_(mu, o_mu, N * 4); DNL_(sigma2, o_s2, N * 4); DNL_(state, o_st, N * 4); DNL_(z, o_z, N * 8);
+    DNL_(matched_px, o_mp, N * 16); DNL_(pos_world, o_pw, N * 24);
+#undef DNL_
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_updated) { int c = 0; for (int i = 0; i < n; ++i) c += state[i] == 0 || state[i] == 5 || state[i] == 6; *n_updated = c; }
     return YGZ_OK;
 }
