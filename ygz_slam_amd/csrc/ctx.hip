@@ -1,6 +1,7 @@
 // Context, HBM frame store and host<->device plumbing of the C ABI (include/ygz_hip.h).
 #include "ygz_internal.h"
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <new>
 
@@ -177,8 +178,13 @@ int ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable)
     if (rc != YGZ_OK) return rc;
     if (enable && !ctx->aux[0]) {
         YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        int prio_lo = 0, prio_hi = 0;                       // numerically greatest = lowest priority
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const char *pe = getenv("YGZ_AUX_PRIORITY");       // experiment switch: "low" = side streams below the main stream
+        const bool low = pe && pe[0] == 'l';
         for (int i = 0; i < 3; ++i) {
-            YGZ_HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+            if (low) YGZ_HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_lo));
+            else YGZ_HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
             YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
         }
     }
@@ -301,6 +307,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
     int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->n_levels_alloc);
     if (rc != YGZ_OK) return rc;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 1;
+    ctx->klt_prep_valid = false;
     return YGZ_OK;
 }
 

@@ -500,7 +500,19 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
     }
 }
 
-int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
+static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm, bool prep_only);
+int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm) { return launch_klt_impl(ctx, n_pairs, prm, false); }
+// the tracker's working images (reflect-framed copies + Scharr images of the distinct slots of the pair table) ahead of the LK launch:
+// they depend only on the pyramids, so a pipeline can build them before it forks its side-stream stages
+int ygz_klt_prepare_early(ygz_hip_ctx *ctx)
+{
+    ygz_klt_params prm;
+    ygz_hip_default_klt_params(&prm);
+    int rc = launch_klt_impl(ctx, ctx->n_pairs, &prm, true);
+    if (rc == YGZ_OK) ctx->klt_prep_valid = true;
+    return rc;
+}
+static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm, bool prep_only)
 {
     if (prm->win < 3 || prm->win > KLT_MAXWIN || prm->max_level < 0 || prm->max_level >= YGZ_MAX_LEVELS) return YGZ_E_INVALID;
     // buildOpticalFlowPyramid: stop when the next level would not exceed the window
@@ -526,11 +538,14 @@ int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm)
         }
         if (!ctx->klt_pad[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_pad[L], (size_t)ctx->prm.max_frames * psz + 64));
         A.pad[L] = ctx->klt_pad[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = w; A.h[L] = h;
+        if (ctx->klt_prep_valid) continue;                       // the working images of this pair table were built ahead (ygz_klt_prepare_early)
         YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(pw / 4, 64), ygz_div_up(ph, 4), ygz_round_up8(ctx->n_klt_slots)), dim3(256),
                    ctx->lvl[L], ctx->klt_pad[L], ctx->klt_slots, w, h, ctx->n_klt_slots);
         YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(ygz_div_up(w, 4), 64), ygz_div_up(h, 4), ygz_round_up8(ctx->n_klt_refs)), dim3(256),
                    ctx->klt_pad[L], ctx->deriv[L], ctx->klt_slots + ctx->n_klt_slots, w, h, ctx->n_klt_refs);
     }
+    ctx->klt_prep_valid = false;
+    if (prep_only) return YGZ_OK;
     A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);
     const double eps = prm->eps < 0 ? 0 : (prm->eps > 10 ? 10 : prm->eps);

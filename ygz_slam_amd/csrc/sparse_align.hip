@@ -230,7 +230,8 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
             // changes when a feature enters or leaves the image (first iteration of a level: every used feature enters).
             double acc[27];
 #pragma unroll
-            for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+            for (int k = 21; k < 27; ++k) acc[k] = 0.0;
+            uint32_t chg_mask = 0u, add_mask = 0u;                  // per lane: which of its features (f0_ / SA_THREADS) entered / left this iteration
             const double fl = (double)((A.fx + A.fy) / 2) / (double)(1 << level);
 #pragma unroll 1
             for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {             // uniform trip count: the chunk scan below needs whole wavefronts
@@ -240,9 +241,16 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 float res[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) res[k] = 0.f;
-                bool use = visible[f] != 0;
+                // everything that does not depend on the iterate is fetched up front, unconditionally and in one batch (one memory
+                // latency instead of one per dependent branch below): the feature's flags, pixel, depth, reference patch and gradients
+                const uint8_t vis_f = visible[f], pu_f = prev_used[f];
+                const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
+                const float4 *pcp = reinterpret_cast<const float4 *>(patch_cache + 16 * (size_t)f);
+                const float4 c0 = pcp[0], c1 = pcp[1], c2 = pcp[2], c3 = pcp[3];
+                const float4 *gp = reinterpret_cast<const float4 *>(dxy + 32 * (size_t)f);
+                const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3], g4 = gp[4], g5 = gp[5], g6 = gp[6], g7 = gp[7];
+                bool use = vis_f != 0;
                 if (use) {
-                    const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
                     const double xyz_ref[3] = { (pxx - A.cx) * dep / A.fx, (pxy - A.cy) * dep / A.fy, dep };
                     double xyz_cur[3];
                     se3_act_d(&T, xyz_ref, xyz_cur);
@@ -255,8 +263,6 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                         const float su = __fsub_rn(u_cur, (float)ui), sv = __fsub_rn(v_cur, (float)vi);
                         const float w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv)), w_tr = (float)((double)su * (1.0 - (double)sv));
                         const float w_bl = (float)((1.0 - (double)su) * (double)sv), w_br = __fmul_rn(su, sv);
-                        const float4 *pcp = reinterpret_cast<const float4 *>(patch_cache + 16 * (size_t)f);
-                        const float4 c0 = pcp[0], c1 = pcp[1], c2 = pcp[2], c3 = pcp[3];
                         const float refp[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
                         uint32_t wl[5], wh[5];            // rows vi-2..vi+2, columns ui-2..ui+2
 #pragma unroll
@@ -279,23 +285,24 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dst[(size_t)k * A.cells + f] = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
                 used[f] = use ? 1 : 0;
-                const bool pu = prev_used[f] != 0;
-                if (use != pu) {
-                    prev_used[f] = use ? 1 : 0;
-#pragma unroll
-                    for (int k = 0; k < 21; ++k) { const double h = Hf[21 * (size_t)f + k]; acc[k] += use ? h : -h; }
+                const bool pu = pu_f != 0;
+                if (use != pu) {                                     // rare after the first iteration of a level: H changes by +-Hf, added in the
+                    prev_used[f] = use ? 1 : 0;                      // second loop below (same feature order per lane, same sums) so that the 21
+                    chg_mask |= 1u << (f0_ / SA_THREADS);            // FP64 accumulators are not live across the residual arithmetic
+                    if (use) add_mask |= 1u << (f0_ / SA_THREADS);
                 }
                 if (use) {
                     my_meas += 16;
                     double gA = 0.0, gB = 0.0;
+                    const float gxv[16] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w };
+                    const float gyv[16] = { g4.x, g4.y, g4.z, g4.w, g5.x, g5.y, g5.z, g5.w, g6.x, g6.y, g6.z, g6.w, g7.x, g7.y, g7.z, g7.w };
 #pragma unroll
                     for (int pc = 0; pc < 16; ++pc) {
-                        gA += (double)dxy[32 * (size_t)f + pc] * (double)res[pc];
-                        gB += (double)dxy[32 * (size_t)f + 16 + pc] * (double)res[pc];
+                        gA += (double)gxv[pc] * (double)res[pc];
+                        gB += (double)gyv[pc] * (double)res[pc];
                     }
                     // the 2x6 frame Jacobian is recomputed (a dozen FP64 operations from the values above, the same expressions
                     // as in the set-up) instead of fetched: 96 bytes less per feature and iteration
-                    const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
                     const double jx = (pxx - A.cx) * dep / A.fx, jy = (pxy - A.cy) * dep / A.fy;
                     const double z_inv = 1. / dep, z_inv_2 = z_inv * z_inv;
                     double fj[12];      // cvutils::JacobXYZ2Cam (CVUtils.h:77-99)
@@ -312,6 +319,18 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 if (lane == 63) ctot[f >> 6] = incl;
             }
 #undef BIL
+#pragma unroll
+            for (int k = 0; k < 21; ++k) acc[k] = 0.0;
+            if (__ballot(chg_mask != 0u) != 0ull) {                 // wave-uniform skip: no feature of this wavefront changed state
+#pragma unroll 1
+                for (int c = 0; c * SA_THREADS < n; ++c) {
+                    if (!((chg_mask >> c) & 1u)) continue;
+                    const int f = c * SA_THREADS + tid;
+                    const bool add = (add_mask >> c) & 1u;
+#pragma unroll
+                    for (int k = 0; k < 21; ++k) { const double h = Hf[21 * (size_t)f + k]; acc[k] += add ? h : -h; }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
             {

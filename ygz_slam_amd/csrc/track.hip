@@ -5,6 +5,7 @@
 // (k_track_load) or from host arrays by the single-pair entry points of the ABI.
 #include "ygz_internal.h"
 #include "se3_dev.h"
+#include <stdlib.h>
 
 int ygz_track_ensure(ygz_hip_ctx *ctx)
 {
@@ -64,6 +65,7 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
     }
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_pairs = n_pairs;
+    ctx->klt_prep_valid = false;
     return YGZ_OK;
 }
 
@@ -218,7 +220,10 @@ int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
     YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
-    return launch_load(ctx, predict);
+    int rc = launch_load(ctx, predict);
+    if (rc != YGZ_OK) return rc;
+    { const char *e = getenv("YGZ_KLT_PREP"); if (e && e[0] == 'e') rc = ygz_klt_prepare_early(ctx); }      // experiment switch (schedule)
+    return rc;
 }
 
 int ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm)

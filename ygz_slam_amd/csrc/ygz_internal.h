@@ -80,6 +80,7 @@ struct ygz_hip_ctx {
     uint8_t *sa_work = nullptr;              // [F][sa_work_stride]
     size_t   sa_work_stride = 0;
     int      deriv_slots = 0;                // slots covered by the Scharr buffers
+    bool     klt_prep_valid = false;         // the LK working images of the current pair table / pyramids are already built
 
     // optional stage overlap: independent resident stages run on side streams (forked from / joined to `stream`)
     int overlap = 0;
@@ -177,6 +178,7 @@ int ygz_track_ensure(ygz_hip_ctx *ctx);                      // allocates the re
 int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
                         const double *T_ref, int n_pairs);
 int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm);
+int ygz_klt_prepare_early(ygz_hip_ctx *ctx);
 int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs);
 int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int min_level, int n_iter);
 // ba::OptimizeCurrentPoseOnly on device arrays (pose_only.hip): rows of frame f = [off[f], off[f+1]) or, when cnt != nullptr,
