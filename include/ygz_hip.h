@@ -342,6 +342,13 @@ typedef struct {
 void ygz_hip_ceres_default_options(ygz_ceres_options *opt);
 int  ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                             const ygz_ceres_options *opt, ygz_ceres_summary *summary);
+/* The same loop entirely on the GPU for uploaded formulation-2 windows window_begin .. +n_windows-1 (at most 14 free and 16 poses per
+ * window, no repeated (point, pose) pair): one workgroup per window runs every trust-region iteration (scaled Schur complement,
+ * Cholesky, step validity, candidate cost, radius policy) in HBM / LDS, all windows concurrently; the windows' states are updated
+ * in place (ygz_hip_ba_get_state).  summaries [n_windows] may be NULL (then the call is asynchronous).  ygz_hip_ba_solve_ceres
+ * uses it when the window qualifies. */
+int  ygz_hip_ba_solve_ceres_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, const ygz_ceres_options *opt,
+                                     ygz_ceres_summary *summaries);
 
 /* ---- B7: ba::OptimizeCurrentPoseOnly (src/Algorithm/BA.cpp:188-264; the per-frame call of
  *      LocalMapping::OptimizeCurrent, src/Module/LocalMapping.cpp:126) for a batch of frames: one workgroup per frame runs

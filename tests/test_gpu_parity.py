@@ -703,6 +703,50 @@ def test_ba_solve_ceres_variants(hip_lib, oracle):
     ctx.close()
 
 
+def test_ba_solve_ceres_resident_windows(hip_lib, oracle, monkeypatch):
+    """SURVEY 8f-1, second half: the ceres trust-region loop resident on the GPU (k_ba_ceres), five different windows in ONE launch --
+    ba::LocalBA problems of two sizes, all poses constant (OptimizeCurrentPointOnly), HuberLoss(0.1) with one free pose
+    (OptimizeCurrent), and a pose-only window that fails at iteration zero (point behind the camera) -- against the oracle's
+    ceres::Solve restatement and against the host-loop form of the same entry point (YGZ_BA_HOST_LOOP=1)."""
+    fa = fixtures.ba_to_ceres(synth.ba_window(6, 300, seed=5)); fb = fixtures.ba_to_ceres(fixtures.ba_fixture_test_local_ba(noise=True))
+    fc = fixtures.ba_to_ceres(synth.ba_window(5, 200, seed=9))
+    onefree = np.ones(len(fc["poses"]), np.uint8); onefree[-1] = 0
+    f = fixtures.pose_only_fixture(n=60, seed=8, outlier_frac=0.0)
+    n = len(f["px"])
+    obs_po = np.stack([(f["px"][:, 0] - synth.CX) / synth.FX, (f["px"][:, 1] - synth.CY) / synth.FY], axis=1)
+    pw = f["pw"].copy(); pw[7, 2] = -3.0
+    wins = [dict(poses=fa["poses"], fixed=fa["fixed"], points=fa["points"], ep=fa["edge_pose"], el=fa["edge_point"], obs=fa["obs_n"]),
+            dict(poses=fb["poses"], fixed=fb["fixed"], points=fb["points"], ep=fb["edge_pose"], el=fb["edge_point"], obs=fb["obs_n"]),
+            dict(poses=fc["poses"], fixed=np.ones(len(fc["poses"]), np.uint8), points=fc["points"], ep=fc["edge_pose"], el=fc["edge_point"], obs=fc["obs_n"]),
+            dict(poses=fc["poses"], fixed=onefree, points=fc["points"], ep=fc["edge_pose"], el=fc["edge_point"], obs=fc["obs_n"], huber=np.full(len(fc["obs_n"]), 0.1))]
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for w, d in enumerate(wins):
+        ctx.ba_upload(w, d["poses"], d["fixed"], d["points"], d["ep"], d["el"], d["obs"], huber_delta=0.0, formulation=2, edge_huber=d.get("huber"))
+    sums = ctx.ba_solve_ceres_resident(0, len(wins))
+    for w, d in enumerate(wins):
+        po, pt, so = oracle.ceres_solve(d["poses"], d["fixed"], d["points"], d["ep"], d["el"], d["obs"], edge_huber=d.get("huber"))
+        sg = sums[w]
+        assert (sg["iterations"], sg["successful_steps"], sg["unsuccessful_steps"], sg["termination"]) == \
+               (so["iterations"], so["successful_steps"], so["unsuccessful_steps"], so["termination"]), w
+        assert abs(sg["initial_cost"] - so["initial_cost"]) <= 1e-11 * so["initial_cost"] and abs(sg["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"]
+        pg, tg = ctx.ba_get_state(w, len(d["poses"]), len(d["points"]))
+        assert _rel(pg, po) < 1e-6 and _rel(tg, pt) < 1e-6, w
+        fixed = d["fixed"].astype(bool)
+        assert np.array_equal(pg[fixed], d["poses"][fixed])                           # constant poses are not touched
+    # the failure at iteration zero (PoseOnly functor, p_z < 0) and the host-loop form of the same problems
+    ctx.ba_upload(0, f["entry"][None], None, pw, np.zeros(n, np.int32), np.arange(n, dtype=np.int32), obs_po, huber_delta=0.0, formulation=2,
+                  point_fixed=np.ones(n, np.uint8))
+    sg = ctx.ba_solve_ceres_resident(0, 1, options=ctx.ceres_options(fail_behind_camera=1))[0]
+    pg, _ = ctx.ba_get_state(0, 1, n)
+    assert sg["termination"] == 5 and np.array_equal(pg[0], f["entry"])
+    d = wins[0]
+    r_po, r_pt, r_s = ctx.ba_solve_ceres(d["poses"], d["fixed"], d["points"], d["ep"], d["el"], d["obs"])
+    monkeypatch.setenv("YGZ_BA_HOST_LOOP", "1")
+    h_po, h_pt, h_s = ctx.ba_solve_ceres(d["poses"], d["fixed"], d["points"], d["ep"], d["el"], d["obs"])
+    assert (r_s["iterations"], r_s["termination"]) == (h_s["iterations"], h_s["termination"]) and _rel(r_po, h_po) < 1e-8 and _rel(r_pt, h_pt) < 1e-8
+    ctx.close()
+
+
 def test_optimize_pose_only_batch(hip_lib, oracle):
     """ba::OptimizeCurrentPoseOnly for a batch of frames in one launch (one workgroup per frame, four rounds on the device)
     vs the oracle frame by frame: flags, inlier counts and rounds equal; pose within 1e-7 relative (bar 1e-5), depth 1e-9."""

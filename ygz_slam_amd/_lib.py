@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
-    "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_optimize_pose_only",
+    "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
     "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map",
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
@@ -677,6 +677,12 @@ class HipContext:
                                                   C.byref(sm)), "ba_solve_ceres")
         return po, pt, {k: getattr(sm, k) for k, _ in CeresSummary._fields_}
 
+    def ba_solve_ceres_resident(self, window_begin, n_windows, options=None):
+        sm = (CeresSummary * n_windows)()
+        opt = options or self.ceres_options()
+        self._chk(self.lib.ygz_hip_ba_solve_ceres_resident(self._ctx, window_begin, n_windows, C.byref(opt), sm), "ba_solve_ceres_resident")
+        return [{k: getattr(s, k) for k, _ in CeresSummary._fields_} for s in sm]
+
     def optimize_pose_only(self, frame_off, px, pw, poses, depth=None):
         """ba::OptimizeCurrentPoseOnly for a batch of frames; returns (poses, bad, depth, inliers, rounds)."""
         off = np.ascontiguousarray(frame_off, np.int32)
@@ -712,8 +718,9 @@ class HipContext:
         self._chk(self.lib.ygz_hip_ba_get_state(self._ctx, window, _p(po, C.c_double), _p(pt, C.c_double)), "ba_get_state")
         return po, pt
 
-    def ba_upload(self, window, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None):
-        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam)
+    def ba_upload(self, window, poses, fixed, points, edge_pose, edge_point, obs, huber_delta=5.991, formulation=0, cam=None,
+                  point_fixed=None, edge_huber=None, edge_enable=None):
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam, point_fixed, edge_huber, edge_enable)
         self._chk(self.lib.ygz_hip_ba_upload(self._ctx, window, C.byref(pb)), "ba_upload")
         return pb.n_poses, pb.n_points, pb.n_edges
 

@@ -163,7 +163,7 @@ static BaDev ba_dev(const ygz_hip_ctx::BaWindow *w)
     B.Hpp = w->Hpp; B.bp = w->bp; B.chi2 = w->chi2; B.Hll_c = w->Hll_c; B.bl_c = w->bl_c; B.Hpl_c = w->Hpl_c; B.err_c = w->err_c;
     B.chi2e_c = w->chi2e_c; B.part_pose = w->part_pose; B.part_chi = w->part_chi;
     B.poses_w = w->poses; B.points_w = w->points; B.poses_bk = w->poses_bk; B.points_bk = w->points_bk;
-    B.Y_c = w->Y_c; B.Dinv = w->Dinv; B.xl = w->xl;
+    B.Y_c = w->Y_c; B.Dinv = w->Dinv; B.xl = w->xl; B.sc_p = w->sc_p; B.sc_l = w->sc_l;
     return B;
 }
 
@@ -254,7 +254,8 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
                     + (size_t)K * 36 + (size_t)K * 6 + 1 + (size_t)Q * 9 * 64 + (size_t)Q * 3 * 64  // Hpp, bp, chi2, Hll_c, bl_c
                     + Rz * 18 * 64 + Rz * 2 * 64 + Rz * 64                                        // Hpl_c, err_c, chi2e_c
                     + (size_t)Q * Kfz * 27 + (size_t)Q                                            // partials
-                    + (size_t)K * 6 + (size_t)P * 3 + Rz * 18 * 64 + (size_t)P * 9 + (size_t)P * 3;   // LM: backups, Y_c, Dinv, xl
+                    + (size_t)K * 6 + (size_t)P * 3 + Rz * 18 * 64 + (size_t)P * 9 + (size_t)P * 3   // LM: backups, Y_c, Dinv, xl
+                    + (size_t)K * 6 + (size_t)P * 3;                                               // trust-region loop: Jacobi scales
     const size_t ni = Rz * 64 + (size_t)Q + 1 + Ez + 2 * (size_t)K + 1;
     const size_t ns = (size_t)P * Kfz + 1 + Rz * 64;
     const size_t bytes = nd * 8 + ni * 4 + ((ns * 2 + 3) & ~(size_t)3) + (size_t)K + (size_t)P + Rz * 64 + 64;
@@ -269,6 +270,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     w->part_pose = d; d += (size_t)Q * Kfz * 27; w->part_chi = d; d += (size_t)Q;
     w->poses_bk = d; d += (size_t)K * 6; w->points_bk = d; d += (size_t)P * 3; w->Y_c = d; d += Rz * 18 * 64;
     w->Dinv = d; d += (size_t)P * 9; w->xl = d; d += (size_t)P * 3;
+    w->sc_p = d; d += (size_t)K * 6; w->sc_l = d; d += (size_t)P * 3;
     int32_t *ii = (int32_t *)d;
     w->pose_c = ii; ii += Rz * 64; w->slot_off = ii; ii += (size_t)Q + 1; w->edge_rl = ii; ii += Ez;
     w->free_idx = ii; ii += K; w->free_pose = ii; ii += K; w->n_behind = ii; ii += 1;

@@ -37,6 +37,7 @@ struct ygz_hip_ctx::BaWindow {
     double *part_pose, *part_chi;    // [Q][Kf][27], [Q]: per-wavefront partial sums of the pose blocks / chi2
     // work space of the resident Levenberg-Marquardt kernel (ba_resident_lm.hip)
     double *poses_bk, *points_bk, *Y_c, *Dinv, *xl;       // Y_c [R][18][64]
+    double *sc_p, *sc_l;             // [K][6], [P][3] Jacobi column scales of the resident trust-region loop
     // host side: where each edge lives (for ygz_hip_ba_set_enable)
     std::vector<int32_t> h_edge_rl;
 };
@@ -52,6 +53,7 @@ struct BaDev {
     double *Hpp, *bp, *chi2, *Hll_c, *bl_c, *Hpl_c, *err_c, *chi2e_c, *part_pose, *part_chi;
     double *poses_w, *points_w;      // the same state arrays, writable (LM update / restore)
     double *poses_bk, *points_bk, *Y_c, *Dinv, *xl;
+    double *sc_p, *sc_l;
 };
 const BaDev *ygz_ba_table(ygz_hip_ctx *ctx, int *rc);        // device table of all uploaded windows, rebuilt when dirty
 

@@ -253,6 +253,19 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
     prob.poses = poses_io; prob.points = points_io;
     int rc = ygz_hip_ba_upload(ctx, W, &prob);
     if (rc != YGZ_OK) return rc;
+    {   // the whole trust-region loop on the GPU when the reduced system fits LDS (ba_resident_lm.hip::k_ba_ceres); YGZ_BA_HOST_LOOP=1
+        // forces the loop below (reduced system on the host; also the path for repeated (point, pose) edges and large windows)
+        int Kfree = 0;
+        for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
+        const char *force = getenv("YGZ_BA_HOST_LOOP");
+        if (Kfree <= 14 && K <= 16 && !(force && force[0] == '1') && !ygz_ba_window_has_dup(ctx, W)) {
+            ygz_ceres_summary sm;
+            if ((rc = ygz_hip_ba_solve_ceres_resident(ctx, W, 1, &opt, &sm)) != YGZ_OK) return rc;
+            if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;
+            if (summary) *summary = sm;
+            return YGZ_OK;
+        }
+    }
     BlockSystem BS; block_system_init(BS, pb);
     const std::vector<int> &fidx = BS.free_idx;
     std::vector<double> Hpp((size_t)K * 36), bp((size_t)K * 6), Hll((size_t)P * 9), bl((size_t)P * 3), Hpl((size_t)std::max(E, 1) * 18);
