@@ -15,6 +15,7 @@
 // train index, exactly the order-dependent "strictly smaller replaces" rule of OpenCV.
 #include "ygz_internal.h"
 #include <string.h>
+#include <stdlib.h>
 
 #define HM_TILE 256
 #ifndef HM_ROWS
@@ -109,6 +110,135 @@ __global__ __launch_bounds__(256) void k_hamming_nn(HamArgs A)
     }
 }
 
+// ---- the same nearest-neighbour search on the matrix cores --------------------------------------------------------------------------
+// popcount(a ^ b) = |a| + |b| - 2 a.b with a.b the dot product of the two descriptors as 0/1 vectors of length 256: the 1000 x 1000
+// distance matrix of a frame pair is an int8 GEMM with K = 256 (5.4e8 multiply-adds) plus rank-one terms, so the search runs on
+// v_mfma_i32_32x32x32_i8 and the VALU only has to (a) turn bits into bytes and (b) keep the running minimum.
+//  (a) bit i of a byte stays where it is: the B operand's byte is w & (1 << i) = b 2^i (ONE v_and per 4 bytes), the A operand's byte
+//      is -a 2^(6 - i), every product is -64 a b.  Bit 7 would be the sign bit: it is read as (w >> 1) & 0x40 against A's -a.
+//      K-step s of lane (l31, half) covers byte-bit i = 4 (s & 1) + {0..3} of dword 4 half + (s >> 1): a lane touches 16 bytes of
+//      its row.  Any bijection bit -> k shared by the two operands gives the same dot product.
+//  (b) the accumulator holds -64 a.b, so key = (|b| + 512) << 16 | column, plus acc << 11, is ONE v_lshl_add; |a| is constant along
+//      a matrix row and is added after the search.  Keys order by distance, then by column: the first minimum wins as in the
+//      reference's scan.  The running minima are per (row, column mod 32); the 32-lane reduction happens once, after the last tile.
+// A wavefront owns 32 RG rows of set A -- expanded once, 32 RG VGPRs -- and walks set B in tiles of 32 rows, every expanded B
+// operand feeding RG independent accumulator chains.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+// + 4 (lane >> 5).
+typedef int hm_v4i __attribute__((ext_vector_type(4)));
+typedef int hm_v16i __attribute__((ext_vector_type(16)));
+#define HM_RG 2                                                      // row groups of 32 per wavefront
+
+__device__ __forceinline__ hm_v4i hm_expand_a(uint32_t w, int hi)
+{   // byte-bits 4 hi + {0..3} of the 4 bytes of w -> -2^(6 - i) (bit 7: -1)
+    hm_v4i r;
+    const uint32_t x = w >> (4 * hi);
+    uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u, b2 = (x >> 2) & 0x01010101u, b3 = (x >> 3) & 0x01010101u;
+    const int sh = 6 - 4 * hi;                                       // i = 4 hi + q -> shift 6 - i = sh - q ; the last one (i = 7) is 0
+    b0 <<= sh; b1 <<= sh - 1; b2 <<= sh - 2; b3 <<= (hi ? 0 : sh - 3);
+    // per-byte negation: bytes are 0 or a power of two <= 64, so (0x80 - b) ^ 0x80 is the two's complement byte without borrows
+    r.x = (int)((0x80808080u - b0) ^ 0x80808080u); r.y = (int)((0x80808080u - b1) ^ 0x80808080u);
+    r.z = (int)((0x80808080u - b2) ^ 0x80808080u); r.w = (int)((0x80808080u - b3) ^ 0x80808080u);
+    return r;
+}
+
+__device__ __forceinline__ hm_v4i hm_expand_b(uint32_t w, int hi)
+{   // byte-bits 4 hi + {0..3} of the 4 bytes of w -> 2^i (bit 7: 2^6)
+    hm_v4i r;
+    if (hi == 0) { r.x = (int)(w & 0x01010101u); r.y = (int)(w & 0x02020202u); r.z = (int)(w & 0x04040404u); r.w = (int)(w & 0x08080808u); }
+    else         { r.x = (int)(w & 0x10101010u); r.y = (int)(w & 0x20202020u); r.z = (int)(w & 0x40404040u); r.w = (int)((w >> 1) & 0x40404040u); }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A)
+{
+    const int p = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sa = A.pair_a[p], sb = A.pair_b[p];
+    const int nA = A.set_count[sa], nB = A.set_count[sb];
+    const int r0 = (blockIdx.y * 4 + wv) * (32 * HM_RG);
+    if (r0 >= nA) return;                                            // wave-uniform; no block-level barrier below
+    const uint32_t *da = A.desc + (size_t)sa * A.set_stride, *db = A.desc + (size_t)sb * A.set_stride;
+    const int half = lane >> 5, l31 = lane & 31;
+    // ---- this wavefront's rows of A: lane (l31, half) holds dwords [4 half, 4 half + 4) of rows r0 + 32 g + l31
+    hm_v4i Aop[HM_RG][8];
+    int pa[HM_RG];                                                   // |a| of row r0 + 32 g + l31
+#pragma unroll
+    for (int g = 0; g < HM_RG; ++g) {
+        uint4 a = make_uint4(0, 0, 0, 0);
+        const int row = r0 + 32 * g + l31;
+        if (row < nA) a = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[half];
+        const uint32_t w[4] = { a.x, a.y, a.z, a.w };
+        int pc = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) Aop[g][s] = hm_expand_a(w[s >> 1], s & 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pc += __popc(w[q]);
+        pa[g] = pc + __shfl_xor(pc, 32);
+    }
+    uint32_t run[HM_RG][16];
+#pragma unroll
+    for (int g = 0; g < HM_RG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) run[g][r] = 0xffffffffu;
+    const int n_tiles = (nB + 31) >> 5;
+    uint4 b = make_uint4(0, 0, 0, 0);                                // software pipeline: the next tile's rows are in flight
+    if (l31 < nB) b = reinterpret_cast<const uint4 *>(db + 8 * (size_t)l31)[half];
+    for (int t = 0; t < n_tiles; ++t) {
+        const int j = 32 * t + l31;
+        const uint32_t w[4] = { b.x, b.y, b.z, b.w };
+        {
+            const int jn = j + 32;
+            b = make_uint4(0, 0, 0, 0);
+            if (jn < nB) b = reinterpret_cast<const uint4 *>(db + 8 * (size_t)jn)[half];
+        }
+        hm_v16i acc[HM_RG];
+#pragma unroll
+        for (int g = 0; g < HM_RG; ++g) acc[g] = (hm_v16i){ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const hm_v4i Bop = hm_expand_b(w[s >> 1], s & 1);
+#pragma unroll
+            for (int g = 0; g < HM_RG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[g][s], Bop, acc[g], 0, 0, 0);
+        }
+        int pb = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
+        pb += __shfl_xor(pb, 32);
+        // key = (|b| + 512 - 2 a.b) << 16 | j ; columns past the end of B can never win
+        const uint32_t kc = (j < nB) ? (((uint32_t)(pb + 512) << 16) | (uint32_t)j) : 0xfffe0000u;
+#pragma unroll
+        for (int g = 0; g < HM_RG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) run[g][r] = min(run[g][r], kc + ((uint32_t)acc[g][r] << 11));
+    }
+    // ---- minimum over the 32 columns-mod-32 of every row: the lanes of one half hold the same 16 rows
+    const int rowl = (l31 & 3) + 8 * ((l31 & 15) >> 2) + 4 * half;
+#pragma unroll
+    for (int g = 0; g < HM_RG; ++g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            uint32_t v = run[g][r];
+            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));    // row_half_mirror
+            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));    // row_mirror
+            v = min(v, (uint32_t)__shfl_xor((int)v, 16));                                              // the two rows of 16 of this half
+            run[g][r] = v;
+        }
+        // lane (half, l31 = r < 16) writes row (r & 3) + 8 (r >> 2) + 4 half of the group
+        const int row = r0 + 32 * g + rowl;
+        const int pa_row = __shfl(pa[g], rowl);                      // |a| lives in lane rowl; every lane takes part in the shuffle
+        if (l31 < 16 && row < nA) {
+            uint32_t key = run[g][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) key = (l31 == r) ? run[g][r] : key;
+            int idx = -1, dist = 0x7FFFFFFF;
+            if (nB > 0) { idx = (int)(key & 0xffffu); dist = (int)(key >> 16) - 512 + pa_row; }
+            const size_t o = (size_t)p * A.out_stride + row;
+            A.out_idx[o] = idx; A.out_dist[o] = dist;
+            if (A.scatter_key && idx >= 0)
+                atomicMin(&A.scatter_key[(size_t)p * A.out_stride + idx], ((unsigned long long)(uint32_t)dist << 32) | (uint32_t)row);
+        }
+    }
+}
+
 // cross_check 1: decode the scatter keys; cross_check 2: mutual test qi -> tq
 __global__ __launch_bounds__(256) void k_match_finalize(const int32_t *__restrict__ set_count, const int32_t *__restrict__ pair_q,
                                                         size_t out_stride, int mode, const unsigned long long *__restrict__ key,
@@ -140,12 +270,15 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
     const dim3 grid(n_pairs, ygz_div_up(max_rows, 256)), block(256), grid_f(ygz_div_up(max_rows, 256), n_pairs);
     const dim3 grid_s(n_pairs, ygz_div_up(max_rows, 256 * HM_ROWS));
     const bool wide = max_rows > 0xFFFF;              // the <false> kernel packs (distance, row) into one 32-bit key
+    static const bool valu_only = [] { const char *e = getenv("YGZ_HAMMING_VALU"); return e && e[0] == '1'; }();   // A/B switch: the VALU form
+    const dim3 grid_m(n_pairs, ygz_div_up(max_rows, 128 * HM_RG));
     if (cross_check == 0 || cross_check == 2) {       // query -> train
         A.pair_a = pair_q; A.pair_b = pair_t;
         A.out_idx = ctx->m_idx; A.out_dist = ctx->m_dist; A.out_dist2 = want_second ? ctx->m_dist2 : nullptr;
         A.scatter_key = nullptr;
         if (want_second || wide) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<true, 1>), grid, block, A);
-        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
+        else if (valu_only) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block, A);
     }
     if (cross_check == 1 || cross_check == 2) {       // train -> query
         if (cross_check == 1)
@@ -154,7 +287,8 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
         A.out_idx = ctx->m_tq; A.out_dist = ctx->m_td; A.out_dist2 = nullptr;
         A.scatter_key = (cross_check == 1) ? ctx->m_key : nullptr;
         if (wide) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<true, 1>), grid, block, A);
-        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
+        else if (valu_only) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block, A);
         YGZ_LAUNCH(ctx, KID_MATCH_FINALIZE, k_match_finalize, grid_f, block, set_count, pair_q, Cn, cross_check,
                            ctx->m_key, ctx->m_tq, ctx->m_idx, ctx->m_dist);
     }
