@@ -215,8 +215,8 @@ def cpu_baseline(pipe, budget_s=12.0):
 
 
 def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
-    """VALU issue roofline of k_klt3 (the probed launches of the timed region) and of k_hamming_nn (probed here, outside the timed
-    region): wave64 VALU instructions per launch (profiles/valu_counts.json: SQ_INSTS_VALU of a counter pass, scaled to this batch and
+    """VALU issue roofline of k_klt3 (the probed launches of the timed region, and alone) and the matrix-core roofline of the
+    matcher k_hamming_mfma (probed here, outside the timed region): wave64 VALU instructions per launch (profiles/valu_counts.json: SQ_INSTS_VALU of a counter pass, scaled to this batch and
     keypoint count) / launch time / SIMDs, against the issue ceiling of the kernel's opcode mix (profiles/valu_mix.json from
     tools/valu_mix.py + the per-opcode rates measured by tools/ubench/valu_peak, profiles/r02_valu_peak.txt)."""
     base = os.path.join(ROOT, "profiles")
@@ -242,13 +242,30 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
         out["kernels"]["k_klt3"] = entry("k_klt3", counts["kernels"]["k_klt3"]["valu_per_unit"], n_kp / kp_ref, probe_avg_s, "HIP events inside the timed region")
     c = pipe.ctx
     c.synchronize()
+    if probe_kernel == "k_klt":                               # the same launch with the GPU to itself (in the step it shares the CUs with the side streams)
+        c.probe_begin("k_klt", 64)
+        for _ in range(3):
+            c.track_klt()
+        ms, n = c.probe_end()
+        if n:
+            e = out["kernels"]["k_klt3"]
+            alone = e["valu_instr_per_launch"] / n_simd / (ms / n * 1e-3) / 1e9
+            e["alone"] = {"avg_launch_us": ms / n * 1e3, "achieved": alone, "frac": alone / e["issue_ceiling_of_the_mix"],
+                          "timed": "HIP events, 3 runs of the LK stage alone after the timed region (%d launches)" % n}
+    # the matcher runs on the matrix cores (k_hamming_mfma): int8 multiply-adds of the 0/1 expansion, 2 x 256 x |A| x |B| per direction
     c.probe_begin("k_hamming_nn", 64)
     for _ in range(3):
         c.match_slots_again(1)
     ms, n = c.probe_end()
     if n:
-        out["kernels"]["k_hamming_nn"] = entry("k_hamming_nn", counts["kernels"]["k_hamming_nn"]["valu_per_unit"], (n_kp / kp_ref) ** 2, ms / n * 1e-3,
-                                               "HIP events, 3 runs of the matcher stage alone after the timed region (%d launches)" % n)
+        ops = 2.0 * 256.0 * n_kp * n_kp * a.batch            # per launch: every pair of the batch, one direction
+        t = ms / n * 1e-3
+        out["mfma"] = {"kernel": "k_hamming_mfma", "bound": "mfma", "unit": "TOP/s (int8)", "ops_per_launch": ops, "avg_launch_us": t * 1e6,
+                       "achieved": ops / t / 1e12, "peak": 5000.0, "peak_measured_guide": 3944.0, "frac": ops / t / 1e12 / 5000.0,
+                       "frac_of_measured_peak": ops / t / 1e12 / 3944.0,
+                       "note": "algorithmic ops (unpadded |A| x |B| x 256 x 2); peak = dense int8 MFMA of MI355X_MICROARCH.md (2 x the 2.5 PFLOP/s bf16 "
+                               "peak; its micro-benchmark reaches 3944); the VALU side of the kernel expands bits to bytes and keeps the running minima",
+                       "timed": "HIP events, 3 runs of the matcher stage alone after the timed region (%d launches)" % n}
     return out
 
 

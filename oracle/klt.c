@@ -33,6 +33,9 @@ static inline int refl101(int i, int n)
     return i;
 }
 
+/* analysis tap (tools/klt_iter_stats.py): when set, [n][YO_MAX_LEVELS] mismatch evaluations per point and level */
+int *yo_klt_iter_log = NULL;
+
 typedef struct { int w, h; uint8_t *img; int16_t *deriv; /* [h][w][2] */ } klt_level;
 
 static inline int I_at(const klt_level *L, int x, int y)
@@ -122,6 +125,7 @@ void yo_klt_track(const uint8_t *prev, const uint8_t *next, int w, int h,
     for (int level = max_level; level >= 0; --level) {
         const klt_level *I = &pl[level], *J = &nl[level];
         for (int p = 0; p < n; ++p) {
+            if (yo_klt_iter_log) yo_klt_iter_log[(size_t)p * YO_MAX_LEVELS + level] = 0;
             const float s = (float)(1. / (1 << level));
             float prevx = prev_pts[2 * p] * s, prevy = prev_pts[2 * p + 1] * s;
             float nx, ny;
@@ -174,6 +178,7 @@ void yo_klt_track(const uint8_t *prev, const uint8_t *next, int w, int h,
                     if (level == 0) status[p] = 0;
                     break;
                 }
+                if (yo_klt_iter_log) yo_klt_iter_log[(size_t)p * YO_MAX_LEVELS + level] = j + 1;
                 a = nx - inx; b = ny - iny;
                 iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
                 iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
