@@ -854,6 +854,33 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
     ctx.close()
 
 
+def test_ba_optimize_resident_team_size_invariance(hip_lib):
+    """k_ba_lm_team gives a window to 1, 2, 4 or 8 cooperating workgroups depending on how many windows the launch holds; the points
+    are reduced in 8 fixed parts whatever the team size, so the optimum, the trial sequence and the refined state must be BIT-identical
+    (this is what keeps a sharded offline run equal to the unsharded one).  The same window solved alone (8 workgroups), among 10
+    (4), among 20 (2) and among 70 (1)."""
+    w = synth.ba_window(8, 1500, seed=21)
+    others = synth.ba_window(4, 60, seed=22)
+    ctx = make_ctx(hip_lib, max_frames=1)
+    N = 70
+    for i in range(N):
+        u = w if i == 0 else others
+        ctx.ba_upload(i, u["poses"], u["fixed"], u["points"], u["edge_pose"], u["edge_point"], u["obs"])
+    ref = None
+    for n_launch in (1, 10, 20, N):
+        ctx.ba_set_state(0, w["poses"], w["points"])
+        for i in range(1, n_launch):
+            ctx.ba_set_state(i, others["poses"], others["points"])
+        st = ctx.ba_optimize_resident(0, n_launch, iterations=20)[0]
+        pg, tg = ctx.ba_get_state(0, len(w["poses"]), len(w["points"]))
+        cur = (st.iterations, st.lm_trials, st.chi2_initial, st.chi2_final, st.lambda_final, pg.tobytes(), tg.tobytes())
+        assert st.chi2_final < 0.1 * st.chi2_initial
+        if ref is None:
+            ref = cur
+        assert cur == ref, n_launch
+    ctx.close()
+
+
 # ------------------------------------------------------------------------------------- M4 / M5 (SURVEY 8f-2): BoW-guided matching
 def test_bow_transform_and_guided_matching(hip_lib, oracle):
     """Frame::ComputeBoW (DBoW3 tree descent), Matcher::SearchByBoW and Matcher::SearchForTriangulation on extracted frames

@@ -1,24 +1,26 @@
 // SURVEY 8f-1 -- the whole Levenberg-Marquardt loop of ba::LocalBAG2O (src/Algorithm/BA.cpp:390-395,501-502: g2o
 // OptimizationAlgorithmLevenberg + BlockSolver_6_3 with marginalised points + a Cholesky solve of the reduced pose system)
-// resident on the GPU: one workgroup per BA window runs linearisation, Schur complement, Cholesky, back-substitution, state
-// update, trial evaluation and the lambda policy without a host round trip, so hundreds of windows optimise concurrently
-// (one per CU).  The host-loop form (ba_lm.hip::ygz_hip_ba_optimize) keeps the same arithmetic with the reduced system on the
+// resident on the GPU: a team of 1-8 workgroups per BA window (k_ba_lm_team, see there) runs linearisation, Schur complement,
+// Cholesky, back-substitution, state update, trial evaluation and the lambda policy without a host round trip; hundreds of
+// windows optimise concurrently (one per CU), a handful use eight CUs each.  The host-loop form (ba_lm.hip::ygz_hip_ba_optimize) keeps the same arithmetic with the reduced system on the
 // CPU; oracle/ceres_ba.c::yo_g2o_lm restates it for the tests [frozen spec of g2o, see there].
 //
 // Per LM trial and window (K <= 16 poses, 14 of them free; P points; E edges):
 //   1. Dinv_l = (Hll_l + lambda I)^-1 and Y_e = Hpl_e Dinv_l per point (lane = point).
-//   2. S = blockdiag(Hpp + lambda I) - sum_l Y_a(l) Hpl_b(l)^T: one wavefront per pose pair (a <= b) sweeps the points 64 at a
-//      time through the (point, pose) -> edge table, accumulates the 6x6 block in registers and reduces it in a fixed order
-//      (no floating-point atomics); S lives in LDS (84 x 84 doubles).
+//   2. S = blockdiag(Hpp + lambda I) - sum_l Y_a(l) Hpl_b(l)^T: one wavefront per (pose pair a <= b, part of the points) sweeps
+//      its points 128 at a time through the (point, pose) -> edge table, accumulates the 6x6 block in registers and reduces it
+//      in a fixed order (no floating-point atomics); S lives in LDS (84 x 84 doubles).
 //   3. right-looking Cholesky in LDS (the same subtraction order per element as the host's left-looking loop), column-oriented
 //      forward / backward substitution inside one wavefront.
 //   4. x_l = Dinv_l (b_l - sum_e Hpl_e^T x_p) (lane = point), oplus on the poses (lane = pose), trial chi2, rho, lambda.
 #include "ba_dev.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include <string.h>
 #include <float.h>
 
-#define LM_THREADS 1024
+#define LM_THREADS 512
 #define LM_WAVES   (LM_THREADS / 64)
 #define LM_MAXKF   14
 #define LM_MAXN    (6 * LM_MAXKF)
@@ -119,67 +121,267 @@ __device__ double lm_errors(const BaDev &B, double *red)
     return lm_block_sum(chi, red);
 }
 
-__global__ __launch_bounds__(LM_THREADS) void k_ba_lm(const BaDev *__restrict__ wins, int max_iterations, ygz_ba_stats *__restrict__ stats)
+// Schur complement of the point blocks: S(a,b) -= sum_l Y_a(l) W_b(l)^T and bs_a -= sum_l Y_a(l) b_l over the points l seen by both
+// free poses a <= b.  One wavefront per pose pair, lanes over the points, a fixed-order wavefront sum at the end.  The sweep is
+// bound by the latency of its two dependent loads (edge slot of the point in pose a / b, then the 36 block entries), so every lane
+// keeps TWO points in flight and the slots of the next two are requested before the blocks of the current ones are used.
+// sc_p / sc_l (SC: ceres' Jacobi scaling): W and b_l are taken column-scaled, (Hpl * s_pose) * s_point as the host-loop form does.
+template <bool SC>
+__device__ __forceinline__ void lm_sweep_point(const BaDev &B, int l, int ca, int cb, bool diag, const double *spb, const double *sc_l,
+                                               double *acc /*[36]*/, double *accb /*[6]*/)
+{
+    const bool v = ca >= 0 && cb >= 0;
+    const int row0 = v ? B.slot_off[l >> 6] : 0, ln = l & 63;
+    double Ya[18], Wb[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) { Ya[i] = v ? BA_EC(B.Y_c, row0 + ca, 18, i, ln) : 0.0; Wb[i] = v ? BA_EC(B.Hpl_c, row0 + cb, 18, i, ln) : 0.0; }
+    double s0 = 1.0, s1 = 1.0, s2 = 1.0;
+    if (SC && v) { s0 = sc_l[3 * (size_t)l]; s1 = sc_l[3 * (size_t)l + 1]; s2 = sc_l[3 * (size_t)l + 2]; }
+    if (SC) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { Wb[3 * c] = Wb[3 * c] * spb[c] * s0; Wb[3 * c + 1] = Wb[3 * c + 1] * spb[c] * s1; Wb[3 * c + 2] = Wb[3 * c + 2] * spb[c] * s2; }
+    }
+    if (v) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * r + c] = fma(Ya[3 * r + 2], Wb[3 * c + 2], fma(Ya[3 * r + 1], Wb[3 * c + 1], fma(Ya[3 * r], Wb[3 * c], acc[6 * r + c])));
+        }
+        if (diag) {
+            double g0 = BA_PC(B.bl_c, l, 3, 0), g1 = BA_PC(B.bl_c, l, 3, 1), g2 = BA_PC(B.bl_c, l, 3, 2);
+            if (SC) { g0 *= s0; g1 *= s1; g2 *= s2; }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) accb[r] += Ya[3 * r] * g0 + Ya[3 * r + 1] * g1 + Ya[3 * r + 2] * g2;
+        }
+    }
+}
+
+template <bool SC>
+__device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double *bs, int n, const double *sc_p, const double *sc_l)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Kf = B.Kf, P = B.P, npairs = Kf * (Kf + 1) / 2;
+    for (int pr = wv; pr < npairs; pr += LM_WAVES) {
+        int a = 0, rem = pr;
+        while (rem >= Kf - a) { rem -= Kf - a; ++a; }
+        const int b = a + rem;
+        double acc[36], accb[6], spb[6];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) accb[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) spb[c] = SC ? sc_p[6 * (size_t)B.free_pose[b] + c] : 1.0;
+        int l = lane;
+        int ca0 = l < P ? B.ppc[(size_t)l * Kf + a] : -1, cb0 = l < P ? B.ppc[(size_t)l * Kf + b] : -1;
+        int ca1 = l + 64 < P ? B.ppc[(size_t)(l + 64) * Kf + a] : -1, cb1 = l + 64 < P ? B.ppc[(size_t)(l + 64) * Kf + b] : -1;
+        for (int base = 0; base < P; base += 128, l += 128) {           // wave-uniform trip count
+            const int na0 = l + 128 < P ? B.ppc[(size_t)(l + 128) * Kf + a] : -1, nb0 = l + 128 < P ? B.ppc[(size_t)(l + 128) * Kf + b] : -1;
+            const int na1 = l + 192 < P ? B.ppc[(size_t)(l + 192) * Kf + a] : -1, nb1 = l + 192 < P ? B.ppc[(size_t)(l + 192) * Kf + b] : -1;
+            lm_sweep_point<SC>(B, l, ca0, cb0, a == b, spb, sc_l, acc, accb);
+            lm_sweep_point<SC>(B, l + 64, ca1, cb1, a == b, spb, sc_l, acc, accb);
+            ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
+        }
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] = lm_wave_sum(acc[i]);
+        if (a == b) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) accb[i] = lm_wave_sum(accb[i]);
+        }
+        if (lane == 0) {
+            for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+                S[(6 * a + r) * n + 6 * b + c] -= acc[6 * r + c];
+                if (a != b) S[(6 * b + c) * n + 6 * a + r] -= acc[6 * r + c];
+            }
+            if (a == b) for (int r = 0; r < 6; ++r) bs[6 * a + r] -= accb[r];
+        }
+    }
+}
+
+// =====================================================================================================================================
+// The same Levenberg-Marquardt loop by a TEAM of G workgroups per window.  One workgroup per window leaves 255 of the 256 CUs idle
+// when a launch holds a handful of windows (the BA round of the offline run) and is bound by what ONE CU can read: the Schur sweep
+// alone moves 16 MB per trial through one vector memory pipeline.  Here the points of a window are cut into LM_V = 8 fixed PARTS
+// (whole 64-point chunks); a part is always reduced by one workgroup in one fixed order and the parts are combined in part order,
+// so the result does not depend on G (1, 2, 4 or 8 workgroups: the launch picks G from the number of windows, and a sharded and an
+// unsharded offline run stay bit-identical).  Per trial: every workgroup inverts the point blocks of its parts (Y = Hpl Dinv) |
+// barrier | one wavefront per (pose pair, part) forms that part's share of the Schur complement | barrier | workgroup 0 assembles S,
+// factors it and publishes x_p | barrier | every workgroup back-substitutes its points, applies the update and evaluates the errors
+// of the trial state | barrier (partials of scale / chi2) | every workgroup takes the same accept / reject decision.  The pose state
+// is private to a workgroup (identical copies): a shared copy updated by everybody would be a read-modify-write race.
+// Barriers: one monotonic counter per window, lane 0 releases at agent scope before it arrives and acquires after the wait
+// (MI355X: per-CU L1 and per-XCD L2 are not coherent); cross-workgroup scalars travel through agent-scope atomics.  All blocks of
+// a team must be resident: the launch keeps windows x G <= 64 workgroups (a CU holds one of these), every wait is bounded and a
+// timeout aborts the whole team with YGZ_E_HIP.  blockIdx -> (XCD slot, team member): the members of a team share an XCD / L2
+// when the dispatcher places block b on XCD b % 8 (speed only).
+#define LM_V      8
+#define LM_PARTW  (8 + 27 * LM_MAXKF)          // per part: chi2, max |diag|, singular flag, scale, trial chi2, -, -, -, pose sums [Kf][27]
+#define LM_SPW    42                           // per (pair, part): 36 block entries + 6 of the right-hand side
+
+struct LmTeamArgs {
+    const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
+    unsigned char *scratch; size_t stride;     // per window: bar[4] u32, behind-camera counts [8] i32 | xpub | part | Sp | private pose state of the G members
+    int Kmax;
+};
+
+__device__ __forceinline__ double tl_ld(const double *p)
+{ return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void tl_st(double *p, double v)
+{ __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// false: a member did not arrive in time (or another member gave up): the caller returns, the host reports YGZ_E_HIP
+__device__ __forceinline__ bool lm_team_barrier(unsigned *bar, unsigned &epoch, int G, int *s_ok)
+{
+    if (G == 1) { __syncthreads(); return true; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wavefront drains its own stores
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)G;
+        int ok = 1;
+        for (unsigned spins = 0; __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spins) {
+            if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+            if (spins > (1u << 22)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+__global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 {
     __shared__ double S[LM_MAXN * LM_MAXN];
     __shared__ double bs[LM_MAXN], xp[LM_MAXN];
+    __shared__ double sH[LM_MAXKF][28];            // Hpp upper triangle (21) + bp (6) of the free poses at the linearisation point
     __shared__ double red27[LM_WAVES][28];
     __shared__ double red[LM_WAVES];
-    __shared__ int s_fail;
-    const BaDev B = wins[blockIdx.x];
+    __shared__ int s_fail, s_ok;
+    const int G = A.G;
+    const int xslot = blockIdx.x & 7, j = blockIdx.x >> 3, g = j % G, w = (j / G) * 8 + xslot;
+    if (w >= A.n_windows) return;
+    BaDev B = A.wins[w];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf;
+    const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf, Q = B.Q, npairs = Kf * (Kf + 1) / 2;
+    unsigned char *scr = A.scratch + (size_t)w * A.stride;
+    unsigned *bar = reinterpret_cast<unsigned *>(scr);
+    double *xpub = reinterpret_cast<double *>(scr + 48);                       // [LM_MAXN + 2]
+    double *part = xpub + LM_MAXN + 2;                                          // [LM_V][LM_PARTW]
+    double *Sp = part + (size_t)LM_V * LM_PARTW;                                // [npairs][LM_V][LM_SPW]
+    double *priv = Sp + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW + (size_t)g * A.Kmax * (6 + 6 + BA_POSED);
+    double *my_poses = priv, *my_bk = priv + 6 * (size_t)A.Kmax, *my_posed = my_bk + 6 * (size_t)A.Kmax;
+    double *const out_poses = B.poses_w;
+    int32_t *const n_behind = B.n_behind;
+    B.n_behind = reinterpret_cast<int32_t *>(bar + 4 + g);                     // the member's own count of edges behind the camera
+    // the member's private pose state replaces the window's arrays in everything below
+    for (int i = tid; i < 6 * K; i += LM_THREADS) my_poses[i] = B.poses[i];
+    B.poses = my_poses; B.poses_w = my_poses; B.poses_bk = my_bk; B.posed = my_posed;
+    unsigned epoch = 0;
+    __syncthreads();
+
     double lambda = 0.0, ni = 2.0, currentChi = 0.0, chi_initial = 0.0;
     int iterations = 0, trials = 0;
+#define LM_PART_RANGE(v) const int p0_ = 64 * (int)(((long long)(v) * Q) / LM_V), p1_ = min(P, 64 * (int)(((long long)((v) + 1) * Q) / LM_V));
 
-    for (int it = 0; it < max_iterations; ++it) {
-        currentChi = lm_linearize(B, red27, red);
-        if (it == 0) {
-            chi_initial = currentChi;
-            double mx = 0.0;                                        // computeLambdaInit: tau * max |diag| over the active vertices
-            for (int i = tid; i < 6 * Kf; i += LM_THREADS) mx = fmax(mx, fabs(B.Hpp[36 * (size_t)B.free_pose[i / 6] + 7 * (i % 6)]));
-            for (int i = tid; i < 3 * P; i += LM_THREADS) mx = fmax(mx, fabs(BA_PC(B.Hll_c, i / 3, 9, 4 * (i % 3))));
-            lambda = 1e-5 * lm_block_max(mx, red); ni = 2.0;
+    for (int it = 0; it < A.max_iterations; ++it) {
+        // ---- computeActiveErrors + buildSystem: per part chi2, max |diag Hll|, the 27 sums of every free pose
+        if (tid < K) ba_pose_prep_one(B, tid);
+        if (tid == 0) __hip_atomic_store(B.n_behind, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        for (int v = g; v < LM_V; v += G) {
+            LM_PART_RANGE(v)
+            double chi = 0.0, mx = 0.0;
+            for (int il = p0_ + tid; il < p1_; il += LM_THREADS) {
+                chi += ba_point_edges(B, il);
+                if (it == 0) for (int d = 0; d < 3; ++d) mx = fmax(mx, fabs(BA_PC(B.Hll_c, il, 9, 4 * d)));
+            }
+            chi = lm_block_sum(chi, red);
+            if (it == 0) mx = lm_block_max(mx, red);
+            if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW, chi); if (it == 0) tl_st(part + (size_t)v * LM_PARTW + 1, mx);
+                            tl_st(part + (size_t)v * LM_PARTW + 5, (double)__hip_atomic_load(B.n_behind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            __hip_atomic_store(B.n_behind, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            for (int a = 0; a < Kf; ++a) {
+                double acc[27];
+#pragma unroll
+                for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+                for (int il = p0_ + tid; il < p1_; il += LM_THREADS) ba_pose_contrib(B, il, a, acc);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 27; ++i) { const double t = lm_wave_sum(acc[i]); if (lane == 0) red27[wv][i] = t; }
+                __syncthreads();
+                if (tid < 27) {
+                    double t = 0.0;
+                    for (int ww = 0; ww < LM_WAVES; ++ww) t += red27[ww][tid];
+                    tl_st(part + (size_t)v * LM_PARTW + 8 + 27 * a + tid, t);
+                }
+            }
+        }
+        if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+        {   // every member adds the parts in part order: identical sH, chi2 (and lambda at the first iteration)
+            for (int i = tid; i < 27 * Kf; i += LM_THREADS) {
+                double t = 0.0;
+                for (int v = 0; v < LM_V; ++v) t += tl_ld(part + (size_t)v * LM_PARTW + 8 + i);
+                sH[i / 27][i % 27] = t;
+            }
+            double chi = 0.0, mx = 0.0;
+            for (int v = 0; v < LM_V; ++v) { chi += tl_ld(part + (size_t)v * LM_PARTW); if (it == 0) mx = fmax(mx, tl_ld(part + (size_t)v * LM_PARTW + 1)); }
+            currentChi = chi;
+            __syncthreads();
+            if (g == 0 && tid == LM_THREADS - 1) { double nb = 0.0; for (int v = 0; v < LM_V; ++v) nb += tl_ld(part + (size_t)v * LM_PARTW + 5); *n_behind = (int)nb; }
+            if (g == 0 && tid < 27 * Kf) {                                     // the window's Hpp / bp as the ABI exposes them
+                const int a = tid / 27, i = tid % 27, k = B.free_pose[a];
+                if (i < 21) { int u = 0, rem = i; while (rem >= 6 - u) { rem -= 6 - u; ++u; } const int vv = u + rem;
+                              B.Hpp[36 * (size_t)k + 6 * u + vv] = sH[a][i]; B.Hpp[36 * (size_t)k + 6 * vv + u] = sH[a][i]; }
+                else B.bp[6 * (size_t)k + (i - 21)] = sH[a][i];
+            }
+            if (it == 0) {
+                chi_initial = currentChi;
+                for (int a = 0; a < Kf; ++a) { int q = 0; for (int u = 0; u < 6; ++u) { mx = fmax(mx, fabs(sH[a][q])); q += 6 - u; } }   // diagonal entries of the packed triangle
+                lambda = 1e-5 * mx; ni = 2.0;
+            }
         }
         double rho = 0.0; int qmax = 0;
         do {
-            // ---- _optimizer->push(): backup of the state
-            for (int i = tid; i < 6 * K; i += LM_THREADS) B.poses_bk[i] = B.poses_w[i];
-            for (int i = tid; i < 3 * P; i += LM_THREADS) B.points_bk[i] = B.points_w[i];
+            // ---- push(), 1. Dinv, Y = Hpl Dinv for the member's parts
+            for (int i = tid; i < 6 * K; i += LM_THREADS) my_bk[i] = my_poses[i];
             if (tid == 0) s_fail = 0;
             __syncthreads();
-            // ---- 1. Dinv, Y = Hpl Dinv
-            for (int il = tid; il < P; il += LM_THREADS) {
-                double *Di = B.Dinv + 9 * (size_t)il;
-                if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; continue; }
-                double D[9];
-                for (int i = 0; i < 9; ++i) D[i] = BA_PC(B.Hll_c, il, 9, i);
-                D[0] += lambda; D[4] += lambda; D[8] += lambda;
-                double Dv[9];
-                if (!lm_inv3(D, Dv)) { s_fail = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
-                for (int i = 0; i < 9; ++i) Di[i] = Dv[i];
-                const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
-                for (int c = 0; c < rows; ++c) {
-                    const int row = row0 + c;
-                    if (B.pose_c[(size_t)row * 64 + ln] < 0) continue;
-                    double W[18];
-                    for (int i = 0; i < 18; ++i) W[i] = BA_EC(B.Hpl_c, row, 18, i, ln);
-                    for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc)
-                        BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
+            int bad = 0;
+            for (int v = g; v < LM_V; v += G) {
+                LM_PART_RANGE(v)
+                for (int il = p0_ + tid; il < p1_; il += LM_THREADS) {
+                    for (int d = 0; d < 3; ++d) B.points_bk[3 * (size_t)il + d] = B.points_w[3 * (size_t)il + d];
+                    double *Di = B.Dinv + 9 * (size_t)il;
+                    if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; continue; }
+                    double D[9], Dv[9];
+                    for (int i = 0; i < 9; ++i) D[i] = BA_PC(B.Hll_c, il, 9, i);
+                    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+                    if (!lm_inv3(D, Dv)) { bad = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
+                    for (int i = 0; i < 9; ++i) Di[i] = Dv[i];
+                    const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                    for (int c = 0; c < rows; ++c) {
+                        const int row = row0 + c;
+                        if (B.pose_c[(size_t)row * 64 + ln] < 0) continue;
+                        double W[18];
+                        for (int i = 0; i < 18; ++i) W[i] = BA_EC(B.Hpl_c, row, 18, i, ln);
+                        for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc)
+                            BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
+                    }
                 }
             }
-            // ---- 2. S = blockdiag(Hpp + lambda I), bs = bp
-            for (int i = tid; i < n * n; i += LM_THREADS) {
-                const int r = i / n, c = i - r * n, a = r / 6, b = c / 6;
-                double v = 0.0;
-                if (a == b) { v = B.Hpp[36 * (size_t)B.free_pose[a] + 6 * (r - 6 * a) + (c - 6 * b)]; if (r == c) v += lambda; }
-                S[i] = v;
-            }
-            for (int i = tid; i < n; i += LM_THREADS) bs[i] = B.bp[6 * (size_t)B.free_pose[i / 6] + (i % 6)];
+            if (bad) s_fail = 1;
             __syncthreads();
-            //         S(a,b) -= sum_l Y_a(l) W_b(l)^T, bs_a -= sum_l Y_a(l) b_l: one wavefront per pose pair
-            const int npairs = Kf * (Kf + 1) / 2;
-            for (int pr = wv; pr < npairs; pr += LM_WAVES) {
+            if (tid == 0) for (int v = g; v < LM_V; v += G) tl_st(part + (size_t)v * LM_PARTW + 2, s_fail ? 1.0 : 0.0);
+            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            // ---- 2. one wavefront per (pose pair, part): that part's share of sum_l Y_a(l) W_b(l)^T and sum_l Y_a(l) b_l
+            for (int task = g * LM_WAVES + wv; task < npairs * LM_V; task += G * LM_WAVES) {
+                const int pr = task / LM_V, v = task - pr * LM_V;
+                LM_PART_RANGE(v)
                 int a = 0, rem = pr;
                 while (rem >= Kf - a) { rem -= Kf - a; ++a; }
                 const int b = a + rem;
@@ -188,132 +390,165 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm(const BaDev *__restrict__ 
                 for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) accb[i] = 0.0;
-                for (int l = lane; l < P; l += 64) {
-                    const int ca = B.ppc[(size_t)l * Kf + a], cb = B.ppc[(size_t)l * Kf + b];
-                    if (ca < 0 || cb < 0) continue;
-                    const int row0 = B.slot_off[l >> 6], ln = l & 63;
-                    double Ya[18], Wb[18];
-#pragma unroll
-                    for (int i = 0; i < 18; ++i) { Ya[i] = BA_EC(B.Y_c, row0 + ca, 18, i, ln); Wb[i] = BA_EC(B.Hpl_c, row0 + cb, 18, i, ln); }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) acc[6 * r + c] += Ya[3 * r] * Wb[3 * c] + Ya[3 * r + 1] * Wb[3 * c + 1] + Ya[3 * r + 2] * Wb[3 * c + 2];
-                    }
-                    if (a == b) {
-                        const double g0 = BA_PC(B.bl_c, l, 3, 0), g1 = BA_PC(B.bl_c, l, 3, 1), g2 = BA_PC(B.bl_c, l, 3, 2);
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) accb[r] += Ya[3 * r] * g0 + Ya[3 * r + 1] * g1 + Ya[3 * r + 2] * g2;
-                    }
+                int l = p0_ + lane;
+                int ca0 = l < p1_ ? B.ppc[(size_t)l * Kf + a] : -1, cb0 = l < p1_ ? B.ppc[(size_t)l * Kf + b] : -1;
+                int ca1 = l + 64 < p1_ ? B.ppc[(size_t)(l + 64) * Kf + a] : -1, cb1 = l + 64 < p1_ ? B.ppc[(size_t)(l + 64) * Kf + b] : -1;
+                for (int base = p0_; base < p1_; base += 128, l += 128) {
+                    const int na0 = l + 128 < p1_ ? B.ppc[(size_t)(l + 128) * Kf + a] : -1, nb0 = l + 128 < p1_ ? B.ppc[(size_t)(l + 128) * Kf + b] : -1;
+                    const int na1 = l + 192 < p1_ ? B.ppc[(size_t)(l + 192) * Kf + a] : -1, nb1 = l + 192 < p1_ ? B.ppc[(size_t)(l + 192) * Kf + b] : -1;
+                    lm_sweep_point<false>(B, l, ca0, cb0, a == b, nullptr, nullptr, acc, accb);
+                    lm_sweep_point<false>(B, l + 64, ca1, cb1, a == b, nullptr, nullptr, acc, accb);
+                    ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
                 }
+                double *o = Sp + ((size_t)pr * LM_V + v) * LM_SPW;
 #pragma unroll
-                for (int i = 0; i < 36; ++i) acc[i] = lm_wave_sum(acc[i]);
+                for (int i = 0; i < 36; ++i) { const double t = lm_wave_sum(acc[i]); if (lane == 0) tl_st(o + i, t); }
                 if (a == b) {
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) accb[i] = lm_wave_sum(accb[i]);
+                    for (int i = 0; i < 6; ++i) { const double t = lm_wave_sum(accb[i]); if (lane == 0) tl_st(o + 36 + i, t); }
                 }
-                if (lane == 0) {
-                    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-                        S[(6 * a + r) * n + 6 * b + c] -= acc[6 * r + c];
-                        if (a != b) S[(6 * b + c) * n + 6 * a + r] -= acc[6 * r + c];
+            }
+            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            // ---- 3. member 0: S = blockdiag(Hpp + lambda I) - sum of the parts (in part order), Cholesky, substitutions, publish x_p
+            if (g == 0) {
+                for (int i = tid; i < n * n; i += LM_THREADS) {
+                    const int r = i / n, c = i - r * n, a = r / 6, b = c / 6, rr = r - 6 * a, cc = c - 6 * b;
+                    double t = 0.0;
+                    if (a == b) { const int u = min(rr, cc), vv = max(rr, cc); t = sH[a][u * 6 - u * (u - 1) / 2 + (vv - u)]; if (r == c) t += lambda; }
+                    const int pa = min(a, b), pb = max(a, b), pr = pa * Kf - pa * (pa - 1) / 2 + (pb - pa);
+                    const int e = (a <= b) ? 6 * rr + cc : 6 * cc + rr;        // block (pa, pb) holds rows of pa x columns of pb
+                    double sub = 0.0;
+                    for (int v = 0; v < LM_V; ++v) sub += tl_ld(Sp + ((size_t)pr * LM_V + v) * LM_SPW + e);
+                    S[i] = t - sub;
+                }
+                for (int i = tid; i < n; i += LM_THREADS) {
+                    const int a = i / 6, pr = a * Kf - a * (a - 1) / 2;
+                    double sub = 0.0;
+                    for (int v = 0; v < LM_V; ++v) sub += tl_ld(Sp + ((size_t)pr * LM_V + v) * LM_SPW + 36 + (i % 6));
+                    bs[i] = sH[a][21 + (i % 6)] - sub;
+                }
+                if (tid == 0) { double f = 0.0; for (int v = 0; v < LM_V; ++v) f += tl_ld(part + (size_t)v * LM_PARTW + 2); s_fail = f != 0.0; }
+                __syncthreads();
+                for (int jc = 0; jc < n; ++jc) {
+                    if (tid == 0) { const double d = S[jc * n + jc]; if (!(d > 0) || !isfinite(d)) s_fail = 1; S[jc * n + jc] = sqrt(d > 0 ? d : 1.0); }
+                    __syncthreads();
+                    const double dj = S[jc * n + jc];
+                    for (int i = jc + 1 + tid; i < n; i += LM_THREADS) S[i * n + jc] = S[i * n + jc] / dj;
+                    __syncthreads();
+                    const int m = n - jc - 1;
+                    for (int t = tid; t < m * m; t += LM_THREADS) {
+                        const int i = jc + 1 + t / m, k = jc + 1 + t % m;
+                        if (k <= i) S[i * n + k] -= S[i * n + jc] * S[k * n + jc];
                     }
-                    if (a == b) for (int r = 0; r < 6; ++r) bs[6 * a + r] -= accb[r];
+                    __syncthreads();
                 }
+                if (wv == 0) {
+                    for (int k = 0; k < n; ++k) {
+                        if (lane == 0) bs[k] = bs[k] / S[k * n + k];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        const double yk = bs[k];
+                        for (int i = k + 1 + lane; i < n; i += 64) bs[i] -= S[i * n + k] * yk;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    }
+                    for (int k = n - 1; k >= 0; --k) {
+                        if (lane == 0) bs[k] = bs[k] / S[k * n + k];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                        const double xk = bs[k];
+                        for (int i = lane; i < k; i += 64) bs[i] -= S[k * n + i] * xk;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                    }
+                    for (int i = lane; i < n; i += 64) tl_st(xpub + i, bs[i]);
+                    if (lane == 0) tl_st(xpub + LM_MAXN, s_fail ? 1.0 : 0.0);
+                }
+            }
+            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            for (int i = tid; i < n; i += LM_THREADS) xp[i] = tl_ld(xpub + i);
+            const bool ok2 = tl_ld(xpub + LM_MAXN) == 0.0;
+            __syncthreads();
+            // ---- 4. x_l, update(x), computeScale; then computeActiveErrors at the trial state -- per part
+            if (ok2 && tid < Kf) {
+                const int k = B.free_pose[tid];
+                double pose[6], upd[6];
+                for (int d = 0; d < 6; ++d) { pose[d] = my_poses[6 * (size_t)k + d]; upd[d] = xp[6 * tid + d]; }
+                lm_oplus_pose(pose, upd);
+                for (int d = 0; d < 6; ++d) my_poses[6 * (size_t)k + d] = pose[d];
             }
             __syncthreads();
-            // ---- 3. Cholesky (right-looking) + substitutions
-            for (int j = 0; j < n; ++j) {
-                if (tid == 0) { const double d = S[j * n + j]; if (!(d > 0) || !isfinite(d)) s_fail = 1; S[j * n + j] = sqrt(d > 0 ? d : 1.0); }
-                __syncthreads();
-                const double dj = S[j * n + j];
-                for (int i = j + 1 + tid; i < n; i += LM_THREADS) S[i * n + j] = S[i * n + j] / dj;
-                __syncthreads();
-                const int m = n - j - 1;                              // trailing block: rows i > j, columns j < k <= i
-                for (int t = tid; t < m * m; t += LM_THREADS) {
-                    const int i = j + 1 + t / m, k = j + 1 + t % m;
-                    if (k <= i) S[i * n + k] -= S[i * n + j] * S[k * n + j];
-                }
-                __syncthreads();
-            }
-            if (wv == 0) {                                            // L y = bs, then L^T x = y (column-oriented, one wavefront)
-                for (int k = 0; k < n; ++k) {
-                    if (lane == 0) bs[k] = bs[k] / S[k * n + k];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    const double yk = bs[k];
-                    for (int i = k + 1 + lane; i < n; i += 64) bs[i] -= S[i * n + k] * yk;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                }
-                for (int k = n - 1; k >= 0; --k) {
-                    if (lane == 0) bs[k] = bs[k] / S[k * n + k];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    const double xk = bs[k];
-                    for (int i = lane; i < k; i += 64) bs[i] -= S[k * n + i] * xk;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                }
-                for (int i = lane; i < n; i += 64) xp[i] = bs[i];
-            }
+            if (ok2 && tid < K) ba_pose_prep_one(B, tid);
             __syncthreads();
-            const bool ok2 = s_fail == 0;
-            double scale = 0.0;
+            for (int v = g; v < LM_V; v += G) {
+                LM_PART_RANGE(v)
+                double scale = 0.0, chi = 0.0;
+                if (ok2) {
+                    for (int il = p0_ + tid; il < p1_; il += LM_THREADS) {
+                        if (B.point_fixed[il]) { B.xl[3 * (size_t)il] = B.xl[3 * (size_t)il + 1] = B.xl[3 * (size_t)il + 2] = 0.0; }
+                        else {
+                            double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
+                            const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                            for (int c = 0; c < rows; ++c) {
+                                const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + ln];
+                                if (ip < 0) continue;
+                                const int a = B.free_idx[ip];
+                                if (a < 0) continue;
+                                for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= BA_EC(B.Hpl_c, row, 18, 3 * r + cc, ln) * xp[6 * a + r];
+                            }
+                            const double *Di = B.Dinv + 9 * (size_t)il;
+                            double x3[3];
+                            for (int cc = 0; cc < 3; ++cc) x3[cc] = Di[3 * cc] * r3[0] + Di[3 * cc + 1] * r3[1] + Di[3 * cc + 2] * r3[2];
+                            for (int cc = 0; cc < 3; ++cc) {
+                                B.xl[3 * (size_t)il + cc] = x3[cc];
+                                scale += x3[cc] * (lambda * x3[cc] + BA_PC(B.bl_c, il, 3, cc));
+                                B.points_w[3 * (size_t)il + cc] += x3[cc];
+                            }
+                        }
+                        chi += ba_point_chi2(B, il);                             // the lane's own point at its trial position
+                    }
+                }
+                scale = lm_block_sum(scale, red);
+                chi = lm_block_sum(chi, red);
+                if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW + 3, scale); tl_st(part + (size_t)v * LM_PARTW + 4, chi); }
+            }
+            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            double scale = 0.0, tempChi = DBL_MAX;
             if (ok2) {
-                // ---- 4. x_l, then _optimizer->update(x)
-                for (int il = tid; il < P; il += LM_THREADS) {
-                    if (B.point_fixed[il]) { B.xl[3 * (size_t)il] = B.xl[3 * (size_t)il + 1] = B.xl[3 * (size_t)il + 2] = 0.0; continue; }
-                    double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
-                    const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
-                    for (int c = 0; c < rows; ++c) {
-                        const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + ln];
-                        if (ip < 0) continue;
-                        const int a = B.free_idx[ip];
-                        if (a < 0) continue;
-                        for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= BA_EC(B.Hpl_c, row, 18, 3 * r + cc, ln) * xp[6 * a + r];
-                    }
-                    const double *Di = B.Dinv + 9 * (size_t)il;
-                    double x3[3];
-                    for (int cc = 0; cc < 3; ++cc) x3[cc] = Di[3 * cc] * r3[0] + Di[3 * cc + 1] * r3[1] + Di[3 * cc + 2] * r3[2];
-                    for (int cc = 0; cc < 3; ++cc) {
-                        B.xl[3 * (size_t)il + cc] = x3[cc];
-                        scale += x3[cc] * (lambda * x3[cc] + BA_PC(B.bl_c, il, 3, cc));             // computeScale
-                        B.points_w[3 * (size_t)il + cc] += x3[cc];
-                    }
-                }
-                if (tid < Kf) {
-                    const int k = B.free_pose[tid];
-                    double pose[6], upd[6];
-                    for (int d = 0; d < 6; ++d) { pose[d] = B.poses_w[6 * (size_t)k + d]; upd[d] = xp[6 * tid + d]; scale += upd[d] * (lambda * upd[d] + B.bp[6 * (size_t)k + d]); }
-                    lm_oplus_pose(pose, upd);
-                    for (int d = 0; d < 6; ++d) B.poses_w[6 * (size_t)k + d] = pose[d];
-                }
+                tempChi = 0.0;
+                for (int v = 0; v < LM_V; ++v) { scale += tl_ld(part + (size_t)v * LM_PARTW + 3); tempChi += tl_ld(part + (size_t)v * LM_PARTW + 4); }
+                for (int a = 0; a < Kf; ++a) for (int d = 0; d < 6; ++d) scale += xp[6 * a + d] * (lambda * xp[6 * a + d] + sH[a][21 + d]);
             }
-            scale = lm_block_sum(scale, red);                          // (barriers inside: the trial state is visible)
-            // ---- computeActiveErrors at the trial state
-            double tempChi = DBL_MAX;
-            if (ok2) tempChi = lm_errors(B, red);
             rho = (currentChi - tempChi) / (scale + 1e-3);
             ++trials;
-            if (rho > 0 && isfinite(tempChi)) {                       // good step
+            if (rho > 0 && isfinite(tempChi)) {
                 double alpha = 1. - pow((2 * rho - 1), 3);
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
                 ni = 2; currentChi = tempChi;
-            } else {                                                  // bad step: _optimizer->pop()
+            } else {                                                             // pop(): the member's own points and its pose copy
                 lambda *= ni; ni *= 2;
                 __syncthreads();
-                for (int i = tid; i < 6 * K; i += LM_THREADS) B.poses_w[i] = B.poses_bk[i];
-                for (int i = tid; i < 3 * P; i += LM_THREADS) B.points_w[i] = B.points_bk[i];
+                for (int i = tid; i < 6 * K; i += LM_THREADS) my_poses[i] = my_bk[i];
+                for (int v = g; v < LM_V; v += G) {
+                    LM_PART_RANGE(v)
+                    for (int il = p0_ + tid; il < p1_; il += LM_THREADS)
+                        for (int d = 0; d < 3; ++d) B.points_w[3 * (size_t)il + d] = B.points_bk[3 * (size_t)il + d];
+                }
                 __syncthreads();
                 if (!isfinite(lambda)) break;
             }
             qmax++;
         } while (rho < 0 && qmax < 10);
         ++iterations;
-        if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;        // Terminate
+        if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
     }
-    if (tid == 0) {
-        ygz_ba_stats st;
-        st.iterations = iterations; st.lm_trials = trials; st.chi2_initial = chi_initial; st.chi2_final = currentChi; st.lambda_final = lambda;
-        stats[blockIdx.x] = st;
+    if (g == 0) {
+        __syncthreads();
+        for (int i = tid; i < 6 * K; i += LM_THREADS) out_poses[i] = my_poses[i];
+        if (tid == 0) {
+            ygz_ba_stats st;
+            st.iterations = iterations; st.lm_trials = trials; st.chi2_initial = chi_initial; st.chi2_final = currentChi; st.lambda_final = lambda;
+            A.stats[w] = st;
+        }
     }
+#undef LM_PART_RANGE
 }
 
 extern "C" {
@@ -331,14 +566,31 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);
     if (!table) return rc;
-    void *d_stats = nullptr;
-    if ((rc = ygz_scratch(ctx, SCR_BA_0, (size_t)n_windows * sizeof(ygz_ba_stats), &d_stats)) != YGZ_OK) return rc;
+    // team size: windows x G <= 64 workgroups (each owns a CU; several launches of this kind may share the GPU), G a power of two
+    int G = 1, Kmax = 1;
+    static const bool single = [] { const char *e = getenv("YGZ_BA_LM_TEAM"); return e && e[0] == '1' && e[1] == 0; }();   // A/B switch: one workgroup per window
+    if (!single) while (G < LM_V && n_windows * (2 * G) <= 64) G *= 2;
+    for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
+    size_t stride = 48 + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW
+                                           + (size_t)G * Kmax * (6 + 6 + BA_POSED));
+    stride = (stride + 255) & ~(size_t)255;
+    const size_t stats_bytes = (((size_t)n_windows * sizeof(ygz_ba_stats)) + 255) & ~(size_t)255;
+    void *d_scr = nullptr;
+    if ((rc = ygz_scratch(ctx, SCR_BA_0, stats_bytes + (size_t)n_windows * stride, &d_scr)) != YGZ_OK) return rc;
+    LmTeamArgs A;
+    A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
+    A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax;
     YgzAuxScope aux(ctx, 1);
-    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm, dim3(n_windows), dim3(LM_THREADS), table + window_begin, max_iterations, (ygz_ba_stats *)d_stats);
+    YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, 48, (size_t)n_windows, ctx->stream));         // barrier counters, abort flags
+    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (stats) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(stats, d_stats, (size_t)n_windows * sizeof(ygz_ba_stats), hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<unsigned> flags(12 * (size_t)n_windows);
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(stats, d_scr, (size_t)n_windows * sizeof(ygz_ba_stats), hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpy2DAsync(flags.data(), 48, A.scratch, stride, 48, (size_t)n_windows, hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n_windows; ++i)
+            if (flags[12 * (size_t)i + 1]) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return YGZ_E_HIP; }   // a member never reached a team barrier
     }
     return YGZ_OK;
 }
@@ -465,51 +717,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_ceres(const BaDev *__restrict
             }
             for (int i = tid; i < n; i += LM_THREADS) { const int k = B.free_pose[i / 6]; bs[i] = B.bp[6 * (size_t)k + (i % 6)] * B.sc_p[6 * (size_t)k + (i % 6)]; }
             __syncthreads();
-            const int npairs = Kf * (Kf + 1) / 2;
-            for (int pr = wv; pr < npairs; pr += LM_WAVES) {
-                int a = 0, rem = pr;
-                while (rem >= Kf - a) { rem -= Kf - a; ++a; }
-                const int b = a + rem, kb = B.free_pose[b];
-                double acc[36], accb[6];
-#pragma unroll
-                for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) accb[i] = 0.0;
-                for (int l = lane; l < P; l += 64) {
-                    const int ca = B.ppc[(size_t)l * Kf + a], cb = B.ppc[(size_t)l * Kf + b];
-                    if (ca < 0 || cb < 0 || B.point_fixed[l]) continue;
-                    const int row0 = B.slot_off[l >> 6], ln = l & 63;
-                    const double sl[3] = { B.sc_l[3 * (size_t)l], B.sc_l[3 * (size_t)l + 1], B.sc_l[3 * (size_t)l + 2] };
-                    double Ya[18], Wb[18];
-#pragma unroll
-                    for (int i = 0; i < 18; ++i) { Ya[i] = BA_EC(B.Y_c, row0 + ca, 18, i, ln); Wb[i] = BA_EC(B.Hpl_c, row0 + cb, 18, i, ln) * B.sc_p[6 * (size_t)kb + i / 3] * sl[i % 3]; }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) acc[6 * r + c] += Ya[3 * r] * Wb[3 * c] + Ya[3 * r + 1] * Wb[3 * c + 1] + Ya[3 * r + 2] * Wb[3 * c + 2];
-                    }
-                    if (a == b) {
-                        const double g0 = BA_PC(B.bl_c, l, 3, 0) * sl[0], g1 = BA_PC(B.bl_c, l, 3, 1) * sl[1], g2 = BA_PC(B.bl_c, l, 3, 2) * sl[2];
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) accb[r] += Ya[3 * r] * g0 + Ya[3 * r + 1] * g1 + Ya[3 * r + 2] * g2;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 36; ++i) acc[i] = lm_wave_sum(acc[i]);
-                if (a == b) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) accb[i] = lm_wave_sum(accb[i]);
-                }
-                if (lane == 0) {
-                    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-                        S[(6 * a + r) * n + 6 * b + c] -= acc[6 * r + c];
-                        if (a != b) S[(6 * b + c) * n + 6 * a + r] -= acc[6 * r + c];
-                    }
-                    if (a == b) for (int r = 0; r < 6; ++r) bs[6 * a + r] -= accb[r];
-                }
-            }
+            lm_pair_sweep<true>(B, S, bs, n, B.sc_p, B.sc_l);
             __syncthreads();
-            // ---- 3. Cholesky + substitutions (as in k_ba_lm)
+            // ---- 3. Cholesky + substitutions (as in k_ba_lm_team)
             for (int j = 0; j < n; ++j) {
                 if (tid == 0) { const double d = S[j * n + j]; if (!(d > 0) || !isfinite(d)) s_fail = 1; S[j * n + j] = sqrt(d > 0 ? d : 1.0); }
                 __syncthreads();

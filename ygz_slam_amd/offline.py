@@ -309,8 +309,10 @@ class OfflineVO:
     def ba_round(self, kf_tab, traj):
         """every rank builds and optimises the windows it owns; window states travel through a device buffer that RCCL fills
         (owner -> everybody), and ygz_hip_ba_set_state_device installs them into the resident windows"""
+        import time
         import torch
         c = self.ctx
+        tb = time.perf_counter()
         wins = ba_windows(self.n_total, self.kf_stride, self.window_kfs)
         owner = [frame_owner(w[0], self.n_total, self.world) for w in wins]
         mine = [i for i, o in enumerate(owner) if o == self.rank]
@@ -326,12 +328,16 @@ class OfflineVO:
             row[:b["poses"].size] = b["poses"].ravel()
             row[K * 6:K * 6 + b["points"].size] = b["points"].ravel()
             state[wi] = torch.from_numpy(row).to(dev)
+        t_built = time.perf_counter()
         self._exchange(state, owner)                            # the map replica now holds every window's initial state
         torch.cuda.synchronize(dev)                             # the exchange ran on torch's stream, the ABI context has its own
         for li, wi in enumerate(mine):
             base = state[wi].data_ptr()
             c.ba_set_state_device(li, base, base + 8 * K * 6)
+        t_x = time.perf_counter()
         stats = c.ba_optimize_resident(0, len(mine), self.ba_iterations) if mine else []
+        t_s = time.perf_counter()
+        self.ba_timing = {"build_upload": (t_built - tb) * 1e3, "exchange_install": (t_x - t_built) * 1e3, "lm_resident": (t_s - t_x) * 1e3}
         for li, wi in enumerate(mine):
             b = built[wi]
             poses, points = c.ba_get_state(li, len(b["poses"]), len(b["points"]))
@@ -369,6 +375,7 @@ class OfflineVO:
         windows, built = self.ba_round(kf_tab, traj)
         t3 = time.perf_counter()
         self.timing = {"track_shard": (t1 - t0) * 1e3, "gather": (t2 - t1) * 1e3, "ba_round": (t3 - t2) * 1e3}
+        self.timing.update({"ba_" + k: v for k, v in getattr(self, "ba_timing", {}).items()})
         kf_pose = {}
         for w in windows:
             for k, f in enumerate(w["kfs"]):
