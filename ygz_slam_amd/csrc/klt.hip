@@ -377,18 +377,17 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
         KLT_WEIGHTS(a, b);
         // the lane's 3 x 7 patch values stay in registers for the whole level: image << 5, and the derivatives of two
         // consecutive pixels per register (dx_k | dx_k+1 << 16, same for dy) -- the layout v_dot2 wants for the mismatch sums
-        int cI[21]; uint32_t pDx[11], pDy[11];                      // cI = 256 - (patch value << 9), see KLT_DIFF9P
-#pragma unroll
-        for (int k = 0; k < 21; ++k) cI[k] = 256;
-#pragma unroll
-        for (int k = 0; k < 11; ++k) { pDx[k] = 0u; pDy[k] = 0u; }
+        int cI[21]; uint32_t pDx[11], pDy[11];                      // cI = 256 - (patch value << 9), see KLT_DIFF9P; only read where in_lv
         float sA11 = 0.f, sA12 = 0.f, sA22 = 0.f;
         if (in_lv) {
             const int o = __mul24(ipy + row0, pw) + ipx + x0;
             uint32_t il[4], ih[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) klt_load8(I + o + r * pw, il[r], ih[r]);
-            int q11 = 0, q12 = 0, q22 = 0;                      // exact: |Scharr| < 2^12, 21 products < 2^29
+            // the (short) casts of the reference are value-preserving (0 <= ival <= 255 << 5, |Scharr| <= 16 * 255): the raw sums are
+            // packed two pixels per register with one v_perm, and the A-matrix sums run on the packed pairs (11 v_dot2 each
+            // instead of 21 multiply-adds; exact: 21 products < 2^29)
+            int prev_x = 0, prev_y = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 uint32_t d0[8], d1[8];
@@ -399,14 +398,16 @@ __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
                     const int ival = klt_dot2(KLT_PAIR(il[r + 1], ih[r + 1], kk), wbot, klt_dot2_sacc(KLT_PAIR(il[r], ih[r], kk), wtop, 256)) >> 9;
                     const int ixval = klt_dot2(KLT_DXP(d1[kk], d1[kk + 1]), wbot, klt_dot2_sacc(KLT_DXP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
                     const int iyval = klt_dot2(KLT_DYP(d1[kk], d1[kk + 1]), wbot, klt_dot2_sacc(KLT_DYP(d0[kk], d0[kk + 1]), wtop, 8192)) >> 14;
-                    const int sx = (int)(int16_t)ixval, sy = (int)(int16_t)iyval;
                     const int li = 7 * r + kk;
-                    cI[li] = 256 - ((int)(int16_t)ival << 9);
-                    if (li & 1) { pDx[li >> 1] |= (uint32_t)sx << 16; pDy[li >> 1] |= (uint32_t)sy << 16; }
-                    else { pDx[li >> 1] = (uint32_t)sx & 0xffffu; pDy[li >> 1] = (uint32_t)sy & 0xffffu; }
-                    q11 += __mul24(sx, sx); q12 += __mul24(sx, sy); q22 += __mul24(sy, sy);
+                    cI[li] = 256 - (ival << 9);
+                    if (li & 1) { pDx[li >> 1] = KLT_DXP((uint32_t)prev_x, (uint32_t)ixval); pDy[li >> 1] = KLT_DXP((uint32_t)prev_y, (uint32_t)iyval); }
+                    else if (li == 20) { pDx[10] = (uint32_t)ixval & 0xffffu; pDy[10] = (uint32_t)iyval & 0xffffu; }
+                    else { prev_x = ixval; prev_y = iyval; }
                 }
             }
+            int q11 = 0, q12 = 0, q22 = 0;
+#pragma unroll
+            for (int kk = 0; kk < 11; ++kk) { q11 = klt_dot2(pDx[kk], pDx[kk], q11); q12 = klt_dot2(pDx[kk], pDy[kk], q12); q22 = klt_dot2(pDy[kk], pDy[kk], q22); }
             sA11 = (float)q11; sA12 = (float)q12; sA22 = (float)q22;
         }
         const float A11 = __fmul_rn(klt_seg21_sum(sA11, lane, q, seg), FLT_SCALE), A12 = __fmul_rn(klt_seg21_sum(sA12, lane, q, seg), FLT_SCALE),
