@@ -1,0 +1,57 @@
+"""bench.py through its command line on the GPU box: the contract line at N = 1, and the N > 1 control flow (barriers, the RCCL /
+gloo exchange, max-over-ranks timing, rank-0 printing) with two ranks on ONE device (YGZ_BENCH_ONE_DEVICE=1 -> gloo; RCCL refuses two
+ranks on one GPU, and 8-GPU runs are the driver's).  Small batches: this checks plumbing, not speed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _last_json(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_contract_line_one_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "roofline_valu"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["unit"] == "frames/s"
+    assert d["config"]["frames_per_gpu_per_step"] == 32 and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "valu" and rf["kernel"] == "k_klt3" and rf["launches"] == 3 and rf["avg_launch_us"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["roofline_valu"]["mfma"]["kernel"] == "k_hamming_mfma" and 0 < d["roofline_valu"]["mfma"]["frac"] < 1
+    # value = frames / time: consistent with ms_per_step
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("mode", ["step", "offline"])
+def test_bench_two_ranks_on_one_device(mode):
+    env = dict(os.environ, YGZ_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    port = {"step": "29631", "offline": "29632"}[mode]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    cmd += ["--batch", "16"] if mode == "step" else ["--mode", "offline", "--frames", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+    if mode == "step":
+        assert d["scaling"] == "weak" and abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    else:
+        assert d["scaling"] == "strong" and d["config"]["frames_total"] == 32
+        assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+        assert d["result_check"]["max_abs_trajectory_error_vs_ground_truth"] < 0.05
