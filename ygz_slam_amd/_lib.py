@@ -6,6 +6,7 @@ missing or no gfx950 device is usable the calls raise.
 """
 import ctypes as C
 import os
+import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -111,6 +112,15 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libygz_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  If this library is mapped first it pulls in
+        # /opt/rocm's copy, a later `import torch` maps the second one, and torch then reports "No HIP GPUs are available".  Mapped
+        # after torch, libygz_hip.so binds to the runtime that is already there.  This harness (tests / bench.py, which use
+        # torch.distributed) therefore imports torch first when it is installed; a C / C++ caller is not concerned.
+        if "torch" not in sys.modules and os.environ.get("YGZ_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _lib = C.CDLL(LIB_PATH)
         _lib.ygz_hip_error_string.restype = C.c_char_p
     return _lib

@@ -152,7 +152,7 @@ class OfflineVO:
     """One rank of the offline run.  frame_source(i) -> BGR uint8 [h, w, 3]; depth_source(i) -> float [h, w]."""
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
-                 max_points=2000, ba_iterations=20, overlap=True, process_group=None, exchange_on_device=True, keep=False):
+                 max_points=2000, ba_iterations=20, overlap=True, process_group=None, exchange_on_device=True, keep=False, lanes=2):
         from . import _lib
         self.lib = _lib
         self.w, self.h, self.levels = width, height, levels
@@ -165,10 +165,18 @@ class OfflineVO:
         n_slots = min(self.count, chunk) + 1
         self.ctx = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
         self.ctx.set_overlap(overlap)
+        # a second context (own streams, own slots) takes every other chunk from its own host thread: the H2D copy of one chunk and
+        # the host-side depth look-up of its keypoints run under the kernels of the other (the C calls release the GIL)
+        self.lanes = [self.ctx]
+        if lanes > 1 and self.count > chunk:
+            c2 = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
+            c2.set_overlap(overlap)
+            self.lanes.append(c2)
         self.timing = {}
 
     def close(self):
-        self.ctx.close()
+        for c in self.lanes:
+            c.close()
 
     # ------------------------------------------------------------------ phase 1: the hot path over this shard
     def track_shard(self, frame_source, depth_source, block_source=None):
@@ -177,73 +185,93 @@ class OfflineVO:
         per-frame sources when the caller holds the sequence in (page-locked) memory.  Per chunk: one upload, the batched
         kernels, one download of the keypoint pixels (the depth look-up is the stand-in for the map, see the module text), one
         upload of the depths, and one download of the per-pair summary."""
-        c = self.ctx
-        rec = {}                      # frame -> dict
+        rec = {}                      # frame -> dict (the lanes write disjoint keys)
         first, last = self.start, self.start + self.count
-        cells = c.cells
-        for c0 in range(first, last, self.chunk):
-            c1 = min(c0 + self.chunk, last)
-            frames = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))      # one-frame halo: the predecessor of the chunk
-            slot_of = {f: k for k, f in enumerate(frames)}
-            n = len(frames)
-            if block_source is not None:
-                bgr, dmaps = block_source(frames)
-            else:
-                bgr = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
-                dmaps = [depth_source(f) for f in frames]
-            c.upload_bgr_batch(0, bgr)
-            c.build_pyramid(0, n, from_bgr=True)
-            c.detect(0, n)
-            px, cnt = c.get_keypoint_pixels_batch(0, n)
-            depth = np.zeros((n, cells), np.float64)
-            for k in range(n):
-                m = int(cnt[k])
-                if m:
-                    depth[k, :m] = dmaps[k][px[k, :m, 1].astype(np.int64), px[k, :m, 0].astype(np.int64)]
-            c.set_keypoint_depths_batch(0, depth, (depth > 0).astype(np.uint8))
-            pairs = [(f, f - 1) for f in frames if f - 1 in slot_of and f >= c0]
-            S = None
-            if pairs:
-                q = [slot_of[a] for a, _ in pairs]
-                t = [slot_of[b] for _, b in pairs]
-                ident = np.tile(I7, (len(pairs), 1))
-                c.match_slots(q, t, 1)
-                c.match_postfilter()
-                c.track_begin(q, t, ident, ident, predict=False)
-                c.track_sparse_align()
-                c.track_klt()
-                c.track_adopt_pose()
-                c.track_direct()
-                c.track_pose_only()
-                S = c.track_get_summary().copy()
-            for f in range(c0, c1):
-                k = slot_of[f]
-                r = dict(n_kp=int(cnt[k]))
-                if self.keep or f % self.kf_stride == 0:
-                    kp = c.get_keypoints(k)
-                    kp["depth"] = depth[k, :int(cnt[k])].copy()
-                    if self.keep:
-                        r["kp"] = kp
-                    if f % self.kf_stride == 0:
-                        r["kf"] = {key: kp[key] for key in ("px", "level", "desc", "depth")}
-                rec[f] = r
-            for p, (cur, ref) in enumerate(pairs):
-                r = rec[cur]
-                r.update(T_sa=S[p, 0:7].copy(), sa_n_meas=int(S[p, 7]), T_rel=S[p, 24:31].copy(), po_inliers=int(S[p, 14]),
-                         po_rounds=int(S[p, 15]), n_match=int(S[p, 16]), n_good=int(S[p, 17]), min_dis=float(S[p, 18]),
-                         n_klt=int(S[p, 19]), n_fdp=int(S[p, 20]))
-                if self.keep:                      # everything a parity test wants to look at
-                    n_meas, T_sa, iters = c.track_get_pose(p)
-                    po = c.track_get_pose_only(p)
-                    good, n_good, min_dis = c.get_good_matches(p)
-                    idx, dist_ = c.get_matches(p)
-                    pts, st, err = c.track_get_klt(p)
-                    ok, pxd, lvl = c.track_get_direct(p)
-                    assert np.array_equal(T_sa, r["T_sa"]) and np.array_equal(po["T"], r["T_rel"]) and n_good == r["n_good"]
-                    assert int(st.astype(bool).sum()) == r["n_klt"] and int(ok.sum()) == r["n_fdp"] and int((idx >= 0).sum()) == r["n_match"]
-                    r.update(sa_iters=iters, m_idx=idx, m_dist=dist_, m_good=good, klt_pts=pts, klt_status=st, klt_err=err,
-                             fdp_ok=ok, fdp_px=pxd, fdp_level=lvl, po_bad=po["bad"], po_pose=po["pose"])
+        chunks = [(c0, min(c0 + self.chunk, last)) for c0 in range(first, last, self.chunk)]
+        if len(self.lanes) == 1 or len(chunks) < 2:
+            for c0, c1 in chunks:
+                self._track_chunk(self.ctx, c0, c1, rec, frame_source, depth_source, block_source)
+            return rec
+        import threading
+        errors = []
+
+        def lane(k):
+            try:
+                for c0, c1 in chunks[k::len(self.lanes)]:
+                    self._track_chunk(self.lanes[k], c0, c1, rec, frame_source, depth_source, block_source)
+            except BaseException as e:                       # surfaces in the caller's thread
+                errors.append(e)
+        th = [threading.Thread(target=lane, args=(k,)) for k in range(len(self.lanes))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
         return rec
+
+    def _track_chunk(self, c, c0, c1, rec, frame_source, depth_source, block_source):
+        cells = c.cells
+        frames = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))      # one-frame halo: the predecessor of the chunk
+        slot_of = {f: k for k, f in enumerate(frames)}
+        n = len(frames)
+        if block_source is not None:
+            bgr, dmaps = block_source(frames)
+        else:
+            bgr = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
+            dmaps = [depth_source(f) for f in frames]
+        c.upload_bgr_batch(0, bgr)
+        c.build_pyramid(0, n, from_bgr=True)
+        c.detect(0, n)
+        px, cnt = c.get_keypoint_pixels_batch(0, n)
+        depth = np.zeros((n, cells), np.float64)
+        for k in range(n):
+            m = int(cnt[k])
+            if m:
+                depth[k, :m] = dmaps[k][px[k, :m, 1].astype(np.int64), px[k, :m, 0].astype(np.int64)]
+        c.set_keypoint_depths_batch(0, depth, (depth > 0).astype(np.uint8))
+        pairs = [(f, f - 1) for f in frames if f - 1 in slot_of and f >= c0]
+        S = None
+        if pairs:
+            q = [slot_of[a] for a, _ in pairs]
+            t = [slot_of[b] for _, b in pairs]
+            ident = np.tile(I7, (len(pairs), 1))
+            c.match_slots(q, t, 1)
+            c.match_postfilter()
+            c.track_begin(q, t, ident, ident, predict=False)
+            c.track_sparse_align()
+            c.track_klt()
+            c.track_adopt_pose()
+            c.track_direct()
+            c.track_pose_only()
+            S = c.track_get_summary().copy()
+        for f in range(c0, c1):
+            k = slot_of[f]
+            r = dict(n_kp=int(cnt[k]))
+            if self.keep or f % self.kf_stride == 0:
+                kp = c.get_keypoints(k)
+                kp["depth"] = depth[k, :int(cnt[k])].copy()
+                if self.keep:
+                    r["kp"] = kp
+                if f % self.kf_stride == 0:
+                    r["kf"] = {key: kp[key] for key in ("px", "level", "desc", "depth")}
+            rec[f] = r
+        for p, (cur, ref) in enumerate(pairs):
+            r = rec[cur]
+            r.update(T_sa=S[p, 0:7].copy(), sa_n_meas=int(S[p, 7]), T_rel=S[p, 24:31].copy(), po_inliers=int(S[p, 14]),
+                     po_rounds=int(S[p, 15]), n_match=int(S[p, 16]), n_good=int(S[p, 17]), min_dis=float(S[p, 18]),
+                     n_klt=int(S[p, 19]), n_fdp=int(S[p, 20]))
+            if self.keep:                      # everything a parity test wants to look at
+                n_meas, T_sa, iters = c.track_get_pose(p)
+                po = c.track_get_pose_only(p)
+                good, n_good, min_dis = c.get_good_matches(p)
+                idx, dist_ = c.get_matches(p)
+                pts, st, err = c.track_get_klt(p)
+                ok, pxd, lvl = c.track_get_direct(p)
+                assert np.array_equal(T_sa, r["T_sa"]) and np.array_equal(po["T"], r["T_rel"]) and n_good == r["n_good"]
+                assert int(st.astype(bool).sum()) == r["n_klt"] and int(ok.sum()) == r["n_fdp"] and int((idx >= 0).sum()) == r["n_match"]
+                r.update(sa_iters=iters, m_idx=idx, m_dist=dist_, m_good=good, klt_pts=pts, klt_status=st, klt_err=err,
+                         fdp_ok=ok, fdp_px=pxd, fdp_level=lvl, po_bad=po["bad"], po_pose=po["pose"])
 
     # ------------------------------------------------------------------ phase 2: trajectory all-gather
     def gather(self, rec):
