@@ -130,6 +130,13 @@ int  ygz_hip_match_postfilter(ygz_hip_ctx *ctx, double min_floor, double min_cei
 int  ygz_hip_get_good_matches(ygz_hip_ctx *ctx, int pair, uint8_t *good /*[nq]*/, int capacity, int *nq, int *n_good, double *min_dis);
 /* the same on host arrays as ygz_hip_hamming_match returned them (train_idx < 0: no match).  nq == 0 (the reference dereferences
  * end() there) is defined as "nothing kept". */
+/* M1-M3 over many host descriptor sets in one call (the matching a keyframe window needs: one set against several others):
+ * desc[s] = count[s] rows of 32 bytes; pair p matches query set pair_q[p] against train set pair_t[p] with BFMatcher semantics
+ * (test/test_orb_match.cpp:86-93) and, when any of good / n_good / min_dis is given, applies the good-match rule of :95-104.
+ * train_idx / dist / good: [n_pairs][ygz_hip_max_keypoints()] rows (entries past count[pair_q[p]] are not written). */
+int  ygz_hip_match_sets(ygz_hip_ctx *ctx, int n_sets, const uint8_t *const *desc, const int32_t *count, int n_pairs,
+                        const int32_t *pair_q, const int32_t *pair_t, int cross_check, int32_t *train_idx, int32_t *dist,
+                        uint8_t *good, int32_t *n_good, double *min_dis, double min_floor, double min_ceil, double factor);
 int  ygz_hip_match_postfilter_host(ygz_hip_ctx *ctx, const int32_t *train_idx, const int32_t *dist, int nq, double min_floor,
                                    double min_ceil, double factor, uint8_t *good, int *n_good, double *min_dis);
 /* ---- M6: Matcher::CheckFrameDescriptors (src/Algorithm/Matcher.cpp:45-84): Hamming distance of n given (index1, index2) feature

@@ -61,6 +61,34 @@ def test_match_postfilter_and_check_frame_descriptors(hip_lib, oracle):
     ctx.close()
 
 
+def test_match_sets_equals_the_per_pair_calls(hip_lib, oracle):
+    """ygz_hip_match_sets (all pairs of a keyframe window in one call: sets of different sizes, an empty set, a set matched against
+    itself) against the oracle's BFMatcher + good-match rule, and against the one-pair entry points"""
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    sets = [base[:500].copy()]
+    for n in (640, 333, 0, 700):
+        d = base[:n].copy()
+        flip = rng.random(d.shape) < 0.02                        # related descriptors: matches with small distances exist
+        d[flip] ^= rng.integers(1, 256, int(flip.sum()), dtype=np.uint8)
+        sets.append(d[rng.permutation(n)] if n else d)
+    pq, pt = [0, 0, 0, 0, 2, 1], [1, 2, 3, 4, 1, 1]
+    ctx = make_ctx(hip_lib, max_frames=8)
+    res = ctx.match_sets(sets, pq, pt)
+    for p, r in enumerate(res):
+        q, t = sets[pq[p]], sets[pt[p]]
+        oi, od, _ = oracle.bf_match(q, t, 1)
+        og, ong = oracle.good_match_filter(oi, od)
+        assert np.array_equal(r["idx"], oi) and np.array_equal(r["dist"], od), p
+        assert np.array_equal(r["good"], og.astype(bool)) and r["n_good"] == ong, p
+        if len(t):
+            gi, gd = ctx.hamming_match(q, t, cross_check=1)
+            gg, gn, gm = ctx.match_postfilter_host(gi, gd)
+            assert np.array_equal(gi, r["idx"]) and np.array_equal(gg, r["good"]) and gn == r["n_good"] and gm == r["min_dis"], p
+    assert res[2]["n_good"] == 0 and np.all(res[2]["idx"] == -1)       # empty train set
+    ctx.close()
+
+
 def _oracle_pair(oracle, seq, ref, cur, T_sa=None):
     """the oracle's composition of one frame pair of the offline run (T_ref = identity)"""
     w, h = seq.w, seq.h

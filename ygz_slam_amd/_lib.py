@@ -94,7 +94,7 @@ ABI_SYMBOLS = [
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
     "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map",
-    "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_check_frame_descriptors",
+    "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_match_sets", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
     "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
@@ -363,6 +363,31 @@ class HipContext:
                                                          C.c_double(min_ceil), C.c_double(factor), _p(good, C.c_uint8), C.byref(ng), C.byref(md)),
                   "match_postfilter_host")
         return good[:len(ti)].astype(bool), ng.value, md.value
+
+    def match_sets(self, descs, pair_q, pair_t, cross_check=1, good_filter=True, min_floor=20.0, min_ceil=50.0, factor=3.0):
+        """M1-M3 over host descriptor sets in ONE call: descs = list of [n_s, 32] uint8 arrays; returns per pair (rows of the query set)
+        train_idx, dist and -- with good_filter -- the kept flags, their count and the clamped minimum distance"""
+        ds = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descs]
+        n_sets, n_pairs = len(ds), len(pair_q)
+        ptrs = (C.POINTER(C.c_uint8) * n_sets)(*[_p(d, C.c_uint8) for d in ds])
+        cnt = np.array([len(d) for d in ds], np.int32)
+        pq = np.ascontiguousarray(pair_q, np.int32); pt = np.ascontiguousarray(pair_t, np.int32)
+        idx = np.empty((n_pairs, self.cells), np.int32); dist = np.empty((n_pairs, self.cells), np.int32)
+        good = np.zeros((n_pairs, self.cells), np.uint8) if good_filter else None
+        ng = np.zeros(n_pairs, np.int32); md = np.zeros(n_pairs, np.float64)
+        self.lib.ygz_hip_match_sets.argtypes = None
+        self._chk(self.lib.ygz_hip_match_sets(self._ctx, n_sets, ptrs, _p(cnt, C.c_int32), n_pairs, _p(pq, C.c_int32), _p(pt, C.c_int32), cross_check,
+                                              _p(idx, C.c_int32), _p(dist, C.c_int32), _p(good, C.c_uint8) if good_filter else None,
+                                              _p(ng, C.c_int32) if good_filter else None, _p(md, C.c_double) if good_filter else None,
+                                              C.c_double(min_floor), C.c_double(min_ceil), C.c_double(factor)), "match_sets")
+        out = []
+        for p in range(n_pairs):
+            n = int(cnt[pq[p]])
+            r = dict(idx=idx[p, :n], dist=dist[p, :n])
+            if good_filter:
+                r.update(good=good[p, :n].astype(bool), n_good=int(ng[p]), min_dis=float(md[p]))
+            out.append(r)
+        return out
 
     def check_frame_descriptors(self, slot1, slot2, idx1, idx2, init_low=30, init_high=80, ratio=3.0):
         i1 = np.ascontiguousarray(idx1, np.int32); i2 = np.ascontiguousarray(idx2, np.int32)

@@ -15,6 +15,7 @@
 // train index, exactly the order-dependent "strictly smaller replaces" rule of OpenCV.
 #include "ygz_internal.h"
 #include <string.h>
+#include <vector>
 #include <stdlib.h>
 
 #define HM_TILE 256
@@ -371,6 +372,60 @@ int ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint
     if (train_idx) YGZ_HIPCHK(ctx, hipMemcpyAsync(train_idx, ctx->m_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (dist) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist, ctx->m_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (dist2) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist2, ctx->m_dist2, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_pairs = 0;      // per-pair buffers were reused
+    return YGZ_OK;
+}
+
+// M1-M3 over many host descriptor sets in one call: every set crosses PCIe once, all pairs run in one launch per direction, the
+// good-match rule (test/test_orb_match.cpp:95-104) on the device, one copy back.  Rows are [n_pairs][cells] like the resident buffers.
+int ygz_hip_match_sets(ygz_hip_ctx *ctx, int n_sets, const uint8_t *const *desc, const int32_t *count, int n_pairs, const int32_t *pair_q,
+                       const int32_t *pair_t, int cross_check, int32_t *train_idx, int32_t *dist, uint8_t *good, int32_t *n_good, double *min_dis,
+                       double min_floor, double min_ceil, double factor)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || n_sets < 1 || n_pairs < 1 || !desc || !count || !pair_q || !pair_t || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
+    if (good && (!(min_floor <= min_ceil) || !(factor > 0))) return YGZ_E_INVALID;
+    if (n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;               // the per-pair result buffers
+    int max_rows = 0;
+    for (int s = 0; s < n_sets; ++s) {
+        if (count[s] < 0 || (count[s] > 0 && !desc[s])) return YGZ_E_INVALID;
+        if (count[s] > ctx->cells) return YGZ_E_CAPACITY;
+        max_rows = count[s] > max_rows ? count[s] : max_rows;
+    }
+    for (int p = 0; p < n_pairs; ++p) if (pair_q[p] < 0 || pair_q[p] >= n_sets || pair_t[p] < 0 || pair_t[p] >= n_sets) return YGZ_E_INVALID;
+    const size_t Cn = (size_t)ctx->cells;
+    if (max_rows == 0) {
+        for (int p = 0; p < n_pairs; ++p) { if (n_good) n_good[p] = 0; if (min_dis) min_dis[p] = min_ceil; }
+        return YGZ_OK;
+    }
+    const size_t stride_u32 = (size_t)max_rows * 8 + 8;
+    const size_t hdr_ints = (size_t)n_sets + 2 * (size_t)n_pairs, hdr_bytes = (hdr_ints * 4 + 63) & ~(size_t)63;
+    uint8_t *buf = nullptr;
+    int rc = ygz_scratch(ctx, SCR_MATCH_Q, hdr_bytes + stride_u32 * 4 * (size_t)n_sets, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    std::vector<int32_t> hdr(hdr_ints);
+    for (int s = 0; s < n_sets; ++s) hdr[s] = count[s];
+    for (int p = 0; p < n_pairs; ++p) { hdr[(size_t)n_sets + p] = pair_q[p]; hdr[(size_t)n_sets + n_pairs + p] = pair_t[p]; }
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf, hdr.data(), hdr_ints * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *d = reinterpret_cast<uint32_t *>(buf + hdr_bytes);
+    for (int s = 0; s < n_sets; ++s)
+        if (count[s] > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(d + (size_t)s * stride_u32, desc[s], (size_t)count[s] * 32, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                     // hdr is about to go out of scope for the async copy engine
+    const int32_t *cnt = reinterpret_cast<const int32_t *>(buf), *pq = cnt + n_sets, *pt = pq + n_pairs;
+    rc = run_match(ctx, d, stride_u32, cnt, pq, pt, n_pairs, max_rows, cross_check, false);
+    if (rc != YGZ_OK) return rc;
+    if (good || n_good || min_dis) {
+        rc = ygz_launch_match_postfilter(ctx, cnt, pq, n_pairs, min_floor, min_ceil, factor);
+        if (rc != YGZ_OK) return rc;
+    }
+    const size_t rows = (size_t)n_pairs * Cn;
+    if (train_idx) YGZ_HIPCHK(ctx, hipMemcpyAsync(train_idx, ctx->m_idx, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist, ctx->m_dist, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (good) YGZ_HIPCHK(ctx, hipMemcpyAsync(good, ctx->m_good, rows, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_good) YGZ_HIPCHK(ctx, hipMemcpyAsync(n_good, ctx->m_good_n, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (min_dis) YGZ_HIPCHK(ctx, hipMemcpyAsync(min_dis, ctx->m_min_dis, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_pairs = 0;      // per-pair buffers were reused
     return YGZ_OK;

@@ -121,6 +121,20 @@ int ygz_pf_ensure(ygz_hip_ctx *ctx)
     return YGZ_OK;
 }
 
+// the filter over the resident match rows of n_pairs pairs whose query-set sizes are set_count[pair_q[p]] (device arrays)
+int ygz_launch_match_postfilter(ygz_hip_ctx *ctx, const int32_t *set_count, const int32_t *pair_q, int n_pairs, double lo, double hi, double factor)
+{
+    int rc = ygz_pf_ensure(ctx);
+    if (rc != YGZ_OK) return rc;
+    PfArgs A;
+    A.set_count = set_count; A.pair_q = pair_q; A.idx = ctx->m_idx; A.dist = ctx->m_dist; A.stride = (size_t)ctx->cells;
+    A.good = ctx->m_good; A.n_good = ctx->m_good_n; A.min_dis = ctx->m_min_dis;
+    A.lo = lo; A.hi = hi; A.factor = factor;
+    YGZ_LAUNCH(ctx, KID_MATCH_POSTFILTER, k_match_postfilter, dim3(n_pairs), dim3(PF_THREADS), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
 extern "C" {
 
 int ygz_hip_match_postfilter(ygz_hip_ctx *ctx, double min_floor, double min_ceil, double factor)

@@ -190,6 +190,7 @@ struct YgzPoDev {
 };
 int ygz_launch_pose_only(ygz_hip_ctx *ctx, int n_frames, const YgzPoDev &d);
 int ygz_pf_ensure(ygz_hip_ctx *ctx);
+int ygz_launch_match_postfilter(ygz_hip_ctx *ctx, const int32_t *set_count, const int32_t *pair_q, int n_pairs, double lo, double hi, double factor);
 bool ygz_ba_window_has_dup(const ygz_hip_ctx *ctx, int window);    // an uploaded BA window repeats a (point, free pose) pair (ba.hip)
 
 // ---------------------------------------------------------------------------------------------

@@ -106,11 +106,25 @@ def se3_exp_g2o(v):
 
 
 def chain(T_rel):
-    """T[0] = identity (the first frame defines the world); T[i] = T_rel[i] * T[i-1]"""
+    """T[0] = identity (the first frame defines the world); T[i] = T_rel[i] * T[i-1] -- se3_mul's formulas on Python floats (a
+    thousand 7-vector products through numpy temporaries cost 25 ms, this loop 3)"""
     out = np.empty_like(T_rel)
     out[0] = I7
-    for i in range(1, len(T_rel)):
-        out[i] = se3_mul(T_rel[i], out[i - 1])
+    bx, by, bz, bw, px, py, pz = (float(v) for v in I7)
+    rows = T_rel.tolist()
+    for i in range(1, len(rows)):
+        ax, ay, az, aw, tx, ty, tz = rows[i]
+        qx = aw * bx + ax * bw + ay * bz - az * by
+        qy = aw * by - ax * bz + ay * bw + az * bx
+        qz = aw * bz + ax * by - ay * bx + az * bw
+        qw = aw * bw - ax * bx - ay * by - az * bz
+        n = (qx * qx + qy * qy + qz * qz + qw * qw) ** 0.5
+        c0, c1, c2 = 2.0 * (ay * pz - az * py), 2.0 * (az * px - ax * pz), 2.0 * (ax * py - ay * px)       # 2 u x p
+        nx = px + aw * c0 + (ay * c2 - az * c1) + tx
+        ny = py + aw * c1 + (az * c0 - ax * c2) + ty
+        nz = pz + aw * c2 + (ax * c1 - ay * c0) + tz
+        bx, by, bz, bw, px, py, pz = qx / n, qy / n, qz / n, qw / n, nx, ny, nz
+        out[i] = (bx, by, bz, bw, px, py, pz)
     return out
 
 
@@ -303,9 +317,9 @@ class OfflineVO:
         return torch.device("cuda", self.device)
 
     # ------------------------------------------------------------------ phase 3: BA round
-    def build_window(self, kfs, kf_tab, traj):
+    def build_window(self, kfs, kf_tab, traj, c=None):
         """graph of ba::LocalBAG2O for one window: poses (g2o order), points, edges; anchor = kfs[0] held fixed"""
-        c = self.ctx
+        c = c or self.ctx
         A = kf_tab[kfs[0]]
         sel = np.nonzero(A["depth"] > 0)[0][:self.max_points]
         T_a = traj[kfs[0]]
@@ -314,14 +328,12 @@ class OfflineVO:
         pc = np.stack([(A["px"][sel, 0] - cx) * z / fx, (A["px"][sel, 1] - cy) * z / fy, z], axis=1)     # Pixel2Camera (Camera.h:56-62)
         pw = se3_act(se3_inv(T_a), pc) if len(sel) else np.zeros((0, 3))
         ep, el, obs = [np.zeros(len(sel), np.int32)], [np.arange(len(sel), dtype=np.int32)], [A["px"][sel]]
-        for j, f in enumerate(kfs[1:], start=1):
-            B = kf_tab[f]
-            if len(sel) == 0 or len(B["level"]) == 0:
-                continue
-            idx, dist_ = c.hamming_match(A["desc"][sel], B["desc"], cross_check=1)
-            good, _, _ = c.match_postfilter_host(idx, dist_)
-            g = np.nonzero(good)[0]
-            ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(B["px"][idx[g]])
+        others = [(j, f) for j, f in enumerate(kfs[1:], start=1) if len(sel) and len(kf_tab[f]["level"])]
+        if others:                                             # the anchor's descriptors against every other keyframe of the window: one call
+            res = c.match_sets([A["desc"][sel]] + [kf_tab[f]["desc"] for _, f in others], [0] * len(others), list(range(1, len(others) + 1)))
+            for (j, f), r in zip(others, res):
+                g = np.nonzero(r["good"])[0]
+                ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(kf_tab[f]["px"][r["idx"][g]])
         ep, el, obs = np.concatenate(ep), np.concatenate(el), np.concatenate(obs)
         n_obs = np.bincount(el, minlength=len(sel))
         keep_pt = n_obs >= 2                                   # a point seen only by the fixed anchor constrains nothing
@@ -349,8 +361,21 @@ class OfflineVO:
         dev = self._torch_device()
         state = torch.zeros((len(wins), S), dtype=torch.float64, device=dev)
         built = {}
+        if len(self.lanes) > 1 and len(mine) > 1:                # the windows' matcher calls on both contexts, from two host threads
+            import threading
+
+            def lane(k):
+                for wi in mine[k::len(self.lanes)]:
+                    built[wi] = self.build_window(wins[wi], kf_tab, traj, self.lanes[k])
+            th = [threading.Thread(target=lane, args=(k,)) for k in range(len(self.lanes))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert len(built) == len(mine)
+        t_match = time.perf_counter()
         for li, wi in enumerate(mine):
-            b = built[wi] = self.build_window(wins[wi], kf_tab, traj)
+            b = built[wi] if wi in built else built.setdefault(wi, self.build_window(wins[wi], kf_tab, traj))
             c.ba_upload(li, b["poses"], b["fixed"], b["points"], b["edge_pose"], b["edge_point"], b["obs"])
             row = np.zeros(S)
             row[:b["poses"].size] = b["poses"].ravel()
@@ -365,7 +390,7 @@ class OfflineVO:
         t_x = time.perf_counter()
         stats = c.ba_optimize_resident(0, len(mine), self.ba_iterations) if mine else []
         t_s = time.perf_counter()
-        self.ba_timing = {"build_upload": (t_built - tb) * 1e3, "exchange_install": (t_x - t_built) * 1e3, "lm_resident": (t_s - t_x) * 1e3}
+        self.ba_timing = {"build_windows": (t_match - tb) * 1e3, "build_upload": (t_built - tb) * 1e3, "exchange_install": (t_x - t_built) * 1e3, "lm_resident": (t_s - t_x) * 1e3}
         for li, wi in enumerate(mine):
             b = built[wi]
             poses, points = c.ba_get_state(li, len(b["poses"]), len(b["points"]))
