@@ -261,10 +261,12 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
         ops = 2.0 * 256.0 * n_kp * n_kp * a.batch            # per launch: every pair of the batch, one direction
         t = ms / n * 1e-3
         out["mfma"] = {"kernel": "k_hamming_mfma", "bound": "mfma", "unit": "TOP/s (int8)", "ops_per_launch": ops, "avg_launch_us": t * 1e6,
-                       "achieved": ops / t / 1e12, "peak": 5000.0, "peak_measured_guide": 3944.0, "frac": ops / t / 1e12 / 5000.0,
-                       "frac_of_measured_peak": ops / t / 1e12 / 3944.0,
+                       "achieved": ops / t / 1e12, "peak": 5000.0, "peak_measured_guide": 3944.0, "peak_measured_here": 4392.0,
+                       "frac": ops / t / 1e12 / 5000.0, "frac_of_measured_peak": ops / t / 1e12 / 4392.0,
                        "note": "algorithmic ops (unpadded |A| x |B| x 256 x 2); peak = dense int8 MFMA of MI355X_MICROARCH.md (2 x the 2.5 PFLOP/s bf16 "
-                               "peak; its micro-benchmark reaches 3944); the VALU side of the kernel expands bits to bytes and keeps the running minima",
+                               "peak; its micro-benchmark reaches 3944, tools/ubench/mfma_i8_rate 4392 for this shape: profiles/r02_mfma_i8_rate.txt); a SIMD "
+                               "hides ~4 VALU instructions behind one MFMA (profiles/r02_mfma_valu_mix.txt), the kernel needs ~4.4 (bits to bytes, running "
+                               "minima), and a quarter of a launch is wavefront start-up latency",
                        "timed": "HIP events, 3 runs of the matcher stage alone after the timed region (%d launches)" % n}
     return out
 

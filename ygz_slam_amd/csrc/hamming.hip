@@ -112,33 +112,44 @@ __global__ __launch_bounds__(256) void k_hamming_nn(HamArgs A)
 }
 
 // ---- the same nearest-neighbour search on the matrix cores --------------------------------------------------------------------------
-// popcount(a ^ b) = |a| + |b| - 2 a.b with a.b the dot product of the two descriptors as 0/1 vectors of length 256: the 1000 x 1000
-// distance matrix of a frame pair is an int8 GEMM with K = 256 (5.4e8 multiply-adds) plus rank-one terms, so the search runs on
+// With a' = 1 - 2a in {+1, -1}:  popcount(a ^ b) = |a| + a'.b  (a'.b = |b| - 2 a.b): the 1000 x 1000 distance matrix of a frame pair is
+// an int8 GEMM with K = 256 (2.6e8 multiply-adds) plus a term that is constant along a row, so the search runs on
 // v_mfma_i32_32x32x32_i8 and the VALU only has to (a) turn bits into bytes and (b) keep the running minimum.
 //  (a) bit i of a byte stays where it is: the B operand's byte is w & (1 << i) = b 2^i (ONE v_and per 4 bytes), the A operand's byte
-//      is -a 2^(6 - i), every product is -64 a b.  Bit 7 would be the sign bit: it is read as (w >> 1) & 0x40 against A's -a.
+//      is a' 2^(6 - i), every product is 64 a' b.  Bit 7 would be the sign bit: it is read as (w >> 1) & 0x40 against A's a'.
 //      K-step s of lane (l31, half) covers byte-bit i = 4 (s & 1) + {0..3} of dword 4 half + (s >> 1): a lane touches 16 bytes of
 //      its row.  Any bijection bit -> k shared by the two operands gives the same dot product.
-//  (b) the accumulator holds -64 a.b, so key = (|b| + 512) << 16 | column, plus acc << 11, is ONE v_lshl_add; |a| is constant along
-//      a matrix row and is added after the search.  Keys order by distance, then by column: the first minimum wins as in the
-//      reference's scan.  The running minima are per (row, column mod 32); the 32-lane reduction happens once, after the last tile.
+//  (b) the accumulator chain of a tile STARTS from the tile index t (C operand = splat(t), 16 registers shared by all chains of the
+//      wavefront, bumped once per tile) and ends as 64 (dist - |a|) + t: ordered by distance, then by tile, so the running minimum
+//      is ONE v_min_i32 per accumulator and the first minimum wins as in the reference's scan.  The minima are per (row, column
+//      mod 32); every 64 tiles (and at the end) they are folded into 32-bit keys (dist - |a| + 512) << 16 | column, reduced over the
+//      32 lanes once, and |a| is added.  Columns past the end of B exist only in the last tile: they get a bias no real column has.
 // A wavefront owns 32 RG rows of set A -- expanded once, 32 RG VGPRs -- and walks set B in tiles of 32 rows, every expanded B
-// operand feeding RG independent accumulator chains.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+// operand feeding RG independent accumulator chains.  tools/ubench/mfma_valu_mix (profiles/r02_mfma_valu_mix.txt): a SIMD hides about
+// four VALU instructions behind one of these MFMAs and serialises the rest, so the VALU work per MFMA decides the speed: RG = 3
+// gives 24 MFMAs against ~100 VALU instructions per tile and 232 VGPRs (two wavefronts per SIMD), RG = 2 gives 16 against ~70 at 168 VGPRs (three):
+// the start of a wavefront (two dependent memory latencies before its first MFMA) is a quarter of the kernel, and the third wavefront
+// hides more of it than the better ratio buys (102 against 106 microseconds per 512 pairs).  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
 // + 4 (lane >> 5).
 typedef int hm_v4i __attribute__((ext_vector_type(4)));
 typedef int hm_v16i __attribute__((ext_vector_type(16)));
+#ifndef HM_RG
 #define HM_RG 2                                                      // row groups of 32 per wavefront
+#endif
 
 __device__ __forceinline__ hm_v4i hm_expand_a(uint32_t w, int hi)
-{   // byte-bits 4 hi + {0..3} of the 4 bytes of w -> -2^(6 - i) (bit 7: -1)
+{   // byte-bits 4 hi + {0..3} of the 4 bytes of w -> +2^(6 - i) for a clear bit, -2^(6 - i) for a set bit (bit 7: +-1)
+    // per byte: bit b -> mask t = 255 b; (m ^ t) + b is m for b = 0 and 256 - m for b = 1 (1 <= m <= 64: no carry leaves the byte)
     hm_v4i r;
     const uint32_t x = w >> (4 * hi);
-    uint32_t b0 = x & 0x01010101u, b1 = (x >> 1) & 0x01010101u, b2 = (x >> 2) & 0x01010101u, b3 = (x >> 3) & 0x01010101u;
     const int sh = 6 - 4 * hi;                                       // i = 4 hi + q -> shift 6 - i = sh - q ; the last one (i = 7) is 0
-    b0 <<= sh; b1 <<= sh - 1; b2 <<= sh - 2; b3 <<= (hi ? 0 : sh - 3);
-    // per-byte negation: bytes are 0 or a power of two <= 64, so (0x80 - b) ^ 0x80 is the two's complement byte without borrows
-    r.x = (int)((0x80808080u - b0) ^ 0x80808080u); r.y = (int)((0x80808080u - b1) ^ 0x80808080u);
-    r.z = (int)((0x80808080u - b2) ^ 0x80808080u); r.w = (int)((0x80808080u - b3) ^ 0x80808080u);
+#define HM_PM(q_, m_) { const uint32_t b_ = (x >> (q_)) & 0x01010101u; o_ = (int)((((m_)) ^ ((b_ << 8) - b_)) + b_); }
+    int o_;
+    HM_PM(0, 0x01010101u << sh) r.x = o_;
+    HM_PM(1, 0x01010101u << (sh - 1)) r.y = o_;
+    HM_PM(2, 0x01010101u << (sh - 2)) r.z = o_;
+    HM_PM(3, hi ? 0x01010101u : (0x01010101u << (sh - 3))) r.w = o_;
+#undef HM_PM
     return r;
 }
 
@@ -150,13 +161,13 @@ __device__ __forceinline__ hm_v4i hm_expand_b(uint32_t w, int hi)
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A)
+__global__ __launch_bounds__(64) void k_hamming_mfma(HamArgs A)
 {
-    const int p = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x, lane = threadIdx.x;
     const int sa = A.pair_a[p], sb = A.pair_b[p];
     const int nA = A.set_count[sa], nB = A.set_count[sb];
-    const int r0 = (blockIdx.y * 4 + wv) * (32 * HM_RG);
-    if (r0 >= nA) return;                                            // wave-uniform; no block-level barrier below
+    const int r0 = blockIdx.y * (32 * HM_RG);
+    if (r0 >= nA) return;
     const uint32_t *da = A.desc + (size_t)sa * A.set_stride, *db = A.desc + (size_t)sb * A.set_stride;
     const int half = lane >> 5, l31 = lane & 31;
     // ---- this wavefront's rows of A: lane (l31, half) holds dwords [4 half, 4 half + 4) of rows r0 + 32 g + l31
@@ -175,61 +186,92 @@ __global__ __launch_bounds__(256) void k_hamming_mfma(HamArgs A)
         for (int q = 0; q < 4; ++q) pc += __popc(w[q]);
         pa[g] = pc + __shfl_xor(pc, 32);
     }
-    uint32_t run[HM_RG][16];
+    // folded keys (dist - |a| + 512) << 16 | column, [accumulator][lane]: a lane's own column of LDS, written once per 64 tiles
+    // (as registers they would cost a wavefront per SIMD) and read TRANSPOSED at the end: the 32 lanes of one half hold the 32
+    // column classes of the same matrix row, so the row's minimum is the minimum of 32 consecutive dwords
+    __shared__ uint32_t fin[HM_RG * 16][64];
+    int run[HM_RG][16];                                              // 64 (dist - |a|) + tile of the current block of 64 tiles
 #pragma unroll
     for (int g = 0; g < HM_RG; ++g)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) run[g][r] = 0xffffffffu;
+        for (int r = 0; r < 16; ++r) run[g][r] = 0x7fffffff;
     const int n_tiles = (nB + 31) >> 5;
-    uint4 b = make_uint4(0, 0, 0, 0);                                // software pipeline: the next tile's rows are in flight
-    if (l31 < nB) b = reinterpret_cast<const uint4 *>(db + 8 * (size_t)l31)[half];
+    // software pipeline: the rows of the next three tiles are in flight (an L2 hit takes longer than one tile of MFMAs)
+#define HM_LDB(dst_, j_) { dst_ = make_uint4(0, 0, 0, 0); if ((j_) < nB) dst_ = reinterpret_cast<const uint4 *>(db + 8 * (size_t)(j_))[half]; }
+    uint4 b, bn1, bn2;
+    HM_LDB(b, l31) HM_LDB(bn1, l31 + 32) HM_LDB(bn2, l31 + 64)
+    hm_v16i cinit = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };                // splat(tile index inside the block of 64)
+    bool folded = false;
     for (int t = 0; t < n_tiles; ++t) {
-        const int j = 32 * t + l31;
         const uint32_t w[4] = { b.x, b.y, b.z, b.w };
-        {
-            const int jn = j + 32;
-            b = make_uint4(0, 0, 0, 0);
-            if (jn < nB) b = reinterpret_cast<const uint4 *>(db + 8 * (size_t)jn)[half];
-        }
+        b = bn1; bn1 = bn2;
+        HM_LDB(bn2, 32 * t + l31 + 96)
         hm_v16i acc[HM_RG];
-#pragma unroll
-        for (int g = 0; g < HM_RG; ++g) acc[g] = (hm_v16i){ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const hm_v4i Bop = hm_expand_b(w[s >> 1], s & 1);
 #pragma unroll
-            for (int g = 0; g < HM_RG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[g][s], Bop, acc[g], 0, 0, 0);
+            for (int g = 0; g < HM_RG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[g][s], Bop, s == 0 ? cinit : acc[g], 0, 0, 0);
         }
-        int pb = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-        pb += __shfl_xor(pb, 32);
-        // key = (|b| + 512 - 2 a.b) << 16 | j ; columns past the end of B can never win
-        const uint32_t kc = (j < nB) ? (((uint32_t)(pb + 512) << 16) | (uint32_t)j) : 0xfffe0000u;
+        if (t == n_tiles - 1 && 32 * t + l31 >= nB) {                // the ragged end of B (its rows are zero: they would win)
+#pragma unroll
+            for (int g = 0; g < HM_RG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0x7fffffff;
+        }
 #pragma unroll
         for (int g = 0; g < HM_RG; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) run[g][r] = min(run[g][r], kc + ((uint32_t)acc[g][r] << 11));
-    }
-    // ---- minimum over the 32 columns-mod-32 of every row: the lanes of one half hold the same 16 rows
-    const int rowl = (l31 & 3) + 8 * ((l31 & 15) >> 2) + 4 * half;
+            for (int r = 0; r < 16; ++r) run[g][r] = min(run[g][r], acc[g][r]);
 #pragma unroll
-    for (int g = 0; g < HM_RG; ++g) {
+        for (int r = 0; r < 16; ++r) cinit[r] += 1;
+        if ((t & 63) == 63 || t == n_tiles - 1) {                    // fold the block of 64 tiles into the 32-bit keys
+            const int tb = t & ~63;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            uint32_t v = run[g][r];
-            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xF, 0xF, false));    // row_half_mirror
-            v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xF, 0xF, false));    // row_mirror
-            v = min(v, (uint32_t)__shfl_xor((int)v, 16));                                              // the two rows of 16 of this half
-            run[g][r] = v;
+            for (int g = 0; g < HM_RG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int v = run[g][r];
+                    uint32_t key = ((uint32_t)((v >> 6) + 512) << 16) | (uint32_t)(32 * (tb + (v & 63)) + l31);
+                    key = v != 0x7fffffff ? key : 0xffffffffu;
+                    if (folded) key = min(key, fin[16 * g + r][lane]);                   // (wave-uniform: sets beyond 2048 rows only)
+                    fin[16 * g + r][lane] = key;
+                    run[g][r] = 0x7fffffff;
+                }
+            folded = true;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cinit[r] = 0;
         }
-        // lane (half, l31 = r < 16) writes row (r & 3) + 8 (r >> 2) + 4 half of the group
-        const int row = r0 + 32 * g + rowl;
-        const int pa_row = __shfl(pa[g], rowl);                      // |a| lives in lane rowl; every lane takes part in the shuffle
-        if (l31 < 16 && row < nA) {
-            uint32_t key = run[g][0];
+    }
+#undef HM_LDB
+    if (!folded) {
 #pragma unroll
-            for (int r = 1; r < 16; ++r) key = (l31 == r) ? run[g][r] : key;
+        for (int k = 0; k < HM_RG * 16; ++k) fin[k][lane] = 0xffffffffu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- lane q takes matrix row q of the wavefront (and q + 64 in a second pass): accumulator reg = (q & 3) + 4 ((q & 31) >> 3),
+    // half = (q >> 2) & 1  [C/D map: row = (reg & 3) + 8 (reg >> 2) + 4 half]; its 32 keys are 8 x 16 bytes, read in a lane-rotated
+    // order so that the 64 lanes do not all start on the same LDS banks
+#pragma unroll
+    for (int pass = 0; pass < (32 * HM_RG + 63) / 64; ++pass) {
+        const int q = 64 * pass + lane, g = q >> 5, rowl = q & 31;
+        const bool live = q < 32 * HM_RG;
+        const int reg = (rowl & 3) + 4 * (rowl >> 3), hq = (rowl >> 2) & 1;
+        uint32_t key = 0xffffffffu;
+        if (live) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(&fin[16 * g + reg][32 * hq]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 v = src[(j + lane) & 7];
+                key = min(key, min(min(v.x, v.y), min(v.z, v.w)));
+            }
+        }
+        int pa_row = 0;                                               // |a| of row q lives in lane rowl of group g; every lane takes part
+#pragma unroll
+        for (int gg = 0; gg < HM_RG; ++gg) { const int v = __shfl(pa[gg], rowl); pa_row = (g == gg) ? v : pa_row; }
+        const int row = r0 + q;
+        if (live && row < nA) {
             int idx = -1, dist = 0x7FFFFFFF;
             if (nB > 0) { idx = (int)(key & 0xffffu); dist = (int)(key >> 16) - 512 + pa_row; }
             const size_t o = (size_t)p * A.out_stride + row;
@@ -272,14 +314,14 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
     const dim3 grid_s(n_pairs, ygz_div_up(max_rows, 256 * HM_ROWS));
     const bool wide = max_rows > 0xFFFF;              // the <false> kernel packs (distance, row) into one 32-bit key
     static const bool valu_only = [] { const char *e = getenv("YGZ_HAMMING_VALU"); return e && e[0] == '1'; }();   // A/B switch: the VALU form
-    const dim3 grid_m(n_pairs, ygz_div_up(max_rows, 128 * HM_RG));
+    const dim3 grid_m(n_pairs, ygz_div_up(max_rows, 32 * HM_RG)), block_m(64);
     if (cross_check == 0 || cross_check == 2) {       // query -> train
         A.pair_a = pair_q; A.pair_b = pair_t;
         A.out_idx = ctx->m_idx; A.out_dist = ctx->m_dist; A.out_dist2 = want_second ? ctx->m_dist2 : nullptr;
         A.scatter_key = nullptr;
         if (want_second || wide) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<true, 1>), grid, block, A);
         else if (valu_only) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
-        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block, A);
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block_m, A);
     }
     if (cross_check == 1 || cross_check == 2) {       // train -> query
         if (cross_check == 1)
@@ -289,7 +331,7 @@ static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, 
         A.scatter_key = (cross_check == 1) ? ctx->m_key : nullptr;
         if (wide) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<true, 1>), grid, block, A);
         else if (valu_only) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
-        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block, A);
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block_m, A);
         YGZ_LAUNCH(ctx, KID_MATCH_FINALIZE, k_match_finalize, grid_f, block, set_count, pair_q, Cn, cross_check,
                            ctx->m_key, ctx->m_tq, ctx->m_idx, ctx->m_dist);
     }
