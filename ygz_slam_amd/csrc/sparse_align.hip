@@ -36,6 +36,7 @@ struct SaArgs {
     uint8_t *work; size_t work_stride;            // per pair: Hf, (unused), dxy, prev_used (96 doubles/cell) | patch_cache | r2 | ctot | pre | fmap | pmap | visible | used
     double *out;                                  // [pairs][16]: pose 7 (in: initial cur->_TCW, out: result), n_meas, iters
     double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
+    int lcap;                                     // features whose per-iteration scratch (r2, maps, prefixes) lives in LDS; multiple of 64
 };
 
 #define wave_sum_d ygz_wave_sum_d
@@ -107,6 +108,21 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
     int4 *fmap = reinterpret_cast<int4 *>(pre + A.cells);               // [cells] 16-term parity map of the feature: t0, t1, E, bad | head << 1
     int2 *pmap = reinterpret_cast<int2 *>(fmap + A.cells);              // [cells] map of the features from the head of f's segment to f
     uint8_t *visible = (uint8_t *)(pmap + A.cells);                     // [cells]
+    // The per-iteration scratch of the first A.lcap features lives in LDS (dynamic, ~92 bytes per feature): the squared residuals are
+    // written by the residual pass and read twice (map build, wave 0's walk), the maps once each -- 250 of the ~480 bytes a feature
+    // moved per iteration went through L2 / MALL for data only this workgroup ever sees.  Features beyond lcap use the global arrays.
+    extern __shared__ __attribute__((aligned(16))) unsigned char sa_dyn[];
+    const int LC = A.lcap;
+    float4 *const l_r2 = reinterpret_cast<float4 *>(sa_dyn);                              // [4][LC]
+    int4 *const l_fmap = reinterpret_cast<int4 *>(l_r2 + 4 * (size_t)LC);                  // [LC]
+    int2 *const l_pmap = reinterpret_cast<int2 *>(l_fmap + LC);                            // [LC]
+    float *const l_pre = reinterpret_cast<float *>(l_pmap + LC);                           // [LC]
+    float *const l_ctot = l_pre + LC;                                                      // [LC / 64]
+#define SA_R2(q_, f_) (*((f_) < LC ? l_r2 + (size_t)(q_) * LC + (f_) : reinterpret_cast<float4 *>(r2) + (size_t)(q_) * A.cells + (f_)))
+#define SA_FMAP(f_) (*((f_) < LC ? l_fmap + (f_) : fmap + (f_)))
+#define SA_PMAP(f_) (*((f_) < LC ? l_pmap + (f_) : pmap + (f_)))
+#define SA_PRE(f_) (*((f_) < LC ? l_pre + (f_) : pre + (f_)))
+#define SA_CTOT(c_) (*((c_) * 64 < LC ? l_ctot + (c_) : ctot + (c_)))
     uint8_t *used = visible + A.cells;                                  // [cells] feature contributes this iteration
     Se3 T_ref;
     for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
@@ -281,9 +297,8 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 float xs[16];
 #pragma unroll
                 for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
-                float4 *dst = reinterpret_cast<float4 *>(r2);          // the chain terms, quarter-major: lanes write 1 KB contiguous per store
 #pragma unroll
-                for (int k = 0; k < 4; ++k) dst[(size_t)k * A.cells + f] = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
+                for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);      // the chain terms, quarter-major
                 used[f] = use ? 1 : 0;
                 const bool pu = pu_f != 0;
                 if (use != pu) {                                     // rare after the first iteration of a level: H changes by +-Hf, added in the
@@ -315,8 +330,8 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 }   // f < n
                 // approximate value of the chi2 chain at the start of the feature, relative to its chunk of 64 (= this wavefront)
                 const float incl = ygz_wave_scan_f(sq);
-                if (f < n) pre[f] = incl - sq;
-                if (lane == 63) ctot[f >> 6] = incl;
+                if (f < n) SA_PRE(f) = incl - sq;
+                if (lane == 63) SA_CTOT(f >> 6) = incl;
             }
 #undef BIL
 #pragma unroll
@@ -350,14 +365,13 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 if (64 * chunk >= n) continue;                                // wave-uniform
                 const int f = f0_ + tid, cnt = min(64, n - 64 * chunk);
                 float part = 0.f;
-                for (int c2 = lane; c2 < chunk; c2 += 64) part += ctot[c2];
+                for (int c2 = lane; c2 < chunk; c2 += 64) part += SA_CTOT(c2);
                 const float base = ygz_wave_sum_f(part);
                 int t0 = 0, t1 = 0, bad = 0, E = 0;
                 if (f < n) {
-                    const float4 *src = reinterpret_cast<const float4 *>(r2) + f;
-                    const float4 a0 = src[0], a1 = src[A.cells], a2 = src[2 * (size_t)A.cells], a3 = src[3 * (size_t)A.cells];
+                    const float4 a0 = SA_R2(0, f), a1 = SA_R2(1, f), a2 = SA_R2(2, f), a3 = SA_R2(3, f);
                     const float x[16] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
-                    E = (int)(__float_as_uint(base + pre[f]) >> 23);
+                    E = (int)(__float_as_uint(base + SA_PRE(f)) >> 23);
                     bad = !(E > 0 && E < 255);
 #pragma unroll
                     for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 SA_SCAN(0x142, 0xA, (lane & 16) != 0)                          // row_bcast:15 -> rows 1, 3
                 SA_SCAN(0x143, 0xC, lane >= 32)                                // row_bcast:31 -> rows 2, 3
 #undef SA_SCAN
-                if (f < n) { fmap[f] = make_int4(t0, t1, E, bad | (head << 1)); pmap[f] = make_int2(p0, p1); }
+                if (f < n) { SA_FMAP(f) = make_int4(t0, t1, E, bad | (head << 1)); SA_PMAP(f) = make_int2(p0, p1); }
             }
             __syncthreads();
             SA_PHASE(13);     // maps + scan
@@ -393,8 +407,7 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                 float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: chunk j + 1 is in flight
                 int4 nm = make_int4(0, 0, 0, 0); int2 np = make_int2(0, 0);
                 if (lane < n) {
-                    const float4 *src = reinterpret_cast<const float4 *>(r2) + lane;
-                    n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells]; nm = fmap[lane]; np = pmap[lane];
+                    n0 = SA_R2(0, lane); n1 = SA_R2(1, lane); n2 = SA_R2(2, lane); n3 = SA_R2(3, lane); nm = SA_FMAP(lane); np = SA_PMAP(lane);
                 }
 #define SA_TRY(m0_, m1_, mE_, mbad_, taken)                                                                            \
                     { taken = false;                                                                                   \
@@ -411,8 +424,7 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
                         const int fn = 64 * (j + 1) + lane;
                         n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nm = make_int4(0, 0, 0, 0); np = make_int2(0, 0);
                         if (fn < n) {
-                            const float4 *src = reinterpret_cast<const float4 *>(r2) + fn;
-                            n0 = src[0]; n1 = src[A.cells]; n2 = src[2 * (size_t)A.cells]; n3 = src[3 * (size_t)A.cells]; nm = fmap[fn]; np = pmap[fn];
+                            n0 = SA_R2(0, fn); n1 = SA_R2(1, fn); n2 = SA_R2(2, fn); n3 = SA_R2(3, fn); nm = SA_FMAP(fn); np = SA_PMAP(fn);
                         }
                     }
                     SA_PHASE(9);
@@ -528,8 +540,19 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
     const char *env_t = getenv("YGZ_SA_THREADS");
     const int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
-    if (threads == 512) YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align<512>, dim3(n_pairs), dim3(512), A);
-    else YGZ_LAUNCH(ctx, KID_SPARSE_ALIGN, k_sparse_align<256>, dim3(n_pairs), dim3(256), A);
+    // per-iteration scratch of the first lcap features in LDS: 4 x 16 (r2) + 16 (fmap) + 8 (pmap) + 4 (pre) bytes each + chunk totals
+    static const int lcap_env = [] { const char *e = getenv("YGZ_SA_LDS"); return e ? atoi(e) : 1024; }();
+    A.lcap = ((lcap_env < ctx->cells ? lcap_env : ctx->cells) + 63) / 64 * 64;
+    if (A.lcap < 0) A.lcap = 0;
+    const size_t dyn = (size_t)A.lcap * 92 + (size_t)(A.lcap / 64 + 1) * 4 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    if (threads == 512) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align<512>, dim3(n_pairs), dim3(512), dyn, A);
+    else YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align<256>, dim3(n_pairs), dim3(256), dyn, A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         double h[16];

@@ -137,6 +137,13 @@ enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIB
          hipLaunchKernelGGL(kern, grid, block, 0, (ctx)->stream, __VA_ARGS__);                                 \
          if (pr_) { (void)hipEventRecord((ctx)->probe_ev[(ctx)->probe_used + 1], (ctx)->stream); (ctx)->probe_used += 2; } } while (0)
 
+// the same with dynamic LDS bytes
+#define YGZ_LAUNCH_DYN(ctx, kid, kern, grid, block, dyn, ...)                                                \
+    do { const bool pr_ = (ctx)->probe_id == (kid) && (ctx)->probe_used + 2 <= (int)(ctx)->probe_ev.size();    \
+         if (pr_) (void)hipEventRecord((ctx)->probe_ev[(ctx)->probe_used], (ctx)->stream);                     \
+         hipLaunchKernelGGL(kern, grid, block, dyn, (ctx)->stream, __VA_ARGS__);                               \
+         if (pr_) { (void)hipEventRecord((ctx)->probe_ev[(ctx)->probe_used + 1], (ctx)->stream); (ctx)->probe_used += 2; } } while (0)
+
 // scratch ids
 enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR_SA_OUT, SCR_SA_WORK,
        SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_LMAP, SCR_GEN_0 = 16 };
