@@ -234,8 +234,12 @@ class OfflineVO:
         else:
             bgr = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
             dmaps = [depth_source(f) for f in frames]
-        c.upload_bgr_batch(0, bgr)
-        c.build_pyramid(0, n, from_bgr=True)
+        if bgr.ndim == 3:                                      # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
+            c.upload_gray_batch(0, bgr)
+            c.build_pyramid(0, n, from_bgr=False)
+        else:
+            c.upload_bgr_batch(0, bgr)
+            c.build_pyramid(0, n, from_bgr=True)
         c.detect(0, n)
         px, cnt = c.get_keypoint_pixels_batch(0, n)
         depth = np.zeros((n, cells), np.float64)
