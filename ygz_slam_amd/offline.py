@@ -177,13 +177,13 @@ class OfflineVO:
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
-        self.ctx = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
+        self.ctx = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2, window_kfs), device=device)
         self.ctx.set_overlap(overlap)
         # a second context (own streams, own slots) takes every other chunk from its own host thread: the H2D copy of one chunk and
         # the host-side depth look-up of its keypoints run under the kernels of the other (the C calls release the GIL)
         self.lanes = [self.ctx]
         if lanes > 1 and self.count > chunk:
-            c2 = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
+            c2 = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2, window_kfs), device=device)
             c2.set_overlap(overlap)
             self.lanes.append(c2)
         self.timing = {}
