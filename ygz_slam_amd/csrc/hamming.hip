@@ -170,14 +170,23 @@ __global__ __launch_bounds__(64) void k_hamming_mfma(HamArgs A)
     if (r0 >= nA) return;
     const uint32_t *da = A.desc + (size_t)sa * A.set_stride, *db = A.desc + (size_t)sb * A.set_stride;
     const int half = lane >> 5, l31 = lane & 31;
+    // every load the wavefront starts with goes out before anything is computed: the A rows and the first three B tiles (one
+    // memory latency at the start of a wavefront instead of two)
+#define HM_LDB(dst_, j_) { dst_ = make_uint4(0, 0, 0, 0); if ((j_) < nB) dst_ = reinterpret_cast<const uint4 *>(db + 8 * (size_t)(j_))[half]; }
+    uint4 a_raw[HM_RG], b, bn1, bn2;
+#pragma unroll
+    for (int g = 0; g < HM_RG; ++g) {
+        a_raw[g] = make_uint4(0, 0, 0, 0);
+        const int row = r0 + 32 * g + l31;
+        if (row < nA) a_raw[g] = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[half];
+    }
+    HM_LDB(b, l31) HM_LDB(bn1, l31 + 32) HM_LDB(bn2, l31 + 64)
     // ---- this wavefront's rows of A: lane (l31, half) holds dwords [4 half, 4 half + 4) of rows r0 + 32 g + l31
     hm_v4i Aop[HM_RG][8];
     int pa[HM_RG];                                                   // |a| of row r0 + 32 g + l31
 #pragma unroll
     for (int g = 0; g < HM_RG; ++g) {
-        uint4 a = make_uint4(0, 0, 0, 0);
-        const int row = r0 + 32 * g + l31;
-        if (row < nA) a = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[half];
+        const uint4 a = a_raw[g];
         const uint32_t w[4] = { a.x, a.y, a.z, a.w };
         int pc = 0;
 #pragma unroll
@@ -197,9 +206,6 @@ __global__ __launch_bounds__(64) void k_hamming_mfma(HamArgs A)
         for (int r = 0; r < 16; ++r) run[g][r] = 0x7fffffff;
     const int n_tiles = (nB + 31) >> 5;
     // software pipeline: the rows of the next three tiles are in flight (an L2 hit takes longer than one tile of MFMAs)
-#define HM_LDB(dst_, j_) { dst_ = make_uint4(0, 0, 0, 0); if ((j_) < nB) dst_ = reinterpret_cast<const uint4 *>(db + 8 * (size_t)(j_))[half]; }
-    uint4 b, bn1, bn2;
-    HM_LDB(b, l31) HM_LDB(bn1, l31 + 32) HM_LDB(bn2, l31 + 64)
     hm_v16i cinit = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };                // splat(tile index inside the block of 64)
     bool folded = false;
     for (int t = 0; t < n_tiles; ++t) {
