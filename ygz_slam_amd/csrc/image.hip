@@ -51,12 +51,14 @@ __device__ __forceinline__ int reflect101(int i, int n)
 }
 
 // cv::pyrDown 8u: separable [1 4 6 4 1], dst = (sum + 128) >> 8, BORDER_REFLECT_101.
-// One block = 64x16 output pixels; the (2*64+3+pad) x (2*16+3) source window is staged in LDS
-// with 4-byte loads (rows start 4-byte aligned when sw % 4 == 0), borders reflected on the fly.
+// One block = 64 x 32 output pixels; the 160 x 67 source window is staged in LDS with 16-byte loads (rows are 16-byte aligned when
+// sw % 16 == 0), borders reflected on the fly.
 #define PD_TW 64
-#define PD_TH 16
-#define PD_SW 136          // staged row: source x in [2*ox0 - 4, 2*ox0 + 132)
-#define PD_SH 35           // source y in [2*oy0 - 2, 2*oy0 + 33)
+#define PD_TH 32
+#define PD_RPT (PD_TH / 4)   // output rows per thread
+#define PD_SW 160          // staged row: source x in [2*ox0 - 16, 2*ox0 + 144): ten 16-byte vectors, 16-byte aligned when sw % 16 == 0
+#define PD_SH (2 * PD_TH + 3)   // source y in [2*oy0 - 2, 2*oy0 + 2*PD_TH + 1)
+#define PD_X0 16           // staged column of source x = 2*ox0
 __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                   int sw, int sh, int dw, int dh, int slot_begin)
 {
@@ -65,34 +67,54 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ sr
     const uint8_t *s = src + slot * (size_t)sw * sh;
     uint8_t *d = dst + slot * (size_t)dw * dh;
     const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
-    const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
-    const bool aligned = (sw & 3) == 0;
-    for (int i = threadIdx.x; i < PD_SH * (PD_SW / 4); i += 256) {
-        const int r = i / (PD_SW / 4), c4 = (i % (PD_SW / 4)) * 4;
-        const int sy = reflect101(sy0 + r, sh), sx = sx0 + c4;
-        uint32_t v;
-        if (aligned && sx >= 0 && sx + 3 < sw) {
-            v = *reinterpret_cast<const uint32_t *>(s + (size_t)sy * sw + sx);
-        } else {
+    const int sx0 = 2 * ox0 - PD_X0, sy0 = 2 * oy0 - 2;
+    const bool aligned = (sw & 15) == 0;
+    // 16 bytes per lane and load (4-byte loads ran the kernel at a quarter of the HBM rate), and all of a thread's staging loads go
+    // out before the first LDS store
+    constexpr int PD_RW = PD_SW / 16, PD_TOT = PD_SH * PD_RW, PD_N = (PD_TOT + 255) / 256;
+    uint4 stage[PD_N];
+#pragma unroll
+    for (int k = 0; k < PD_N; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int r = i / PD_RW, c16 = (i % PD_RW) * 16;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i < PD_TOT) {
+            const int sy = reflect101(sy0 + r, sh), sx = sx0 + c16;
             const uint8_t *row = s + (size_t)sy * sw;
-            v = (uint32_t)row[reflect101(sx, sw)] | ((uint32_t)row[reflect101(sx + 1, sw)] << 8) |
-                ((uint32_t)row[reflect101(sx + 2, sw)] << 16) | ((uint32_t)row[reflect101(sx + 3, sw)] << 24);
+            if (aligned && sx >= 0 && sx + 15 < sw) v = *reinterpret_cast<const uint4 *>(row + sx);
+            else {
+                uint32_t w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w4[q] = (uint32_t)row[reflect101(sx + 4 * q, sw)] | ((uint32_t)row[reflect101(sx + 4 * q + 1, sw)] << 8) |
+                            ((uint32_t)row[reflect101(sx + 4 * q + 2, sw)] << 16) | ((uint32_t)row[reflect101(sx + 4 * q + 3, sw)] << 24);
+                v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
         }
-        *reinterpret_cast<uint32_t *>(&tile[r][c4]) = v;
+        stage[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < PD_N; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < PD_TOT) *reinterpret_cast<uint4 *>(&tile[i / PD_RW][(i % PD_RW) * 16]) = stage[k];
     }
     __syncthreads();
-    // lane = output column, each thread 4 output rows (shares source rows between them)
-    const int tx = threadIdx.x & 63, ty0 = (threadIdx.x >> 6) * 4;
+    // lane = output column, each thread PD_RPT consecutive output rows (they share source rows)
+    const int tx = threadIdx.x & 63, ty0 = (threadIdx.x >> 6) * PD_RPT;
     const int ox = ox0 + tx;
-    int hrow[11];                                   // horizontal sums of source rows 2*ty0-2 .. 2*ty0+8
+    int hrow[2 * PD_RPT + 3];                       // horizontal sums of source rows 2*ty0-2 .. 2*ty0+2*PD_RPT
 #pragma unroll
-    for (int r = 0; r < 11; ++r) {
-        const uint8_t *t = &tile[2 * ty0 + r][2 * tx + 2];      // source x = 2*ox - 2
-        hrow[r] = t[0] + 4 * t[1] + 6 * t[2] + 4 * t[3] + t[4];
+    for (int r = 0; r < 2 * PD_RPT + 3; ++r) {
+        // the five taps start at source x = 2*ox - 2, byte 2*tx + PD_X0 - 2 of the staged row: two aligned LDS dwords, the first four taps
+        // with their weights 1 4 6 4 as ONE v_dot4_u32_u8 (five byte reads and eight ALU operations per row before)
+        const uint32_t *tw = reinterpret_cast<const uint32_t *>(&tile[2 * ty0 + r][(2 * tx + PD_X0 - 2) & ~3]);
+        const uint32_t d0 = tw[0], d1 = tw[1], sh = (uint32_t)((2 * tx + PD_X0 - 2) & 3);
+        const uint32_t v4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        hrow[r] = (int)__builtin_amdgcn_udot4(v4, 0x04060401u, (d1 >> (8 * sh)) & 255u, false);
     }
     if (ox < dw) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PD_RPT; ++k) {
             const int oy = oy0 + ty0 + k;
             if (oy < dh) {
                 const int v = hrow[2 * k] + 4 * hrow[2 * k + 1] + 6 * hrow[2 * k + 2] + 4 * hrow[2 * k + 3] + hrow[2 * k + 4];
