@@ -96,11 +96,16 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
     if (tid == 0) { n_list = 0; n_cand = 0; }
     for (int i = tid; i < R1_H * R1_LW / 4; i += 256) reinterpret_cast<uint32_t *>(&sc[0][0])[i] = 0u;
     const bool aligned = (A.w & 3) == 0;
-    for (int i = tid; i < FT_LH * (FT_LW / 4); i += 256) {
+    // all of a thread's tile loads go out before the first LDS store (rolled, the loop was a chain of four dependent memory latencies)
+    constexpr int FT_TOT = FT_LH * (FT_LW / 4), FT_LN = (FT_TOT + 255) / 256;
+    uint32_t tv[FT_LN];
+#pragma unroll
+    for (int k4 = 0; k4 < FT_LN; ++k4) {
+        const int i = tid + 256 * k4;
         const int r = i / (FT_LW / 4), c4 = (i % (FT_LW / 4)) * 4;
         const int y = y0 - FT_Y0 + r, x = x0 - FT_X0 + c4;
         uint32_t v = 0;
-        if (y >= 0 && y < A.h) {
+        if (i < FT_TOT && y >= 0 && y < A.h) {
             const uint8_t *row = img + (size_t)y * A.w;
             if (aligned && x >= 0 && x + 3 < A.w) v = *reinterpret_cast<const uint32_t *>(row + x);
             else {
@@ -108,7 +113,12 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
                 for (int k = 0; k < 4; ++k) if (x + k >= 0 && x + k < A.w) v |= (uint32_t)row[x + k] << (8 * k);
             }
         }
-        *reinterpret_cast<uint32_t *>(&tile[r][c4]) = v;
+        tv[k4] = v;
+    }
+#pragma unroll
+    for (int k4 = 0; k4 < FT_LN; ++k4) {
+        const int i = tid + 256 * k4;
+        if (i < FT_TOT) *reinterpret_cast<uint32_t *>(&tile[i / (FT_LW / 4)][(i % (FT_LW / 4)) * 4]) = tv[k4];
     }
     __syncthreads();
     FS_PHASE(0);
@@ -390,17 +400,31 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
     const int n = w * h;
     // 39 x 39 neighbourhood, linear addressing as center[dy*step+dx] (reads outside the level buffer are 0): 39 rows x 10
     // dwords, each from two aligned dword loads + v_alignbyte (a wave-wide byte gather costs as much as a dword load)
-    for (int item = lane; item < DP_W * 10; item += 64) {
+    // The lane's seven items are requested as ONE batch (14 loads in flight) and written to LDS afterwards: as a rolled loop this
+    // was a chain of seven dependent memory latencies per keypoint, most of the kernel's time.
+    constexpr int DP_ITEMS = DP_W * 10, DP_LN = (DP_ITEMS + 63) / 64;
+    uint32_t w_lo[DP_LN], w_hi[DP_LN], w_sh[DP_LN];
+    bool w_in[DP_LN];
+#pragma unroll
+    for (int k = 0; k < DP_LN; ++k) {
+        const int item = lane + 64 * k;
         const int r = item / 10, j = item - 10 * r;
         const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
-        uint32_t v;
-        if (idx0 >= 0 && idx0 + 4 <= n) {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(img + idx0);
-            ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
-            v = __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)(a & 3));
-        } else {
+        w_in[k] = item < DP_ITEMS && idx0 >= 0 && idx0 + 4 <= n;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(img + (w_in[k] ? idx0 : 0));
+        ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
+        w_lo[k] = q[0]; w_hi[k] = q[1]; w_sh[k] = (uint32_t)(a & 3);
+    }
+#pragma unroll
+    for (int k = 0; k < DP_LN; ++k) {
+        const int item = lane + 64 * k;
+        if (item >= DP_ITEMS) continue;
+        uint32_t v = __builtin_amdgcn_alignbyte(w_hi[k], w_lo[k], w_sh[k]);
+        if (!w_in[k]) {                             // the window leaves the level buffer: byte by byte, zeros outside (rare)
+            const int r = item / 10, j = item - 10 * r;
+            const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
             v = 0;
-            for (int k = 0; k < 4; ++k) { const int idx = idx0 + k; if (idx >= 0 && idx < n) v |= (uint32_t)img[idx] << (8 * k); }
+            for (int kk = 0; kk < 4; ++kk) { const int idx = idx0 + kk; if (idx >= 0 && idx < n) v |= (uint32_t)img[idx] << (8 * kk); }
         }
         patch32[item] = v;                          // item == r * (DP_P / 4) + j
     }
