@@ -42,59 +42,72 @@ __device__ __forceinline__ int refl101(int i, int n)
 #define KLT_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
 typedef uint32_t __attribute__((aligned(1))) klt_u32u;      // 4 adjacent bytes at any address: one (unaligned) global_load_dword
 
-// padded copy: out[(y+B)*pw + x+B] = in[refl101(y)][refl101(x)], 4 output pixels per lane, once per distinct slot
+typedef uint32_t klt_u32x4 __attribute__((ext_vector_type(4)));
+typedef klt_u32x4 __attribute__((aligned(1))) klt_u32x4u;      // 16 adjacent bytes at any address: one (unaligned) global_load_dwordx4
+
+// padded copy: out[(y+B)*pw + x+B] = in[refl101(y)][refl101(x)], 16 output pixels per lane (4-byte accesses ran these two
+// streaming kernels at a third of the HBM rate), once per distinct slot
 __global__ __launch_bounds__(256) void k_klt_pad(const uint8_t *__restrict__ img_base, uint8_t *__restrict__ pad_base,
                                                  const int32_t *__restrict__ slots, int w, int h, int n_slots)
 {
     int bx_, by_, z_;
     if (!ygz_xcd_remap3(n_slots, bx_, by_, z_)) return;
     const int pw = KLT_PW(w), ph = h + 2 * KLT_B;
-    const int x4 = (bx_ * 64 + (threadIdx.x & 63)) * 4, y = by_ * 4 + (threadIdx.x >> 6);
-    if (x4 >= pw || y >= ph) return;
+    const int chunks = (pw + 15) >> 4, item = bx_ * 256 + (int)threadIdx.x;       // flat (row, 16-pixel chunk) items: no idle lanes at any width
+    const int y = item / chunks, x16 = (item - y * chunks) * 16;
+    if (y >= ph) return;
     const size_t slot = (size_t)slots[z_];
     const uint8_t *row = img_base + slot * (size_t)w * h + (size_t)refl101(y - KLT_B, h) * w;
-    const int sx = x4 - KLT_B;
-    uint32_t v = 0;
-    if (sx >= 0 && sx + 3 < w) v = *reinterpret_cast<const klt_u32u *>(row + sx);
-    else {
+    uint8_t *out = pad_base + slot * (size_t)pw * ph + (size_t)y * pw + x16;
+    const int sx = x16 - KLT_B;
+    if (x16 + 15 < pw && sx >= 0 && sx + 15 < w) { *reinterpret_cast<klt_u32x4u *>(out) = *reinterpret_cast<const klt_u32x4u *>(row + sx); return; }
+    for (int q = 0; q < 4 && x16 + 4 * q < pw; ++q) {             // the frame columns and the ragged end of the row: dword by dword
+        uint32_t v = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v |= (uint32_t)row[refl101(sx + k, w)] << (8 * k);
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)row[refl101(sx + 4 * q + k, w)] << (8 * k);
+        *reinterpret_cast<uint32_t *>(out + 4 * q) = v;
     }
-    *reinterpret_cast<uint32_t *>(pad_base + slot * (size_t)pw * ph + (size_t)y * pw + x4) = v;
 }
 
 // calcSharrDeriv: dx = smooth_v(x+1) - smooth_v(x-1), dy = 3/10/3 smooth_h of (row+1 - row-1); output zero-framed.
-// Reads the framed copy (its BORDER_REFLECT_101 frame is exactly the border rule of the derivative), 4 pixels per lane:
-// three rows of 6 bytes as two unaligned dword loads each, one 16-byte store.
+// Reads the framed copy (its BORDER_REFLECT_101 frame is exactly the border rule of the derivative).  A lane owns 4 pixels x 4 rows:
+// six source rows of 6 bytes (two unaligned dword loads each, all twelve in flight together) feed four output rows, and every
+// 16-byte store of the wavefront is one contiguous kilobyte (consecutive lanes, consecutive pixels).
 __global__ __launch_bounds__(256) void k_scharr(const uint8_t *__restrict__ pad_base, int16_t *__restrict__ deriv_base,
                                                 const int32_t *__restrict__ slots, int w, int h, int n_slots)
 {
     int bx_, by_, z_;
     if (!ygz_xcd_remap3(n_slots, bx_, by_, z_)) return;
-    const int x = (bx_ * 64 + (threadIdx.x & 63)) * 4, y = by_ * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    const int chunks = (w + 3) >> 2, item = bx_ * 256 + (int)threadIdx.x;         // flat (4-row strip, 4-pixel chunk) items
+    const int strip = item / chunks, x = (item - strip * chunks) * 4, y0 = 4 * strip;
+    if (y0 >= h) return;
     const size_t slot = (size_t)slots[z_];
     const int pw = KLT_PW(w), ph = h + 2 * KLT_B;
-    const uint8_t *p = pad_base + slot * (size_t)pw * ph + (size_t)(y + KLT_B - 1) * pw + (x + KLT_B - 1);
-    uint32_t *deriv = reinterpret_cast<uint32_t *>(deriv_base) + slot * (size_t)pw * ph + (size_t)(y + KLT_B) * pw + (x + KLT_B);
-    uint32_t lo[3], hi[3];
+    const uint8_t *p = pad_base + slot * (size_t)pw * ph + (size_t)(y0 + KLT_B - 1) * pw + (x + KLT_B - 1);
+    uint32_t *deriv = reinterpret_cast<uint32_t *>(deriv_base) + slot * (size_t)pw * ph + (size_t)(y0 + KLT_B) * pw + (x + KLT_B);
+    uint32_t lo[6], hi[6];                                        // rows y0-1 .. y0+4 (inside the frame: KLT_B >= 5), columns x-1 .. x+6
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { lo[r] = *reinterpret_cast<const klt_u32u *>(p + (size_t)r * pw); hi[r] = *reinterpret_cast<const klt_u32u *>(p + (size_t)r * pw + 4); }
-    int t0[6], t1[6];            // trow0 = (s0+s2)*3 + s1*10 ; trow1 = s2 - s0 for columns x-1 .. x+4
+    for (int r = 0; r < 6; ++r) { lo[r] = *reinterpret_cast<const klt_u32u *>(p + (size_t)r * pw); hi[r] = *reinterpret_cast<const klt_u32u *>(p + (size_t)r * pw + 4); }
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-        const int s0 = KLT_BYTE(lo[0], hi[0], c), s1 = KLT_BYTE(lo[1], hi[1], c), s2 = KLT_BYTE(lo[2], hi[2], c);
-        t0[c] = (s0 + s2) * 3 + s1 * 10; t1[c] = s2 - s0;
+    for (int q = 0; q < 4; ++q) {
+        if (y0 + q >= h) break;
+        int t0[6], t1[6];        // trow0 = (s0+s2)*3 + s1*10 ; trow1 = s2 - s0 for columns x-1 .. x+4
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int s0 = KLT_BYTE(lo[q], hi[q], c), s1 = KLT_BYTE(lo[q + 1], hi[q + 1], c), s2 = KLT_BYTE(lo[q + 2], hi[q + 2], c);
+            t0[c] = (s0 + s2) * 3 + s1 * 10; t1[c] = s2 - s0;
+        }
+        uint32_t out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dx = (int16_t)(t0[k + 2] - t0[k]);
+            const int dy = (int16_t)((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10);
+            out[k] = ((uint32_t)(uint16_t)dx) | ((uint32_t)(uint16_t)dy << 16);
+        }
+        uint32_t *drow = deriv + (size_t)q * pw;
+        if (x + 3 < w) *reinterpret_cast<uint4 *>(drow) = make_uint4(out[0], out[1], out[2], out[3]);
+        else { for (int k = 0; k < 4; ++k) if (x + k < w) drow[k] = out[k]; }       // the zero frame stays zero
     }
-    uint32_t out[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int dx = (int16_t)(t0[k + 2] - t0[k]);
-        const int dy = (int16_t)((t1[k + 2] + t1[k]) * 3 + t1[k + 1] * 10);
-        out[k] = ((uint32_t)(uint16_t)dx) | ((uint32_t)(uint16_t)dy << 16);
-    }
-    if (x + 3 < w) *reinterpret_cast<uint4 *>(deriv) = make_uint4(out[0], out[1], out[2], out[3]);
-    else { for (int k = 0; k < 4; ++k) if (x + k < w) deriv[k] = out[k]; }       // the zero frame stays zero
 }
 
 struct KltArgs {
@@ -540,9 +553,9 @@ static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *
         if (!ctx->klt_pad[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_pad[L], (size_t)ctx->prm.max_frames * psz + 64));
         A.pad[L] = ctx->klt_pad[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = w; A.h[L] = h;
         if (ctx->klt_prep_valid) continue;                       // the working images of this pair table were built ahead (ygz_klt_prepare_early)
-        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(pw / 4, 64), ygz_div_up(ph, 4), ygz_round_up8(ctx->n_klt_slots)), dim3(256),
+        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(ygz_div_up(pw, 16) * ph, 256), 1, ygz_round_up8(ctx->n_klt_slots)), dim3(256),
                    ctx->lvl[L], ctx->klt_pad[L], ctx->klt_slots, w, h, ctx->n_klt_slots);
-        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(ygz_div_up(w, 4), 64), ygz_div_up(h, 4), ygz_round_up8(ctx->n_klt_refs)), dim3(256),
+        YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(ygz_div_up(w, 4) * ygz_div_up(h, 4), 256), 1, ygz_round_up8(ctx->n_klt_refs)), dim3(256),
                    ctx->klt_pad[L], ctx->deriv[L], ctx->klt_slots + ctx->n_klt_slots, w, h, ctx->n_klt_refs);
     }
     ctx->klt_prep_valid = false;
