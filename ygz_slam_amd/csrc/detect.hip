@@ -477,11 +477,28 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
     }
 }
 
+// the per-cell selection state of the slots about to be extracted, in one launch (three fill launches cost 18 us of the step's serial head)
+__global__ __launch_bounds__(256) void k_detect_clear(uint32_t *__restrict__ cell_first, unsigned long long *__restrict__ cell_best,
+                                                      uint8_t *__restrict__ occupied /* or null: the caller supplied the mask */, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    cell_first[i] = 0xFFFFFFFFu; cell_best[i] = 0ull;
+    if (occupied) occupied[i] = 0;
+}
+
+static int detect_clear(ygz_hip_ctx *ctx, int slot_begin, int n_slots, bool clear_occupied)
+{
+    const size_t Cn = (size_t)ctx->cells, n = (size_t)n_slots * Cn, o = (size_t)slot_begin * Cn;
+    hipLaunchKernelGGL(k_detect_clear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->cell_first + o,
+                       reinterpret_cast<unsigned long long *>(ctx->cell_best) + o, clear_occupied ? ctx->occupied + o : nullptr, n);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
 int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
 {
     const size_t Cn = (size_t)ctx->cells;
-    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->cell_first + (size_t)slot_begin * Cn, 0xFF, (size_t)n_slots * Cn * 4, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->cell_best + (size_t)slot_begin * Cn, 0, (size_t)n_slots * Cn * 8, ctx->stream));
     for (int L = 0; L < ctx->prm.pyramid_levels; ++L) {
         const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
         if (ctx->prm.debug_maps) {
@@ -549,7 +566,7 @@ int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t 
     const size_t Cn = (size_t)ctx->cells;
     if (occupied) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->occupied + (size_t)slot_begin * Cn, occupied, (size_t)n_slots * Cn,
                                                   hipMemcpyHostToDevice, ctx->stream));
-    else YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->occupied + (size_t)slot_begin * Cn, 0, (size_t)n_slots * Cn, ctx->stream));
+    { const int rc = detect_clear(ctx, slot_begin, n_slots, occupied == nullptr); if (rc != YGZ_OK) return rc; }
     return ygz_launch_detect(ctx, slot_begin, n_slots);
 }
 
