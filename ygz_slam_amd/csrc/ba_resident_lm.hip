@@ -641,7 +641,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_ceres(const BaDev *__restrict
     __shared__ double red27[LM_WAVES][28];
     __shared__ double red[LM_WAVES];
     __shared__ double dxp[16 * 6];
-    __shared__ int s_fail, s_behind;
+    __shared__ int s_fail;
     const BaDev B = wins[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_ceres(const BaDev *__restrict
             if (radius <= o.min_trust_region_radius) { term = YGZ_CERES_MIN_RADIUS; break; }
             ++R.iterations;
             __syncthreads();
-            if (tid == 0) { s_fail = 0; s_behind = 0; }
+            if (tid == 0) s_fail = 0;
             __syncthreads();
             // ---- 1. per point: D = sHll + diag(clamp(diag sHll) / radius), Dinv, Y_e = sHpl_e Dinv (sH = column-scaled blocks)
             for (int il = tid; il < P; il += LM_THREADS) {

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
 #define DP_W   39
 #define DP_N   (DP_W * DP_W)
 
-static __device__ const int c_umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+// canonical ORB half-widths umax[|v|] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 } (packed as nibbles in k_describe)
 static __device__ const signed char c_pattern[1024] = { YGZ_ORB_PATTERN_VALUES };
 
 struct DescArgs {
