@@ -498,7 +498,6 @@ static int detect_clear(ygz_hip_ctx *ctx, int slot_begin, int n_slots, bool clea
 
 int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
 {
-    const size_t Cn = (size_t)ctx->cells;
     for (int L = 0; L < ctx->prm.pyramid_levels; ++L) {
         const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
         if (ctx->prm.debug_maps) {
