@@ -61,15 +61,13 @@ __device__ __forceinline__ bool ring10(uint32_t m)
     return (c & (a >> 8) & 0xFFFFu) != 0;
 }
 
-__global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
+static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const int bx_, const int by_, const int so_)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[FT_LH][FT_LW];
     __shared__ __attribute__((aligned(16))) uint8_t sc[R1_H][R1_LW];      // 0 = no corner, else score+1
     __shared__ uint16_t list[R1_W * R1_H], cand[R1_W * R1_H];
     __shared__ int n_list, n_cand;
 
-    int bx_, by_, so_;
-    if (!ygz_xcd_remap3(A.n_slots, bx_, by_, so_)) return;          // frame pinned to one XCD's L2 (block-uniform)
     const int slot = A.slot_begin + so_;
     const size_t npix = (size_t)A.w * A.h;
     const uint8_t *img = A.img + (size_t)slot * npix;
@@ -272,6 +270,21 @@ __global__ __launch_bounds__(256) void k_fast_select(FastArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// All pyramid levels of the extractor in ONE launch: block x enumerates the tiles of level 0, then level 1, ... of a frame (the
+// levels only meet in the per-cell atomicMax, which does not care about order); three launches cost two launch gaps and two tails.
+struct FastArgsAll { FastArgs lv[YGZ_MAX_LEVELS]; int n_levels; int tiles_x[YGZ_MAX_LEVELS]; int tile_end[YGZ_MAX_LEVELS]; };
+
+__global__ __launch_bounds__(256) void k_fast_select(FastArgsAll AA)
+{
+    int t_, y_, so_;
+    if (!ygz_xcd_remap3(AA.lv[0].n_slots, t_, y_, so_)) return;      // frame pinned to one XCD's L2 (block-uniform)
+    int L = 0;
+    while (L + 1 < AA.n_levels && t_ >= AA.tile_end[L]) ++L;
+    const int tl = t_ - (L ? AA.tile_end[L - 1] : 0);
+    const int by_ = tl / AA.tiles_x[L], bx_ = tl - by_ * AA.tiles_x[L];
+    fast_select_body(AA.lv[L], bx_, by_, so_);
+}
+
 __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ cell_first,
                                                   const unsigned long long *__restrict__ cell_best, int cells,
                                                   double *__restrict__ kp_px, int32_t *__restrict__ kp_level,
@@ -498,13 +511,16 @@ static int detect_clear(ygz_hip_ctx *ctx, int slot_begin, int n_slots, bool clea
 
 int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
 {
+    FastArgsAll AA;
+    AA.n_levels = ctx->prm.pyramid_levels;
+    int tiles = 0;
     for (int L = 0; L < ctx->prm.pyramid_levels; ++L) {
         const size_t npix = (size_t)ctx->lw[L] * ctx->lh[L];
         if (ctx->prm.debug_maps) {
             YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->dbg_score[L] + (size_t)slot_begin * npix, 0, (size_t)n_slots * npix, ctx->stream));
             YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->dbg_nms[L] + (size_t)slot_begin * npix, 0, (size_t)n_slots * npix, ctx->stream));
         }
-        FastArgs A;
+        FastArgs &A = AA.lv[L];
         A.img = ctx->lvl[L]; A.w = ctx->lw[L]; A.h = ctx->lh[L]; A.level = L;
         A.thr = ctx->prm.fast_threshold; A.tie = ctx->prm.nms_tie_suppress;
         A.img_cols = ctx->lw[0]; A.img_rows = ctx->lh[0];
@@ -517,8 +533,12 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
 #ifdef YGZ_FAST_TIMERS
         { void *dd = nullptr; if (getenv("YGZ_FAST_DEBUG") && ygz_scratch(ctx, SCR_GEN_0 + 1, 3 * 65536, &dd) == YGZ_OK) { if (L == 0) (void)hipMemsetAsync(dd, 0, 3 * 65536, ctx->stream); A.dbg_cyc = (long long *)dd + 8192 * L; } }
 #endif
-        YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(ygz_div_up(A.w, FT_W), ygz_div_up(A.h, FT_H), ygz_round_up8(n_slots)), dim3(256), A);
+        AA.tiles_x[L] = ygz_div_up(A.w, FT_W);
+        tiles += AA.tiles_x[L] * ygz_div_up(A.h, FT_H);
+        AA.tile_end[L] = tiles;
     }
+    for (int L = ctx->prm.pyramid_levels; L < YGZ_MAX_LEVELS; ++L) { AA.lv[L] = AA.lv[0]; AA.tiles_x[L] = 1; AA.tile_end[L] = tiles; }
+    YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(tiles, 1, ygz_round_up8(n_slots)), dim3(256), AA);
     YGZ_LAUNCH(ctx, KID_COMPACT, k_compact, dim3(n_slots), dim3(1024), ctx->cell_first, ctx->cell_best, ctx->cells,
                        ctx->kp_px, ctx->kp_level, ctx->kp_score, ctx->n_kp, slot_begin);
     YGZ_HIPCHK(ctx, hipGetLastError());
