@@ -180,10 +180,14 @@ int ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable)
         YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         int prio_lo = 0, prio_hi = 0;                       // numerically greatest = lowest priority
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        const char *pe = getenv("YGZ_AUX_PRIORITY");       // experiment switch: "low" = side streams below the main stream
-        const bool low = pe && pe[0] == 'l';
+        // experiment switch: "low" = every side stream below the main stream; or one letter per side stream (sparse alignment, BA,
+        // matcher + direct projection): h = highest, l = lowest priority, anything else = default
+        const char *pe = getenv("YGZ_AUX_PRIORITY");
+        const bool all_low = pe && strcmp(pe, "low") == 0;
         for (int i = 0; i < 3; ++i) {
-            if (low) YGZ_HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_lo));
+            const char c = all_low ? 'l' : (pe && strlen(pe) > (size_t)i ? pe[i] : 'n');
+            if (c == 'l') YGZ_HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_lo));
+            else if (c == 'h') YGZ_HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_hi));
             else YGZ_HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
             YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
         }
