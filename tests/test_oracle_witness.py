@@ -189,6 +189,49 @@ def test_witness_g2o_lm_reaches_the_least_squares_optimum(oracle):
     assert np.allclose(pts_s, scale * pt, atol=2e-4 * max(1.0, scale)) and np.allclose(Ts[:, 4:], scale * To[:, 4:], atol=2e-5 * max(1.0, scale))
 
 
+def _huberised(x, f, free, K, delta):
+    """the robustified objective of g2o's RobustKernelHuber (rho(s) = s for s <= delta^2, 2 sqrt(s) delta - delta^2 beyond, s = |r_e|^2 of
+    the 2-D edge error) written as a plain least-squares problem: every edge's residual pair is scaled by sqrt(rho(s) / s)"""
+    r = _reproj_residuals(x, f, free, K).reshape(-1, 2)
+    s2 = np.maximum(np.sum(r * r, axis=1), 1e-300)
+    rho = np.where(s2 <= delta * delta, s2, 2.0 * np.sqrt(s2) * delta - delta * delta)
+    return (r * np.sqrt(rho / s2)[:, None]).ravel()
+
+
+@pytest.mark.parametrize("lo,hi,step,same_basin", [(10.0, 15.0, 16, True), (25.0, 40.0, 8, False)])
+def test_witness_g2o_huber_kernel_optimum(oracle, lo, hi, step, same_basin):
+    """the same problem with outliers (every step-th observation moved by lo..hi px) and the reference's kernel width sqrt(5.991)
+    (BA.cpp:450-452).  g2o robustifies by re-weighting (rho' on the information matrix), whose fixed points are the stationary points
+    of sum_e rho(|r_e|^2); scipy minimises that sum directly.  Moderate outliers: both end in the same minimum.  Gross outliers make
+    the problem multi-modal, so there the check is that the oracle's end point is a minimum scipy cannot improve."""
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=11)
+    clean = f["obs"].copy()
+    rng = np.random.default_rng(4)
+    obs = clean.copy()
+    bad = np.arange(0, len(obs), step)
+    obs[bad] += rng.uniform(lo, hi, (len(bad), 2)) * rng.choice([-1.0, 1.0], (len(bad), 2))
+    f = dict(f, obs=obs)
+    K = len(f["poses"])
+    free = np.nonzero(f["fixed"] == 0)[0]
+    delta = float(np.sqrt(5.991))
+    po, pt, st = oracle.g2o_lm(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"], huber_delta=delta, max_iterations=300)
+    xo = np.concatenate([po[free].ravel(), pt.ravel()])
+    # the oracle's chi2 IS the robustified sum, evaluated here from the textbook kernel
+    assert abs(float(np.sum(_huberised(xo, f, free, K, delta) ** 2)) - st["chi2_final"]) <= 1e-9 * st["chi2_final"]
+    kw = dict(method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, max_nfev=600)
+    again = optimize.least_squares(_huberised, xo, args=(f, free, K, delta), **kw)
+    assert float(np.sum(again.fun ** 2)) >= st["chi2_final"] * (1 - 1e-9)          # nothing to gain from the oracle's end point
+    if same_basin:
+        x0 = np.concatenate([f["poses"][free].ravel(), f["points"].ravel()])
+        sol = optimize.least_squares(_huberised, x0, args=(f, free, K, delta), **kw)
+        assert abs(st["chi2_final"] - float(np.sum(sol.fun ** 2))) <= 1e-8 * st["chi2_final"]
+    # robust: the outliers enter linearly, so the optimum's cost is a fraction of their squared size, and the inliers stay at noise level
+    assert st["chi2_final"] < 0.35 * float(np.sum((obs[bad] - clean[bad]) ** 2))
+    r = _reproj_residuals(xo, f, free, K).reshape(-1, 2)
+    inl = np.ones(len(obs), bool); inl[bad] = False
+    assert np.sqrt(np.mean(np.sum(r[inl] ** 2, axis=1))) < 4.0
+
+
 def _ceres_residuals(x, c, free, K):
     """CeresReprojectionError (Ceres/CeresReprojectionError.h:33-69): pose = [t; angle-axis], residual = u_n - p / p_z"""
     poses = c["poses"].copy()
