@@ -272,6 +272,37 @@ def test_witness_ceres_solve_reaches_the_least_squares_optimum(oracle):
     assert np.allclose(ps[:, :3], scale * po[:, :3], atol=2e-5 * max(1.0, scale)) and np.allclose(pts_s, scale * pt, atol=2e-4 * max(1.0, scale))
 
 
+def test_witness_ceres_huber_loss_optimum(oracle):
+    """ceres::HuberLoss(a) + Corrector as OptimizeCurrent uses them (BA.cpp:136-140, a = 0.1 on the normalised plane): rho(s) = s for
+    s <= a^2, 2 a sqrt(s) - a^2 beyond, cost 1/2 sum rho.  The oracle's trust-region restatement (Corrector and all) against scipy
+    minimising the same sum written as a plain least-squares problem, from the same start."""
+    f = fixtures.ba_fixture_test_local_ba(noise=True, seed=13)
+    c = fixtures.ba_to_ceres(f)
+    rng = np.random.default_rng(8)
+    obs = c["obs_n"].copy()
+    bad = np.arange(3, len(obs), 16)
+    obs[bad] += rng.uniform(0.02, 0.03, (len(bad), 2)) * rng.choice([-1.0, 1.0], (len(bad), 2))     # 10-15 px at f = 500
+    c = dict(c, obs_n=obs)
+    K = len(c["poses"])
+    free = np.nonzero(c["fixed"] == 0)[0]
+    a = 0.005                                                            # ~2.5 px: the outliers are far in the linear part
+    hub = np.full(len(obs), a)
+
+    def robust(x):
+        r = _ceres_residuals(x, c, free, K).reshape(-1, 2)
+        s2 = np.maximum(np.sum(r * r, axis=1), 1e-300)
+        rho = np.where(s2 <= a * a, s2, 2.0 * a * np.sqrt(s2) - a * a)
+        return (r * np.sqrt(rho / s2)[:, None]).ravel()
+    x0 = np.concatenate([c["poses"][free].ravel(), c["points"].ravel()])
+    sol = optimize.least_squares(robust, x0, method="trf", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=800)
+    opt = oracle.ceres_options(max_num_iterations=300, function_tolerance=1e-15, parameter_tolerance=1e-15, gradient_tolerance=1e-18)
+    po, pt, sm = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], edge_huber=hub, options=opt)
+    xo = np.concatenate([po[free].ravel(), pt.ravel()])
+    cost_at_oracle = 0.5 * float(np.sum(robust(xo) ** 2))
+    assert abs(cost_at_oracle - sm["final_cost"]) <= 1e-9 * sm["final_cost"]               # the reported cost is 1/2 sum rho of the textbook kernel
+    assert abs(sm["final_cost"] - 0.5 * float(np.sum(sol.fun ** 2))) <= 1e-6 * sm["final_cost"]
+
+
 def test_witness_two_view_ba_lm_vs_dogleg_optimum(oracle):
     """ba::TwoViewBACeres asks ceres for the DOGLEG trust-region strategy (BA.cpp:58-62); the restated solver (and the GPU path behind
     it) has Levenberg-Marquardt only.  Both are descent methods on the same cost: what LM returns must be a minimum that a
