@@ -16,7 +16,7 @@ They pin the restatements against a mistake of transcription; they cannot prove 
 import numpy as np
 import pytest
 import fixtures
-from scipy import ndimage, optimize
+from scipy import linalg, ndimage, optimize
 from ygz_slam_amd import synth
 
 
@@ -333,3 +333,51 @@ def test_witness_two_view_ba_lm_vs_dogleg_optimum(oracle):
         sol0 = optimize.least_squares(_ceres_residuals, x0, args=(c, free, 2), method="dogbox", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=2000)
     assert sm["final_cost"] <= sm["initial_cost"] * 1e-3 and sm["final_cost"] <= 0.5 * float(np.sum(sol0.fun ** 2)) * 1.001 + 1e-9
     assert inl.sum() >= 14
+
+
+# ---------------------------------------------------------------------------------------- Sophus SE3 (pinned, cross-checked) / Eigen LDLT
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def test_witness_se3_exp_log_against_the_matrix_exponential(oracle):
+    """Sophus::SE3::exp / log (thirdparty/Sophus/sophus/se3.cpp, tangent [upsilon; omega]) against scipy.linalg.expm / logm of the 4x4
+    twist matrix: the group element is the matrix exponential whatever closed form a library uses.  Small, generic and near-pi angles."""
+    rng = np.random.default_rng(12)
+    for scale in (1e-9, 1e-3, 0.3, 1.5, 3.1):
+        for _ in range(6):
+            om = rng.normal(size=3); om *= scale / np.linalg.norm(om)
+            ups = rng.normal(size=3)
+            xi = np.zeros((4, 4))
+            xi[:3, :3] = [[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]]
+            xi[:3, 3] = ups
+            M = linalg.expm(xi)
+            T = oracle.se3_exp(np.concatenate([ups, om]))
+            assert np.allclose(_quat_to_R(T[:4]), M[:3, :3], atol=1e-12) and np.allclose(T[4:], M[:3, 3], atol=1e-12)
+            back = oracle.se3_log(T)
+            assert np.allclose(back, np.concatenate([ups, om]), atol=1e-9 * max(1.0, 1.0 / (np.pi - min(scale, 3.1) + 1e-3)))
+            # composition and inverse are the matrix product and inverse
+            T2 = oracle.se3_exp(rng.normal(size=6) * 0.4)
+            M2 = np.eye(4); M2[:3, :3] = _quat_to_R(T2[:4]); M2[:3, 3] = T2[4:]
+            P = oracle.se3_mul(T, T2)
+            assert np.allclose(_quat_to_R(P[:4]), (M @ M2)[:3, :3], atol=1e-12) and np.allclose(P[4:], (M @ M2)[:3, 3], atol=1e-12)
+            Ti = oracle.se3_inv(T)
+            assert np.allclose(_quat_to_R(Ti[:4]), M[:3, :3].T, atol=1e-12) and np.allclose(Ti[4:], -M[:3, :3].T @ M[:3, 3], atol=1e-11)
+
+
+def test_witness_ldlt6_against_numpy(oracle):
+    """Eigen's ldlt().solve on the 6x6 normal equations of the Gauss-Newton drivers [frozen spec] against numpy.linalg.solve on
+    symmetric positive definite systems of graded conditioning"""
+    rng = np.random.default_rng(13)
+    for cond in (1e1, 1e4, 1e8):
+        for _ in range(5):
+            Q, _r = np.linalg.qr(rng.normal(size=(6, 6)))
+            H = Q @ np.diag(np.geomspace(1.0, cond, 6)) @ Q.T
+            H = 0.5 * (H + H.T)
+            b = rng.normal(size=6)
+            ok, x = oracle.ldlt6_solve(H, b)
+            want = np.linalg.solve(H, b)
+            assert ok and np.allclose(x, want, rtol=1e-9 * cond ** 0.5, atol=1e-12 * np.abs(want).max() * cond ** 0.5)
