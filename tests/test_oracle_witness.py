@@ -381,3 +381,80 @@ def test_witness_ldlt6_against_numpy(oracle):
             ok, x = oracle.ldlt6_solve(H, b)
             want = np.linalg.solve(H, b)
             assert ok and np.allclose(x, want, rtol=1e-9 * cond ** 0.5, atol=1e-12 * np.abs(want).max() * cond ** 0.5)
+
+
+# ---------------------------------------------------------------------------------------- IC_Angle / rotated BRIEF from their definitions
+def _orb_pattern():
+    import os, re
+    txt = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ygz_orb_pattern.h")).read()
+    body = txt[txt.index("#define YGZ_ORB_PATTERN_VALUES"):]
+    vals = [int(v) for v in re.findall(r"-?\d+", body.split("#endif")[0].replace("YGZ_ORB_PATTERN_VALUES", ""))]
+    return np.array(vals[:1024], np.int64).reshape(512, 2)              # 512 sample points, two per bit
+
+
+def test_witness_ic_angle_and_rotated_brief(oracle):
+    """FeatureDetector::IC_Angle / ComputeOrbDescriptor (FeatureDetector.cpp:509-566) re-derived with numpy on the keypoints the oracle
+    extracts from a synthetic frame: the intensity-centroid moments over the circular patch of radius 15 give the angle (atan2, within
+    fastAtan2's 0.3 degrees); with that angle every descriptor bit is the comparison of two pattern points rotated in float and rounded
+    half to even.  Keypoints of all three levels whose patch lies inside the level image."""
+    seq = synth.Sequence(1, 640, 480, seed=21, step=0.1)
+    gray = oracle.bgr2gray(seq.frame(0))
+    lv = oracle.pyramid(gray, 3)
+    kp = oracle.detect(lv, oracle.default_params(640, 480, 3))
+    pat = _orb_pattern()
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    checked = 0
+    for i in range(0, len(kp), 3):
+        L = int(kp["level"][i])
+        img = lv[L].astype(np.int64)
+        h, w = img.shape
+        cx, cy = int(np.rint(kp["px"][i] / (1 << L))), int(np.rint(kp["py"][i] / (1 << L)))
+        if cx < 20 or cy < 20 or cx >= w - 20 or cy >= h - 20:
+            continue
+        m10 = sum(u * img[cy, cx + u] for u in range(-15, 16))
+        m01 = 0
+        for v in range(1, 16):
+            d = umax[v]
+            for u in range(-d, d + 1):
+                plus, minus = img[cy + v, cx + u], img[cy - v, cx + u]
+                m01 += v * (plus - minus); m10 += u * (plus + minus)
+        want_deg = np.degrees(np.arctan2(float(m01), float(m10))) % 360.0
+        got_deg = float(kp["angle"][i])
+        assert abs((got_deg - want_deg + 180.0) % 360.0 - 180.0) < 0.3
+        ang = np.float32(got_deg) * np.float32(np.pi / 180.0)
+        a, b = np.float32(np.cos(np.float64(ang))), np.float32(np.sin(np.float64(ang)))
+        px, py = pat[:, 0].astype(np.float32), pat[:, 1].astype(np.float32)
+        yy = np.rint(px * b + py * a).astype(np.int64); xx = np.rint(px * a - py * b).astype(np.int64)
+        vals = img[cy + yy, cx + xx]
+        bits = (vals[0::2] < vals[1::2]).astype(np.uint8)               # bit k of the descriptor: point 2k against point 2k + 1
+        desc = np.packbits(bits.reshape(32, 8)[:, ::-1], axis=1).ravel()  # byte i = bits 8i .. 8i+7, bit j at position j
+        assert np.array_equal(desc, kp["desc"][i]), i
+        checked += 1
+    assert checked > 150
+
+
+def test_witness_shi_tomasi_is_the_smaller_eigenvalue(oracle):
+    """FeatureDetector::ShiTomasiScore (FeatureDetector.cpp:467-507): central differences over the 8 x 8 box [u-4, u+4) x [v-4, v+4),
+    structure tensor / (2 * 64), smaller eigenvalue -- against numpy.linalg.eigvalsh of the same tensor, on random and on structured
+    images; 0 when the box touches the border"""
+    rng = np.random.default_rng(17)
+    for kind in range(3):
+        if kind == 0:
+            img = rng.integers(0, 256, (60, 80), dtype=np.uint8)
+        elif kind == 1:
+            img = np.kron(rng.integers(0, 256, (6, 8)), np.ones((10, 10))).astype(np.uint8)
+        else:
+            yy, xx = np.mgrid[0:60, 0:80]
+            img = np.clip(128 + 100 * np.sin(xx / 3.0), 0, 255).astype(np.uint8)          # an edge pattern: the smaller eigenvalue is ~0
+        I = img.astype(np.float64)
+        for _ in range(60):
+            u, v = int(rng.integers(0, 80)), int(rng.integers(0, 60))
+            got = oracle.shi_tomasi(img, u, v)
+            if u - 4 < 1 or u + 4 >= 80 - 1 or v - 4 < 1 or v + 4 >= 60 - 1:
+                assert got == 0.0
+                continue
+            ys, xs = np.mgrid[v - 4:v + 4, u - 4:u + 4]
+            dx = I[ys, xs + 1] - I[ys, xs - 1]; dy = I[ys + 1, xs] - I[ys - 1, xs]
+            T = np.array([[np.sum(dx * dx), np.sum(dx * dy)], [np.sum(dx * dy), np.sum(dy * dy)]]) / 128.0
+            want = float(np.linalg.eigvalsh(T)[0])
+            assert abs(got - want) <= 2e-5 * max(1.0, abs(T).max())
