@@ -458,3 +458,45 @@ def test_witness_shi_tomasi_is_the_smaller_eigenvalue(oracle):
             T = np.array([[np.sum(dx * dx), np.sum(dx * dy)], [np.sum(dx * dy), np.sum(dy * dy)]]) / 128.0
             want = float(np.linalg.eigvalsh(T)[0])
             assert abs(got - want) <= 2e-5 * max(1.0, abs(T).max())
+
+
+def test_witness_depth_from_triangulation_is_the_least_squares_ray_intersection(oracle):
+    """cvutils::DepthFromTriangulation (CVUtils.h:18-38): the depths along the two rays that bring them closest, i.e. the least-squares
+    solution of [R f_ref, -f_cur] d = -t.  Checked against numpy.linalg.lstsq and against the known depths of exact correspondences."""
+    rng = np.random.default_rng(19)
+    for _ in range(40):
+        T = oracle.se3_exp(np.concatenate([rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.2]))     # T_search_ref
+        R, t = _quat_to_R(T[:4]), T[4:]
+        p_ref = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(2, 6)])
+        p_cur = R @ p_ref + t
+        if p_cur[2] < 0.5:
+            continue
+        f_ref, f_cur = p_ref / p_ref[2], p_cur / p_cur[2]                        # unit-plane rays as the callers build them
+        d1, d2, ok = oracle.depth_from_triangulation(T, f_ref, f_cur)
+        A = np.stack([R @ f_ref, -f_cur], axis=1)
+        if np.linalg.det(A.T @ A) < 1e-5:
+            assert not ok[0]
+            continue
+        sol = np.linalg.lstsq(A, -t, rcond=None)[0]
+        assert ok[0] and abs(d1[0] - abs(sol[0])) < 1e-9 * max(1, abs(sol[0])) and abs(d2[0] - abs(sol[1])) < 1e-9 * max(1, abs(sol[1]))
+        assert abs(d1[0] - p_ref[2]) < 1e-8 and abs(d2[0] - p_cur[2]) < 1e-8      # exact rays intersect at the point
+    # parallel rays: the normal matrix is singular -> rejected
+    T0 = oracle.se3_exp(np.array([0.1, 0, 0, 0, 0, 0.0]))
+    _, _, ok = oracle.depth_from_triangulation(T0, np.array([0, 0, 1.0]), np.array([0, 0, 1.0]))
+    assert not ok[0]
+
+
+def test_witness_sparse_image_alignment_recovers_the_rendered_motion(oracle):
+    """SparseImgAlign (SparseImageAlign.cpp:21-238) on two rendered frames of a textured scene with known depth: started from the
+    identity it has to find the relative pose the renderer used (this is what the method is for; the GPU tests compare trajectories of
+    the Gauss-Newton loop, this one the answer)."""
+    seq = synth.Sequence(2, 640, 480, seed=31, step=0.15)
+    lv = [oracle.pyramid(oracle.bgr2gray(seq.frame(i)), 3) for i in range(2)]
+    kp = oracle.detect(lv[0], oracle.default_params(640, 480, 3))
+    px = np.stack([kp["px"], kp["py"]], axis=1).astype(np.float64)
+    dep = seq.depth(0)[px[:, 1].astype(int), px[:, 0].astype(int)].astype(np.float64)
+    I7 = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    n_meas, T, st = oracle.sparse_align(lv[0], I7, lv[1], I7, px, dep, (dep > 0).astype(np.uint8))
+    gt = oracle.se3_mul(seq.poses[1], oracle.se3_inv(seq.poses[0]))
+    assert n_meas > 300                                                   # run() returns n_meas_ / patch_area_: features that contributed
+    assert np.abs(T[:4] - gt[:4]).max() < 2e-3 and np.abs(T[4:] - gt[4:]).max() < 1e-2
