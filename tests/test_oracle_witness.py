@@ -10,6 +10,12 @@ with oracle/*.c -- and derives the expected value from the textbook definition o
   cv::BFMatcher(crossCheck)    OpenCV 3.1 batchDistance semantics
   cv::calcOpticalFlowPyrLK     known answer: a pure translation of a smooth image is recovered
   g2o LM / ceres trust region  the optimum they converge to is the least-squares optimum: scipy.optimize.least_squares
+  g2o Huber / ceres HuberLoss  scipy minimising sum rho(|r|^2) of the textbook kernel directly
+  Eigen ldlt().solve (6x6)     numpy.linalg.solve
+
+and, for rows restated from code that is in the reference tree (pinned), re-derivations from the definitions: Sophus SE3 against
+scipy.linalg.expm, IC_Angle / rotated BRIEF / ShiTomasiScore with numpy, DepthFromTriangulation against numpy.linalg.lstsq,
+SparseImgAlign recovering a rendered motion.
 
 They pin the restatements against a mistake of transcription; they cannot prove bit-equality with the binaries of the libraries
 (those are not in the image), which is why DESIGN.md keeps the words "parity unpinned" for these rows."""
