@@ -506,3 +506,29 @@ def test_witness_sparse_image_alignment_recovers_the_rendered_motion(oracle):
     gt = oracle.se3_mul(seq.poses[1], oracle.se3_inv(seq.poses[0]))
     assert n_meas > 300                                                   # run() returns n_meas_ / patch_area_: features that contributed
     assert np.abs(T[:4] - gt[:4]).max() < 2e-3 and np.abs(T[4:] - gt[4:]).max() < 1e-2
+
+
+def test_witness_find_direct_projection_lands_on_the_true_projection(oracle):
+    """Matcher::FindDirectProjection (Matcher.cpp:356-466: affine warp of the reference patch, Align2D in the current frame) with the
+    true poses and depths of two rendered frames: started up to 2 px away from the true projection of each feature, the refined pixel
+    has to come back to it."""
+    seq = synth.Sequence(2, 640, 480, seed=33, step=0.2)
+    lv = [oracle.pyramid(oracle.bgr2gray(seq.frame(i)), 3) for i in range(2)]
+    kp = oracle.detect(lv[0], oracle.default_params(640, 480, 3))
+    px = np.stack([kp["px"], kp["py"]], axis=1).astype(np.float64)
+    dep = seq.depth(0)[px[:, 1].astype(int), px[:, 0].astype(int)].astype(np.float64)
+    cam = oracle.camera()
+    fx, fy, cx, cy = float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy)
+    pc0 = np.stack([(px[:, 0] - cx) * dep / fx, (px[:, 1] - cy) * dep / fy, dep], axis=1)
+    T10 = oracle.se3_mul(seq.poses[1], oracle.se3_inv(seq.poses[0]))
+    pc1 = pc0 @ _quat_to_R(T10[:4]).T + T10[4:]
+    true_px = np.stack([fx * pc1[:, 0] / pc1[:, 2] + cx, fy * pc1[:, 1] / pc1[:, 2] + cy], axis=1)
+    sel = np.nonzero((dep > 0) & (true_px[:, 0] > 30) & (true_px[:, 0] < 610) & (true_px[:, 1] > 30) & (true_px[:, 1] < 450))[0][:400]
+    rng = np.random.default_rng(2)
+    start = true_px[sel] + rng.uniform(-2, 2, (len(sel), 2))
+    ok, out, lvl = oracle.find_direct_projection_n(lv[0], seq.poses[0], lv[1], seq.poses[1], px[sel], dep[sel], kp["level"][sel], start)
+    ok = ok.astype(bool)
+    assert ok.mean() > 0.8
+    err = np.linalg.norm(out[ok] - true_px[sel][ok], axis=1)
+    assert np.median(err) < 0.25 and np.percentile(err, 90) < 1.0
+    assert np.median(err) < 0.3 * np.median(np.linalg.norm(start[ok] - true_px[sel][ok], axis=1))     # a real refinement of the start
