@@ -57,3 +57,16 @@ def test_product_package_does_not_touch_the_oracle():
         for f in fs:
             txt = open(os.path.join(dp, f), errors="ignore").read()
             assert "ygz_oracle" not in txt, f
+
+
+def test_header_is_plain_c_and_matches_the_loader():
+    """include/ygz_hip.h is the boundary a cgo / JNI / ctypes binding reads: it has to compile as C99 without any C++ or HIP header,
+    and every function it declares has to be in the loader's symbol list (and the other way round)."""
+    import re
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "ygz_hip.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    declared = set(re.findall(r"\b(ygz_hip_[a-z0-9_]+)\s*\(", open(hdr).read()))
+    from ygz_slam_amd import _lib
+    assert declared == set(_lib.ABI_SYMBOLS), (sorted(declared - set(_lib.ABI_SYMBOLS)), sorted(set(_lib.ABI_SYMBOLS) - declared))
