@@ -541,8 +541,10 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     const char *env_t = getenv("YGZ_SA_THREADS");
     const int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
     // per-iteration scratch of the first lcap features in LDS: 4 x 16 (r2) + 16 (fmap) + 8 (pmap) + 4 (pre) bytes each + chunk totals
-    static const int lcap_env = [] { const char *e = getenv("YGZ_SA_LDS"); return e ? atoi(e) : 1024; }();
-    A.lcap = ((lcap_env < ctx->cells ? lcap_env : ctx->cells) + 63) / 64 * 64;
+    // (a 512-lane problem owns its CU -- nothing else fits beside 512 x 256 registers -- so it may take nearly all of the LDS)
+    static const int lcap_env = [] { const char *e = getenv("YGZ_SA_LDS"); return e ? atoi(e) : -1; }();
+    const int lcap_want = lcap_env >= 0 ? lcap_env : (threads == 512 ? 1600 : 1024);
+    A.lcap = ((lcap_want < ctx->cells ? lcap_want : ctx->cells) + 63) / 64 * 64;
     if (A.lcap < 0) A.lcap = 0;
     const size_t dyn = (size_t)A.lcap * 92 + (size_t)(A.lcap / 64 + 1) * 4 + 16;
     static bool attr_set = false;
