@@ -257,6 +257,18 @@ int  ygz_hip_get_keypoints_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, 
 /* Feature::_depth / _mappoint != nullptr of n slots: depth [n_slots][cells], has_mappoint [n_slots][cells] */
 int  ygz_hip_set_keypoint_depths_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const double *depth, const uint8_t *has_mappoint,
                                        int wait);
+/* n_kp of n consecutive slots (what Frame::_features.size() would be), e.g. beside ygz_hip_track_get_summary */
+int  ygz_hip_get_keypoint_counts(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int32_t *count, int wait);
+/* RGB-D style input: a depth image per slot, dw x dh samples covering the level-0 frame (dw <= width, dh <= height; kind 0: float32
+ * metres, kind 1: uint16 with depth = value * scale, TUM RGB-D: 1 / 5000, kind 2: float64 metres); depth [n_slots][dh][dw].  ygz_hip_keypoint_depths_from_image
+ * then sets Feature::_depth of every keypoint of the slots to the sample at ((int)x * dw / width, (int)y * dh / height) and
+ * _mappoint != nullptr to depth > 0, on the device -- what ygz_hip_set_keypoint_depths[_batch] do from host arrays.  (In the reference
+ * a feature's depth is the z of its map point, src/Module/LocalMapping.cpp:100-111; the offline run's depth image stands in for the map.) */
+int  ygz_hip_upload_depth_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const void *depth, int dw, int dh, int kind, double scale,
+                                int wait);
+int  ygz_hip_keypoint_depths_from_image(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
+/* Feature::_depth / _mappoint != nullptr of the keypoints of a slot as they stand on the device (either output may be NULL) */
+int  ygz_hip_get_keypoint_depths(ygz_hip_ctx *ctx, int slot, double *depth, uint8_t *has_mappoint, int capacity, int *n);
 /* per pair of the resident pair table 32 doubles, reduced on the device: [0..6] pose after sparse alignment, [7] its n_meas / 16,
  * [8..13] pose after pose-only BA [t; log so3], [14] inliers, [15] rounds, [16] cross-checked matches, [17] good matches (M3),
  * [18] min_dis, [19] KLT tracks with status 1, [20] direct-projection successes, [21] reference features, [22] query keypoints, [23] 0,
@@ -327,6 +339,47 @@ int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *pos
 int  ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, int max_iterations,
                                   ygz_ba_stats *stats);
 int  ygz_hip_ba_get_state(ygz_hip_ctx *ctx, int window, double *poses, double *points);
+/* statistics of the last ygz_hip_ba_optimize_resident run on each window of the range (it may have been asynchronous) and the graph
+ * sizes dims [n][4] = poses, points, edges, free poses; either output may be NULL.  YGZ_E_HIP: a team of workgroups timed out at a
+ * barrier (its members were not resident together); YGZ_E_STATE: no resident run yet.  Synchronises. */
+int  ygz_hip_ba_get_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, ygz_ba_stats *stats, int32_t *dims);
+
+/* ---- the keyframe side of a batched run kept in HBM: what LocalMapping::LocalBA gathers on the host before ba::LocalBAG2O
+ *      (src/Module/LocalMapping.cpp:149-208: the window's keyframes, their map points and observations; src/Algorithm/BA.cpp:397-470:
+ *      vertices and edges) is assembled on the device from a store of keyframe rows, so a BA round moves no keypoint table and no graph
+ *      across PCIe.  Contexts of one device share the store: tracking contexts copy their keyframes into it device to device. ---- */
+/* order everything enqueued on `waiter` from now on behind everything enqueued on `signaler` so far (same device; no host wait) */
+int  ygz_hip_stream_wait(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler);
+/* bytes of one keyframe row for this context's grid: pixels f64 [cells][2] | depth f64 [cells] | level i32 [cells] | descriptors
+ * [cells][32] | count i32, each part 64-byte aligned.  Rows are fixed-size so that the rows of other ranks arrive by ONE all-gather
+ * on the store's memory. */
+size_t ygz_hip_kf_row_bytes(const ygz_hip_ctx *ctx);
+/* a store of n_keyframes rows (+ max_windows rows of work space behind them), the relative pose T_rel of n_frames frames (pose of
+ * frame f in the frame of f - 1; (qx,qy,qz,qw,tx,ty,tz)).  rows_mem: device memory of the caller (>= (n_keyframes + max_windows) *
+ * row bytes, e.g. a tensor its collectives can address) or NULL to let the library allocate. */
+int  ygz_hip_kf_store_create(ygz_hip_ctx *ctx, int n_keyframes, int n_frames, int max_windows, void *rows_mem, size_t rows_mem_bytes);
+int  ygz_hip_kf_store_info(ygz_hip_ctx *ctx, void **rows, size_t *row_bytes, void **trel, int *n_keyframes, int *n_frames);
+/* row kf_index[i] <- the keypoints (Feature::_pixel, _level, _desc, _depth) of slot src_slot[i] of `src`; enqueued on src's stream */
+int  ygz_hip_kf_store_put(ygz_hip_ctx *store, ygz_hip_ctx *src, int n, const int32_t *src_slot, const int32_t *kf_index);
+/* T_rel[first_frame + i] <- the pose ygz_hip_track_pose_only left for pair first_pair + i of `src` (on src's stream); the host form
+ * for frames tracked elsewhere (asynchronous on the store's stream) */
+int  ygz_hip_kf_store_put_trel(ygz_hip_ctx *store, ygz_hip_ctx *src, int first_pair, int n_pairs, int first_frame);
+int  ygz_hip_kf_store_set_trel(ygz_hip_ctx *ctx, int first_frame, int n, const double *T_rel);
+/* call after a collective wrote rows into the store's memory (re-reads the rows' counts) */
+int  ygz_hip_kf_store_refresh(ygz_hip_ctx *ctx);
+/* BA windows whose graph the device builds: capacity K keyframes (pose 0 constant, BA.cpp:404) x max_points map points */
+int  ygz_hip_ba_reserve_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, int K, int max_points, double huber_delta);
+/* window i = the n_kfs[i] keyframes in store rows kf_index[i][0..K) = frames kf_frame[i][.] of the sequence (ascending; entry 0 is the
+ * anchor).  Map points: the anchor's features with depth (first max_points in keypoint order), Pixel2Camera in the anchor's camera
+ * (Camera.h:56-62); observations: the anchor's pixel plus the good cross-checked Hamming matches of the anchor's descriptors in the
+ * other keyframes (test/test_orb_match.cpp:86-104); points seen by fewer than two keyframes are dropped; vertex j = log of
+ * T_rel(kf_frame[j]) * ... * T_rel(anchor + 1) as [omega; upsilon] (G2oTypes.h:88), the anchor at the identity.  Asynchronous;
+ * ygz_hip_ba_optimize_resident / ygz_hip_ba_linearize_resident run on the result, ygz_hip_ba_get_stats returns the sizes. */
+int  ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, const int32_t *kf_index, const int32_t *kf_frame,
+                              const int32_t *n_kfs);
+/* one row per window: [poses 6 K | points 3 max_points | K, P, E, iterations, lm_trials, chi2_initial, chi2_final, lambda_final], unused
+ * entries 0, rows row_doubles apart; dst in device memory (dst_on_device != 0: e.g. the buffer of the map exchange) or host memory */
+int  ygz_hip_ba_pack_states(ygz_hip_ctx *ctx, int window_begin, int n_windows, double *dst, size_t row_doubles, int dst_on_device, int wait);
 
 
 /* ---- B6/B7: ceres::Solve as the reference configures it (src/Algorithm/BA.cpp:219-226,372-375: default options =

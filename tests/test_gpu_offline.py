@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 from conftest import make_ctx, ROOT
 from ygz_slam_amd import synth, offline
+from ygz_slam_amd import dist as ydist
 
 pytestmark = pytest.mark.gpu
 I7 = np.array([0, 0, 0, 1.0, 0, 0, 0])
@@ -89,15 +90,16 @@ def test_match_sets_equals_the_per_pair_calls(hip_lib, oracle):
     ctx.close()
 
 
-def _oracle_pair(oracle, seq, ref, cur, T_sa=None):
-    """the oracle's composition of one frame pair of the offline run (T_ref = identity)"""
+def _oracle_pair(oracle, seq, ref, cur, T_sa=None, depth_fn=None):
+    """the oracle's composition of one frame pair of the offline run (T_ref = identity); depth_fn(frame, px) = Feature::_depth of
+    the keypoints (default: the sequence's depth map at the pixel, what a full-resolution float64 depth image gives)"""
     w, h = seq.w, seq.h
     lv_r = oracle.pyramid(oracle.bgr2gray(seq.frame(ref)), 3)
     lv_c = oracle.pyramid(oracle.bgr2gray(seq.frame(cur)), 3)
     prm = oracle.default_params(w, h, 3)
     kr, kc = oracle.detect(lv_r, prm), oracle.detect(lv_c, prm)
     px = np.stack([kr["px"], kr["py"]], axis=1).astype(np.float64)
-    dep = seq.depth(ref)[px[:, 1].astype(np.int64), px[:, 0].astype(np.int64)].astype(np.float64)
+    dep = seq.depth(ref)[px[:, 1].astype(np.int64), px[:, 0].astype(np.int64)].astype(np.float64) if depth_fn is None else depth_fn(ref, px)
     out = dict(kr=kr, kc=kc, px=px, depth=dep)
     out["m_idx"], out["m_dist"], _ = oracle.bf_match(kc["desc"], kr["desc"], 1)
     out["m_good"], out["n_good"] = oracle.good_match_filter(out["m_idx"], out["m_dist"])
@@ -157,12 +159,15 @@ def test_track_handover_and_pose_only_vga(hip_lib, oracle):
 
 
 N_SEQ = 16
+# (window_kfs, depth image): windows aligned with the two shards / a window that straddles the shard boundary (its keyframe rows and
+# relative poses cross ranks) with the quarter-resolution uint16 depth image of the bench
+VARIANTS = {"aligned": dict(window_kfs=4, depth_div=1, depth_dtype="float64"), "straddling": dict(window_kfs=3, depth_div=4, depth_dtype="uint16")}
 
 
-def _run_offline(rank, world, port, outdir, chunk):
+def _run_offline(rank, world, port, outdir, chunk, variant="aligned", pipeline_ba=True):
     import sys
     sys.path.insert(0, ROOT)
-    pg = None
+    v = VARIANTS[variant]
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -170,11 +175,11 @@ def _run_offline(rank, world, port, outdir, chunk):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)         # RCCL refuses two ranks on one device; gloo carries the same calls
     seq = synth.Sequence(N_SEQ, 1280, 720, seed=11, step=0.05)
-    vo = offline.OfflineVO(1280, 720, N_SEQ, rank=rank, world=world, device=0, chunk=chunk, kf_stride=2, window_kfs=4,
-                           max_points=2000, keep=True, exchange_on_device=False)
+    vo = offline.OfflineVO(1280, 720, N_SEQ, rank=rank, world=world, device=0, chunk=chunk, kf_stride=2, window_kfs=v["window_kfs"],
+                           max_points=2000, keep=True, exchange_on_device=False, depth_div=v["depth_div"], depth_dtype=np.dtype(v["depth_dtype"]),
+                           pipeline_ba=pipeline_ba)
     res = vo.run(seq.frame, seq.depth)
     vo.close()
-    res.pop("built")
     with open(os.path.join(outdir, "r%d_of_%d.pkl" % (rank, world)), "wb") as f:
         pickle.dump(res, f)
     if world > 1:
@@ -203,25 +208,33 @@ def _same(a, b, path=""):
         assert a == b or (a != a and b != b), path
 
 
-def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path):
+@pytest.mark.parametrize("variant", ["aligned", "straddling"])
+def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path, variant):
     """BASELINE configs[4] at test size: a 16-frame 1280x720 sequence (a) unsharded in one chunk, (b) unsharded in chunks of 5
-    frames (halo between chunks), (c) as 2 shards in 2 processes (gloo, both on this box's GPU): keypoints, matches, tracks,
-    poses, BA windows and the gathered trajectory are IDENTICAL; two pairs are checked against the oracle."""
+    frames (halo between chunks, two lanes, windows built while later chunks run), (c) unsharded with the BA round after the tracking
+    instead of pipelined, (d) as 2 shards in 2 processes (gloo, both on this box's GPU): keypoints, matches, tracks, poses, BA windows
+    and the gathered trajectory are IDENTICAL; two pairs are checked against the oracle."""
     import torch.multiprocessing as mp
     out = str(tmp_path)
-    _run_offline(0, 1, 0, out, N_SEQ)
+    v = VARIANTS[variant]
+    _run_offline(0, 1, 0, out, N_SEQ, variant)
     full = pickle.load(open(os.path.join(out, "r0_of_1.pkl"), "rb"))
-    os.rename(os.path.join(out, "r0_of_1.pkl"), os.path.join(out, "full.pkl"))
-    _run_offline(0, 1, 0, out, 5)
+    _run_offline(0, 1, 0, out, 5, variant)
     chunked = pickle.load(open(os.path.join(out, "r0_of_1.pkl"), "rb"))
     _same(full, chunked)
-    mp.spawn(_run_offline, args=(2, _free_port(), out, N_SEQ), nprocs=2, join=True)
+    _run_offline(0, 1, 0, out, 7, variant, pipeline_ba=False)
+    late = pickle.load(open(os.path.join(out, "r0_of_1.pkl"), "rb"))
+    _same(full, late)
+    mp.spawn(_run_offline, args=(2, _free_port(), out, N_SEQ, variant), nprocs=2, join=True)
     parts = [pickle.load(open(os.path.join(out, "r%d_of_2.pkl" % r), "rb")) for r in range(2)]
     # every rank ends with the same global trajectory, relative poses, windows and keyframe poses as the unsharded run
     owners = [[w.pop("owner") for w in r["windows"]] for r in [full] + parts]
-    assert owners == [[0, 0], [0, 1], [0, 1]]                  # the second window belongs to the rank that owns frame 8
+    if variant == "aligned":
+        assert owners == [[0, 0], [0, 1], [0, 1]]              # the second window belongs to the rank that owns frame 8
+    else:
+        assert owners == [[0, 0, 0], [0, 0, 1], [0, 0, 1]]     # window [6, 8, 10]: anchor on rank 0, the other keyframes on rank 1
     for part in parts:
-        for k in ("T_rel", "trajectory", "windows", "keyframe_pose"):
+        for k in ("T_rel", "trajectory", "windows", "keyframe_pose", "built"):
             _same(full[k], part[k], k)
     merged = {}
     for part in parts:
@@ -230,17 +243,123 @@ def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path):
     assert sorted(parts[0]["records"]) == list(range(8)) and sorted(parts[1]["records"]) == list(range(8, 16))
     _same(full["records"], merged, "records")
     # sanity of the run itself
-    assert len(full["windows"]) == 2
-    for w in full["windows"]:
+    assert len(full["windows"]) == (2 if variant == "aligned" else 3)
+    for wi, w in enumerate(full["windows"]):
         chi0, chi1, its, n_edges = w["stats"]
-        assert n_edges > 1000 and chi1 < chi0 and its >= 1
+        K, P, E = full["built"][wi]
+        assert K == len(w["kfs"]) and E == n_edges and n_edges > 1000 and P > 300 and chi1 < chi0 and its >= 1
     seq = synth.Sequence(N_SEQ, 1280, 720, seed=11, step=0.05)
     gt = np.stack([offline.se3_mul(seq.poses[i], offline.se3_inv(seq.poses[0])) for i in range(N_SEQ)])
     assert np.abs(full["trajectory"] - gt).max() < 2e-2
+    # the refined keyframe poses stay close to the ground truth too (the windows live in their anchor's gauge: composed with the trajectory)
+    for f, T in full["keyframe_pose"].items():
+        assert np.abs(T - gt[f]).max() < 3e-2, f
     # oracle parity on a subset: one pair inside shard 0 and the pair that straddles the shard boundary (cur = 8, ref = 7: the halo)
+    dt = np.dtype(v["depth_dtype"])
+    dfn = lambda f, px: offline.depth_at(offline.depth_image(seq.depth(f), v["depth_div"], dt), px, 1280, 720)
     for cur in (3, 8):
-        o = _oracle_pair(oracle, seq, cur - 1, cur, T_sa=full["records"][cur]["T_sa"])
+        o = _oracle_pair(oracle, seq, cur - 1, cur, T_sa=full["records"][cur]["T_sa"], depth_fn=dfn)
         _check_pair(full["records"][cur], o)
+        assert np.array_equal(full["records"][cur - 1]["kp"]["depth"], o["depth"])
+
+
+def test_device_built_window_equals_host_built(hip_lib, oracle):
+    """ygz_hip_ba_build_windows against the host restatement offline.build_window_host on the keyframes of a tracked sequence: the same
+    map points (bit-equal), vertices (1e-13: the host chains the relative poses through numpy), and -- with the device's state installed
+    in the host-built graph -- bit-identical linearisations (every edge in the same row, the same observation, the same pose)."""
+    n = 10
+    seq = synth.Sequence(n, 640, 480, seed=3, step=0.2)
+    vo = offline.OfflineVO(640, 480, n, chunk=n, kf_stride=2, window_kfs=4, max_points=700, keep=True, pipeline_ba=False)
+    rec = vo.track_shard(seq.frame, seq.depth)
+    assert vo.wins == [[0, 2, 4, 6]] and vo.mine == [0]          # frames 8, 9: a lone keyframe makes no window
+    vo._ba_launch(vo.mine, optimize=False)
+    K, P, E, Kf = (int(x) for x in vo.ba.ba_get_stats(0, 1, want_stats=False)[1][0])
+    kf_tab = {f: rec[f]["kp"] for f in vo.wins[0]}
+    T_rel = np.stack([rec[f].get("T_rel", offline.I7) for f in range(n)])
+    cam = vo.ba.params
+    h = offline.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, vo.ba.match_sets)
+    assert (K, P, E, Kf) == (4, len(h["points"]), len(h["obs"]), 3) and P > 200 and E > 2 * P
+    poses, points = vo.ba.ba_get_state(0, 4, 700)
+    assert np.array_equal(points[:P], h["points"])
+    assert np.allclose(poses[:K], h["poses"], rtol=0, atol=1e-13) and np.all(poses[0] == 0)
+    vo.ba.ba_upload(100, poses[:K], h["fixed"], points[:P], h["edge_pose"], h["edge_point"], h["obs"])
+    vo.ba.ba_linearize_resident(0, 1); vo.ba.ba_linearize_resident(100, 1)
+    a, b = vo.ba.ba_download(0, K, P, E), vo.ba.ba_download(100, K, P, E)
+    for k in ("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2_edge"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["chi2"] == b["chi2"] and a["chi2"] > 0
+    # ... and the resident LM on the two graphs walks the same trials
+    sa = vo.ba.ba_optimize_resident(0, 1, 10)[0]
+    sb = vo.ba.ba_optimize_resident(100, 1, 10)[0]
+    assert (sa.iterations, sa.lm_trials, sa.chi2_initial, sa.chi2_final) == (sb.iterations, sb.lm_trials, sb.chi2_initial, sb.chi2_final)
+    pa, qa = vo.ba.ba_get_state(0, 4, 700); pb, qb = vo.ba.ba_get_state(100, K, P)
+    assert np.array_equal(pa[:K], pb) and np.array_equal(qa[:P], qb) and sa.chi2_final < sa.chi2_initial
+    vo.close()
+
+
+N_LONG = 128
+
+
+def _render_long(i):
+    seq = synth.Sequence(N_LONG, 1280, 720, seed=11, step=0.02)
+    return seq.frame(i), offline.depth_image(seq.depth(i), 4, np.uint16)
+
+
+def _run_long(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ygz_slam_amd import _lib
+    s0, cnt, halo = ydist.shard_frames(N_LONG, rank, world)
+    base = s0 - halo
+    bgr = _lib.PinnedArray((cnt + halo, 720, 1280, 3), np.uint8); dimg = _lib.PinnedArray((cnt + halo, 180, 320), np.uint16)
+    bgr.array[:] = np.load(os.path.join(outdir, "bgr.npy"), mmap_mode="r")[base:base + cnt + halo]
+    dimg.array[:] = np.load(os.path.join(outdir, "depth.npy"), mmap_mode="r")[base:base + cnt + halo]
+    vo = offline.OfflineVO(1280, 720, N_LONG, rank=rank, world=world, device=0, chunk=24, kf_stride=8, window_kfs=6, max_points=2000,
+                           exchange_on_device=False, depth_div=4, depth_dtype=np.uint16)
+    block = lambda frames: (bgr.array[frames[0] - base:frames[-1] + 1 - base], dimg.array[frames[0] - base:frames[-1] + 1 - base])   # page-locked: every copy is asynchronous
+    res = vo.run(None, None, block)
+    vo.close()
+    with open(os.path.join(outdir, "long_r%d_of_%d.pkl" % (rank, world)), "wb") as f:
+        pickle.dump({k: res[k] for k in ("T_rel", "trajectory", "windows", "keyframe_pose", "built")}, f)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_offline_128_frames_720p_two_ranks(hip_lib, tmp_path):
+    """configs[4] at 128 frames of 1280x720, the bench's settings (chunks on two lanes, quarter-resolution uint16 depth, asynchronous
+    block source, windows pipelined behind the tracking): 2 shards on this box's GPU reproduce the unsharded run exactly -- including
+    the window whose keyframes lie on both sides of the shard boundary."""
+    import multiprocessing
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    with multiprocessing.get_context("spawn").Pool(min(16, os.cpu_count() or 1)) as pool:
+        fr = pool.map(_render_long, range(N_LONG), chunksize=4)
+    np.save(os.path.join(out, "bgr.npy"), np.stack([f[0] for f in fr])); np.save(os.path.join(out, "depth.npy"), np.stack([f[1] for f in fr]))
+    del fr
+    _run_long(0, 1, 0, out)
+    full = pickle.load(open(os.path.join(out, "long_r0_of_1.pkl"), "rb"))
+    mp.spawn(_run_long, args=(2, _free_port(), out), nprocs=2, join=True)
+    owners = None
+    for r in range(2):
+        part = pickle.load(open(os.path.join(out, "long_r%d_of_2.pkl" % r), "rb"))
+        owners = [w.pop("owner") for w in part["windows"]]
+        for w in full["windows"]:
+            w.pop("owner", None)
+        _same(full, part, "rank %d" % r)
+    assert owners == [0, 0, 1]                                    # window [48 .. 88] is anchored on rank 0 and ends on rank 1
+    seq = synth.Sequence(N_LONG, 1280, 720, seed=11, step=0.02)
+    gt = np.stack([offline.se3_mul(seq.poses[i], offline.se3_inv(seq.poses[0])) for i in range(N_LONG)])
+    assert np.abs(full["trajectory"] - gt).max() < 2e-2
+    for w in full["windows"]:
+        assert w["stats"][1] < w["stats"][0] and w["stats"][3] > 5000
 
 
 def test_create_map_points_triangulation_loop(hip_lib, oracle):

@@ -98,6 +98,9 @@ ABI_SYMBOLS = [
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
     "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
+    "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_stream_wait",
+    "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
+    "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states",
 ]
 
 SUMMARY_FIELDS = 32
@@ -123,6 +126,7 @@ def load():
                 pass
         _lib = C.CDLL(LIB_PATH)
         _lib.ygz_hip_error_string.restype = C.c_char_p
+        _lib.ygz_hip_kf_row_bytes.restype = C.c_size_t
     return _lib
 
 
@@ -257,6 +261,82 @@ class HipContext:
         assert depth.dtype == np.float64 and has_mp.dtype == np.uint8 and depth.shape[1] == self.cells and has_mp.shape == depth.shape
         self._chk(self.lib.ygz_hip_set_keypoint_depths_batch(self._ctx, slot_begin, len(depth), _p(depth, C.c_double), _p(has_mp, C.c_uint8),
                                                              int(wait)), "set_keypoint_depths_batch")
+
+    def get_keypoint_counts(self, slot_begin, n_slots, out=None, wait=True):
+        out = np.empty(n_slots, np.int32) if out is None else out
+        self._chk(self.lib.ygz_hip_get_keypoint_counts(self._ctx, slot_begin, n_slots, _p(out, C.c_int32), int(wait)), "get_keypoint_counts")
+        return out
+
+    def upload_depth_batch(self, slot_begin, depth, scale=1.0, wait=True):
+        """depth [n, dh, dw]: float32 / float64 metres, or uint16 with depth = value * scale"""
+        assert depth.ndim == 3 and depth.flags["C_CONTIGUOUS"] and depth.dtype in (np.float32, np.uint16, np.float64)
+        kind = {np.dtype(np.float32): 0, np.dtype(np.uint16): 1, np.dtype(np.float64): 2}[depth.dtype]
+        self._chk(self.lib.ygz_hip_upload_depth_batch(self._ctx, slot_begin, len(depth), C.c_void_p(depth.ctypes.data), depth.shape[2], depth.shape[1],
+                                                      kind, C.c_double(scale), int(wait)), "upload_depth_batch")
+
+    def get_keypoint_depths(self, slot):
+        d, m, n = np.empty(self.cells, np.float64), np.empty(self.cells, np.uint8), C.c_int(0)
+        self._chk(self.lib.ygz_hip_get_keypoint_depths(self._ctx, slot, _p(d, C.c_double), _p(m, C.c_uint8), self.cells, C.byref(n)), "get_keypoint_depths")
+        return d[:n.value].copy(), m[:n.value].copy()
+
+    def keypoint_depths_from_image(self, slot_begin, n_slots):
+        self._chk(self.lib.ygz_hip_keypoint_depths_from_image(self._ctx, slot_begin, n_slots), "keypoint_depths_from_image")
+
+    # ---- keyframe store / device-built BA windows (configs[4])
+    def stream_wait(self, signaler):
+        self._chk(self.lib.ygz_hip_stream_wait(self._ctx, signaler._ctx), "stream_wait")
+
+    def kf_row_bytes(self):
+        return int(self.lib.ygz_hip_kf_row_bytes(self._ctx))
+
+    def kf_store_create(self, n_keyframes, n_frames, max_windows, rows_ptr=None, rows_bytes=0):
+        self._chk(self.lib.ygz_hip_kf_store_create(self._ctx, n_keyframes, n_frames, max_windows, C.c_void_p(rows_ptr) if rows_ptr else None,
+                                                   C.c_size_t(rows_bytes)), "kf_store_create")
+
+    def kf_store_info(self):
+        rows, trel, rb, nk, nf = C.c_void_p(0), C.c_void_p(0), C.c_size_t(0), C.c_int(0), C.c_int(0)
+        self._chk(self.lib.ygz_hip_kf_store_info(self._ctx, C.byref(rows), C.byref(rb), C.byref(trel), C.byref(nk), C.byref(nf)), "kf_store_info")
+        return dict(rows=rows.value, row_bytes=rb.value, trel=trel.value, n_keyframes=nk.value, n_frames=nf.value)
+
+    def kf_store_put(self, src, src_slots, kf_index):
+        a = np.ascontiguousarray(src_slots, np.int32); b = np.ascontiguousarray(kf_index, np.int32)
+        assert len(a) == len(b)
+        self._chk(self.lib.ygz_hip_kf_store_put(self._ctx, src._ctx, len(a), _p(a, C.c_int32), _p(b, C.c_int32)), "kf_store_put")
+
+    def kf_store_put_trel(self, src, first_pair, n_pairs, first_frame):
+        self._chk(self.lib.ygz_hip_kf_store_put_trel(self._ctx, src._ctx, first_pair, n_pairs, first_frame), "kf_store_put_trel")
+
+    def kf_store_set_trel(self, first_frame, T_rel):
+        T = np.ascontiguousarray(T_rel, np.float64).reshape(-1, 7)
+        self._chk(self.lib.ygz_hip_kf_store_set_trel(self._ctx, first_frame, len(T), _p(T, C.c_double)), "kf_store_set_trel")
+
+    def kf_store_refresh(self):
+        self._chk(self.lib.ygz_hip_kf_store_refresh(self._ctx), "kf_store_refresh")
+
+    def ba_reserve_windows(self, window_begin, n_windows, K, max_points, huber_delta=5.991):
+        self._chk(self.lib.ygz_hip_ba_reserve_windows(self._ctx, window_begin, n_windows, K, max_points, C.c_double(huber_delta)), "ba_reserve_windows")
+
+    def ba_build_windows(self, window_begin, kf_index, kf_frame, n_kfs):
+        """kf_index / kf_frame [n, K] (entries past n_kfs[i] ignored), n_kfs [n]"""
+        a = np.ascontiguousarray(kf_index, np.int32); b = np.ascontiguousarray(kf_frame, np.int32); c = np.ascontiguousarray(n_kfs, np.int32)
+        assert a.shape == b.shape and a.ndim == 2 and len(c) == len(a)
+        self._chk(self.lib.ygz_hip_ba_build_windows(self._ctx, window_begin, len(a), _p(a, C.c_int32), _p(b, C.c_int32), _p(c, C.c_int32)), "ba_build_windows")
+
+    def ba_pack_states(self, window_begin, n_windows, row_doubles, dst_ptr=None, out=None, wait=True):
+        """state rows into device memory at dst_ptr, or into (and returning) a host array [n_windows, row_doubles]"""
+        if dst_ptr is not None:
+            self._chk(self.lib.ygz_hip_ba_pack_states(self._ctx, window_begin, n_windows, C.c_void_p(dst_ptr), C.c_size_t(row_doubles), 1, int(wait)), "ba_pack_states")
+            return None
+        out = np.empty((n_windows, row_doubles), np.float64) if out is None else out
+        self._chk(self.lib.ygz_hip_ba_pack_states(self._ctx, window_begin, n_windows, C.c_void_p(out.ctypes.data), C.c_size_t(row_doubles), 0, int(wait)), "ba_pack_states")
+        return out
+
+    def ba_get_stats(self, window_begin, n_windows, want_stats=True):
+        """(statistics of the last resident LM run per window, dims [n, 4] = poses, points, edges, free poses)"""
+        st = (BaStats * n_windows)()
+        dims = np.empty((n_windows, 4), np.int32)
+        self._chk(self.lib.ygz_hip_ba_get_stats(self._ctx, window_begin, n_windows, st if want_stats else None, _p(dims, C.c_int32)), "ba_get_stats")
+        return (list(st) if want_stats else None), dims
 
     def track_get_summary(self, out=None, wait=True):
         if out is None:

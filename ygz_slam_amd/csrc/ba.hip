@@ -149,6 +149,7 @@ extern "C" void ygz_hip_ba_free_all(ygz_hip_ctx *ctx)
     for (auto *w : ctx->ba) ba_free(w);
     ctx->ba.clear();
     if (ctx->ba_table) { (void)hipFree(ctx->ba_table); ctx->ba_table = nullptr; }
+    if (ctx->ba_table_host) { delete static_cast<std::vector<BaDev> *>(ctx->ba_table_host); ctx->ba_table_host = nullptr; }
 }
 
 static BaDev ba_dev(const ygz_hip_ctx::BaWindow *w)
@@ -163,33 +164,103 @@ static BaDev ba_dev(const ygz_hip_ctx::BaWindow *w)
     B.Hpp = w->Hpp; B.bp = w->bp; B.chi2 = w->chi2; B.Hll_c = w->Hll_c; B.bl_c = w->bl_c; B.Hpl_c = w->Hpl_c; B.err_c = w->err_c;
     B.chi2e_c = w->chi2e_c; B.part_pose = w->part_pose; B.part_chi = w->part_chi;
     B.poses_w = w->poses; B.points_w = w->points; B.poses_bk = w->poses_bk; B.points_bk = w->points_bk;
-    B.Y_c = w->Y_c; B.Dinv = w->Dinv; B.xl = w->xl; B.sc_p = w->sc_p; B.sc_l = w->sc_l;
+    B.Y_c = w->Y_c; B.Dinv = w->Dinv; B.xl = w->xl; B.sc_p = w->sc_p; B.sc_l = w->sc_l; B.lm_out = w->lm_out;
     return B;
 }
 
-// descriptor table of all windows (changes only at upload time)
+// descriptor table of all windows: an entry changes when its window is uploaded / reserved (host) or rebuilt on the device (the build
+// kernel patches the sizes in place), so only the entries of windows marked dirty are copied
 const BaDev *ygz_ba_table(ygz_hip_ctx *ctx, int *rc)
 {
 #define TAB_CHK_(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->last_hip_error = (int)e_; *rc = YGZ_E_HIP; return nullptr; } } while (0)
     if (ctx->ba_table_dirty) { const int rj = ygz_join(ctx); if (rj != YGZ_OK) { *rc = rj; return nullptr; } }
     if (ctx->ba_table_dirty) {
-        std::vector<BaDev> tab(1024);
-        memset(tab.data(), 0, tab.size() * sizeof(BaDev));
+        if (!ctx->ba_table_host) { auto *v = new std::vector<BaDev>(1024); memset(v->data(), 0, v->size() * sizeof(BaDev)); ctx->ba_table_host = v; }
+        std::vector<BaDev> &tab = *static_cast<std::vector<BaDev> *>(ctx->ba_table_host);
+        if (!ctx->ba_table) {
+            TAB_CHK_(hipMalloc(&ctx->ba_table, 1024 * sizeof(BaDev)));
+            TAB_CHK_(hipMemsetAsync(ctx->ba_table, 0, 1024 * sizeof(BaDev), ctx->stream));
+        }
         ctx->ba_max_K = ctx->ba_max_P = 0;
-        for (size_t i = 0; i < ctx->ba.size() && i < 1024; ++i)
-            if (ctx->ba[i]) {
-                tab[i] = ba_dev(ctx->ba[i]);
-                if (ctx->ba[i]->K > ctx->ba_max_K) ctx->ba_max_K = ctx->ba[i]->K;
-                if (ctx->ba[i]->P > ctx->ba_max_P) ctx->ba_max_P = ctx->ba[i]->P;
-            }
-        if (!ctx->ba_table) TAB_CHK_(hipMalloc(&ctx->ba_table, 1024 * sizeof(BaDev)));
-        TAB_CHK_(hipMemcpyAsync(ctx->ba_table, tab.data(), tab.size() * sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+        for (size_t i = 0; i < ctx->ba.size() && i < 1024; ++i) {
+            auto *w = ctx->ba[i];
+            if (!w) continue;
+            if (w->K > ctx->ba_max_K) ctx->ba_max_K = w->K;
+            if (w->P > ctx->ba_max_P) ctx->ba_max_P = w->P;
+            if (!w->table_dirty) continue;
+            tab[i] = ba_dev(w);
+            TAB_CHK_(hipMemcpyAsync((BaDev *)ctx->ba_table + i, &tab[i], sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+            w->table_dirty = false;
+        }
         TAB_CHK_(hipStreamSynchronize(ctx->stream));
         ctx->ba_table_dirty = false;
     }
 #undef TAB_CHK_
     *rc = YGZ_OK;
     return reinterpret_cast<const BaDev *>(ctx->ba_table);
+}
+
+// one allocation per window: doubles, then int32, then int16, then bytes; R rows, E edges, Q chunks, Kf free poses (each >= 1 here)
+static int ba_carve(ygz_hip_ctx *ctx, ygz_hip_ctx::BaWindow *w, size_t K, size_t P, size_t Rz, size_t Ez, size_t Q, size_t Kfz)
+{
+    const size_t nd = K * 6 + P * 3 + K * BA_POSED                                                  // poses, points, posed
+                    + Rz * 128 + Rz * 64                                                            // obs_c, huber_c
+                    + K * 36 + K * 6 + 1 + Q * 9 * 64 + Q * 3 * 64                                  // Hpp, bp, chi2, Hll_c, bl_c
+                    + Rz * 18 * 64 + Rz * 2 * 64 + Rz * 64                                          // Hpl_c, err_c, chi2e_c
+                    + Q * Kfz * 27 + Q                                                              // partials
+                    + K * 6 + P * 3 + Rz * 18 * 64 + P * 9 + P * 3                                  // LM: backups, Y_c, Dinv, xl
+                    + K * 6 + P * 3                                                                 // trust-region loop: Jacobi scales
+                    + 16;                                                                           // lm_out
+    const size_t ni = Rz * 64 + Q + 1 + Ez + 2 * K + 1;
+    const size_t ns = P * Kfz + 1 + Rz * 64;
+    const size_t bytes = nd * 8 + ni * 4 + ((ns * 2 + 3) & ~(size_t)3) + K + P + Rz * 64 + 64;
+    hipError_t he = hipMalloc(&w->blob, bytes);
+    if (he != hipSuccess) { ctx->last_hip_error = (int)he; return YGZ_E_HIP; }
+    double *d = (double *)w->blob;
+    w->poses = d; d += K * 6; w->points = d; d += P * 3; w->posed = d; d += K * BA_POSED;
+    w->obs_c = d; d += Rz * 128; w->huber_c = d; d += Rz * 64;
+    w->Hpp = d; d += K * 36; w->bp = d; d += K * 6; w->chi2 = d; d += 1;
+    w->Hll_c = d; d += Q * 9 * 64; w->bl_c = d; d += Q * 3 * 64;
+    w->Hpl_c = d; d += Rz * 18 * 64; w->err_c = d; d += Rz * 2 * 64; w->chi2e_c = d; d += Rz * 64;
+    w->part_pose = d; d += Q * Kfz * 27; w->part_chi = d; d += Q;
+    w->poses_bk = d; d += K * 6; w->points_bk = d; d += P * 3; w->Y_c = d; d += Rz * 18 * 64;
+    w->Dinv = d; d += P * 9; w->xl = d; d += P * 3;
+    w->sc_p = d; d += K * 6; w->sc_l = d; d += P * 3;
+    w->lm_out = d; d += 16;
+    int32_t *ii = (int32_t *)d;
+    w->pose_c = ii; ii += Rz * 64; w->slot_off = ii; ii += Q + 1; w->edge_rl = ii; ii += Ez;
+    w->free_idx = ii; ii += K; w->free_pose = ii; ii += K; w->n_behind = ii; ii += 1;
+    w->ppc = (int16_t *)ii; w->dupn = w->ppc + P * Kfz + 1;
+    uint8_t *bb = (uint8_t *)ii + ((ns * 2 + 3) & ~(size_t)3);
+    w->fixed = bb; bb += K; w->point_fixed = bb; bb += P; w->enable_c = bb;
+    YGZ_HIPCHK(ctx, hipMemsetAsync(w->lm_out, 0xFF, 16 * 8, ctx->stream));        // iterations = -1: no resident LM has run
+    return YGZ_OK;
+}
+
+// bytes of the region [Hpp, part_pose) that the kernels never write for constant poses / padding lanes: zeroed at upload / build
+size_t ygz_ba_zero_bytes(const ygz_hip_ctx::BaWindow *w) { return (size_t)((const uint8_t *)w->part_pose - (const uint8_t *)w->Hpp); }
+
+// Capacity window for a graph that ygz_hip_ba_build_windows assembles on the device (window.hip): K poses of which pose 0 is constant,
+// up to P points, every point seen by up to K poses.
+int ygz_ba_reserve_window(ygz_hip_ctx *ctx, int window, int K, int P, double huber)
+{
+    if (window < 0 || window > 1022 || K < 2 || K > 16 || P < 1) return YGZ_E_INVALID;
+    if ((int)ctx->ba.size() <= window) ctx->ba.resize(window + 1, nullptr);
+    if (ctx->ba[window]) {
+        auto *o = ctx->ba[window];
+        if (o->device_built && o->cap_K == K && o->cap_P == P && o->huber == huber) return YGZ_OK;
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ba_free(o); ctx->ba[window] = nullptr;
+    }
+    auto *w = new ygz_hip_ctx::BaWindow();
+    const int Q = (P + 63) / 64, R = Q * K;
+    w->K = K; w->P = P; w->E = P * K; w->formulation = 0; w->Kf = K - 1; w->R = R; w->Q = Q;
+    w->fx = ctx->prm.fx; w->fy = ctx->prm.fy; w->cx = ctx->prm.cx; w->cy = ctx->prm.cy; w->huber = huber;
+    w->device_built = true; w->cap_K = K; w->cap_P = P;
+    const int rc = ba_carve(ctx, w, (size_t)K, (size_t)P, (size_t)R, (size_t)P * K, (size_t)Q, (size_t)(K - 1));
+    if (rc != YGZ_OK) { delete w; return rc; }
+    ctx->ba[window] = w;
+    w->table_dirty = true; ctx->ba_table_dirty = true;
+    return YGZ_OK;
 }
 
 extern "C" {
@@ -248,37 +319,9 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
         }
     }
     w->h_edge_rl = edge_rl;
-    // ---- one blob: doubles, then int32, then int16, then bytes
-    const size_t nd = (size_t)K * 6 + (size_t)P * 3 + (size_t)K * BA_POSED                      // poses, points, posed
-                    + Rz * 128 + Rz * 64                                                          // obs_c, huber_c
-                    + (size_t)K * 36 + (size_t)K * 6 + 1 + (size_t)Q * 9 * 64 + (size_t)Q * 3 * 64  // Hpp, bp, chi2, Hll_c, bl_c
-                    + Rz * 18 * 64 + Rz * 2 * 64 + Rz * 64                                        // Hpl_c, err_c, chi2e_c
-                    + (size_t)Q * Kfz * 27 + (size_t)Q                                            // partials
-                    + (size_t)K * 6 + (size_t)P * 3 + Rz * 18 * 64 + (size_t)P * 9 + (size_t)P * 3   // LM: backups, Y_c, Dinv, xl
-                    + (size_t)K * 6 + (size_t)P * 3;                                               // trust-region loop: Jacobi scales
-    const size_t ni = Rz * 64 + (size_t)Q + 1 + Ez + 2 * (size_t)K + 1;
-    const size_t ns = (size_t)P * Kfz + 1 + Rz * 64;
-    const size_t bytes = nd * 8 + ni * 4 + ((ns * 2 + 3) & ~(size_t)3) + (size_t)K + (size_t)P + Rz * 64 + 64;
-    hipError_t he = hipMalloc(&w->blob, bytes);
-    if (he != hipSuccess) { ctx->last_hip_error = (int)he; delete w; return YGZ_E_HIP; }
-    double *d = (double *)w->blob;
-    w->poses = d; d += (size_t)K * 6; w->points = d; d += (size_t)P * 3; w->posed = d; d += (size_t)K * BA_POSED;
-    w->obs_c = d; d += Rz * 128; w->huber_c = d; d += Rz * 64;
-    w->Hpp = d; d += (size_t)K * 36; w->bp = d; d += (size_t)K * 6; w->chi2 = d; d += 1;
-    w->Hll_c = d; d += (size_t)Q * 9 * 64; w->bl_c = d; d += (size_t)Q * 3 * 64;
-    w->Hpl_c = d; d += Rz * 18 * 64; w->err_c = d; d += Rz * 2 * 64; w->chi2e_c = d; d += Rz * 64;
-    w->part_pose = d; d += (size_t)Q * Kfz * 27; w->part_chi = d; d += (size_t)Q;
-    w->poses_bk = d; d += (size_t)K * 6; w->points_bk = d; d += (size_t)P * 3; w->Y_c = d; d += Rz * 18 * 64;
-    w->Dinv = d; d += (size_t)P * 9; w->xl = d; d += (size_t)P * 3;
-    w->sc_p = d; d += (size_t)K * 6; w->sc_l = d; d += (size_t)P * 3;
-    int32_t *ii = (int32_t *)d;
-    w->pose_c = ii; ii += Rz * 64; w->slot_off = ii; ii += (size_t)Q + 1; w->edge_rl = ii; ii += Ez;
-    w->free_idx = ii; ii += K; w->free_pose = ii; ii += K; w->n_behind = ii; ii += 1;
-    w->ppc = (int16_t *)ii; w->dupn = w->ppc + (size_t)P * Kfz + 1;
-    uint8_t *bb = (uint8_t *)ii + ((ns * 2 + 3) & ~(size_t)3);
-    w->fixed = bb; bb += K; w->point_fixed = bb; bb += P; w->enable_c = bb;
+    { const int rcv = ba_carve(ctx, w, (size_t)K, (size_t)P, Rz, Ez, (size_t)Q, Kfz); if (rcv != YGZ_OK) { delete w; return rcv; } }
     ctx->ba[window] = w;
-    ctx->ba_table_dirty = true;
+    w->table_dirty = true; ctx->ba_table_dirty = true;
     std::vector<uint8_t> fixed(K, 0), pfixed(P, 0);
     if (pb->pose_fixed) memcpy(fixed.data(), pb->pose_fixed, K);
     if (pb->point_fixed) memcpy(pfixed.data(), pb->point_fixed, P);
@@ -291,7 +334,7 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     UP_(w->fixed, fixed.data(), (size_t)K); UP_(w->point_fixed, pfixed.data(), (size_t)P); UP_(w->enable_c, enable_c.data(), Rz * 64);
 #undef UP_
     // blocks of constant poses / padding lanes are never written by the kernels: zero once
-    YGZ_HIPCHK(ctx, hipMemsetAsync(w->Hpp, 0, ((size_t)K * 42 + 1 + (size_t)Q * 12 * 64 + Rz * 21 * 64) * 8, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(w->Hpp, 0, ygz_ba_zero_bytes(w), ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // host vectors go out of scope
     return YGZ_OK;
 }
@@ -345,7 +388,14 @@ int ygz_hip_ba_download(ygz_hip_ctx *ctx, int window, double *Hpp, double *bp, d
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
-    const size_t K = w->K, P = w->P, E = w->E;
+    size_t K = w->K, P = w->P, E = w->E;
+    if (w->device_built) {                                   // the actual sizes live in the device table entry (k_win_edges)
+        int dims[7];
+        if (!ctx->ba_table || w->table_dirty) return YGZ_E_STATE;
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(dims, (const BaDev *)ctx->ba_table + window, sizeof(dims), hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        K = (size_t)dims[0]; P = (size_t)dims[1]; E = (size_t)dims[2];
+    }
 #define DL_(dst, src, n) if ((dst) && (n) > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync((dst), (src), (n) * 8, hipMemcpyDeviceToHost, ctx->stream))
     DL_(Hpp, w->Hpp, K * 36); DL_(bp, w->bp, K * 6); DL_(chi2, w->chi2, (size_t)1);
     // chunked -> ABI order through a staging buffer
@@ -389,6 +439,7 @@ int ygz_hip_ba_set_enable(ygz_hip_ctx *ctx, int window, const uint8_t *edge_enab
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || !edge_enable || window < 0 || window >= (int)ctx->ba.size() || !ctx->ba[window]) return YGZ_E_INVALID;
     auto *w = ctx->ba[window];
+    if (w->device_built) return YGZ_E_STATE;                 // the host does not know where the edges of a device-built graph live
     std::vector<uint8_t> en((size_t)(w->R > 0 ? w->R : 1) * 64, 0);
     for (int e = 0; e < w->E; ++e) en[w->h_edge_rl[e]] = edge_enable[e] ? 1 : 0;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(w->enable_c, en.data(), en.size(), hipMemcpyHostToDevice, ctx->stream));

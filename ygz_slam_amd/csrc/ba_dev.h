@@ -38,8 +38,14 @@ struct ygz_hip_ctx::BaWindow {
     // work space of the resident Levenberg-Marquardt kernel (ba_resident_lm.hip)
     double *poses_bk, *points_bk, *Y_c, *Dinv, *xl;       // Y_c [R][18][64]
     double *sc_p, *sc_l;             // [K][6], [P][3] Jacobi column scales of the resident trust-region loop
+    double *lm_out;                  // [16]: ygz_ba_stats of the last resident LM run on this window (iterations < 0: none, or a team member timed out)
     // host side: where each edge lives (for ygz_hip_ba_set_enable)
     std::vector<int32_t> h_edge_rl;
+    // windows whose graph is built on the device (window.hip): the blob is carved for the capacities below, the kernels read the actual
+    // K / Kf / P / E / R / Q from the DEVICE table entry, which k_win_edges patches; the host fields above keep the capacities
+    bool device_built = false;
+    int cap_K = 0, cap_P = 0;
+    bool table_dirty = true;         // the device table entry must be re-uploaded from the host fields
 };
 #define BA_POSED 32      // doubles per prepared pose: q(4) t(3) R(9) J_l(9)
 
@@ -54,6 +60,7 @@ struct BaDev {
     double *poses_w, *points_w;      // the same state arrays, writable (LM update / restore)
     double *poses_bk, *points_bk, *Y_c, *Dinv, *xl;
     double *sc_p, *sc_l;
+    double *lm_out;
 };
 const BaDev *ygz_ba_table(ygz_hip_ctx *ctx, int *rc);        // device table of all uploaded windows, rebuilt when dirty
 

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             ygz_ba_stats st;
             st.iterations = iterations; st.lm_trials = trials; st.chi2_initial = chi_initial; st.chi2_final = currentChi; st.lambda_final = lambda;
             A.stats[w] = st;
+            *reinterpret_cast<ygz_ba_stats *>(B.lm_out) = st;               // kept with the window (ygz_hip_ba_get_stats)
         }
     }
 #undef LM_PART_RANGE
@@ -566,10 +567,12 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);
     if (!table) return rc;
-    // team size: windows x G <= 64 workgroups (each owns a CU; several launches of this kind may share the GPU), G a power of two
+    // team size: windows x G <= a quarter of the device's CUs (every member spins at the team barriers, so all of them must be
+    // resident together -- also beside the kernels of other streams and of the offline run's tracking lanes), G a power of two
     int G = 1, Kmax = 1;
     static const bool single = [] { const char *e = getenv("YGZ_BA_LM_TEAM"); return e && e[0] == '1' && e[1] == 0; }();   // A/B switch: one workgroup per window
-    if (!single) while (G < LM_V && n_windows * (2 * G) <= 64) G *= 2;
+    const int wg_budget = ctx->n_cu / 4 > 8 ? ctx->n_cu / 4 : 8;
+    if (!single) while (G < LM_V && n_windows * (2 * G) <= wg_budget) G *= 2;
     for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
     size_t stride = 48 + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW
                                            + (size_t)G * Kmax * (6 + 6 + BA_POSED));
@@ -582,16 +585,44 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax;
     YgzAuxScope aux(ctx, 1);
     YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, 48, (size_t)n_windows, ctx->stream));         // barrier counters, abort flags
+    YGZ_HIPCHK(ctx, hipMemsetAsync(d_scr, 0xFF, stats_bytes, ctx->stream));                               // iterations = -1 until a team finishes
+    for (int i = window_begin; i < window_begin + n_windows; ++i)                                         // the same in the windows' own records
+        YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->ba[i]->lm_out, 0xFE, sizeof(ygz_ba_stats), ctx->stream));      // (0xFF = never run, ba_carve)
     YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (stats) {
-        std::vector<unsigned> flags(12 * (size_t)n_windows);
+        // a team whose member never reached a barrier (not co-resident within the spin bound) leaves without writing its record: the
+        // caller gets YGZ_E_HIP whether it asked for statistics here or reads them later with ygz_hip_ba_get_stats
         YGZ_HIPCHK(ctx, hipMemcpyAsync(stats, d_scr, (size_t)n_windows * sizeof(ygz_ba_stats), hipMemcpyDeviceToHost, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpy2DAsync(flags.data(), 48, A.scratch, stride, 48, (size_t)n_windows, hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < n_windows; ++i)
-            if (flags[12 * (size_t)i + 1]) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return YGZ_E_HIP; }   // a member never reached a team barrier
+            if (stats[i].iterations < 0) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return YGZ_E_HIP; }
     }
+    return YGZ_OK;
+}
+
+// statistics of the last ygz_hip_ba_optimize_resident run of every window in the range (which may have been asynchronous), and the
+// actual graph sizes dims [n][4] = K, P, E, free poses (what ygz_hip_ba_build_windows assembled; the uploaded sizes otherwise).
+// YGZ_E_HIP when a window's team timed out at a barrier, YGZ_E_STATE when no resident LM has run on one.  Synchronises.
+int ygz_hip_ba_get_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, ygz_ba_stats *stats, int32_t *dims)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size() || (!stats && !dims)) return YGZ_E_INVALID;
+    for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i]) return YGZ_E_INVALID;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    int rc = YGZ_OK;
+    const BaDev *table = ygz_ba_table(ctx, &rc);
+    if (!table) return rc;
+    std::vector<int32_t> hd(8 * (size_t)n_windows);
+    for (int i = 0; i < n_windows; ++i) {
+        if (stats) YGZ_HIPCHK(ctx, hipMemcpyAsync(stats + i, ctx->ba[window_begin + i]->lm_out, sizeof(ygz_ba_stats), hipMemcpyDeviceToHost, ctx->stream));
+        if (dims) YGZ_HIPCHK(ctx, hipMemcpyAsync(hd.data() + 8 * (size_t)i, table + window_begin + i, 7 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dims) for (int i = 0; i < n_windows; ++i) {
+        dims[4 * i] = hd[8 * (size_t)i]; dims[4 * i + 1] = hd[8 * (size_t)i + 1]; dims[4 * i + 2] = hd[8 * (size_t)i + 2]; dims[4 * i + 3] = hd[8 * (size_t)i + 4];
+    }
+    if (stats) for (int i = 0; i < n_windows; ++i) if (stats[i].iterations < 0) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return stats[i].lm_trials == -1 ? YGZ_E_STATE : YGZ_E_HIP; }
     return YGZ_OK;
 }
 

@@ -49,6 +49,31 @@ __global__ __launch_bounds__(256) void k_track_summary(SumArgs A)
     }
 }
 
+
+// Feature::_depth of the keypoints of a slot sampled from the slot's depth image (the RGB-D style input of the offline run; in the
+// reference the depth of a feature is the z of its map point in the camera frame, Feature.h:30 -- the depth image stands in for the
+// map).  dw x dh samples cover the level-0 frame: pixel (x, y) reads sample ((int)x * dw / w, (int)y * dh / h).  kind 0: float32 metres,
+// kind 1: uint16 with depth = value * scale (TUM RGB-D: scale = 1 / 5000), kind 2: float64 metres.  depth <= 0 or NaN = no map point.
+struct DepthArgs {
+    const void *img; int dw, dh, kind; double scale; int w, h, cells, slot_begin;
+    const int32_t *n_kp; const double *kp_px; double *kp_depth; uint8_t *kp_has_mp;
+};
+__global__ __launch_bounds__(256) void k_kp_depth_from_image(DepthArgs A)
+{
+    const int slot = A.slot_begin + blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n_kp[slot]) return;
+    const size_t o = (size_t)slot * A.cells + i;
+    int ix = (int)(((long long)(int)A.kp_px[2 * o] * A.dw) / A.w), iy = (int)(((long long)(int)A.kp_px[2 * o + 1] * A.dh) / A.h);
+    ix = ix < 0 ? 0 : (ix >= A.dw ? A.dw - 1 : ix); iy = iy < 0 ? 0 : (iy >= A.dh ? A.dh - 1 : iy);
+    const size_t p = ((size_t)slot * A.dh + iy) * A.dw + ix;
+    double d;
+    if (A.kind == 1) d = (double)reinterpret_cast<const uint16_t *>(A.img)[p] * A.scale;
+    else if (A.kind == 2) d = reinterpret_cast<const double *>(A.img)[p];
+    else d = (double)reinterpret_cast<const float *>(A.img)[p];
+    if (!(d > 0)) d = 0.0;
+    A.kp_depth[o] = d; A.kp_has_mp[o] = (uint8_t)(d > 0);
+}
+
 extern "C" {
 
 int ygz_hip_pinned_alloc(void **out, size_t bytes)
@@ -127,6 +152,74 @@ int ygz_hip_set_keypoint_depths_batch(ygz_hip_ctx *ctx, int slot_begin, int n_sl
     const size_t Cn = (size_t)ctx->cells, o = (size_t)slot_begin * Cn, N = (size_t)n_slots * Cn;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_depth + o, depth, N * 8, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->kp_has_mp + o, has_mappoint, N, hipMemcpyHostToDevice, ctx->stream));
+    if (wait) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_upload_depth_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const void *depth, int dw, int dh, int kind, double scale, int wait)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !depth || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames || dw < 1 || dh < 1 ||
+        dw > ctx->lw[0] || dh > ctx->lh[0] || kind < 0 || kind > 2 || !(scale > 0)) return YGZ_E_INVALID;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    const size_t esz = kind == 1 ? 2 : (kind == 2 ? 8 : 4), fb = (size_t)dw * dh * esz;
+    if (ctx->depth_img && (ctx->depth_w != dw || ctx->depth_h != dh || ctx->depth_kind != kind)) {
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->depth_img); ctx->depth_img = nullptr;
+    }
+    if (!ctx->depth_img) {
+        YGZ_HIPCHK(ctx, hipMalloc(&ctx->depth_img, (size_t)ctx->prm.max_frames * fb + 64));
+        YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->depth_img, 0, (size_t)ctx->prm.max_frames * fb, ctx->stream));
+        ctx->depth_w = dw; ctx->depth_h = dh; ctx->depth_kind = kind;
+    }
+    ctx->depth_scale = scale;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync((uint8_t *)ctx->depth_img + (size_t)slot_begin * fb, depth, (size_t)n_slots * fb, hipMemcpyHostToDevice, ctx->stream));
+    if (wait) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_keypoint_depths_from_image(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (!ctx->depth_img) return YGZ_E_STATE;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    int rc = ygz_track_ensure(ctx);
+    if (rc != YGZ_OK) return rc;
+    DepthArgs A;
+    A.img = ctx->depth_img; A.dw = ctx->depth_w; A.dh = ctx->depth_h; A.kind = ctx->depth_kind; A.scale = ctx->depth_scale;
+    A.w = ctx->lw[0]; A.h = ctx->lh[0]; A.cells = ctx->cells; A.slot_begin = slot_begin;
+    A.n_kp = ctx->n_kp; A.kp_px = ctx->kp_px; A.kp_depth = ctx->kp_depth; A.kp_has_mp = ctx->kp_has_mp;
+    YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_kp_depth_from_image, dim3(ygz_div_up(ctx->cells, 256), n_slots), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+int ygz_hip_get_keypoint_depths(ygz_hip_ctx *ctx, int slot, double *depth, uint8_t *has_mappoint, int capacity, int *n_out)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !n_out || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
+    if (!ctx->trk_alloc) return YGZ_E_STATE;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    int n = 0;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(&n, ctx->n_kp + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    if (n > capacity) return YGZ_E_CAPACITY;
+    const size_t o = (size_t)slot * ctx->cells;
+    if (n > 0) {
+        if (depth) YGZ_HIPCHK(ctx, hipMemcpyAsync(depth, ctx->kp_depth + o, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (has_mappoint) YGZ_HIPCHK(ctx, hipMemcpyAsync(has_mappoint, ctx->kp_has_mp + o, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return YGZ_OK;
+}
+
+int ygz_hip_get_keypoint_counts(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int32_t *count, int wait)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !count || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(count, ctx->n_kp + slot_begin, (size_t)n_slots * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (wait) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }

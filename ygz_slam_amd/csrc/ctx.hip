@@ -50,6 +50,28 @@ int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out)
     return YGZ_OK;
 }
 
+void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes)
+{
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (ctx->stage_used + bytes > ctx->stage_cap) {
+        // everything handed out so far must have been consumed before the arena is recycled (or replaced)
+        if (ctx->stage && hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+        ctx->stage_used = 0;
+        if (bytes > ctx->stage_cap) {
+            if (ctx->stage) (void)hipHostFree(ctx->stage);
+            ctx->stage = nullptr; ctx->stage_cap = 0;
+            const size_t cap = bytes > ((size_t)1 << 20) ? bytes : ((size_t)1 << 20);
+            void *p = nullptr;
+            const hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+            if (e != hipSuccess) { ctx->last_hip_error = (int)e; return nullptr; }
+            ctx->stage = (uint8_t *)p; ctx->stage_cap = cap;
+        }
+    }
+    uint8_t *r = ctx->stage + ctx->stage_used;
+    ctx->stage_used += bytes;
+    return r;
+}
+
 int ygz_join(ygz_hip_ctx *ctx, unsigned skip_mask)
 {
     for (int i = 0; i < 3; ++i)
@@ -146,6 +168,10 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ygz_hip_ba_free_all(ctx);
     ygz_hip_vocab_free(ctx);
+    ygz_kf_store_free(ctx);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->depth_img) (void)hipFree(ctx->depth_img);
+    if (ctx->ev_xctx) (void)hipEventDestroy(ctx->ev_xctx);
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
         if (ctx->lvl[L]) (void)hipFree(ctx->lvl[L]);
         if (ctx->deriv[L]) (void)hipFree(ctx->deriv[L]);
@@ -203,6 +229,21 @@ int ygz_hip_synchronize(ygz_hip_ctx *ctx)
     int rcj = ygz_join(ctx);
     if (rcj != YGZ_OK) return rcj;
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stage_used = 0;                                      // every staged table has been consumed
+    return YGZ_OK;
+}
+
+// Everything enqueued on `waiter` after this call runs after everything enqueued on `signaler` before it (both contexts on one
+// device; no host synchronisation).  The offline run uses it to order the BA context behind the tracking lanes.
+int ygz_hip_stream_wait(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler)
+{
+    if (!waiter || !signaler || waiter->device != signaler->device) return YGZ_E_INVALID;
+    if (waiter == signaler) return YGZ_OK;
+    YgzDeviceGuard dg_(signaler);
+    { int rj = ygz_join(signaler); if (rj != YGZ_OK) return rj; }
+    if (!signaler->ev_xctx) YGZ_HIPCHK(signaler, hipEventCreateWithFlags(&signaler->ev_xctx, hipEventDisableTiming));
+    YGZ_HIPCHK(signaler, hipEventRecord(signaler->ev_xctx, signaler->stream));
+    YGZ_HIPCHK(waiter, hipStreamWaitEvent(waiter->stream, signaler->ev_xctx, 0));
     return YGZ_OK;
 }
 
@@ -229,7 +270,7 @@ static const char *const k_kernel_names[KID_COUNT] = {
     "k_bgr2gray", "k_pyr_down", "k_fast_select", "k_compact", "k_describe", "k_hamming_nn", "k_match_finalize", "k_track_load",
     "k_find_direct_projection", "k_align2d", "k_sparse_align", "k_scharr", "k_klt", "k_klt_pad", "k_ba_pose_prep", "k_ba_points", "k_ba_final",
     "k_ba_chi2", "k_pose_only_ba", "k_ba_lm", "k_bow_transform", "k_bow_match", "k_depth_from_triangulation", "k_lmap_match", "k_lmap_aux",
-    "k_match_postfilter", "k_track_aux", "k_depth_filter" };
+    "k_match_postfilter", "k_track_aux", "k_depth_filter", "k_window" };
 
 int ygz_hip_probe_begin(ygz_hip_ctx *ctx, const char *kernel_name, int max_launches)
 {

@@ -309,8 +309,8 @@ __global__ __launch_bounds__(256) void k_match_finalize(const int32_t *__restric
     }
 }
 
-static int run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, const int32_t *set_count,
-                     const int32_t *pair_q, const int32_t *pair_t, int n_pairs, int max_rows, int cross_check, bool want_second)
+int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, const int32_t *set_count,
+                  const int32_t *pair_q, const int32_t *pair_t, int n_pairs, int max_rows, int cross_check, bool want_second)
 {
     const size_t Cn = (size_t)ctx->cells;
     ctx->pf_valid = false;                            // the M3 flags of the previous result are stale
@@ -356,11 +356,15 @@ int ygz_hip_match_slots(ygz_hip_ctx *ctx, const int32_t *query_slot, const int32
     for (int i = 0; i < n_pairs; ++i)
         if (query_slot[i] < 0 || query_slot[i] >= ctx->prm.max_frames || train_slot[i] < 0 || train_slot[i] >= ctx->prm.max_frames)
             return YGZ_E_INVALID;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, query_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, train_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // host arrays may be temporaries
+    // the caller's arrays may be temporaries: the copy engine reads a page-locked copy (no wait for the stream -- a pipeline
+    // enqueues this call behind an upload and an extraction that are still running)
+    int32_t *st = (int32_t *)ygz_stage(ctx, (size_t)n_pairs * 8);
+    if (!st) return YGZ_E_HIP;
+    memcpy(st, query_slot, (size_t)n_pairs * 4); memcpy(st + n_pairs, train_slot, (size_t)n_pairs * 4);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, st, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, st + n_pairs, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
     ctx->n_pairs = n_pairs;
-    return run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, n_pairs, ctx->cells,
+    return ygz_run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, n_pairs, ctx->cells,
                      cross_check, false);
 }
 
@@ -370,7 +374,7 @@ int ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check)
     YgzDeviceGuard dg_(ctx);
     if (!ctx || ctx->n_pairs < 1 || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     YgzAuxScope aux(ctx, 2);
-    return run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->n_pairs, ctx->cells,
+    return ygz_run_match(ctx, ctx->kp_desc, (size_t)ctx->cells * 8, ctx->n_kp, ctx->pair_q, ctx->pair_t, ctx->n_pairs, ctx->cells,
                      cross_check, false);
 }
 
@@ -415,7 +419,7 @@ int ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint
     if (nt > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(d + stride_u32, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int32_t *cnt = reinterpret_cast<const int32_t *>(buf);
-    rc = run_match(ctx, d, stride_u32, cnt, cnt + 2, cnt + 3, 1, nq > nt ? nq : nt, cross_check, dist2 != nullptr);
+    rc = ygz_run_match(ctx, d, stride_u32, cnt, cnt + 2, cnt + 3, 1, nq > nt ? nq : nt, cross_check, dist2 != nullptr);
     if (rc != YGZ_OK) return rc;
     if (train_idx) YGZ_HIPCHK(ctx, hipMemcpyAsync(train_idx, ctx->m_idx, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (dist) YGZ_HIPCHK(ctx, hipMemcpyAsync(dist, ctx->m_dist, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -462,7 +466,7 @@ int ygz_hip_match_sets(ygz_hip_ctx *ctx, int n_sets, const uint8_t *const *desc,
         if (count[s] > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(d + (size_t)s * stride_u32, desc[s], (size_t)count[s] * 32, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                     // hdr is about to go out of scope for the async copy engine
     const int32_t *cnt = reinterpret_cast<const int32_t *>(buf), *pq = cnt + n_sets, *pt = pq + n_pairs;
-    rc = run_match(ctx, d, stride_u32, cnt, pq, pt, n_pairs, max_rows, cross_check, false);
+    rc = ygz_run_match(ctx, d, stride_u32, cnt, pq, pt, n_pairs, max_rows, cross_check, false);
     if (rc != YGZ_OK) return rc;
     if (good || n_good || min_dis) {
         rc = ygz_launch_match_postfilter(ctx, cnt, pq, n_pairs, min_floor, min_ceil, factor);

@@ -6,6 +6,7 @@
 #include "ygz_internal.h"
 #include "se3_dev.h"
 #include <stdlib.h>
+#include <string.h>
 
 int ygz_track_ensure(ygz_hip_ctx *ctx)
 {
@@ -44,26 +45,30 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
         if (cur_slot[i] < 0 || cur_slot[i] >= ctx->prm.max_frames || ref_slot[i] < 0 || ref_slot[i] >= ctx->prm.max_frames) return YGZ_E_INVALID;
     int rc = ygz_track_ensure(ctx);
     if (rc != YGZ_OK) return rc;
-    std::vector<double> T((size_t)n_pairs * 14);
+    const int F = ctx->prm.max_frames;
+    // page-locked copies of the caller's tables (ygz_stage): no wait for the stream, the call can be enqueued behind running work
+    uint8_t *st = (uint8_t *)ygz_stage(ctx, (size_t)n_pairs * (8 + 14 * 8) + (size_t)F * 8);
+    if (!st) return YGZ_E_HIP;
+    int32_t *h_q = (int32_t *)st, *h_t = h_q + n_pairs, *h_lst = h_t + n_pairs;
+    double *T = (double *)(st + (((size_t)n_pairs * 8 + (size_t)F * 8 + 7) & ~(size_t)7));
+    memcpy(h_q, cur_slot, (size_t)n_pairs * 4); memcpy(h_t, ref_slot, (size_t)n_pairs * 4);
     for (int i = 0; i < n_pairs; ++i)
         for (int k = 0; k < 7; ++k) { T[14 * i + k] = T_ref[7 * i + k]; T[14 * i + 7 + k] = T_cur[7 * i + k]; }
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, cur_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, ref_slot, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_T, T.data(), T.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, h_q, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, h_t, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_T, T, (size_t)n_pairs * 14 * 8, hipMemcpyHostToDevice, ctx->stream));
     {   // distinct slots of the table (a frame is usually the current frame of one pair and the reference of the next): the
         // tracker prepares its working images once per slot
-        const int F = ctx->prm.max_frames;
         std::vector<uint8_t> any(F, 0), isref(F, 0);
         for (int i = 0; i < n_pairs; ++i) { any[cur_slot[i]] = 1; any[ref_slot[i]] = 1; isref[ref_slot[i]] = 1; }
-        std::vector<int32_t> lst;
-        for (int s = 0; s < F; ++s) if (any[s]) lst.push_back(s);
-        ctx->n_klt_slots = (int)lst.size();
-        for (int s = 0; s < F; ++s) if (isref[s]) lst.push_back(s);
-        ctx->n_klt_refs = (int)lst.size() - ctx->n_klt_slots;
+        int n = 0;
+        for (int s = 0; s < F; ++s) if (any[s]) h_lst[n++] = s;
+        ctx->n_klt_slots = n;
+        for (int s = 0; s < F; ++s) if (isref[s]) h_lst[n++] = s;
+        ctx->n_klt_refs = n - ctx->n_klt_slots;
         if (!ctx->klt_slots) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_slots, (size_t)F * 8));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_slots, lst.data(), lst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (n > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_slots, h_lst, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_pairs = n_pairs;
     ctx->klt_prep_valid = false;
     return YGZ_OK;

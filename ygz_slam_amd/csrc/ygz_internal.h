@@ -101,9 +101,23 @@ struct ygz_hip_ctx {
     Vocab *vocab = nullptr;                  // DBoW3 vocabulary tree + per-keypoint BoW (bow.hip)
     struct BaWindow;
     std::vector<BaWindow*> ba;
-    void *ba_table = nullptr;                // device array of per-window descriptors
-    bool  ba_table_dirty = true;
+    void *ba_table = nullptr;                // device array of per-window descriptors (entries of device-built windows are patched by k_win_edges)
+    void *ba_table_host = nullptr;           // host mirror (std::vector<BaDev>*), entries re-uploaded one by one when their window changed
+    bool  ba_table_dirty = true;             // some window's entry must be (re)uploaded
     int   ba_max_K = 0, ba_max_P = 0;
+
+    // page-locked staging arena for the small host tables an asynchronous entry point hands to the copy engine (pair tables, poses,
+    // window descriptors): a slice stays valid until the next ygz_hip_synchronize of this context, so no entry point has to wait for the
+    // stream just because its host arguments are temporaries
+    uint8_t *stage = nullptr; size_t stage_cap = 0, stage_used = 0;
+    // per-slot depth images (RGB-D style input of the offline run: Feature::_depth of the keypoints is sampled from them on the device)
+    void *depth_img = nullptr; int depth_w = 0, depth_h = 0, depth_kind = 0; double depth_scale = 1.0;
+    // keyframe store + relative-pose store of the offline run (window.hip)
+    struct KfStore;
+    KfStore *kfs = nullptr;
+    hipEvent_t ev_xctx = nullptr;            // ygz_hip_stream_wait: recorded on this context's stream, waited for by another's
+    bool sa_attr_set = false;                // the dynamic-LDS opt-in of k_sparse_align was made on this context's device
+    int  klt_prep_levels = 0;                // levels covered by the LK working images while klt_prep_valid
 };
 
 #define YGZ_HIPCHK(ctx, call)                                            \
@@ -129,7 +143,7 @@ struct YgzDeviceGuard {
 // kernel ids for the probe
 enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIBE, KID_HAMMING_NN, KID_MATCH_FINALIZE,
        KID_TRACK_LOAD, KID_FDP, KID_ALIGN2D, KID_SPARSE_ALIGN, KID_SCHARR, KID_KLT, KID_KLT_PAD, KID_BA_POSE_PREP, KID_BA_POINTS,
-       KID_BA_POSES, KID_BA_CHI2, KID_POSE_ONLY, KID_BA_LM, KID_BOW_TRANSFORM, KID_BOW_MATCH, KID_DEPTH_TRI, KID_LMAP_MATCH, KID_LMAP_AUX, KID_MATCH_POSTFILTER, KID_TRACK_AUX, KID_DEPTH_FILTER, KID_COUNT };
+       KID_BA_POSES, KID_BA_CHI2, KID_POSE_ONLY, KID_BA_LM, KID_BOW_TRANSFORM, KID_BOW_MATCH, KID_DEPTH_TRI, KID_LMAP_MATCH, KID_LMAP_AUX, KID_MATCH_POSTFILTER, KID_TRACK_AUX, KID_DEPTH_FILTER, KID_WINDOW, KID_COUNT };
 
 #define YGZ_LAUNCH(ctx, kid, kern, grid, block, ...)                                                         \
     do { const bool pr_ = (ctx)->probe_id == (kid) && (ctx)->probe_used + 2 <= (int)(ctx)->probe_ev.size();    \
@@ -146,9 +160,16 @@ enum { KID_BGR2GRAY = 0, KID_PYR_DOWN, KID_FAST_SELECT, KID_COMPACT, KID_DESCRIB
 
 // scratch ids
 enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR_SA_OUT, SCR_SA_WORK,
-       SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_LMAP, SCR_GEN_0 = 16 };
+       SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_LMAP, SCR_WIN, SCR_GEN_0 = 16 };
 
 int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
+// `bytes` of page-locked host memory that stay valid until the next ygz_hip_synchronize (nullptr: allocation failed)
+void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes);
+// the brute-force matcher over descriptor sets desc + s * set_stride (u32 units), sizes set_count[s], pairs (pair_q[p], pair_t[p]): device
+// arrays; results in ctx->m_idx / m_dist [n_pairs][cells] (hamming.hip)
+int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, const int32_t *set_count, const int32_t *pair_q,
+                  const int32_t *pair_t, int n_pairs, int max_rows, int cross_check, bool want_second);
+void ygz_kf_store_free(ygz_hip_ctx *ctx);   // window.hip
 int ygz_join(ygz_hip_ctx *ctx, unsigned skip_mask = 0);   // main stream waits for every pending side-stream stage (bit i of
                                                           // skip_mask: leave side stream i pending -- for entry points that do not
                                                           // touch what that stage reads or writes)

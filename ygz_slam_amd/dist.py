@@ -52,3 +52,23 @@ def gather_trajectories(local_poses, n_total, rank, world, device=None):
     outs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(outs, t)
     return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)], 0)
+
+
+def all_gather_rows(local, counts, pg=None, via_host=False):
+    """One all-gather of ragged row blocks: rank r contributes counts[r] rows (`local`, a torch tensor [counts[rank], ...] on any
+    device); returns a tensor [world, max(counts), ...] on local's device whose block r holds rank r's rows (the tail of a short
+    block is padding).  Fixed shapes, so this is a single collective (RCCL all_gather_into_tensor on device buffers; with
+    via_host=True -- gloo, the CPU tests and the two-ranks-on-one-GPU tests -- the same call on host copies)."""
+    import torch
+    import torch.distributed as dist
+    world = len(counts)
+    mx = max(max(counts), 1)
+    lbuf = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device="cpu" if via_host else local.device)
+    if local.shape[0]:
+        lbuf[:local.shape[0]] = local
+    gbuf = torch.empty((world,) + tuple(lbuf.shape), dtype=local.dtype, device=lbuf.device)
+    if via_host:
+        dist.all_gather(list(gbuf.unbind(0)), lbuf, group=pg)
+        return gbuf.to(local.device)
+    dist.all_gather_into_tensor(gbuf, lbuf, group=pg)
+    return gbuf

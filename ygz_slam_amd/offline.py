@@ -1,7 +1,7 @@
 """Batched offline visual odometry (BASELINE.json configs[4]): a sequence of N frames sharded over `world` GPUs in
 contiguous chunks with a one-frame halo, the per-frame hot path run for every consecutive pair, a local-BA round per
-window of keyframes, and the two exchanges SURVEY 8e names: the BA-window state (map points + keyframe poses) broadcast
-from its owner straight into HBM, and the all-gather of per-shard trajectories.
+window of keyframes, and the two exchanges SURVEY 8e names: the refined BA-window states (map points + keyframe poses) from
+their owners to every rank, and the all-gather of per-shard trajectories.
 
 What runs per frame pair (cur = i, ref = i - 1), all pairs of a chunk per launch, mirrors VisualOdometry::AddFrame in state
 VO_GOOD (src/Module/VisualOdometry.cpp:62-93):
@@ -14,12 +14,22 @@ VO_GOOD (src/Module/VisualOdometry.cpp:62-93):
 Every pair starts from T_ref = identity, so its result T_rel (pose of cur in the frame of ref) is a function of the two
 frames alone: a shard needs no pose from its neighbour, and the global trajectory T[i] = T_rel[i] * T[i-1] is chained
 after the all-gather, identically on every rank.  The reference gets Feature::_depth from map points made by its
-initialiser / triangulation (out of scope); here the sequence supplies a depth map per frame.
+initialiser / triangulation (out of scope); here the sequence supplies a depth image per frame (RGB-D style),
+sampled at the keypoints ON THE DEVICE (ygz_hip_keypoint_depths_from_image).
 
 BA round (LocalMapping::LocalBA -> ba::LocalBAG2O, LocalMapping.cpp:149-208, BA.cpp:386-543): keyframes are every
 `kf_stride`-th frame, a window = `window_kfs` consecutive keyframes owned by the rank that owns its first keyframe (the
 anchor, held fixed like keyframe 0 at BA.cpp:404); map points = the anchor's features with depth, observations = the
-good cross-checked Hamming matches of the anchor's descriptors in the other keyframes of the window.
+good cross-checked Hamming matches of the anchor's descriptors in the other keyframes of the window.  The windows are built ON
+THE DEVICE from a store of keyframe rows (csrc/window.hip), in the gauge of their anchor (anchor pose = identity, the other
+vertices chained from the frames' relative poses), so a window depends on its own frames only: it is built and optimised as soon
+as the chunk holding its last keyframe has been enqueued -- beside the uploads and kernels of the following chunks -- and the
+sharded run reproduces the unsharded one bit for bit.
+
+The run is driven from ONE host thread: every call on the tracking path is asynchronous (page-locked buffers, staged tables), two
+contexts ("lanes") take alternate chunks so that the H2D copy of one chunk runs under the kernels of the other, a third context
+owns the keyframe store and the BA windows; the host blocks only when it re-uses a lane and reads that lane's 32-double-per-pair
+summary.
 
 This module is host logic over the C ABI (ygz_slam_amd._lib); it never touches oracle/.
 """
@@ -148,25 +158,57 @@ def frame_owner(frame, n_total, world):
     raise ValueError(frame)
 
 
-def exchange_rows(buf, owner, world, pg=None):
-    """The map exchange: row i of `buf` (a torch tensor, in HBM on the GPU box) is owned by rank owner[i]; every owner broadcasts
-    its rows -- they are contiguous, windows being ordered by anchor frame -- so that all ranks end with the same replica.
-    One collective per owner and round (RCCL over xGMI with backend nccl; gloo in the CPU tests)."""
+def exchange_rows(buf, owner, world, pg=None, via_host=None):
+    """The map exchange: row i of `buf` (a torch tensor, in HBM on the GPU box) is owned by rank owner[i] -- owners hold contiguous
+    row ranges, windows being ordered by anchor frame --; afterwards every rank holds every owner's rows.  ONE collective
+    (all-gather of fixed-shape blocks; RCCL over xGMI with backend nccl, gloo on host copies in the CPU tests)."""
     if world == 1:
         return
     import torch.distributed as dist
+    rank = dist.get_rank(pg)
+    rows = [[i for i, o in enumerate(owner) if o == r] for r in range(world)]
+    for r in rows:
+        assert r == list(range(r[0], r[-1] + 1)) if r else True
+    mine = rows[rank]
+    local = buf[mine[0]:mine[-1] + 1] if mine else buf[:0]
+    if via_host is None:
+        via_host = buf.device.type == "cpu" or dist.get_backend(pg) == "gloo"
+    g = ydist.all_gather_rows(local, [len(r) for r in rows], pg, via_host)
     for r in range(world):
-        rows = [i for i, o in enumerate(owner) if o == r]
-        if rows:
-            assert rows == list(range(rows[0], rows[-1] + 1))
-            dist.broadcast(buf[rows[0]:rows[-1] + 1], src=r, group=pg)
+        if r != rank and rows[r]:
+            buf[rows[r][0]:rows[r][-1] + 1] = g[r, :len(rows[r])]
+
+
+def depth_image(d, div=1, dtype=np.float64, scale=1.0 / 5000.0):
+    """depth map of the sequence (metres) -> the image the device samples: every div-th sample as float64 / float32 metres or, for
+    uint16, round(depth / scale) (TUM RGB-D: scale = 1 / 5000)"""
+    d = np.asarray(d)[::div, ::div]
+    if np.dtype(dtype) == np.uint16:
+        return np.clip(np.rint(d / scale), 0, 65535).astype(np.uint16)
+    return np.ascontiguousarray(d, dtype)
+
+
+def depth_at(dimg, px, w, h, scale=1.0 / 5000.0):
+    """what ygz_hip_keypoint_depths_from_image reads for level-0 pixels px [n, 2] of a w x h frame from depth image dimg
+    (host restatement of the look-up: the tests' reference and the oracle legs' input)"""
+    dh, dw = dimg.shape
+    ix = (px[:, 0].astype(np.int64) * dw) // w
+    iy = (px[:, 1].astype(np.int64) * dh) // h
+    v = dimg[iy, ix]
+    d = v.astype(np.float64) * scale if dimg.dtype == np.uint16 else v.astype(np.float64)
+    return np.where(d > 0, d, 0.0)
 
 
 class OfflineVO:
-    """One rank of the offline run.  frame_source(i) -> BGR uint8 [h, w, 3]; depth_source(i) -> float [h, w]."""
+    """One rank of the offline run.  frame_source(i) -> BGR uint8 [h, w, 3] (or gray [h, w]); depth_source(i) -> depth map [h, w]
+    (metres).  block_source(frames) -> (frames [n, h, w, 3] or [n, h, w] uint8, depth images [n, dh, dw]) replaces the per-frame
+    sources when the caller holds the sequence in page-locked memory in the form the ABI uploads (then every copy is asynchronous).
+    depth_div / depth_dtype: the depth image handed to the device is depth_source(i)[::depth_div, ::depth_div] as float64 / float32
+    metres or, for uint16, round(depth / depth_scale) (TUM RGB-D: depth_scale = 1 / 5000)."""
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
-                 max_points=2000, ba_iterations=20, overlap=True, process_group=None, exchange_on_device=True, keep=False, lanes=2):
+                 max_points=2000, ba_iterations=20, overlap=True, process_group=None, exchange_on_device=True, keep=False, lanes=2,
+                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True):
         from . import _lib
         self.lib = _lib
         self.w, self.h, self.levels = width, height, levels
@@ -174,82 +216,104 @@ class OfflineVO:
         self.chunk, self.kf_stride, self.window_kfs = chunk, kf_stride, window_kfs
         self.max_points, self.ba_iterations = max_points, ba_iterations
         self.overlap, self.pg, self.exchange_on_device, self.keep = overlap, process_group, exchange_on_device, keep
+        self.depth_div, self.depth_dtype, self.depth_scale = depth_div, np.dtype(depth_dtype), depth_scale
+        self.pipeline_ba = pipeline_ba
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
-        self.ctx = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2, window_kfs), device=device)
-        self.ctx.set_overlap(overlap)
-        # a second context (own streams, own slots) takes every other chunk from its own host thread: the H2D copy of one chunk and
-        # the host-side depth look-up of its keypoints run under the kernels of the other (the C calls release the GIL)
-        self.lanes = [self.ctx]
-        if lanes > 1 and self.count > chunk:
-            c2 = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2, window_kfs), device=device)
-            c2.set_overlap(overlap)
-            self.lanes.append(c2)
+        n_lanes = 2 if (lanes > 1 and self.count > chunk) else 1
+        self.lanes = []
+        for _ in range(n_lanes):
+            c = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
+            c.set_overlap(overlap)
+            self.lanes.append(c)
+        self.ctx = self.lanes[0]
+        # windows, owners; the third context holds the keyframe store and the BA windows of this rank
+        self.wins = ba_windows(n_total, kf_stride, window_kfs)
+        self.owner = [frame_owner(w[0], n_total, world) for w in self.wins]
+        self.mine = [i for i, o in enumerate(self.owner) if o == rank]
+        last = self.start + self.count
+        self.local = [i for i in self.mine if self.wins[i][-1] < last]            # every keyframe tracked by this rank
+        self.any_cross = any(frame_owner(w[-1], n_total, world) != o for w, o in zip(self.wins, self.owner))
+        self.n_kf = len(keyframes(n_total, kf_stride))
+        K1 = max(1, window_kfs - 1)
+        self.build_group = max(1, min(len(self.mine), 16))                       # windows per build call (matcher rows: group x (K - 1) pairs)
+        self.ba = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(8, self.build_group * K1), device=device)
+        self.rows_t = None
+        if world > 1 and self.any_cross:                                          # rows of other ranks arrive by a collective: torch owns the memory
+            import torch
+            rb = self.ba.kf_row_bytes()
+            self.rows_t = torch.zeros((self.n_kf + self.build_group) * rb, dtype=torch.uint8, device=torch.device("cuda", device))
+            self.ba.kf_store_create(self.n_kf, n_total, self.build_group, self.rows_t.data_ptr(), self.rows_t.numel())
+        else:
+            self.ba.kf_store_create(self.n_kf, n_total, self.build_group)
+        if self.mine:
+            self.ba.ba_reserve_windows(0, len(self.mine), window_kfs, max_points)
+        self.S = 6 * window_kfs + 3 * max_points + 8                              # one window state row: poses | points | K P E its trials chi2_0 chi2 lambda
+        cap = max(n_slots, 2)
+        self._pin = [dict(sum=_lib.PinnedArray((cap, _lib.SUMMARY_FIELDS), np.float64), cnt=_lib.PinnedArray((cap,), np.int32)) for _ in self.lanes]
         self.timing = {}
 
     def close(self):
         for c in self.lanes:
             c.close()
+        self.ba.close()
+        for p in self._pin:
+            p["sum"].free(); p["cnt"].free()
 
-    # ------------------------------------------------------------------ phase 1: the hot path over this shard
+    # ------------------------------------------------------------------ depth images
+    def depth_image(self, d):
+        return depth_image(d, self.depth_div, self.depth_dtype, self.depth_scale)
+
+    def depth_at(self, dimg, px):
+        return depth_at(dimg, px, self.w, self.h, self.depth_scale)
+
+    # ------------------------------------------------------------------ phase 1: the hot path over this shard (+ the BA windows it completes)
     def track_shard(self, frame_source, depth_source, block_source=None):
-        """The hot path over the frames this rank owns, chunk by chunk; returns per-frame records (+ the keyframe tables of the
-        owned keyframes).  block_source(frames) -> (bgr [n, h, w, 3] uint8 C-contiguous, depth maps [n, h, w]) replaces the
-        per-frame sources when the caller holds the sequence in (page-locked) memory.  Per chunk: one upload, the batched
-        kernels, one download of the keypoint pixels (the depth look-up is the stand-in for the map, see the module text), one
-        upload of the depths, and one download of the per-pair summary."""
-        rec = {}                      # frame -> dict (the lanes write disjoint keys)
+        """The hot path over the frames this rank owns, chunk by chunk on alternating lanes; returns per-frame records.  Per chunk:
+        one upload of the frames and depth images, the batched kernels, the keyframes' rows and the pairs' relative poses into the
+        store (device to device), one download of the per-pair summary -- no host round trip in between.  Windows whose keyframes
+        are all in are built and optimised on the third context while the next chunks run (pipeline_ba)."""
+        rec = {}
         first, last = self.start, self.start + self.count
         chunks = [(c0, min(c0 + self.chunk, last)) for c0 in range(first, last, self.chunk)]
-        if len(self.lanes) == 1 or len(chunks) < 2:
-            for c0, c1 in chunks:
-                self._track_chunk(self.ctx, c0, c1, rec, frame_source, depth_source, block_source)
-            return rec
-        import threading
-        errors = []
-
-        def lane(k):
-            try:
-                for c0, c1 in chunks[k::len(self.lanes)]:
-                    self._track_chunk(self.lanes[k], c0, c1, rec, frame_source, depth_source, block_source)
-            except BaseException as e:                       # surfaces in the caller's thread
-                errors.append(e)
-        th = [threading.Thread(target=lane, args=(k,)) for k in range(len(self.lanes))]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errors:
-            raise errors[0]
+        pending = [None] * len(self.lanes)
+        self._ba_done = set()
+        for ci, (c0, c1) in enumerate(chunks):
+            li = ci % len(self.lanes)
+            if pending[li] is not None:
+                self._collect(li, pending[li], rec)
+            pending[li] = self._enqueue(li, c0, c1, frame_source, depth_source, block_source)
+            if self.keep:                                      # parity runs read everything back before the lane moves on
+                self._collect(li, pending[li], rec); pending[li] = None
+            if self.pipeline_ba:
+                self._ba_launch([i for i in self.local if i not in self._ba_done and self.wins[i][-1] < c1])
+        for li in range(len(self.lanes)):
+            if pending[li] is not None:
+                self._collect(li, pending[li], rec)
         return rec
 
-    def _track_chunk(self, c, c0, c1, rec, frame_source, depth_source, block_source):
-        cells = c.cells
+    def _enqueue(self, li, c0, c1, frame_source, depth_source, block_source):
+        c = self.lanes[li]
         frames = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))      # one-frame halo: the predecessor of the chunk
         slot_of = {f: k for k, f in enumerate(frames)}
         n = len(frames)
-        if block_source is not None:
-            bgr, dmaps = block_source(frames)
+        asyn = block_source is not None
+        if asyn:
+            img, dimg = block_source(frames)
         else:
-            bgr = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
-            dmaps = [depth_source(f) for f in frames]
-        if bgr.ndim == 3:                                      # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
-            c.upload_gray_batch(0, bgr)
+            img = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
+            dimg = np.ascontiguousarray(np.stack([self.depth_image(depth_source(f)) for f in frames]))
+        if img.ndim == 3:                                      # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
+            c.upload_gray_batch(0, img, wait=not asyn)
             c.build_pyramid(0, n, from_bgr=False)
         else:
-            c.upload_bgr_batch(0, bgr)
+            c.upload_bgr_batch(0, img, wait=not asyn)
             c.build_pyramid(0, n, from_bgr=True)
         c.detect(0, n)
-        px, cnt = c.get_keypoint_pixels_batch(0, n)
-        depth = np.zeros((n, cells), np.float64)
-        for k in range(n):
-            m = int(cnt[k])
-            if m:
-                depth[k, :m] = dmaps[k][px[k, :m, 1].astype(np.int64), px[k, :m, 0].astype(np.int64)]
-        c.set_keypoint_depths_batch(0, depth, (depth > 0).astype(np.uint8))
+        c.upload_depth_batch(0, dimg, self.depth_scale, wait=not asyn)
+        c.keypoint_depths_from_image(0, n)                     # Feature::_depth / _mappoint of the fresh keypoints
         pairs = [(f, f - 1) for f in frames if f - 1 in slot_of and f >= c0]
-        S = None
         if pairs:
             q = [slot_of[a] for a, _ in pairs]
             t = [slot_of[b] for _, b in pairs]
@@ -262,19 +326,31 @@ class OfflineVO:
             c.track_adopt_pose()
             c.track_direct()
             c.track_pose_only()
-            S = c.track_get_summary().copy()
-        for f in range(c0, c1):
+            c.track_get_summary(out=self._pin[li]["sum"].array, wait=False)
+            self.ba.kf_store_put_trel(c, 0, len(pairs), pairs[0][0])
+        c.get_keypoint_counts(0, n, out=self._pin[li]["cnt"].array, wait=False)
+        kf = [f for f in range(c0, c1) if f % self.kf_stride == 0]
+        if kf:
+            self.ba.kf_store_put(c, [slot_of[f] for f in kf], [f // self.kf_stride for f in kf])
+        return dict(c0=c0, c1=c1, frames=frames, slot_of=slot_of, pairs=pairs, dimg=dimg if self.keep else None)
+
+    def _collect(self, li, info, rec):
+        """wait for the lane, then read its chunk's results out of the page-locked buffers"""
+        c = self.lanes[li]
+        c.synchronize()
+        S = self._pin[li]["sum"].array[:len(info["pairs"])].copy()
+        cnt = self._pin[li]["cnt"].array[:len(info["frames"])].copy()
+        slot_of = info["slot_of"]
+        for f in range(info["c0"], info["c1"]):
             k = slot_of[f]
             r = dict(n_kp=int(cnt[k]))
-            if self.keep or f % self.kf_stride == 0:
+            if self.keep:
                 kp = c.get_keypoints(k)
-                kp["depth"] = depth[k, :int(cnt[k])].copy()
-                if self.keep:
-                    r["kp"] = kp
-                if f % self.kf_stride == 0:
-                    r["kf"] = {key: kp[key] for key in ("px", "level", "desc", "depth")}
+                kp["depth"], has_mp = c.get_keypoint_depths(k)
+                assert np.array_equal(kp["depth"], self.depth_at(info["dimg"][k], kp["px"])) and np.array_equal(has_mp, kp["depth"] > 0)   # the device's look-up
+                r["kp"] = kp
             rec[f] = r
-        for p, (cur, ref) in enumerate(pairs):
+        for p, (cur, ref) in enumerate(info["pairs"]):
             r = rec[cur]
             r.update(T_sa=S[p, 0:7].copy(), sa_n_meas=int(S[p, 7]), T_rel=S[p, 24:31].copy(), po_inliers=int(S[p, 14]),
                      po_rounds=int(S[p, 15]), n_match=int(S[p, 16]), n_good=int(S[p, 17]), min_dis=float(S[p, 18]),
@@ -303,138 +379,136 @@ class OfflineVO:
         T_rel[0] = I7
         return T_rel, chain(T_rel)
 
-    def gather_keyframes(self, rec):
-        """keyframe tables (pixels, levels, descriptors, depths) of every keyframe on every rank"""
-        mine = {f: rec[f]["kf"] for f in rec if "kf" in rec[f]}
-        if self.world == 1:
-            return mine
-        import torch.distributed as dist
-        allk = [None] * self.world
-        dist.all_gather_object(allk, mine, group=self.pg)
-        out = {}
-        for d in allk:
-            out.update(d)
-        return out
+    def gather_keyframes(self):
+        """keyframe rows (pixels, levels, descriptors, depths: fixed-size rows of the device store) of every keyframe on every
+        rank: ONE all-gather on the store's memory -- needed only when a window straddles a shard boundary"""
+        if self.world == 1 or not self.any_cross:
+            return
+        import torch
+        rb = self.ba.kf_row_bytes()
+        rows = self.rows_t[:self.n_kf * rb].view(self.n_kf, rb)
+        own = [[k for k, f in enumerate(keyframes(self.n_total, self.kf_stride)) if frame_owner(f, self.n_total, self.world) == r]
+               for r in range(self.world)]
+        mine = own[self.rank]
+        local = rows[mine[0]:mine[-1] + 1] if mine else rows[:0]
+        torch.cuda.synchronize(self._torch_device())
+        g = ydist.all_gather_rows(local, [len(o) for o in own], self.pg, via_host=not self.exchange_on_device)
+        for r in range(self.world):
+            if r != self.rank and own[r]:
+                rows[own[r][0]:own[r][-1] + 1] = g[r, :len(own[r])]
+        torch.cuda.synchronize(self._torch_device())           # torch's stream wrote the rows, the ABI context has its own
+        self.ba.kf_store_refresh()
 
     def _torch_device(self):
         import torch
         return torch.device("cuda", self.device)
 
     # ------------------------------------------------------------------ phase 3: BA round
-    def build_window(self, kfs, kf_tab, traj, c=None):
-        """graph of ba::LocalBAG2O for one window: poses (g2o order), points, edges; anchor = kfs[0] held fixed"""
-        c = c or self.ctx
-        A = kf_tab[kfs[0]]
-        sel = np.nonzero(A["depth"] > 0)[0][:self.max_points]
-        T_a = traj[kfs[0]]
-        fx, fy, cx, cy = (float(c.params.fx), float(c.params.fy), float(c.params.cx), float(c.params.cy))
-        z = A["depth"][sel]
-        pc = np.stack([(A["px"][sel, 0] - cx) * z / fx, (A["px"][sel, 1] - cy) * z / fy, z], axis=1)     # Pixel2Camera (Camera.h:56-62)
-        pw = se3_act(se3_inv(T_a), pc) if len(sel) else np.zeros((0, 3))
-        ep, el, obs = [np.zeros(len(sel), np.int32)], [np.arange(len(sel), dtype=np.int32)], [A["px"][sel]]
-        others = [(j, f) for j, f in enumerate(kfs[1:], start=1) if len(sel) and len(kf_tab[f]["level"])]
-        if others:                                             # the anchor's descriptors against every other keyframe of the window: one call
-            res = c.match_sets([A["desc"][sel]] + [kf_tab[f]["desc"] for _, f in others], [0] * len(others), list(range(1, len(others) + 1)))
-            for (j, f), r in zip(others, res):
-                g = np.nonzero(r["good"])[0]
-                ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(kf_tab[f]["px"][r["idx"][g]])
-        ep, el, obs = np.concatenate(ep), np.concatenate(el), np.concatenate(obs)
-        n_obs = np.bincount(el, minlength=len(sel))
-        keep_pt = n_obs >= 2                                   # a point seen only by the fixed anchor constrains nothing
-        remap = -np.ones(len(sel), np.int64); remap[keep_pt] = np.arange(int(keep_pt.sum()))
-        ke = keep_pt[el]
-        ep, el, obs = ep[ke], remap[el[ke]].astype(np.int32), obs[ke]
-        order = np.lexsort((ep, el))
-        poses = np.stack([se3_log_g2o(traj[f]) for f in kfs])
-        fixed = np.zeros(len(kfs), np.uint8); fixed[0] = 1
-        return dict(kfs=list(kfs), poses=poses, fixed=fixed, points=pw[keep_pt], edge_pose=ep[order], edge_point=el[order], obs=obs[order],
-                    anchor_feature=sel[keep_pt])
+    def _ba_launch(self, wis, optimize=True):
+        """build + optimise the given (owned) windows on the BA context, behind everything the lanes have enqueued so far"""
+        if not wis:
+            return
+        for c in self.lanes:
+            self.ba.stream_wait(c)
+        K = self.window_kfs
+        for g0 in range(0, len(wis), self.build_group):
+            grp = wis[g0:g0 + self.build_group]
+            assert grp == list(range(grp[0], grp[-1] + 1))
+            kfi = np.zeros((len(grp), K), np.int32); kff = np.zeros((len(grp), K), np.int32)
+            for a, wi in enumerate(grp):
+                w = self.wins[wi]
+                kff[a, :len(w)] = w
+                kfi[a, :len(w)] = [f // self.kf_stride for f in w]
+            slot0 = self.mine.index(grp[0])
+            self.ba.ba_build_windows(slot0, kfi, kff, [len(self.wins[wi]) for wi in grp])
+            if optimize:
+                self.ba.ba_optimize_resident(slot0, len(grp), self.ba_iterations, want_stats=False)
+        self._ba_done.update(wis)
 
-    def ba_round(self, kf_tab, traj):
-        """every rank builds and optimises the windows it owns; window states travel through a device buffer that RCCL fills
-        (owner -> everybody), and ygz_hip_ba_set_state_device installs them into the resident windows"""
+    def ba_round(self, T_rel):
+        """the windows this rank owns that are not optimised yet (those straddling a shard boundary; all of them without
+        pipeline_ba), then the exchange: every owner's refined window states to every rank in one all-gather"""
         import time
-        import torch
-        c = self.ctx
-        tb = time.perf_counter()
-        wins = ba_windows(self.n_total, self.kf_stride, self.window_kfs)
-        owner = [frame_owner(w[0], self.n_total, self.world) for w in wins]
-        mine = [i for i, o in enumerate(owner) if o == self.rank]
+        t0 = time.perf_counter()
+        rest = [i for i in self.mine if i not in self._ba_done]
+        if rest:
+            if self.world > 1:                                 # relative poses of the frames other ranks tracked
+                self.ba.kf_store_set_trel(0, T_rel)
+            self._ba_launch(rest)
+        self.ba.synchronize()
+        t1 = time.perf_counter()
+        n_w, S = len(self.wins), self.S
+        if self.world == 1:
+            host = self.ba.ba_pack_states(0, n_w, S) if n_w else np.zeros((0, S))
+        else:
+            import torch
+            dev = self._torch_device()
+            state = torch.zeros((n_w, S), dtype=torch.float64, device=dev)
+            if self.mine:
+                self.ba.ba_pack_states(0, len(self.mine), S, dst_ptr=state[self.mine[0]].data_ptr(), wait=True)
+            exchange_rows(state, self.owner, self.world, self.pg, via_host=not self.exchange_on_device)
+            host = state.cpu().numpy()
+        t2 = time.perf_counter()
+        self.ba_timing = {"tail_after_tracking": (t1 - t0) * 1e3, "exchange_download": (t2 - t1) * 1e3}
         K, P = self.window_kfs, self.max_points
-        S = K * 6 + P * 3                                       # one window state: poses | points
-        dev = self._torch_device()
-        state = torch.zeros((len(wins), S), dtype=torch.float64, device=dev)
-        built = {}
-        if len(self.lanes) > 1 and len(mine) > 1:                # the windows' matcher calls on both contexts, from two host threads
-            import threading
-
-            def lane(k):
-                for wi in mine[k::len(self.lanes)]:
-                    built[wi] = self.build_window(wins[wi], kf_tab, traj, self.lanes[k])
-            th = [threading.Thread(target=lane, args=(k,)) for k in range(len(self.lanes))]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            assert len(built) == len(mine)
-        t_match = time.perf_counter()
-        for li, wi in enumerate(mine):
-            b = built[wi] if wi in built else built.setdefault(wi, self.build_window(wins[wi], kf_tab, traj))
-            c.ba_upload(li, b["poses"], b["fixed"], b["points"], b["edge_pose"], b["edge_point"], b["obs"])
-            row = np.zeros(S)
-            row[:b["poses"].size] = b["poses"].ravel()
-            row[K * 6:K * 6 + b["points"].size] = b["points"].ravel()
-            state[wi] = torch.from_numpy(row).to(dev)
-        t_built = time.perf_counter()
-        self._exchange(state, owner)                            # the map replica now holds every window's initial state
-        torch.cuda.synchronize(dev)                             # the exchange ran on torch's stream, the ABI context has its own
-        for li, wi in enumerate(mine):
-            base = state[wi].data_ptr()
-            c.ba_set_state_device(li, base, base + 8 * K * 6)
-        t_x = time.perf_counter()
-        stats = c.ba_optimize_resident(0, len(mine), self.ba_iterations) if mine else []
-        t_s = time.perf_counter()
-        self.ba_timing = {"build_windows": (t_match - tb) * 1e3, "build_upload": (t_built - tb) * 1e3, "exchange_install": (t_x - t_built) * 1e3, "lm_resident": (t_s - t_x) * 1e3}
-        for li, wi in enumerate(mine):
-            b = built[wi]
-            poses, points = c.ba_get_state(li, len(b["poses"]), len(b["points"]))
-            row = np.zeros(S)
-            row[:poses.size] = poses.ravel()
-            row[K * 6:K * 6 + points.size] = points.ravel()
-            state[wi] = torch.from_numpy(row).to(dev)
-        self._exchange(state, owner)                            # ... and every window's refined state
-        chi2 = torch.zeros((len(wins), 4), dtype=torch.float64, device=dev)
-        for li, wi in enumerate(mine):
-            s = stats[li]
-            chi2[wi] = torch.tensor([s.chi2_initial, s.chi2_final, float(s.iterations), float(len(built[wi]["obs"]))],
-                                    dtype=torch.float64, device=dev)
-        self._exchange(chi2, owner)
-        host = state.cpu().numpy()
-        out = []
-        for wi, w in enumerate(wins):
-            out.append(dict(kfs=w, owner=owner[wi], poses=host[wi, :len(w) * 6].reshape(len(w), 6).copy(),
-                            state=host[wi].copy(), stats=chi2[wi].cpu().numpy()))
-        return out, built
-
-    def _exchange(self, buf, owner):
-        exchange_rows(buf, owner, self.world, self.pg)
+        out, dims = [], {}
+        for wi, w in enumerate(self.wins):
+            tail = host[wi, 6 * K + 3 * P:]
+            if tail[3] < 0:
+                raise RuntimeError("BA window %d: the resident LM did not finish (team barrier time-out)" % wi)
+            dims[wi] = (int(tail[0]), int(tail[1]), int(tail[2]))
+            out.append(dict(kfs=w, owner=self.owner[wi], poses=host[wi, :len(w) * 6].reshape(len(w), 6).copy(), state=host[wi].copy(),
+                            stats=np.array([tail[5], tail[6], tail[3], tail[2]])))
+        return out, dims
 
     # ------------------------------------------------------------------ whole run
     def run(self, frame_source, depth_source, block_source=None):
         import time
         t0 = time.perf_counter()
         rec = self.track_shard(frame_source, depth_source, block_source)
-        self.ctx.synchronize()
         t1 = time.perf_counter()
         T_rel, traj = self.gather(rec)
-        kf_tab = self.gather_keyframes(rec)
+        self.gather_keyframes()
         t2 = time.perf_counter()
-        windows, built = self.ba_round(kf_tab, traj)
+        windows, dims = self.ba_round(T_rel)
         t3 = time.perf_counter()
         self.timing = {"track_shard": (t1 - t0) * 1e3, "gather": (t2 - t1) * 1e3, "ba_round": (t3 - t2) * 1e3}
         self.timing.update({"ba_" + k: v for k, v in getattr(self, "ba_timing", {}).items()})
         kf_pose = {}
-        for w in windows:
+        for w in windows:                       # the windows live in the gauge of their anchor: world pose = T(anchor -> kf) * T(world -> anchor)
             for k, f in enumerate(w["kfs"]):
-                kf_pose[f] = se3_exp_g2o(w["poses"][k])
-        return dict(records=rec, T_rel=T_rel, trajectory=traj, windows=windows, keyframe_pose=kf_pose, built=built)
+                kf_pose[f] = se3_mul(se3_exp_g2o(w["poses"][k]), traj[w["kfs"][0]])
+        return dict(records=rec, T_rel=T_rel, trajectory=traj, windows=windows, keyframe_pose=kf_pose, built=dims)
+
+
+def build_window_host(kf_tab, kfs, T_rel, fx, fy, cx, cy, max_points, match_sets):
+    """Host restatement of what ygz_hip_ba_build_windows assembles for one window (the tests compare the device-built graph with it):
+    kf_tab[f] = dict(px, level, desc, depth) of keyframe f, match_sets(descs, pair_q, pair_t) = HipContext.match_sets.  Returns the
+    graph of ba::LocalBAG2O in the anchor's gauge: poses (g2o order), points, edges sorted by (point, keyframe)."""
+    A = kf_tab[kfs[0]]
+    sel = np.nonzero(A["depth"] > 0)[0][:max_points]
+    z = A["depth"][sel]
+    pc = np.stack([(A["px"][sel, 0] - cx) * z / fx, (A["px"][sel, 1] - cy) * z / fy, z], axis=1)     # Pixel2Camera (Camera.h:56-62)
+    ep, el, obs = [np.zeros(len(sel), np.int32)], [np.arange(len(sel), dtype=np.int32)], [A["px"][sel]]
+    others = [(j, f) for j, f in enumerate(kfs[1:], start=1)]
+    if others and len(sel):
+        res = match_sets([A["desc"][sel]] + [kf_tab[f]["desc"] for _, f in others], [0] * len(others), list(range(1, len(others) + 1)))
+        for (j, f), r in zip(others, res):
+            g = np.nonzero(r["good"])[0]
+            ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(kf_tab[f]["px"][r["idx"][g]])
+    ep, el, obs = np.concatenate(ep), np.concatenate(el), np.concatenate(obs)
+    n_obs = np.bincount(el, minlength=len(sel))
+    keep_pt = n_obs >= 2                                   # a point seen only by the fixed anchor constrains nothing
+    remap = -np.ones(len(sel), np.int64); remap[keep_pt] = np.arange(int(keep_pt.sum()))
+    ke = keep_pt[el]
+    ep, el, obs = ep[ke], remap[el[ke]].astype(np.int32), obs[ke]
+    order = np.lexsort((ep, el))
+    T = I7.copy()
+    poses = [se3_log_g2o(T)]
+    for f in range(kfs[0] + 1, kfs[-1] + 1):
+        T = se3_mul(T_rel[f], T)
+        if f in kfs:
+            poses.append(se3_log_g2o(T))
+    fixed = np.zeros(len(kfs), np.uint8); fixed[0] = 1
+    return dict(kfs=list(kfs), poses=np.stack(poses), fixed=fixed, points=pc[keep_pt], edge_pose=ep[order], edge_point=el[order], obs=obs[order],
+                anchor_feature=sel[keep_pt])
