@@ -340,7 +340,8 @@ def cpu_offline_baseline(bgr, dimg, vo, budget_s=12.0):
             "sample": "%d consecutive %dx%d frame pairs of the sequence (oracle/, gcc -O3, single thread; the BA round is not included)" % (n, OFF_W, OFF_H)}
 
 
-def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=1, chunk=128, probe="k_klt", one_dev=False, cpu_baseline_s=0.0):
+def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=1, chunk=128, probe="k_klt", one_dev=False, cpu_baseline_s=0.0,
+                overlap=False, lm_group=8, lanes=3):
     """BASELINE configs[4] on the frames offline_render produced: one sequence sharded over the ranks (strong scaling).  A step = one
     complete offline run; the timed region holds every upload, kernel, result copy, collective and the BA round.  Returns the result
     dict on rank 0 (None elsewhere)."""
@@ -352,7 +353,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     pin = _lib.PinnedArray((len(need), H_, W_) if gray_in else (len(need), H_, W_, 3), np.uint8)
     dpin = _lib.PinnedArray((len(need), H_ // DEPTH_DIV, W_ // DEPTH_DIV), np.uint16)
     vo = offline.OfflineVO(W_, H_, n_frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
-                           exchange_on_device=not one_dev, depth_div=DEPTH_DIV, depth_dtype=np.uint16, depth_scale=DEPTH_SCALE)
+                           exchange_on_device=not one_dev, depth_div=DEPTH_DIV, depth_dtype=np.uint16, depth_scale=DEPTH_SCALE, overlap=overlap, lm_group=lm_group, lanes=lanes)
     for k, (i, b, d) in enumerate(R["rendered"]):
         assert i == need[k]
         if gray_in:
@@ -389,6 +390,14 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     barrier()
     dt = time.perf_counter() - t0
     probe_ms, probe_n = vo.ctx.probe_end()
+    if vo.trace is not None and rank == 0:                   # YGZ_OFFLINE_TRACE=1: where the host thread spent the timed region
+        tr = [e for e in vo.trace if e[1] >= t0]
+        agg = {}
+        for name, a_, b_ in tr:
+            g = agg.setdefault(name, [0, 0.0, 0.0]); g[0] += 1; g[1] += b_ - a_; g[2] = max(g[2], b_ - a_)
+        print("[offline trace] host time inside ABI calls %.1f ms of %.1f ms" % (sum(v[1] for v in agg.values()) * 1e3, dt * 1e3), file=sys.stderr)
+        for name, (cnt, tot, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
+            print("[offline trace] %-36s calls %4d total %8.2f ms max %7.2f ms" % (name, cnt, tot * 1e3, mx * 1e3), file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -416,7 +425,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
                                       "(+ a quarter-resolution uint16 depth image) and D2H of the results inside the timed region"
                                       % (n_frames, W_, H_),
                           "frames_total": n_frames, "frames_per_gpu": count, "chunk": chunk, "keypoints_per_frame": n_kp,
-                          "parallelism": "frames sharded x%d" % world, "frames_cross_pcie_as": upload,
+                          "parallelism": "frames sharded x%d" % world, "frames_cross_pcie_as": upload, "lanes": len(vo.lanes), "windows_per_lm_launch": lm_group,
                           "h2d_bytes_per_frame": frame_bytes, "h2d_GBps": frame_bytes * count * steps / dt / 1e9},
                "phases_ms": med, "render_s_outside_timed_region": R["render_s"],
                "result_check": {"pairs": len(pairs), "mean_pose_only_inliers": float(np.mean([r["po_inliers"] for r in pairs])),
@@ -450,7 +459,7 @@ def main_offline(a):
         dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world)
     chunk = a.batch if a.batch != 512 else 128
     out = offline_run(R, rank, world, local_rank, dist, upload=a.upload, steps=a.steps, warmup=a.warmup, chunk=chunk, probe=a.probe, one_dev=one_dev,
-                      cpu_baseline_s=0.0 if a.no_cpu_baseline else 12.0)
+                      cpu_baseline_s=0.0 if a.no_cpu_baseline else 12.0, overlap=a.lane_overlap, lm_group=a.lm_group, lanes=a.lanes)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -478,6 +487,10 @@ def main():
                          "the ranks (strong scaling) through ygz_slam_amd/offline.py, uploads, result copies, collectives and the BA round included")
     ap.add_argument("--frames", type=int, default=1024, help="offline mode: length of the sequence (all ranks together)")
     ap.add_argument("--offline-frames", type=int, default=1024, help="length of the configs[4] sequence measured for the `offline` block of the default line")
+    ap.add_argument("--lane-overlap", action="store_true", help="offline mode: side streams inside each tracking lane (measured slower: the two lanes "
+                                                               "and the BA context already fill the GPU and the hardware queues)")
+    ap.add_argument("--lanes", type=int, default=3, help="offline mode: tracking contexts that take the chunks in turn")
+    ap.add_argument("--lm-group", type=int, default=8, help="offline mode: BA windows per resident-LM launch")
     ap.add_argument("--no-extras", action="store_true", help="default mode: skip the `offline` and `stream` blocks (the timed region is the same either way)")
     ap.add_argument("--upload", default="bgr", choices=["bgr", "gray"], help="stream mode: what crosses PCIe per frame (3 or 1 byte per pixel)")
     ap.add_argument("--size", default=None, choices=["vga", "720p"],

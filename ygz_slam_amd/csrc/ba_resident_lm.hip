@@ -222,7 +222,9 @@ struct LmTeamArgs {
     const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
     unsigned char *scratch; size_t stride;     // per window: bar[4] u32, behind-camera counts [8] i32 | xpub | part | Sp | private pose state of the G members
     int Kmax;
+    long long *dbg;                            // YGZ_LM_DEBUG: [16] wall-clock ticks (10 ns) per phase of member 0 of the first window
 };
+#define LM_TICK(k) do { if (A.dbg && blockIdx.x == 0 && tid == 0) { const long long tn_ = wall_clock64(); s_t[k] += tn_ - t_prev; t_prev = tn_; } } while (0)
 
 __device__ __forceinline__ double tl_ld(const double *p)
 { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
@@ -262,11 +264,14 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     __shared__ double red27[LM_WAVES][28];
     __shared__ double red[LM_WAVES];
     __shared__ int s_fail, s_ok;
+    __shared__ long long s_t[16];
     const int G = A.G;
     const int xslot = blockIdx.x & 7, j = blockIdx.x >> 3, g = j % G, w = (j / G) * 8 + xslot;
     if (w >= A.n_windows) return;
     BaDev B = A.wins[w];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    long long t_prev = 0;
+    if (A.dbg && blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 16; ++i) s_t[i] = 0; t_prev = wall_clock64(); }
     const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf, Q = B.Q, npairs = Kf * (Kf + 1) / 2;
     unsigned char *scr = A.scratch + (size_t)w * A.stride;
     unsigned *bar = reinterpret_cast<unsigned *>(scr);
@@ -321,7 +326,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 }
             }
         }
+        LM_TICK(0);
         if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+        LM_TICK(1);
         {   // every member adds the parts in part order: identical sH, chi2 (and lambda at the first iteration)
             for (int i = tid; i < 27 * Kf; i += LM_THREADS) {
                 double t = 0.0;
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             }
         }
         double rho = 0.0; int qmax = 0;
+        LM_TICK(2);
         do {
             // ---- push(), 1. Dinv, Y = Hpl Dinv for the member's parts
             for (int i = tid; i < 6 * K; i += LM_THREADS) my_bk[i] = my_poses[i];
@@ -377,7 +385,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             if (bad) s_fail = 1;
             __syncthreads();
             if (tid == 0) for (int v = g; v < LM_V; v += G) tl_st(part + (size_t)v * LM_PARTW + 2, s_fail ? 1.0 : 0.0);
+            LM_TICK(3);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            LM_TICK(4);
             // ---- 2. one wavefront per (pose pair, part): that part's share of sum_l Y_a(l) W_b(l)^T and sum_l Y_a(l) b_l
             for (int task = g * LM_WAVES + wv; task < npairs * LM_V; task += G * LM_WAVES) {
                 const int pr = task / LM_V, v = task - pr * LM_V;
@@ -408,7 +418,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     for (int i = 0; i < 6; ++i) { const double t = lm_wave_sum(accb[i]); if (lane == 0) tl_st(o + 36 + i, t); }
                 }
             }
+            LM_TICK(5);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            LM_TICK(6);
             // ---- 3. member 0: S = blockdiag(Hpp + lambda I) - sum of the parts (in part order), Cholesky, substitutions, publish x_p
             if (g == 0) {
                 for (int i = tid; i < n * n; i += LM_THREADS) {
@@ -429,6 +441,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 }
                 if (tid == 0) { double f = 0.0; for (int v = 0; v < LM_V; ++v) f += tl_ld(part + (size_t)v * LM_PARTW + 2); s_fail = f != 0.0; }
                 __syncthreads();
+                LM_TICK(7);
                 for (int jc = 0; jc < n; ++jc) {
                     if (tid == 0) { const double d = S[jc * n + jc]; if (!(d > 0) || !isfinite(d)) s_fail = 1; S[jc * n + jc] = sqrt(d > 0 ? d : 1.0); }
                     __syncthreads();
@@ -442,6 +455,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     }
                     __syncthreads();
                 }
+                LM_TICK(8);
                 if (wv == 0) {
                     for (int k = 0; k < n; ++k) {
                         if (lane == 0) bs[k] = bs[k] / S[k * n + k];
@@ -461,7 +475,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     if (lane == 0) tl_st(xpub + LM_MAXN, s_fail ? 1.0 : 0.0);
                 }
             }
+            LM_TICK(9);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            LM_TICK(10);
             for (int i = tid; i < n; i += LM_THREADS) xp[i] = tl_ld(xpub + i);
             const bool ok2 = tl_ld(xpub + LM_MAXN) == 0.0;
             __syncthreads();
@@ -508,7 +524,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 chi = lm_block_sum(chi, red);
                 if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW + 3, scale); tl_st(part + (size_t)v * LM_PARTW + 4, chi); }
             }
+            LM_TICK(11);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            LM_TICK(12);
             double scale = 0.0, tempChi = DBL_MAX;
             if (ok2) {
                 tempChi = 0.0;
@@ -535,10 +553,12 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 if (!isfinite(lambda)) break;
             }
             qmax++;
+            LM_TICK(13);
         } while (rho < 0 && qmax < 10);
         ++iterations;
         if (qmax == 10 || rho == 0 || !isfinite(lambda)) break;
     }
+    if (A.dbg && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 16; ++i) A.dbg[i] = s_t[i];
     if (g == 0) {
         __syncthreads();
         for (int i = tid; i < 6 * K; i += LM_THREADS) out_poses[i] = my_poses[i];
@@ -583,6 +603,9 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     LmTeamArgs A;
     A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
     A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax;
+    A.dbg = nullptr;
+    static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
+    if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
     YgzAuxScope aux(ctx, 1);
     YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, 48, (size_t)n_windows, ctx->stream));         // barrier counters, abort flags
     YGZ_HIPCHK(ctx, hipMemsetAsync(d_scr, 0xFF, stats_bytes, ctx->stream));                               // iterations = -1 until a team finishes
@@ -590,6 +613,17 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
         YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->ba[i]->lm_out, 0xFE, sizeof(ygz_ba_stats), ctx->stream));      // (0xFF = never run, ba_carve)
     YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
+    if (A.dbg) {
+        long long h[16];
+        static const char *const nm[14] = { "linearise + pose sums", "barrier", "combine parts", "Dinv, Y = Hpl Dinv", "barrier", "Schur sweep", "barrier",
+                                            "assemble S", "Cholesky", "substitutions", "barrier", "update + trial chi2", "barrier", "accept / reject" };
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        long long tot = 0; for (int i = 0; i < 14; ++i) tot += h[i];
+        fprintf(stderr, "[lm-debug] %d windows, team of %d: member 0 of window 0, %.1f us in all:", n_windows, G, tot * 0.01);
+        for (int i = 0; i < 14; ++i) fprintf(stderr, " %s %.1f;", nm[i], h[i] * 0.01);
+        fprintf(stderr, "\n");
+    }
     if (stats) {
         // a team whose member never reached a barrier (not co-resident within the spin bound) leaves without writing its record: the
         // caller gets YGZ_E_HIP whether it asked for statistics here or reads them later with ygz_hip_ba_get_stats

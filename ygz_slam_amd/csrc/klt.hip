@@ -523,7 +523,12 @@ int ygz_klt_prepare_early(ygz_hip_ctx *ctx)
     ygz_klt_params prm;
     ygz_hip_default_klt_params(&prm);
     int rc = launch_klt_impl(ctx, ctx->n_pairs, &prm, true);
-    if (rc == YGZ_OK) ctx->klt_prep_valid = true;
+    if (rc == YGZ_OK) {
+        // the levels that were prepared (default tracker): a later call with other parameters may need more
+        int max_level = prm.max_level, sw = ctx->lw[0], sh = ctx->lh[0];
+        for (int level = 0; level <= prm.max_level; ++level) { sw = (sw + 1) / 2; sh = (sh + 1) / 2; if (sw <= prm.win || sh <= prm.win) { max_level = level; break; } }
+        ctx->klt_prep_valid = true; ctx->klt_prep_levels = max_level + 1;
+    }
     return rc;
 }
 static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm, bool prep_only)
@@ -552,7 +557,7 @@ static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *
         }
         if (!ctx->klt_pad[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_pad[L], (size_t)ctx->prm.max_frames * psz + 64));
         A.pad[L] = ctx->klt_pad[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = w; A.h[L] = h;
-        if (ctx->klt_prep_valid) continue;                       // the working images of this pair table were built ahead (ygz_klt_prepare_early)
+        if (ctx->klt_prep_valid && L < ctx->klt_prep_levels) continue;   // this level's working images were built ahead (ygz_klt_prepare_early)
         YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(ygz_div_up(pw, 16) * ph, 256), 1, ygz_round_up8(ctx->n_klt_slots)), dim3(256),
                    ctx->lvl[L], ctx->klt_pad[L], ctx->klt_slots, w, h, ctx->n_klt_slots);
         YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(ygz_div_up(w, 4) * ygz_div_up(h, 4), 256), 1, ygz_round_up8(ctx->n_klt_refs)), dim3(256),

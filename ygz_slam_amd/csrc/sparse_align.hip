@@ -539,19 +539,27 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.dbg = nullptr;
     if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
     const char *env_t = getenv("YGZ_SA_THREADS");
-    const int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
+    int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
+    // the deferred H update keeps one bit per feature of a lane (chg_mask / add_mask, 32 bits): a problem may hold up to 32 x lanes features
+    if (ctx->cells > 32 * 256) threads = 512;
+    if (ctx->cells > 32 * 512) return YGZ_E_CAPACITY;
     // per-iteration scratch of the first lcap features in LDS: 4 x 16 (r2) + 16 (fmap) + 8 (pmap) + 4 (pre) bytes each + chunk totals
     // (a 512-lane problem owns its CU -- nothing else fits beside 512 x 256 registers -- so it may take nearly all of the LDS)
     static const int lcap_env = [] { const char *e = getenv("YGZ_SA_LDS"); return e ? atoi(e) : -1; }();
     const int lcap_want = lcap_env >= 0 ? lcap_env : (threads == 512 ? 1600 : 1024);
     A.lcap = ((lcap_want < ctx->cells ? lcap_want : ctx->cells) + 63) / 64 * 64;
     if (A.lcap < 0) A.lcap = 0;
+    {   // dynamic + static LDS must fit the device's per-block limit (static: < 3 KB, see -Rpass-analysis=kernel-resource-usage)
+        int lim = 64 * 1024;
+        (void)hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
+        const int room = (lim - 4096 - 16) / 96;                                   // 92 bytes per feature + 4 per 64 features
+        if (A.lcap > room) A.lcap = room > 0 ? room / 64 * 64 : 0;
+    }
     const size_t dyn = (size_t)A.lcap * 92 + (size_t)(A.lcap / 64 + 1) * 4 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+    if (!ctx->sa_attr_set) {                                                       // function attributes are per device: once per context
+        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        ctx->sa_attr_set = true;
     }
     if (threads == 512) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align<512>, dim3(n_pairs), dim3(512), dyn, A);
     else YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align<256>, dim3(n_pairs), dim3(256), dyn, A);

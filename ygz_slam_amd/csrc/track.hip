@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_track_load(LoadArgs A)
 struct AdoptArgs {
     const int32_t *trk_n; int cells, w, h;
     double *pair_T; const double *sa_out;
-    const double *trk_px, *trk_depth; double *fdp_px; uint8_t *fdp_cand;
+    const double *trk_px, *trk_depth; const uint8_t *trk_has_mp; double *fdp_px; uint8_t *fdp_cand;
     double fx, fy, cx, cy;
 };
 __global__ __launch_bounds__(256) void k_track_adopt_pose(AdoptArgs A)
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_track_adopt_pose(AdoptArgs A)
     const double x = A.trk_px[2 * d], y = A.trk_px[2 * d + 1], dep = A.trk_depth[d];
     bool cand = false;
     double ox = x, oy = y;
-    if (dep > 0) {
+    if (dep > 0 && A.trk_has_mp[d]) {                 // candidates come from map points (LocalMapping.cpp:52-56: the loop runs over the local map's points that are not _bad)
         Se3 Tr, Tc, Tri;
         for (int k = 0; k < 4; ++k) { Tr.q[k] = A.pair_T[14 * (size_t)p + k]; Tc.q[k] = A.sa_out[16 * (size_t)p + k]; }
         for (int k = 0; k < 3; ++k) { Tr.t[k] = A.pair_T[14 * (size_t)p + 4 + k]; Tc.t[k] = A.sa_out[16 * (size_t)p + 4 + k]; }
@@ -265,7 +265,7 @@ int ygz_hip_track_adopt_pose(ygz_hip_ctx *ctx)
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     AdoptArgs A;
     A.trk_n = ctx->trk_n; A.cells = ctx->cells; A.w = ctx->lw[0]; A.h = ctx->lh[0];
-    A.pair_T = ctx->pair_T; A.sa_out = ctx->sa_out; A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth;
+    A.pair_T = ctx->pair_T; A.sa_out = ctx->sa_out; A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
     A.fdp_px = ctx->fdp_px; A.fdp_cand = ctx->fdp_cand;
     A.fx = ctx->prm.fx; A.fy = ctx->prm.fy; A.cx = ctx->prm.cx; A.cy = ctx->prm.cy;
     YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_track_adopt_pose, dim3(ygz_div_up(ctx->cells, 256), ctx->n_pairs), dim3(256), A);

@@ -27,8 +27,9 @@ as the chunk holding its last keyframe has been enqueued -- beside the uploads a
 sharded run reproduces the unsharded one bit for bit.
 
 The run is driven from ONE host thread: every call on the tracking path is asynchronous (page-locked buffers, staged tables), two
-contexts ("lanes") take alternate chunks so that the H2D copy of one chunk runs under the kernels of the other, a third context
-owns the keyframe store and the BA windows; the host blocks only when it re-uses a lane and reads that lane's 32-double-per-pair
+or three contexts ("lanes") take the chunks in turn so that the H2D copy of one chunk runs under the kernels of another (three: the
+copy of the next chunk is already queued when a copy ends, PCIe never waits for the host), one more context owns the keyframe
+store and the BA windows; the host blocks only when it re-uses a lane and reads that lane's 32-double-per-pair
 summary.
 
 This module is host logic over the C ABI (ygz_slam_amd._lib); it never touches oracle/.
@@ -199,6 +200,27 @@ def depth_at(dimg, px, w, h, scale=1.0 / 5000.0):
     return np.where(d > 0, d, 0.0)
 
 
+class _Traced:
+    """debug aid (YGZ_OFFLINE_TRACE=1): times every ABI call of a context on the host -- a call that blocks shows up here"""
+
+    def __init__(self, obj, log, tag):
+        object.__setattr__(self, "_o", obj); object.__setattr__(self, "_log", log); object.__setattr__(self, "_tag", tag)
+
+    def __getattr__(self, name):
+        a = getattr(self._o, name)
+        if not callable(a):
+            return a
+        import time
+
+        def call(*args, **kw):
+            args = tuple(x._o if isinstance(x, _Traced) else x for x in args)
+            t0 = time.perf_counter()
+            r = a(*args, **kw)
+            self._log.append((self._tag + "." + name, t0, time.perf_counter()))
+            return r
+        return call
+
+
 class OfflineVO:
     """One rank of the offline run.  frame_source(i) -> BGR uint8 [h, w, 3] (or gray [h, w]); depth_source(i) -> depth map [h, w]
     (metres).  block_source(frames) -> (frames [n, h, w, 3] or [n, h, w] uint8, depth images [n, dh, dw]) replaces the per-frame
@@ -207,8 +229,8 @@ class OfflineVO:
     metres or, for uint16, round(depth / depth_scale) (TUM RGB-D: depth_scale = 1 / 5000)."""
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
-                 max_points=2000, ba_iterations=20, overlap=True, process_group=None, exchange_on_device=True, keep=False, lanes=2,
-                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True):
+                 max_points=2000, ba_iterations=20, overlap=False, process_group=None, exchange_on_device=True, keep=False, lanes=3,
+                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=4):
         from . import _lib
         self.lib = _lib
         self.w, self.h, self.levels = width, height, levels
@@ -217,11 +239,11 @@ class OfflineVO:
         self.max_points, self.ba_iterations = max_points, ba_iterations
         self.overlap, self.pg, self.exchange_on_device, self.keep = overlap, process_group, exchange_on_device, keep
         self.depth_div, self.depth_dtype, self.depth_scale = depth_div, np.dtype(depth_dtype), depth_scale
-        self.pipeline_ba = pipeline_ba
+        self.pipeline_ba, self.lm_group = pipeline_ba, max(1, lm_group)
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
-        n_lanes = 2 if (lanes > 1 and self.count > chunk) else 1
+        n_lanes = max(1, min(lanes, -(-self.count // chunk)))                     # never more lanes than chunks
         self.lanes = []
         for _ in range(n_lanes):
             c = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
@@ -249,6 +271,13 @@ class OfflineVO:
             self.ba.kf_store_create(self.n_kf, n_total, self.build_group)
         if self.mine:
             self.ba.ba_reserve_windows(0, len(self.mine), window_kfs, max_points)
+        self.trace = None
+        import os
+        if os.environ.get("YGZ_OFFLINE_TRACE") == "1":
+            self.trace = []
+            self.lanes = [_Traced(c, self.trace, "lane%d" % i) for i, c in enumerate(self.lanes)]
+            self.ctx = self.lanes[0]
+            self.ba = _Traced(self.ba, self.trace, "ba")
         self.S = 6 * window_kfs + 3 * max_points + 8                              # one window state row: poses | points | K P E its trials chi2_0 chi2 lambda
         cap = max(n_slots, 2)
         self._pin = [dict(sum=_lib.PinnedArray((cap, _lib.SUMMARY_FIELDS), np.float64), cnt=_lib.PinnedArray((cap,), np.int32)) for _ in self.lanes]
@@ -278,7 +307,7 @@ class OfflineVO:
         first, last = self.start, self.start + self.count
         chunks = [(c0, min(c0 + self.chunk, last)) for c0 in range(first, last, self.chunk)]
         pending = [None] * len(self.lanes)
-        self._ba_done = set()
+        self._ba_done, self._ba_built = set(), []
         for ci, (c0, c1) in enumerate(chunks):
             li = ci % len(self.lanes)
             if pending[li] is not None:
@@ -287,7 +316,15 @@ class OfflineVO:
             if self.keep:                                      # parity runs read everything back before the lane moves on
                 self._collect(li, pending[li], rec); pending[li] = None
             if self.pipeline_ba:
-                self._ba_launch([i for i in self.local if i not in self._ba_done and self.wins[i][-1] < c1])
+                # windows whose keyframes are all in: built at once (a matcher launch and two small kernels); the resident LM is a latency-
+                # bound kernel that takes as long for two windows as for eight, so it is launched per lm_group windows (and for the rest
+                # after the last chunk): its launches then fit beside the tracking of the following chunks instead of queueing up
+                new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and self.wins[i][-1] < c1]
+                self._ba_launch(new, optimize=False)
+                self._ba_built += new
+                if len(self._ba_built) >= self.lm_group or ci == len(chunks) - 1:
+                    self._ba_optimize(self._ba_built)
+                    self._ba_built = []
         for li in range(len(self.lanes)):
             if pending[li] is not None:
                 self._collect(li, pending[li], rec)
@@ -404,8 +441,15 @@ class OfflineVO:
         return torch.device("cuda", self.device)
 
     # ------------------------------------------------------------------ phase 3: BA round
+    def _ba_optimize(self, wis):
+        """the resident LM on windows that are built (consecutive owned windows), asynchronous"""
+        if wis:
+            assert wis == list(range(wis[0], wis[-1] + 1))
+            self.ba.ba_optimize_resident(self.mine.index(wis[0]), len(wis), self.ba_iterations, want_stats=False)
+            self._ba_done.update(wis)
+
     def _ba_launch(self, wis, optimize=True):
-        """build + optimise the given (owned) windows on the BA context, behind everything the lanes have enqueued so far"""
+        """build (+ optimise) the given (owned) windows on the BA context, behind everything the lanes have enqueued so far"""
         if not wis:
             return
         for c in self.lanes:
@@ -423,7 +467,8 @@ class OfflineVO:
             self.ba.ba_build_windows(slot0, kfi, kff, [len(self.wins[wi]) for wi in grp])
             if optimize:
                 self.ba.ba_optimize_resident(slot0, len(grp), self.ba_iterations, want_stats=False)
-        self._ba_done.update(wis)
+        if optimize:
+            self._ba_done.update(wis)
 
     def ba_round(self, T_rel):
         """the windows this rank owns that are not optimised yet (those straddling a shard boundary; all of them without
