@@ -528,7 +528,10 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    # one HIP stream shared by torch (RCCL broadcast) and the ABI context, so the exchange is ordered with the kernels
+    # Step mode shards by frame: every rank runs the same step on its own resident batch -- replicas, no data-path collective (SURVEY 8e:
+    # frames are independent units; the BA windows of the step are per-frame copies of one 10 x 2000 window).  The exchange the path does
+    # have -- refined BA-window states from their owners to every rank, trajectory all-gather -- belongs to the offline run and is
+    # measured there (the `offline` block of this line, `--mode offline`).
     # --double-buffer: two resident batches per GPU, each behind its own ABI context and streams: step k runs on batch k % 2,
     # so the next step's extraction does not wait for the latency-bound tail (sparse alignment, BA) of this one.  Every step is
     # still one full pass of the hot path over one batch of a.batch frames.
@@ -541,8 +544,6 @@ def main():
         if a.mode == "stream":
             q.setup_stream(a.upload)
     pipe = pipes[0]
-    n_pts = pipe.ba["points"].size
-    map_buf = torch.from_numpy(np.concatenate([pipe.ba["points"].ravel(), pipe.ba["poses"].ravel()])).cuda()
     step_no = [0]
 
     def barrier():
@@ -555,10 +556,6 @@ def main():
     def one_step():
         q = pipes[step_no[0] % n_buf]
         step_no[0] += 1
-        if dist is not None:                 # the path's only exchange: map points + keyframe poses of the shared BA window
-            with torch.cuda.stream(streams[pipes.index(q)]):     # the stream the batch's kernels are ordered on
-                dist.broadcast(map_buf, src=0)                   # RCCL over xGMI, ~50 KB, once per BA round
-            q.ctx.ba_set_state_device(0, map_buf.data_ptr() + 8 * n_pts, map_buf.data_ptr())
         if a.mode == "stream":
             q.stream_step()
         else:
@@ -622,7 +619,7 @@ def main():
                "config": {"workload": "2x%dx%d-pair pipeline: ORB extract + 256-bit Hamming BF cross-check + KLT 21x21x5 + "
                                       "FindDirectProjection + SparseImgAlign + local-BA 10x2000 linearise, per frame" % (W, H),
                           "frames_per_gpu_per_step": a.batch, "resident_batches_per_gpu": n_buf, "keypoints_per_frame": n_kp,
-                          "parallelism": "frames sharded x%d" % world},
+                          "parallelism": "frames sharded x%d (replicas: no data-path collective in this mode; see the `offline` block)" % world},
                "stage_ms_per_batch": stages, "roofline": roofline, "roofline_valu": roofline_valu}
         if a.mode == "stream":
             res["metric"] += ", frames streamed from host memory"
@@ -674,30 +671,36 @@ def main():
         dist.destroy_process_group()
 
 
-def stream_block(pipe, a, local_rank, rank, steps=8, warmup=2):
+def stream_block(pipe, a, local_rank, rank, steps=9, warmup=3):
     """the transfer-inclusive mode (bench.py --mode stream) measured after the default timed region: every step uploads its batch
     from page-locked memory (BGR, then gray), runs the same hot path + good-match filter and copies all keypoint fields and the
-    per-pair summary back; two batches in flight"""
+    per-pair summary back; three batches in flight, each behind its own context (the upload of the next batch is queued before the
+    current one ends, so PCIe never waits for the host), the stages of a batch on one stream (side streams of three contexts would
+    share the hardware queues)"""
     import torch
-    st = torch.cuda.Stream()
-    second = Pipeline(a.batch, local_rank, rank, stream=st.cuda_stream, overlap=not a.no_overlap,
-                      inputs=(pipe.frames, pipe.poses, pipe.depths, pipe.ba))
-    second.setup()
-    pipes = [pipe, second]
-    out = {"steps": steps, "warmup": warmup, "frames_per_step": a.batch,
+    n_buf = int(os.environ.get("YGZ_STREAM_BUFS", "3"))
+    side = os.environ.get("YGZ_STREAM_OVERLAP", "0") == "1"
+    streams = [torch.cuda.Stream() for _ in range(n_buf - 1)]
+    pipes = [pipe]
+    for st in streams:
+        q = Pipeline(a.batch, local_rank, rank, stream=st.cuda_stream, overlap=side, inputs=(pipe.frames, pipe.poses, pipe.depths, pipe.ba))
+        q.setup()
+        pipes.append(q)
+    pipe.ctx.set_overlap(side)
+    out = {"steps": steps, "warmup": warmup, "frames_per_step": a.batch, "batches_in_flight": n_buf,
            "note": "every step: H2D of the batch from page-locked memory, the 8-call hot path + good-match filter, D2H of all keypoint fields "
-                   "and the per-pair summary, host reads them; two batches in flight"}
+                   "and the per-pair summary, host reads them"}
     for upload in ("bgr", "gray"):
         for q in pipes:
             q.setup_stream(upload)
         k = 0
         for _ in range(warmup):
-            pipes[k % 2].stream_step(); k += 1
+            pipes[k % n_buf].stream_step(); k += 1
         for q in pipes:
             q.ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            pipes[k % 2].stream_step(); k += 1
+            pipes[k % n_buf].stream_step(); k += 1
         for q in pipes:
             q.ctx.synchronize()
             if q.in_flight:
@@ -706,7 +709,9 @@ def stream_block(pipe, a, local_rank, rank, steps=8, warmup=2):
         out[upload] = {"value": a.batch * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
                        "h2d_bytes_per_step": pipe.h2d_bytes, "d2h_bytes_per_step": pipe.d2h_bytes,
                        "h2d_GBps": pipe.h2d_bytes / (dt / steps) / 1e9, "d2h_GBps": pipe.d2h_bytes / (dt / steps) / 1e9}
-    second.ctx.close()
+    for q in pipes[1:]:
+        q.ctx.close()
+    pipe.ctx.set_overlap(not a.no_overlap)
     return out
 
 

@@ -1,8 +1,10 @@
 // ygz::ba -- local bundle adjustment with the surface of include/ygz/Algorithm/BA.h:23-66.
 // LocalBAG2O reproduces ba::LocalBAG2O (src/Algorithm/BA.cpp:386-543): graph build, Levenberg-Marquardt with
 // Schur complement (g2o BlockSolver_6_3 restated), 20 iterations, Huber delta 5.991, chi2 > 5.991 -> Feature::_bad.
-// Every linearisation (residuals, Jacobians, Hpp/Hll/Hpl/b blocks, robust chi2) runs on the GPU; the reduced
-// 6K x 6K system is solved on the host.
+// The whole loop -- linearisations (residuals, Jacobians, Hpp/Hll/Hpl/b blocks, robust chi2), Schur complement, Cholesky of the
+// reduced 6K x 6K system, update and lambda policy -- runs on the GPU (ygz_hip_ba_optimize -> k_ba_lm_team) for windows of up to
+// 14 free poses without repeated (point, pose) edges; other windows keep the linearisations on the GPU and solve the reduced system
+// on the host.
 // The ceres-based entry points (BA.cpp:11-384) are the same edge stack in the ceres parametrisation (pose = [t; angle-axis],
 // normalised observations, additive update; C ABI formulation 2) under ceres' default trust-region Levenberg-Marquardt
 // (ygz_hip_ba_solve_ceres); OptimizeCurrentPoseOnly -- the per-frame call of LocalMapping -- runs all four rounds in one

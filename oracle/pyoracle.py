@@ -133,7 +133,9 @@ def _f64(a):
 class Oracle:
     """Thin numpy front-end; every method names the yo_* function it calls."""
 
-    def __init__(self, variant=""):
+    def __init__(self, variant=None):
+        if variant is None:
+            variant = os.environ.get("YGZ_ORACLE_VARIANT", "")      # e.g. "asan": the sanitizer run of the test suite
         self.lib = C.CDLL(build(variant=variant))
         L = self.lib
         L.yo_shi_tomasi.restype = C.c_float
