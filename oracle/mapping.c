@@ -1,5 +1,6 @@
 /* ORACLE (test infrastructure) -- the map-building loops that follow the matcher.  See ygz_oracle.h. */
 #include "ygz_oracle.h"
+#include "../include/ygz_exp.h"
 #include <math.h>
 #include <string.h>
 
@@ -256,13 +257,18 @@ static double compute_tau(const yo_se3 *T_ref_cur, const double f[3], double z, 
     return z_plus - z;
 }
 
+/* expf [frozen spec of libm, like sqrtf]: the double exponential of include/ygz_exp.h (plain IEEE operations, the same sequence on the
+ * host and on the device) rounded once to float.  glibc's own expf is within 0.502 ulp of it; the device's native expf (1-2 ulp) is not,
+ * and one ulp of the pdf is amplified ~100 x by the cancellations of the Beta update below -- so both sides use this form. */
+static float yo_expf_cr(float x) { return (float)ygz_exp_nonpos((double)x); }
+
 /* DepthFilter::UpdateSeed, src/optimizer.cpp:683-708 (all float) */
 static void update_seed(float x, float tau2, float *a, float *b, float *mu, float z_range, float *sigma2)
 {
     const float norm_scale = sqrtf(*sigma2 + tau2);
     if (isnan(norm_scale)) return;
     float e_ = x - *mu; e_ *= -e_; e_ /= 2 * norm_scale * norm_scale;
-    const float pdf = expf(e_) / (norm_scale * sqrtf(2 * 3.14159265358979323846f));
+    const float pdf = yo_expf_cr(e_) / (norm_scale * sqrtf(2 * 3.14159265358979323846f));
     const float s2 = (float)(1. / (1. / *sigma2 + 1. / tau2));
     const float m = s2 * (*mu / *sigma2 + x / tau2);
     float C1 = *a / (*a + *b) * pdf;

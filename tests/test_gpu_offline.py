@@ -407,10 +407,11 @@ def test_create_map_points_triangulation_loop(hip_lib, oracle):
 
 def test_depth_filter_update_seeds(hip_lib, oracle):
     """the legacy SVO depth filter (DepthFilter::UpdateSeeds + FindEpipolarMatchDirect, src/optimizer.cpp:537-735, src/utils.cpp:330-661):
-    seeds of one keyframe updated by four later frames.  Every update runs on identical inputs on both sides (the oracle's carried
-    seed list): states, matched pixels and depths are equal (integer ZMSSD search and float Align2D chains are reproduced exactly); the
-    Bayesian parameters agree to 1e-5 relative (expf / acos differ in the last ulp between libm and the device -- which is also why
-    the carried state is the oracle's: one ulp in mu moves the next frame's search interval)."""
+    seeds of one keyframe updated by four later frames, TWO chains side by side: the oracle iterates its own carried seed list and the GPU
+    iterates ITS own (nothing is fed back from the oracle).  States, matched pixels and depths are equal (integer ZMSSD search and float
+    Align2D chains are reproduced exactly); the Bayesian parameters mu, sigma2, a, b agree to 1e-6 relative after every frame: every
+    operation of UpdateSeed is a correctly rounded IEEE float operation on both sides, including expf (the double exponential rounded
+    once, oracle/mapping.c::yo_expf_cr) and sqrtf."""
     seq = synth.Sequence(6, 640, 480, seed=4, step=0.45)
     ctx = make_ctx(hip_lib, max_frames=6)
     for s in range(6):
@@ -427,32 +428,34 @@ def test_depth_filter_update_seeds(hip_lib, oracle):
     seeds = dict(kp=k0["px"].astype(np.float32), octave=k0["level"], ref=np.zeros(n, np.int32), frame_id=np.zeros(n, np.uint64),
                  a=np.full(n, 10, np.float32), b=np.full(n, 10, np.float32), mu=mu0, z_range=z_range, sigma2=(z_range * z_range / 36).astype(np.float32))
     seeds["frame_id"][::97] = 9                                                   # seeds of a frame "from the future": int - unsigned wraps -> erased as too old
-    og = dict(seeds)
+    og, gg = dict(seeds), dict(seeds)                                             # the oracle's and the GPU's own carried lists
     seen = set()
     total_conv = 0
     err0 = np.abs(1.0 / og["mu"] - zt)
+    exact = []
     for f in (1, 2, 3, 5):
         o = oracle.depth_filter_update(lv[f], seq.poses[f], [lv[0]], [seq.poses[0]], og, batch_counter=1)
-        g = ctx.depth_filter_update(f, seq.poses[f], [0], [seq.poses[0]], og, batch_counter=1)
+        g = ctx.depth_filter_update(f, seq.poses[f], [0], [seq.poses[0]], gg, batch_counter=1)
         assert np.array_equal(g["state"], o["state"]), np.nonzero(g["state"] != o["state"])
         assert g["updated"] == o["updated"]
         assert np.array_equal(g["matched_px"], o["matched_px"]) and np.allclose(g["z"], o["z"], rtol=1e-12)
-        assert np.allclose(g["mu"], o["mu"], rtol=1e-5, atol=1e-9)
-        for k in ("a", "b", "sigma2"):                   # differences of nearly equal float terms (sigma2 = E[x^2] - mu^2; a, b from (e - f) / (f - e / f)):
-            assert np.allclose(g[k], o[k], rtol=2e-4, atol=1e-9), k      # one ulp of expf is amplified ~10-100 x
+        for k in ("mu", "a", "b", "sigma2"):
+            assert np.allclose(g[k], o[k], rtol=1e-6, atol=1e-12), (k, f, float(np.nanmax(np.abs(g[k] - o[k]) / np.maximum(np.abs(o[k]), 1e-30))))
+            exact.append(float(np.mean(g[k] == o[k])))
         m = o["state"] == 5
         assert np.allclose(g["pos_world"][m], o["pos_world"][m], rtol=1e-6)
         seen |= set(np.unique(o["state"]).tolist())
         total_conv += int(m.sum())
         keep = np.isin(o["state"], (0, 1, 2, 3))                                  # erased seeds leave the list
         for k in ("a", "b", "mu", "sigma2"):
-            og[k] = o[k][keep]
+            og[k] = o[k][keep]; gg[k] = g[k][keep]                                # each side keeps ITS values
         for k in ("kp", "octave", "ref", "frame_id", "z_range"):
-            og[k] = og[k][keep]
+            og[k] = og[k][keep]; gg[k] = gg[k][keep]
         zt, err0 = zt[keep], err0[keep]
+    assert min(exact) > 0.99, exact                                               # in fact (almost) every parameter is bit-equal
     assert {0, 3, 4}.issubset(seen), seen
     # the filter does its job: after four frames the depth of the surviving seeds is closer to the rendered depth than the prior was
-    assert np.median(np.abs(1.0 / og["mu"] - zt)) < 0.5 * np.median(err0)
+    assert np.median(np.abs(1.0 / gg["mu"] - zt)) < 0.5 * np.median(err0)
     e = ctx.depth_filter_update(1, seq.poses[1], [0], [seq.poses[0]], {k: v[:0] for k, v in og.items()}, batch_counter=1)
     assert e["updated"] == 0
     ctx.close()

@@ -10,6 +10,7 @@
 // conflict-free), gradients are re-derived from it instead of being stored; current-image
 // pixels come straight from HBM/L2 (9x9 window per iteration, one new column per step).
 #include "ygz_internal.h"
+#include "../../include/ygz_exp.h"
 #include "se3_dev.h"
 
 struct Cam { float fx, fy, cx, cy; };
@@ -197,6 +198,7 @@ struct FdpArgs {
     const double *trk_px, *trk_depth; const int32_t *trk_level;
     double *px_cur; int32_t *search_level; uint8_t *ok;      // [pairs][cells]
     const uint8_t *cand;                                     // [pairs][cells] or nullptr: 0 = not a candidate (FindCandidates dropped it)
+    int prio;                                                // != 0: raise the wavefronts' issue priority (gather-latency bound)
 };
 
 // the body shared by both Matcher::FindDirectProjection overloads (Matcher.cpp:356-417) from Pixel2Camera(px_ref, depth) on:
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(64) void k_find_direct_projection(FdpArgs A)
     __shared__ uint8_t pwb_all[100 * 64];
     __shared__ uint32_t stg_all[STG_DWORDS * 64];
     int bx, pair;
+    ygz_raise_prio(A.prio);
     if (!ygz_xcd_remap(A.n_pairs, bx, pair)) return;
     const int ii = bx * 64 + threadIdx.x;
     if (ii >= A.trk_n[pair]) return;
@@ -368,6 +371,7 @@ int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs)
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_level = ctx->trk_level;
     A.px_cur = ctx->fdp_px; A.search_level = ctx->fdp_level; A.ok = ctx->fdp_ok; A.cand = ctx->fdp_cand;
+    A.prio = (ctx->wave_prio_mask >> 1) & 1;
     YGZ_LAUNCH(ctx, KID_FDP, k_find_direct_projection, dim3(ygz_div_up(ctx->cells, 64), ygz_round_up8(n_pairs)), dim3(64), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
@@ -478,7 +482,7 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     LmapArgs A;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 0;
-    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy }; A.F.prio = 0;
     A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;
     A.F.px_cur = nullptr; A.F.search_level = nullptr; A.F.ok = nullptr;
     A.cur_slot = cur_slot; A.P = P; A.C = Cn; A.K = K; A.T_cur = d_T;
@@ -627,7 +631,7 @@ extern "C" int ygz_hip_create_map_points(ygz_hip_ctx *ctx, int slot1, const doub
     CmpArgs A;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 1;
-    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
+    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy }; A.F.prio = 0;
     A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;
     A.F.px_cur = nullptr; A.F.search_level = nullptr; A.F.ok = nullptr;
     A.slot1 = slot1; A.slot2 = slot2; A.n = n; A.T = (const double *)buf;
@@ -929,7 +933,7 @@ __global__ __launch_bounds__(64) void k_depth_filter(DfArgs A)
         const float norm_scale = ygz_sqrtf_cr(__fadd_rn(sigma2, tau2));
         if (!(norm_scale != norm_scale)) {
             float e_ = __fsub_rn(x, mu); e_ = __fmul_rn(e_, -e_); e_ = __fdiv_rn(e_, __fmul_rn(__fmul_rn(2.f, norm_scale), norm_scale));
-            const float pdf = __fdiv_rn(expf(e_), __fmul_rn(norm_scale, ygz_sqrtf_cr(__fmul_rn(2.f, 3.14159265358979323846f))));
+            const float pdf = __fdiv_rn((float)ygz_exp_nonpos((double)e_) /* = oracle/mapping.c::yo_expf_cr */, __fmul_rn(norm_scale, ygz_sqrtf_cr(__fmul_rn(2.f, 3.14159265358979323846f))));
             const float s2 = (float)(1. / (1. / (double)sigma2 + 1. / (double)tau2));
             const float m = __fmul_rn(s2, __fadd_rn(__fdiv_rn(mu, sigma2), __fdiv_rn(x, tau2)));
             float C1 = __fmul_rn(__fdiv_rn(a, __fadd_rn(a, b)), pdf);

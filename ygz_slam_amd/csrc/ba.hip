@@ -83,8 +83,9 @@ __global__ __launch_bounds__(64) void k_ba_pose_prep(const BaDev *__restrict__ w
     ba_pose_prep_one(B, k);
 }
 
-__global__ __launch_bounds__(128) void k_ba_points(const BaDev *__restrict__ wins)
+__global__ __launch_bounds__(128) void k_ba_points(const BaDev *__restrict__ wins, int prio)
 {
+    ygz_raise_prio(prio);                                   // HBM-write bound: keeps its pace beside a VALU-bound kernel
     const BaDev B = wins[blockIdx.y];
     const int il = blockIdx.x * 128 + threadIdx.x, lane = threadIdx.x & 63, q = il >> 6;
     if (q >= B.Q) return;                                   // wavefront-uniform
@@ -375,7 +376,7 @@ int ygz_hip_ba_linearize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
     const BaDev *tab = table + window_begin;
     YgzAuxScope aux(ctx, 1);
     YGZ_LAUNCH(ctx, KID_BA_POSE_PREP, k_ba_pose_prep, dim3(ygz_div_up(ctx->ba_max_K, 64), n_windows), dim3(64), tab);
-    YGZ_LAUNCH(ctx, KID_BA_POINTS, k_ba_points, dim3(ygz_div_up(ctx->ba_max_P, 128), n_windows), dim3(128), tab);
+    YGZ_LAUNCH(ctx, KID_BA_POINTS, k_ba_points, dim3(ygz_div_up(ctx->ba_max_P, 128), n_windows), dim3(128), tab, (ctx->wave_prio_mask >> 2) & 1);
     YGZ_LAUNCH(ctx, KID_BA_POSES, k_ba_final, dim3(n_windows), dim3(256), tab);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;

@@ -221,7 +221,7 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 struct LmTeamArgs {
     const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
     unsigned char *scratch; size_t stride;     // per window: bar[4] u32, behind-camera counts [8] i32 | xpub | part | Sp | private pose state of the G members
-    int Kmax;
+    int Kmax, prio;
     long long *dbg;                            // YGZ_LM_DEBUG: [16] wall-clock ticks (10 ns) per phase of member 0 of the first window
 };
 #define LM_TICK(k) do { if (A.dbg && blockIdx.x == 0 && tid == 0) { const long long tn_ = wall_clock64(); s_t[k] += tn_ - t_prev; t_prev = tn_; } } while (0)
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     const int G = A.G;
     const int xslot = blockIdx.x & 7, j = blockIdx.x >> 3, g = j % G, w = (j / G) * 8 + xslot;
     if (w >= A.n_windows) return;
+    ygz_raise_prio(A.prio);                                 // a latency chain of barriers and short phases on a few CUs
     BaDev B = A.wins[w];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     long long t_prev = 0;
@@ -603,7 +604,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     LmTeamArgs A;
     A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
     A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax;
-    A.dbg = nullptr;
+    A.dbg = nullptr; A.prio = (ctx->wave_prio_mask >> 3) & 1;
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
     YgzAuxScope aux(ctx, 1);

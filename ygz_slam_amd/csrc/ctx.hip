@@ -112,6 +112,7 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
     ctx->prm = *prm;
     ctx->device = device;
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->n_cu = ncu; }
+    { const char *e = getenv("YGZ_WAVE_PRIO"); if (e) ctx->wave_prio_mask = atoi(e); }
     int rc = YGZ_OK;
     do {
         if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }

@@ -37,6 +37,7 @@ struct SaArgs {
     double *out;                                  // [pairs][16]: pose 7 (in: initial cur->_TCW, out: result), n_meas, iters
     double *dbg;                                  // optional [pairs][8] phase cycle counters (profiling aid) or null
     int lcap;                                     // features whose per-iteration scratch (r2, maps, prefixes) lives in LDS; multiple of 64
+    int prio;                                     // != 0: raise the wavefronts' issue priority (the kernel is latency-bound: one wavefront per SIMD)
 };
 
 #define wave_sum_d ygz_wave_sum_d
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
     __shared__ double s_H[21];                  // H of the current level (updated by the change per iteration)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pair = blockIdx.x;
+    ygz_raise_prio(A.prio);
     const int n = A.trk_n[pair];
     double *out = A.out + 16 * (size_t)pair;
     if (n <= 0) {                                      // run() returns 0 and leaves the pose (:25-29)
@@ -536,7 +538,7 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
-    A.dbg = nullptr;
+    A.dbg = nullptr; A.prio = ctx->wave_prio_mask & 1;
     if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
     const char *env_t = getenv("YGZ_SA_THREADS");
     int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);

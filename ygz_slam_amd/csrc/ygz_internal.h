@@ -118,6 +118,10 @@ struct ygz_hip_ctx {
     hipEvent_t ev_xctx = nullptr;            // ygz_hip_stream_wait: recorded on this context's stream, waited for by another's
     bool sa_attr_set = false;                // the dynamic-LDS opt-in of k_sparse_align was made on this context's device
     int  klt_prep_levels = 0;                // levels covered by the LK working images while klt_prep_valid
+    // instruction-issue priority (s_setprio 0..3) the latency- / memory-bound kernels raise their wavefronts to, so that they keep
+    // their pace when a VALU-bound kernel of another stream shares their SIMDs (bit 0: sparse alignment, bit 1: direct projection,
+    // bit 2: BA linearisation, bit 3: LM / ceres / pose-only loops); YGZ_WAVE_PRIO=<mask> overrides
+    int  wave_prio_mask = 0;
 };
 
 #define YGZ_HIPCHK(ctx, call)                                            \
@@ -225,6 +229,8 @@ bool ygz_ba_window_has_dup(const ygz_hip_ctx *ctx, int window);    // an uploade
 // device helpers
 #ifdef __HIPCC__
 __device__ __forceinline__ int ygz_lane() { return (int)(threadIdx.x & 63); }
+// wave-uniform: raise this wavefront's issue priority for the rest of the kernel (on != 0)
+__device__ __forceinline__ void ygz_raise_prio(int on) { if (on) __builtin_amdgcn_s_setprio(3); }
 
 // order-preserving map float -> uint32 (for atomicMax on non-NaN floats)
 __device__ __forceinline__ uint32_t ygz_f2ord(float f)
