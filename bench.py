@@ -341,7 +341,7 @@ def cpu_offline_baseline(bgr, dimg, vo, budget_s=12.0):
 
 
 def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=1, chunk=128, probe="k_klt", one_dev=False, cpu_baseline_s=0.0,
-                overlap=False, lm_group=8, lanes=3):
+                overlap=False, lm_group=None, lanes=3):
     """BASELINE configs[4] on the frames offline_render produced: one sequence sharded over the ranks (strong scaling).  A step = one
     complete offline run; the timed region holds every upload, kernel, result copy, collective and the BA round.  Returns the result
     dict on rank 0 (None elsewhere)."""
@@ -350,6 +350,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     W_, H_ = OFF_W, OFF_H
     need, n_frames, count = R["need"], R["n_frames"], R["count"]
     gray_in = upload == "gray"                                # the caller hands gray frames over (cv::cvtColor's fixed-point weights, on the host)
+    chunk = min(chunk, max(32, -(-count // 4)))               # a shard is cut into >= 4 chunks: uploads, kernels and the BA windows of a rank overlap
     pin = _lib.PinnedArray((len(need), H_, W_) if gray_in else (len(need), H_, W_, 3), np.uint8)
     dpin = _lib.PinnedArray((len(need), H_ // DEPTH_DIV, W_ // DEPTH_DIV), np.uint16)
     vo = offline.OfflineVO(W_, H_, n_frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
@@ -425,7 +426,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
                                       "(+ a quarter-resolution uint16 depth image) and D2H of the results inside the timed region"
                                       % (n_frames, W_, H_),
                           "frames_total": n_frames, "frames_per_gpu": count, "chunk": chunk, "keypoints_per_frame": n_kp,
-                          "parallelism": "frames sharded x%d" % world, "frames_cross_pcie_as": upload, "lanes": len(vo.lanes), "windows_per_lm_launch": lm_group,
+                          "parallelism": "frames sharded x%d" % world, "frames_cross_pcie_as": upload, "lanes": len(vo.lanes), "windows_per_lm_launch": vo.lm_group,
                           "h2d_bytes_per_frame": frame_bytes, "h2d_GBps": frame_bytes * count * steps / dt / 1e9},
                "phases_ms": med, "render_s_outside_timed_region": R["render_s"],
                "result_check": {"pairs": len(pairs), "mean_pose_only_inliers": float(np.mean([r["po_inliers"] for r in pairs])),
@@ -490,7 +491,7 @@ def main():
     ap.add_argument("--lane-overlap", action="store_true", help="offline mode: side streams inside each tracking lane (measured slower: the two lanes "
                                                                "and the BA context already fill the GPU and the hardware queues)")
     ap.add_argument("--lanes", type=int, default=3, help="offline mode: tracking contexts that take the chunks in turn")
-    ap.add_argument("--lm-group", type=int, default=8, help="offline mode: BA windows per resident-LM launch")
+    ap.add_argument("--lm-group", type=int, default=None, help="offline mode: BA windows per resident-LM launch")
     ap.add_argument("--no-extras", action="store_true", help="default mode: skip the `offline` and `stream` blocks (the timed region is the same either way)")
     ap.add_argument("--upload", default="bgr", choices=["bgr", "gray"], help="stream mode: what crosses PCIe per frame (3 or 1 byte per pixel)")
     ap.add_argument("--size", default=None, choices=["vga", "720p"],

@@ -350,6 +350,10 @@ int  ygz_hip_ba_get_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, ygz
  *      across PCIe.  Contexts of one device share the store: tracking contexts copy their keyframes into it device to device. ---- */
 /* order everything enqueued on `waiter` from now on behind everything enqueued on `signaler` so far (same device; no host wait) */
 int  ygz_hip_stream_wait(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler);
+/* finer: ygz_hip_mark remembers what the context has enqueued so far (e.g. up to an upload); ygz_hip_wait_mark orders what `waiter`
+ * enqueues from now on behind signaler's last mark only.  Uploads chained this way cross PCIe first-in-first-out at the full rate. */
+int  ygz_hip_mark(ygz_hip_ctx *ctx);
+int  ygz_hip_wait_mark(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler);
 /* bytes of one keyframe row for this context's grid: pixels f64 [cells][2] | depth f64 [cells] | level i32 [cells] | descriptors
  * [cells][32] | count i32, each part 64-byte aligned.  Rows are fixed-size so that the rows of other ranks arrive by ONE all-gather
  * on the store's memory. */

@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
     "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
-    "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_stream_wait",
+    "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
     "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
     "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states",
 ]
@@ -285,6 +285,12 @@ class HipContext:
     # ---- keyframe store / device-built BA windows (configs[4])
     def stream_wait(self, signaler):
         self._chk(self.lib.ygz_hip_stream_wait(self._ctx, signaler._ctx), "stream_wait")
+
+    def mark(self):
+        self._chk(self.lib.ygz_hip_mark(self._ctx), "mark")
+
+    def wait_mark(self, signaler):
+        self._chk(self.lib.ygz_hip_wait_mark(self._ctx, signaler._ctx), "wait_mark")
 
     def kf_row_bytes(self):
         return int(self.lib.ygz_hip_kf_row_bytes(self._ctx))

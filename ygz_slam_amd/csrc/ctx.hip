@@ -173,6 +173,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->depth_img) (void)hipFree(ctx->depth_img);
     if (ctx->ev_xctx) (void)hipEventDestroy(ctx->ev_xctx);
+    if (ctx->ev_mark) (void)hipEventDestroy(ctx->ev_mark);
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
         if (ctx->lvl[L]) (void)hipFree(ctx->lvl[L]);
         if (ctx->deriv[L]) (void)hipFree(ctx->deriv[L]);
@@ -245,6 +246,28 @@ int ygz_hip_stream_wait(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler)
     if (!signaler->ev_xctx) YGZ_HIPCHK(signaler, hipEventCreateWithFlags(&signaler->ev_xctx, hipEventDisableTiming));
     YGZ_HIPCHK(signaler, hipEventRecord(signaler->ev_xctx, signaler->stream));
     YGZ_HIPCHK(waiter, hipStreamWaitEvent(waiter->stream, signaler->ev_xctx, 0));
+    return YGZ_OK;
+}
+
+// ygz_hip_mark remembers the point the context's stream has reached (everything enqueued so far, e.g. an upload); ygz_hip_wait_mark
+// orders what `waiter` enqueues from now on behind the last mark of `signaler` -- but not behind what signaler enqueued after it.  The
+// offline run chains the uploads of its lanes this way: copies queue up first-in-first-out at full PCIe rate instead of sharing it,
+// so the kernels of chunk k start while chunk k + 1 is still crossing the link.
+int ygz_hip_mark(ygz_hip_ctx *ctx)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx) return YGZ_E_INVALID;
+    if (!ctx->ev_mark) YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_mark, hipEventDisableTiming));
+    YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev_mark, ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_wait_mark(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler)
+{
+    if (!waiter || !signaler || waiter->device != signaler->device) return YGZ_E_INVALID;
+    if (waiter == signaler || !signaler->ev_mark) return YGZ_OK;           // nothing marked yet
+    YgzDeviceGuard dg_(waiter);
+    YGZ_HIPCHK(waiter, hipStreamWaitEvent(waiter->stream, signaler->ev_mark, 0));
     return YGZ_OK;
 }
 

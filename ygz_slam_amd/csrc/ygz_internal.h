@@ -116,6 +116,7 @@ struct ygz_hip_ctx {
     struct KfStore;
     KfStore *kfs = nullptr;
     hipEvent_t ev_xctx = nullptr;            // ygz_hip_stream_wait: recorded on this context's stream, waited for by another's
+    hipEvent_t ev_mark = nullptr;            // ygz_hip_mark / ygz_hip_wait_mark
     bool sa_attr_set = false;                // the dynamic-LDS opt-in of k_sparse_align was made on this context's device
     int  klt_prep_levels = 0;                // levels covered by the LK working images while klt_prep_valid
     // instruction-issue priority (s_setprio 0..3) the latency- / memory-bound kernels raise their wavefronts to, so that they keep

@@ -230,7 +230,7 @@ class OfflineVO:
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
                  max_points=2000, ba_iterations=20, overlap=False, process_group=None, exchange_on_device=True, keep=False, lanes=3,
-                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=4):
+                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None):
         from . import _lib
         self.lib = _lib
         self.w, self.h, self.levels = width, height, levels
@@ -239,7 +239,9 @@ class OfflineVO:
         self.max_points, self.ba_iterations = max_points, ba_iterations
         self.overlap, self.pg, self.exchange_on_device, self.keep = overlap, process_group, exchange_on_device, keep
         self.depth_div, self.depth_dtype, self.depth_scale = depth_div, np.dtype(depth_dtype), depth_scale
-        self.pipeline_ba, self.lm_group = pipeline_ba, max(1, lm_group)
+        self.pipeline_ba, self.lm_group = pipeline_ba, lm_group
+        import os as _os
+        self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
@@ -260,6 +262,12 @@ class OfflineVO:
         self.n_kf = len(keyframes(n_total, kf_stride))
         K1 = max(1, window_kfs - 1)
         self.build_group = max(1, min(len(self.mine), 16))                       # windows per build call (matcher rows: group x (K - 1) pairs)
+        if self.lm_group is None:
+            # windows per resident-LM launch.  A launch takes 8-9 ms whether it holds one window or eight (latency-bound) and the launches
+            # queue on one stream, so they only hide behind the tracking of the following chunks if there are few of them: half of this
+            # rank's windows per launch (at most 8) on a long shard, all of them in one launch on a short one
+            self.lm_group = min(8, len(self.mine) // 2) if self.count > 256 else min(8, len(self.mine))
+        self.lm_group = max(1, self.lm_group)
         self.ba = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(8, self.build_group * K1), device=device)
         self.rows_t = None
         if world > 1 and self.any_cross:                                          # rows of other ranks arrive by a collective: torch owns the memory
@@ -308,6 +316,7 @@ class OfflineVO:
         chunks = [(c0, min(c0 + self.chunk, last)) for c0 in range(first, last, self.chunk)]
         pending = [None] * len(self.lanes)
         self._ba_done, self._ba_built = set(), []
+        self._last_upload = None
         for ci, (c0, c1) in enumerate(chunks):
             li = ci % len(self.lanes)
             if pending[li] is not None:
@@ -341,14 +350,16 @@ class OfflineVO:
         else:
             img = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
             dimg = np.ascontiguousarray(np.stack([self.depth_image(depth_source(f)) for f in frames]))
+        if self._last_upload is not None and self.fifo_uploads:
+            c.wait_mark(self._last_upload)                     # uploads cross PCIe one after the other, each at the full rate
         if img.ndim == 3:                                      # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
             c.upload_gray_batch(0, img, wait=not asyn)
-            c.build_pyramid(0, n, from_bgr=False)
         else:
             c.upload_bgr_batch(0, img, wait=not asyn)
-            c.build_pyramid(0, n, from_bgr=True)
-        c.detect(0, n)
         c.upload_depth_batch(0, dimg, self.depth_scale, wait=not asyn)
+        c.mark(); self._last_upload = c
+        c.build_pyramid(0, n, from_bgr=img.ndim != 3)
+        c.detect(0, n)
         c.keypoint_depths_from_image(0, n)                     # Feature::_depth / _mappoint of the fresh keypoints
         pairs = [(f, f - 1) for f in frames if f - 1 in slot_of and f >= c0]
         if pairs:
