@@ -257,7 +257,8 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
             alone = e["valu_instr_per_launch"] / n_simd / (ms / n * 1e-3) / 1e9
             e["alone"] = {"avg_launch_us": ms / n * 1e3, "achieved": alone, "frac": alone / e["issue_ceiling_of_the_mix"],
                           "timed": "HIP events, 3 runs of the LK stage alone after the timed region (%d launches)" % n}
-    # the matcher runs on the matrix cores (k_hamming_mfma): int8 multiply-adds of the 0/1 expansion, 2 x 256 x |A| x |B| per direction
+    # the matcher runs on the matrix cores (k_hamming_f4: FP4 block-scaled MFMA, K = 64 per instruction): multiply-adds of the 0 / +-1
+    # expansion, 2 x 256 x |A| x |B| operations per direction
     c.probe_begin("k_hamming_nn", 64)
     for _ in range(3):
         c.match_slots_again(1)
@@ -265,13 +266,16 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
     if n:
         ops = 2.0 * 256.0 * n_kp * n_kp * a.batch            # per launch: every pair of the batch, one direction
         t = ms / n * 1e-3
-        out["mfma"] = {"kernel": "k_hamming_mfma", "bound": "mfma", "unit": "TOP/s (int8)", "ops_per_launch": ops, "avg_launch_us": t * 1e6,
-                       "achieved": ops / t / 1e12, "peak": 5000.0, "peak_measured_guide": 3944.0, "peak_measured_here": 4392.0,
-                       "frac": ops / t / 1e12 / 5000.0, "frac_of_measured_peak": ops / t / 1e12 / 4392.0,
-                       "note": "algorithmic ops (unpadded |A| x |B| x 256 x 2); peak = dense int8 MFMA of MI355X_MICROARCH.md (2 x the 2.5 PFLOP/s bf16 "
-                               "peak; its micro-benchmark reaches 3944, tools/ubench/mfma_i8_rate 4392 for this shape: profiles/r02_mfma_i8_rate.txt); a SIMD "
-                               "hides ~4 VALU instructions behind one MFMA (profiles/r02_mfma_valu_mix.txt), the kernel needs ~4.4 (bits to bytes, running "
-                               "minima), and a quarter of a launch is wavefront start-up latency",
+        form = {"1": "k_hamming_mfma (int8 32x32x32)"}.get(os.environ.get("YGZ_HAMMING_FORM", "0"), "k_hamming_f4 (FP4 32x32x64, block scale 2^6)")
+        out["mfma"] = {"kernel": form, "bound": "mfma", "unit": "TOP/s", "ops_per_launch": ops, "avg_launch_us": t * 1e6,
+                       "achieved": ops / t / 1e12, "peak": 10000.0, "peak_int8": 5000.0, "peak_measured_here_fp4": 7630.0, "peak_measured_here_int8": 4392.0,
+                       "frac": ops / t / 1e12 / 10000.0, "frac_of_int8_peak": ops / t / 1e12 / 5000.0,
+                       "frac_of_measured_fp4_rate": ops / t / 1e12 / 7630.0,
+                       "note": "algorithmic ops (unpadded |A| x |B| x 256 x 2).  peak = dense FP4 MFMA of MI355X_MICROARCH.md (~10 PF; its micro-benchmark reaches "
+                               "9099, tools/ubench/mfma_f4_probe 7630 with four chains per wavefront: profiles/r03_mfma_f4_probe.txt); peak_int8 = the 5 POP/s the "
+                               "int8 form of rounds 1-2 was priced against (north_star's matcher target: 0.60 of it).  The kernel is VALU-bound: per tile of 32 "
+                               "columns 8 MFMAs against 67 VALU instructions (32 running minima, 20 bit -> nibble, 10 for the C operand), and a SIMD hides about "
+                               "four VALU instructions behind one MFMA (profiles/r02_mfma_valu_mix.txt)",
                        "timed": "HIP events, 3 runs of the matcher stage alone after the timed region (%d launches)" % n}
     return out
 

@@ -55,6 +55,9 @@ def test_alternate_paths_give_identical_results(tmp_path):
     ref = _run(tmp_path, "default", {})
     assert ref["lm"][2] > 0 and len(ref["match"]) == 2
     for name, env, keys in (("valu_matcher", {"YGZ_HAMMING_VALU": "1"}, ("match",)),
+                            ("matcher_int8_mfma", {"YGZ_HAMMING_FORM": "1"}, ("match",)),
+                            ("matcher_int8_mfma_shared_b", {"YGZ_HAMMING_WG": "1"}, ("match",)),
+                            ("wave_priority", {"YGZ_WAVE_PRIO": "15"}, ("match", "sa", "lm")),
                             ("lm_single_workgroup", {"YGZ_BA_LM_TEAM": "1"}, ("lm",)),
                             ("sa_scratch_in_hbm", {"YGZ_SA_LDS": "0"}, ("sa",)),
                             ("sa_scratch_split", {"YGZ_SA_LDS": "256"}, ("sa",))):
