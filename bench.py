@@ -79,15 +79,20 @@ class Pipeline:
         self.consumed = 0.0
         self.in_flight = False
 
-    def stream_step(self):
+    def stream_step(self, after=None):
+        """after: the pipeline whose upload was enqueued last -- this one's upload queues behind it (first-in-first-out at the full PCIe
+        rate instead of sharing the link: the kernels of the earlier batch start sooner)"""
         c = self.ctx
         if self.in_flight:                                    # the step issued on this buffer two steps ago: wait, then the host reads its results
             c.synchronize()
             self.consume()
+        if after is not None and after is not self:
+            c.wait_mark(after.ctx)
         if self.upload == "gray":
             c.upload_gray_batch(0, self.pin.array, wait=False)
         else:
             c.upload_bgr_batch(0, self.pin.array, wait=False)
+        c.mark()
         self.step()
         c.match_postfilter()
         c.get_keypoints_batch(0, self.B, out=self.kp_out, wait=False)
@@ -562,7 +567,7 @@ def main():
         q = pipes[step_no[0] % n_buf]
         step_no[0] += 1
         if a.mode == "stream":
-            q.stream_step()
+            q.stream_step(pipes[(step_no[0] - 2) % n_buf] if step_no[0] > 1 else None)
         else:
             q.step()
 
@@ -676,7 +681,7 @@ def main():
         dist.destroy_process_group()
 
 
-def stream_block(pipe, a, local_rank, rank, steps=9, warmup=3):
+def stream_block(pipe, a, local_rank, rank, steps=18, warmup=3):
     """the transfer-inclusive mode (bench.py --mode stream) measured after the default timed region: every step uploads its batch
     from page-locked memory (BGR, then gray), runs the same hot path + good-match filter and copies all keypoint fields and the
     per-pair summary back; three batches in flight, each behind its own context (the upload of the next batch is queued before the
@@ -699,13 +704,14 @@ def stream_block(pipe, a, local_rank, rank, steps=9, warmup=3):
         for q in pipes:
             q.setup_stream(upload)
         k = 0
+        fifo = os.environ.get("YGZ_STREAM_FIFO", "1") != "0"
         for _ in range(warmup):
-            pipes[k % n_buf].stream_step(); k += 1
+            pipes[k % n_buf].stream_step(pipes[(k - 1) % n_buf] if fifo and k else None); k += 1
         for q in pipes:
             q.ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            pipes[k % n_buf].stream_step(); k += 1
+            pipes[k % n_buf].stream_step(pipes[(k - 1) % n_buf] if fifo else None); k += 1
         for q in pipes:
             q.ctx.synchronize()
             if q.in_flight:
