@@ -238,7 +238,9 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
     import torch
     n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     kp_ref = counts["keypoints_per_frame"]
-    out = {"unit": "G wave64 VALU instructions / s / SIMD", "simds": n_simd, "peak_full_rate_measured": mix["peak_full_rate"],
+    from ygz_slam_amd.srchash import kernel_source_hash
+    counts_stale = counts.get("kernel_source_hash") != kernel_source_hash()
+    out = {"unit": "G wave64 VALU instructions / s / SIMD", "simds": n_simd, "counts_collected_on_other_kernel_sources": counts_stale, "peak_full_rate_measured": mix["peak_full_rate"],
            "peak_half_rate_measured": mix["peak_half_rate"], "peak_guide": mix["peak_guide_2cycles_2p4GHz"], "kernels": {}}
 
     def entry(name, per_unit, scale, avg_s, launches_note):
@@ -606,7 +608,7 @@ def main():
         avg_s = (probe_ms / max(probe_n, 1)) * 1e-3
         ach = alg / avg_s / 1e9 if avg_s > 0 else 0.0
         # HBM bytes per launch from the PMC passes of this same command (tools/collect_profiles.sh -> profiles/traffic.json)
-        traffic = None
+        traffic, traffic_stale = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -615,11 +617,14 @@ def main():
             tname = tname if tname in tj.get("kernels", {}) else probe_kernel
             if tj.get("batch") == a.batch and tname in tj.get("kernels", {}):
                 traffic = tj["kernels"][tname]["hbm_bytes"]
+            from ygz_slam_amd.srchash import kernel_source_hash
+            traffic_stale = tj.get("kernel_source_hash") != kernel_source_hash()     # the counters were collected on other kernel sources
         # The limiter of the dominant kernel is VALU issue, not HBM (its counter traffic is BELOW the algorithmic bytes: the window re-reads
         # hit L1 / L2).  `roofline` keeps the HBM view the contract asks for (achieved / peak / frac in GB/s, traffic from the PMC passes) and
         # names the real bound; `roofline_valu` prices the same launches against the measured VALU issue ceiling of the kernel's opcode mix.
         roofline = {"bound": "valu", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                     "kernel": {"k_klt": "k_klt3"}.get(probe_kernel, probe_kernel), "launches": probe_n, "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg,
+                    "traffic_collected_on_other_kernel_sources": traffic_stale,
                     "note": "frac is the HBM fraction (algorithmic bytes / launch time / 8 TB/s); the kernel is VALU-issue bound, see roofline_valu"}
         roofline_valu = valu_roofline(pipe, a, probe_kernel, avg_s, n_kp)
         res = {"metric": "frames/sec (extract+match+LK+local-BA), %dx%d, %d ORB kpts" % (W, H, int(round(n_kp, -3)) if n_kp >= 500 else int(n_kp)),

@@ -10,7 +10,7 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"     # the timed region of the default command (the extra blocks follow it)
 timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/stats -- $CMD > $OUT/bench_stats.log 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/bench_fetch.log 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/bench_write.log 2>&1

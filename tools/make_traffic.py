@@ -4,7 +4,9 @@
 rocprofv3's FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE tallies the
 128-byte read requests of a wide streaming read at 64 B, i.e. reports half the bytes -> doubled here; WRITE_SIZE is taken
 as reported (uncalibrated).  Usage: make_traffic.py pmc_fetch.md pmc_write.md out.json [frames per step of the profiled command]"""
-import json, sys
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ygz_slam_amd.srchash import kernel_source_hash
 
 
 def table(path, col):
@@ -21,7 +23,9 @@ def table(path, col):
 
 f, w = table(sys.argv[1], "FETCH_SIZE"), table(sys.argv[2], "WRITE_SIZE")
 res = {"note": "HBM bytes per dispatch: fetch = 2 x FETCH_SIZE KiB x 1024 (gfx950 correction), write = WRITE_SIZE KiB x 1024; "
-               "bench.py --steps 5 --warmup 2", "batch": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "kernels": {}}
+               "bench.py --steps 5 --warmup 2", "batch": int(sys.argv[4]) if len(sys.argv) > 4 else 256,
+       "kernel_source_hash": kernel_source_hash(),      # bench.py compares it with the sources it runs: a stale table is flagged, not used silently
+       "kernels": {}}
 for k in sorted(set(f) | set(w)):
     fb, wb = 2.0 * f.get(k, 0.0) * 1024.0, w.get(k, 0.0) * 1024.0
     res["kernels"][k] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
