@@ -69,8 +69,16 @@ __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &
     t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
 }
 
+// -DYGZ_SA_CAP2 (experiment): at most 256 registers, so that two 256-lane problems share a CU (with YGZ_SA_LDS <= 832):
+// the stage alone drops from 1.09 to 0.86 ms per 512 pairs, the step gets SLOWER (5.95 -> 6.15 ms): the second problem takes the CU's
+// registers and LDS from the LK and matcher wavefronts that would otherwise run beside the first.
+#ifdef YGZ_SA_CAP2
+#define SA_MIN_WAVES 2
+#else
+#define SA_MIN_WAVES 1
+#endif
 template <int SA_THREADS>
-__global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align(SaArgs A)
+__global__ __launch_bounds__(SA_THREADS, SA_MIN_WAVES) void k_sparse_align(SaArgs A)
 {
     __shared__ double red[SA_THREADS / 64][28];
     __shared__ Se3 sT;
