@@ -19,7 +19,8 @@ def _last_json(out):
 
 
 def test_bench_contract_line_one_gpu():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu-baseline",
+                        "--offline-frames", "64"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -31,7 +32,12 @@ def test_bench_contract_line_one_gpu():
     rf = d["roofline"]
     assert rf["bound"] == "valu" and rf["kernel"] == "k_klt3" and rf["launches"] == 3 and rf["avg_launch_us"] > 0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert d["roofline_valu"]["mfma"]["kernel"] == "k_hamming_mfma" and 0 < d["roofline_valu"]["mfma"]["frac"] < 1
+    assert d["roofline_valu"]["mfma"]["kernel"].startswith("k_hamming_f4") and 0 < d["roofline_valu"]["mfma"]["frac"] < 1
+    # the extra blocks measured after the timed region: BASELINE configs[4] (here a 64-frame sequence) and the transfer-inclusive mode
+    off, st = d["offline"], d["stream"]
+    assert "error" not in off and off["value"] > 0 and off["config"]["frames_total"] == 64 and off["result_check"]["ba_windows"] == 1
+    assert off["result_check"]["max_abs_trajectory_error_vs_ground_truth"] < 0.05 and off["gray"]["value"] > 0
+    assert "error" not in st and st["bgr"]["value"] > 0 and st["gray"]["value"] > 0 and st["batches_in_flight"] == 3
     # value = frames / time: consistent with ms_per_step
     assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
 

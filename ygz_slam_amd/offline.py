@@ -530,11 +530,47 @@ class OfflineVO:
         t3 = time.perf_counter()
         self.timing = {"track_shard": (t1 - t0) * 1e3, "gather": (t2 - t1) * 1e3, "ba_round": (t3 - t2) * 1e3}
         self.timing.update({"ba_" + k: v for k, v in getattr(self, "ba_timing", {}).items()})
-        kf_pose = {}
-        for w in windows:                       # the windows live in the gauge of their anchor: world pose = T(anchor -> kf) * T(world -> anchor)
-            for k, f in enumerate(w["kfs"]):
-                kf_pose[f] = se3_mul(se3_exp_g2o(w["poses"][k]), traj[w["kfs"][0]])
-        return dict(records=rec, T_rel=T_rel, trajectory=traj, windows=windows, keyframe_pose=kf_pose, built=dims)
+        res = dict(records=rec, T_rel=T_rel, trajectory=traj, windows=windows, built=dims)
+        res["keyframe_pose"] = _LazyKeyframePoses(windows, traj)
+        return res
+
+
+class _LazyKeyframePoses(dict):
+    """refined world poses of the keyframes: the windows live in the gauge of their anchor, world pose = T(anchor -> kf) * T(world ->
+    anchor).  Composed on first use (128 small numpy products are 3 ms -- as much as the exchange of the whole BA round)"""
+
+    def __init__(self, windows, traj):
+        super().__init__()
+        self._src = (windows, traj)
+
+    def _fill(self):
+        if self._src is not None:
+            windows, traj = self._src
+            self._src = None
+            for w in windows:
+                for k, f in enumerate(w["kfs"]):
+                    dict.__setitem__(self, f, se3_mul(se3_exp_g2o(w["poses"][k]), traj[w["kfs"][0]]))
+
+    def __getitem__(self, k):
+        self._fill(); return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill(); return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill(); return dict.__len__(self)
+
+    def items(self):
+        self._fill(); return dict.items(self)
+
+    def keys(self):
+        self._fill(); return dict.keys(self)
+
+    def values(self):
+        self._fill(); return dict.values(self)
+
+    def __reduce__(self):                                   # pickles as a plain dict
+        self._fill(); return (dict, (dict(dict.items(self)),))
 
 
 def build_window_host(kf_tab, kfs, T_rel, fx, fy, cx, cy, max_points, match_sets):
