@@ -287,4 +287,55 @@ __device__ __forceinline__ void ba_pose_contrib(const BaDev &B, int il, int a, d
     }
 }
 
+// Sums of 27 (padded to 32) per-lane FP64 values over the 64 lanes of a wavefront, all at once: a butterfly in which every
+// level halves the number of values a lane still carries -- it keeps one half and hands the other to its partner
+// (lane ^ 1, ^ 2, ^ 4, ^ 8, ^ 16), so 16 + 8 + 4 + 2 + 1 exchanges replace 27 separate 6-step reductions (~210 instead of ~620
+// instructions; the pose blocks of k_ba_points need 9 such sums per chunk).  On return lane l (and l + 32) holds the total
+// of value *idx = bit-reversed low five bits of l.  The order of the additions is fixed.
+__device__ __forceinline__ double ba_dpp_d(double v, const int ctrl_is_xor1)
+{   // partner's value for lane ^ 1 (quad_perm [1,0,3,2]) or lane ^ 2 (quad_perm [2,3,0,1])
+    const int lo = ctrl_is_xor1 ? __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false)
+                                : __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xF, 0xF, false);
+    const int hi = ctrl_is_xor1 ? __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false)
+                                : __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ba_ror8_d(double v)
+{   // lane ^ 8 inside a row of 16: row_ror:8
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x128, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x128, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double ba_reduce32(const double (&acc)[27], int lane, int *idx)
+{
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8, b4 = lane & 16;
+    double v1[16], v2[8], v3[4], v4[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double lo = acc[j], hi = (16 + j < 27) ? acc[16 + j] : 0.0;
+        const double keep = b0 ? hi : lo, send = b0 ? lo : hi;
+        v1[j] = keep + ba_dpp_d(send, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double keep = b1 ? v1[8 + j] : v1[j], send = b1 ? v1[j] : v1[8 + j];
+        v2[j] = keep + ba_dpp_d(send, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double keep = b2 ? v2[4 + j] : v2[j], send = b2 ? v2[j] : v2[4 + j];
+        v3[j] = keep + __shfl_xor(send, 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double keep = b3 ? v3[2 + j] : v3[j], send = b3 ? v3[j] : v3[2 + j];
+        v4[j] = keep + ba_ror8_d(send);
+    }
+    const double keep = b4 ? v4[1] : v4[0], send = b4 ? v4[0] : v4[1];
+    double v5 = keep + __shfl_xor(send, 16);
+    v5 = v5 + __shfl_xor(v5, 32);
+    *idx = (b0 ? 16 : 0) + (b1 ? 8 : 0) + (b2 ? 4 : 0) + (b3 ? 2 : 0) + (b4 ? 1 : 0);
+    return v5;
+}
+
+
 #endif

@@ -13,6 +13,9 @@
 //   3. right-looking Cholesky in LDS (the same subtraction order per element as the host's left-looking loop), column-oriented
 //      forward / backward substitution inside one wavefront.
 //   4. x_l = Dinv_l (b_l - sum_e Hpl_e^T x_p) (lane = point), oplus on the poses (lane = pose), trial chi2, rho, lambda.
+// the per-edge blocks (Hpl, residuals) are re-read three times per trial by the same few CUs: plain stores keep them in L2 (the
+// streaming stores of the one-shot linearisation, ba.hip, would send every re-read to HBM)
+#define YGZ_BA_PLAIN_STORES
 #include "ba_dev.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,10 +23,11 @@
 #include <string.h>
 #include <float.h>
 
-#define LM_THREADS 512
+#define LM_THREADS 256
 #define LM_WAVES   (LM_THREADS / 64)
 #define LM_MAXKF   14
 #define LM_MAXN    (6 * LM_MAXKF)
+#define LM_LDSK    16                                   // windows of up to 16 poses keep their per-pose tables in LDS
 
 #define lm_wave_sum ygz_wave_sum_d
 // block-wide sum in a fixed order (xor tree inside the wavefronts, then the wavefronts left to right); result on every lane
@@ -73,6 +77,32 @@ __device__ void lm_oplus_pose(double pose[6], const double upd[6])
     se3_mul_d(&A, &Bm, &Cm);
     se3_log_d(&Cm, r);
     pose[0] = r[3]; pose[1] = r[4]; pose[2] = r[5]; pose[3] = r[0]; pose[4] = r[1]; pose[5] = r[2];
+}
+
+// ba_point_chi2 with the inputs of row c + 1 in flight while row c is evaluated: in the resident loop a thread owns one point and its
+// edge loop is a chain of dependent round trips to L2 (measured: 53 us per trial for 16 such iterations), not arithmetic
+__device__ __forceinline__ double lm_point_chi2_pf(const BaDev &B, int il)
+{
+    const int lane = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+    const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
+    double sum = 0.0;
+    int n_ip = -1, n_en = 0; double n_ox = 0, n_oy = 0, n_hub = 0;
+#define LM_FETCH_(row_)                                                                                            \
+    { n_ip = B.pose_c[(size_t)(row_) * 64 + lane]; n_en = B.enable_c[(size_t)(row_) * 64 + lane];                   \
+      n_ox = BA_EC(B.obs_c, row_, 2, 0, lane); n_oy = BA_EC(B.obs_c, row_, 2, 1, lane); n_hub = B.huber_c[(size_t)(row_) * 64 + lane]; }
+    if (rows > 0) LM_FETCH_(row0)
+    for (int c = 0; c < rows; ++c) {
+        const int ip = n_ip, en = n_en;
+        const double ox = n_ox, oy = n_oy, hub = n_hub;
+        if (c + 1 < rows) LM_FETCH_(row0 + c + 1)
+        if (ip < 0 || !en) continue;
+        double p[3], r[2], rho0, rho1;
+        ba_project(B, B.posed + BA_POSED * (size_t)ip, pt, ox, oy, p, r);
+        ba_robust(r[0] * r[0] + r[1] * r[1], hub, &rho0, &rho1);
+        sum += rho0;
+    }
+#undef LM_FETCH_
+    return sum;
 }
 
 // computeActiveErrors + buildSystem at the current state; returns the robustified chi2 (block-uniform)
@@ -215,6 +245,7 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 // timeout aborts the whole team with YGZ_E_HIP.  blockIdx -> (XCD slot, team member): the members of a team share an XCD / L2
 // when the dispatcher places block b on XCD b % 8 (speed only).
 #define LM_V      8
+#define LM_HDR    128                          // per-window header of the scratch: barrier counter + abort flag (bar[0..3]), one behind-camera count per member
 #define LM_PARTW  (8 + 27 * LM_MAXKF)          // per part: chi2, max |diag|, singular flag, scale, trial chi2, -, -, -, pose sums [Kf][27]
 #define LM_SPW    42                           // per (pair, part): 36 block entries + 6 of the right-hand side
 
@@ -261,7 +292,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     __shared__ double S[LM_MAXN * LM_MAXN];
     __shared__ double bs[LM_MAXN], xp[LM_MAXN];
     __shared__ double sH[LM_MAXKF][28];            // Hpp upper triangle (21) + bp (6) of the free poses at the linearisation point
-    __shared__ double red27[LM_WAVES][28];
+    __shared__ double redK[LM_MAXKF][LM_WAVES][28];  // per free pose and wavefront: the 27 sums (Hpp upper triangle, bp)
+    __shared__ double s_posed[LM_LDSK][BA_POSED];
+    __shared__ int32_t s_free_idx[LM_LDSK], s_free_pose[LM_LDSK];
+    __shared__ uint8_t s_fixed[LM_LDSK];
     __shared__ double red[LM_WAVES];
     __shared__ int s_fail, s_ok;
     __shared__ long long s_t[16];
@@ -276,7 +310,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf, Q = B.Q, npairs = Kf * (Kf + 1) / 2;
     unsigned char *scr = A.scratch + (size_t)w * A.stride;
     unsigned *bar = reinterpret_cast<unsigned *>(scr);
-    double *xpub = reinterpret_cast<double *>(scr + 48);                       // [LM_MAXN + 2]
+    double *xpub = reinterpret_cast<double *>(scr + LM_HDR);                   // [LM_MAXN + 2]
     double *part = xpub + LM_MAXN + 2;                                          // [LM_V][LM_PARTW]
     double *Sp = part + (size_t)LM_V * LM_PARTW;                                // [npairs][LM_V][LM_SPW]
     double *priv = Sp + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW + (size_t)g * A.Kmax * (6 + 6 + BA_POSED);
@@ -287,6 +321,12 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     // the member's private pose state replaces the window's arrays in everything below
     for (int i = tid; i < 6 * K; i += LM_THREADS) my_poses[i] = B.poses[i];
     B.poses = my_poses; B.poses_w = my_poses; B.poses_bk = my_bk; B.posed = my_posed;
+    // the per-pose tables every edge looks up through its pose index (prepared pose, free index, constant flag) live in LDS: in the
+    // per-point edge loops they were a dependent global load per edge on top of the edge's own data
+    if (K <= LM_LDSK) {
+        for (int i = tid; i < K; i += LM_THREADS) { s_free_idx[i] = B.free_idx[i]; s_free_pose[i] = B.free_pose[i]; s_fixed[i] = B.fixed[i]; }
+        B.posed = &s_posed[0][0]; B.free_idx = s_free_idx; B.free_pose = s_free_pose; B.fixed = s_fixed;
+    }
     unsigned epoch = 0;
     __syncthreads();
 
@@ -311,20 +351,22 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW, chi); if (it == 0) tl_st(part + (size_t)v * LM_PARTW + 1, mx);
                             tl_st(part + (size_t)v * LM_PARTW + 5, (double)__hip_atomic_load(B.n_behind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                             __hip_atomic_store(B.n_behind, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            __syncthreads();                                               // redK is free (the previous part's sums have been read)
             for (int a = 0; a < Kf; ++a) {
                 double acc[27];
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = 0.0;
                 for (int il = p0_ + tid; il < p1_; il += LM_THREADS) ba_pose_contrib(B, il, a, acc);
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < 27; ++i) { const double t = lm_wave_sum(acc[i]); if (lane == 0) red27[wv][i] = t; }
-                __syncthreads();
-                if (tid < 27) {
-                    double t = 0.0;
-                    for (int ww = 0; ww < LM_WAVES; ++ww) t += red27[ww][tid];
-                    tl_st(part + (size_t)v * LM_PARTW + 8 + 27 * a + tid, t);
-                }
+                int idx;                                                   // all 27 sums of the wavefront in one butterfly (ba_dev.h), fixed order
+                const double tot = ba_reduce32(acc, lane, &idx);
+                if (lane < 32 && idx < 27) redK[a][wv][idx] = tot;
+            }
+            __syncthreads();
+            for (int i = tid; i < 27 * Kf; i += LM_THREADS) {
+                const int a = i / 27, k = i - 27 * a;
+                double t = 0.0;
+                for (int ww = 0; ww < LM_WAVES; ++ww) t += redK[a][ww][k];
+                tl_st(part + (size_t)v * LM_PARTW + 8 + 27 * a + k, t);
             }
         }
         LM_TICK(0);
@@ -373,13 +415,24 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     if (!lm_inv3(D, Dv)) { bad = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
                     for (int i = 0; i < 9; ++i) Di[i] = Dv[i];
                     const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                    double Wn[18]; int ipn = -1;                               // row c + 1 is in flight while row c is multiplied
+                    if (rows > 0) { ipn = B.pose_c[(size_t)row0 * 64 + ln];
+#pragma unroll
+                                    for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row0, 18, i, ln); }
                     for (int c = 0; c < rows; ++c) {
-                        const int row = row0 + c;
-                        if (B.pose_c[(size_t)row * 64 + ln] < 0) continue;
+                        const int row = row0 + c, ipc = ipn;
                         double W[18];
-                        for (int i = 0; i < 18; ++i) W[i] = BA_EC(B.Hpl_c, row, 18, i, ln);
-                        for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 3; ++cc)
-                            BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
+#pragma unroll
+                        for (int i = 0; i < 18; ++i) W[i] = Wn[i];
+                        if (c + 1 < rows) { ipn = B.pose_c[(size_t)(row + 1) * 64 + ln];
+#pragma unroll
+                                            for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row + 1, 18, i, ln); }
+                        if (ipc < 0) continue;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < 3; ++cc)
+                                BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
                     }
                 }
             }
@@ -419,6 +472,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     for (int i = 0; i < 6; ++i) { const double t = lm_wave_sum(accb[i]); if (lane == 0) tl_st(o + 36 + i, t); }
                 }
             }
+            // (two pairs per wavefront walking the points together -- to overlap their load chains -- needs 84 accumulators: 110 spilled
+            // registers, 2040 instead of 1680 us per 24 sweeps)
             LM_TICK(5);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
             LM_TICK(6);
@@ -456,6 +511,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     }
                     __syncthreads();
                 }
+                // (a one-wavefront form -- lane = column of the trailing matrix, no workgroup barriers -- was measured at 60 instead of
+                // 29 us per factorisation: its dependent LDS read-modify-write chain is longer than 3 x 42 barriers)
                 LM_TICK(8);
                 if (wv == 0) {
                     for (int k = 0; k < n; ++k) {
@@ -493,6 +550,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             __syncthreads();
             if (ok2 && tid < K) ba_pose_prep_one(B, tid);
             __syncthreads();
+            LM_TICK(14);
             for (int v = g; v < LM_V; v += G) {
                 LM_PART_RANGE(v)
                 double scale = 0.0, chi = 0.0;
@@ -502,12 +560,22 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         else {
                             double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
                             const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                            double Wn[18]; int ipn = -1;                       // row c + 1 is in flight while row c is accumulated
+                            if (rows > 0) { ipn = B.pose_c[(size_t)row0 * 64 + ln];
+#pragma unroll
+                                            for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row0, 18, i, ln); }
                             for (int c = 0; c < rows; ++c) {
-                                const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + ln];
+                                const int row = row0 + c, ip = ipn;
+                                double W[18];
+#pragma unroll
+                                for (int i = 0; i < 18; ++i) W[i] = Wn[i];
+                                if (c + 1 < rows) { ipn = B.pose_c[(size_t)(row + 1) * 64 + ln];
+#pragma unroll
+                                                    for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row + 1, 18, i, ln); }
                                 if (ip < 0) continue;
                                 const int a = B.free_idx[ip];
                                 if (a < 0) continue;
-                                for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= BA_EC(B.Hpl_c, row, 18, 3 * r + cc, ln) * xp[6 * a + r];
+                                for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= W[3 * r + cc] * xp[6 * a + r];
                             }
                             const double *Di = B.Dinv + 9 * (size_t)il;
                             double x3[3];
@@ -518,9 +586,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                                 B.points_w[3 * (size_t)il + cc] += x3[cc];
                             }
                         }
-                        chi += ba_point_chi2(B, il);                             // the lane's own point at its trial position
+                        chi += lm_point_chi2_pf(B, il);                          // the lane's own point at its trial position
                     }
                 }
+                LM_TICK(15);
                 scale = lm_block_sum(scale, red);
                 chi = lm_block_sum(chi, red);
                 if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW + 3, scale); tl_st(part + (size_t)v * LM_PARTW + 4, chi); }
@@ -592,10 +661,10 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     // resident together -- also beside the kernels of other streams and of the offline run's tracking lanes), G a power of two
     int G = 1, Kmax = 1;
     static const bool single = [] { const char *e = getenv("YGZ_BA_LM_TEAM"); return e && e[0] == '1' && e[1] == 0; }();   // A/B switch: one workgroup per window
-    const int wg_budget = ctx->n_cu / 4 > 8 ? ctx->n_cu / 4 : 8;
+    const int wg_budget = ctx->n_cu / 2 > 8 ? ctx->n_cu / 2 : 8;
     if (!single) while (G < LM_V && n_windows * (2 * G) <= wg_budget) G *= 2;
     for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
-    size_t stride = 48 + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW
+    size_t stride = LM_HDR + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW
                                            + (size_t)G * Kmax * (6 + 6 + BA_POSED));
     stride = (stride + 255) & ~(size_t)255;
     const size_t stats_bytes = (((size_t)n_windows * sizeof(ygz_ba_stats)) + 255) & ~(size_t)255;
@@ -608,7 +677,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
     YgzAuxScope aux(ctx, 1);
-    YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, 48, (size_t)n_windows, ctx->stream));         // barrier counters, abort flags
+    YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, LM_HDR, (size_t)n_windows, ctx->stream));         // barrier counters, abort flags
     YGZ_HIPCHK(ctx, hipMemsetAsync(d_scr, 0xFF, stats_bytes, ctx->stream));                               // iterations = -1 until a team finishes
     for (int i = window_begin; i < window_begin + n_windows; ++i)                                         // the same in the windows' own records
         YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->ba[i]->lm_out, 0xFE, sizeof(ygz_ba_stats), ctx->stream));      // (0xFF = never run, ba_carve)
@@ -616,13 +685,14 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         long long h[16];
-        static const char *const nm[14] = { "linearise + pose sums", "barrier", "combine parts", "Dinv, Y = Hpl Dinv", "barrier", "Schur sweep", "barrier",
-                                            "assemble S", "Cholesky", "substitutions", "barrier", "update + trial chi2", "barrier", "accept / reject" };
+        static const char *const nm[16] = { "linearise + pose sums", "barrier", "combine parts", "Dinv, Y = Hpl Dinv", "barrier", "Schur sweep", "barrier",
+                                            "assemble S", "Cholesky", "substitutions", "barrier", "block sums of the update", "barrier", "accept / reject",
+                                            "pose update (oplus, SE3::exp)", "point update + trial chi2" };
         YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        long long tot = 0; for (int i = 0; i < 14; ++i) tot += h[i];
+        long long tot = 0; for (int i = 0; i < 16; ++i) tot += h[i];
         fprintf(stderr, "[lm-debug] %d windows, team of %d: member 0 of window 0, %.1f us in all:", n_windows, G, tot * 0.01);
-        for (int i = 0; i < 14; ++i) fprintf(stderr, " %s %.1f;", nm[i], h[i] * 0.01);
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %s %.1f;", nm[i], h[i] * 0.01);
         fprintf(stderr, "\n");
     }
     if (stats) {
