@@ -290,7 +290,7 @@ __device__ __forceinline__ bool lm_team_barrier(unsigned *bar, unsigned &epoch, 
 __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 {
     __shared__ double S[LM_MAXN * LM_MAXN];
-    __shared__ double bs[LM_MAXN], xp[LM_MAXN];
+    __shared__ double bs[LM_MAXN], xp[LM_MAXN], dg[LM_MAXN];       // dg: the diagonal of the Cholesky factor
     __shared__ double sH[LM_MAXKF][28];            // Hpp upper triangle (21) + bp (6) of the free poses at the linearisation point
     __shared__ double redK[LM_MAXKF][LM_WAVES][28];  // per free pose and wavefront: the 27 sums (Hpp upper triangle, bp)
     __shared__ double s_posed[LM_LDSK][BA_POSED];
@@ -479,8 +479,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             LM_TICK(6);
             // ---- 3. member 0: S = blockdiag(Hpp + lambda I) - sum of the parts (in part order), Cholesky, substitutions, publish x_p
             if (g == 0) {
-                for (int i = tid; i < n * n; i += LM_THREADS) {
+                for (int i = tid; i < n * n; i += LM_THREADS) {                // the LOWER triangle: nothing below reads an entry above the diagonal
                     const int r = i / n, c = i - r * n, a = r / 6, b = c / 6, rr = r - 6 * a, cc = c - 6 * b;
+                    if (c > r) continue;
                     double t = 0.0;
                     if (a == b) { const int u = min(rr, cc), vv = max(rr, cc); t = sH[a][u * 6 - u * (u - 1) / 2 + (vv - u)]; if (r == c) t += lambda; }
                     const int pa = min(a, b), pb = max(a, b), pr = pa * Kf - pa * (pa - 1) / 2 + (pb - pa);
@@ -499,9 +500,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 __syncthreads();
                 LM_TICK(7);
                 for (int jc = 0; jc < n; ++jc) {
-                    if (tid == 0) { const double d = S[jc * n + jc]; if (!(d > 0) || !isfinite(d)) s_fail = 1; S[jc * n + jc] = sqrt(d > 0 ? d : 1.0); }
-                    __syncthreads();
-                    const double dj = S[jc * n + jc];
+                    // every lane takes the pivot itself (the diagonal entry stays as it is, its root goes to dg[]): two barriers per column, not three
+                    const double d = S[jc * n + jc], dj = sqrt(d > 0 ? d : 1.0);
+                    if (tid == 0) { if (!(d > 0) || !isfinite(d)) s_fail = 1; dg[jc] = dj; }
                     for (int i = jc + 1 + tid; i < n; i += LM_THREADS) S[i * n + jc] = S[i * n + jc] / dj;
                     __syncthreads();
                     const int m = n - jc - 1;
@@ -516,14 +517,14 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 LM_TICK(8);
                 if (wv == 0) {
                     for (int k = 0; k < n; ++k) {
-                        if (lane == 0) bs[k] = bs[k] / S[k * n + k];
+                        if (lane == 0) bs[k] = bs[k] / dg[k];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                         const double yk = bs[k];
                         for (int i = k + 1 + lane; i < n; i += 64) bs[i] -= S[i * n + k] * yk;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                     }
                     for (int k = n - 1; k >= 0; --k) {
-                        if (lane == 0) bs[k] = bs[k] / S[k * n + k];
+                        if (lane == 0) bs[k] = bs[k] / dg[k];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                         const double xk = bs[k];
                         for (int i = lane; i < k; i += 64) bs[i] -= S[k * n + i] * xk;
@@ -662,7 +663,9 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     int G = 1, Kmax = 1;
     static const bool single = [] { const char *e = getenv("YGZ_BA_LM_TEAM"); return e && e[0] == '1' && e[1] == 0; }();   // A/B switch: one workgroup per window
     const int wg_budget = ctx->n_cu / 2 > 8 ? ctx->n_cu / 2 : 8;
-    if (!single) while (G < LM_V && n_windows * (2 * G) <= wg_budget) G *= 2;
+    // up to 4 x LM_V members: the members beyond LM_V own no part of the points -- they only take (pose pair, part) tasks of the Schur sweep,
+    // the longest phase of a trial with four wavefronts per member (28 pairs x 8 parts over 32 wavefronts: 7 rounds; over 64: 3.5)
+    if (!single) while (G < 4 * LM_V && n_windows * (2 * G) <= wg_budget) G *= 2;
     for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
     size_t stride = LM_HDR + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW
                                            + (size_t)G * Kmax * (6 + 6 + BA_POSED));
