@@ -354,6 +354,9 @@ int  ygz_hip_stream_wait(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler);
  * enqueues from now on behind signaler's last mark only.  Uploads chained this way cross PCIe first-in-first-out at the full rate. */
 int  ygz_hip_mark(ygz_hip_ctx *ctx);
 int  ygz_hip_wait_mark(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler);
+/* host helper: T_out[0] = identity, T_out[i] = T_rel[i] * T_out[i - 1] (Sophus SE3 product; poses as 7 doubles): the trajectory of a
+ * batched run from its per-pair relative poses (VisualOdometry.cpp:66 chains the same product frame by frame).  No device work. */
+int  ygz_hip_se3_chain(const double *T_rel, int n, double *T_out);
 /* bytes of one keyframe row for this context's grid: pixels f64 [cells][2] | depth f64 [cells] | level i32 [cells] | descriptors
  * [cells][32] | count i32, each part 64-byte aligned.  Rows are fixed-size so that the rows of other ranks arrive by ONE all-gather
  * on the store's memory. */

@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
     "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
-    "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
+    "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_se3_chain", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
     "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
     "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states",
 ]
@@ -132,6 +132,16 @@ def load():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def se3_chain(T_rel):
+    """T[0] = identity, T[i] = T_rel[i] * T[i - 1] (host code of the library)"""
+    T = np.ascontiguousarray(T_rel, np.float64).reshape(-1, 7)
+    out = np.empty_like(T)
+    rc = load().ygz_hip_se3_chain(_p(T, C.c_double), len(T), _p(out, C.c_double))
+    if rc != OK:
+        raise YgzHipError(rc, "se3_chain")
+    return out
 
 
 class PinnedArray:

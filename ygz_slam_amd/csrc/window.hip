@@ -9,7 +9,7 @@
 //   window build     per window of K keyframes, anchor = keyframe 0 (held fixed like keyframe 0 at BA.cpp:404):
 //                    k_win_select   the anchor's features with depth (first max_points, keypoint order) -> a compacted descriptor set;
 //                    matcher        that set against every other keyframe of the window: BFMatcher(crossCheck) + the good-match rule
-//                                   (test/test_orb_match.cpp:86-104) -- k_hamming_mfma / k_match_postfilter on the store's rows;
+//                                   (test/test_orb_match.cpp:86-104) -- k_hamming_f4 / k_match_postfilter on the store's rows;
 //                    k_win_edges    points seen by >= 2 keyframes, their observations as the chunked row layout of ba_dev.h, the
 //                                   (point, pose) -> edge table, and the window's poses chained from the relative poses:
 //                                   T(anchor) = identity, T(f) = T_rel(f) * T(f - 1), vertex estimate = log as [omega; upsilon];
@@ -292,6 +292,26 @@ void ygz_kf_store_free(ygz_hip_ctx *ctx)
 }
 
 extern "C" {
+
+// host helper of the offline run: the trajectory T[0] = identity, T[i] = T_rel[i] * T[i - 1] (Sophus SE3 product, the formulas the device
+// uses for the windows' chains): a thousand products are microseconds here and a millisecond in an interpreter loop
+int ygz_hip_se3_chain(const double *T_rel, int n, double *T_out)
+{
+    if (!T_rel || !T_out || n < 0) return YGZ_E_INVALID;
+    Se3 acc; acc.q[0] = acc.q[1] = acc.q[2] = 0; acc.q[3] = 1; acc.t[0] = acc.t[1] = acc.t[2] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (i > 0) {
+            Se3 r, c;
+            for (int k = 0; k < 4; ++k) r.q[k] = T_rel[7 * (size_t)i + k];
+            for (int k = 0; k < 3; ++k) r.t[k] = T_rel[7 * (size_t)i + 4 + k];
+            se3_mul_d(&r, &acc, &c);
+            acc = c;
+        }
+        for (int k = 0; k < 4; ++k) T_out[7 * (size_t)i + k] = acc.q[k];
+        for (int k = 0; k < 3; ++k) T_out[7 * (size_t)i + 4 + k] = acc.t[k];
+    }
+    return YGZ_OK;
+}
 
 size_t ygz_hip_kf_row_bytes(const ygz_hip_ctx *ctx)
 {

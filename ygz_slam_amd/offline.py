@@ -117,8 +117,13 @@ def se3_exp_g2o(v):
 
 
 def chain(T_rel):
-    """T[0] = identity (the first frame defines the world); T[i] = T_rel[i] * T[i-1] -- se3_mul's formulas on Python floats (a
-    thousand 7-vector products through numpy temporaries cost 25 ms, this loop 3)"""
+    """T[0] = identity (the first frame defines the world); T[i] = T_rel[i] * T[i-1]: host code of the library (ygz_hip_se3_chain; the
+    same Sophus product as the device's window chains).  chain_py is the interpreter form (1 ms per thousand poses) kept as its check."""
+    from . import _lib
+    return _lib.se3_chain(T_rel)
+
+
+def chain_py(T_rel):
     out = np.empty_like(T_rel)
     out[0] = I7
     bx, by, bz, bw, px, py, pz = (float(v) for v in I7)
@@ -178,6 +183,25 @@ def exchange_rows(buf, owner, world, pg=None, via_host=None):
     for r in range(world):
         if r != rank and rows[r]:
             buf[rows[r][0]:rows[r][-1] + 1] = g[r, :len(rows[r])]
+
+
+def chunk_schedule(first, last, chunk, ramp=True):
+    """[first, last) cut into chunks of `chunk` frames, with a ramp at both ends (chunk / 4, chunk / 2, chunk ... chunk, chunk / 2, chunk / 4)
+    when there is room: nothing overlaps the upload of the first chunk or the kernels of the last one, so those two are kept short"""
+    n = last - first
+    sizes = []
+    if ramp and chunk >= 64 and n >= 4 * chunk:
+        head = [chunk // 4, chunk // 2]
+        tail = [chunk // 2, chunk // 4]
+        body = n - sum(head) - sum(tail)
+        sizes = head + [chunk] * (body // chunk) + ([body % chunk] if body % chunk else []) + tail
+    else:
+        sizes = [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
+    out, c0 = [], first
+    for s_ in sizes:
+        out.append((c0, c0 + s_)); c0 += s_
+    assert c0 == last or n <= 0
+    return out
 
 
 def depth_image(d, div=1, dtype=np.float64, scale=1.0 / 5000.0):
@@ -242,6 +266,7 @@ class OfflineVO:
         self.pipeline_ba, self.lm_group = pipeline_ba, lm_group
         import os as _os
         self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
+        self.ramp = _os.environ.get("YGZ_OFF_RAMP", "1") != "0"
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
@@ -313,7 +338,7 @@ class OfflineVO:
         are all in are built and optimised on the third context while the next chunks run (pipeline_ba)."""
         rec = {}
         first, last = self.start, self.start + self.count
-        chunks = [(c0, min(c0 + self.chunk, last)) for c0 in range(first, last, self.chunk)]
+        chunks = chunk_schedule(first, last, self.chunk, self.ramp)
         pending = [None] * len(self.lanes)
         self._ba_done, self._ba_built = set(), []
         self._last_upload = None
