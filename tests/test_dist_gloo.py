@@ -154,3 +154,38 @@ def test_offline_exchange_world_size_2_gloo():
         assert np.array_equal(buf, exp)                          # every rank holds every owner's rows
         assert np.array_equal(got, T_rel_all)
         assert np.array_equal(offline.chain(got), offline.chain(T_rel_all))
+
+
+def test_offline_chunk_schedule_and_depth_images():
+    """host logic of the offline pipeline: the ramped chunk schedule covers the shard exactly, and the host restatement of the device's depth
+    look-up (offline.depth_at) samples what the docstring says for every depth-image format"""
+    for first, last, chunk in ((0, 1024, 128), (128, 256, 32), (0, 512, 128), (0, 16, 5), (8, 16, 16), (0, 600, 128), (3, 4, 128), (0, 1024, 64)):
+        for ramp in (True, False):
+            c = offline.chunk_schedule(first, last, chunk, ramp)
+            assert c[0][0] == first and c[-1][1] == last and all(a[1] == b[0] for a, b in zip(c, c[1:]))
+            assert all(0 < b - a <= chunk for a, b in c)
+            if ramp and chunk >= 64 and last - first >= 4 * chunk:
+                assert c[0][1] - c[0][0] == chunk // 4 and c[-1][1] - c[-1][0] == chunk // 4     # short first upload, short last kernels
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0.5, 6.0, (48, 64))
+    d[5, 7] = 0.0
+    px = np.stack([rng.integers(0, 64, 200), rng.integers(0, 48, 200)], 1).astype(np.float64)
+    px[0] = [7, 5]
+    full = offline.depth_at(offline.depth_image(d, 1, np.float64), px, 64, 48)
+    assert np.array_equal(full, d[px[:, 1].astype(int), px[:, 0].astype(int)]) and full[0] == 0.0
+    f32 = offline.depth_at(offline.depth_image(d, 1, np.float32), px, 64, 48)
+    assert np.array_equal(f32, d.astype(np.float32)[px[:, 1].astype(int), px[:, 0].astype(int)].astype(np.float64))
+    q = offline.depth_image(d, 4, np.uint16)                       # quarter resolution, TUM scale
+    assert q.shape == (12, 16) and q.dtype == np.uint16
+    got = offline.depth_at(q, px, 64, 48)
+    ref = np.rint(d[4 * (px[:, 1].astype(int) // 4), 4 * (px[:, 0].astype(int) // 4)] * 5000.0) / 5000.0
+    assert np.allclose(got, ref, rtol=0, atol=1e-12)
+    assert np.abs(got - full).max() < 6.0                           # (a coarse prior: neighbouring samples of a random map differ)
+
+
+def test_offline_chain_matches_the_interpreter_form():
+    rng = np.random.default_rng(5)
+    T_rel = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(300)])
+    a, b = offline.chain(T_rel), offline.chain_py(T_rel)
+    assert np.array_equal(a[0], offline.I7) and np.allclose(a, b, rtol=0, atol=1e-13)
+    assert offline.chain(T_rel[:1]).shape == (1, 7) and offline.chain(np.zeros((0, 7))).shape == (0, 7)
