@@ -1,11 +1,11 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel timeline (start / end per dispatch, microseconds from the first dispatch of the step) of the LAST
-# step of `bench.py --steps 3 --warmup 1 --no-cpu-baseline`, from one rocprofv3 --kernel-trace run.  -> gpurun_out/timeline.txt
+# step of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras`, from one rocprofv3 --kernel-trace run.  -> gpurun_out/timeline.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace -d $OUT/raw -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/log.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace -d $OUT/raw -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/log.txt 2>&1
 DB=$(find $OUT/raw -name '*.db' | head -1)
 python - "$DB" > $R/gpurun_out/timeline.txt <<'PY'
 import sqlite3, sys
