@@ -50,6 +50,8 @@ class Pipeline:
         self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device, stream=stream)
         self.frames, self.poses, self.depths, self.ba = inputs if inputs is not None else build_inputs(batch, rank)
         self.from_bgr = True
+        self.klt_prepare = os.environ.get("YGZ_BENCH_KLT_PREPARE", "0") == "1"
+        self.ba_early = os.environ.get("YGZ_BENCH_BA_EARLY", "0") == "1"
 
     def setup_stream(self, upload):
         """stream mode: the batch lives in page-locked host memory and crosses PCIe every step; so do the results"""
@@ -134,10 +136,15 @@ class Pipeline:
         # alignment and the HBM / FP64-bound BA build then share the CUs with the VALU-bound extractor, LK and matcher.
         # (Issuing the BA build -- it depends on no image -- before the extractor was measured slower: 3.64 against 3.55 ms.)
         c.build_pyramid(0, self.B, from_bgr=self.from_bgr)    # A1  InitFrame
+        if self.klt_prepare:
+            c.track_klt_prepare()                             # LK's working images on a side stream, beside the extractor
+        if self.ba_early:
+            c.ba_linearize_resident(0, self.B)
         c.detect(0, self.B)                                   # A2-A7 FeatureDetector::Detect
         c.track_reload(True)                                  # track sets from the fresh keypoints
         c.track_sparse_align()                                # L3  SparseImgAlign::run
-        c.ba_linearize_resident(0, self.B)                    # B1-B5 one Jacobian/JtJ build per frame
+        if not self.ba_early:
+            c.ba_linearize_resident(0, self.B)                # B1-B5 one Jacobian/JtJ build per frame
         c.match_slots_again(1)                                # M1-M3 BFMatcher(crossCheck) vs predecessor
         c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D (side stream, beside LK)
         c.track_klt()                                         # L4  Tracker::TrackKLT

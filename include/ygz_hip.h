@@ -222,6 +222,10 @@ int  ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_
                          const double *T_ref, int n_pairs, int predict);
 int  ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict);       /* device-side reload only (next step, same pairs) */
 int  ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm);
+/* optional: the working images of calcOpticalFlowPyrLK (buildOpticalFlowPyramid's framed levels + Scharr derivatives, OpenCV
+   lkpyramid.cpp; called from src/Algorithm/Tracker.cpp:97) for the current pair table, built ahead on a side stream -- call after
+   ygz_hip_build_pyramid; ygz_hip_track_klt (default parameters) then skips them.  Same results with or without. */
+int  ygz_hip_track_klt_prepare(ygz_hip_ctx *ctx);
 int  ygz_hip_track_direct(ygz_hip_ctx *ctx);
 int  ygz_hip_track_sparse_align(ygz_hip_ctx *ctx, int max_level, int min_level, int n_iter);
 /* VisualOdometry::TrackRefFrame -> TrackLocalMap hand-over (src/Module/VisualOdometry.cpp:281-302, src/Module/LocalMapping.cpp:47-80)

@@ -571,6 +571,18 @@ def test_resident_batched_tracking(hip_lib, oracle, overlap):
     ctx.track_reload(True); ctx.track_klt(); ctx.track_direct(); ctx.track_sparse_align()
     nm2, T2, _ = ctx.track_get_pose(2)
     assert nm2 == nm and np.array_equal(T2, T)
+    # LK's working images built ahead, beside the extractor (ygz_hip_track_klt_prepare): the same tracks bit for bit
+    klt_ref = [ctx.track_get_klt(p) for p in range(3)]
+    ctx.build_pyramid(0, 4); ctx.track_klt_prepare(); ctx.detect(0, 4)
+    ctx.track_reload(True); ctx.track_sparse_align(); ctx.track_direct(); ctx.track_klt()
+    for p in range(3):
+        for a_, b_ in zip(ctx.track_get_klt(p), klt_ref[p]):
+            assert np.array_equal(a_, b_, equal_nan=True), p
+    ctx.build_pyramid(0, 4); ctx.track_klt_prepare(); ctx.build_pyramid(0, 4)      # prepared, then overwritten: rebuilt by the LK call
+    ctx.detect(0, 4); ctx.track_reload(True); ctx.track_klt()
+    for p in range(3):
+        for a_, b_ in zip(ctx.track_get_klt(p), klt_ref[p]):
+            assert np.array_equal(a_, b_, equal_nan=True), p
     ctx.close()
 
 

@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
     "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
     "ygz_hip_default_klt_params", "ygz_hip_klt_track", "ygz_hip_klt_track_filtered",
-    "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_direct",
+    "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_klt_prepare", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
@@ -609,6 +609,9 @@ class HipContext:
 
     def track_reload(self, predict=True):
         self._chk(self.lib.ygz_hip_track_reload(self._ctx, int(predict)), "track_reload")
+
+    def track_klt_prepare(self):
+        self._chk(self.lib.ygz_hip_track_klt_prepare(self._ctx), "track_klt_prepare")
 
     def track_klt(self, params=None):
         prm = params or self.klt_params()

@@ -75,7 +75,10 @@ void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes)
 int ygz_join(ygz_hip_ctx *ctx, unsigned skip_mask)
 {
     for (int i = 0; i < 3; ++i)
-        if (ctx->aux_pending[i] && !((skip_mask >> i) & 1u)) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); ctx->aux_pending[i] = false; }
+        if (ctx->aux_pending[i] && !((skip_mask >> i) & 1u)) {
+            YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[i], 0)); ctx->aux_pending[i] = false;
+            if (i == YGZ_AUX_MATCH) ctx->match_aux_reads_track = false;
+        }
     return YGZ_OK;
 }
 
@@ -113,6 +116,7 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
     ctx->device = device;
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->n_cu = ncu; }
     { const char *e = getenv("YGZ_WAVE_PRIO"); if (e) ctx->wave_prio_mask = atoi(e); }
+    { const char *e = getenv("YGZ_DESCRIBE_ASIDE"); if (e) ctx->describe_aside = atoi(e) != 0; }
     int rc = YGZ_OK;
     do {
         if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
@@ -174,6 +178,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
     if (ctx->depth_img) (void)hipFree(ctx->depth_img);
     if (ctx->ev_xctx) (void)hipEventDestroy(ctx->ev_xctx);
     if (ctx->ev_mark) (void)hipEventDestroy(ctx->ev_mark);
+    if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
         if (ctx->lvl[L]) (void)hipFree(ctx->lvl[L]);
         if (ctx->deriv[L]) (void)hipFree(ctx->deriv[L]);
@@ -373,6 +378,7 @@ int ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int fro
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     if (from_bgr && !ctx->bgr) return YGZ_E_STATE;
     { int rj = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj != YGZ_OK) return rj; }      // a pending BA linearisation reads no image
+    if (ctx->klt_prep_pending) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0)); ctx->klt_prep_pending = false; }   // ... but LK working images being built do
     int rc = ygz_launch_gray_pyramid(ctx, slot_begin, n_slots, from_bgr, ctx->n_levels_alloc);
     if (rc != YGZ_OK) return rc;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 1;

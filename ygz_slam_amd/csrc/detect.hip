@@ -557,6 +557,11 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
         }
     }
 #endif
+    if (ctx->describe_aside) {
+        // descriptors feed the matcher only: its side stream runs them while the main stream goes on to the track sets and LK
+        YgzAuxScope aux(ctx, YGZ_AUX_MATCH);
+        return ygz_launch_describe(ctx, slot_begin, n_slots);
+    }
     return ygz_launch_describe(ctx, slot_begin, n_slots);
 }
 

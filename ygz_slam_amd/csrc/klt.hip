@@ -565,6 +565,7 @@ static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *
     }
     ctx->klt_prep_valid = false;
     if (prep_only) return YGZ_OK;
+    if (ctx->klt_prep_pending) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0)); ctx->klt_prep_pending = false; }
     A.max_level = max_level; A.win = prm->win; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.max_count = prm->max_iter < 0 ? 0 : (prm->max_iter > 100 ? 100 : prm->max_iter);
     const double eps = prm->eps < 0 ? 0 : (prm->eps > 10 ? 10 : prm->eps);

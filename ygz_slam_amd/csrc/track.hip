@@ -223,7 +223,9 @@ int ygz_hip_track_begin(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
 int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
 {
     YgzDeviceGuard dg_(ctx);
-    if (ctx) { int rj_ = ygz_join(ctx, 1u << YGZ_AUX_BA); if (rj_ != YGZ_OK) return rj_; }
+    // the track sets are built from pixel / level / depth of the keypoints: neither a BA build nor descriptors still being computed
+    // on the matcher's stream (describe_aside) are read or written here
+    if (ctx) { int rj_ = ygz_join(ctx, (1u << YGZ_AUX_BA) | (ctx->describe_aside && !ctx->match_aux_reads_track ? 1u << YGZ_AUX_MATCH : 0u)); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     int rc = launch_load(ctx, predict);
     if (rc != YGZ_OK) return rc;
@@ -239,12 +241,30 @@ int ygz_hip_track_klt(ygz_hip_ctx *ctx, const ygz_klt_params *prm)
     return ygz_launch_klt(ctx, ctx->n_pairs, prm);
 }
 
+// The reflect-framed copies and Scharr images LK works on depend on the pyramids only: a pipeline that calls this right after
+// ygz_hip_build_pyramid has them built on a side stream beside the extractor (memory-bound work beside VALU/LDS-bound work), and
+// ygz_hip_track_klt then starts with the LK kernel itself.  Without it ygz_hip_track_klt builds them first; same results.
+int ygz_hip_track_klt_prepare(ygz_hip_ctx *ctx)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx) return YGZ_E_INVALID;
+    if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
+    if (!ctx->ev_prep) YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    YgzAuxScope aux(ctx, YGZ_AUX_BA);                        // idle at this point of a step: the BA build is issued after the extractor
+    const int rc = ygz_klt_prepare_early(ctx);
+    if (rc != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream));
+    ctx->klt_prep_pending = true;
+    return YGZ_OK;
+}
+
 int ygz_hip_track_direct(ygz_hip_ctx *ctx)
 {
     YgzDeviceGuard dg_(ctx);
     if (!ctx) return YGZ_E_INVALID;
     if (ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     YgzAuxScope aux(ctx, YGZ_AUX_MATCH);                     // independent of LK: shares the matcher's side stream
+    ctx->match_aux_reads_track = aux.active;
     return ygz_launch_fdp(ctx, ctx->n_pairs);
 }
 

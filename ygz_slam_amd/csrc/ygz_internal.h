@@ -117,6 +117,10 @@ struct ygz_hip_ctx {
     KfStore *kfs = nullptr;
     hipEvent_t ev_xctx = nullptr;            // ygz_hip_stream_wait: recorded on this context's stream, waited for by another's
     hipEvent_t ev_mark = nullptr;            // ygz_hip_mark / ygz_hip_wait_mark
+    hipEvent_t ev_prep = nullptr;            // end of the LK working images built ahead on a side stream (ygz_hip_track_klt_prepare)
+    bool klt_prep_pending = false;           // ... and nobody has waited for it yet
+    bool match_aux_reads_track = false;      // a direct projection (reads the track sets) is pending on the matcher's side stream
+    bool describe_aside = false;             // ygz_hip_detect leaves the descriptor kernel on the matcher's side stream (YGZ_DESCRIBE_ASIDE=1)
     bool sa_attr_set = false;                // the dynamic-LDS opt-in of k_sparse_align was made on this context's device
     int  klt_prep_levels = 0;                // levels covered by the LK working images while klt_prep_valid
     // instruction-issue priority (s_setprio 0..3) the latency- / memory-bound kernels raise their wavefronts to, so that they keep
