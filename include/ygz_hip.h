@@ -342,6 +342,11 @@ int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *pos
  * place (ygz_hip_ba_get_state reads them back); stats [n_windows] may be NULL (then the call is asynchronous). */
 int  ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, int max_iterations,
                                   ygz_ba_stats *stats);
+/* A launch of few windows gives every window a TEAM of workgroups (up to 32; results are bit-identical for every team size) as long
+ * as windows x team <= budget workgroups; each of them owns a CU for the whole launch.  Default (0): half of the device's CUs.  A
+ * pipeline that runs the LM beside other kernels lowers it for those launches (a member that waits for a CU to drain keeps the
+ * members already placed spinning) and restores it for the launch nothing else runs beside.  Clamped to [1, CUs]. */
+int  ygz_hip_ba_set_team_budget(ygz_hip_ctx *ctx, int workgroups);
 int  ygz_hip_ba_get_state(ygz_hip_ctx *ctx, int window, double *poses, double *points);
 /* statistics of the last ygz_hip_ba_optimize_resident run on each window of the range (it may have been asynchronous) and the graph
  * sizes dims [n][4] = poses, points, edges, free poses; either output may be NULL.  YGZ_E_HIP: a team of workgroups timed out at a

@@ -240,18 +240,22 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 // of the trial state | barrier (partials of scale / chi2) | every workgroup takes the same accept / reject decision.  The pose state
 // is private to a workgroup (identical copies): a shared copy updated by everybody would be a read-modify-write race.
 // Barriers: one monotonic counter per window, lane 0 releases at agent scope before it arrives and acquires after the wait
-// (MI355X: per-CU L1 and per-XCD L2 are not coherent); cross-workgroup scalars travel through agent-scope atomics.  All blocks of
-// a team must be resident: the launch keeps windows x G <= 64 workgroups (a CU holds one of these), every wait is bounded and a
+// (MI355X: per-CU L1 and per-XCD L2 are not coherent); what members exchange is written with agent-scope stores and read with plain loads after the barrier's acquire (the parts of a pose pair, read by whoever delivers the last one without a barrier in between: agent-scope loads).  All blocks of
+// a team must be resident: the launch keeps windows x G <= half of the CUs (a CU holds one of these; ygz_hip_ba_set_team_budget), every wait is bounded and a
 // timeout aborts the whole team with YGZ_E_HIP.  blockIdx -> (XCD slot, team member): the members of a team share an XCD / L2
 // when the dispatcher places block b on XCD b % 8 (speed only).
 #define LM_V      8
-#define LM_HDR    128                          // per-window header of the scratch: barrier counter + abort flag (bar[0..3]), one behind-camera count per member
+#define LM_MAXG   (4 * LM_V)                   // members of a team (the launch never picks more)
+#define LM_NPAIR  (LM_MAXKF * (LM_MAXKF + 1) / 2)
+#define LM_HDR    1024                         // per-window header of the scratch (zeroed by the launch): barrier counter + abort flag (bar[0..3]), one
+                                               // behind-camera count per member (bar[4..4+LM_MAXG)), one arrival counter per pose pair (bar[64..64+LM_NPAIR))
 #define LM_PARTW  (8 + 27 * LM_MAXKF)          // per part: chi2, max |diag|, singular flag, scale, trial chi2, -, -, -, pose sums [Kf][27]
 #define LM_SPW    42                           // per (pair, part): 36 block entries + 6 of the right-hand side
+static_assert(16 + 4 * LM_MAXG <= 256 && 256 + 4 * LM_NPAIR <= LM_HDR, "scratch header");
 
 struct LmTeamArgs {
     const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
-    unsigned char *scratch; size_t stride;     // per window: bar[4] u32, behind-camera counts [8] i32 | xpub | part | Sp | private pose state of the G members
+    unsigned char *scratch; size_t stride;     // per window: header (LM_HDR) | xpub | part | Sp | Sfin | private pose state of the G members
     int Kmax, prio;
     long long *dbg;                            // YGZ_LM_DEBUG: [16] wall-clock ticks (10 ns) per phase of member 0 of the first window
 };
@@ -287,10 +291,175 @@ __device__ __forceinline__ bool lm_team_barrier(unsigned *bar, unsigned &epoch, 
     return *s_ok != 0;
 }
 
+
+// Sums of N <= 64 per-lane FP64 values over the 64 lanes of a wavefront, all at once: ba_reduce32's butterfly with one more level
+// (32 + 16 + 8 + 4 + 2 + 1 exchanges instead of N separate 6-step reductions).  On return every lane holds the total of value
+// *idx = its lane number bit-reversed (6 bits); the order of the additions is fixed.
+template <int N>
+__device__ __forceinline__ double lm_reduce64(const double (&acc)[N], int lane, int *idx)
+{
+    static_assert(N <= 64, "one value per lane");
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8, b4 = lane & 16, b5 = lane & 32;
+    double v1[32], v2[16], v3[8], v4[4], v5[2];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const double lo = j < N ? acc[j < N ? j : 0] : 0.0, hi = 32 + j < N ? acc[32 + j < N ? 32 + j : 0] : 0.0;
+        const double keep = b0 ? hi : lo, send = b0 ? lo : hi;
+        v1[j] = keep + ba_dpp_d(send, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const double keep = b1 ? v1[16 + j] : v1[j], send = b1 ? v1[j] : v1[16 + j]; v2[j] = keep + ba_dpp_d(send, 0); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const double keep = b2 ? v2[8 + j] : v2[j], send = b2 ? v2[j] : v2[8 + j]; v3[j] = keep + __shfl_xor(send, 4); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double keep = b3 ? v3[4 + j] : v3[j], send = b3 ? v3[j] : v3[4 + j]; v4[j] = keep + ba_ror8_d(send); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const double keep = b4 ? v4[2 + j] : v4[j], send = b4 ? v4[j] : v4[2 + j]; v5[j] = keep + __shfl_xor(send, 16); }
+    const double keep = b5 ? v5[1] : v5[0], send = b5 ? v5[0] : v5[1];
+    *idx = (b0 ? 32 : 0) + (b1 ? 16 : 0) + (b2 ? 8 : 0) + (b3 ? 4 : 0) + (b4 ? 2 : 0) + (b5 ? 1 : 0);
+    return keep + __shfl_xor(send, 32);
+}
+
+// 1 / d to the last bit or two: v_rcp_f64 (about 2^-23) and two Newton steps -- five dependent instructions where the IEEE
+// division is a chain of fifteen; the pivots of the reduced system are far from the limits of the exponent range
+__device__ __forceinline__ double lm_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    return r;
+}
+
+// The reduced pose system S x = b of one trial, n = 6 nb unknowns, by member 0 of a team: S = L D L^T by 6 x 6 BLOCK columns (nb <= 14
+// of them, two workgroup barriers each, where the scalar right-looking form took 3 n), then the two triangular solves by one
+// wavefront, again a block at a time.  Per block column: every thread factors the diagonal block for itself in registers (21 LDS
+// broadcasts, no barrier); thread i takes row i of the panel below it (X = A L^-T D^-1, and T = X D kept aside for the update);
+// the trailing matrix loses T X^T.  S holds the lower triangle, row-major with stride n; on return S holds L below the diagonal,
+// bs holds x.  *fail is set when a pivot is not positive (the matrix is not positive definite: the trial is rejected).
+__device__ __forceinline__ void lm_factor_blocked(double *S, double *dgv /*[n]*/, double *rdg /*[n]*/, double (*Tb)[6], int n, int *fail)
+{
+    const int tid = threadIdx.x, nb = n / 6;
+    for (int kb = 0; kb < nb; ++kb) {
+        const int j0 = 6 * kb, m = n - j0 - 6;
+        double Lk[15], d[6], rd[6];                                  // unit lower triangle (r, c < r) at r (r - 1) / 2 + c
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double t[5];                                             // t[k] = L(c, k) d[k]
+            double dc = S[(j0 + c) * n + j0 + c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) { t[k] = Lk[c * (c - 1) / 2 + k] * d[k]; dc -= Lk[c * (c - 1) / 2 + k] * t[k]; }
+            if (!(dc > 0) || !isfinite(dc)) { bad = true; dc = 1.0; }
+            d[c] = dc; rd[c] = lm_rcp(dc);
+#pragma unroll
+            for (int r = c + 1; r < 6; ++r) {
+                double a = S[(j0 + r) * n + j0 + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) a -= Lk[r * (r - 1) / 2 + k] * t[k];
+                Lk[r * (r - 1) / 2 + c] = a * rd[c];
+            }
+        }
+        if (m > 0 && tid < m) {                                      // panel: row i of the rows below the block
+            const int i = j0 + 6 + tid;
+            double T[6], X[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double a = S[i * n + j0 + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) a -= T[k] * Lk[c * (c - 1) / 2 + k];
+                T[c] = a; X[c] = a * rd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { S[i * n + j0 + c] = X[c]; Tb[i][c] = T[c]; }
+        }
+        __syncthreads();                                             // every thread has read the diagonal block; the panel is in place
+        if (tid == 0) {
+            if (bad) *fail = 1;
+#pragma unroll
+            for (int r = 1; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < r; ++c) S[(j0 + r) * n + j0 + c] = Lk[r * (r - 1) / 2 + c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { dgv[j0 + c] = d[c]; rdg[j0 + c] = rd[c]; }
+        }
+        if (m > 0) {                                                 // trailing matrix (its lower triangle); (ii, kk) steps by LM_THREADS without a division
+            const int dq = LM_THREADS / m, dr = LM_THREADS - dq * m;
+            int ii = tid / m, kk = tid - ii * m;
+            for (; ii < m; ii += dq, kk += dr) {
+                if (kk >= m) { kk -= m; ++ii; if (ii >= m) break; }
+                if (kk > ii) continue;
+                const int i = j0 + 6 + ii, k = j0 + 6 + kk;
+                double a = S[i * n + k];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a -= Tb[i][c] * S[k * n + j0 + c];
+                S[i * n + k] = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void lm_subst_blocked(const double *S, double *bs, const double *rdg, int n)
+{
+    const int tid = threadIdx.x, lane = tid & 63, nb = n / 6;
+    if (tid < 64) {
+#define LM_WSYNC_() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+        for (int kb = 0; kb < nb; ++kb) {                            // L z = b
+            const int j0 = 6 * kb;
+            double z[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double a = bs[j0 + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) a -= S[(j0 + c) * n + j0 + k] * z[k];
+                z[c] = a;
+            }
+            LM_WSYNC_()                                              // every lane has read b of the block
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) bs[j0 + c] = z[c];
+            }
+            for (int i = j0 + 6 + lane; i < n; i += 64) {
+                double a = bs[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a -= S[i * n + j0 + c] * z[c];
+                bs[i] = a;
+            }
+            LM_WSYNC_()
+        }
+        for (int i = lane; i < n; i += 64) bs[i] *= rdg[i];          // y = D^-1 z
+        LM_WSYNC_()
+        for (int kb = nb - 1; kb >= 0; --kb) {                       // L^T x = y
+            const int j0 = 6 * kb;
+            double x[6];
+#pragma unroll
+            for (int c = 5; c >= 0; --c) {
+                double a = bs[j0 + c];
+#pragma unroll
+                for (int k = 5; k > c; --k) a -= S[(j0 + k) * n + j0 + c] * x[k];
+                x[c] = a;
+            }
+            LM_WSYNC_()
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) bs[j0 + c] = x[c];
+            }
+            for (int i = lane; i < j0; i += 64) {
+                double a = bs[i];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) a -= S[(j0 + c) * n + i] * x[c];
+                bs[i] = a;
+            }
+            LM_WSYNC_()
+        }
+#undef LM_WSYNC_
+    }
+}
+
 __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 {
     __shared__ double S[LM_MAXN * LM_MAXN];
-    __shared__ double bs[LM_MAXN], xp[LM_MAXN], dg[LM_MAXN];       // dg: the diagonal of the Cholesky factor
+    __shared__ double bs[LM_MAXN], xp[LM_MAXN], dg[LM_MAXN], rdg[LM_MAXN];   // dg / rdg: D of S = L D L^T and its reciprocals
+    __shared__ double Tb[LM_MAXN][6];              // the panel of the current block column times D (lm_solve_blocked)
     __shared__ double sH[LM_MAXKF][28];            // Hpp upper triangle (21) + bp (6) of the free poses at the linearisation point
     __shared__ double redK[LM_MAXKF][LM_WAVES][28];  // per free pose and wavefront: the 27 sums (Hpp upper triangle, bp)
     __shared__ double s_posed[LM_LDSK][BA_POSED];
@@ -313,7 +482,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     double *xpub = reinterpret_cast<double *>(scr + LM_HDR);                   // [LM_MAXN + 2]
     double *part = xpub + LM_MAXN + 2;                                          // [LM_V][LM_PARTW]
     double *Sp = part + (size_t)LM_V * LM_PARTW;                                // [npairs][LM_V][LM_SPW]
-    double *priv = Sp + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW + (size_t)g * A.Kmax * (6 + 6 + BA_POSED);
+    double *Sfin = Sp + (size_t)LM_NPAIR * LM_V * LM_SPW;                       // [npairs][LM_SPW]: the assembled blocks of the reduced system
+    double *priv = Sfin + (size_t)LM_NPAIR * LM_SPW + (size_t)g * A.Kmax * (6 + 6 + BA_POSED);
+    unsigned *pair_cnt = bar + 64;                                              // arrivals per pose pair (monotonic: LM_V per trial)
     double *my_poses = priv, *my_bk = priv + 6 * (size_t)A.Kmax, *my_posed = my_bk + 6 * (size_t)A.Kmax;
     double *const out_poses = B.poses_w;
     int32_t *const n_behind = B.n_behind;
@@ -375,14 +546,14 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
         {   // every member adds the parts in part order: identical sH, chi2 (and lambda at the first iteration)
             for (int i = tid; i < 27 * Kf; i += LM_THREADS) {
                 double t = 0.0;
-                for (int v = 0; v < LM_V; ++v) t += tl_ld(part + (size_t)v * LM_PARTW + 8 + i);
+                for (int v = 0; v < LM_V; ++v) t += part[(size_t)v * LM_PARTW + 8 + i];
                 sH[i / 27][i % 27] = t;
             }
             double chi = 0.0, mx = 0.0;
-            for (int v = 0; v < LM_V; ++v) { chi += tl_ld(part + (size_t)v * LM_PARTW); if (it == 0) mx = fmax(mx, tl_ld(part + (size_t)v * LM_PARTW + 1)); }
+            for (int v = 0; v < LM_V; ++v) { chi += part[(size_t)v * LM_PARTW]; if (it == 0) mx = fmax(mx, part[(size_t)v * LM_PARTW + 1]); }
             currentChi = chi;
             __syncthreads();
-            if (g == 0 && tid == LM_THREADS - 1) { double nb = 0.0; for (int v = 0; v < LM_V; ++v) nb += tl_ld(part + (size_t)v * LM_PARTW + 5); *n_behind = (int)nb; }
+            if (g == 0 && tid == LM_THREADS - 1) { double nb = 0.0; for (int v = 0; v < LM_V; ++v) nb += part[(size_t)v * LM_PARTW + 5]; *n_behind = (int)nb; }
             if (g == 0 && tid < 27 * Kf) {                                     // the window's Hpp / bp as the ABI exposes them
                 const int a = tid / 27, i = tid % 27, k = B.free_pose[a];
                 if (i < 21) { int u = 0, rem = i; while (rem >= 6 - u) { rem -= 6 - u; ++u; } const int vv = u + rem;
@@ -464,12 +635,41 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     lm_sweep_point<false>(B, l + 64, ca1, cb1, a == b, nullptr, nullptr, acc, accb);
                     ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
                 }
-                double *o = Sp + ((size_t)pr * LM_V + v) * LM_SPW;
+                // the 42 sums of the wavefront in one butterfly, one coalesced store; the wavefront that delivers the LAST part of a pair
+                // adds the parts -- in part order, whoever it is -- and leaves the finished block of S (and of the right-hand side) in Sfin
+                double all[LM_SPW];
 #pragma unroll
-                for (int i = 0; i < 36; ++i) { const double t = lm_wave_sum(acc[i]); if (lane == 0) tl_st(o + i, t); }
-                if (a == b) {
+                for (int i = 0; i < 36; ++i) all[i] = acc[i];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) { const double t = lm_wave_sum(accb[i]); if (lane == 0) tl_st(o + 36 + i, t); }
+                for (int i = 0; i < 6; ++i) all[36 + i] = accb[i];
+                int idx;
+                const double tot = lm_reduce64<LM_SPW>(all, lane, &idx);
+                if (idx < LM_SPW) tl_st(Sp + ((size_t)pr * LM_V + v) * LM_SPW + idx, tot);
+                // the parts travel through agent-scope stores and loads (write-through / re-read at the scope of the device) and have been
+                // acknowledged (vmcnt) before the arrival is counted: no agent-scope fence here -- a release writes the WHOLE L2 of the XCD
+                // back and an acquire drops its lines, per task and for every kernel that shares the XCD (measured on the offline run:
+                // + 2.4 ms of tracking per 1024 frames beside the two BA launches)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                unsigned arrived = 0;
+                if (lane == 0) arrived = __hip_atomic_fetch_add(pair_cnt + pr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+                if ((arrived % LM_V) == LM_V - 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (lane < LM_SPW) {
+                        double pv[LM_V], sub = 0.0;                            // all parts requested before the first is added
+#pragma unroll
+                        for (int vv = 0; vv < LM_V; ++vv) pv[vv] = tl_ld(Sp + ((size_t)pr * LM_V + vv) * LM_SPW + lane);
+#pragma unroll
+                        for (int vv = 0; vv < LM_V; ++vv) sub += pv[vv];
+                        double t = 0.0;
+                        if (a == b) {
+                            if (lane < 36) { const int rr = lane / 6, cc = lane - 6 * rr, u = min(rr, cc), w2 = max(rr, cc);
+                                             t = sH[a][u * 6 - u * (u - 1) / 2 + (w2 - u)]; if (rr == cc) t += lambda; }
+                            else t = sH[a][21 + (lane - 36)];
+                        }
+                        tl_st(Sfin + (size_t)pr * LM_SPW + lane, t - sub);
+                    }
                 }
             }
             // (two pairs per wavefront walking the points together -- to overlap their load chains -- needs 84 accumulators: 110 spilled
@@ -477,59 +677,34 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             LM_TICK(5);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
             LM_TICK(6);
-            // ---- 3. member 0: S = blockdiag(Hpp + lambda I) - sum of the parts (in part order), Cholesky, substitutions, publish x_p
+            // ---- 3. member 0: the blocks of S from Sfin, L D L^T by block columns, substitutions, publish x_p
             if (g == 0) {
-                for (int i = tid; i < n * n; i += LM_THREADS) {                // the LOWER triangle: nothing below reads an entry above the diagonal
-                    const int r = i / n, c = i - r * n, a = r / 6, b = c / 6, rr = r - 6 * a, cc = c - 6 * b;
-                    if (c > r) continue;
-                    double t = 0.0;
-                    if (a == b) { const int u = min(rr, cc), vv = max(rr, cc); t = sH[a][u * 6 - u * (u - 1) / 2 + (vv - u)]; if (r == c) t += lambda; }
-                    const int pa = min(a, b), pb = max(a, b), pr = pa * Kf - pa * (pa - 1) / 2 + (pb - pa);
-                    const int e = (a <= b) ? 6 * rr + cc : 6 * cc + rr;        // block (pa, pb) holds rows of pa x columns of pb
-                    double sub = 0.0;
-                    for (int v = 0; v < LM_V; ++v) sub += tl_ld(Sp + ((size_t)pr * LM_V + v) * LM_SPW + e);
-                    S[i] = t - sub;
+                // (plain loads: the team barrier has made the finished blocks visible like every other array the members share)
+                for (int i0 = tid; i0 < npairs * LM_SPW; i0 += 6 * LM_THREADS) {   // six loads in flight per thread (n = 42: 1176 values, one round)
+                    double val[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) { const int i = i0 + u * LM_THREADS; val[u] = i < npairs * LM_SPW ? Sfin[i] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {                              // block (b <= a) of pair pr: rows of b x columns of a -> the LOWER triangle of S
+                        const int i = i0 + u * LM_THREADS;
+                        if (i >= npairs * LM_SPW) break;
+                        const int pr = i / LM_SPW, e = i - pr * LM_SPW;
+                        int b = 0, rem = pr;
+                        while (rem >= Kf - b) { rem -= Kf - b; ++b; }
+                        const int a = b + rem;
+                        if (e >= 36) { if (a == b) bs[6 * a + (e - 36)] = val[u]; continue; }
+                        const int x = e / 6, y = e - 6 * x;                    // entry (6 b + x, 6 a + y) = (6 a + y, 6 b + x)
+                        if (a == b) { if (x >= y) S[(6 * a + x) * n + 6 * a + y] = val[u]; }
+                        else S[(6 * a + y) * n + 6 * b + x] = val[u];
+                    }
                 }
-                for (int i = tid; i < n; i += LM_THREADS) {
-                    const int a = i / 6, pr = a * Kf - a * (a - 1) / 2;
-                    double sub = 0.0;
-                    for (int v = 0; v < LM_V; ++v) sub += tl_ld(Sp + ((size_t)pr * LM_V + v) * LM_SPW + 36 + (i % 6));
-                    bs[i] = sH[a][21 + (i % 6)] - sub;
-                }
-                if (tid == 0) { double f = 0.0; for (int v = 0; v < LM_V; ++v) f += tl_ld(part + (size_t)v * LM_PARTW + 2); s_fail = f != 0.0; }
+                if (tid == 0) { double f = 0.0; for (int v = 0; v < LM_V; ++v) f += part[(size_t)v * LM_PARTW + 2]; s_fail = f != 0.0; }
                 __syncthreads();
                 LM_TICK(7);
-                for (int jc = 0; jc < n; ++jc) {
-                    // every lane takes the pivot itself (the diagonal entry stays as it is, its root goes to dg[]): two barriers per column, not three
-                    const double d = S[jc * n + jc], dj = sqrt(d > 0 ? d : 1.0);
-                    if (tid == 0) { if (!(d > 0) || !isfinite(d)) s_fail = 1; dg[jc] = dj; }
-                    for (int i = jc + 1 + tid; i < n; i += LM_THREADS) S[i * n + jc] = S[i * n + jc] / dj;
-                    __syncthreads();
-                    const int m = n - jc - 1;
-                    for (int t = tid; t < m * m; t += LM_THREADS) {
-                        const int i = jc + 1 + t / m, k = jc + 1 + t % m;
-                        if (k <= i) S[i * n + k] -= S[i * n + jc] * S[k * n + jc];
-                    }
-                    __syncthreads();
-                }
-                // (a one-wavefront form -- lane = column of the trailing matrix, no workgroup barriers -- was measured at 60 instead of
-                // 29 us per factorisation: its dependent LDS read-modify-write chain is longer than 3 x 42 barriers)
+                lm_factor_blocked(S, dg, rdg, Tb, n, &s_fail);
                 LM_TICK(8);
+                lm_subst_blocked(S, bs, rdg, n);
                 if (wv == 0) {
-                    for (int k = 0; k < n; ++k) {
-                        if (lane == 0) bs[k] = bs[k] / dg[k];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                        const double yk = bs[k];
-                        for (int i = k + 1 + lane; i < n; i += 64) bs[i] -= S[i * n + k] * yk;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    }
-                    for (int k = n - 1; k >= 0; --k) {
-                        if (lane == 0) bs[k] = bs[k] / dg[k];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                        const double xk = bs[k];
-                        for (int i = lane; i < k; i += 64) bs[i] -= S[k * n + i] * xk;
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-                    }
                     for (int i = lane; i < n; i += 64) tl_st(xpub + i, bs[i]);
                     if (lane == 0) tl_st(xpub + LM_MAXN, s_fail ? 1.0 : 0.0);
                 }
@@ -537,8 +712,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             LM_TICK(9);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
             LM_TICK(10);
-            for (int i = tid; i < n; i += LM_THREADS) xp[i] = tl_ld(xpub + i);
-            const bool ok2 = tl_ld(xpub + LM_MAXN) == 0.0;
+            for (int i = tid; i < n; i += LM_THREADS) xp[i] = xpub[i];
+            const bool ok2 = xpub[LM_MAXN] == 0.0;
             __syncthreads();
             // ---- 4. x_l, update(x), computeScale; then computeActiveErrors at the trial state -- per part
             if (ok2 && tid < Kf) {
@@ -601,7 +776,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             double scale = 0.0, tempChi = DBL_MAX;
             if (ok2) {
                 tempChi = 0.0;
-                for (int v = 0; v < LM_V; ++v) { scale += tl_ld(part + (size_t)v * LM_PARTW + 3); tempChi += tl_ld(part + (size_t)v * LM_PARTW + 4); }
+                for (int v = 0; v < LM_V; ++v) { scale += part[(size_t)v * LM_PARTW + 3]; tempChi += part[(size_t)v * LM_PARTW + 4]; }
                 for (int a = 0; a < Kf; ++a) for (int d = 0; d < 6; ++d) scale += xp[6 * a + d] * (lambda * xp[6 * a + d] + sH[a][21 + d]);
             }
             rho = (currentChi - tempChi) / (scale + 1e-3);
@@ -645,6 +820,13 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 
 extern "C" {
 
+int ygz_hip_ba_set_team_budget(ygz_hip_ctx *ctx, int workgroups)
+{
+    if (!ctx || workgroups < 0) return YGZ_E_INVALID;
+    ctx->lm_team_budget = workgroups > ctx->n_cu ? ctx->n_cu : workgroups;
+    return YGZ_OK;
+}
+
 int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, int max_iterations, ygz_ba_stats *stats)
 {
     YgzDeviceGuard dg_(ctx);
@@ -662,12 +844,12 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     // resident together -- also beside the kernels of other streams and of the offline run's tracking lanes), G a power of two
     int G = 1, Kmax = 1;
     static const bool single = [] { const char *e = getenv("YGZ_BA_LM_TEAM"); return e && e[0] == '1' && e[1] == 0; }();   // A/B switch: one workgroup per window
-    const int wg_budget = ctx->n_cu / 2 > 8 ? ctx->n_cu / 2 : 8;
+    const int wg_budget = ctx->lm_team_budget > 0 ? ctx->lm_team_budget : (ctx->n_cu / 2 > 8 ? ctx->n_cu / 2 : 8);
     // up to 4 x LM_V members: the members beyond LM_V own no part of the points -- they only take (pose pair, part) tasks of the Schur sweep,
     // the longest phase of a trial with four wavefronts per member (28 pairs x 8 parts over 32 wavefronts: 7 rounds; over 64: 3.5)
-    if (!single) while (G < 4 * LM_V && n_windows * (2 * G) <= wg_budget) G *= 2;
+    if (!single) while (G < LM_MAXG && n_windows * (2 * G) <= wg_budget) G *= 2;           // windows x G <= budget
     for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
-    size_t stride = LM_HDR + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)(LM_MAXKF * (LM_MAXKF + 1) / 2) * LM_V * LM_SPW
+    size_t stride = LM_HDR + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)LM_NPAIR * LM_V * LM_SPW + (size_t)LM_NPAIR * LM_SPW
                                            + (size_t)G * Kmax * (6 + 6 + BA_POSED));
     stride = (stride + 255) & ~(size_t)255;
     const size_t stats_bytes = (((size_t)n_windows * sizeof(ygz_ba_stats)) + 255) & ~(size_t)255;
@@ -689,7 +871,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     if (A.dbg) {
         long long h[16];
         static const char *const nm[16] = { "linearise + pose sums", "barrier", "combine parts", "Dinv, Y = Hpl Dinv", "barrier", "Schur sweep", "barrier",
-                                            "assemble S", "Cholesky", "substitutions", "barrier", "block sums of the update", "barrier", "accept / reject",
+                                            "load S", "L D L^T", "substitutions", "barrier", "block sums of the update", "barrier", "accept / reject",
                                             "pose update (oplus, SE3::exp)", "point update + trial chi2" };
         YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

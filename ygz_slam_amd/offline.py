@@ -293,6 +293,8 @@ class OfflineVO:
             # rank's windows per launch (at most 8) on a long shard, all of them in one launch on a short one
             self.lm_group = min(8, len(self.mine) // 2) if self.count > 256 else min(8, len(self.mine))
         self.lm_group = max(1, self.lm_group)
+        self.bg_team_budget = int(_os.environ.get("YGZ_OFF_BG_BUDGET", "0"))
+        self.lm_sched = [max(1, int(x)) for x in _os.environ.get("YGZ_OFF_LM_SCHED", "").split(",") if x.strip()]
         self.ba = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(8, self.build_group * K1), device=device)
         self.rows_t = None
         if world > 1 and self.any_cross:                                          # rows of other ranks arrive by a collective: torch owns the memory
@@ -341,6 +343,7 @@ class OfflineVO:
         chunks = chunk_schedule(first, last, self.chunk, self.ramp)
         pending = [None] * len(self.lanes)
         self._ba_done, self._ba_built = set(), []
+        self._lm_launches = 0
         self._last_upload = None
         for ci, (c0, c1) in enumerate(chunks):
             li = ci % len(self.lanes)
@@ -356,13 +359,23 @@ class OfflineVO:
                 new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and self.wins[i][-1] < c1]
                 self._ba_launch(new, optimize=False)
                 self._ba_built += new
-                if len(self._ba_built) >= self.lm_group or ci == len(chunks) - 1:
+                if len(self._ba_built) >= self._lm_next() or ci == len(chunks) - 1:
+                    # beside the tracking of the next chunks a launch keeps to a few CUs (its members each own one, and wait for it while a
+                    # tracking workgroup drains); the last launch, which nothing runs beside, takes the default half of the device
+                    self.ba.ba_set_team_budget(self.bg_team_budget if ci < len(chunks) - 1 else 0)
                     self._ba_optimize(self._ba_built)
                     self._ba_built = []
+                    self._lm_launches += 1
         for li in range(len(self.lanes)):
             if pending[li] is not None:
                 self._collect(li, pending[li], rec)
         return rec
+
+    def _lm_next(self):
+        """windows the next resident-LM launch waits for: lm_group, or the k-th entry of the schedule (YGZ_OFF_LM_SCHED, experiment)"""
+        if self.lm_sched:
+            return self.lm_sched[min(self._lm_launches, len(self.lm_sched) - 1)]
+        return self.lm_group
 
     def _enqueue(self, li, c0, c1, frame_source, depth_source, block_source):
         c = self.lanes[li]
@@ -515,6 +528,7 @@ class OfflineVO:
         if rest:
             if self.world > 1:                                 # relative poses of the frames other ranks tracked
                 self.ba.kf_store_set_trel(0, T_rel)
+            self.ba.ba_set_team_budget(0)
             self._ba_launch(rest)
         self.ba.synchronize()
         t1 = time.perf_counter()
