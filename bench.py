@@ -18,6 +18,10 @@ import time
 
 import numpy as np
 
+# the offline run with gray frames keeps 4 tracking lanes + the BA context = 5 HIP streams busy; the runtime maps streams onto 4 hardware
+# queues unless told otherwise, and streams that share a queue serialise.  Read when the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -359,7 +363,7 @@ def cpu_offline_baseline(bgr, dimg, vo, budget_s=12.0):
 
 
 def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=1, chunk=128, probe="k_klt", one_dev=False, cpu_baseline_s=0.0,
-                overlap=False, lm_group=None, lanes=3):
+                overlap=False, lm_group=None, lanes=None):
     """BASELINE configs[4] on the frames offline_render produced: one sequence sharded over the ranks (strong scaling).  A step = one
     complete offline run; the timed region holds every upload, kernel, result copy, collective and the BA round.  Returns the result
     dict on rank 0 (None elsewhere)."""
@@ -369,6 +373,10 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     need, n_frames, count = R["need"], R["n_frames"], R["count"]
     gray_in = upload == "gray"                                # the caller hands gray frames over (cv::cvtColor's fixed-point weights, on the host)
     chunk = min(chunk, max(32, -(-count // 4)))               # a shard is cut into >= 4 chunks: uploads, kernels and the BA windows of a rank overlap
+    if lanes is None:
+        # BGR frames: the run is PCIe-bound, three lanes keep the link busy (four: 57.1 against 56.0 ms of tracking per 1024 frames);
+        # gray frames: kernel-bound, a fourth lane fills more of the GPU (38.6 against 40.1 ms)
+        lanes = 4 if gray_in else 3
     pin = _lib.PinnedArray((len(need), H_, W_) if gray_in else (len(need), H_, W_, 3), np.uint8)
     dpin = _lib.PinnedArray((len(need), H_ // DEPTH_DIV, W_ // DEPTH_DIV), np.uint16)
     vo = offline.OfflineVO(W_, H_, n_frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
@@ -508,7 +516,7 @@ def main():
     ap.add_argument("--offline-frames", type=int, default=1024, help="length of the configs[4] sequence measured for the `offline` block of the default line")
     ap.add_argument("--lane-overlap", action="store_true", help="offline mode: side streams inside each tracking lane (measured slower: the two lanes "
                                                                "and the BA context already fill the GPU and the hardware queues)")
-    ap.add_argument("--lanes", type=int, default=3, help="offline mode: tracking contexts that take the chunks in turn")
+    ap.add_argument("--lanes", type=int, default=None, help="offline mode: tracking contexts that take the chunks in turn (default: 3 with BGR frames, 4 with gray frames)")
     ap.add_argument("--lm-group", type=int, default=None, help="offline mode: BA windows per resident-LM launch")
     ap.add_argument("--no-extras", action="store_true", help="default mode: skip the `offline` and `stream` blocks (the timed region is the same either way)")
     ap.add_argument("--upload", default="bgr", choices=["bgr", "gray"], help="stream mode: what crosses PCIe per frame (3 or 1 byte per pixel)")
@@ -670,7 +678,9 @@ def main():
         one_dev = os.environ.get("YGZ_BENCH_ONE_DEVICE") == "1"
         try:
             off = offline_run(R_off, rank, world, local_rank, dist, upload="bgr", steps=2, warmup=1, one_dev=one_dev)
-            off_g = offline_run(R_off, rank, world, local_rank, dist, upload="gray", steps=2, warmup=1, one_dev=one_dev)
+            # (three lanes here: this process still holds the streams of the step pipeline, and the runtime deals hardware queues to
+            # streams in creation order -- with a fourth lane two of them ended up on one queue: 19.6 k instead of 23.3 k standalone)
+            off_g = offline_run(R_off, rank, world, local_rank, dist, upload="gray", steps=2, warmup=1, one_dev=one_dev, lanes=3)
             if rank == 0:
                 keep = ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "config", "phases_ms", "result_check")
                 res["offline"] = {k: off[k] for k in keep}

@@ -896,6 +896,14 @@ def test_ba_optimize_resident_team_size_invariance(hip_lib):
         if ref is None:
             ref = cur
         assert cur == ref, n_launch
+    # the same through the team budget (ygz_hip_ba_set_team_budget): 1 window with 32, 4 and 1 workgroups
+    for budget in (0, 4, 1):
+        ctx.ba_set_team_budget(budget)
+        ctx.ba_set_state(0, w["poses"], w["points"])
+        st = ctx.ba_optimize_resident(0, 1, iterations=20)[0]
+        pg, tg = ctx.ba_get_state(0, len(w["poses"]), len(w["points"]))
+        assert (st.iterations, st.lm_trials, st.chi2_initial, st.chi2_final, st.lambda_final, pg.tobytes(), tg.tobytes()) == ref, budget
+    ctx.ba_set_team_budget(0)
     ctx.close()
 
 
