@@ -254,7 +254,7 @@ class OfflineVO:
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
                  max_points=2000, ba_iterations=20, overlap=False, process_group=None, exchange_on_device=True, keep=False, lanes=3,
-                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None):
+                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None, upload_ahead=0):
         from . import _lib
         self.lib = _lib
         self.w, self.h, self.levels = width, height, levels
@@ -271,6 +271,11 @@ class OfflineVO:
         self.device = device
         n_slots = min(self.count, chunk) + 1
         n_lanes = max(1, min(lanes, -(-self.count // chunk)))                     # never more lanes than chunks
+        # `depth` chunks compute at a time; with upload_ahead > 0 there are more contexts than that, and the kernels of chunk i wait for
+        # chunk i - depth while its upload (first in its stream) does not: the link runs ahead of the kernels by upload_ahead chunks
+        self.depth = n_lanes
+        if n_lanes == lanes:
+            n_lanes += max(0, int(_os.environ.get("YGZ_OFF_AHEAD", upload_ahead)))
         self.lanes = []
         for _ in range(n_lanes):
             c = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
@@ -349,7 +354,7 @@ class OfflineVO:
             li = ci % len(self.lanes)
             if pending[li] is not None:
                 self._collect(li, pending[li], rec)
-            pending[li] = self._enqueue(li, c0, c1, frame_source, depth_source, block_source)
+            pending[li] = self._enqueue(li, c0, c1, frame_source, depth_source, block_source, ci)
             if self.keep:                                      # parity runs read everything back before the lane moves on
                 self._collect(li, pending[li], rec); pending[li] = None
             if self.pipeline_ba:
@@ -377,7 +382,7 @@ class OfflineVO:
             return self.lm_sched[min(self._lm_launches, len(self.lm_sched) - 1)]
         return self.lm_group
 
-    def _enqueue(self, li, c0, c1, frame_source, depth_source, block_source):
+    def _enqueue(self, li, c0, c1, frame_source, depth_source, block_source, ci=0):
         c = self.lanes[li]
         frames = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))      # one-frame halo: the predecessor of the chunk
         slot_of = {f: k for k, f in enumerate(frames)}
@@ -396,6 +401,8 @@ class OfflineVO:
             c.upload_bgr_batch(0, img, wait=not asyn)
         c.upload_depth_batch(0, dimg, self.depth_scale, wait=not asyn)
         c.mark(); self._last_upload = c
+        if len(self.lanes) > self.depth and ci >= self.depth:
+            c.stream_wait(self.lanes[(ci - self.depth) % len(self.lanes)])      # at most `depth` chunks' kernels share the GPU
         c.build_pyramid(0, n, from_bgr=img.ndim != 3)
         c.detect(0, n)
         c.keypoint_depths_from_image(0, n)                     # Feature::_depth / _mappoint of the fresh keypoints
