@@ -27,6 +27,7 @@
 #define LM_WAVES   (LM_THREADS / 64)
 #define LM_MAXKF   14
 #define LM_MAXN    (6 * LM_MAXKF)
+#define LM_RB      4                                    // rows (edges of a point) whose blocks a lane requests together
 #define LM_LDSK    16                                   // windows of up to 16 poses keep their per-pose tables in LDS
 
 #define lm_wave_sum ygz_wave_sum_d
@@ -79,29 +80,32 @@ __device__ void lm_oplus_pose(double pose[6], const double upd[6])
     pose[0] = r[3]; pose[1] = r[4]; pose[2] = r[5]; pose[3] = r[0]; pose[4] = r[1]; pose[5] = r[2];
 }
 
-// ba_point_chi2 with the inputs of row c + 1 in flight while row c is evaluated: in the resident loop a thread owns one point and its
+// ba_point_chi2 with the inputs of LM_RB rows requested together: in the resident loop a thread owns one point and its
 // edge loop is a chain of dependent round trips to L2 (measured: 53 us per trial for 16 such iterations), not arithmetic
 __device__ __forceinline__ double lm_point_chi2_pf(const BaDev &B, int il)
 {
     const int lane = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
     double sum = 0.0;
-    int n_ip = -1, n_en = 0; double n_ox = 0, n_oy = 0, n_hub = 0;
-#define LM_FETCH_(row_)                                                                                            \
-    { n_ip = B.pose_c[(size_t)(row_) * 64 + lane]; n_en = B.enable_c[(size_t)(row_) * 64 + lane];                   \
-      n_ox = BA_EC(B.obs_c, row_, 2, 0, lane); n_oy = BA_EC(B.obs_c, row_, 2, 1, lane); n_hub = B.huber_c[(size_t)(row_) * 64 + lane]; }
-    if (rows > 0) LM_FETCH_(row0)
-    for (int c = 0; c < rows; ++c) {
-        const int ip = n_ip, en = n_en;
-        const double ox = n_ox, oy = n_oy, hub = n_hub;
-        if (c + 1 < rows) LM_FETCH_(row0 + c + 1)
-        if (ip < 0 || !en) continue;
-        double p[3], r[2], rho0, rho1;
-        ba_project(B, B.posed + BA_POSED * (size_t)ip, pt, ox, oy, p, r);
-        ba_robust(r[0] * r[0] + r[1] * r[1], hub, &rho0, &rho1);
-        sum += rho0;
+    for (int c0 = 0; c0 < rows; c0 += LM_RB) {
+        int ipg[LM_RB], eng[LM_RB]; double oxg[LM_RB], oyg[LM_RB], hubg[LM_RB];
+#pragma unroll
+        for (int u = 0; u < LM_RB; ++u) {
+            const bool in_ = c0 + u < rows;
+            const size_t row = (size_t)(row0 + c0 + u);
+            ipg[u] = in_ ? B.pose_c[row * 64 + lane] : -1; eng[u] = in_ ? B.enable_c[row * 64 + lane] : 0;
+            oxg[u] = in_ ? BA_EC(B.obs_c, row, 2, 0, lane) : 0.0; oyg[u] = in_ ? BA_EC(B.obs_c, row, 2, 1, lane) : 0.0;
+            hubg[u] = in_ ? B.huber_c[row * 64 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < LM_RB; ++u) {
+            if (ipg[u] < 0 || !eng[u]) continue;
+            double p[3], r[2], rho0, rho1;
+            ba_project(B, B.posed + BA_POSED * (size_t)ipg[u], pt, oxg[u], oyg[u], p, r);
+            ba_robust(r[0] * r[0] + r[1] * r[1], hubg[u], &rho0, &rho1);
+            sum += rho0;
+        }
     }
-#undef LM_FETCH_
     return sum;
 }
 
@@ -580,31 +584,35 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     for (int d = 0; d < 3; ++d) B.points_bk[3 * (size_t)il + d] = B.points_w[3 * (size_t)il + d];
                     double *Di = B.Dinv + 9 * (size_t)il;
                     if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; continue; }
+                    // the blocks of LM_RB rows (edges of the point) are requested together, the first group before the inverse is formed: the
+                    // loop was a chain of one L2 round trip per edge (14 us per trial for <= 8 edges), its arithmetic is 54 multiply-adds
+                    const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+                    double Wg[LM_RB][18]; int ipg[LM_RB];
+#define LM_LOADG_(c0_)                                                                                                   \
+                    _Pragma("unroll") for (int u = 0; u < LM_RB; ++u) {                                                   \
+                        const bool in_ = (c0_) + u < rows;                                                               \
+                        ipg[u] = in_ ? B.pose_c[(size_t)(row0 + (c0_) + u) * 64 + ln] : -1;                                \
+                        _Pragma("unroll") for (int i = 0; i < 18; ++i) Wg[u][i] = in_ ? BA_EC(B.Hpl_c, row0 + (c0_) + u, 18, i, ln) : 0.0; }
+                    LM_LOADG_(0)
                     double D[9], Dv[9];
                     for (int i = 0; i < 9; ++i) D[i] = BA_PC(B.Hll_c, il, 9, i);
                     D[0] += lambda; D[4] += lambda; D[8] += lambda;
                     if (!lm_inv3(D, Dv)) { bad = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
                     for (int i = 0; i < 9; ++i) Di[i] = Dv[i];
-                    const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
-                    double Wn[18]; int ipn = -1;                               // row c + 1 is in flight while row c is multiplied
-                    if (rows > 0) { ipn = B.pose_c[(size_t)row0 * 64 + ln];
+                    for (int c0 = 0; c0 < rows; c0 += LM_RB) {
+                        if (c0 > 0) LM_LOADG_(c0)
 #pragma unroll
-                                    for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row0, 18, i, ln); }
-                    for (int c = 0; c < rows; ++c) {
-                        const int row = row0 + c, ipc = ipn;
-                        double W[18];
+                        for (int u = 0; u < LM_RB; ++u) {
+                            if (c0 + u >= rows || ipg[u] < 0) continue;
+                            const int row = row0 + c0 + u;
 #pragma unroll
-                        for (int i = 0; i < 18; ++i) W[i] = Wn[i];
-                        if (c + 1 < rows) { ipn = B.pose_c[(size_t)(row + 1) * 64 + ln];
+                            for (int r = 0; r < 6; ++r)
 #pragma unroll
-                                            for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row + 1, 18, i, ln); }
-                        if (ipc < 0) continue;
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < 3; ++cc)
-                                BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = W[3 * r] * Dv[cc] + W[3 * r + 1] * Dv[3 + cc] + W[3 * r + 2] * Dv[6 + cc];
+                                for (int cc = 0; cc < 3; ++cc)
+                                    BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = Wg[u][3 * r] * Dv[cc] + Wg[u][3 * r + 1] * Dv[3 + cc] + Wg[u][3 * r + 2] * Dv[6 + cc];
+                        }
                     }
+#undef LM_LOADG_
                 }
             }
             if (bad) s_fail = 1;
@@ -736,22 +744,22 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         else {
                             double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
                             const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
-                            double Wn[18]; int ipn = -1;                       // row c + 1 is in flight while row c is accumulated
-                            if (rows > 0) { ipn = B.pose_c[(size_t)row0 * 64 + ln];
+                            for (int c0 = 0; c0 < rows; c0 += LM_RB) {         // the blocks of LM_RB rows requested together (see step 1), used in row order
+                                double Wg[LM_RB][18]; int ipg[LM_RB];
 #pragma unroll
-                                            for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row0, 18, i, ln); }
-                            for (int c = 0; c < rows; ++c) {
-                                const int row = row0 + c, ip = ipn;
-                                double W[18];
+                                for (int u = 0; u < LM_RB; ++u) {
+                                    const bool in_ = c0 + u < rows;
+                                    ipg[u] = in_ ? B.pose_c[(size_t)(row0 + c0 + u) * 64 + ln] : -1;
 #pragma unroll
-                                for (int i = 0; i < 18; ++i) W[i] = Wn[i];
-                                if (c + 1 < rows) { ipn = B.pose_c[(size_t)(row + 1) * 64 + ln];
+                                    for (int i = 0; i < 18; ++i) Wg[u][i] = in_ ? BA_EC(B.Hpl_c, row0 + c0 + u, 18, i, ln) : 0.0;
+                                }
 #pragma unroll
-                                                    for (int i = 0; i < 18; ++i) Wn[i] = BA_EC(B.Hpl_c, row + 1, 18, i, ln); }
-                                if (ip < 0) continue;
-                                const int a = B.free_idx[ip];
-                                if (a < 0) continue;
-                                for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= W[3 * r + cc] * xp[6 * a + r];
+                                for (int u = 0; u < LM_RB; ++u) {
+                                    if (ipg[u] < 0) continue;
+                                    const int a = B.free_idx[ipg[u]];
+                                    if (a < 0) continue;
+                                    for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= Wg[u][3 * r + cc] * xp[6 * a + r];
+                                }
                             }
                             const double *Di = B.Dinv + 9 * (size_t)il;
                             double x3[3];
