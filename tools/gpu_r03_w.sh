@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r03w
 timeout 900 python -m pytest tests -q -m gpu --no-header -rf -x 2>&1 | tail -4
-bash tools/collect_profiles.sh r03_v2 > gpurun_out/r03w/collect.log 2>&1; tail -3 gpurun_out/r03w/collect.log
+bash tools/collect_profiles.sh r03_v3 > gpurun_out/r03w/collect.log 2>&1; tail -3 gpurun_out/r03w/collect.log
 bash tools/pmc_one_pass.sh > gpurun_out/r03w/sq.log 2>&1; tail -2 gpurun_out/r03w/sq.log | cut -c1-200
 bash tools/timeline.sh > gpurun_out/r03w/timeline.log 2>&1; tail -2 gpurun_out/r03w/timeline.log | cut -c1-200
 timeout 500 python bench.py > gpurun_out/r03w/bench_default.json 2> gpurun_out/r03w/bench_default.err; tail -c 1500 gpurun_out/r03w/bench_default.json
