@@ -1,0 +1,108 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): tools/gpu_r04.sh <batch-name> -- the measurement batches of round 4, one function per batch.
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+B=${1:-a}
+OUT=gpurun_out/r04$B
+mkdir -p $OUT
+benchline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-24s %9.1f frames/s  ms %.3f" % (sys.argv[2], d["value"], d["ms_per_step"]))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
+STEP="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras"
+case $B in
+a)  # second form of k_sparse_align + framed copies written by the pyramid kernels: parity, bit-identity against the first forms, timing
+    timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 python tools/step_dump.py $OUT/d_old.npz > $OUT/dump.log 2>&1
+    python tools/step_dump.py $OUT/d_new.npz >> $OUT/dump.log 2>&1
+    YGZ_SA_HINLINE=0 python tools/step_dump.py $OUT/d_new_b.npz >> $OUT/dump.log 2>&1
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 python tools/step_dump.py $OUT/d7_old.npz --size 720p --batch 8 >> $OUT/dump.log 2>&1
+    python tools/step_dump.py $OUT/d7_new.npz --size 720p --batch 8 >> $OUT/dump.log 2>&1
+    python tools/step_dump.py --compare $OUT/d_old.npz $OUT/d_new.npz
+    python tools/step_dump.py --compare $OUT/d_old.npz $OUT/d_new_b.npz
+    python tools/step_dump.py --compare $OUT/d7_old.npz $OUT/d7_new.npz
+    tail -5 $OUT/dump.log
+    for f in 0 1; do YGZ_SA_FORM=$f python tools/stage_bench.py sparse --batch 512 --reps 5; done
+    YGZ_SA_HINLINE=0 python tools/stage_bench.py sparse --batch 512 --reps 5
+    YGZ_SA_PLDS=0 python tools/stage_bench.py sparse --batch 512 --reps 5
+    YGZ_SA_FORM=0 python tools/stage_bench.py sparse --batch 256 --reps 5
+    python tools/stage_bench.py sparse --batch 256 --reps 5
+    YGZ_PAD_FUSE=0 python tools/stage_bench.py klt --batch 512 --reps 5
+    python tools/stage_bench.py klt --batch 512 --reps 5
+    YGZ_PAD_FUSE=0 python tools/stage_bench.py pyramid --batch 512 --reps 5
+    python tools/stage_bench.py pyramid --batch 512 --reps 5
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 benchline old $STEP
+    YGZ_SA_FORM=1 YGZ_PAD_FUSE=0 benchline sa2 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=1 benchline fuse $STEP
+    benchline new $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 benchline old_b $STEP
+    benchline new_b $STEP
+    ;;
+b)  # why the step got slower with the faster sparse alignment / without k_klt_pad: footprint and schedule matrix, two timelines
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 benchline base $STEP
+    YGZ_SA_PLDS=0 YGZ_SA_HINLINE=0 YGZ_PAD_FUSE=0 benchline sa2_p0_h0 $STEP
+    YGZ_SA_PLDS=0 YGZ_SA_HINLINE=1 YGZ_PAD_FUSE=0 benchline sa2_p0_h1 $STEP
+    YGZ_SA_HINLINE=0 YGZ_PAD_FUSE=0 benchline sa2_p960_h0 $STEP
+    YGZ_SA_LDS=512 YGZ_SA_PLDS=512 YGZ_SA_HINLINE=0 YGZ_PAD_FUSE=0 benchline sa2_l512_p512_h0 $STEP
+    YGZ_SA_LDS=512 YGZ_SA_PLDS=0 YGZ_SA_HINLINE=0 YGZ_PAD_FUSE=0 benchline sa2_l512_p0_h0 $STEP
+    YGZ_SA_FORM=0 YGZ_SA_LDS=512 YGZ_PAD_FUSE=0 benchline sa1_l512 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=6 benchline fuse_join6 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=7 benchline fuse_join7 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=2 benchline fuse_join2 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=4 benchline fuse_join4 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 YGZ_KLT_JOIN=6 benchline nofuse_join6 $STEP
+    YGZ_SA_PLDS=0 YGZ_SA_HINLINE=0 YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=6 benchline sa2_p0_h0_fuse_join6 $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 benchline base_b $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=1 bash tools/timeline.sh r04b_tl_fuse > /dev/null 2>&1
+    YGZ_SA_FORM=1 YGZ_PAD_FUSE=0 bash tools/timeline.sh r04b_tl_sa2 > /dev/null 2>&1
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 bash tools/timeline.sh r04b_tl_base > /dev/null 2>&1
+    ;;
+c)  # resident sparse-alignment workgroups (no second round to starve), flat frame kernel
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 python tools/step_dump.py $OUT/d_old.npz > $OUT/dump.log 2>&1
+    python tools/step_dump.py $OUT/d_new.npz >> $OUT/dump.log 2>&1
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 python tools/step_dump.py $OUT/d_old5.npz --batch 520 >> $OUT/dump.log 2>&1
+    python tools/step_dump.py $OUT/d_new5.npz --batch 520 >> $OUT/dump.log 2>&1
+    python tools/step_dump.py --compare $OUT/d_old.npz $OUT/d_new.npz
+    python tools/step_dump.py --compare $OUT/d_old5.npz $OUT/d_new5.npz
+    python tools/stage_bench.py sparse --batch 512 --reps 5
+    YGZ_SA_PERSIST=0 python tools/stage_bench.py sparse --batch 512 --reps 5
+    python tools/stage_bench.py pyramid --batch 512 --reps 5
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 benchline base $STEP
+    YGZ_PAD_FUSE=0 benchline persist $STEP
+    YGZ_PAD_FUSE=1 benchline persist_fuse $STEP
+    YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=6 benchline persist_fuse_join6 $STEP
+    YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=2 benchline persist_fuse_join2 $STEP
+    YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=4 benchline persist_fuse_join4 $STEP
+    YGZ_PAD_FUSE=1 YGZ_KLT_JOIN=1 benchline persist_fuse_join1 $STEP
+    YGZ_PAD_FUSE=1 YGZ_SA_HINLINE=1 benchline persist_fuse_h1 $STEP
+    YGZ_PAD_FUSE=1 YGZ_SA_PLDS=0 benchline persist_fuse_p0 $STEP
+    YGZ_PAD_FUSE=1 YGZ_BENCH_KLT_PREPARE=1 benchline persist_fuse_prep $STEP
+    YGZ_PAD_FUSE=0 YGZ_SA_PERSIST=0 benchline nopersist $STEP
+    YGZ_SA_FORM=0 YGZ_PAD_FUSE=0 benchline base_b $STEP
+    YGZ_PAD_FUSE=1 bash tools/timeline.sh r04c_tl_persist_fuse > /dev/null 2>&1
+    YGZ_PAD_FUSE=0 bash tools/timeline.sh r04c_tl_persist > /dev/null 2>&1
+    ;;
+d)  # resident grid size, register cap, LK working images beside the extractor
+    benchline dflt $STEP
+    YGZ_BENCH_KLT_PREPARE=1 benchline prep $STEP
+    YGZ_SA_GRID=128 benchline grid128 $STEP
+    YGZ_SA_GRID=192 benchline grid192 $STEP
+    YGZ_SA_GRID=224 benchline grid224 $STEP
+    YGZ_SA_GRID=128 YGZ_BENCH_KLT_PREPARE=1 benchline grid128_prep $STEP
+    YGZ_SA_GRID=192 YGZ_BENCH_KLT_PREPARE=1 benchline grid192_prep $STEP
+    YGZ_SA_REGS=288 benchline r288 $STEP
+    YGZ_SA_REGS=288 YGZ_BENCH_KLT_PREPARE=1 benchline r288_prep $STEP
+    YGZ_SA_REGS=288 YGZ_SA_PLDS=0 benchline r288_p0 $STEP
+    YGZ_SA_LDS=512 YGZ_SA_PLDS=512 benchline l512_p512 $STEP
+    YGZ_BENCH_BA_EARLY=1 benchline ba_early $STEP
+    YGZ_BENCH_BA_EARLY=1 YGZ_BENCH_KLT_PREPARE=1 benchline ba_early_prep $STEP
+    YGZ_SA_REGS=288 python tools/stage_bench.py sparse --batch 512 --reps 5
+    benchline dflt_b $STEP
+    ;;
+*)  echo "unknown batch $B"; exit 2 ;;
+esac

@@ -1,13 +1,14 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel timeline (start / end per dispatch, microseconds from the first dispatch of the step) of the LAST
-# step of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras`, from one rocprofv3 --kernel-trace run.  -> gpurun_out/timeline.txt
+# step of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras`, from one rocprofv3 --kernel-trace run.  -> gpurun_out/<tag>.txt (tools/timeline.sh <tag>)
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/timeline
+TAG=${1:-timeline}          # output: gpurun_out/<tag>.txt (experiment switches come from the environment)
+OUT=$R/gpurun_out/tl_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 200 rocprofv3 --kernel-trace -d $OUT/raw -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/log.txt 2>&1
 DB=$(find $OUT/raw -name '*.db' | head -1)
-python - "$DB" > $R/gpurun_out/timeline.txt <<'PY'
+python - "$DB" > $R/gpurun_out/$TAG.txt <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]

@@ -98,7 +98,7 @@ int ygz_hip_upload_bgr_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, cons
     if (!ctx->bgr) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->bgr, (size_t)ctx->prm.max_frames * fb + 64));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->bgr + (size_t)slot_begin * fb, bgr, (size_t)n_slots * fb, hipMemcpyHostToDevice, ctx->stream));
     if (wait) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 0;
+    for (int s = slot_begin; s < slot_begin + n_slots; ++s) { ctx->pyr_valid[s] = 0; ctx->pad_levels[s] = 0; }
     return YGZ_OK;
 }
 
@@ -110,7 +110,7 @@ int ygz_hip_upload_gray_batch(ygz_hip_ctx *ctx, int slot_begin, int n_slots, con
     const size_t fb = (size_t)ctx->lw[0] * ctx->lh[0];
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->lvl[0] + (size_t)slot_begin * fb, gray, (size_t)n_slots * fb, hipMemcpyHostToDevice, ctx->stream));
     if (wait) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pyr_valid[s] = 0;
+    for (int s = slot_begin; s < slot_begin + n_slots; ++s) { ctx->pyr_valid[s] = 0; ctx->pad_levels[s] = 0; }
     return YGZ_OK;
 }
 

@@ -155,6 +155,7 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
         if (hipMemsetAsync(ctx->n_kp, 0, F * 4, ctx->stream) != hipSuccess ||
             hipMemsetAsync(ctx->occupied, 0, F * Cn, ctx->stream) != hipSuccess) { rc = YGZ_E_HIP; break; }
         ctx->pyr_valid.assign(F, 0);
+        ctx->pad_levels.assign(F, 0);
     } while (0);
     if (rc != YGZ_OK) { ygz_hip_destroy(ctx); return rc; }
     *out = ctx;
@@ -354,7 +355,7 @@ int ygz_hip_upload_bgr(ygz_hip_ctx *ctx, int slot, const uint8_t *bgr, int strid
     YGZ_HIPCHK(ctx, hipMemcpy2DAsync(ctx->bgr + (size_t)slot * w * h * 3, (size_t)w * 3, bgr, (size_t)stride_bytes,
                                      (size_t)w * 3, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pyr_valid[slot] = 0;
+    ctx->pyr_valid[slot] = 0; ctx->pad_levels[slot] = 0;
     return YGZ_OK;
 }
 
@@ -368,7 +369,7 @@ int ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int str
     YGZ_HIPCHK(ctx, hipMemcpy2DAsync(ctx->lvl[0] + (size_t)slot * w * h, (size_t)w, gray, (size_t)stride_bytes,
                                      (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pyr_valid[slot] = 0;
+    ctx->pyr_valid[slot] = 0; ctx->pad_levels[slot] = 0;
     return YGZ_OK;
 }
 

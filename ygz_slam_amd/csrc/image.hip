@@ -11,8 +11,12 @@ __device__ __forceinline__ uint32_t gray1(uint32_t b, uint32_t g, uint32_t r)
 }
 
 // 16 pixels per lane: 3 x 16-byte loads, 1 x 16-byte store.  npix % 16 == 0.
+// pad != nullptr (needs w % 16 == 0): the same 16 pixels also go into the interior of the tracker's framed copy of level 0
+// (klt.hip; 8-byte aligned there), so that no separate copy kernel has to re-read the level.
+typedef uint32_t img_u32x4 __attribute__((ext_vector_type(4)));
+typedef img_u32x4 __attribute__((aligned(4))) img_u32x4u;
 __global__ __launch_bounds__(256) void k_bgr2gray16(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
-                                                    unsigned npix, int slot_begin)
+                                                    unsigned npix, int slot_begin, uint8_t *__restrict__ pad, int width, int height)
 {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;          // group of 16 pixels
     if (i * 16u >= npix) return;
@@ -31,6 +35,12 @@ __global__ __launch_bounds__(256) void k_bgr2gray16(const uint8_t *__restrict__ 
         out[q] = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
     }
     reinterpret_cast<uint4 *>(gray + slot * npix)[i] = make_uint4(out[0], out[1], out[2], out[3]);
+    if (pad) {
+        const unsigned p0 = i * 16u, y = p0 / (unsigned)width, x = p0 - y * (unsigned)width;
+        const size_t pw = (size_t)KLT_PW(width), ph = (size_t)height + 2 * KLT_B;
+        img_u32x4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
+        *reinterpret_cast<img_u32x4u *>(pad + slot * pw * ph + ((size_t)y + KLT_B) * pw + (x + KLT_B)) = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bgr2gray1(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
@@ -59,13 +69,16 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define PD_SW 160          // staged row: source x in [2*ox0 - 16, 2*ox0 + 144): ten 16-byte vectors, 16-byte aligned when sw % 16 == 0
 #define PD_SH (2 * PD_TH + 3)   // source y in [2*oy0 - 2, 2*oy0 + 2*PD_TH + 1)
 #define PD_X0 16           // staged column of source x = 2*ox0
+// pad != nullptr: every result byte also goes into the interior of the tracker's framed copy of the destination level.
 __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                  int sw, int sh, int dw, int dh, int slot_begin)
+                                                  int sw, int sh, int dw, int dh, int slot_begin, uint8_t *__restrict__ pad)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH][PD_SW];
     const size_t slot = (size_t)(slot_begin + blockIdx.z);
     const uint8_t *s = src + slot * (size_t)sw * sh;
     uint8_t *d = dst + slot * (size_t)dw * dh;
+    const int dpw = KLT_PW(dw);
+    uint8_t *pd = pad ? pad + slot * (size_t)dpw * (dh + 2 * KLT_B) + (size_t)KLT_B * dpw + KLT_B : nullptr;
     const int ox0 = blockIdx.x * PD_TW, oy0 = blockIdx.y * PD_TH;
     const int sx0 = 2 * ox0 - PD_X0, sy0 = 2 * oy0 - 2;
     const bool aligned = (sw & 15) == 0;
@@ -118,10 +131,58 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ sr
             const int oy = oy0 + ty0 + k;
             if (oy < dh) {
                 const int v = hrow[2 * k] + 4 * hrow[2 * k + 1] + 6 * hrow[2 * k + 2] + 4 * hrow[2 * k + 3] + hrow[2 * k + 4];
-                d[(size_t)oy * dw + ox] = (uint8_t)((v + 128) >> 8);
+                const uint8_t o8 = (uint8_t)((v + 128) >> 8);
+                d[(size_t)oy * dw + ox] = o8;
+                if (pd) pd[(size_t)oy * dpw + ox] = o8;
             }
         }
     }
+}
+
+// The BORDER_REFLECT_101 frame of the tracker's working images (what buildOpticalFlowPyramid makes with copyMakeBorder), for the levels
+// of a range of slots in ONE launch: the interiors were written by the kernels above, a lane fills one dword of the frame
+// (top and bottom bands, left and right columns of the middle rows; the dwords of all levels form one flat item space, blockIdx.y = slot).  With full != 0 the level-0
+// interior is copied too (level 0 came from a gray upload, not from k_bgr2gray16).
+struct FrameArgs {
+    const uint8_t *img[YGZ_MAX_LEVELS]; uint8_t *pad[YGZ_MAX_LEVELS];
+    int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
+    int first[YGZ_MAX_LEVELS], items[YGZ_MAX_LEVELS];      // first block of each level, its number of items (dwords of frame)
+    int n_levels, slot_begin, full0;
+};
+typedef uint32_t __attribute__((aligned(1))) img_u32u;      // 4 adjacent bytes at any address: one (unaligned) global_load_dword
+__global__ __launch_bounds__(256) void k_klt_frame(FrameArgs A)
+{
+    // a block belongs to ONE level (first[] counts blocks), so the level is wave-uniform
+    int L = 0;
+#pragma unroll
+    for (int k = 1; k < YGZ_MAX_LEVELS; ++k) if (k < A.n_levels && (int)blockIdx.x >= A.first[k]) L = k;
+    const int item = ((int)blockIdx.x - A.first[L]) * 256 + (int)threadIdx.x;
+    if (item >= A.items[L]) return;
+    const int w = A.w[L], h = A.h[L], pw = KLT_PW(w), ph = h + 2 * KLT_B, pw4 = pw >> 2;
+    int y, dc;
+    if (A.full0 && L == 0) { y = item / pw4; dc = item - y * pw4; }      // every dword of the framed level
+    else {
+        const int r0 = (KLT_B + w) >> 2, nr = pw4 - r0, band = KLT_B * pw4, mid = (KLT_B >> 2) + nr;
+        if (item < band) { y = item / pw4; dc = item - y * pw4; }
+        else if (item < 2 * band) { const int j = item - band; y = j / pw4; dc = j - y * pw4; y += KLT_B + h; }
+        else {
+            const int j = item - 2 * band;
+            y = j / mid;
+            const int c = j - y * mid;
+            y += KLT_B;
+            dc = c < (KLT_B >> 2) ? c : r0 + (c - (KLT_B >> 2));
+        }
+    }
+    const size_t slot = (size_t)(A.slot_begin + (int)blockIdx.y);
+    const uint8_t *row = A.img[L] + slot * (size_t)w * h + (size_t)reflect101(y - KLT_B, h) * w;
+    const int x = 4 * dc - KLT_B;
+    uint32_t v = 0;
+    if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const img_u32u *>(row + x);      // inside the row: the bands above and below the image
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)row[reflect101(x + k, w)] << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(A.pad[L] + slot * (size_t)pw * ph + (size_t)y * pw + 4 * dc) = v;
 }
 
 int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr, int up_to_level)
@@ -129,18 +190,40 @@ int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int f
     int rc = ygz_ensure_levels(ctx, up_to_level);
     if (rc != YGZ_OK) return rc;
     const unsigned npix = (unsigned)ctx->lw[0] * (unsigned)ctx->lh[0];
+    // the tracker's framed copies are written along with the levels once its buffers exist (first LK call): no copy kernel per step
+    static const int fuse_env = [] { const char *e = getenv("YGZ_PAD_FUSE"); return e ? atoi(e) : 1; }();
+    bool fuse = fuse_env != 0 && up_to_level >= 1;
+    for (int L = 0; L < up_to_level && fuse; ++L) if (!ctx->klt_pad[L]) fuse = false;
+    const bool l0_fused = fuse && from_bgr && (npix & 15u) == 0 && (ctx->lw[0] & 15) == 0;
     if (from_bgr) {
         if ((npix & 15u) == 0)
             YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray16, dim3(ygz_div_up((int)(npix / 16), 256), n_slots), dim3(256),
-                               ctx->bgr, ctx->lvl[0], npix, slot_begin);
+                               ctx->bgr, ctx->lvl[0], npix, slot_begin, l0_fused ? ctx->klt_pad[0] : (uint8_t *)nullptr, ctx->lw[0], ctx->lh[0]);
         else
             YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray1, dim3(ygz_div_up((int)npix, 256), n_slots), dim3(256),
                                ctx->bgr, ctx->lvl[0], npix, slot_begin);
     }
     for (int L = 1; L < up_to_level; ++L) {
         const int sw = ctx->lw[L - 1], sh = ctx->lh[L - 1], dw = ctx->lw[L], dh = ctx->lh[L];
-        YGZ_LAUNCH(ctx, KID_PYR_DOWN, k_pyr_down, dim3(ygz_div_up(dw, PD_TW), ygz_div_up(dh, PD_TH), n_slots), dim3(256), ctx->lvl[L - 1], ctx->lvl[L], sw, sh, dw, dh, slot_begin);
+        YGZ_LAUNCH(ctx, KID_PYR_DOWN, k_pyr_down, dim3(ygz_div_up(dw, PD_TW), ygz_div_up(dh, PD_TH), n_slots), dim3(256), ctx->lvl[L - 1], ctx->lvl[L], sw, sh, dw, dh, slot_begin,
+                   fuse ? ctx->klt_pad[L] : (uint8_t *)nullptr);
     }
+    if (fuse) {
+        FrameArgs F;
+        for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { F.img[L] = nullptr; F.pad[L] = nullptr; F.w[L] = F.h[L] = 0; F.first[L] = 0; F.items[L] = 0; }
+        int total = 0;                                  // blocks
+        for (int L = 0; L < up_to_level; ++L) {
+            const int w = ctx->lw[L], h = ctx->lh[L], pw4 = KLT_PW(w) >> 2;
+            F.img[L] = ctx->lvl[L]; F.pad[L] = ctx->klt_pad[L]; F.w[L] = w; F.h[L] = h;
+            F.first[L] = total;
+            F.items[L] = (L == 0 && !l0_fused) ? pw4 * (h + 2 * KLT_B) : 2 * KLT_B * pw4 + h * ((KLT_B >> 2) + pw4 - ((KLT_B + w) >> 2));
+            total += ygz_div_up(F.items[L], 256);
+        }
+        F.n_levels = up_to_level; F.slot_begin = slot_begin; F.full0 = l0_fused ? 0 : 1;
+        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_frame, dim3(total, n_slots), dim3(256), F);
+    }
+    if ((int)ctx->pad_levels.size() >= slot_begin + n_slots)
+        for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pad_levels[s] = (uint8_t)(fuse ? up_to_level : 0);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }

@@ -29,8 +29,6 @@
 #include <stdlib.h>
 
 #define KLT_MAXWIN 21
-#define KLT_B      24          // reflect-101 frame around every level (>= window + 1, multiple of 4)
-#define KLT_PW(w)  (((w) + 2 * KLT_B + 3) & ~3)      // framed row pitch, 4-byte aligned for any level width
 
 __device__ __forceinline__ int refl101(int i, int n)
 {
@@ -558,11 +556,18 @@ static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *
         if (!ctx->klt_pad[L]) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_pad[L], (size_t)ctx->prm.max_frames * psz + 64));
         A.pad[L] = ctx->klt_pad[L]; A.deriv[L] = ctx->deriv[L]; A.w[L] = w; A.h[L] = h;
         if (ctx->klt_prep_valid && L < ctx->klt_prep_levels) continue;   // this level's working images were built ahead (ygz_klt_prepare_early)
-        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(ygz_div_up(pw, 16) * ph, 256), 1, ygz_round_up8(ctx->n_klt_slots)), dim3(256),
-                   ctx->lvl[L], ctx->klt_pad[L], ctx->klt_slots, w, h, ctx->n_klt_slots);
+        // the framed copy of a level is normally written by the pyramid kernels (image.hip); k_klt_pad only runs for slots whose pyramid
+        // was built before the tracker's buffers existed (first call) or without the fused stores
+        bool have_pad = (int)ctx->klt_slots_host.size() == ctx->n_klt_slots;
+        for (int i = 0; i < ctx->n_klt_slots && have_pad; ++i) if (ctx->pad_levels[ctx->klt_slots_host[i]] <= L) have_pad = false;
+        if (!have_pad)
+            YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_pad, dim3(ygz_div_up(ygz_div_up(pw, 16) * ph, 256), 1, ygz_round_up8(ctx->n_klt_slots)), dim3(256),
+                       ctx->lvl[L], ctx->klt_pad[L], ctx->klt_slots, w, h, ctx->n_klt_slots);
         YGZ_LAUNCH(ctx, KID_SCHARR, k_scharr, dim3(ygz_div_up(ygz_div_up(w, 4) * ygz_div_up(h, 4), 256), 1, ygz_round_up8(ctx->n_klt_refs)), dim3(256),
                    ctx->klt_pad[L], ctx->deriv[L], ctx->klt_slots + ctx->n_klt_slots, w, h, ctx->n_klt_refs);
     }
+    if ((int)ctx->klt_slots_host.size() == ctx->n_klt_slots)          // every level 0 .. max_level of these slots now has its framed copy
+        for (int i = 0; i < ctx->n_klt_slots; ++i) { uint8_t &pl = ctx->pad_levels[ctx->klt_slots_host[i]]; if (pl < max_level + 1) pl = (uint8_t)(max_level + 1); }
     ctx->klt_prep_valid = false;
     if (prep_only) return YGZ_OK;
     if (ctx->klt_prep_pending) { YGZ_HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0)); ctx->klt_prep_pending = false; }
@@ -576,6 +581,10 @@ static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
     A.dbg = nullptr;
     if (getenv("YGZ_KLT_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_KLT_OUT, (size_t)n_pairs * ctx->cells * 32, &d) == YGZ_OK) { A.dbg = (long long *)d; (void)hipMemsetAsync(d, 0, (size_t)n_pairs * ctx->cells * 32, ctx->stream); } }
+    {   // experiment switch (schedule): the LK kernel waits for the side-stream stages in the mask (bit 0 sparse alignment, 1 BA build, 2 matcher / direct projection)
+        static const int join_mask = [] { const char *e = getenv("YGZ_KLT_JOIN"); return e ? atoi(e) & 7 : 0; }();
+        if (join_mask) { const int rj = ygz_join(ctx, ~(unsigned)join_mask & 7u); if (rj != YGZ_OK) return rj; }
+    }
     if (A.win == KLT_MAXWIN && !A.dbg && !getenv("YGZ_KLT_ONE_POINT")) YGZ_LAUNCH(ctx, KID_KLT, k_klt3, dim3(ygz_div_up(ctx->cells, 12), ygz_round_up8(n_pairs)), dim3(256), A);
     else if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
     else YGZ_LAUNCH(ctx, KID_KLT, k_klt<false>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);

@@ -68,6 +68,7 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
         ctx->n_klt_refs = n - ctx->n_klt_slots;
         if (!ctx->klt_slots) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_slots, (size_t)F * 8));
         if (n > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_slots, h_lst, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->klt_slots_host.assign(h_lst, h_lst + ctx->n_klt_slots);
     }
     ctx->n_pairs = n_pairs;
     ctx->klt_prep_valid = false;

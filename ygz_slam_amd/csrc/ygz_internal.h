@@ -7,6 +7,9 @@
 #include "../../include/ygz_hip.h"
 
 #define YGZ_KLT_LEVELS 5          // Tracker.cpp:97 maxLevel 4 -> 5 levels
+// the tracker's working images: every level inside a reflect-101 frame of KLT_B pixels (klt.hip; written by the pyramid kernels, image.hip)
+#define KLT_B      24          // >= window + 1, multiple of 4
+#define KLT_PW(w)  (((w) + 2 * KLT_B + 3) & ~3)      // framed row pitch, 4-byte aligned for any level width
 #define YGZ_N_SCRATCH  24
 
 struct ygz_hip_ctx {
@@ -31,6 +34,8 @@ struct ygz_hip_ctx {
     int16_t *deriv[YGZ_MAX_LEVELS] = {nullptr};
     uint8_t *klt_pad[YGZ_MAX_LEVELS] = {nullptr};       // reflect-101 framed copies of the levels (KLT working images)
     int32_t *klt_slots = nullptr; int n_klt_slots = 0, n_klt_refs = 0;   // distinct slots of the pair table: [0, n_klt_slots) all, then the reference slots
+    std::vector<int32_t> klt_slots_host;    // the first n_klt_slots entries of klt_slots
+    std::vector<uint8_t> pad_levels;        // per slot: the framed copies of levels [0, pad_levels) match the slot's pyramid (written by the pyramid kernels or by k_klt_pad)
 
     // extractor state per slot
     uint32_t *cell_first = nullptr;         // [F][cells]  min over candidates of (visit<<1 | isnan)
