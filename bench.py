@@ -287,7 +287,7 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
         form = {"1": "k_hamming_mfma (int8 32x32x32)"}.get(os.environ.get("YGZ_HAMMING_FORM", "0"), "k_hamming_f4 (FP4 32x32x64, block scale 2^6)")
         out["mfma"] = {"kernel": form, "bound": "mfma", "unit": "TOP/s", "ops_per_launch": ops, "avg_launch_us": t * 1e6,
                        "achieved": ops / t / 1e12, "peak": 10000.0, "peak_int8": 5000.0, "peak_measured_here_fp4": 7630.0, "peak_measured_here_int8": 4392.0,
-                       "frac": ops / t / 1e12 / 10000.0, "frac_of_int8_peak": ops / t / 1e12 / 5000.0,
+                       "frac": ops / t / 1e12 / 10000.0,
                        "frac_of_measured_fp4_rate": ops / t / 1e12 / 7630.0,
                        "note": "algorithmic ops (unpadded |A| x |B| x 256 x 2).  peak = dense FP4 MFMA of MI355X_MICROARCH.md (~10 PF; its micro-benchmark reaches "
                                "9099, tools/ubench/mfma_f4_probe 7630 with four chains per wavefront: profiles/r03_mfma_f4_probe.txt); peak_int8 = the 5 POP/s the "
@@ -447,8 +447,9 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
                "dtype": "u8/f32/f64", "data": "synthetic",
                "config": {"workload": "BASELINE configs[4]: %d synthetic %dx%d frames, contiguous shards with a one-frame halo, per pair ORB extract + "
                                       "BF cross-check match + good-match filter + KLT 21x21x5 + SparseImgAlign + FindCandidates/FindDirectProjection + "
-                                      "pose-only BA; BA round: windows of 8 keyframes (stride 8) x <= 2000 points built on the device, 20 LM iterations "
-                                      "resident, pipelined behind the tracking chunks; map exchange + trajectory all-gather; H2D of every frame "
+                                      "pose-only BA; BA round: windows of 8 keyframes (stride 8) x <= 2000 points built on the device (observations: the map points "
+                                      "projected into the keyframes and refined by FindDirectProjection), 20 LM iterations resident + the chi2 > 5.991 inlier test, "
+                                      "pipelined behind the tracking chunks; map exchange + trajectory all-gather; H2D of every frame "
                                       "(+ a quarter-resolution uint16 depth image) and D2H of the results inside the timed region"
                                       % (n_frames, W_, H_),
                           "frames_total": n_frames, "frames_per_gpu": count, "chunk": chunk, "keypoints_per_frame": n_kp,
@@ -459,7 +460,16 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
                                 "max_abs_trajectory_error_vs_ground_truth": traj_err,
                                 "ba_windows": len(res["windows"]),
                                 "ba_window_sizes_K_P_E": [list(res["built"][i]) for i in sorted(res["built"])[:4]],
-                                "ba_chi2_initial_final": [[float(w["stats"][0]), float(w["stats"][1])] for w in res["windows"][:4]]},
+                                "ba_chi2_initial_final": [[float(w["stats"][0]), float(w["stats"][1])] for w in res["windows"][:4]],
+                                # observations by direct projection (LocalMapping.cpp:82-120); the inlier test of BA.cpp:503-515 after optimize(20)
+                                "ba_observations": vo.obs_mode,
+                                "ba_edges_outliers_chi2_chi2inliers": [[w["inliers"]["edges"], w["inliers"]["outliers"], w["inliers"]["chi2"], w["inliers"]["chi2_inliers"]]
+                                                                       for w in res["windows"][:4]],
+                                "ba_mean_chi2_per_inlier_edge_px2": float(np.mean([w["inliers"]["chi2_inliers"] / max(1, w["inliers"]["edges"] - w["inliers"]["outliers"])
+                                                                                   for w in res["windows"]])),
+                                "ba_outlier_share": float(sum(w["inliers"]["outliers"] for w in res["windows"]) / max(1, sum(w["inliers"]["edges"] for w in res["windows"]))),
+                                # keyframe poses relative to their window's anchor against the ground truth, before (chained tracking) and after the BA round
+                                "keyframe_pose_error_vs_ground_truth": {k: float(v.mean()) for k, v in offline.window_pose_errors(res["windows"], res["trajectory"], gt).items()}},
                "roofline": {"bound": "valu", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
                             "kernel": {"k_klt": "k_klt3"}.get(probe, probe), "launches": probe_n, "avg_launch_us": avg_s * 1e6,
                             "algorithmic_bytes_per_launch": alg,
@@ -594,9 +604,18 @@ def main():
     probe_kernel = a.probe
     pipe.ctx.probe_begin(probe_kernel, 8 * (a.steps + 1) * 8)
     barrier()
+    # per-step device times (median / p10 / p90): an event on the pipeline's stream at the start of every step and one
+    # behind the last (after the side streams have joined); step k = the interval between events k and k + 1.  One resident batch only: with two,
+    # consecutive steps run on different streams.
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)] if n_buf == 1 and a.mode == "step" else None
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for k in range(a.steps):
+        if step_ev is not None:
+            step_ev[k].record(streams[0])
         one_step()
+    if step_ev is not None:
+        pipe.ctx.join()
+        step_ev[a.steps].record(streams[0])
     barrier()
     if a.mode == "stream":                                   # the last steps' results are read inside the timed region too
         for q in pipes:
@@ -609,6 +628,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # who took part: one line per rank (device index, UUID, name) gathered to rank 0, so that a record of an N > 1 run shows N ranks on N
+    # distinct devices and the backend the collectives ran on
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "device": props.name, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+    ranks = [me]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     if rank == 0:
         frames = a.batch * a.steps * world
         stages = pipe.stage_times()
@@ -642,14 +669,25 @@ def main():
                     "traffic_collected_on_other_kernel_sources": traffic_stale,
                     "note": "frac is the HBM fraction (algorithmic bytes / launch time / 8 TB/s); the kernel is VALU-issue bound, see roofline_valu"}
         roofline_valu = valu_roofline(pipe, a, probe_kernel, avg_s, n_kp)
-        res = {"metric": "frames/sec (extract+match+LK+local-BA), %dx%d, %d ORB kpts" % (W, H, int(round(n_kp, -3)) if n_kp >= 500 else int(n_kp)),
-               "value": frames / dt, "unit": "frames/s",
+        step_ms = None
+        if step_ev is not None:
+            per = np.array([step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(a.steps)])
+            step_ms = {"median": float(np.median(per)), "p10": float(np.percentile(per, 10)), "p90": float(np.percentile(per, 90)),
+                       "min": float(per.min()), "max": float(per.max()), "steps": int(a.steps),
+                       "how": "HIP events on the pipeline's stream at the start of every step of the timed region and behind the last one (side streams joined); "
+                              "rank 0's device"}
+        res = {"metric": "frames/sec (extract+match+LK+local-BA), %dx%d, %d ORB kpts; frames resident in HBM (PCIe-inclusive rate: value_with_transfers)%s"
+                         % (W, H, int(round(n_kp, -3)) if n_kp >= 500 else int(n_kp),
+                            "" if world == 1 else "; %d independent replicas, one per GPU (weak scaling, no data-path collective) -- the sharded configs[4] run is the `offline` block (strong scaling)" % world),
+               "value": frames / dt, "unit": "frames/s", "value_with_transfers": None, "step_ms": step_ms,
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
                "config": {"workload": "2x%dx%d-pair pipeline: ORB extract + 256-bit Hamming BF cross-check + KLT 21x21x5 + "
                                       "FindDirectProjection + SparseImgAlign + local-BA 10x2000 linearise, per frame" % (W, H),
                           "frames_per_gpu_per_step": a.batch, "resident_batches_per_gpu": n_buf, "keypoints_per_frame": n_kp,
                           "parallelism": "frames sharded x%d (replicas: no data-path collective in this mode; see the `offline` block)" % world},
+               "ranks": {"world": world, "backend": (dist.get_backend() if dist is not None else None), "distinct_devices": len({r["uuid"] or r["local_rank"] for r in ranks}),
+                         "per_rank": ranks},
                "stage_ms_per_batch": stages, "roofline": roofline, "roofline_valu": roofline_valu}
         if a.mode == "stream":
             res["metric"] += ", frames streamed from host memory"
@@ -693,6 +731,7 @@ def main():
         if world == 1:
             try:
                 res["stream"] = stream_block(pipe, a, local_rank, rank)
+                res["value_with_transfers"] = res["stream"]["bgr"]["value"]       # every step: H2D of the BGR frames, the same hot path, D2H of the results
             except Exception as e:
                 res["stream"] = {"error": repr(e)}
         done.set()

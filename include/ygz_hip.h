@@ -64,6 +64,9 @@ void ygz_hip_default_params(ygz_hip_params *p);
 int  ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, void *stream);
 void ygz_hip_destroy(ygz_hip_ctx *ctx);
 int  ygz_hip_synchronize(ygz_hip_ctx *ctx);
+/* the context's stream waits for every stage pending on a side stream (what ygz_hip_synchronize does first), without blocking the host:
+ * an event recorded on the stream afterwards marks the end of everything enqueued so far (bench.py's per-step timing) */
+int  ygz_hip_join(ygz_hip_ctx *ctx);
 /* enable != 0: the resident stages that do not depend on each other -- ygz_hip_track_sparse_align,
  * ygz_hip_ba_linearize_resident, ygz_hip_match_slots_again -- are launched on side HIP streams forked from the context's
  * stream, so they overlap with whatever is enqueued after them (KLT, direct projection); every entry point that reads or
@@ -367,13 +370,14 @@ int  ygz_hip_wait_mark(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler);
  * batched run from its per-pair relative poses (VisualOdometry.cpp:66 chains the same product frame by frame).  No device work. */
 int  ygz_hip_se3_chain(const double *T_rel, int n, double *T_out);
 /* bytes of one keyframe row for this context's grid: pixels f64 [cells][2] | depth f64 [cells] | level i32 [cells] | descriptors
- * [cells][32] | count i32, each part 64-byte aligned.  Rows are fixed-size so that the rows of other ranks arrive by ONE all-gather
- * on the store's memory. */
-size_t ygz_hip_kf_row_bytes(const ygz_hip_ctx *ctx);
+ * [cells][32] | count i32 | (with_images != 0) the keyframe's pyramid, levels 0 .. pyramid_levels - 1 -- each part 64-byte aligned.
+ * Rows are fixed-size so that the rows of other ranks arrive by ONE all-gather on the store's memory. */
+size_t ygz_hip_kf_row_bytes(const ygz_hip_ctx *ctx, int with_images);
 /* a store of n_keyframes rows (+ max_windows rows of work space behind them), the relative pose T_rel of n_frames frames (pose of
  * frame f in the frame of f - 1; (qx,qy,qz,qw,tx,ty,tz)).  rows_mem: device memory of the caller (>= (n_keyframes + max_windows) *
- * row bytes, e.g. a tensor its collectives can address) or NULL to let the library allocate. */
-int  ygz_hip_kf_store_create(ygz_hip_ctx *ctx, int n_keyframes, int n_frames, int max_windows, void *rows_mem, size_t rows_mem_bytes);
+ * row bytes, e.g. a tensor its collectives can address) or NULL to let the library allocate.  with_images != 0: ygz_hip_kf_store_put also
+ * copies the keyframe's pyramid into its row (what ygz_hip_ba_build_windows needs for obs_mode 1). */
+int  ygz_hip_kf_store_create(ygz_hip_ctx *ctx, int n_keyframes, int n_frames, int max_windows, void *rows_mem, size_t rows_mem_bytes, int with_images);
 int  ygz_hip_kf_store_info(ygz_hip_ctx *ctx, void **rows, size_t *row_bytes, void **trel, int *n_keyframes, int *n_frames);
 /* row kf_index[i] <- the keypoints (Feature::_pixel, _level, _desc, _depth) of slot src_slot[i] of `src`; enqueued on src's stream */
 int  ygz_hip_kf_store_put(ygz_hip_ctx *store, ygz_hip_ctx *src, int n, const int32_t *src_slot, const int32_t *kf_index);
@@ -387,14 +391,26 @@ int  ygz_hip_kf_store_refresh(ygz_hip_ctx *ctx);
 int  ygz_hip_ba_reserve_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, int K, int max_points, double huber_delta);
 /* window i = the n_kfs[i] keyframes in store rows kf_index[i][0..K) = frames kf_frame[i][.] of the sequence (ascending; entry 0 is the
  * anchor).  Map points: the anchor's features with depth (first max_points in keypoint order), Pixel2Camera in the anchor's camera
- * (Camera.h:56-62); observations: the anchor's pixel plus the good cross-checked Hamming matches of the anchor's descriptors in the
- * other keyframes (test/test_orb_match.cpp:86-104); points seen by fewer than two keyframes are dropped; vertex j = log of
+ * (Camera.h:56-62); observations: the anchor's pixel plus, in every other keyframe of the window,
+ *   obs_mode 0: the good cross-checked Hamming match of the anchor's descriptor (test/test_orb_match.cpp:86-104);
+ *   obs_mode 1: what LocalMapping::ProjectMapPoints leaves there (src/Module/LocalMapping.cpp:47-120): the map point projected with the
+ *               chained pose, kept if in front of the camera and InFrame(px, 20) (FindCandidates), refined by Matcher::FindDirectProjection
+ *               (Matcher.cpp:356-383) from the anchor's image into the keyframe's; needs a store created with images;
+ * points seen by fewer than two keyframes are dropped; vertex j = log of
  * T_rel(kf_frame[j]) * ... * T_rel(anchor + 1) as [omega; upsilon] (G2oTypes.h:88), the anchor at the identity.  Asynchronous;
  * ygz_hip_ba_optimize_resident / ygz_hip_ba_linearize_resident run on the result, ygz_hip_ba_get_stats returns the sizes. */
 int  ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, const int32_t *kf_index, const int32_t *kf_frame,
-                              const int32_t *n_kfs);
-/* one row per window: [poses 6 K | points 3 max_points | K, P, E, iterations, lm_trials, chi2_initial, chi2_final, lambda_final], unused
- * entries 0, rows row_doubles apart; dst in device memory (dst_on_device != 0: e.g. the buffer of the map exchange) or host memory */
+                              const int32_t *n_kfs, int obs_mode);
+/* the inlier test after optimize() (src/Algorithm/BA.cpp:503-515): every enabled edge's chi2 (identity information, no robust kernel) at
+ * the windows' current state against chi2_threshold (5.991); asynchronous, behind the resident LM of the same windows.  disable != 0:
+ * outlier edges are switched off for later runs (the effect of Feature::_bad = true on the next LocalBAG2O, BA.cpp:436).
+ * ygz_hip_ba_get_outlier_stats: out [n_windows][4] = edges tested, outliers, chi2 of the tested edges, chi2 of the inliers (-1: not
+ * computed since the last resident LM); synchronises. */
+int  ygz_hip_ba_mark_outliers(ygz_hip_ctx *ctx, int window_begin, int n_windows, double chi2_threshold, int disable);
+int  ygz_hip_ba_get_outlier_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, double *out);
+/* one row per window: [poses 6 K | points 3 max_points | K, P, E, iterations, lm_trials, chi2_initial, chi2_final, lambda_final | edges
+ * tested, outliers, chi2 of the tested edges, chi2 of the inliers (ygz_hip_ba_mark_outliers)], unused entries 0, rows row_doubles
+ * (>= 6 K + 3 max_points + 12) apart; dst in device memory (dst_on_device != 0: e.g. the buffer of the map exchange) or host memory */
 int  ygz_hip_ba_pack_states(ygz_hip_ctx *ctx, int window_begin, int n_windows, double *dst, size_t row_doubles, int dst_on_device, int wait);
 
 

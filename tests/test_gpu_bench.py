@@ -40,6 +40,12 @@ def test_bench_contract_line_one_gpu():
     assert "error" not in st and st["bgr"]["value"] > 0 and st["gray"]["value"] > 0 and st["batches_in_flight"] == 3
     # value = frames / time: consistent with ms_per_step
     assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    # per-step device times, and the PCIe-inclusive rate next to the HBM-resident value
+    sm = d["step_ms"]
+    assert sm["steps"] == 3 and 0 < sm["p10"] <= sm["median"] <= sm["p90"] and sm["median"] < 2.0 * d["ms_per_step"]
+    assert d["value_with_transfers"] == st["bgr"]["value"] and "resident in HBM" in d["metric"]
+    assert "frac_of_int8_peak" not in d["roofline_valu"]["mfma"]
+    assert d["ranks"]["world"] == 1 and d["ranks"]["distinct_devices"] == 1 and len(d["ranks"]["per_rank"]) == 1
 
 
 @pytest.mark.parametrize("mode", ["step", "offline"])
@@ -57,6 +63,9 @@ def test_bench_two_ranks_on_one_device(mode):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
     if mode == "step":
         assert d["scaling"] == "weak" and abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+        # who took part: two ranks (here on one device, through gloo); the metric says what the N > 1 value is
+        assert d["ranks"]["world"] == 2 and [r["rank"] for r in d["ranks"]["per_rank"]] == [0, 1] and d["ranks"]["backend"] == "gloo"
+        assert "replicas" in d["metric"]
     else:
         assert d["scaling"] == "strong" and d["config"]["frames_total"] == 32
         assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]

@@ -265,13 +265,16 @@ def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path, varian
         assert np.array_equal(full["records"][cur - 1]["kp"]["depth"], o["depth"])
 
 
-def test_device_built_window_equals_host_built(hip_lib, oracle):
+@pytest.mark.parametrize("obs_mode", ["direct", "match"])
+def test_device_built_window_equals_host_built(hip_lib, oracle, obs_mode):
     """ygz_hip_ba_build_windows against the host restatement offline.build_window_host on the keyframes of a tracked sequence: the same
     map points (bit-equal), vertices (1e-13: the host chains the relative poses through numpy), and -- with the device's state installed
-    in the host-built graph -- bit-identical linearisations (every edge in the same row, the same observation, the same pose)."""
+    in the host-built graph -- bit-identical linearisations (every edge in the same row, the same observation, the same pose).
+    obs_mode "direct": the host takes its observations from per-pair ygz_hip_find_direct_projection calls on a context that holds the
+    keyframes (FindCandidates' test and the prediction in numpy); "match": from ygz_hip_match_sets."""
     n = 10
     seq = synth.Sequence(n, 640, 480, seed=3, step=0.2)
-    vo = offline.OfflineVO(640, 480, n, chunk=n, kf_stride=2, window_kfs=4, max_points=700, keep=True, pipeline_ba=False)
+    vo = offline.OfflineVO(640, 480, n, chunk=n, kf_stride=2, window_kfs=4, max_points=700, keep=True, pipeline_ba=False, obs_mode=obs_mode)
     rec = vo.track_shard(seq.frame, seq.depth)
     assert vo.wins == [[0, 2, 4, 6]] and vo.mine == [0]          # frames 8, 9: a lone keyframe makes no window
     vo._ba_launch(vo.mine, optimize=False)
@@ -279,7 +282,21 @@ def test_device_built_window_equals_host_built(hip_lib, oracle):
     kf_tab = {f: rec[f]["kp"] for f in vo.wins[0]}
     T_rel = np.stack([rec[f].get("T_rel", offline.I7) for f in range(n)])
     cam = vo.ba.params
-    h = offline.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, vo.ba.match_sets)
+    if obs_mode == "direct":
+        kc = hip_lib.HipContext(width=640, height=480, levels=3, max_frames=4)
+        slot = {f: k for k, f in enumerate(vo.wins[0])}
+        for f, k in slot.items():
+            kc.upload_bgr(k, seq.frame(f))
+        kc.build_pyramid(0, 4, from_bgr=True)
+
+        def direct(ref, cur, T, px_ref, depth, level, px_cur):
+            ok, px, _ = kc.find_direct_projection(slot[ref], offline.I7, slot[cur], T, px_ref, depth, level, px_cur)
+            return ok, px
+        h = offline.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, direct=direct,
+                                      width=640, height=480)
+        kc.close()
+    else:
+        h = offline.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, vo.ba.match_sets)
     assert (K, P, E, Kf) == (4, len(h["points"]), len(h["obs"]), 3) and P > 200 and E > 2 * P
     poses, points = vo.ba.ba_get_state(0, 4, 700)
     assert np.array_equal(points[:P], h["points"])
@@ -290,12 +307,21 @@ def test_device_built_window_equals_host_built(hip_lib, oracle):
     for k in ("Hpp", "bp", "Hll", "bl", "Hpl", "err", "chi2_edge"):
         assert np.array_equal(a[k], b[k]), k
     assert a["chi2"] == b["chi2"] and a["chi2"] > 0
+    if obs_mode == "direct":                                      # sub-pixel aligned observations: the initial graph is already consistent to a few pixels^2 per edge
+        assert a["chi2"] / E < 25.0, a["chi2"] / E
     # ... and the resident LM on the two graphs walks the same trials
     sa = vo.ba.ba_optimize_resident(0, 1, 10)[0]
     sb = vo.ba.ba_optimize_resident(100, 1, 10)[0]
     assert (sa.iterations, sa.lm_trials, sa.chi2_initial, sa.chi2_final) == (sb.iterations, sb.lm_trials, sb.chi2_initial, sb.chi2_final)
     pa, qa = vo.ba.ba_get_state(0, 4, 700); pb, qb = vo.ba.ba_get_state(100, K, P)
     assert np.array_equal(pa[:K], pb) and np.array_equal(qa[:P], qb) and sa.chi2_final < sa.chi2_initial
+    # the inlier test of BA.cpp:503-515 on both: the same counts; switched off, the outliers leave the next linearisation
+    vo.ba.ba_mark_outliers(0, 1, 5.991, disable=True); vo.ba.ba_mark_outliers(100, 1, 5.991, disable=False)
+    oa, ob = vo.ba.ba_get_outlier_stats(0, 1)[0], vo.ba.ba_get_outlier_stats(100, 1)[0]
+    assert np.array_equal(oa, ob) and oa[0] == E and 0 <= oa[1] < E and oa[3] <= oa[2]
+    vo.ba.ba_linearize_resident(0, 1)
+    c = vo.ba.ba_download(0, K, P, E)
+    assert int((c["chi2_edge"] > 0).sum()) == E - int(oa[1]) or oa[1] == 0
     vo.close()
 
 
@@ -362,6 +388,14 @@ def test_offline_128_frames_720p_two_ranks(hip_lib, tmp_path):
     assert np.abs(full["trajectory"] - gt).max() < 2e-2
     for w in full["windows"]:
         assert w["stats"][1] < w["stats"][0] and w["stats"][3] > 5000
+        # observations by direct projection (LocalMapping.cpp:82-120): after optimize(20) the inlier edges sit at sub-pixel reprojection error and
+        # few edges fail the chi2 > 5.991 test of BA.cpp:503-515
+        inl = w["inliers"]
+        assert inl["edges"] == w["stats"][3] and inl["outliers"] < 0.2 * inl["edges"], inl
+        assert inl["chi2_inliers"] / max(1, inl["edges"] - inl["outliers"]) < 2.0, inl
+    # ... and the BA round moves the keyframes towards the ground truth (poses relative to each window's anchor)
+    pe = offline.window_pose_errors(full["windows"], full["trajectory"], gt)
+    assert pe["t_after"].mean() < pe["t_before"].mean() and pe["r_after"].mean() < pe["r_before"].mean(), {k: float(v.mean()) for k, v in pe.items()}
 
 
 def test_create_map_points_triangulation_loop(hip_lib, oracle):

@@ -104,5 +104,21 @@ d)  # resident grid size, register cap, LK working images beside the extractor
     YGZ_SA_REGS=288 python tools/stage_bench.py sparse --batch 512 --reps 5
     benchline dflt_b $STEP
     ;;
+e)  # parity suite on the new defaults + the three profile passes behind profiles/
+    timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+    bash tools/collect_profiles.sh r04e_prof > $OUT/collect.log 2>&1
+    cat gpurun_out/r04e_prof/kernel_stats.md
+    cat gpurun_out/r04e_prof/traffic.json | head -80
+    ;;
+f)  # BA windows with direct-projection observations: offline tests, the offline bench line
+    timeout 1200 python -m pytest tests/test_gpu_offline.py -x -q > $OUT/pytest.log 2>&1; tail -15 $OUT/pytest.log
+    timeout 300 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/off.json 2> $OUT/off.err
+    python - $OUT/off.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("offline %.1f frames/s  %.2f ms" % (d["value"], d["ms_per_step"]), {k: round(v,2) for k,v in d["phases_ms"].items()})
+print(json.dumps(d["result_check"], indent=1))
+PY
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

@@ -82,7 +82,7 @@ class BaStats(C.Structure):
 
 # every symbol include/ygz_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_set_overlap", "ygz_hip_error_string",
+    "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_join", "ygz_hip_set_overlap", "ygz_hip_error_string",
     "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end", "ygz_hip_probe_begin", "ygz_hip_probe_end",
     "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_level_size",
     "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_describe_given_angle", "ygz_hip_get_fast_maps",
@@ -100,7 +100,7 @@ ABI_SYMBOLS = [
     "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
     "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_se3_chain", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
     "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
-    "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states",
+    "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states", "ygz_hip_ba_mark_outliers", "ygz_hip_ba_get_outlier_stats",
 ]
 
 SUMMARY_FIELDS = 32
@@ -210,6 +210,10 @@ class HipContext:
     def synchronize(self):
         self._chk(self.lib.ygz_hip_synchronize(self._ctx), "synchronize")
 
+    def join(self):
+        """the context's stream waits for the stages pending on side streams; the host does not block"""
+        self._chk(self.lib.ygz_hip_join(self._ctx), "join")
+
     def set_overlap(self, enable=True):
         self._chk(self.lib.ygz_hip_set_overlap(self._ctx, int(enable)), "set_overlap")
 
@@ -302,12 +306,13 @@ class HipContext:
     def wait_mark(self, signaler):
         self._chk(self.lib.ygz_hip_wait_mark(self._ctx, signaler._ctx), "wait_mark")
 
-    def kf_row_bytes(self):
-        return int(self.lib.ygz_hip_kf_row_bytes(self._ctx))
+    def kf_row_bytes(self, with_images=False):
+        return int(self.lib.ygz_hip_kf_row_bytes(self._ctx, int(with_images)))
 
-    def kf_store_create(self, n_keyframes, n_frames, max_windows, rows_ptr=None, rows_bytes=0):
+    def kf_store_create(self, n_keyframes, n_frames, max_windows, rows_ptr=None, rows_bytes=0, with_images=False):
+        """with_images: the rows also hold the keyframes' pyramids (ba_build_windows(..., obs_mode=1) reads them)"""
         self._chk(self.lib.ygz_hip_kf_store_create(self._ctx, n_keyframes, n_frames, max_windows, C.c_void_p(rows_ptr) if rows_ptr else None,
-                                                   C.c_size_t(rows_bytes)), "kf_store_create")
+                                                   C.c_size_t(rows_bytes), int(with_images)), "kf_store_create")
 
     def kf_store_info(self):
         rows, trel, rb, nk, nf = C.c_void_p(0), C.c_void_p(0), C.c_size_t(0), C.c_int(0), C.c_int(0)
@@ -332,11 +337,23 @@ class HipContext:
     def ba_reserve_windows(self, window_begin, n_windows, K, max_points, huber_delta=5.991):
         self._chk(self.lib.ygz_hip_ba_reserve_windows(self._ctx, window_begin, n_windows, K, max_points, C.c_double(huber_delta)), "ba_reserve_windows")
 
-    def ba_build_windows(self, window_begin, kf_index, kf_frame, n_kfs):
-        """kf_index / kf_frame [n, K] (entries past n_kfs[i] ignored), n_kfs [n]"""
+    def ba_build_windows(self, window_begin, kf_index, kf_frame, n_kfs, obs_mode=0):
+        """kf_index / kf_frame [n, K] (entries past n_kfs[i] ignored), n_kfs [n]; obs_mode 0: observations = good Hamming matches, 1: direct
+        projection of the map points into the keyframes (FindCandidates + FindDirectProjection; the store must hold the images)"""
         a = np.ascontiguousarray(kf_index, np.int32); b = np.ascontiguousarray(kf_frame, np.int32); c = np.ascontiguousarray(n_kfs, np.int32)
         assert a.shape == b.shape and a.ndim == 2 and len(c) == len(a)
-        self._chk(self.lib.ygz_hip_ba_build_windows(self._ctx, window_begin, len(a), _p(a, C.c_int32), _p(b, C.c_int32), _p(c, C.c_int32)), "ba_build_windows")
+        self._chk(self.lib.ygz_hip_ba_build_windows(self._ctx, window_begin, len(a), _p(a, C.c_int32), _p(b, C.c_int32), _p(c, C.c_int32), int(obs_mode)),
+                  "ba_build_windows")
+
+    def ba_mark_outliers(self, window_begin, n_windows, chi2_threshold=5.991, disable=False):
+        """BA.cpp:503-515 on the windows' current state (asynchronous, behind the resident LM)"""
+        self._chk(self.lib.ygz_hip_ba_mark_outliers(self._ctx, window_begin, n_windows, C.c_double(chi2_threshold), int(disable)), "ba_mark_outliers")
+
+    def ba_get_outlier_stats(self, window_begin, n_windows):
+        """[n, 4]: edges tested, outliers, chi2 of the tested edges, chi2 of the inliers"""
+        out = np.empty((n_windows, 4), np.float64)
+        self._chk(self.lib.ygz_hip_ba_get_outlier_stats(self._ctx, window_begin, n_windows, _p(out, C.c_double)), "ba_get_outlier_stats")
+        return out
 
     def ba_pack_states(self, window_begin, n_windows, row_doubles, dst_ptr=None, out=None, wait=True):
         """state rows into device memory at dst_ptr, or into (and returning) a host array [n_windows, row_doubles]"""

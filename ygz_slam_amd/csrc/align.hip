@@ -190,6 +190,7 @@ static __device__ __forceinline__ void warp_affine_lds(const double Am[4], const
 
 struct FdpArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
+    size_t sstride[YGZ_MAX_LEVELS];               // bytes from one slot's level image to the next slot's (w * h in a context's frame store; the row size in a keyframe store)
     int w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
     int n_levels, cells, n_pairs;
     Cam cam;
@@ -238,9 +239,9 @@ static __device__ __forceinline__ bool fdp_core(const FdpArgs &A, int ref_slot, 
         while (D > 3.0 && sl < A.n_levels - 1) { sl += 1; D *= 0.25; }
     }
     // WarpAffine (Matcher.cpp:438-466), half_patch_size 5
-    warp_affine_lds(Am, A.lvl[Lr] + (size_t)ref_slot * A.w[Lr] * A.h[Lr], A.w[Lr], A.h[Lr], px_ref, Lr, sl, pwb);
+    warp_affine_lds(Am, A.lvl[Lr] + (size_t)ref_slot * A.sstride[Lr], A.w[Lr], A.h[Lr], px_ref, Lr, sl, pwb);
     const int cw = A.w[sl], ch = A.h[sl];
-    const uint8_t *cur = A.lvl[sl] + (size_t)cur_slot * cw * ch;
+    const uint8_t *cur = A.lvl[sl] + (size_t)cur_slot * A.sstride[sl];
     double u = px_cur[0] / (double)(1 << sl), v = px_cur[1] / (double)(1 << sl);
     const bool good = align2d_core(cur, cw, ch, pwb, stg, 10, &u, &v, nullptr);
     const double ox = u * (double)(1 << sl), oy = v * (double)(1 << sl);
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(64) void k_align2d(const uint8_t *__restrict__ cur,
 int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs)
 {
     FdpArgs A;
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; }
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.lvl[L] = ctx->lvl[L]; A.w[L] = ctx->lw[L]; A.h[L] = ctx->lh[L]; A.sstride[L] = (size_t)ctx->lw[L] * ctx->lh[L]; }
     A.n_levels = ctx->prm.pyramid_levels; A.cells = ctx->cells; A.n_pairs = n_pairs;
     A.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy };
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.pair_T = ctx->pair_T;
@@ -373,6 +374,64 @@ int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs)
     A.px_cur = ctx->fdp_px; A.search_level = ctx->fdp_level; A.ok = ctx->fdp_ok; A.cand = ctx->fdp_cand;
     A.prio = (ctx->wave_prio_mask >> 1) & 1;
     YGZ_LAUNCH(ctx, KID_FDP, k_find_direct_projection, dim3(ygz_div_up(ctx->cells, 64), ygz_round_up8(n_pairs)), dim3(64), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+// ---- the observations of a BA window by direct projection (the offline run's stand-in for what LocalMapping::ProjectMapPoints leaves in
+// every keyframe: a Feature at the patch-aligned pixel of each local map point, src/Module/LocalMapping.cpp:82-120) ----
+struct WinProjArgs { FdpArgs F; YgzWinProject P; };
+__global__ __launch_bounds__(64) void k_win_project(WinProjArgs A)
+{
+    __shared__ uint8_t pwb_all[100 * 64];
+    __shared__ uint32_t stg_all[STG_DWORDS * 64];
+    int bx, p;
+    if (!ygz_xcd_remap(A.P.n_pairs, bx, p)) return;
+    const int w = A.P.pair_w[p], j = A.P.pair_j[p], s = bx * 64 + (int)threadIdx.x;
+    const int S = A.P.set_base + w;
+    if (s >= A.P.counts[S] || s >= A.P.Pcap) return;
+    const uint8_t *srow = A.P.rows + (size_t)S * A.P.row_bytes;
+    const double *spx = reinterpret_cast<const double *>(srow + A.P.off_px), *sdp = reinterpret_cast<const double *>(srow + A.P.off_depth);
+    const int32_t *slv = reinterpret_cast<const int32_t *>(srow + A.P.off_level);
+    const size_t o = (size_t)p * A.P.stride + s;
+    const double px_ref[2] = { spx[2 * s], spx[2 * s + 1] };
+    double pw[3];
+    pixel2camera_d(A.F.cam, px_ref, sdp[s], pw);                // the map point in the anchor's camera = the window's gauge (Camera.h:53-59)
+    const double *Tc7 = A.P.Tj + 7 * ((size_t)w * A.P.Kcap + j);
+    Se3 T;
+    for (int k = 0; k < 4; ++k) T.q[k] = Tc7[k];
+    for (int k = 0; k < 3; ++k) T.t[k] = Tc7[4 + k];
+    double pc[3], px_cur[2];
+    se3_act_d(&T, pw, pc);
+    camera2pixel_d(A.F.cam, pc, px_cur);
+    // FindCandidates (LocalMapping.cpp:60-64): behind the camera or outside InFrame(px, 20) -> not a candidate
+    const bool vis = !(pc[2] < 0) && px_cur[0] >= 20 && px_cur[0] < A.F.w[0] - 20 && px_cur[1] >= 20 && px_cur[1] < A.F.h[0] - 20;
+    bool ok = false;
+    if (vis) {
+        const double I7[7] = { 0, 0, 0, 1, 0, 0, 0 };           // the anchor's pose in its own gauge
+        Se3 Ti; Ti.q[0] = Ti.q[1] = Ti.q[2] = 0; Ti.q[3] = 1; Ti.t[0] = Ti.t[1] = Ti.t[2] = 0;
+        double pr[3];
+        se3_act_d(&Ti, pw, pr);                                  // depth = World2Camera(mp->_pos_world, ref->_TCW)[2] (Matcher.cpp:362)
+        int sl;
+        ok = fdp_core(A.F, A.P.kf_index[(size_t)w * A.P.Kcap], A.P.kf_index[(size_t)w * A.P.Kcap + j], I7, Tc7, px_ref, pr[2], slv[s],
+                      pwb_all + threadIdx.x, stg_all + threadIdx.x, px_cur, &sl);
+    }
+    A.P.obs_px[2 * o] = px_cur[0]; A.P.obs_px[2 * o + 1] = px_cur[1];
+    A.P.obs_ok[o] = (uint8_t)ok;
+}
+
+int ygz_launch_win_project(ygz_hip_ctx *ctx, const YgzWinProject &P)
+{
+    WinProjArgs A;
+    A.P = P;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
+        A.F.lvl[L] = L < P.n_levels ? P.rows + P.off_img[L] : nullptr; A.F.sstride[L] = P.row_bytes; A.F.w[L] = P.w[L]; A.F.h[L] = P.h[L];
+    }
+    A.F.n_levels = P.n_levels; A.F.cells = ctx->cells; A.F.n_pairs = P.n_pairs;
+    A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy }; A.F.prio = 0;
+    A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;
+    A.F.px_cur = nullptr; A.F.search_level = nullptr; A.F.ok = nullptr;
+    YGZ_LAUNCH(ctx, KID_FDP, k_win_project, dim3(ygz_div_up(P.Pcap, 64), ygz_round_up8(P.n_pairs)), dim3(64), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
@@ -480,7 +539,7 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
         YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cl, m->cand_level, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     LmapArgs A;
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; A.F.sstride[L] = (size_t)ctx->lw[L] * ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 0;
     A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy }; A.F.prio = 0;
     A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;
@@ -629,7 +688,7 @@ extern "C" int ygz_hip_create_map_points(ygz_hip_ctx *ctx, int slot1, const doub
     YGZ_HIPCHK(ctx, hipMemcpyAsync(buf + o_lv, level1, N * 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemsetAsync(buf + o_d1, 0, N * 40, ctx->stream));
     CmpArgs A;
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; }
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; A.F.sstride[L] = (size_t)ctx->lw[L] * ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 1;
     A.F.cam = Cam{ ctx->prm.fx, ctx->prm.fy, ctx->prm.cx, ctx->prm.cy }; A.F.prio = 0;
     A.F.pair_q = A.F.pair_t = A.F.trk_n = nullptr; A.F.pair_T = A.F.trk_px = A.F.trk_depth = nullptr; A.F.trk_level = nullptr; A.F.cand = nullptr;

@@ -821,9 +821,44 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             st.iterations = iterations; st.lm_trials = trials; st.chi2_initial = chi_initial; st.chi2_final = currentChi; st.lambda_final = lambda;
             A.stats[w] = st;
             *reinterpret_cast<ygz_ba_stats *>(B.lm_out) = st;               // kept with the window (ygz_hip_ba_get_stats)
+            for (int i = 4; i < 8; ++i) B.lm_out[i] = -1.0;                 // the outlier record of this state is not computed yet (ygz_hip_ba_mark_outliers)
         }
     }
 #undef LM_PART_RANGE
+}
+
+// ---- the inlier statistics after optimize() (BA.cpp:503-515): every edge's UNROBUSTIFIED chi2 at the final state against the threshold
+// (5.991); an edge above it is an outlier -- the reference sets Feature::_bad, which takes the observation out of every later BA
+// (BA.cpp:436).  Here: counted, summed, and with disable != 0 switched off (enable = 0) so that another optimisation of the same window
+// runs without it.  One workgroup per window; sums in a fixed order.  lm_out[4..7] = edges tested, outliers, chi2 of all tested edges,
+// chi2 of the inliers.
+struct OutlierArgs { const BaDev *wins; double thr; int disable; };
+__global__ __launch_bounds__(256) void k_ba_outliers(OutlierArgs A)
+{
+    __shared__ double red[4][256];
+    BaDev B = A.wins[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < B.K) ba_pose_prep_one(B, tid);
+    __syncthreads();
+    double n_en = 0.0, n_out = 0.0, chi_all = 0.0, chi_in = 0.0;
+    uint8_t *enable_c = const_cast<uint8_t *>(B.enable_c);
+    for (int il = tid; il < B.P; il += 256) {
+        const int lane = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
+        const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
+        for (int c = 0; c < rows; ++c) {
+            const int row = row0 + c, ip = B.pose_c[(size_t)row * 64 + lane];
+            if (ip < 0 || !B.enable_c[(size_t)row * 64 + lane]) continue;
+            double p[3], r[2];
+            ba_project(B, B.posed + BA_POSED * (size_t)ip, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
+            const double e2 = r[0] * r[0] + r[1] * r[1];                       // edge->chi2() with identity information (BA.cpp:509)
+            n_en += 1.0; chi_all += e2;
+            if (e2 > A.thr) { n_out += 1.0; if (A.disable) enable_c[(size_t)row * 64 + lane] = 0; }
+            else chi_in += e2;
+        }
+    }
+    red[0][tid] = n_en; red[1][tid] = n_out; red[2][tid] = chi_all; red[3][tid] = chi_in;
+    __syncthreads();
+    if (tid < 4) { double t = 0.0; for (int i = 0; i < 256; ++i) t += red[tid][i]; B.lm_out[4 + tid] = t; }
 }
 
 extern "C" {
@@ -921,6 +956,37 @@ int ygz_hip_ba_get_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, ygz_
         dims[4 * i] = hd[8 * (size_t)i]; dims[4 * i + 1] = hd[8 * (size_t)i + 1]; dims[4 * i + 2] = hd[8 * (size_t)i + 2]; dims[4 * i + 3] = hd[8 * (size_t)i + 4];
     }
     if (stats) for (int i = 0; i < n_windows; ++i) if (stats[i].iterations < 0) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return stats[i].lm_trials == -1 ? YGZ_E_STATE : YGZ_E_HIP; }
+    return YGZ_OK;
+}
+
+// BA.cpp:503-515 for the windows of the range, behind whatever optimised them (asynchronous): see k_ba_outliers.  disable != 0 switches the
+// outlier edges off for later runs on the same windows (the effect of Feature::_bad = true on the next LocalBAG2O, BA.cpp:436).
+int ygz_hip_ba_mark_outliers(ygz_hip_ctx *ctx, int window_begin, int n_windows, double chi2_threshold, int disable)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size() || !(chi2_threshold >= 0)) return YGZ_E_INVALID;
+    for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i] || ctx->ba[i]->K > 256) return YGZ_E_INVALID;
+    int rc = YGZ_OK;
+    const BaDev *table = ygz_ba_table(ctx, &rc);
+    if (!table) return rc;
+    OutlierArgs A; A.wins = table + window_begin; A.thr = chi2_threshold; A.disable = disable;
+    YgzAuxScope aux(ctx, 1);                                   // the stream the resident LM runs on
+    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_outliers, dim3(n_windows), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+
+// out [n_windows][4]: edges tested, outliers, chi2 of all tested edges, chi2 of the inliers, as ygz_hip_ba_mark_outliers left them
+// (-1: not computed for the window's current state).  Synchronises.
+int ygz_hip_ba_get_outlier_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, double *out)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !out || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size()) return YGZ_E_INVALID;
+    for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i]) return YGZ_E_INVALID;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    for (int i = 0; i < n_windows; ++i)
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(out + 4 * (size_t)i, ctx->ba[window_begin + i]->lm_out + 4, 32, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }
 

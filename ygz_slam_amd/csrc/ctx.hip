@@ -241,6 +241,13 @@ int ygz_hip_synchronize(ygz_hip_ctx *ctx)
     return YGZ_OK;
 }
 
+int ygz_hip_join(ygz_hip_ctx *ctx)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx) return YGZ_E_INVALID;
+    return ygz_join(ctx);
+}
+
 // Everything enqueued on `waiter` after this call runs after everything enqueued on `signaler` before it (both contexts on one
 // device; no host synchronisation).  The offline run uses it to order the BA context behind the tracking lanes.
 int ygz_hip_stream_wait(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler)

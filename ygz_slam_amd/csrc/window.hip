@@ -16,7 +16,7 @@
 //                                   map points = Pixel2Camera(pixel, depth) in the anchor's camera (Camera.h:56-62).
 //                    A window is therefore a function of its own frames only: whichever rank builds it, and whenever, the graph and
 //                    the LM result are bit-identical, and no window waits for the global trajectory.
-//   state rows       [poses 6K | points 3P | K P E iterations trials chi2_0 chi2 lambda] per window, packed on the device for the
+//   state rows       [poses 6K | points 3P | K P E iterations trials chi2_0 chi2 lambda | edges tested, outliers, chi2, chi2 of inliers] per window, packed on the device for the
 //                    exchange (owner -> everybody) and the host.
 #include "ba_dev.h"
 #include <string.h>
@@ -28,6 +28,8 @@ int ygz_ba_reserve_window(ygz_hip_ctx *ctx, int window, int K, int P, double hub
 struct ygz_hip_ctx::KfStore {
     int n_kf = 0, n_frames = 0, max_windows = 0;
     size_t row_bytes = 0, off_px = 0, off_depth = 0, off_level = 0, off_desc = 0, off_count = 0;
+    bool with_images = false;                              // rows also hold the keyframe's pyramid (levels 0 .. pyramid_levels - 1), for the direct-projection observations
+    size_t off_img[YGZ_MAX_LEVELS] = {0};
     uint8_t *rows = nullptr; bool own_rows = false;       // [n_kf + max_windows] rows: keyframes, then the compacted anchor sets
     double *trel = nullptr;                                // [n_frames][7]
     int32_t *counts = nullptr;                             // [n_kf + max_windows] rows in use per row (contiguous: the matcher's set sizes)
@@ -43,12 +45,18 @@ __device__ __forceinline__ int32_t *kfv_level(const KfView &V, int r) { return r
 __device__ __forceinline__ uint4 *kfv_desc(const KfView &V, int r) { return reinterpret_cast<uint4 *>(V.rows + (size_t)r * V.row_bytes + V.off_desc); }
 __device__ __forceinline__ int32_t *kfv_count(const KfView &V, int r) { return reinterpret_cast<int32_t *>(V.rows + (size_t)r * V.row_bytes + V.off_count); }
 
-static void kf_layout(int cells, size_t *off, size_t *row_bytes)
+// off[0..4]: pixels, depth, level, descriptors, count; off_img[L] (with images): level L of the keyframe's pyramid, each 64-byte aligned
+static void kf_layout(const ygz_hip_ctx *ctx, bool with_images, size_t *off, size_t *off_img, size_t *row_bytes)
 {
-    const size_t C = (size_t)cells;
+    const size_t C = (size_t)ctx->cells;
     auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
     off[0] = 0; off[1] = al(16 * C); off[2] = al(off[1] + 8 * C); off[3] = al(off[2] + 4 * C); off[4] = al(off[3] + 32 * C);
-    *row_bytes = (off[4] + 64 + 255) & ~(size_t)255;
+    size_t end = off[4] + 64;
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) off_img[L] = 0;
+    if (with_images)
+        for (int L = 0; L < ctx->prm.pyramid_levels; ++L) { off_img[L] = al(end); end = off_img[L] + (size_t)ctx->lw[L] * ctx->lh[L]; }
+    if (with_images) end += 64;                          // the row-wise window loads may touch a few bytes past a level
+    *row_bytes = (end + 255) & ~(size_t)255;
 }
 
 static KfView kf_view(const ygz_hip_ctx *ctx)
@@ -82,6 +90,22 @@ __global__ __launch_bounds__(256) void k_kf_put(KfPutArgs A)
     uint4 *dd = kfv_desc(A.V, kf) + 2 * (size_t)i;
     dd[0] = sd[0]; dd[1] = sd[1];
 }
+// the keyframe's pyramid levels into its row (16 bytes per lane; blockIdx.y = keyframe of the call, blockIdx.z = level)
+struct KfImgArgs {
+    uint8_t *rows; size_t row_bytes, off_img[YGZ_MAX_LEVELS], bytes[YGZ_MAX_LEVELS];
+    const uint8_t *lvl[YGZ_MAX_LEVELS];
+    int32_t slot[KF_PUT_MAX], kf[KF_PUT_MAX];
+};
+__global__ __launch_bounds__(256) void k_kf_put_img(KfImgArgs A)
+{
+    const int b = blockIdx.y, L = blockIdx.z;
+    const size_t n = A.bytes[L], i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= n) return;
+    const uint8_t *src = A.lvl[L] + (size_t)A.slot[b] * n + i;
+    uint8_t *dst = A.rows + (size_t)A.kf[b] * A.row_bytes + A.off_img[L] + i;
+    if (i + 16 <= n && (n & 15) == 0) *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(src);
+    else for (size_t k = 0; k < 16 && i + k < n; ++k) dst[k] = src[k];
+}
 __global__ __launch_bounds__(256) void k_trel_put(double *__restrict__ trel, const double *__restrict__ po_T, int n)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -105,6 +129,9 @@ struct WinArgs {
     BaDev *wins;                                              // table entries of the windows being built
     int32_t *sel_idx, *sc_new, *sc_cnt, *sc_e0;               // [n_win][Pcap] scratch
     const int32_t *m_idx; const uint8_t *m_good; size_t m_stride;
+    // direct != 0: the observations come from FindDirectProjection (k_win_project) instead of the Hamming matches: o_ok / o_px [pairs][m_stride]
+    int direct; const uint8_t *o_ok; const double *o_px;
+    double *Tj;                                               // [n_win][Kcap][7] pose of keyframe j relative to the anchor (k_win_poses)
 };
 
 __device__ __forceinline__ int win_wave_incl_scan(int v, int lane)
@@ -158,6 +185,29 @@ __global__ __launch_bounds__(WIN_THREADS) void k_win_select(WinArgs A)
     if (tid == 0) { const int n = running < A.Pcap ? running : A.Pcap; A.V.counts[S] = n; *kfv_count(A.V, S) = n; }
 }
 
+// keyframe j's pose relative to the anchor, chained from the frames' relative poses: T(anchor) = identity, T(f) = T_rel(f) * T(f - 1)
+__device__ __forceinline__ void win_chain(const WinArgs &A, int w, int j, Se3 &T)
+{
+    const int32_t *kff = A.kf_frame + (size_t)w * A.Kcap;
+    T.q[0] = T.q[1] = T.q[2] = 0; T.q[3] = 1; T.t[0] = T.t[1] = T.t[2] = 0;
+    for (int f = kff[0] + 1; f <= kff[j]; ++f) {
+        Se3 Rl, C;
+        const double *r = A.V.trel + 7 * (size_t)f;
+        Rl.q[0] = r[0]; Rl.q[1] = r[1]; Rl.q[2] = r[2]; Rl.q[3] = r[3]; Rl.t[0] = r[4]; Rl.t[1] = r[5]; Rl.t[2] = r[6];
+        se3_mul_d(&Rl, &T, &C);
+        T = C;
+    }
+}
+__global__ __launch_bounds__(64) void k_win_poses(WinArgs A)
+{
+    const int w = blockIdx.x, j = threadIdx.x;
+    if (j >= A.Kcap) return;
+    Se3 T; T.q[0] = T.q[1] = T.q[2] = 0; T.q[3] = 1; T.t[0] = T.t[1] = T.t[2] = 0;
+    if (j >= 1 && j < A.n_kfs[w]) win_chain(A, w, j, T);
+    double *o = A.Tj + 7 * ((size_t)w * A.Kcap + j);
+    o[0] = T.q[0]; o[1] = T.q[1]; o[2] = T.q[2]; o[3] = T.q[3]; o[4] = T.t[0]; o[5] = T.t[1]; o[6] = T.t[2];
+}
+
 __global__ __launch_bounds__(WIN_THREADS) void k_win_edges(WinArgs A)
 {
     __shared__ int red[WIN_WAVES];
@@ -179,7 +229,9 @@ __global__ __launch_bounds__(WIN_THREADS) void k_win_edges(WinArgs A)
             cnt = 1;                                                           // the anchor's own observation
             for (int j = 1; j < nk; ++j) {
                 const int p = pof[j];
-                if (p >= 0 && A.m_idx[(size_t)p * A.m_stride + s] >= 0 && A.m_good[(size_t)p * A.m_stride + s]) ++cnt;
+                if (p < 0) continue;
+                if (A.direct ? A.o_ok[(size_t)p * A.m_stride + s] != 0
+                             : (A.m_idx[(size_t)p * A.m_stride + s] >= 0 && A.m_good[(size_t)p * A.m_stride + s])) ++cnt;
             }
         }
         const bool keep = cnt >= 2;                                            // seen only by the constant anchor: constrains nothing
@@ -224,12 +276,19 @@ __global__ __launch_bounds__(WIN_THREADS) void k_win_edges(WinArgs A)
         for (int j = 1; j < nk; ++j) {
             const int p = pof[j];
             if (p < 0) continue;
-            const int t = A.m_idx[(size_t)p * A.m_stride + s];
-            if (t < 0 || !A.m_good[(size_t)p * A.m_stride + s]) continue;
-            const double *kpx = kfv_px(A.V, kfi[j]);
+            double ox, oy;
+            if (A.direct) {
+                if (!A.o_ok[(size_t)p * A.m_stride + s]) continue;
+                ox = A.o_px[2 * ((size_t)p * A.m_stride + s)]; oy = A.o_px[2 * ((size_t)p * A.m_stride + s) + 1];
+            } else {
+                const int t = A.m_idx[(size_t)p * A.m_stride + s];
+                if (t < 0 || !A.m_good[(size_t)p * A.m_stride + s]) continue;
+                const double *kpx = kfv_px(A.V, kfi[j]);
+                ox = kpx[2 * (size_t)t]; oy = kpx[2 * (size_t)t + 1];
+            }
             const size_t r = (size_t)row0 + c;
             pose_c[r * 64 + lane] = j; enable_c[r * 64 + lane] = 1; huber_c[r * 64 + lane] = B.huber;
-            BA_EC(obs_c, r, 2, 0, lane) = kpx[2 * (size_t)t]; BA_EC(obs_c, r, 2, 1, lane) = kpx[2 * (size_t)t + 1];
+            BA_EC(obs_c, r, 2, 0, lane) = ox; BA_EC(obs_c, r, 2, 1, lane) = oy;
             edge_rl[e0 + c] = (int32_t)(r * 64 + lane);
             ppc[(size_t)l * Kf + (j - 1)] = (int16_t)c;
             ++c;
@@ -244,15 +303,8 @@ __global__ __launch_bounds__(WIN_THREADS) void k_win_edges(WinArgs A)
         if (j >= 1) free_pose[j - 1] = j;
         double est[6] = { 0, 0, 0, 0, 0, 0 };
         if (j >= 1 && j < nk) {
-            const int32_t *kff = A.kf_frame + (size_t)w * A.Kcap;
-            Se3 T; T.q[0] = T.q[1] = T.q[2] = 0; T.q[3] = 1; T.t[0] = T.t[1] = T.t[2] = 0;
-            for (int f = kff[0] + 1; f <= kff[j]; ++f) {
-                Se3 Rl, C;
-                const double *r = A.V.trel + 7 * (size_t)f;
-                Rl.q[0] = r[0]; Rl.q[1] = r[1]; Rl.q[2] = r[2]; Rl.q[3] = r[3]; Rl.t[0] = r[4]; Rl.t[1] = r[5]; Rl.t[2] = r[6];
-                se3_mul_d(&Rl, &T, &C);
-                T = C;
-            }
+            Se3 T;
+            win_chain(A, w, j, T);
             double lg[6];
             se3_log_d(&T, lg);                                              // [upsilon; omega]
             est[0] = lg[3]; est[1] = lg[4]; est[2] = lg[5]; est[3] = lg[0]; est[4] = lg[1]; est[5] = lg[2];   // VertexSE3Sophus: [omega; upsilon]
@@ -265,7 +317,7 @@ __global__ __launch_bounds__(WIN_THREADS) void k_win_edges(WinArgs A)
     }
 }
 
-// [poses 6 Kcap | points 3 Pcap | K P E iterations trials chi2_initial chi2_final lambda] per window (unused entries 0)
+// [poses 6 Kcap | points 3 Pcap | K P E iterations trials chi2_initial chi2_final lambda | edges tested, outliers, chi2 of the tested edges, chi2 of the inliers] per window (unused entries 0)
 __global__ __launch_bounds__(256) void k_ba_pack(const BaDev *__restrict__ wins, double *__restrict__ out, size_t row_doubles, int Kcap, int Pcap)
 {
     const BaDev B = wins[blockIdx.x];
@@ -277,6 +329,7 @@ __global__ __launch_bounds__(256) void k_ba_pack(const BaDev *__restrict__ wins,
         const ygz_ba_stats st = *reinterpret_cast<const ygz_ba_stats *>(B.lm_out);
         double *d = o + 6 * (size_t)Kcap + 3 * (size_t)Pcap;
         d[0] = B.K; d[1] = B.P; d[2] = B.E; d[3] = st.iterations; d[4] = st.lm_trials; d[5] = st.chi2_initial; d[6] = st.chi2_final; d[7] = st.lambda_final;
+        for (int i = 0; i < 4; ++i) d[8 + i] = B.lm_out[4 + i];           // edges tested, outliers, chi2 of all tested edges, chi2 of the inliers (ygz_hip_ba_mark_outliers; -1: not computed)
     }
 }
 
@@ -313,22 +366,23 @@ int ygz_hip_se3_chain(const double *T_rel, int n, double *T_out)
     return YGZ_OK;
 }
 
-size_t ygz_hip_kf_row_bytes(const ygz_hip_ctx *ctx)
+size_t ygz_hip_kf_row_bytes(const ygz_hip_ctx *ctx, int with_images)
 {
     if (!ctx) return 0;
-    size_t off[5], rb;
-    kf_layout(ctx->cells, off, &rb);
+    size_t off[5], oi[YGZ_MAX_LEVELS], rb;
+    kf_layout(ctx, with_images != 0, off, oi, &rb);
     return rb;
 }
 
-int ygz_hip_kf_store_create(ygz_hip_ctx *ctx, int n_keyframes, int n_frames, int max_windows, void *rows_mem, size_t rows_mem_bytes)
+int ygz_hip_kf_store_create(ygz_hip_ctx *ctx, int n_keyframes, int n_frames, int max_windows, void *rows_mem, size_t rows_mem_bytes, int with_images)
 {
     YgzDeviceGuard dg_(ctx);
     if (!ctx || n_keyframes < 1 || n_frames < 1 || max_windows < 1) return YGZ_E_INVALID;
     if (ctx->kfs) { YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ygz_kf_store_free(ctx); }
     auto *S = new ygz_hip_ctx::KfStore();
     size_t off[5];
-    kf_layout(ctx->cells, off, &S->row_bytes);
+    S->with_images = with_images != 0;
+    kf_layout(ctx, S->with_images, off, S->off_img, &S->row_bytes);
     S->off_px = off[0]; S->off_depth = off[1]; S->off_level = off[2]; S->off_desc = off[3]; S->off_count = off[4];
     S->n_kf = n_keyframes; S->n_frames = n_frames; S->max_windows = max_windows;
     const size_t n_rows = (size_t)n_keyframes + max_windows, need = n_rows * S->row_bytes;
@@ -378,6 +432,20 @@ int ygz_hip_kf_store_put(ygz_hip_ctx *store, ygz_hip_ctx *src, int n, const int3
         A.n_kp = src->n_kp; A.kp_px = src->kp_px; A.kp_depth = src->kp_depth; A.kp_level = src->kp_level; A.kp_desc = src->kp_desc;
         for (int i = 0; i < KF_PUT_MAX; ++i) { A.slot[i] = i < A.n ? src_slot[b + i] : 0; A.kf[i] = i < A.n ? kf_index[b + i] : 0; }
         YGZ_LAUNCH(src, KID_WINDOW, k_kf_put, dim3(ygz_div_up(src->cells, 256), A.n), dim3(256), A);
+        if (store->kfs->with_images) {
+            if (src->prm.pyramid_levels != store->prm.pyramid_levels || src->lw[0] != store->lw[0] || src->lh[0] != store->lh[0]) return YGZ_E_STATE;
+            KfImgArgs I;
+            size_t mx = 0;
+            for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
+                const bool in = L < store->prm.pyramid_levels;
+                I.lvl[L] = in ? src->lvl[L] : nullptr; I.off_img[L] = store->kfs->off_img[L]; I.bytes[L] = in ? (size_t)src->lw[L] * src->lh[L] : 0;
+                if (I.bytes[L] > mx) mx = I.bytes[L];
+            }
+            I.rows = store->kfs->rows; I.row_bytes = store->kfs->row_bytes;
+            for (int i = 0; i < KF_PUT_MAX; ++i) { I.slot[i] = A.slot[i]; I.kf[i] = A.kf[i]; }
+            for (int i = 0; i < A.n; ++i) if (!src->pyr_valid[I.slot[i]]) return YGZ_E_STATE;
+            YGZ_LAUNCH(src, KID_WINDOW, k_kf_put_img, dim3((unsigned)((mx / 16 + 255) / 256 + 1), A.n, store->prm.pyramid_levels), dim3(256), I);
+        }
     }
     YGZ_HIPCHK(src, hipGetLastError());
     return YGZ_OK;
@@ -435,7 +503,7 @@ int ygz_hip_ba_reserve_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows
 // the device and asynchronous: window i consists of the n_kfs[i] keyframes in store rows kf_index[i][0 .. K) which are the frames
 // kf_frame[i][.] of the sequence (ascending); see the head of this file for what is built.
 int ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, const int32_t *kf_index, const int32_t *kf_frame,
-                             const int32_t *n_kfs)
+                             const int32_t *n_kfs, int obs_mode)
 {
     YgzDeviceGuard dg_(ctx);
     if (!ctx || !ctx->kfs || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size() || !kf_index || !kf_frame || !n_kfs)
@@ -443,9 +511,12 @@ int ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, 
     { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     auto *S = ctx->kfs;
     if (n_windows > S->max_windows) return YGZ_E_CAPACITY;
+    if (obs_mode != 0 && obs_mode != 1) return YGZ_E_INVALID;
+    if (obs_mode == 1 && !S->with_images) return YGZ_E_STATE;                // direct projection reads the keyframes' pyramids from the rows
     const auto *w0 = ctx->ba[window_begin];
     if (!w0 || !w0->device_built) return YGZ_E_STATE;
     const int K = w0->cap_K, P = w0->cap_P;
+    if (K > 64) return YGZ_E_CAPACITY;                                       // k_win_poses: one lane per keyframe of a window
     int n_pairs = 0;
     for (int i = 0; i < n_windows; ++i) {
         const auto *w = ctx->ba[window_begin + i];
@@ -457,16 +528,18 @@ int ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, 
         }
         n_pairs += n_kfs[i] - 1;
     }
-    if (n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;               // the matcher's per-pair result rows
+    if (obs_mode == 0 && n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;   // the matcher's per-pair result rows
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);                            // (uploads the entries of freshly reserved windows)
     if (!table) return rc;
     if ((rc = ygz_pf_ensure(ctx)) != YGZ_OK) return rc;
     // host tables -> page-locked stage -> device scratch
-    const size_t nK = (size_t)n_windows * K, n_int = 3 * nK + n_windows + 2 * (size_t)n_pairs;
+    // int tables: kf_index, kf_frame, pair_of [n_win][K] | n_kfs [n_win] | per pair: (set row, keyframe row) for the matcher, (window, j) for the projection
+    const size_t nK = (size_t)n_windows * K, n_int = 3 * nK + n_windows + 4 * (size_t)n_pairs;
     int32_t *h = (int32_t *)ygz_stage(ctx, n_int * 4);
     if (!h) return YGZ_E_HIP;
-    int32_t *h_kfi = h, *h_kff = h + nK, *h_pof = h + 2 * nK, *h_nk = h + 3 * nK, *h_pq = h_nk + n_windows, *h_pt = h_pq + n_pairs;
+    int32_t *h_kfi = h, *h_kff = h + nK, *h_pof = h + 2 * nK, *h_nk = h + 3 * nK, *h_pq = h_nk + n_windows, *h_pt = h_pq + n_pairs, *h_pw = h_pt + n_pairs,
+            *h_pj = h_pw + n_pairs;
     int p = 0;
     for (int i = 0; i < n_windows; ++i) {
         h_nk[i] = n_kfs[i];
@@ -475,12 +548,14 @@ int ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, 
             h_kfi[(size_t)i * K + j] = in ? kf_index[(size_t)i * K + j] : 0;
             h_kff[(size_t)i * K + j] = in ? kf_frame[(size_t)i * K + j] : 0;
             h_pof[(size_t)i * K + j] = -1;
-            if (in && j >= 1) { h_pof[(size_t)i * K + j] = p; h_pq[p] = S->n_kf + i; h_pt[p] = kf_index[(size_t)i * K + j]; ++p; }
+            if (in && j >= 1) { h_pof[(size_t)i * K + j] = p; h_pq[p] = S->n_kf + i; h_pt[p] = kf_index[(size_t)i * K + j]; h_pw[p] = i; h_pj[p] = j; ++p; }
         }
     }
-    const size_t n_scr_int = n_int + 4 * (size_t)n_windows * P;
+    // scratch: the int tables | 4 x [n_win][P] ints | Tj [n_win][K][7] doubles | (direct) obs_px [pairs][P][2] doubles, obs_ok [pairs][P]
+    const size_t n_scr_int = ((n_int + 4 * (size_t)n_windows * P + 1) & ~(size_t)1);
+    const size_t tj_bytes = nK * 56, opx_bytes = obs_mode == 1 ? (size_t)n_pairs * P * 16 : 0, ook_bytes = obs_mode == 1 ? (size_t)n_pairs * P : 0;
     int32_t *d = nullptr;
-    if ((rc = ygz_scratch(ctx, SCR_WIN, n_scr_int * 4 + 64, (void **)&d)) != YGZ_OK) return rc;
+    if ((rc = ygz_scratch(ctx, SCR_WIN, n_scr_int * 4 + tj_bytes + opx_bytes + ook_bytes + 64, (void **)&d)) != YGZ_OK) return rc;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(d, h, n_int * 4, hipMemcpyHostToDevice, ctx->stream));
     WinArgs A;
     A.V = kf_view(ctx);
@@ -490,16 +565,34 @@ int ygz_hip_ba_build_windows(ygz_hip_ctx *ctx, int window_begin, int n_windows, 
     A.wins = const_cast<BaDev *>(table) + window_begin;
     A.sel_idx = d + n_int; A.sc_new = A.sel_idx + (size_t)n_windows * P; A.sc_cnt = A.sc_new + (size_t)n_windows * P; A.sc_e0 = A.sc_cnt + (size_t)n_windows * P;
     A.m_idx = ctx->m_idx; A.m_good = ctx->m_good; A.m_stride = (size_t)ctx->cells;
+    A.Tj = reinterpret_cast<double *>(d + n_scr_int);
+    double *d_opx = reinterpret_cast<double *>(reinterpret_cast<uint8_t *>(A.Tj) + tj_bytes);
+    uint8_t *d_ook = reinterpret_cast<uint8_t *>(d_opx) + opx_bytes;
+    A.direct = obs_mode; A.o_ok = d_ook; A.o_px = d_opx;
+    if (obs_mode == 1) A.m_stride = (size_t)P;
     for (int i = 0; i < n_windows; ++i) {
         auto *w = ctx->ba[window_begin + i];
         YGZ_HIPCHK(ctx, hipMemsetAsync(w->Hpp, 0, ygz_ba_zero_bytes(w), ctx->stream));
     }
     YGZ_LAUNCH(ctx, KID_WINDOW, k_win_select, dim3(n_windows), dim3(WIN_THREADS), A);
+    YGZ_LAUNCH(ctx, KID_WINDOW, k_win_poses, dim3(n_windows), dim3(64), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    rc = ygz_run_match(ctx, reinterpret_cast<const uint32_t *>(S->rows + S->off_desc), S->row_bytes / 4, S->counts, d_pq, d_pt, n_pairs, ctx->cells, 1, false);
-    if (rc != YGZ_OK) return rc;
-    if ((rc = ygz_launch_match_postfilter(ctx, S->counts, d_pq, n_pairs, 20.0, 50.0, 3.0)) != YGZ_OK) return rc;     // test_orb_match.cpp:97-104
-    ctx->n_pairs = 0; ctx->pf_valid = false;                                // the per-pair buffers of the resident pair table were reused
+    if (obs_mode == 0) {
+        rc = ygz_run_match(ctx, reinterpret_cast<const uint32_t *>(S->rows + S->off_desc), S->row_bytes / 4, S->counts, d_pq, d_pt, n_pairs, ctx->cells, 1, false);
+        if (rc != YGZ_OK) return rc;
+        if ((rc = ygz_launch_match_postfilter(ctx, S->counts, d_pq, n_pairs, 20.0, 50.0, 3.0)) != YGZ_OK) return rc;     // test_orb_match.cpp:97-104
+        ctx->n_pairs = 0; ctx->pf_valid = false;                            // the per-pair buffers of the resident pair table were reused
+    } else {
+        // FindCandidates + ProjectMapPoints (LocalMapping.cpp:47-120): every selected anchor feature into every other keyframe of its window
+        YGZ_HIPCHK(ctx, hipMemsetAsync(d_ook, 0, ook_bytes, ctx->stream));
+        YgzWinProject W;
+        W.rows = S->rows; W.row_bytes = S->row_bytes; W.off_px = S->off_px; W.off_depth = S->off_depth; W.off_level = S->off_level;
+        W.n_levels = ctx->prm.pyramid_levels;
+        for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { W.off_img[L] = S->off_img[L]; W.w[L] = ctx->lw[L]; W.h[L] = ctx->lh[L]; }
+        W.pair_w = d_pt + n_pairs; W.pair_j = W.pair_w + n_pairs; W.kf_index = A.kf_index; W.counts = S->counts;
+        W.n_pairs = n_pairs; W.Kcap = K; W.Pcap = P; W.set_base = S->n_kf; W.Tj = A.Tj; W.obs_px = d_opx; W.obs_ok = d_ook; W.stride = (size_t)P;
+        if ((rc = ygz_launch_win_project(ctx, W)) != YGZ_OK) return rc;
+    }
     YGZ_LAUNCH(ctx, KID_WINDOW, k_win_edges, dim3(n_windows), dim3(WIN_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
@@ -518,14 +611,14 @@ int ygz_hip_ba_pack_states(ygz_hip_ctx *ctx, int window_begin, int n_windows, do
         const auto *w = ctx->ba[window_begin + i];
         if (!w || (w->device_built ? w->cap_K : w->K) != K || (w->device_built ? w->cap_P : w->P) != P) return YGZ_E_INVALID;
     }
-    if (row_doubles < (size_t)6 * K + (size_t)3 * P + 8) return YGZ_E_INVALID;
+    if (row_doubles < (size_t)6 * K + (size_t)3 * P + 12) return YGZ_E_INVALID;
     { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);
     if (!table) return rc;
     double *out = dst;
     if (!dst_on_device && (rc = ygz_scratch(ctx, SCR_GEN_0 + 3, (size_t)n_windows * row_doubles * 8, (void **)&out)) != YGZ_OK) return rc;
-    if (row_doubles > (size_t)6 * K + (size_t)3 * P + 8) YGZ_HIPCHK(ctx, hipMemsetAsync(out, 0, (size_t)n_windows * row_doubles * 8, ctx->stream));
+    if (row_doubles > (size_t)6 * K + (size_t)3 * P + 12) YGZ_HIPCHK(ctx, hipMemsetAsync(out, 0, (size_t)n_windows * row_doubles * 8, ctx->stream));
     YGZ_LAUNCH(ctx, KID_WINDOW, k_ba_pack, dim3(n_windows), dim3(256), table + window_begin, out, row_doubles, K, P);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (!dst_on_device) YGZ_HIPCHK(ctx, hipMemcpyAsync(dst, out, (size_t)n_windows * row_doubles * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -234,6 +234,19 @@ struct YgzPoDev {
 int ygz_launch_pose_only(ygz_hip_ctx *ctx, int n_frames, const YgzPoDev &d);
 int ygz_pf_ensure(ygz_hip_ctx *ctx);
 int ygz_launch_match_postfilter(ygz_hip_ctx *ctx, const int32_t *set_count, const int32_t *pair_q, int n_pairs, double lo, double hi, double factor);
+// LocalMapping::FindCandidates + ProjectMapPoints for the windows of the keyframe store (align.hip, called by window.hip): for pair p =
+// (window pair_w[p], keyframe j = pair_j[p]) and every selected anchor feature s of that window, the map point (the feature's pixel and
+// depth in the anchor's camera) is projected with the chained pose Tj[w][j], tested like FindCandidates and refined with
+// FindDirectProjection from the anchor's image into the keyframe's; images live in the store's rows.
+struct YgzWinProject {
+    const uint8_t *rows; size_t row_bytes, off_px, off_depth, off_level, off_img[YGZ_MAX_LEVELS];
+    int n_levels, w[YGZ_MAX_LEVELS], h[YGZ_MAX_LEVELS];
+    const int32_t *pair_w, *pair_j, *kf_index, *counts;     // [n_pairs], [n_pairs], [n_win][Kcap], the store's per-row counts
+    int n_pairs, Kcap, Pcap, set_base;
+    const double *Tj;                                        // [n_win][Kcap][7]
+    double *obs_px; uint8_t *obs_ok; size_t stride;          // [n_pairs][stride][2], [n_pairs][stride]
+};
+int ygz_launch_win_project(ygz_hip_ctx *ctx, const YgzWinProject &P);
 bool ygz_ba_window_has_dup(const ygz_hip_ctx *ctx, int window);    // an uploaded BA window repeats a (point, free pose) pair (ba.hip)
 
 // ---------------------------------------------------------------------------------------------

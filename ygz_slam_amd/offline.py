@@ -19,8 +19,11 @@ sampled at the keypoints ON THE DEVICE (ygz_hip_keypoint_depths_from_image).
 
 BA round (LocalMapping::LocalBA -> ba::LocalBAG2O, LocalMapping.cpp:149-208, BA.cpp:386-543): keyframes are every
 `kf_stride`-th frame, a window = `window_kfs` consecutive keyframes owned by the rank that owns its first keyframe (the
-anchor, held fixed like keyframe 0 at BA.cpp:404); map points = the anchor's features with depth, observations = the
-good cross-checked Hamming matches of the anchor's descriptors in the other keyframes of the window.  The windows are built ON
+anchor, held fixed like keyframe 0 at BA.cpp:404); map points = the anchor's features with depth; observations (obs_mode "direct",
+the default since round 4) = what LocalMapping::ProjectMapPoints leaves in a keyframe (LocalMapping.cpp:47-120): the map point projected
+with the tracked pose, kept if in view (FindCandidates), refined to sub-pixel by Matcher::FindDirectProjection from the anchor's image --
+the keyframe rows carry the pyramids for that -- or (obs_mode "match", rounds 2-3) the good cross-checked Hamming matches of the anchor's
+descriptors in the other keyframes; after optimize(20) the edges with chi2 > 5.991 are counted as BA.cpp:503-515 does.  The windows are built ON
 THE DEVICE from a store of keyframe rows (csrc/window.hip), in the gauge of their anchor (anchor pose = identity, the other
 vertices chained from the frames' relative poses), so a window depends on its own frames only: it is built and optimised as soon
 as the chunk holding its last keyframe has been enqueued -- beside the uploads and kernels of the following chunks -- and the
@@ -254,7 +257,8 @@ class OfflineVO:
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
                  max_points=2000, ba_iterations=20, overlap=False, process_group=None, exchange_on_device=True, keep=False, lanes=3,
-                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None, upload_ahead=0):
+                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None, upload_ahead=0,
+                 obs_mode="direct", ba_rounds=1, outlier_chi2=5.991):
         from . import _lib
         self.lib = _lib
         self.w, self.h, self.levels = width, height, levels
@@ -264,6 +268,13 @@ class OfflineVO:
         self.overlap, self.pg, self.exchange_on_device, self.keep = overlap, process_group, exchange_on_device, keep
         self.depth_div, self.depth_dtype, self.depth_scale = depth_div, np.dtype(depth_dtype), depth_scale
         self.pipeline_ba, self.lm_group = pipeline_ba, lm_group
+        # observations of a window's map points in its keyframes: "direct" = what LocalMapping::ProjectMapPoints leaves in a keyframe
+        # (projection with the tracked pose + FindDirectProjection from the anchor's image, LocalMapping.cpp:47-120) -- the keyframe rows
+        # then carry the images; "match" = good cross-checked Hamming matches of the anchor's descriptors (rounds 2-3).  After the LM the
+        # edges above outlier_chi2 are counted (BA.cpp:503-515); ba_rounds = 2 switches them off and optimises once more (what the next
+        # LocalBAG2O of the reference sees after Feature::_bad was set).
+        assert obs_mode in ("direct", "match") and ba_rounds in (1, 2)
+        self.obs_mode, self.ba_rounds, self.outlier_chi2 = obs_mode, ba_rounds, outlier_chi2
         import os as _os
         self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
         self.ramp = _os.environ.get("YGZ_OFF_RAMP", "1") != "0"
@@ -304,11 +315,11 @@ class OfflineVO:
         self.rows_t = None
         if world > 1 and self.any_cross:                                          # rows of other ranks arrive by a collective: torch owns the memory
             import torch
-            rb = self.ba.kf_row_bytes()
+            rb = self.ba.kf_row_bytes(self.obs_mode == "direct")
             self.rows_t = torch.zeros((self.n_kf + self.build_group) * rb, dtype=torch.uint8, device=torch.device("cuda", device))
-            self.ba.kf_store_create(self.n_kf, n_total, self.build_group, self.rows_t.data_ptr(), self.rows_t.numel())
+            self.ba.kf_store_create(self.n_kf, n_total, self.build_group, self.rows_t.data_ptr(), self.rows_t.numel(), with_images=self.obs_mode == "direct")
         else:
-            self.ba.kf_store_create(self.n_kf, n_total, self.build_group)
+            self.ba.kf_store_create(self.n_kf, n_total, self.build_group, with_images=self.obs_mode == "direct")
         if self.mine:
             self.ba.ba_reserve_windows(0, len(self.mine), window_kfs, max_points)
         self.trace = None
@@ -318,7 +329,7 @@ class OfflineVO:
             self.lanes = [_Traced(c, self.trace, "lane%d" % i) for i, c in enumerate(self.lanes)]
             self.ctx = self.lanes[0]
             self.ba = _Traced(self.ba, self.trace, "ba")
-        self.S = 6 * window_kfs + 3 * max_points + 8                              # one window state row: poses | points | K P E its trials chi2_0 chi2 lambda
+        self.S = 6 * window_kfs + 3 * max_points + 12                             # one window state row: poses | points | K P E its trials chi2_0 chi2 lambda | edges tested, outliers, chi2, chi2 of inliers
         cap = max(n_slots, 2)
         self._pin = [dict(sum=_lib.PinnedArray((cap, _lib.SUMMARY_FIELDS), np.float64), cnt=_lib.PinnedArray((cap,), np.int32)) for _ in self.lanes]
         self.timing = {}
@@ -478,7 +489,7 @@ class OfflineVO:
         if self.world == 1 or not self.any_cross:
             return
         import torch
-        rb = self.ba.kf_row_bytes()
+        rb = self.ba.kf_row_bytes(self.obs_mode == "direct")
         rows = self.rows_t[:self.n_kf * rb].view(self.n_kf, rb)
         own = [[k for k, f in enumerate(keyframes(self.n_total, self.kf_stride)) if frame_owner(f, self.n_total, self.world) == r]
                for r in range(self.world)]
@@ -501,8 +512,16 @@ class OfflineVO:
         """the resident LM on windows that are built (consecutive owned windows), asynchronous"""
         if wis:
             assert wis == list(range(wis[0], wis[-1] + 1))
-            self.ba.ba_optimize_resident(self.mine.index(wis[0]), len(wis), self.ba_iterations, want_stats=False)
+            self._lm(self.mine.index(wis[0]), len(wis))
             self._ba_done.update(wis)
+
+    def _lm(self, slot0, n):
+        """optimize(20) + the inlier test of BA.cpp:503-515 (+ a second optimisation without the outliers when ba_rounds == 2), asynchronous"""
+        self.ba.ba_optimize_resident(slot0, n, self.ba_iterations, want_stats=False)
+        self.ba.ba_mark_outliers(slot0, n, self.outlier_chi2, disable=self.ba_rounds == 2)
+        if self.ba_rounds == 2:
+            self.ba.ba_optimize_resident(slot0, n, self.ba_iterations, want_stats=False)
+            self.ba.ba_mark_outliers(slot0, n, self.outlier_chi2, disable=False)
 
     def _ba_launch(self, wis, optimize=True):
         """build (+ optimise) the given (owned) windows on the BA context, behind everything the lanes have enqueued so far"""
@@ -520,9 +539,9 @@ class OfflineVO:
                 kff[a, :len(w)] = w
                 kfi[a, :len(w)] = [f // self.kf_stride for f in w]
             slot0 = self.mine.index(grp[0])
-            self.ba.ba_build_windows(slot0, kfi, kff, [len(self.wins[wi]) for wi in grp])
+            self.ba.ba_build_windows(slot0, kfi, kff, [len(self.wins[wi]) for wi in grp], obs_mode=1 if self.obs_mode == "direct" else 0)
             if optimize:
-                self.ba.ba_optimize_resident(slot0, len(grp), self.ba_iterations, want_stats=False)
+                self._lm(slot0, len(grp))
         if optimize:
             self._ba_done.update(wis)
 
@@ -546,6 +565,9 @@ class OfflineVO:
             import torch
             dev = self._torch_device()
             state = torch.zeros((n_w, S), dtype=torch.float64, device=dev)
+            # the zero fill runs on torch's current stream, k_ba_pack on the BA context's own (non-blocking) stream: without this wait the
+            # fill may land after the packed rows and zero them (gather_keyframes guards its buffer the same way)
+            torch.cuda.synchronize(dev)
             if self.mine:
                 self.ba.ba_pack_states(0, len(self.mine), S, dst_ptr=state[self.mine[0]].data_ptr(), wait=True)
             exchange_rows(state, self.owner, self.world, self.pg, via_host=not self.exchange_on_device)
@@ -560,7 +582,8 @@ class OfflineVO:
                 raise RuntimeError("BA window %d: the resident LM did not finish (team barrier time-out)" % wi)
             dims[wi] = (int(tail[0]), int(tail[1]), int(tail[2]))
             out.append(dict(kfs=w, owner=self.owner[wi], poses=host[wi, :len(w) * 6].reshape(len(w), 6).copy(), state=host[wi].copy(),
-                            stats=np.array([tail[5], tail[6], tail[3], tail[2]])))
+                            stats=np.array([tail[5], tail[6], tail[3], tail[2]]),
+                            inliers=dict(edges=int(tail[8]), outliers=int(tail[9]), chi2=float(tail[10]), chi2_inliers=float(tail[11]))))
         return out, dims
 
     # ------------------------------------------------------------------ whole run
@@ -619,17 +642,56 @@ class _LazyKeyframePoses(dict):
         self._fill(); return (dict, (dict(dict.items(self)),))
 
 
-def build_window_host(kf_tab, kfs, T_rel, fx, fy, cx, cy, max_points, match_sets):
+def window_pose_errors(windows, trajectory, gt):
+    """For every non-anchor keyframe of every window: the error of its pose RELATIVE TO THE ANCHOR against the ground truth, before the BA round
+    (the chained tracking result) and after it (the window's refined vertex).  gt / trajectory: [n_frames, 7] world poses.
+    Returns dict(t_before, t_after [m], r_before, r_after [rad]) as arrays over those keyframes."""
+    tb, ta, rb, ra = [], [], [], []
+
+    def err(E, G):
+        D = se3_mul(E, se3_inv(G))
+        return float(np.linalg.norm(D[4:])), float(2.0 * np.arctan2(np.linalg.norm(D[:3]), abs(D[3])))
+    for w in windows:
+        a = w["kfs"][0]
+        for k, f in enumerate(w["kfs"]):
+            if k == 0:
+                continue
+            G = se3_mul(gt[f], se3_inv(gt[a]))
+            e0 = err(se3_mul(trajectory[f], se3_inv(trajectory[a])), G)
+            e1 = err(se3_exp_g2o(w["poses"][k]), G)
+            tb.append(e0[0]); rb.append(e0[1]); ta.append(e1[0]); ra.append(e1[1])
+    return dict(t_before=np.array(tb), t_after=np.array(ta), r_before=np.array(rb), r_after=np.array(ra))
+
+
+def build_window_host(kf_tab, kfs, T_rel, fx, fy, cx, cy, max_points, match_sets=None, direct=None, width=0, height=0):
     """Host restatement of what ygz_hip_ba_build_windows assembles for one window (the tests compare the device-built graph with it):
     kf_tab[f] = dict(px, level, desc, depth) of keyframe f, match_sets(descs, pair_q, pair_t) = HipContext.match_sets.  Returns the
-    graph of ba::LocalBAG2O in the anchor's gauge: poses (g2o order), points, edges sorted by (point, keyframe)."""
+    graph of ba::LocalBAG2O in the anchor's gauge: poses (g2o order), points, edges sorted by (point, keyframe).
+    With direct = fn(ref_frame, cur_frame, T_cur, px_ref, depth_ref, level_ref, px_cur) -> (ok, px) (a per-pair FindDirectProjection, e.g.
+    HipContext.find_direct_projection on a context that holds the keyframes' pyramids) the observations are those of obs_mode 1: the map
+    point projected with the chained pose, FindCandidates' test (z >= 0, InFrame(px, 20) of a width x height frame), FindDirectProjection."""
     A = kf_tab[kfs[0]]
     sel = np.nonzero(A["depth"] > 0)[0][:max_points]
     z = A["depth"][sel]
     pc = np.stack([(A["px"][sel, 0] - cx) * z / fx, (A["px"][sel, 1] - cy) * z / fy, z], axis=1)     # Pixel2Camera (Camera.h:56-62)
     ep, el, obs = [np.zeros(len(sel), np.int32)], [np.arange(len(sel), dtype=np.int32)], [A["px"][sel]]
     others = [(j, f) for j, f in enumerate(kfs[1:], start=1)]
-    if others and len(sel):
+    if others and len(sel) and direct is not None:
+        from . import _lib
+        Tc = _lib.se3_chain(T_rel[kfs[0]:kfs[-1] + 1])            # T(anchor) = identity, the same Sophus products as the device's chain
+        for j, f in others:
+            T = Tc[f - kfs[0]]
+            q = se3_act(T, pc)
+            pred = np.stack([fx * q[:, 0] / q[:, 2] + cx, fy * q[:, 1] / q[:, 2] + cy], axis=1)            # Camera2Pixel (Camera.h:46-51)
+            vis = ~(q[:, 2] < 0) & (pred[:, 0] >= 20) & (pred[:, 0] < width - 20) & (pred[:, 1] >= 20) & (pred[:, 1] < height - 20)
+            g = np.nonzero(vis)[0]
+            if len(g):
+                ok, pxo = direct(kfs[0], f, T, A["px"][sel][g], z[g], A["level"][sel][g], pred[g])
+                g = g[ok]; pxo = pxo[ok]
+            else:
+                pxo = np.zeros((0, 2))
+            ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(pxo)
+    elif others and len(sel):
         res = match_sets([A["desc"][sel]] + [kf_tab[f]["desc"] for _, f in others], [0] * len(others), list(range(1, len(others) + 1)))
         for (j, f), r in zip(others, res):
             g = np.nonzero(r["good"])[0]
