@@ -339,6 +339,12 @@ typedef struct {
 } ygz_ba_stats;
 int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                          int max_iterations, ygz_ba_stats *stats);
+/* Which loop the last ygz_hip_ba_optimize / ygz_hip_ba_solve_ceres of the context ran.  Both route to the resident kernels
+ * (ygz_hip_ba_optimize_resident / ygz_hip_ba_solve_ceres_resident) when the window has at most 14 free poses and no repeated (point, pose)
+ * edge; otherwise the linearisations run on the GPU and the reduced system on the host -- the same results, about ten times slower.
+ * Returns YGZ_BA_PATH_RESIDENT, or YGZ_BA_PATH_HOST_LOOP | the reason bits; 0 before the first call. */
+enum { YGZ_BA_PATH_RESIDENT = 1, YGZ_BA_PATH_HOST_LOOP = 2, YGZ_BA_WHY_FREE_POSES = 16, YGZ_BA_WHY_REPEATED_EDGES = 32, YGZ_BA_WHY_FORCED = 64 };
+int  ygz_hip_ba_last_path(const ygz_hip_ctx *ctx);
 /* The same loop entirely on the GPU for uploaded windows window_begin .. +n_windows-1 (formulation 0, at most 14 free
  * poses per window): one workgroup per window runs linearisation, Schur complement, Cholesky, back-substitution, update and
  * the lambda policy in HBM/LDS without a host round trip, all windows concurrently.  The windows' states are updated in
@@ -507,6 +513,17 @@ int  ygz_hip_search_by_bow_slots(ygz_hip_ctx *ctx, int mode, int n_pairs, const 
 int  ygz_hip_search_by_bow(ygz_hip_ctx *ctx, int mode, const uint8_t *desc1, const int32_t *node1, const double *px1, int n1,
                            const uint8_t *desc2, const int32_t *node2, const double *px2, int n2, const double *E12,
                            int th_low, float knn_ratio, double epipolar_dsqr, int32_t *match12, int *count);
+
+/* Matcher::Options::checkOrientation (Matcher.h:24; Matcher.cpp:247-256, 271-289, ComputeThreeMaxima :293-336) on the result of a mode-0
+ * search: the 30-bin histogram of rot = angle1 - angle2 over the matches, its three maxima, and kept = the count SearchByBoW returns with
+ * the option on (matches outside the three fullest bins are subtracted; the reference does not remove them from the map -- its TODO at
+ * :284 -- so match12 is left alone).  SearchForTriangulation only fills the histogram (:157-165) and never reads it: nothing to call.
+ * Host form: one pair, Feature::_angle as doubles; slot form: the pairs of ygz_hip_search_by_bow_slots, the resident keypoints' angles.
+ * hist ([30] per pair) and maxima ([3] per pair, -1 = none) may be NULL. */
+int  ygz_hip_bow_orientation(ygz_hip_ctx *ctx, const double *angle1, int n1, const double *angle2, int n2, const int32_t *match12,
+                             int *kept, int32_t *hist, int32_t *maxima);
+int  ygz_hip_bow_orientation_slots(ygz_hip_ctx *ctx, int n_pairs, const int32_t *slot1, const int32_t *slot2, const int32_t *match12,
+                                   int32_t *kept, int32_t *hist, int32_t *maxima);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,7 @@ int yo_bow_transform(const yo_vocab *v, const uint8_t *desc, int n, int levelsup
     return m;
 }
 
-/* Matcher::SearchByBoW (Matcher.cpp:196-292), checkOrientation off (its pruning loop is a no-op in the reference).
+/* Matcher::SearchByBoW (Matcher.cpp:196-292) without the checkOrientation part (yo_bow_orientation below: it only changes the count).
  * node1/node2: FeatureVector membership (-1 = not in it).  match12 [n1] = index in frame 2 or -1.  Returns cnt_matches. */
 int yo_search_by_bow(const uint8_t *desc1, const int32_t *node1, int n1, const uint8_t *desc2, const int32_t *node2, int n2,
                      int th_low, float knn_ratio, int32_t *match12)
@@ -121,6 +121,46 @@ int yo_search_by_bow(const uint8_t *desc1, const int32_t *node1, int n1, const u
         if (!any) continue;                                         /* the node is absent from frame 2's FeatureVector */
         if (bestDist1 < th_low && (float)bestDist1 < knn_ratio * (float)bestDist2) { match12[i] = bestIdxF2; ++cnt; }
     }
+    return cnt;
+}
+
+/* Matcher::ComputeThreeMaxima (Matcher.cpp:293-336): the three fullest bins (-1: fewer than a tenth of the fullest) */
+static void compute_three_maxima(const int32_t *hist, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; ++i) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+/* The checkOrientation part of Matcher::SearchByBoW (Matcher.cpp:247-256, 271-289; HISTO_LENGTH = 30, Matcher.h:66) on its result
+ * match12: the histogram of rot = angle1 - angle2 (float; + 360 when negative) over bin = round(rot * (1.0f / 30)) -- the factor as the
+ * reference has it, so only bins 0 .. 12 fill --, the three maxima, and cnt_matches minus the entries of every other bin.  The
+ * reference does NOT remove those matches from the map (its TODO at :284); only the returned count changes.  hist [30], ind [3].
+ * (SearchForTriangulation fills the same histogram and never reads it, :157-165, 180-182: nothing to restate.) */
+int yo_bow_orientation(const double *angle1, const double *angle2, const int32_t *match12, int n1, int32_t *hist, int32_t *ind)
+{
+    const float factor = 1.0f / 30;
+    int cnt = 0;
+    for (int b = 0; b < 30; ++b) hist[b] = 0;
+    for (int i = 0; i < n1; ++i) {
+        if (match12[i] < 0) continue;
+        float rot = (float)(angle1[i] - angle2[match12[i]]);
+        if (rot < 0) rot += 360;
+        int bin = (int)round(rot * factor);
+        if (bin == 30) bin = 0;
+        if (bin < 0 || bin >= 30) continue;                          /* the reference asserts */
+        hist[bin]++; ++cnt;
+    }
+    int i1 = -1, i2 = -1, i3 = -1;
+    compute_three_maxima(hist, 30, &i1, &i2, &i3);
+    ind[0] = i1; ind[1] = i2; ind[2] = i3;
+    for (int b = 0; b < 30; ++b) if (b != i1 && b != i2 && b != i3) cnt -= hist[b];
     return cnt;
 }
 

@@ -584,6 +584,15 @@ class Oracle:
                                         float(knn_ratio), _p(m, C.c_int32))
         return m[:len(d1)], cnt
 
+    def bow_orientation(self, angle1, angle2, match12):
+        """the checkOrientation part of SearchByBoW: (count after the histogram test, hist [30], the three maxima)"""
+        a1 = np.ascontiguousarray(angle1, np.float64); a2 = np.ascontiguousarray(angle2, np.float64); m = np.ascontiguousarray(match12, np.int32)
+        hist = np.zeros(30, np.int32); ind = np.zeros(3, np.int32)
+        self.lib.yo_bow_orientation.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32),
+                                                C.POINTER(C.c_int32)]
+        cnt = self.lib.yo_bow_orientation(_f64(a1), _f64(a2), _p(m, C.c_int32), len(m), _p(hist, C.c_int32), _p(ind, C.c_int32))
+        return cnt, hist, ind
+
     def search_for_triangulation(self, desc1, node1, px1, desc2, node2, px2, E12, th_low=65, epipolar_dsqr=1e-4, cam=None):
         cam = cam or self.camera()
         d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)

@@ -62,6 +62,13 @@ int main(int argc, char **argv)
         matcher._options.knnRatio = 0.7f; bm.clear();
         const int c = matcher.SearchByBoW(&f[0], &f[1], bm);
         fprintf(out, "sbow %d %d %zu\n", c_quirk, c, bm.size());
+        {   // Matcher::Options::checkOrientation (Matcher.h:24): the same matches, the count after the rotation histogram
+            map<int, int> bo;
+            matcher._options.checkOrientation = true;
+            const int co = matcher.SearchByBoW(&f[0], &f[1], bo);
+            matcher._options.checkOrientation = false;
+            fprintf(out, "sbow_o %d %d\n", co, (int)(bo == bm));
+        }
         for (auto &kv : bm) fprintf(out, "sbow_m %d %d\n", kv.first, kv.second);
         // E12 of the true relative pose: x2 = R x1 + t, line in frame 2 = pt1^T E12 with E12 = ([t]x R)^T
         const SE3 T21 = f[1]._TCW * f[0]._TCW.inverse();

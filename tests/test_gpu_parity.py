@@ -869,6 +869,15 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
         del os.environ["YGZ_BA_HOST_LOOP"]
     assert abs(sh.chi2_final - stats[1].chi2_final) <= 1e-9 * sh.chi2_final
     assert _rel(ph, ctx.ba_get_state(1, len(w["poses"]), len(w["points"]))[0]) < 1e-6
+    # the caller can tell which loop ran (the host loop is ~10x slower): forced here, the resident kernel by default
+    assert ctx.ba_last_path() == (False, ["YGZ_BA_HOST_LOOP=1"])
+    ctx.ba_optimize(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
+    assert ctx.ba_last_path() == (True, [])
+    # a window that repeats a (point, pose) edge cannot run on the resident kernel: reported, not silent
+    ep = np.concatenate([w["edge_pose"], w["edge_pose"][:1]]); el = np.concatenate([w["edge_point"], w["edge_point"][:1]])
+    ob = np.concatenate([w["obs"], w["obs"][:1] + 0.25])
+    ctx.ba_optimize(w["poses"], w["fixed"], w["points"], ep, el, ob, iterations=2)
+    assert ctx.ba_last_path() == (False, ["repeated (point, pose) edges"])
     ctx.close()
 
 
@@ -934,6 +943,17 @@ def test_bow_transform_and_guided_matching(hip_lib, oracle):
             a, b = pairs1[p], pairs2[p]
             om, oc = oracle.search_by_bow(kps[a]["desc"], nodes[a], kps[b]["desc"], nodes[b], 65, 0.7)
             assert cnt[p] == oc and np.array_equal(m[p, :len(om)], om), (p, levelsup)
+        # Matcher::Options::checkOrientation: the rotation histogram of the matches, its three maxima and the count that is left (slot form:
+        # the resident keypoints' angles; host form: Feature::_angle as doubles) -- identical to the oracle's
+        kept, hist, ind = ctx.bow_orientation_slots(pairs1, pairs2, m)
+        for p in range(3):
+            a, b = pairs1[p], pairs2[p]
+            oc, oh, oi = oracle.bow_orientation(kps[a]["angle"], kps[b]["angle"], m[p, :len(nodes[a])])
+            assert kept[p] == oc and np.array_equal(hist[p], oh) and np.array_equal(ind[p], oi), (p, levelsup)
+            assert 0 < kept[p] <= cnt[p]
+            hk, hh, hi = ctx.bow_orientation(kps[a]["angle"], kps[b]["angle"], m[p, :len(nodes[a])])
+            assert (hk, list(hh), list(hi)) == (oc, list(oh), list(oi))
+        assert kept[2] == cnt[2] and list(ind[2]) == [0, -1, -1]       # a frame against itself: every rotation is 0
         self_m = m[2, :len(nodes[0])]                          # a frame against itself: whatever matches, matches itself
         assert cnt[2] > 0.9 * (nodes[0] >= 0).sum() and np.all(self_m[self_m >= 0] == np.nonzero(self_m >= 0)[0])
         # SearchForTriangulation with E12 of the true relative pose (E = [t]x R, normalised coordinates)

@@ -100,6 +100,10 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     assert sb == [0, oc, oc] and oc > 50
     got = np.array(r["sbow_m"], dtype=int)
     assert np.array_equal(got[:, 0], np.nonzero(om >= 0)[0]) and np.array_equal(got[:, 1], om[om >= 0])
+    # checkOrientation = true: the map is the same, the count is what the rotation histogram leaves (Matcher.cpp:271-289)
+    ang = [ks[i]["angle"].astype(np.float64) for i in range(2)]
+    okept, ohist, oind = oracle.bow_orientation(ang[0], ang[1], om)
+    assert [int(x) for x in r["sbow_o"][0]] == [okept, 1] and 0 < okept <= oc
     st = [float(x) for x in r["stri"][0]]
     E12 = np.array(st[2:]).reshape(3, 3)
     px = [np.stack([ks[i]["px"], ks[i]["py"]], 1) for i in range(2)]

@@ -119,3 +119,43 @@ def test_search_by_bow_and_triangulation(oracle):
     # empty second frame / nothing in common
     m0, c0 = oracle.search_by_bow(d1, n1, np.zeros((0, 32), np.uint8), np.zeros(0, np.int32))
     assert c0 == 0 and np.all(m0 == -1)
+
+
+def test_bow_orientation_histogram(oracle):
+    """the checkOrientation part of Matcher::SearchByBoW (Matcher.cpp:247-256, 271-289 + ComputeThreeMaxima :293-336) against a numpy
+    re-derivation: float rot, bin = round(rot / 30) (the reference's factor: bins 0 .. 12 only), three maxima with the 0.1 rule, count left"""
+    rng = np.random.default_rng(4)
+    for trial in range(40):
+        n1, n2 = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        a1 = rng.uniform(0, 360, n1).astype(np.float32).astype(np.float64)
+        a2 = rng.uniform(0, 360, n2).astype(np.float32).astype(np.float64)
+        if trial % 3 == 0:                                      # a dominant rotation, as between two real frames
+            m = rng.integers(0, n2, n1)
+            a1 = (a2[m] + rng.normal(25, 4, n1)) % 360
+        m = rng.integers(-1, n2, n1).astype(np.int32)
+        if trial == 7:
+            m[:] = -1
+        cnt, hist, ind = oracle.bow_orientation(a1, a2, m)
+        rot = (a1 - a2[np.maximum(m, 0)]).astype(np.float32)
+        rot = np.where(rot < 0, rot + np.float32(360), rot).astype(np.float32)
+        x = (rot * np.float32(1.0 / 30)).astype(np.float32).astype(np.float64)
+        b = (np.sign(x) * np.floor(np.abs(x) + 0.5)).astype(int)          # C round(): half away from zero
+        b[b == 30] = 0
+        h = np.bincount(b[m >= 0], minlength=30)
+        assert np.array_equal(hist, h) and h[13:].sum() == 0
+        order = []                                                         # the scan of ComputeThreeMaxima, restated
+        mx = [0, 0, 0]; ix = [-1, -1, -1]
+        for i in range(30):
+            s_ = h[i]
+            if s_ > mx[0]:
+                mx = [s_, mx[0], mx[1]]; ix = [i, ix[0], ix[1]]
+            elif s_ > mx[1]:
+                mx = [mx[0], s_, mx[1]]; ix = [ix[0], i, ix[1]]
+            elif s_ > mx[2]:
+                mx[2] = s_; ix[2] = i
+        if np.float32(mx[1]) < np.float32(0.1) * np.float32(mx[0]):
+            ix[1] = ix[2] = -1
+        elif np.float32(mx[2]) < np.float32(0.1) * np.float32(mx[0]):
+            ix[2] = -1
+        assert list(ind) == ix
+        assert cnt == int(sum(h[i] for i in set(ix) if i >= 0))

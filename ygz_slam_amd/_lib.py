@@ -100,7 +100,7 @@ ABI_SYMBOLS = [
     "ygz_hip_get_keypoints_batch", "ygz_hip_set_keypoint_depths_batch", "ygz_hip_track_get_summary", "ygz_hip_create_map_points", "ygz_hip_depth_filter_update",
     "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_se3_chain", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
     "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
-    "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states", "ygz_hip_ba_mark_outliers", "ygz_hip_ba_get_outlier_stats",
+    "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states", "ygz_hip_ba_mark_outliers", "ygz_hip_ba_get_outlier_stats", "ygz_hip_bow_orientation", "ygz_hip_bow_orientation_slots", "ygz_hip_ba_last_path",
 ]
 
 SUMMARY_FIELDS = 32
@@ -772,6 +772,27 @@ class HipContext:
                                                  _p(m, C.c_int32), C.byref(cnt)), "search_by_bow")
         return m[:len(d1)], cnt.value
 
+    def bow_orientation(self, angle1, angle2, match12):
+        """Matcher::Options::checkOrientation on a SearchByBoW result: (count, hist [30], maxima [3])"""
+        a1 = np.ascontiguousarray(angle1, np.float64); a2 = np.ascontiguousarray(angle2, np.float64); m = np.ascontiguousarray(match12, np.int32)
+        kept = C.c_int(0); hist = np.zeros(30, np.int32); ind = np.zeros(3, np.int32)
+        self.lib.ygz_hip_bow_orientation.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32),
+                                                     C.POINTER(C.c_int), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        self._chk(self.lib.ygz_hip_bow_orientation(self._ctx, _p(a1, C.c_double), len(a1), _p(a2, C.c_double), len(a2), _p(m, C.c_int32), C.byref(kept),
+                                                   _p(hist, C.c_int32), _p(ind, C.c_int32)), "bow_orientation")
+        return kept.value, hist, ind
+
+    def bow_orientation_slots(self, slot1, slot2, match12):
+        s1 = np.ascontiguousarray(slot1, np.int32); s2 = np.ascontiguousarray(slot2, np.int32); m = np.ascontiguousarray(match12, np.int32)
+        n = len(s1)
+        assert m.shape == (n, self.cells)
+        kept = np.zeros(n, np.int32); hist = np.zeros((n, 30), np.int32); ind = np.zeros((n, 3), np.int32)
+        self.lib.ygz_hip_bow_orientation_slots.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        self._chk(self.lib.ygz_hip_bow_orientation_slots(self._ctx, n, _p(s1, C.c_int32), _p(s2, C.c_int32), _p(m, C.c_int32), _p(kept, C.c_int32),
+                                                         _p(hist, C.c_int32), _p(ind, C.c_int32)), "bow_orientation_slots")
+        return kept, hist, ind
+
     # ---- BA
     def _ba_problem(self, poses, fixed, points, edge_pose, edge_point, obs, huber_delta, formulation, cam=None,
                     point_fixed=None, edge_huber=None, edge_enable=None):
@@ -863,6 +884,11 @@ class HipContext:
         self._chk(self.lib.ygz_hip_ba_optimize_resident(self._ctx, window_begin, n_windows, iterations, st if want_stats else None),
                   "ba_optimize_resident")
         return list(st) if want_stats else None
+
+    def ba_last_path(self):
+        """(resident?, reasons) of the last ba_optimize / ba_solve_ceres: the resident kernel, or the ~10x slower host loop and why"""
+        v = int(self.lib.ygz_hip_ba_last_path(self._ctx))
+        return bool(v & 1), [n for b, n in ((16, "more than 14 free poses"), (32, "repeated (point, pose) edges"), (64, "YGZ_BA_HOST_LOOP=1")) if v & b]
 
     def ba_set_team_budget(self, workgroups):
         self._chk(self.lib.ygz_hip_ba_set_team_budget(self._ctx, int(workgroups)), "ba_set_team_budget")

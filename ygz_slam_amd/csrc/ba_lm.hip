@@ -151,7 +151,11 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
         int Kfree = 0;
         for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
         const char *force = getenv("YGZ_BA_HOST_LOOP");
-        if (Kfree <= 14 && !(force && force[0] == '1') && !ygz_ba_window_has_dup(ctx, W)) {      // repeated (point, pose) pairs: host-side Schur sums them per edge
+        const bool dup = ygz_ba_window_has_dup(ctx, W), forced = force && force[0] == '1';
+        // which loop ran and why, for ygz_hip_ba_last_path: the host loop is ~10x slower and the caller should be able to tell
+        ctx->ba_last_path = (Kfree <= 14 && !forced && !dup) ? YGZ_BA_PATH_RESIDENT
+                            : (YGZ_BA_PATH_HOST_LOOP | (Kfree > 14 ? YGZ_BA_WHY_FREE_POSES : 0) | (dup ? YGZ_BA_WHY_REPEATED_EDGES : 0) | (forced ? YGZ_BA_WHY_FORCED : 0));
+        if (Kfree <= 14 && !forced && !dup) {      // repeated (point, pose) pairs: host-side Schur sums them per edge
             ygz_ba_stats st;
             if ((rc = ygz_hip_ba_optimize_resident(ctx, W, 1, max_iterations, &st)) != YGZ_OK) return rc;
             if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;
@@ -258,7 +262,10 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
         int Kfree = 0;
         for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
         const char *force = getenv("YGZ_BA_HOST_LOOP");
-        if (Kfree <= 14 && K <= 16 && !(force && force[0] == '1') && !ygz_ba_window_has_dup(ctx, W)) {
+        const bool dup = ygz_ba_window_has_dup(ctx, W), forced = force && force[0] == '1', big = Kfree > 14 || K > 16;
+        ctx->ba_last_path = (!big && !forced && !dup) ? YGZ_BA_PATH_RESIDENT
+                            : (YGZ_BA_PATH_HOST_LOOP | (big ? YGZ_BA_WHY_FREE_POSES : 0) | (dup ? YGZ_BA_WHY_REPEATED_EDGES : 0) | (forced ? YGZ_BA_WHY_FORCED : 0));
+        if (!big && !forced && !dup) {
             ygz_ceres_summary sm;
             if ((rc = ygz_hip_ba_solve_ceres_resident(ctx, W, 1, &opt, &sm)) != YGZ_OK) return rc;
             if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;
@@ -411,4 +418,11 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
     memcpy(poses_io, poses.data(), poses.size() * 8); memcpy(points_io, points.data(), points.size() * 8);
     if (summary) *summary = S;
     return YGZ_OK;
+}
+
+// which loop the last ygz_hip_ba_optimize / ygz_hip_ba_solve_ceres of this context ran: YGZ_BA_PATH_RESIDENT (the whole loop on the GPU) or
+// YGZ_BA_PATH_HOST_LOOP | reason bits (linearisations on the GPU, reduced system on the host: about ten times slower); 0: none yet
+extern "C" int ygz_hip_ba_last_path(const ygz_hip_ctx *ctx)
+{
+    return ctx ? ctx->ba_last_path : 0;
 }

@@ -320,6 +320,126 @@ int ygz_hip_search_by_bow_slots(ygz_hip_ctx *ctx, int mode, int n_pairs, const i
     return YGZ_OK;
 }
 
+// ---- the checkOrientation part of Matcher::SearchByBoW (Matcher.cpp:247-256, 271-289): one workgroup per pair builds the 30-bin histogram of
+// rot = angle1 - angle2 over the pair's matches, thread 0 takes the three maxima (ComputeThreeMaxima, :293-336) and the count that
+// is left.  The reference leaves the matches themselves alone (its TODO at :284): only cnt_matches changes.
+struct BowRotArgs {
+    const double *a1_d, *a2_d; const float *a1_f, *a2_f;      // angles as doubles (host form) or as the extractor's floats (slot form)
+    const int32_t *off1, *off2, *cnt1;                          // [pairs] first element of the pair's angle arrays, features of frame 1
+    const int32_t *match12; size_t stride;                      // [pairs][stride]
+    int32_t *kept, *hist, *ind;                                 // [pairs], [pairs][30], [pairs][3]
+};
+__global__ __launch_bounds__(256) void k_bow_orientation(BowRotArgs A)
+{
+    __shared__ int h[30];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (tid < 30) h[tid] = 0;
+    __syncthreads();
+    const int n1 = A.cnt1[p];
+    const int32_t *m = A.match12 + (size_t)p * A.stride;
+    const float factor = 1.0f / 30;
+    for (int i = tid; i < n1; i += 256) {
+        const int j = m[i];
+        if (j < 0) continue;
+        const double x1 = A.a1_d ? A.a1_d[A.off1[p] + i] : (double)A.a1_f[A.off1[p] + i], x2 = A.a2_d ? A.a2_d[A.off2[p] + j] : (double)A.a2_f[A.off2[p] + j];
+        float rot = (float)(x1 - x2);
+        if (rot < 0) rot = __fadd_rn(rot, 360.f);
+        int bin = (int)round((double)__fmul_rn(rot, factor));
+        if (bin == 30) bin = 0;
+        if (bin >= 0 && bin < 30) atomicAdd(&h[bin], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1, cnt = 0;
+        for (int i = 0; i < 30; ++i) {
+            const int s = h[i];
+            cnt += s;
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+            else if (s > max3) { max3 = s; i3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) i3 = -1;
+        for (int i = 0; i < 30; ++i) if (i != i1 && i != i2 && i != i3) cnt -= h[i];
+        A.kept[p] = cnt; A.ind[3 * p] = i1; A.ind[3 * p + 1] = i2; A.ind[3 * p + 2] = i3;
+    }
+    if (tid < 30) A.hist[30 * p + tid] = h[tid];
+}
+
+// host arrays, one pair (the class surface: Feature::_angle is a double): angle1 [n1], angle2 [n2], match12 [n1] as ygz_hip_search_by_bow
+// returned it.  kept = the count Matcher::SearchByBoW returns with checkOrientation on; hist [30] / maxima [3] may be NULL.
+int ygz_hip_bow_orientation(ygz_hip_ctx *ctx, const double *angle1, int n1, const double *angle2, int n2, const int32_t *match12, int *kept,
+                            int32_t *hist, int32_t *maxima)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || n1 < 0 || n2 < 0 || !kept) return YGZ_E_INVALID;
+    *kept = 0;
+    if (hist) for (int i = 0; i < 30; ++i) hist[i] = 0;
+    if (maxima) maxima[0] = maxima[1] = maxima[2] = -1;
+    if (n1 == 0) return YGZ_OK;
+    if (!angle1 || !match12 || (n2 > 0 && !angle2)) return YGZ_E_INVALID;
+    for (int i = 0; i < n1; ++i) if (match12[i] >= n2) return YGZ_E_INVALID;
+    const size_t N1 = (size_t)n1, N2 = (size_t)(n2 > 0 ? n2 : 1);
+    uint8_t *buf = nullptr;
+    int rc = ygz_scratch(ctx, SCR_GEN_0, (N1 + N2) * 8 + N1 * 4 + 64 * 4, (void **)&buf);
+    if (rc != YGZ_OK) return rc;
+    double *d_a1 = (double *)buf, *d_a2 = d_a1 + N1;
+    int32_t *d_m = (int32_t *)(d_a2 + N2), *d_out = d_m + N1;      // off1, off2, cnt1, kept, ind[3], hist[30]
+    const int32_t head[3] = { 0, 0, n1 };
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_a1, angle1, N1 * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n2 > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(d_a2, angle2, (size_t)n2 * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_m, match12, N1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_out, head, sizeof(head), hipMemcpyHostToDevice, ctx->stream));
+    BowRotArgs A;
+    A.a1_d = d_a1; A.a2_d = d_a2; A.a1_f = A.a2_f = nullptr; A.off1 = d_out; A.off2 = d_out + 1; A.cnt1 = d_out + 2;
+    A.match12 = d_m; A.stride = N1; A.kept = d_out + 3; A.ind = d_out + 4; A.hist = d_out + 8;
+    YGZ_LAUNCH(ctx, KID_BOW_MATCH, k_bow_orientation, dim3(1), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    int32_t h[40];
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *kept = h[3];
+    if (maxima) for (int i = 0; i < 3; ++i) maxima[i] = h[4 + i];
+    if (hist) for (int i = 0; i < 30; ++i) hist[i] = h[8 + i];
+    return YGZ_OK;
+}
+
+// slot form: the pairs and match12 [n_pairs][max_keypoints] of ygz_hip_search_by_bow_slots (mode 0), angles = the resident keypoints' (floats)
+int ygz_hip_bow_orientation_slots(ygz_hip_ctx *ctx, int n_pairs, const int32_t *slot1, const int32_t *slot2, const int32_t *match12, int32_t *kept,
+                                  int32_t *hist, int32_t *maxima)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || n_pairs < 1 || !slot1 || !slot2 || !match12 || !kept) return YGZ_E_INVALID;
+    const size_t stride = (size_t)ctx->cells, NP = (size_t)n_pairs;
+    std::vector<int32_t> nk(ctx->prm.max_frames), tab(3 * NP);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(nk.data(), ctx->n_kp, nk.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = slot1[p], b = slot2[p];
+        if (a < 0 || a >= ctx->prm.max_frames || b < 0 || b >= ctx->prm.max_frames) return YGZ_E_INVALID;
+        tab[p] = (int32_t)((size_t)a * ctx->cells); tab[NP + p] = (int32_t)((size_t)b * ctx->cells); tab[2 * NP + p] = nk[a];
+        for (int i = 0; i < nk[a]; ++i) if (match12[(size_t)p * stride + i] >= nk[b]) return YGZ_E_INVALID;
+    }
+    int32_t *d = nullptr;
+    int rc = ygz_scratch(ctx, SCR_GEN_0, (NP * stride + NP * (3 + 1 + 3 + 30)) * 4 + 64, (void **)&d);
+    if (rc != YGZ_OK) return rc;
+    int32_t *d_tab = d + NP * stride, *d_kept = d_tab + 3 * NP, *d_ind = d_kept + NP, *d_hist = d_ind + 3 * NP;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d, match12, NP * stride * 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    BowRotArgs A;
+    A.a1_d = A.a2_d = nullptr; A.a1_f = ctx->kp_angle; A.a2_f = ctx->kp_angle; A.off1 = d_tab; A.off2 = d_tab + NP; A.cnt1 = d_tab + 2 * NP;
+    A.match12 = d; A.stride = stride; A.kept = d_kept; A.ind = d_ind; A.hist = d_hist;
+    YGZ_LAUNCH(ctx, KID_BOW_MATCH, k_bow_orientation, dim3(n_pairs), dim3(256), A);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(kept, d_kept, NP * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (maxima) YGZ_HIPCHK(ctx, hipMemcpyAsync(maxima, d_ind, NP * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (hist) YGZ_HIPCHK(ctx, hipMemcpyAsync(hist, d_hist, NP * 120, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
 // host-array form of one pair (the class surface): descriptors, FeatureVector nodes (and pixels for mode 1) of both frames
 int ygz_hip_search_by_bow(ygz_hip_ctx *ctx, int mode, const uint8_t *desc1, const int32_t *node1, const double *px1, int n1,
                           const uint8_t *desc2, const int32_t *node2, const double *px2, int n2, const double *E12,

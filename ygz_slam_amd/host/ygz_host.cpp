@@ -532,9 +532,20 @@ int Matcher::SearchByBoW(Frame *kf1, Frame *kf2, map<int, int> &matches)
     hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 0, d1.data(), n1.data(), nullptr, (int)n1.size(), d2.data(), n2.data(), nullptr,
                                      (int)n2.size(), nullptr, _options.th_low, _options.knnRatio, 0.0, m.data(), &cnt), "search_by_bow");
     for (size_t i = 0; i < n1.size(); ++i) if (m[i] >= 0) matches[(int)i] = m[i];
+    if (_options.checkOrientation && !n1.empty()) {
+        // Matcher.cpp:247-256, 271-289: the rotation histogram only lowers the returned count (the matches outside the three fullest bins stay in
+        // the map: the reference's TODO at :284)
+        std::vector<double> a1(n1.size()), a2(std::max<size_t>(n2.size(), 1));
+        for (size_t i = 0; i < n1.size(); ++i) a1[i] = kf1->_features[i]->_angle;
+        for (size_t i = 0; i < n2.size(); ++i) a2[i] = kf2->_features[i]->_angle;
+        hip::check(ygz_hip_bow_orientation(hip::Runtime::Get().ctx(), a1.data(), (int)n1.size(), a2.data(), (int)n2.size(), m.data(), &cnt, nullptr, nullptr),
+                   "bow_orientation");
+    }
     return cnt;
 }
 
+// (checkOrientation: the reference fills a rotation histogram here too, Matcher.cpp:157-165, and never reads it -- "TODO" at :180-182 --, so the
+// option changes nothing in this function)
 int Matcher::SearchForTriangulation(Frame *kf1, Frame *kf2, const Matrix3d &E12, vector<pair<int, int>> &matched_points, const bool &)
 {   // Matcher.cpp:86-193 (+ CheckDistEpipolarLine :338-354)
     assert(!kf1->_feature_vec.empty() && !kf2->_feature_vec.empty());
