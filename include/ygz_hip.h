@@ -89,6 +89,10 @@ int  ygz_hip_upload_gray(ygz_hip_ctx *ctx, int slot, const uint8_t *gray, int st
 /* builds levels 1..pyramid_levels-1 (and level 0 from BGR when from_bgr!=0) for n slots */
 int  ygz_hip_build_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int from_bgr);
 int  ygz_hip_download_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst /* w_l*h_l */);
+/* the tracker's working image of a level: the level inside a 24-pixel BORDER_REFLECT_101 frame (what cv::buildOpticalFlowPyramid makes with
+ * copyMakeBorder), as the pyramid kernels wrote it once the tracker's buffers exist (first ygz_hip_track_klt / ygz_hip_klt_track).
+ * dst [h + 48][w + 48]; YGZ_E_STATE when the slot has no current framed copy of the level.  (Test / debugging aid.) */
+int  ygz_hip_download_framed_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst);
 int  ygz_hip_level_size(const ygz_hip_ctx *ctx, int level, int *w, int *h);
 
 /* ---- A2-A7: extractor -- replaces FeatureDetector::Detect

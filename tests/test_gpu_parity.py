@@ -434,6 +434,58 @@ def test_klt(hip_lib, oracle):
         ctx.close()
 
 
+def test_lk_framed_copies_written_by_the_pyramid_kernels(hip_lib):
+    """The tracker's working images (every level inside a 24-pixel BORDER_REFLECT_101 frame, cv::buildOpticalFlowPyramid's copyMakeBorder) are
+    written by the pyramid kernels once the tracker's buffers exist: k_bgr2gray16 / k_pyr_down store the interior AND the frame, k_klt_frame the
+    small levels and gray uploads, k_klt_pad only the first time.  Every path against numpy's reflect padding, all five levels, and the tracks
+    unchanged whichever kernel wrote the images."""
+    rng = np.random.default_rng(11)
+    for (w, h, bgr) in ((640, 480, True), (640, 480, False), (1280, 720, True), (328, 250, True), (96, 64, True)):
+        ctx = make_ctx(hip_lib, width=w, height=h, max_frames=2)
+        img = [rng.integers(0, 256, (h, w, 3) if bgr else (h, w), dtype=np.uint8) for _ in range(2)]
+        up = ctx.upload_bgr if bgr else ctx.upload_gray
+        for s_ in range(2):
+            up(s_, img[s_])
+        ctx.build_pyramid(0, 2, from_bgr=bgr)
+        assert ctx.download_framed_level(0, 0) is None                 # the tracker has not run: no framed copies yet
+        n = 50
+        pts = np.stack([rng.uniform(0, w, n), rng.uniform(0, h, n)], 1).astype(np.float32)
+        a = ctx.klt_track(0, 1, pts, pts)                              # k_klt_pad builds them (and allocates the buffers)
+        levels = 5
+        seen = set()
+        def check(tag):
+            for s_ in range(2):
+                for L in range(levels):
+                    try:
+                        f = ctx.download_framed_level(s_, L)
+                    except hip_lib.YgzHipError:                          # a level this context never allocated (small frames)
+                        break
+                    if f is None:                                       # a level the tracker does not use at this size
+                        continue
+                    seen.add((tag, L))
+                    ref = np.pad(ctx.download_level(s_, L), 24, mode="reflect")
+                    assert np.array_equal(f, ref), (tag, w, h, bgr, s_, L, np.argwhere(f != ref)[:4])
+        check("k_klt_pad")
+        for s_ in range(2):                                             # new content: the pyramid kernels write the framed copies themselves
+            img[s_] = rng.integers(0, 256, img[s_].shape, dtype=np.uint8)
+            up(s_, img[s_])
+        ctx.build_pyramid(0, 2, from_bgr=bgr)
+        check("pyramid kernels")
+        if w >= 640:                                                    # all five levels, both ways
+            assert seen == {(t, L) for t in ("k_klt_pad", "pyramid kernels") for L in range(5)}, seen
+        b = ctx.klt_track(0, 1, pts, pts)
+        ctx.close()
+        ctx = make_ctx(hip_lib, width=w, height=h, max_frames=2)        # the same frames through k_klt_pad: identical tracks
+        for s_ in range(2):
+            up = ctx.upload_bgr if bgr else ctx.upload_gray
+            up(s_, img[s_])
+        ctx.build_pyramid(0, 2, from_bgr=bgr)
+        c = ctx.klt_track(0, 1, pts, pts)
+        for x, y in zip(b, c):
+            assert np.array_equal(x, y, equal_nan=True)
+        ctx.close()
+
+
 def test_klt_golden(hip_lib):
     g, e = golden("align"), golden("extract")
     ctx = make_ctx(hip_lib, width=320, height=240, max_frames=2)
@@ -874,8 +926,9 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
     ctx.ba_optimize(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
     assert ctx.ba_last_path() == (True, [])
     # a window that repeats a (point, pose) edge cannot run on the resident kernel: reported, not silent
-    ep = np.concatenate([w["edge_pose"], w["edge_pose"][:1]]); el = np.concatenate([w["edge_point"], w["edge_point"][:1]])
-    ob = np.concatenate([w["obs"], w["obs"][:1] + 0.25])
+    e = int(np.nonzero(np.asarray(w["fixed"])[w["edge_pose"]] == 0)[0][0])          # an edge to a FREE pose, once more
+    ep = np.concatenate([w["edge_pose"], w["edge_pose"][e:e + 1]]); el = np.concatenate([w["edge_point"], w["edge_point"][e:e + 1]])
+    ob = np.concatenate([w["obs"], w["obs"][e:e + 1] + 0.25])
     ctx.ba_optimize(w["poses"], w["fixed"], w["points"], ep, el, ob, iterations=2)
     assert ctx.ba_last_path() == (False, ["repeated (point, pose) edges"])
     ctx.close()

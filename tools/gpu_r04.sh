@@ -120,5 +120,19 @@ print("offline %.1f frames/s  %.2f ms" % (d["value"], d["ms_per_step"]), {k: rou
 print(json.dumps(d["result_check"], indent=1))
 PY
     ;;
+g)  # whole parity suite (orientation check, ba_last_path, framed copies from the producers), frame-fold A/B
+    timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -5 $OUT/pytest.log
+    YGZ_FRAME_FUSE=0 python tools/stage_bench.py pyramid --batch 512 --reps 5
+    python tools/stage_bench.py pyramid --batch 512 --reps 5
+    YGZ_PAD_FUSE=0 python tools/stage_bench.py pyramid --batch 512 --reps 5
+    YGZ_FRAME_FUSE=0 benchline frame_kernel $STEP
+    benchline dflt $STEP
+    YGZ_BENCH_KLT_PREPARE=1 benchline prep $STEP
+    YGZ_FRAME_FUSE=0 benchline frame_kernel_b $STEP
+    benchline dflt_b $STEP
+    ;;
+h)  # the rest of the parity suite after the test fix
+    timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; tail -8 $OUT/pytest.log
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

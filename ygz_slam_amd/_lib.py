@@ -84,7 +84,7 @@ class BaStats(C.Structure):
 ABI_SYMBOLS = [
     "ygz_hip_default_params", "ygz_hip_create", "ygz_hip_destroy", "ygz_hip_synchronize", "ygz_hip_join", "ygz_hip_set_overlap", "ygz_hip_error_string",
     "ygz_hip_last_hip_error", "ygz_hip_max_keypoints", "ygz_hip_timer_begin", "ygz_hip_timer_end", "ygz_hip_probe_begin", "ygz_hip_probe_end",
-    "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_level_size",
+    "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_download_framed_level", "ygz_hip_level_size",
     "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_describe_given_angle", "ygz_hip_get_fast_maps",
     "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
     "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
@@ -393,6 +393,16 @@ class HipContext:
         return out
 
     # ---- extractor
+    def download_framed_level(self, slot, level):
+        """the tracker's working image of a level (24-pixel reflect-101 frame), or None when the slot has no current framed copy"""
+        w, h = self.level_size(level)
+        out = np.empty((h + 48, w + 48), np.uint8)
+        rc = self.lib.ygz_hip_download_framed_level(self._ctx, slot, level, _p(out, C.c_uint8))
+        if rc == E_STATE:
+            return None
+        self._chk(rc, "download_framed_level")
+        return out
+
     def detect(self, slot_begin=0, n_slots=1, occupied=None):
         occ = None
         if occupied is not None:

@@ -405,4 +405,19 @@ int ygz_hip_download_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst)
     return YGZ_OK;
 }
 
+// the tracker's framed copy of a level (KLT_B = 24 pixels of BORDER_REFLECT_101 around it, row pitch (w + 48 + 3) & ~3) as the pyramid
+// kernels (or k_klt_pad) left it: dst [h + 48][w + 48].  YGZ_E_STATE when the slot has no current framed copy of that level.
+int ygz_hip_download_framed_level(ygz_hip_ctx *ctx, int slot, int level, uint8_t *dst)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
+    if (!ctx || !dst || slot < 0 || slot >= ctx->prm.max_frames || level < 0 || level >= ctx->n_levels_alloc) return YGZ_E_INVALID;
+    if (!ctx->klt_pad[level] || ctx->pad_levels[slot] <= level) return YGZ_E_STATE;
+    const int w = ctx->lw[level], h = ctx->lh[level], pw = KLT_PW(w), ph = h + 2 * KLT_B;
+    YGZ_HIPCHK(ctx, hipMemcpy2DAsync(dst, (size_t)(w + 2 * KLT_B), ctx->klt_pad[level] + (size_t)slot * pw * ph, (size_t)pw, (size_t)(w + 2 * KLT_B), (size_t)ph,
+                                     hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
 }  // extern "C"

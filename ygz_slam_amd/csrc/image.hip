@@ -3,6 +3,7 @@
 // bit-exact with oracle/image.c.  HBM-bound: every source byte is read once, every result
 // byte written once; 16-byte accesses per lane.
 #include "ygz_internal.h"
+#include <limits.h>
 
 // gray = (1868 B + 9617 G + 4899 R + 8192) >> 14   [OpenCV 3.1 RGB2Gray<uchar>]
 __device__ __forceinline__ uint32_t gray1(uint32_t b, uint32_t g, uint32_t r)
@@ -15,6 +16,8 @@ __device__ __forceinline__ uint32_t gray1(uint32_t b, uint32_t g, uint32_t r)
 // (klt.hip; 8-byte aligned there), so that no separate copy kernel has to re-read the level.
 typedef uint32_t img_u32x4 __attribute__((ext_vector_type(4)));
 typedef img_u32x4 __attribute__((aligned(4))) img_u32x4u;
+typedef img_u32x4 __attribute__((aligned(1))) img_u32x4b;      // 16 bytes at any byte address
+typedef uint32_t __attribute__((aligned(1))) img_u32b;
 __global__ __launch_bounds__(256) void k_bgr2gray16(const uint8_t *__restrict__ bgr, uint8_t *__restrict__ gray,
                                                     unsigned npix, int slot_begin, uint8_t *__restrict__ pad, int width, int height)
 {
@@ -36,10 +39,32 @@ __global__ __launch_bounds__(256) void k_bgr2gray16(const uint8_t *__restrict__ 
     }
     reinterpret_cast<uint4 *>(gray + slot * npix)[i] = make_uint4(out[0], out[1], out[2], out[3]);
     if (pad) {
+        // the framed copy: the 16 pixels at (y, x .. x + 15) of the interior, their BORDER_REFLECT_101 images in the left / right frame columns
+        // (only the first two and the last two lanes of a row hold pixels 1 .. 24 / w - 25 .. w - 2: byte-reversed dwords), and the same again in
+        // the rows above / below the image that mirror row y (y in 1 .. 24 / h - 25 .. h - 2).  Needs w % 16 == 0, w >= 64, h >= 50.
         const unsigned p0 = i * 16u, y = p0 / (unsigned)width, x = p0 - y * (unsigned)width;
         const size_t pw = (size_t)KLT_PW(width), ph = (size_t)height + 2 * KLT_B;
+        uint8_t *base = pad + slot * pw * ph;
         img_u32x4 v; v.x = out[0]; v.y = out[1]; v.z = out[2]; v.w = out[3];
-        *reinterpret_cast<img_u32x4u *>(pad + slot * pw * ph + ((size_t)y + KLT_B) * pw + (x + KLT_B)) = v;
+        const uint32_t r0 = __builtin_amdgcn_perm(out[0], out[0], 0x00010203u), r1 = __builtin_amdgcn_perm(out[1], out[1], 0x00010203u),
+                       r2 = __builtin_amdgcn_perm(out[2], out[2], 0x00010203u), r3 = __builtin_amdgcn_perm(out[3], out[3], 0x00010203u);
+        img_u32x4 rv; rv.x = r3; rv.y = r2; rv.z = r1; rv.w = r0;                 // the 16 pixels in reverse order
+        auto store_row = [&](int r) {
+            uint8_t *row = base + (size_t)r * pw;
+            *reinterpret_cast<img_u32x4u *>(row + x + KLT_B) = v;
+            if (x == 0u) *reinterpret_cast<img_u32x4b *>(row + KLT_B - 15) = rv;                       // pixels 15 .. 0 -> columns 9 .. 24
+            else if (x == 16u) {                                                                        // pixels 24 .. 16 -> columns 0 .. 8
+                *reinterpret_cast<img_u32b *>(row + 5) = r0; *reinterpret_cast<img_u32b *>(row + 1) = r1; row[0] = (uint8_t)(out[2] & 255u);
+            }
+            if ((int)x == width - 16) *reinterpret_cast<img_u32x4b *>(row + KLT_B + width - 1) = rv;    // pixels w-1 .. w-16 -> columns 24+w-1 .. 24+w+14
+            else if ((int)x == width - 32) {                                                            // pixels w-17 .. w-25 -> columns 24+w+15 .. 24+w+23
+                *reinterpret_cast<img_u32b *>(row + KLT_B + width + 15) = r3; *reinterpret_cast<img_u32b *>(row + KLT_B + width + 19) = r2;
+                row[KLT_B + width + 23] = (uint8_t)(out[1] >> 24);
+            }
+        };
+        store_row((int)y + KLT_B);
+        if (y >= 1u && y <= (unsigned)KLT_B) store_row(KLT_B - (int)y);
+        if ((int)y >= height - 1 - KLT_B && (int)y <= height - 2) store_row(KLT_B + 2 * (height - 1) - (int)y);
     }
 }
 
@@ -71,7 +96,7 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define PD_X0 16           // staged column of source x = 2*ox0
 // pad != nullptr: every result byte also goes into the interior of the tracker's framed copy of the destination level.
 __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                  int sw, int sh, int dw, int dh, int slot_begin, uint8_t *__restrict__ pad)
+                                                  int sw, int sh, int dw, int dh, int slot_begin, uint8_t *__restrict__ pad, int frame_here)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[PD_SH][PD_SW];
     const size_t slot = (size_t)(slot_begin + blockIdx.z);
@@ -133,7 +158,23 @@ __global__ __launch_bounds__(256) void k_pyr_down(const uint8_t *__restrict__ sr
                 const int v = hrow[2 * k] + 4 * hrow[2 * k + 1] + 6 * hrow[2 * k + 2] + 4 * hrow[2 * k + 3] + hrow[2 * k + 4];
                 const uint8_t o8 = (uint8_t)((v + 128) >> 8);
                 d[(size_t)oy * dw + ox] = o8;
-                if (pd) pd[(size_t)oy * dpw + ox] = o8;
+                if (pd) {
+                    // the framed copy: the interior pixel and, near the image's edges, its BORDER_REFLECT_101 images in the frame (frame_here:
+                    // dw, dh > KLT_B + 1, so that one reflection reaches every frame pixel; smaller levels leave the frame to k_klt_frame)
+                    pd[(size_t)oy * dpw + ox] = o8;
+                    if (frame_here) {
+                        // (on a small level a pixel mirrors into the left AND the right frame, or the top AND the bottom one)
+                        const bool fl = ox >= 1 && ox <= KLT_B, fr = ox >= dw - 1 - KLT_B && ox <= dw - 2;
+                        const bool ft = oy >= 1 && oy <= KLT_B, fb = oy >= dh - 1 - KLT_B && oy <= dh - 2;
+                        if (fl | fr | ft | fb) {
+                            const ptrdiff_t xl = -ox, xr = 2 * (dw - 1) - ox, yt = (ptrdiff_t)(-oy) * dpw, yb = (ptrdiff_t)(2 * (dh - 1) - oy) * dpw, y0 = (ptrdiff_t)oy * dpw;
+                            if (fl) pd[y0 + xl] = o8;
+                            if (fr) pd[y0 + xr] = o8;
+                            if (ft) { pd[yt + ox] = o8; if (fl) pd[yt + xl] = o8; if (fr) pd[yt + xr] = o8; }
+                            if (fb) { pd[yb + ox] = o8; if (fl) pd[yb + xl] = o8; if (fr) pd[yb + xr] = o8; }
+                        }
+                    }
+                }
             }
         }
     }
@@ -192,13 +233,20 @@ int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int f
     const unsigned npix = (unsigned)ctx->lw[0] * (unsigned)ctx->lh[0];
     // the tracker's framed copies are written along with the levels once its buffers exist (first LK call): no copy kernel per step
     static const int fuse_env = [] { const char *e = getenv("YGZ_PAD_FUSE"); return e ? atoi(e) : 1; }();
-    bool fuse = fuse_env != 0 && up_to_level >= 1;
-    for (int L = 0; L < up_to_level && fuse; ++L) if (!ctx->klt_pad[L]) fuse = false;
-    const bool l0_fused = fuse && from_bgr && (npix & 15u) == 0 && (ctx->lw[0] & 15) == 0;
+    int fuse_levels = 0;                                    // the leading levels that have a framed buffer (the tracker allocates the levels it uses)
+    while (fuse_env != 0 && fuse_levels < up_to_level && ctx->klt_pad[fuse_levels]) ++fuse_levels;
+    const bool fuse = fuse_levels > 0;
+    // level 0 comes framed out of k_bgr2gray16 when its 16-pixel groups line up with the rows and the frame is one reflection away;
+    // level L >= 1 out of k_pyr_down when both its sides exceed the frame (one reflection reaches every frame pixel); k_klt_frame does the rest
+    // (small levels; level 0 of a gray upload: interior + frame)
+    static const int frame_env = [] { const char *e = getenv("YGZ_FRAME_FUSE"); return e ? atoi(e) : 1; }();      // 0: every frame by k_klt_frame (A/B)
+    const bool l0_framed = fuse && frame_env && from_bgr && (npix & 15u) == 0 && (ctx->lw[0] & 15) == 0 && ctx->lw[0] >= 64 && ctx->lh[0] >= 2 * KLT_B + 2;
+    bool framed[YGZ_MAX_LEVELS];
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) framed[L] = L == 0 ? l0_framed : (L < fuse_levels && frame_env && ctx->lw[L] > KLT_B + 1 && ctx->lh[L] > KLT_B + 1);
     if (from_bgr) {
         if ((npix & 15u) == 0)
             YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray16, dim3(ygz_div_up((int)(npix / 16), 256), n_slots), dim3(256),
-                               ctx->bgr, ctx->lvl[0], npix, slot_begin, l0_fused ? ctx->klt_pad[0] : (uint8_t *)nullptr, ctx->lw[0], ctx->lh[0]);
+                               ctx->bgr, ctx->lvl[0], npix, slot_begin, l0_framed ? ctx->klt_pad[0] : (uint8_t *)nullptr, ctx->lw[0], ctx->lh[0]);
         else
             YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray1, dim3(ygz_div_up((int)npix, 256), n_slots), dim3(256),
                                ctx->bgr, ctx->lvl[0], npix, slot_begin);
@@ -206,24 +254,25 @@ int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int f
     for (int L = 1; L < up_to_level; ++L) {
         const int sw = ctx->lw[L - 1], sh = ctx->lh[L - 1], dw = ctx->lw[L], dh = ctx->lh[L];
         YGZ_LAUNCH(ctx, KID_PYR_DOWN, k_pyr_down, dim3(ygz_div_up(dw, PD_TW), ygz_div_up(dh, PD_TH), n_slots), dim3(256), ctx->lvl[L - 1], ctx->lvl[L], sw, sh, dw, dh, slot_begin,
-                   fuse ? ctx->klt_pad[L] : (uint8_t *)nullptr);
+                   L < fuse_levels ? ctx->klt_pad[L] : (uint8_t *)nullptr, framed[L] ? 1 : 0);
     }
     if (fuse) {
         FrameArgs F;
         for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { F.img[L] = nullptr; F.pad[L] = nullptr; F.w[L] = F.h[L] = 0; F.first[L] = 0; F.items[L] = 0; }
         int total = 0;                                  // blocks
-        for (int L = 0; L < up_to_level; ++L) {
+        for (int L = 0; L < fuse_levels; ++L) {
             const int w = ctx->lw[L], h = ctx->lh[L], pw4 = KLT_PW(w) >> 2;
             F.img[L] = ctx->lvl[L]; F.pad[L] = ctx->klt_pad[L]; F.w[L] = w; F.h[L] = h;
             F.first[L] = total;
-            F.items[L] = (L == 0 && !l0_fused) ? pw4 * (h + 2 * KLT_B) : 2 * KLT_B * pw4 + h * ((KLT_B >> 2) + pw4 - ((KLT_B + w) >> 2));
+            // level 0 that k_bgr2gray16 did not write (gray upload, odd width, small frame): interior and frame; a small level L >= 1: its frame
+            F.items[L] = framed[L] ? 0 : (L == 0 ? pw4 * (h + 2 * KLT_B) : 2 * KLT_B * pw4 + h * ((KLT_B >> 2) + pw4 - ((KLT_B + w) >> 2)));
             total += ygz_div_up(F.items[L], 256);
         }
-        F.n_levels = up_to_level; F.slot_begin = slot_begin; F.full0 = l0_fused ? 0 : 1;
-        YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_frame, dim3(total, n_slots), dim3(256), F);
+        F.n_levels = fuse_levels; F.slot_begin = slot_begin; F.full0 = 1;
+        if (total > 0) YGZ_LAUNCH(ctx, KID_KLT_PAD, k_klt_frame, dim3(total, n_slots), dim3(256), F);
     }
     if ((int)ctx->pad_levels.size() >= slot_begin + n_slots)
-        for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pad_levels[s] = (uint8_t)(fuse ? up_to_level : 0);
+        for (int s = slot_begin; s < slot_begin + n_slots; ++s) ctx->pad_levels[s] = (uint8_t)fuse_levels;
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
