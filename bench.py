@@ -463,6 +463,8 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
                                 "ba_chi2_initial_final": [[float(w["stats"][0]), float(w["stats"][1])] for w in res["windows"][:4]],
                                 # observations by direct projection (LocalMapping.cpp:82-120); the inlier test of BA.cpp:503-515 after optimize(20)
                                 "ba_observations": vo.obs_mode,
+                                "ba_lm_iterations_trials": [[w["lm"]["iterations"], w["lm"]["trials"]] for w in res["windows"][:4]],
+                                "ba_degenerate_windows": [i for i, w in enumerate(res["windows"]) if w["lm"]["degenerate"]],
                                 "ba_edges_outliers_chi2_chi2inliers": [[w["inliers"]["edges"], w["inliers"]["outliers"], w["inliers"]["chi2"], w["inliers"]["chi2_inliers"]]
                                                                        for w in res["windows"][:4]],
                                 "ba_mean_chi2_per_inlier_edge_px2": float(np.mean([w["inliers"]["chi2_inliers"] / max(1, w["inliers"]["edges"] - w["inliers"]["outliers"])

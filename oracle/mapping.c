@@ -260,7 +260,13 @@ static double compute_tau(const yo_se3 *T_ref_cur, const double f[3], double z, 
 /* expf [frozen spec of libm, like sqrtf]: the double exponential of include/ygz_exp.h (plain IEEE operations, the same sequence on the
  * host and on the device) rounded once to float.  glibc's own expf is within 0.502 ulp of it; the device's native expf (1-2 ulp) is not,
  * and one ulp of the pdf is amplified ~100 x by the cancellations of the Beta update below -- so both sides use this form. */
-static float yo_expf_cr(float x) { return (float)ygz_exp_nonpos((double)x); }
+static int g_exp_libm = 0;             /* test hook: 1 = glibc's expf (what the unmodified reference calls), to measure what the shared form changes */
+static float yo_expf_cr(float x) { return g_exp_libm ? expf(x) : (float)ygz_exp_nonpos((double)x); }
+void yo_set_exp_libm(int on) { g_exp_libm = on; }
+float yo_expf_shared(float x) { return (float)ygz_exp_nonpos((double)x); }
+/* one DepthFilter::UpdateSeed step on caller-held parameters (the test of the exponential's influence on a, b, mu, sigma2) */
+static void update_seed(float x, float tau2, float *a, float *b, float *mu, float z_range, float *sigma2);
+void yo_update_seed(float x, float tau2, float *a, float *b, float *mu, float z_range, float *sigma2) { update_seed(x, tau2, a, b, mu, z_range, sigma2); }
 
 /* DepthFilter::UpdateSeed, src/optimizer.cpp:683-708 (all float) */
 static void update_seed(float x, float tau2, float *a, float *b, float *mu, float z_range, float *sigma2)

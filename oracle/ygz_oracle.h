@@ -276,6 +276,9 @@ int  yo_bow_transform(const yo_vocab *v, const uint8_t *desc, int n, int levelsu
                       int32_t *bow_word, double *bow_value);
 int  yo_search_by_bow(const uint8_t *desc1, const int32_t *node1, int n1, const uint8_t *desc2, const int32_t *node2, int n2,
                       int th_low, float knn_ratio, int32_t *match12);
+void  yo_set_exp_libm(int on);               /* test hook: DepthFilter::UpdateSeed with glibc's expf instead of include/ygz_exp.h */
+float yo_expf_shared(float x);               /* (float)ygz_exp_nonpos((double)x): the exponential the oracle and the device share */
+void  yo_update_seed(float x, float tau2, float *a, float *b, float *mu, float z_range, float *sigma2);
 int  yo_bow_orientation(const double *angle1, const double *angle2, const int32_t *match12, int n1, int32_t *hist, int32_t *ind);
 int  yo_search_for_triangulation(const yo_camera *cam, const uint8_t *desc1, const int32_t *node1, const double *px1, int n1,
                                  const uint8_t *desc2, const int32_t *node2, const double *px2, int n2,

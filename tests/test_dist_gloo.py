@@ -166,6 +166,14 @@ def test_offline_chunk_schedule_and_depth_images():
             assert all(0 < b - a <= chunk for a, b in c)
             if ramp and chunk >= 64 and last - first >= 4 * chunk:
                 assert c[0][1] - c[0][0] == chunk // 4 and c[-1][1] - c[-1][0] == chunk // 4     # short first upload, short last kernels
+            # with a keyframe stride the frames behind the shard's last keyframe form the last chunk (no BA window waits for them)
+            k = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8)
+            assert k[0][0] == first and k[-1][1] == last and all(a[1] == b[0] for a, b in zip(k, k[1:])) and all(0 < b - a <= chunk for a, b in k)
+            k_last = ((last - 1) // 8) * 8
+            if first <= k_last < last - 1 and c[-1][0] <= k_last:
+                assert k[-1] == (k_last + 1, last) and k[:-2] == c[:-1] and k[-2] == (c[-1][0], k_last + 1)
+            else:
+                assert k == c
     rng = np.random.default_rng(0)
     d = rng.uniform(0.5, 6.0, (48, 64))
     d[5, 7] = 0.0

@@ -325,6 +325,20 @@ def test_device_built_window_equals_host_built(hip_lib, oracle, obs_mode):
     vo.close()
 
 
+def test_degenerate_window_is_reported_not_optimised(hip_lib):
+    """a window whose anchor has no feature with depth (here: a sequence without depth) has no map point: the device builds P = E = 0, the
+    resident LM leaves at once with ZERO iterations (not twenty failed pivots that look like a finished run) and the run says so"""
+    n = 6
+    seq = synth.Sequence(n, 640, 480, seed=5, step=0.2)
+    vo = offline.OfflineVO(640, 480, n, chunk=n, kf_stride=2, window_kfs=3)
+    res = vo.run(seq.frame, lambda f: np.zeros((480, 640)))
+    assert len(res["windows"]) == 1 and res["built"][0][1:] == (0, 0)
+    w = res["windows"][0]
+    assert w["lm"] == dict(iterations=0, trials=0, degenerate=True) and vo.degenerate_windows == [0]
+    assert np.all(w["poses"][0] == 0) and np.all(np.isfinite(w["poses"]))
+    vo.close()
+
+
 N_LONG = 128
 
 

@@ -67,3 +67,44 @@ def test_depth_filter_converges_towards_the_rendered_depth(oracle):
     assert np.all(r["state"] == 4)
     r = oracle.depth_filter_update(lv[1], seq.poses[1], [lv[0]], [seq.poses[0]], old, batch_counter=1)
     assert np.all(r["state"] == 4)
+
+
+def test_shared_exponential_against_libm_and_the_seed_update(oracle):
+    """include/ygz_exp.h (the exponential DepthFilter::UpdateSeed uses on the host AND on the device, so that both round alike) against what the
+    unmodified reference calls, glibc's expf: (i) never more than 1 ulp apart over the range the update uses, and equal to the correctly rounded
+    float exponential (double exp rounded once) almost everywhere; (ii) the drift of a, b, mu, sigma2 when one update step runs with expf
+    instead: recorded bounds.  (iii) both builds forbid FMA contraction, which the bit-identity of the shared form rests on."""
+    import ctypes as C, os, re
+    lib = oracle.lib
+    lib.yo_expf_shared.restype = C.c_float; lib.yo_expf_shared.argtypes = [C.c_float]
+    libm = C.CDLL("libm.so.6"); libm.expf.restype = C.c_float; libm.expf.argtypes = [C.c_float]
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([-rng.uniform(0, 100, 60000), -10.0 ** rng.uniform(-8, 2, 40000), [0.0, -0.0, -1e-30, -87.3, -103.9]]).astype(np.float32)
+    ours = np.array([lib.yo_expf_shared(float(x)) for x in xs], np.float32)
+    theirs = np.array([libm.expf(float(x)) for x in xs], np.float32)
+    cr = np.exp(xs.astype(np.float64)).astype(np.float32)                      # correctly rounded unless the double lands on a rounding boundary
+    ulp = np.abs(ours.view(np.int32).astype(np.int64) - theirs.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1, ulp.max()
+    assert (ours == cr).mean() > 0.9999 and (ulp == 0).mean() > 0.99, ((ours == cr).mean(), (ulp == 0).mean())
+    # (ii) one seed update with either exponential
+    lib.yo_update_seed.argtypes = [C.c_float, C.c_float] + [C.POINTER(C.c_float)] * 3 + [C.c_float, C.POINTER(C.c_float)]
+    worst = np.zeros(4)
+    for _ in range(4000):
+        mu0, s20 = float(rng.uniform(0.2, 2.0)), float(rng.uniform(1e-4, 0.2))
+        x = float(mu0 + rng.normal(0, 2.0 * np.sqrt(s20))); tau2 = float(rng.uniform(1e-5, 1e-2)); zr = float(rng.uniform(1.0, 4.0))
+        a0, b0 = float(rng.uniform(5, 40)), float(rng.uniform(5, 40))
+        res = []
+        for mode in (0, 1):
+            lib.yo_set_exp_libm(mode)
+            a, b, mu, s2 = C.c_float(a0), C.c_float(b0), C.c_float(mu0), C.c_float(s20)
+            lib.yo_update_seed(x, tau2, C.byref(a), C.byref(b), C.byref(mu), zr, C.byref(s2))
+            res.append(np.array([a.value, b.value, mu.value, s2.value], np.float64))
+        lib.yo_set_exp_libm(0)
+        if np.all(np.isfinite(res[0])) and np.all(np.isfinite(res[1])):
+            worst = np.maximum(worst, np.abs(res[0] - res[1]) / np.maximum(np.abs(res[1]), 1e-30))
+    # the Beta parameters feel one ulp of the pdf through a cancellation (e - f, f - e / f); mu and sigma2 do not
+    assert worst[0] < 5e-3 and worst[1] < 5e-3 and worst[2] < 1e-5 and worst[3] < 1e-4, worst
+    # (iii)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert "-ffp-contract=off" in re.search(r"^CFLAGS\s*\?=.*$", open(os.path.join(root, "oracle", "Makefile")).read(), re.M).group(0)
+    assert "-ffp-contract=off" in re.search(r"^FLAGS\s*:=.*$", open(os.path.join(root, "ygz_slam_amd", "csrc", "Makefile")).read(), re.M).group(0)

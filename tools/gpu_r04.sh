@@ -134,5 +134,36 @@ g)  # whole parity suite (orientation check, ba_last_path, framed copies from th
 h)  # the rest of the parity suite after the test fix
     timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; tail -8 $OUT/pytest.log
     ;;
+i)  # keyframe-free last chunk (LM of the last windows beside it), LM phases on the direct-mode graphs, offline timeline
+    timeout 900 python -m pytest tests/test_gpu_offline.py tests/test_gpu_parity.py -m gpu -q -k "offline or resident_windows or framed" > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    OFF="python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline"
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-16s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    YGZ_OFF_KF_TAIL=0 offline tail0 $OFF
+    offline tail1 $OFF
+    YGZ_OFF_KF_TAIL=0 offline tail0_b $OFF
+    offline tail1_b $OFF
+    offline f128 python bench.py --mode offline --frames 128 --steps 3 --warmup 1 --no-cpu-baseline
+    YGZ_OFF_KF_TAIL=0 offline f128_tail0 python bench.py --mode offline --frames 128 --steps 3 --warmup 1 --no-cpu-baseline
+    YGZ_LM_DEBUG=1 timeout 200 python bench.py --mode offline --frames 256 --steps 1 --warmup 1 --no-cpu-baseline 2>&1 | grep "lm-debug" | tail -3
+    bash tools/offline_timeline.sh r04i --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    python - <<'PY'
+rows=[l.rstrip("\n").split("\t") for l in open("gpurun_out/r04i_timeline.tsv")]
+# the last run: everything after the last big gap; print the kernels after the last upload
+ks=[r for r in rows if r[0]=="K"]
+cs=[r for r in rows if r[0]=="C" and float(r[3])-float(r[2])>300]
+t_last=float(cs[-1][3])
+print("last big copy ends", t_last)
+for r in ks:
+    if float(r[3])>t_last-1500: print("%-36s %9.1f %9.1f  %s" % (r[1], float(r[2])-t_last, float(r[3])-t_last, r[4]))
+PY
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

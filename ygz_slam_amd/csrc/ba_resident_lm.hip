@@ -478,6 +478,18 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     ygz_raise_prio(A.prio);                                 // a latency chain of barriers and short phases on a few CUs
     BaDev B = A.wins[w];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (B.P <= 0 || B.E <= 0 || B.Kf <= 0) {
+        // a degenerate window (device-built: no anchor feature with depth was seen in another keyframe): nothing to optimise.  Reported as a
+        // finished run of ZERO iterations (every member leaves here, nobody waits at a barrier) -- not as twenty "iterations" of failed pivots
+        if (g == 0 && tid == 0) {
+            ygz_ba_stats st;
+            st.iterations = 0; st.lm_trials = 0; st.chi2_initial = 0.0; st.chi2_final = 0.0; st.lambda_final = 0.0;
+            A.stats[w] = st;
+            *reinterpret_cast<ygz_ba_stats *>(B.lm_out) = st;
+            for (int i = 4; i < 8; ++i) B.lm_out[i] = -1.0;
+        }
+        return;
+    }
     long long t_prev = 0;
     if (A.dbg && blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 16; ++i) s_t[i] = 0; t_prev = wall_clock64(); }
     const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf, Q = B.Q, npairs = Kf * (Kf + 1) / 2;

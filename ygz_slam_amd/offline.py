@@ -188,9 +188,11 @@ def exchange_rows(buf, owner, world, pg=None, via_host=None):
             buf[rows[r][0]:rows[r][-1] + 1] = g[r, :len(rows[r])]
 
 
-def chunk_schedule(first, last, chunk, ramp=True):
+def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
     """[first, last) cut into chunks of `chunk` frames, with a ramp at both ends (chunk / 4, chunk / 2, chunk ... chunk, chunk / 2, chunk / 4)
-    when there is room: nothing overlaps the upload of the first chunk or the kernels of the last one, so those two are kept short"""
+    when there is room: nothing overlaps the upload of the first chunk or the kernels of the last one, so those two are kept short.
+    kf_stride > 0: the frames behind the shard's last keyframe (they complete no BA window) form a chunk of their own at the very end, so
+    that every window is complete one chunk earlier and the last resident-LM launch runs beside that chunk instead of after it"""
     n = last - first
     sizes = []
     if ramp and chunk >= 64 and n >= 4 * chunk:
@@ -204,6 +206,11 @@ def chunk_schedule(first, last, chunk, ramp=True):
     for s_ in sizes:
         out.append((c0, c0 + s_)); c0 += s_
     assert c0 == last or n <= 0
+    if kf_stride > 0 and out:
+        a, b = out[-1]
+        k_last = ((b - 1) // kf_stride) * kf_stride                # the last keyframe of the shard
+        if a <= k_last and k_last + 1 < b and k_last + 1 > a:
+            out[-1:] = [(a, k_last + 1), (k_last + 1, b)]
     return out
 
 
@@ -278,6 +285,7 @@ class OfflineVO:
         import os as _os
         self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
         self.ramp = _os.environ.get("YGZ_OFF_RAMP", "1") != "0"
+        self.kf_tail = _os.environ.get("YGZ_OFF_KF_TAIL", "1") != "0"          # the frames behind the last keyframe as a chunk of their own (chunk_schedule)
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
@@ -356,7 +364,7 @@ class OfflineVO:
         are all in are built and optimised on the third context while the next chunks run (pipeline_ba)."""
         rec = {}
         first, last = self.start, self.start + self.count
-        chunks = chunk_schedule(first, last, self.chunk, self.ramp)
+        chunks = chunk_schedule(first, last, self.chunk, self.ramp, self.kf_stride if self.kf_tail else 0)
         pending = [None] * len(self.lanes)
         self._ba_done, self._ba_built = set(), []
         self._lm_launches = 0
@@ -375,10 +383,11 @@ class OfflineVO:
                 new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and self.wins[i][-1] < c1]
                 self._ba_launch(new, optimize=False)
                 self._ba_built += new
-                if len(self._ba_built) >= self._lm_next() or ci == len(chunks) - 1:
+                all_built = len(self._ba_done) + len(self._ba_built) == len(self.local)     # nothing more will come: the last launch need not wait for the last chunk
+                if self._ba_built and (len(self._ba_built) >= self._lm_next() or ci == len(chunks) - 1 or all_built):
                     # beside the tracking of the next chunks a launch keeps to a few CUs (its members each own one, and wait for it while a
                     # tracking workgroup drains); the last launch, which nothing runs beside, takes the default half of the device
-                    self.ba.ba_set_team_budget(self.bg_team_budget if ci < len(chunks) - 1 else 0)
+                    self.ba.ba_set_team_budget(self.bg_team_budget if ci < len(chunks) - 1 and not all_built else 0)
                     self._ba_optimize(self._ba_built)
                     self._ba_built = []
                     self._lm_launches += 1
@@ -581,9 +590,12 @@ class OfflineVO:
             if tail[3] < 0:
                 raise RuntimeError("BA window %d: the resident LM did not finish (team barrier time-out)" % wi)
             dims[wi] = (int(tail[0]), int(tail[1]), int(tail[2]))
+            if dims[wi][1] == 0 or dims[wi][2] == 0:            # no map point of the anchor was observed in another keyframe: the window was not optimised
+                self.degenerate_windows = getattr(self, "degenerate_windows", []) + [wi]
             out.append(dict(kfs=w, owner=self.owner[wi], poses=host[wi, :len(w) * 6].reshape(len(w), 6).copy(), state=host[wi].copy(),
                             stats=np.array([tail[5], tail[6], tail[3], tail[2]]),
-                            inliers=dict(edges=int(tail[8]), outliers=int(tail[9]), chi2=float(tail[10]), chi2_inliers=float(tail[11]))))
+                            inliers=dict(edges=int(tail[8]), outliers=int(tail[9]), chi2=float(tail[10]), chi2_inliers=float(tail[11])),
+                            lm=dict(iterations=int(tail[3]), trials=int(tail[4]), degenerate=bool(dims[wi][1] == 0 or dims[wi][2] == 0))))
         return out, dims
 
     # ------------------------------------------------------------------ whole run
