@@ -339,6 +339,25 @@ def test_degenerate_window_is_reported_not_optimised(hip_lib):
     vo.close()
 
 
+def test_timed_out_window_is_rebuilt_and_solved_by_one_workgroup(hip_lib):
+    """the retry path of a resident-LM team that timed out at a barrier (simulated: the statistics of one window read as "no result"): the
+    window is rebuilt and solved by a single workgroup -- bit-identical to the team's result, because the points are reduced in fixed parts
+    whatever the team size"""
+    n = 10
+    seq = synth.Sequence(n, 640, 480, seed=3, step=0.2)
+    vo = offline.OfflineVO(640, 480, n, chunk=n, kf_stride=2, window_kfs=4, max_points=700)
+    res = vo.run(seq.frame, seq.depth)
+    before = vo.ba.ba_pack_states(0, 1, vo.S)
+    assert before[0, -12 + 3] >= 1 and not hasattr(vo, "lm_retries")
+    real = vo.ba.ba_lm_iterations
+    calls = []
+    vo.ba.ba_lm_iterations = lambda a, b: ([-1] * b if not calls.append(1) and len(calls) == 1 else real(a, b))
+    vo._retry_timed_out()
+    after = vo.ba.ba_pack_states(0, 1, vo.S)
+    assert vo.lm_retries == 1 and np.array_equal(before, after)
+    vo.close()
+
+
 N_LONG = 128
 
 

@@ -165,5 +165,12 @@ for r in ks:
     if float(r[3])>t_last-1500: print("%-36s %9.1f %9.1f  %s" % (r[1], float(r[2])-t_last, float(r[3])-t_last, r[4]))
 PY
     ;;
+j)  # factorised H block of the sparse alignment, LM retry / degenerate-window paths: parity + timing
+    timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; tail -6 $OUT/pytest.log
+    python tools/stage_bench.py sparse --batch 512 --reps 5
+    python tools/stage_bench.py sparse --batch 256 --reps 5
+    benchline dflt $STEP
+    benchline dflt_b $STEP
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

@@ -371,6 +371,14 @@ class HipContext:
         self._chk(self.lib.ygz_hip_ba_get_stats(self._ctx, window_begin, n_windows, st if want_stats else None, _p(dims, C.c_int32)), "ba_get_stats")
         return (list(st) if want_stats else None), dims
 
+    def ba_lm_iterations(self, window_begin, n_windows):
+        """iterations of the last resident LM run per window WITHOUT raising: < 0 = the team timed out at a barrier (or no run yet)"""
+        st = (BaStats * n_windows)()
+        rc = self.lib.ygz_hip_ba_get_stats(self._ctx, window_begin, n_windows, st, None)
+        if rc not in (OK, E_HIP, E_STATE):
+            self._chk(rc, "ba_get_stats")
+        return [s.iterations for s in st]
+
     def track_get_summary(self, out=None, wait=True):
         if out is None:
             out = np.empty((self.max_frames, SUMMARY_FIELDS), np.float64)

@@ -566,6 +566,7 @@ class OfflineVO:
             self.ba.ba_set_team_budget(0)
             self._ba_launch(rest)
         self.ba.synchronize()
+        self._retry_timed_out()
         t1 = time.perf_counter()
         n_w, S = len(self.wins), self.S
         if self.world == 1:
@@ -597,6 +598,27 @@ class OfflineVO:
                             inliers=dict(edges=int(tail[8]), outliers=int(tail[9]), chi2=float(tail[10]), chi2_inliers=float(tail[11])),
                             lm=dict(iterations=int(tail[3]), trials=int(tail[4]), degenerate=bool(dims[wi][1] == 0 or dims[wi][2] == 0))))
         return out, dims
+
+    def _retry_timed_out(self):
+        """A resident-LM team whose members were not co-resident within the spin bound of a team barrier (possible beside the tracking
+        kernels of several lanes) leaves without a result.  Its window is rebuilt (the loop updates the points in place) and solved once more
+        by ONE workgroup, which needs no co-residency; a second failure raises."""
+        if not self.mine:
+            return
+        bad = [k for k, it in enumerate(self.ba.ba_lm_iterations(0, len(self.mine))) if it < 0 and self.mine[k] in self._ba_done]
+        if not bad:
+            return
+        self.lm_retries = getattr(self, "lm_retries", 0) + len(bad)
+        self.ba.ba_set_team_budget(1)                          # G = 1: one workgroup per window
+        done = set(self._ba_done)
+        for k in bad:
+            self._ba_launch([self.mine[k]])
+        self._ba_done = done
+        self.ba.ba_set_team_budget(0)
+        self.ba.synchronize()
+        still = [self.mine[k] for k in bad if self.ba.ba_lm_iterations(k, 1)[0] < 0]
+        if still:
+            raise RuntimeError("BA windows %s: the resident LM did not finish even with one workgroup per window" % still)
 
     # ------------------------------------------------------------------ whole run
     def run(self, frame_source, depth_source, block_source=None):
