@@ -172,5 +172,29 @@ j)  # factorised H block of the sparse alignment, LM retry / degenerate-window p
     benchline dflt $STEP
     benchline dflt_b $STEP
     ;;
+k)  # the resident LM on the run's own windows, alone
+    python tools/lm_insitu.py --frames 256 2>&1 | grep -v amdgpu | tail -12
+    YGZ_LM_DEBUG=1 python tools/lm_insitu.py --frames 128 2>&1 | grep "lm-debug" | tail -2
+    ;;
+z)  # round-4 closing batch: full GPU suite, the three rocprofv3 passes of the default command, the SQ pass, the step timeline, the default
+    # bench line with its extra blocks, the offline lines per shard size, the kernel statistics and the device timeline of the offline mode
+    timeout 900 python -m pytest tests -q -m gpu --no-header -rf 2>&1 | tail -4
+    bash tools/collect_profiles.sh r04_v1 > $OUT/collect.log 2>&1; tail -3 $OUT/collect.log
+    bash tools/pmc_one_pass.sh > $OUT/sq.log 2>&1; tail -2 $OUT/sq.log | cut -c1-200
+    bash tools/timeline.sh r04_step_timeline > $OUT/timeline.log 2>&1; tail -2 $OUT/timeline.log | cut -c1-200
+    timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 1200 $OUT/bench_default.json
+    bash tools/stats_cmd.sh r04_offline1024 --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -26
+    for f in 1024 512 256 128; do
+        timeout 300 python bench.py --mode offline --frames $f --steps 5 --warmup 2 --no-cpu-baseline > $OUT/off_f$f.json 2>/dev/null; cut -c1-300 $OUT/off_f$f.json
+    done
+    timeout 300 python bench.py --mode offline --frames 1024 --steps 5 --warmup 2 --no-cpu-baseline --upload gray > $OUT/off_f1024_gray.json 2>/dev/null; cut -c1-300 $OUT/off_f1024_gray.json
+    bash tools/offline_timeline.sh r04_final --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    timeout 200 python bench.py --size 720p --batch 128 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/step_720p.json 2>/dev/null; cut -c1-300 $OUT/step_720p.json
+    ;;
+l)  # Pixel2Camera stored once: sparse-alignment parity + timing
+    timeout 900 python -m pytest tests -m gpu -q -k "sparse or golden or offline or surface" > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+    python tools/stage_bench.py sparse --batch 512 --reps 5
+    benchline dflt $STEP
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

@@ -556,10 +556,9 @@ struct SaLevel { const uint8_t *ref_img, *cur_img; int cols, rows; float scale; 
 
 #define SA_BIL(a, b, c, d) __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w_tl, (float)(a)), __fmul_rn(w_tr, (float)(b))), __fmul_rn(w_bl, (float)(c))), __fmul_rn(w_br, (float)(d)))
 
-// cvutils::JacobXYZ2Cam (CVUtils.h:77-99) of the reference feature
-__device__ __forceinline__ void sa_frame_jacobian(const SaArgs &A, double pxx, double pxy, double dep, double fj[12])
+// cvutils::JacobXYZ2Cam (CVUtils.h:77-99) of the reference feature at xyz_ref = (x, y, dep)
+__device__ __forceinline__ void sa_frame_jacobian(double x, double y, double dep, double fj[12])
 {
-    const double x = (pxx - A.cx) * dep / A.fx, y = (pxy - A.cy) * dep / A.fy;
     const double z_inv = 1. / dep, z_inv_2 = z_inv * z_inv;
     fj[0] = -z_inv; fj[1] = 0.0; fj[2] = x * z_inv_2; fj[3] = y * fj[2]; fj[4] = -(1.0 + x * fj[2]); fj[5] = y * z_inv;
     fj[6] = 0.0; fj[7] = -z_inv; fj[8] = y * z_inv_2; fj[9] = 1.0 + y * fj[8]; fj[10] = -fj[3]; fj[11] = -x * z_inv;
@@ -608,13 +607,15 @@ __device__ __forceinline__ void sa_feature_h(const double fj[12], double fl, con
 
 // computeResiduals for one feature (SparseImageAlign.cpp:147-207): warp, bounds, bilinear window of the current image, residuals.
 // Returns whether the feature is used by this iterate; res stays 0 otherwise.
-__device__ __forceinline__ bool sa_feature_residual(const SaArgs &A, const SaLevel &L, const Se3 &T, double pxx, double pxy, double dep,
+// (xr, yr, dep) = Pixel2Camera of the reference pixel: the same for every level and iterate, so the fused pass stores it once per level
+// and the later passes read it instead of redoing its two FP64 divisions
+__device__ __forceinline__ bool sa_feature_residual(const SaArgs &A, const SaLevel &L, const Se3 &T, double xr, double yr, double dep,
                                                     const float refp[16], float res[16])
 {
     const int border = 3;
 #pragma unroll
     for (int k = 0; k < 16; ++k) res[k] = 0.f;
-    const double xyz_ref[3] = { (pxx - A.cx) * dep / A.fx, (pxy - A.cy) * dep / A.fy, dep };
+    const double xyz_ref[3] = { xr, yr, dep };
     double xyz_cur[3];
     se3_act_d(&T, xyz_ref, xyz_cur);
     const double pu = A.fx * xyz_cur[0] / xyz_cur[2] + A.cx, pv = A.fy * xyz_cur[1] / xyz_cur[2] + A.cy;
@@ -683,6 +684,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
     const uint8_t *has_mp = A.trk_has_mp + (size_t)pair * A.cells;
     uint8_t *wk = A.work + (size_t)pair * A.work_stride;
     // global work arrays of the pair (the layout of the first form; its Hf block is unused here)
+    double *xy = (double *)wk;                                          // [cells][2] Pixel2Camera x, y of the reference pixel (in the first form's Hf block)
     float *dxy = (float *)((double *)wk + 33 * (size_t)A.cells);       // [cells][32] dx[16], dy[16]
     float *patch_g = (float *)((double *)wk + 96 * (size_t)A.cells);    // [cells][16] reference patches of the features beyond pcap
     float *r2 = patch_g + 16 * (size_t)A.cells;                         // the per-iteration scratch of the features beyond lcap: see the first form
@@ -758,6 +760,8 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         const int ui = (int)floorf(u_ref), vi = (int)floorf(v_ref);
                         const bool refill = hm && !(ui - border < 0 || vi - border < 0 || ui + border >= L.cols || vi + border >= L.rows);
                         const bool vis = refill || (fl0 & 1);
+                        const double xr = (pxx - A.cx) * dep / A.fx, yr = (pxy - A.cy) * dep / A.fy;      // Pixel2Camera (Camera.h:53-59)
+                        if (vis) { xy[2 * f] = xr; xy[2 * f + 1] = yr; }
                         float pv[16], dxv[16], dyv[16];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) { pv[k] = 0.f; dxv[k] = 0.f; dyv[k] = 0.f; }
@@ -801,7 +805,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
 #pragma unroll
                         for (int k = 0; k < 16; ++k) res[k] = 0.f;
                         bool use = false;
-                        if (vis) use = sa_feature_residual(A, L, T, pxx, pxy, dep, pv, res);
+                        if (vis) use = sa_feature_residual(A, L, T, xr, yr, dep, pv, res);
                         float xs[16];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
@@ -811,7 +815,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         if (use) {
                             my_meas += 16;
                             double fj[12];
-                            sa_frame_jacobian(A, pxx, pxy, dep, fj);
+                            sa_frame_jacobian(xr, yr, dep, fj);
                             sa_feature_jres(fj, L.fl, dxv, dyv, res, acc + 21);
                             if (refill) {
                                 if (H_INLINE) {
@@ -836,7 +840,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                     float sq = 0.f;
                     if (f < n) {
                         const uint8_t fl0 = flags[f];
-                        const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
+                        const double xr = xy[2 * f], yr = xy[2 * f + 1], dep = depth[f];
                         const float4 c0 = SA_PATCH(0, f), c1 = SA_PATCH(1, f), c2 = SA_PATCH(2, f), c3 = SA_PATCH(3, f);
                         const float4 *gp = reinterpret_cast<const float4 *>(dxy + 32 * (size_t)f);
                         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0, g6 = g0, g7 = g0;
@@ -846,7 +850,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
 #pragma unroll
                         for (int k = 0; k < 16; ++k) res[k] = 0.f;
                         bool use = false;
-                        if (fl0 & 1) use = sa_feature_residual(A, L, T, pxx, pxy, dep, refp, res);
+                        if (fl0 & 1) use = sa_feature_residual(A, L, T, xr, yr, dep, refp, res);
                         float xs[16];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
@@ -863,7 +867,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                             const float gxv[16] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w };
                             const float gyv[16] = { g4.x, g4.y, g4.z, g4.w, g5.x, g5.y, g5.z, g5.w, g6.x, g6.y, g6.z, g6.w, g7.x, g7.y, g7.z, g7.w };
                             double fj[12];
-                            sa_frame_jacobian(A, pxx, pxy, dep, fj);
+                            sa_frame_jacobian(xr, yr, dep, fj);
                             sa_feature_jres(fj, L.fl, gxv, gyv, res, acc + 21);
                         }
                     }
@@ -883,7 +887,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                     const float gxv[16] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w };
                     const float gyv[16] = { g4.x, g4.y, g4.z, g4.w, g5.x, g5.y, g5.z, g5.w, g6.x, g6.y, g6.z, g6.w, g7.x, g7.y, g7.z, g7.w };
                     double fj[12], hf[21];
-                    sa_frame_jacobian(A, px[2 * f], px[2 * f + 1], depth[f], fj);
+                    sa_frame_jacobian(xy[2 * f], xy[2 * f + 1], depth[f], fj);
                     sa_feature_h(fj, L.fl, gxv, gyv, hf);      // the block the fused pass of this level added (or would have added)
 #pragma unroll
                     for (int k = 0; k < 21; ++k) acc[k] += add ? hf[k] : -hf[k];
