@@ -17,7 +17,7 @@ for ln in open(src):
         continue
     rows[c[0].replace("void ", "").split("<")[0]] = {h: float(v) for h, v in zip(head[1:], c[1:])}
 out = {"note": "SQ_INSTS_VALU (wave64 instructions, mean per dispatch) from one rocprofv3 --pmc pass over tools/stage_bench.py ba --reps 2 at batch %d "
-               "(tools/pmc_one_pass.sh, raw table: profiles/r03_sq_counters_raw.md); per_unit = per frame pair of ~%.0f keypoints; cycles = "
+               "(tools/pmc_one_pass.sh, raw table: profiles/r04_sq_counters_raw.md); per_unit = per frame pair of ~%.0f keypoints; cycles = "
                "GRBM_GUI_ACTIVE / 8 XCDs.  The matcher is dispatched twice per cross-checked match (query->train, train->query)." % (batch, n_kp),
        "batch": batch, "keypoints_per_frame": n_kp, "kernel_source_hash": kernel_source_hash(), "kernels": {}}
 for k, v in sorted(rows.items()):
