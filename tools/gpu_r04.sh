@@ -196,5 +196,11 @@ l)  # Pixel2Camera stored once: sparse-alignment parity + timing
     python tools/stage_bench.py sparse --batch 512 --reps 5
     benchline dflt $STEP
     ;;
+m)  # unaligned 8-byte window loads (no v_alignbyte / address masking): parity + stage and step timing
+    timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    for st in klt detect direct sparse; do python tools/stage_bench.py $st --batch 512 --reps 5; done
+    benchline dflt $STEP
+    benchline dflt_b $STEP
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

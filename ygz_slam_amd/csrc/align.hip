@@ -113,11 +113,9 @@ __device__ bool align2d_core(const uint8_t *__restrict__ cur, int w, int h, cons
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const uintptr_t a = reinterpret_cast<uintptr_t>(cur + (size_t)(v_r + r - 4) * w + (u_r - 4));
-                ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
-                const uint32_t sh = (uint32_t)(a & 3), d0 = q[0], d1 = q[1], d2 = q[2];
-                wl[r] = __builtin_amdgcn_alignbyte(d1, d0, sh); wh[r] = __builtin_amdgcn_alignbyte(d2, d1, sh); w8[r] = (d2 >> (8 * sh)) & 255u;
+            for (int r = 0; r < 9; ++r) {                                         // 9 bytes per row: an unaligned 8-byte load and a byte
+                const uint8_t *rp = cur + (size_t)(v_r + r - 4) * w + (u_r - 4);
+                ygz_load8(rp, wl[r], wh[r]); w8[r] = (uint32_t)rp[8];
             }
         }
 #define WIN(r, c) ((c) < 8 ? YGZ_BYTE(wl[r], wh[r], (c) & 7) : (int)w8[r])

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
     const int cx = (int)rint(A.kp_px[2 * o] / sc), cy = (int)rint(A.kp_px[2 * o + 1] / sc);
     const int n = w * h;
     // 39 x 39 neighbourhood, linear addressing as center[dy*step+dx] (reads outside the level buffer are 0): 39 rows x 10
-    // dwords, each from two aligned dword loads + v_alignbyte (a wave-wide byte gather costs as much as a dword load)
+    // dwords, each ONE unaligned dword load (a wave-wide byte gather costs as much as a dword load)
     // The lane's seven items are requested as ONE batch (14 loads in flight) and written to LDS afterwards: as a rolled loop this
     // was a chain of seven dependent memory latencies per keypoint, most of the kernel's time.
     constexpr int DP_ITEMS = DP_W * 10, DP_LN = (DP_ITEMS + 63) / 64;
@@ -424,15 +424,14 @@ __global__ __launch_bounds__(256) void k_describe(DescArgs A)
         const int r = item / 10, j = item - 10 * r;
         const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
         w_in[k] = item < DP_ITEMS && idx0 >= 0 && idx0 + 4 <= n;
-        const uintptr_t a = reinterpret_cast<uintptr_t>(img + (w_in[k] ? idx0 : 0));
-        ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
-        w_lo[k] = q[0]; w_hi[k] = q[1]; w_sh[k] = (uint32_t)(a & 3);
+        w_lo[k] = *(ygz_gptr32u)reinterpret_cast<uintptr_t>(img + (w_in[k] ? idx0 : 0));      // one unaligned dword (rounds 1-3: two aligned loads + v_alignbyte)
+        w_hi[k] = 0u; w_sh[k] = 0u;
     }
 #pragma unroll
     for (int k = 0; k < DP_LN; ++k) {
         const int item = lane + 64 * k;
         if (item >= DP_ITEMS) continue;
-        uint32_t v = __builtin_amdgcn_alignbyte(w_hi[k], w_lo[k], w_sh[k]);
+        uint32_t v = w_lo[k];
         if (!w_in[k]) {                             // the window leaves the level buffer: byte by byte, zeros outside (rare)
             const int r = item / 10, j = item - 10 * r;
             const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;

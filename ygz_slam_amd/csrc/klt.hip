@@ -128,15 +128,25 @@ __device__ __forceinline__ int cv_round_f(float v) { return __float2int_rn(v); }
 
 typedef const __attribute__((address_space(1))) uint32_t *klt_gptr;      // global (not flat) loads
 
-// 8 consecutive bytes from an arbitrary byte address: 3 aligned dword loads + v_alignbyte
+// 8 consecutive bytes from an arbitrary byte address: 3 aligned dword loads (one global_load_dwordx3) + v_alignbyte.
+// Round 4 measured the alternative, ONE unaligned global_load_dwordx2 (-DYGZ_KLT_UNALIGNED_LOADS): it removes 20 of the 229 VALU instructions of
+// a mismatch evaluation in k_klt3 (two v_alignbyte, two v_and and a v_mov per window row) -- and the launch takes exactly as long (2.54 ms
+// per 512 pairs either way): the four row gathers of an evaluation keep the CU's one address unit as busy as the 208 remaining instructions
+// keep a SIMD, and a misaligned 8-byte access costs it more than an aligned 12-byte one.  The aligned form stays (fewer address-unit
+// cycles for the gather-bound kernels that run beside LK in the step).
 __device__ __forceinline__ void klt_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
 {
+#ifndef YGZ_KLT_UNALIGNED_LOADS
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     klt_gptr q = (klt_gptr)(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3);
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
     lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+#else
+    const ygz_u32x2 v = *(ygz_gptr2u)reinterpret_cast<uintptr_t>(p);
+    lo = v.x; hi = v.y;
+#endif
 }
 // all factors fit 24 bits (pixels 8 bit, derivatives 14 bit, weights 15 bit, differences 14 bit): full-rate v_mad_*24
 // instead of the quarter-rate 32-bit multiply

@@ -346,30 +346,44 @@ __device__ __forceinline__ double ygz_wave_sum_d(double v)
 // exact for float inputs (53 >= 2*24+2 bits)
 __device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((double)x); }
 
-// 8 (or 5) consecutive bytes from an arbitrary byte address with aligned dword loads + v_alignbyte: a wave-wide byte gather
-// costs the address unit as much as a dword load, so patch windows are fetched row-wise.  May touch up to 11 bytes past p
-// (every image buffer is allocated with 64 bytes of slack).
+// 8 (or 5) consecutive bytes from an arbitrary byte address: ONE unaligned global_load_dwordx2 (a wave-wide byte gather costs the address
+// unit as much as a dword load, so patch windows are fetched row-wise; the memory pipeline handles the misalignment).  Rounds 1-3 fetched
+// two or three aligned dwords and shifted them together with v_alignbyte: five VALU instructions per row that the VALU-bound kernels
+// could not afford (-DYGZ_ALIGNED_LOADS keeps that form for A/B).  Touches exactly 8 bytes from p (every image buffer has 64 bytes of slack).
 typedef const __attribute__((address_space(1))) uint32_t *ygz_gptr32;
 typedef uint16_t __attribute__((aligned(1))) ygz_u16u;          // 2 adjacent bytes at any address: one (unaligned) global_load_ushort
 typedef uint32_t __attribute__((aligned(1))) ygz_u32u;          // 4 adjacent bytes at any address: one (unaligned) global_load_dword
 typedef const __attribute__((address_space(1))) ygz_u32u *ygz_gptr32u;
+typedef uint32_t ygz_u32x2 __attribute__((ext_vector_type(2)));
+typedef ygz_u32x2 __attribute__((aligned(1))) ygz_u32x2u;       // 8 adjacent bytes at any address: one (unaligned) global_load_dwordx2
+typedef const __attribute__((address_space(1))) ygz_u32x2u *ygz_gptr2u;
 __device__ __forceinline__ void ygz_load8(const uint8_t *p, uint32_t &lo, uint32_t &hi)
 {
+#ifdef YGZ_ALIGNED_LOADS
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3);
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
     lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+#else
+    const ygz_u32x2 v = *(ygz_gptr2u)reinterpret_cast<uintptr_t>(p);
+    lo = v.x; hi = v.y;
+#endif
 }
 __device__ __forceinline__ void ygz_load5(const uint8_t *p, uint32_t &lo, uint32_t &hi)      // bytes 0..4 valid
 {
+#ifdef YGZ_ALIGNED_LOADS
     const uintptr_t a = reinterpret_cast<uintptr_t>(p);
     ygz_gptr32 q = (ygz_gptr32)(a & ~(uintptr_t)3);
     const uint32_t sh = (uint32_t)(a & 3);
     const uint32_t d0 = q[0], d1 = q[1];
     lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
     hi = d1 >> (8 * sh);
+#else
+    const ygz_u32x2 v = *(ygz_gptr2u)reinterpret_cast<uintptr_t>(p);
+    lo = v.x; hi = v.y;
+#endif
 }
 #define YGZ_BYTE(lo, hi, k) ((int)((((k) < 4) ? ((lo) >> (8 * ((k) & 3))) : ((hi) >> (8 * ((k) & 3)))) & 255u))
 __device__ __forceinline__ float ygz_ord2f(uint32_t o)
