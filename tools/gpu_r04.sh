@@ -202,5 +202,17 @@ m)  # unaligned 8-byte window loads (no v_alignbyte / address masking): parity +
     benchline dflt $STEP
     benchline dflt_b $STEP
     ;;
+n)  # k_klt3: fourth window row from the neighbouring lane (LDS crossbar) instead of a fourth gather
+    timeout 900 python -m pytest tests -m gpu -q -k "klt or surface or offline_sharded or golden" > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+    YGZ_KLT_ROW_SHARE=0 python tools/step_dump.py $OUT/d_off.npz > $OUT/dump.log 2>&1
+    python tools/step_dump.py $OUT/d_on.npz >> $OUT/dump.log 2>&1
+    python tools/step_dump.py --compare $OUT/d_off.npz $OUT/d_on.npz
+    YGZ_KLT_ROW_SHARE=0 python tools/stage_bench.py klt --batch 512 --reps 5
+    python tools/stage_bench.py klt --batch 512 --reps 5
+    YGZ_KLT_ROW_SHARE=0 benchline share0 $STEP
+    benchline share1 $STEP
+    YGZ_KLT_ROW_SHARE=0 benchline share0_b $STEP
+    benchline share1_b $STEP
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

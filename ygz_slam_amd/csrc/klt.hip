@@ -354,6 +354,9 @@ __device__ __forceinline__ float klt_seg21_sum(float v, int lane, int q, int seg
     return __shfl(v, seg);
 }
 
+// (Round 4 also measured fetching only three of a lane's four window rows and taking the fourth from the lane that owns the next row triple
+// through the LDS crossbar -- two ds_bpermute instead of a gather: bit-identical and SLOWER, 2.68 against 2.52 ms per 512 pairs; the dependent
+// crossbar round trip in front of the arithmetic costs more than the gather it saves.)
 __global__ __launch_bounds__(256) void k_klt3(KltArgs A)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
