@@ -174,6 +174,25 @@ def test_offline_chunk_schedule_and_depth_images():
                 assert k[-1] == (k_last + 1, last) and k[:-2] == c[:-1] and k[-2] == (c[-1][0], k_last + 1)
             else:
                 assert k == c
+    # the plan with deferred gaps: every frame of the shard exactly once, the frames behind the last keyframes of the last windows at the end,
+    # every window complete (anchor .. last keyframe) before the first deferred gap is processed
+    for first, last, chunk, defer in ((0, 1024, 128, 12), (0, 1024, 128, 16), (128, 256, 32, 2), (0, 128, 32, 2), (0, 100, 32, 3), (64, 200, 32, 5), (0, 16, 5, 2)):
+        wins = offline.ba_windows(1024, 8, 8)
+        plan = offline.chunk_plan(first, last, chunk, True, 8, wins, defer)
+        seen = np.zeros(1024, int)
+        for a, b in plan:
+            assert first <= a < b <= last and b - a <= chunk
+            seen[a:b] += 1
+        assert np.all(seen[first:last] == 1) and seen.sum() == last - first
+        inside = [w for w in wins if w[0] >= first and w[-1] < last]
+        gaps = [(w[-1] + 1, min(last, w[0] + 64)) for w in inside[-defer:] if w[-1] + 1 < min(last, w[0] + 64) and w[-1] + 1 > first]
+        tail = plan[len(plan) - len(gaps):] if gaps else []
+        assert tail == gaps, (plan, gaps)
+        done = np.zeros(1024, bool)
+        for a, b in plan[:len(plan) - len(gaps)]:
+            done[a:b] = True
+        assert all(done[w[0]:w[-1] + 1].all() for w in inside)
+        assert offline.chunk_plan(first, last, chunk, True, 8, wins, 0) == offline.chunk_schedule(first, last, chunk, True, 8)
     rng = np.random.default_rng(0)
     d = rng.uniform(0.5, 6.0, (48, 64))
     d[5, 7] = 0.0

@@ -214,5 +214,22 @@ n)  # k_klt3: fourth window row from the neighbouring lane (LDS crossbar) instea
     YGZ_KLT_ROW_SHARE=0 benchline share0_b $STEP
     benchline share1_b $STEP
     ;;
+o)  # the keyframe-free gaps behind the last keyframes processed at the end of the shard (the last LM launches run beside them)
+    timeout 900 python -m pytest tests/test_gpu_offline.py tests/test_gpu_bench.py -m gpu -q > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-16s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    for d in 0 4 8 12 16; do YGZ_OFF_DEFER=$d offline f1024_d$d python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline; done
+    for d in 0 2; do YGZ_OFF_DEFER=$d offline f128_d$d python bench.py --mode offline --frames 128 --steps 3 --warmup 1 --no-cpu-baseline; done
+    for d in 0 4; do YGZ_OFF_DEFER=$d offline f256_d$d python bench.py --mode offline --frames 256 --steps 3 --warmup 1 --no-cpu-baseline; done
+    YGZ_OFF_DEFER=16 offline gray_d16 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline --upload gray
+    YGZ_OFF_DEFER=0 offline gray_d0 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline --upload gray
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

@@ -214,6 +214,42 @@ def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
     return out
 
 
+def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
+    """The chunks of the shard [first, last) IN PROCESSING ORDER.  Every frame pair is solved from the identity, so the order is free; what it
+    decides is when a BA window is complete (all frames from its anchor to its last keyframe tracked) and therefore where its resident-LM launch
+    -- a latency chain of ~5 ms that uses a fraction of the GPU -- falls.  The frames BEHIND a window's last keyframe (kf_stride - 1 of them, up to
+    the next anchor) complete nothing: for the last `defer` windows that end inside the shard they are taken out of the main pass and processed
+    at the very end, one small chunk per gap, so that the last LM launches run beside them instead of after everything else.  Cost: two more halo
+    frames per deferred gap (the range after a gap and the gap itself each upload their predecessor once more)."""
+    if defer <= 0:
+        return chunk_schedule(first, last, chunk, ramp, kf_stride)
+    inside = [w for w in windows if w[0] >= first and w[-1] < last]
+    anchors = sorted(w[0] for w in windows)
+    gaps = []
+    for w in inside[-defer:]:
+        nxt = [a for a in anchors if a > w[-1]]
+        g0, g1 = w[-1] + 1, min(last, nxt[0] if nxt else last)
+        if g1 > g0 and g0 > first:
+            gaps.append((g0, g1))
+    if not gaps:
+        return chunk_schedule(first, last, chunk, ramp, kf_stride)
+    main, a = [], first
+    for g0, g1 in gaps:
+        if g0 > a:
+            main.append((a, g0))
+        a = g1
+    if a < last:
+        main.append((a, last))
+    out = []
+    for k, (a, b) in enumerate(main):
+        if k == 0 and ramp and chunk >= 64 and b - a < 4 * chunk and b - a > chunk // 2:
+            out.append((a, a + chunk // 4)); a += chunk // 4      # a short first range still starts with a short upload (nothing runs beside it)
+        out += chunk_schedule(a, b, chunk, ramp and k == 0)
+    for g0, g1 in gaps:
+        out += chunk_schedule(g0, g1, chunk, False)
+    return out
+
+
 def depth_image(d, div=1, dtype=np.float64, scale=1.0 / 5000.0):
     """depth map of the sequence (metres) -> the image the device samples: every div-th sample as float64 / float32 metres or, for
     uint16, round(depth / scale) (TUM RGB-D: scale = 1 / 5000)"""
@@ -285,7 +321,12 @@ class OfflineVO:
         import os as _os
         self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
         self.ramp = _os.environ.get("YGZ_OFF_RAMP", "1") != "0"
-        self.kf_tail = _os.environ.get("YGZ_OFF_KF_TAIL", "1") != "0"          # the frames behind the last keyframe as a chunk of their own (chunk_schedule)
+        self.kf_tail = _os.environ.get("YGZ_OFF_KF_TAIL", "1") != "0"
+        # experiment (measured slower): the keyframe-free frames behind the last keyframe of the last `defer_gaps` windows of
+        # the shard processed at the very end (chunk_plan), so that the last LM launches have company.  The LM tail disappears (4.7 -> 0.3 ms at
+        # 1024 frames) but the tracking grows by more (55.6 -> 60.7 ms): the small chunks are latency-bound, and a resident-LM workgroup needs a
+        # whole CU's registers, so it does not start beside busy tracking kernels anyway
+        self.defer_gaps = int(_os.environ.get("YGZ_OFF_DEFER", "0"))          # the frames behind the last keyframe as a chunk of their own (chunk_schedule)
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
         self.device = device
         n_slots = min(self.count, chunk) + 1
@@ -364,7 +405,8 @@ class OfflineVO:
         are all in are built and optimised on the third context while the next chunks run (pipeline_ba)."""
         rec = {}
         first, last = self.start, self.start + self.count
-        chunks = chunk_schedule(first, last, self.chunk, self.ramp, self.kf_stride if self.kf_tail else 0)
+        chunks = chunk_plan(first, last, self.chunk, self.ramp, self.kf_stride if self.kf_tail else 0, self.wins, self.defer_gaps if self.pipeline_ba else 0)
+        tracked = np.zeros(self.n_total, bool)
         pending = [None] * len(self.lanes)
         self._ba_done, self._ba_built = set(), []
         self._lm_launches = 0
@@ -380,7 +422,8 @@ class OfflineVO:
                 # windows whose keyframes are all in: built at once (a matcher launch and two small kernels); the resident LM is a latency-
                 # bound kernel that takes as long for two windows as for eight, so it is launched per lm_group windows (and for the rest
                 # after the last chunk): its launches then fit beside the tracking of the following chunks instead of queueing up
-                new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and self.wins[i][-1] < c1]
+                tracked[c0:c1] = True
+                new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and tracked[self.wins[i][0]:self.wins[i][-1] + 1].all()]
                 self._ba_launch(new, optimize=False)
                 self._ba_built += new
                 all_built = len(self._ba_done) + len(self._ba_built) == len(self.local)     # nothing more will come: the last launch need not wait for the last chunk
