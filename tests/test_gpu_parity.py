@@ -385,6 +385,28 @@ def test_sparse_align(hip_lib, oracle, lanes, monkeypatch):
         ctx.close()
 
 
+def test_sparse_align_more_than_16384_grid_cells(hip_lib, oracle):
+    """a 1920x1080 frame has 192 x 108 = 20 736 grid cells: beyond the 32 x 512 features the first form of the kernel could mark per problem (it
+    returned YGZ_E_CAPACITY); the second form marks entering / leaving features in their flags byte.  ~6000 features against the oracle."""
+    w, h = 1920, 1080
+    imgs, poses, depths = _frames(2, w, h, seed=5, step=0.3)
+    k0 = oracle.detect(oracle.pyramid(imgs[0], 3), oracle.default_params(w, h, 3))
+    px = np.stack([k0["px"], k0["py"]], 1)
+    depth = np.array([depths[0][int(p[1]), int(p[0])] for p in px])
+    has_mp = np.ones(len(px), np.uint8); has_mp[::11] = 0
+    T_init = oracle.se3_mul(synth.se3_exp([0.003, -0.002, 0.002, 0.001, -0.001, 0.001]), poses[1])
+    ctx = make_ctx(hip_lib, width=w, height=h, max_frames=2)
+    assert ctx.cells == 20736 and len(px) > 4000
+    for s_ in range(2):
+        ctx.upload_gray(s_, imgs[s_])
+    ctx.build_pyramid(0, 2)
+    nm, T, iters = ctx.sparse_align(0, poses[0], 1, T_init, px, depth, has_mp)
+    onm, oT, st = oracle.sparse_align(oracle.pyramid(imgs[0], 3), poses[0], oracle.pyramid(imgs[1], 3), T_init, px, depth, has_mp)
+    assert nm == onm and iters == list(st.iters_per_level)[:3]
+    assert np.allclose(T, oT, rtol=1e-9, atol=1e-11)
+    ctx.close()
+
+
 def test_sparse_align_golden_and_empty(hip_lib):
     g, e = golden("align"), golden("extract")
     ctx = make_ctx(hip_lib, width=320, height=240, max_frames=2)

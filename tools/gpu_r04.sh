@@ -231,5 +231,17 @@ PY
     YGZ_OFF_DEFER=16 offline gray_d16 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline --upload gray
     YGZ_OFF_DEFER=0 offline gray_d0 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline --upload gray
     ;;
+p)  # two resident batches per GPU (consecutive steps alternate): does the extractor head of one step hide behind the LK tail of the other now?
+    benchline single $STEP
+    benchline double $STEP --double-buffer
+    YGZ_BENCH_KLT_PREPARE=1 benchline double_prep $STEP --double-buffer
+    benchline single_b $STEP
+    benchline double_b $STEP --double-buffer
+    ;;
+q)  # sparse alignment without the 16 384-cell limit (flags byte instead of per-lane bit masks)
+    timeout 900 python -m pytest tests -m gpu -q -k "sparse or golden or offline_sharded or track_handover" > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    python tools/stage_bench.py sparse --batch 512 --reps 5
+    benchline dflt $STEP
+    ;;
 *)  echo "unknown batch $B"; exit 2 ;;
 esac

@@ -745,7 +745,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
             double acc[27];
 #pragma unroll
             for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-            uint32_t chg_mask = 0u, add_mask = 0u;                  // per lane: which of its features (f0_ / SA_THREADS) entered / left this iteration
+            bool any_chg = false;                                   // some feature of this lane entered / left this iteration: bits 2 (changed) and 3 (entered) of its flags byte say which
             if (it == 0) {
                 // ---- precomputeReferencePatches (:59-122) fused with the first computeResiduals of the level: jacobian_cache_.setZero()
                 // (:42) = zero gradients for the features this level does not refill; H gets the blocks of the used features
@@ -811,7 +811,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
-                        flags[f] = (uint8_t)((vis ? 1 : 0) | (use ? 2 : 0));
+                        flags[f] = (uint8_t)((vis ? 1 : 0) | (use ? 2 : 0) | (!H_INLINE && use && refill ? 12 : 0));
                         if (use) {
                             my_meas += 16;
                             double fj[12];
@@ -823,7 +823,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                                     sa_feature_h(fj, L.fl, dxv, dyv, hf);
 #pragma unroll
                                     for (int k = 0; k < 21; ++k) acc[k] += hf[k];
-                                } else { chg_mask |= 1u << (f0_ / SA_THREADS); add_mask |= 1u << (f0_ / SA_THREADS); }
+                                } else any_chg = true;
                             }
                         }
                     }
@@ -858,9 +858,8 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
                         const bool pu = (fl0 & 2) != 0;
                         if (use != pu) {                                     // rare: H changes by +-(the feature's block), added in the second loop below
-                            flags[f] = (uint8_t)((fl0 & 1) | (use ? 2 : 0));
-                            chg_mask |= 1u << (f0_ / SA_THREADS);
-                            if (use) add_mask |= 1u << (f0_ / SA_THREADS);
+                            flags[f] = (uint8_t)((fl0 & 1) | (use ? 2 : 0) | 4 | (use ? 8 : 0));
+                            any_chg = true;
                         }
                         if (use) {
                             my_meas += 16;
@@ -876,12 +875,15 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                     if (lane == 63) SA_CTOT(f >> 6) = incl;
                 }
             }
-            if (__ballot(chg_mask != 0u) != 0ull) {                 // wave-uniform skip: no feature of this wavefront changed state
+            if (__ballot(any_chg) != 0ull) {                        // wave-uniform skip: no feature of this wavefront changed state
 #pragma unroll 1
                 for (int c = 0; c * SA_THREADS < n; ++c) {
-                    if (!((chg_mask >> c) & 1u)) continue;
                     const int f = c * SA_THREADS + tid;
-                    const bool add = (add_mask >> c) & 1u;
+                    if (!any_chg || f >= n) continue;
+                    const uint8_t flc = flags[f];
+                    if (!(flc & 4)) continue;
+                    flags[f] = (uint8_t)(flc & 3);
+                    const bool add = (flc & 8) != 0;
                     const float4 *gp = reinterpret_cast<const float4 *>(dxy + 32 * (size_t)f);
                     const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3], g4 = gp[4], g5 = gp[5], g6 = gp[6], g7 = gp[7];
                     const float gxv[16] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w };
@@ -1109,10 +1111,11 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
     const char *env_t = getenv("YGZ_SA_THREADS");
     int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
-    // the deferred H update keeps one bit per feature of a lane (chg_mask / add_mask, 32 bits): a problem may hold up to 32 x lanes features
-    if (ctx->cells > 32 * 256) threads = 512;
-    if (ctx->cells > 32 * 512) return YGZ_E_CAPACITY;
     static const int form = [] { const char *e = getenv("YGZ_SA_FORM"); return e ? atoi(e) : 1; }();      // 0: the first form of the kernel (A/B)
+    // the first form keeps one bit per feature of a lane for its deferred H update (32 bits): up to 32 x lanes features per problem; the second
+    // form marks entering / leaving features in their flags byte: any number of grid cells
+    if (ctx->cells > 32 * 256) threads = 512;
+    if (form == 0 && ctx->cells > 32 * 512) return YGZ_E_CAPACITY;
     // per-iteration scratch of the first lcap features in LDS: 4 x 16 (r2) + 16 (fmap) + 8 (pmap) + 4 (pre) bytes each + chunk totals;
     // second form: + 64 bytes (the reference patch) for the first pcap features, from what the scratch leaves
     // (a 512-lane problem owns its CU -- nothing else fits beside 512 x 256 registers -- so it may take nearly all of the LDS)
