@@ -412,6 +412,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     t0 = time.perf_counter()
     phases = []
     for _ in range(steps):
+        t_run = time.perf_counter()
         res = vo.run(None, None, block)
         phases.append(dict(vo.timing))
     barrier()
@@ -425,6 +426,9 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
         print("[offline trace] host time inside ABI calls %.1f ms of %.1f ms" % (sum(v[1] for v in agg.values()) * 1e3, dt * 1e3), file=sys.stderr)
         for name, (cnt, tot, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
             print("[offline trace] %-36s calls %4d total %8.2f ms max %7.2f ms" % (name, cnt, tot * 1e3, mx * 1e3), file=sys.stderr)
+        for name, a_, b_ in tr:                               # the host's side of the LAST run: uploads, waits, BA launches (ms from the start of the run)
+            if a_ >= t_run and (name.split(".")[1] in ("upload_bgr_batch", "upload_gray_batch", "synchronize", "ba_optimize_resident", "ba_build_windows") or b_ - a_ > 2e-4):
+                print("[offline host] %8.2f  %-34s %6.2f ms" % ((a_ - t_run) * 1e3, name, (b_ - a_) * 1e3), file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

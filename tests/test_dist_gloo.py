@@ -167,32 +167,58 @@ def test_offline_chunk_schedule_and_depth_images():
             if ramp and chunk >= 64 and last - first >= 4 * chunk:
                 assert c[0][1] - c[0][0] == chunk // 4 and c[-1][1] - c[-1][0] == chunk // 4     # short first upload, short last kernels
             # with a keyframe stride the frames behind the shard's last keyframe form the last chunk (no BA window waits for them)
-            k = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8)
+            k = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8, kf_small=0)
             assert k[0][0] == first and k[-1][1] == last and all(a[1] == b[0] for a, b in zip(k, k[1:])) and all(0 < b - a <= chunk for a, b in k)
             k_last = ((last - 1) // 8) * 8
             if first <= k_last < last - 1 and c[-1][0] <= k_last:
                 assert k[-1] == (k_last + 1, last) and k[:-2] == c[:-1] and k[-2] == (c[-1][0], k_last + 1)
             else:
                 assert k == c
-    # the plan with deferred gaps: every frame of the shard exactly once, the frames behind the last keyframes of the last windows at the end,
-    # every window complete (anchor .. last keyframe) before the first deferred gap is processed
-    for first, last, chunk, defer in ((0, 1024, 128, 12), (0, 1024, 128, 16), (128, 256, 32, 2), (0, 128, 32, 2), (0, 100, 32, 3), (64, 200, 32, 5), (0, 16, 5, 2)):
+            # ... and the chunk that ends WITH the last keyframe is short (the last LM launch waits for its kernels): at most 12 frames, cut
+            # from the end of the chunk that held the keyframe; everything else as before
+            s8 = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8, kf_small=8)
+            assert s8[0][0] == first and s8[-1][1] == last and all(a[1] == b[0] for a, b in zip(s8, s8[1:])) and all(0 < b - a <= chunk for a, b in s8)
+            ends = [(a, b) for a, b in s8 if b == k_last + 1]
+            if ends and ends[0] in k and ends[0][1] - ends[0][0] <= 12:
+                assert s8 == k
+            elif ends:
+                assert ends[0][1] - ends[0][0] == 8
+                i = s8.index(ends[0])
+                assert s8[:i - 1] + [(s8[i - 1][0], ends[0][1])] + s8[i + 1:] == k
+            else:
+                assert s8 == k
+    # the plan with deferred gaps (a chunk = a tuple of frame ranges): every frame of the shard exactly once, the frames behind the last
+    # keyframes of the last windows at the end -- grouped, about 45 frames per chunk --, every window complete (anchor .. last keyframe) before the
+    # first deferred chunk is processed, never more than `chunk` frames per chunk
+    for first, last, chunk, defer in ((0, 1024, 128, 12), (0, 1024, 128, 16), (128, 256, 32, 2), (0, 128, 32, 2), (0, 100, 32, 3), (64, 200, 32, 5), (0, 16, 5, 2),
+                                      (0, 1024, 128, 13), (0, 512, 128, 13), (256, 512, 64, 13)):
         wins = offline.ba_windows(1024, 8, 8)
         plan = offline.chunk_plan(first, last, chunk, True, 8, wins, defer)
         seen = np.zeros(1024, int)
-        for a, b in plan:
-            assert first <= a < b <= last and b - a <= chunk
-            seen[a:b] += 1
+        for ch in plan:
+            assert len(ch) >= 1 and sum(b - a for a, b in ch) <= chunk
+            assert all(first <= a < b <= last for a, b in ch) and all(x[1] < y[0] for x, y in zip(ch, ch[1:]))     # sorted, not adjacent
+            for a, b in ch:
+                seen[a:b] += 1
         assert np.all(seen[first:last] == 1) and seen.sum() == last - first
         inside = [w for w in wins if w[0] >= first and w[-1] < last]
         gaps = [(w[-1] + 1, min(last, w[0] + 64)) for w in inside[-defer:] if w[-1] + 1 < min(last, w[0] + 64) and w[-1] + 1 > first]
-        tail = plan[len(plan) - len(gaps):] if gaps else []
-        assert tail == gaps, (plan, gaps)
+        gap_frames = sorted(f for a, b in gaps for f in range(a, b))
+        n_tail = 0
+        while gap_frames and sorted(f for ch in plan[len(plan) - n_tail:] for a, b in ch for f in range(a, b)) != gap_frames:
+            n_tail += 1
+            assert n_tail <= len(plan), (plan, gaps)
+        if gap_frames:                                                              # grouped: whole gaps, about 45 frames per chunk, at the very end
+            assert all(all(r in gaps for r in ch) for ch in plan[len(plan) - n_tail:]), (plan, gaps)
+            assert n_tail <= max(1, int(round(len(gap_frames) / 45.0))) + (1 if chunk < 45 else 0), (plan, gaps)
+            cut = offline.chunk_plan(first, last, chunk, True, 8, wins, defer, last_main=16)       # (option: a short last chunk of the main pass)
+            assert sum(b - a for a, b in cut[len(cut) - n_tail - 1]) <= 24 and cut[len(cut) - n_tail:] == plan[len(plan) - n_tail:]
         done = np.zeros(1024, bool)
-        for a, b in plan[:len(plan) - len(gaps)]:
-            done[a:b] = True
+        for ch in plan[:len(plan) - n_tail]:
+            for a, b in ch:
+                done[a:b] = True
         assert all(done[w[0]:w[-1] + 1].all() for w in inside)
-        assert offline.chunk_plan(first, last, chunk, True, 8, wins, 0) == offline.chunk_schedule(first, last, chunk, True, 8)
+        assert offline.chunk_plan(first, last, chunk, True, 8, wins, 0) == [((a, b),) for a, b in offline.chunk_schedule(first, last, chunk, True, 8)]
     rng = np.random.default_rng(0)
     d = rng.uniform(0.5, 6.0, (48, 64))
     d[5, 7] = 0.0

@@ -176,6 +176,145 @@ k)  # the resident LM on the run's own windows, alone
     python tools/lm_insitu.py --frames 256 2>&1 | grep -v amdgpu | tail -12
     YGZ_LM_DEBUG=1 python tools/lm_insitu.py --frames 128 2>&1 | grep "lm-debug" | tail -2
     ;;
+r)  # the chunk that ends with the shard's last keyframe kept short (the last LM launch starts earlier); LM records / reset as one launch each
+    timeout 900 python -m pytest tests/test_gpu_offline.py tests/test_gpu_parity.py -m gpu -q -k "offline or resident or ba_ or window" > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-16s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    for F in 1024 128; do
+        OFF="python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline"
+        YGZ_OFF_KF_SMALL=0 offline f${F}_small0 $OFF
+        offline f${F}_small8 $OFF
+        YGZ_OFF_KF_SMALL=4 offline f${F}_small4 $OFF
+        YGZ_OFF_KF_SMALL=0 offline f${F}_small0_b $OFF
+        offline f${F}_small8_b $OFF
+    done
+    YGZ_OFFLINE_TRACE=1 timeout 300 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep "offline trace" | head -16
+    bash tools/offline_timeline.sh r04r --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    python tools/offline_timeline_summary.py gpurun_out/r04r_timeline.tsv | tail -75
+    ;;
+s)  # where the host is at the end of an offline run (per-call log of the last run), the LM alone with the new reset launch against the memsets
+    python tools/lm_insitu.py --frames 256 2>&1 | grep -v amdgpu | tail -8
+    YGZ_LM_RESET_MEMSETS=1 python tools/lm_insitu.py --frames 256 2>&1 | grep -v amdgpu | tail -6
+    for SM in 0 8; do
+        echo "== KF_SMALL=$SM"
+        YGZ_OFF_KF_SMALL=$SM YGZ_OFFLINE_TRACE=1 timeout 300 python bench.py --mode offline --frames 1024 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep "offline host" | awk '$3 > 40' | head -80
+    done
+    echo "== f128 KF_SMALL=0"
+    YGZ_OFF_KF_SMALL=0 YGZ_OFFLINE_TRACE=1 timeout 300 python bench.py --mode offline --frames 128 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep "offline host" | head -60
+    ;;
+t)  # the end of an offline run: hardware queues (streams that share one serialise) and lanes ahead (a lane is re-used only when its chunk is done)
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-22s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    for F in 1024 128; do
+        OFF="python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline"
+        offline f${F}_base $OFF
+        GPU_MAX_HW_QUEUES=8 offline f${F}_q8 $OFF
+        GPU_MAX_HW_QUEUES=16 offline f${F}_q16 $OFF
+        YGZ_OFF_AHEAD=2 offline f${F}_ahead2 $OFF
+        GPU_MAX_HW_QUEUES=8 YGZ_OFF_AHEAD=2 offline f${F}_q8_ahead2 $OFF
+        GPU_MAX_HW_QUEUES=8 YGZ_OFF_AHEAD=2 YGZ_OFF_KF_SMALL=0 offline f${F}_q8_ahead2_s0 $OFF
+        GPU_MAX_HW_QUEUES=8 YGZ_OFF_KF_SMALL=0 offline f${F}_q8_s0 $OFF
+        offline f${F}_base_b $OFF
+    done
+    GPU_MAX_HW_QUEUES=8 $STEP | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('step q8', d['value'], d['ms_per_step'])"
+    $STEP | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('step base', d['value'], d['ms_per_step'])"
+    ;;
+u)  # the keyframe-free frames behind the last windows processed at the end, grouped into chunks of several ranges: the last LM launch beside them
+    timeout 900 python -m pytest tests/test_gpu_offline.py -m gpu -q -x -k "offline or window" > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-22s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    OFF="python bench.py --mode offline --frames 1024 --steps 5 --warmup 2 --no-cpu-baseline"
+    for D in 0 4 8 13 16 0 13; do YGZ_OFF_DEFER=$D offline f1024_defer$D $OFF; done
+    YGZ_OFF_DEFER=13 YGZ_OFF_KF_SMALL=0 offline f1024_defer13_s0 $OFF
+    for F in 128 256 512; do
+        OFF="python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline"
+        for D in 0 16 0 16; do YGZ_OFF_DEFER=$D offline f${F}_defer$D $OFF; done
+        YGZ_OFF_DEFER=0 YGZ_OFF_KF_SMALL=0 offline f${F}_defer0_s0 $OFF
+        YGZ_OFF_DEFER=16 YGZ_OFF_KF_SMALL=0 offline f${F}_defer16_s0 $OFF
+    done
+    YGZ_OFF_DEFER=13 bash tools/offline_timeline.sh r04u --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    python tools/offline_timeline_summary.py gpurun_out/r04u_timeline.tsv | grep -v "rocclr\|k_pyr\|k_scharr\|k_track\|k_match\|k_compact\|k_detect" | tail -50
+    ;;
+v)  # tuning of the deferred plan: frames per deferred chunk, last chunk of the main pass, number of gaps; short shards on the defaults
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-22s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    OFF="python bench.py --mode offline --frames 1024 --steps 5 --warmup 2 --no-cpu-baseline"
+    offline f1024_default $OFF
+    YGZ_OFF_DEFER=0 offline f1024_defer0 $OFF
+    YGZ_OFF_DEFER_GROUP=32 offline f1024_group32 $OFF
+    YGZ_OFF_DEFER_GROUP=91 offline f1024_group91 $OFF
+    YGZ_OFF_LAST_MAIN=0 offline f1024_lastmain32 $OFF
+    YGZ_OFF_LAST_MAIN=8 offline f1024_lastmain8 $OFF
+    YGZ_OFF_DEFER=10 offline f1024_defer10 $OFF
+    YGZ_OFF_DEFER=16 offline f1024_defer16 $OFF
+    offline f1024_default_b $OFF
+    offline f512_default python bench.py --mode offline --frames 512 --steps 5 --warmup 2 --no-cpu-baseline
+    YGZ_OFF_DEFER=8 offline f512_defer8 python bench.py --mode offline --frames 512 --steps 5 --warmup 2 --no-cpu-baseline
+    offline f128_default python bench.py --mode offline --frames 128 --steps 5 --warmup 2 --no-cpu-baseline
+    offline f1024_gray python bench.py --mode offline --frames 1024 --upload gray --steps 5 --warmup 2 --no-cpu-baseline
+    YGZ_OFF_DEFER=0 offline f1024_gray_defer0 python bench.py --mode offline --frames 1024 --upload gray --steps 5 --warmup 2 --no-cpu-baseline
+    bash tools/offline_timeline.sh r04v --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    python tools/offline_timeline_summary.py gpurun_out/r04v_timeline.tsv | grep -v "rocclr\|k_pyr\|k_scharr\|k_track\|k_match\|k_compact\|k_detect\|k_trel" | tail -60
+    ;;
+w)  # the host enqueues every chunk without waiting for a lane (per-chunk result rows): offline tests, plans with and without it
+    timeout 900 python -m pytest tests/test_gpu_offline.py -m gpu -q -x -k "offline or window" > $OUT/pytest.log 2>&1; tail -4 $OUT/pytest.log
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-22s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    OFF="python bench.py --mode offline --frames 1024 --steps 5 --warmup 2 --no-cpu-baseline"
+    offline f1024_default $OFF
+    YGZ_OFF_LAST_MAIN=0 offline f1024_lastmain32 $OFF
+    YGZ_OFF_RUN_AHEAD=0 YGZ_OFF_LAST_MAIN=0 offline f1024_lastmain32_ra0 $OFF
+    YGZ_OFF_DEFER=0 offline f1024_defer0 $OFF
+    YGZ_OFF_DEFER=0 YGZ_OFF_RUN_AHEAD=0 offline f1024_defer0_ra0 $OFF
+    YGZ_OFF_DEFER=16 offline f1024_defer16 $OFF
+    YGZ_OFF_DEFER_GROUP=32 offline f1024_group32 $OFF
+    offline f1024_default_b $OFF
+    for F in 128 256 512; do
+        OFF="python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline"
+        offline f${F}_default $OFF
+        YGZ_OFF_RUN_AHEAD=0 offline f${F}_ra0 $OFF
+        YGZ_OFF_DEFER=16 offline f${F}_defer16 $OFF
+    done
+    offline f1024_gray python bench.py --mode offline --frames 1024 --upload gray --steps 5 --warmup 2 --no-cpu-baseline
+    YGZ_OFF_RUN_AHEAD=0 YGZ_OFF_DEFER=0 offline f1024_gray_old python bench.py --mode offline --frames 1024 --upload gray --steps 5 --warmup 2 --no-cpu-baseline
+    bash tools/offline_timeline.sh r04w --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+    python tools/offline_timeline_summary.py gpurun_out/r04w_timeline.tsv | grep -v "rocclr\|k_pyr\|k_scharr\|k_track\|k_match\|k_compact\|k_detect\|k_trel" | tail -48
+    ;;
 z)  # round-4 closing batch: full GPU suite, the three rocprofv3 passes of the default command, the SQ pass, the step timeline, the default
     # bench line with its extra blocks, the offline lines per shard size, the kernel statistics and the device timeline of the offline mode
     timeout 900 python -m pytest tests -q -m gpu --no-header -rf 2>&1 | tail -4

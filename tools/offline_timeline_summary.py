@@ -18,20 +18,16 @@ for line in open(path):
     rec = (p[1], float(p[2]) / 1e3, float(p[3]) / 1e3, p[4])          # ms
     (K if p[0] == "K" else C).append(rec)
 
-big = [c for c in C if int(c[0].split(":")[1]) >= 16 << 20]
-# every run uploads the same sequence of chunks: the last run is the last period of the size sequence
-sizes = [c[0] for c in big]
-period = len(big)
-for n in range(1, len(big) // 2 + 1):
-    if sizes[-n:] == sizes[-2 * n:-n]:
-        period = n
-        break
-runs = [big[-period:]]
-up = runs[-1]
+# a run ends with k_ba_pack (the window states packed for the exchange / download): the last run lies between the last two of them
+packs = sorted(k[2] for k in K if k[0].startswith("k_ba_pack"))
+t_end = packs[-1] if packs else max(k[2] for k in K)
+t_begin = packs[-2] if len(packs) > 1 else min(k[1] for k in K)
+up = [c for c in C if t_begin < c[1] < t_end and int(c[0].split(":")[1]) >= 2 << 20 and (int(c[0].split(":")[1]) % 2764800 == 0 or int(c[0].split(":")[1]) % 921600 == 0)]
+up = [c for c in up if int(c[0].split(":")[1]) % (1280 * 720) == 0 and int(c[0].split(":")[1]) >= 1280 * 720 * 2]      # frame uploads (BGR or gray), not depth images
 t0 = up[0][1]
 t_last_upload = up[-1][2]
-kern = [k for k in K if k[1] >= t0 - 0.5]
-end = max(max(k[2] for k in kern), max(c[2] for c in C if c[1] >= t0))
+kern = [k for k in K if t0 - 0.5 <= k[1] <= t_end + 0.5]
+end = max(max(k[2] for k in kern), max(c[2] for c in C if t0 <= c[1] <= t_end + 0.5))
 
 print("# Device timeline of the last timed run of `%s` (1 GPU)\n" % title)
 print("`tools/offline_timeline.sh <tag> ...` (rocprofv3 --kernel-trace --memory-copy-trace; times in ms from the first upload of the run; "

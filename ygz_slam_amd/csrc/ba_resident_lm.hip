@@ -873,6 +873,29 @@ __global__ __launch_bounds__(256) void k_ba_outliers(OutlierArgs A)
     if (tid < 4) { double t = 0.0; for (int i = 0; i < 256; ++i) t += red[tid][i]; B.lm_out[4 + tid] = t; }
 }
 
+__global__ __launch_bounds__(256) void k_ba_lm_reset(const BaDev *__restrict__ wins, unsigned char *__restrict__ scratch, size_t stride,
+                                                       ygz_ba_stats *__restrict__ stats)
+{
+    static_assert(LM_HDR == 256 * 4 && sizeof(ygz_ba_stats) == 32, "one dword per thread; four 8-byte words per record");
+    const int w = blockIdx.x, tid = threadIdx.x;
+    reinterpret_cast<uint32_t *>(scratch + (size_t)w * stride)[tid] = 0u;
+    if (tid < 4) reinterpret_cast<unsigned long long *>(stats + w)[tid] = ~0ull;
+    else if (tid < 8) reinterpret_cast<unsigned long long *>(wins[w].lm_out)[tid - 4] = 0xFEFEFEFEFEFEFEFEull;
+}
+
+// the per-window records of a range in one piece: lm_out[0..8) (statistics of the last resident run, outlier record) and the sizes of the
+// graph as the device table holds them -> rec[w][LM_REC] (ygz_hip_ba_get_stats / ygz_hip_ba_get_outlier_stats: one copy instead of one per window)
+#define LM_REC 12
+__global__ void k_ba_records(const BaDev *__restrict__ wins, int n, double *__restrict__ rec)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n) return;
+    const BaDev &B = wins[w];
+    for (int i = 0; i < 8; ++i) rec[(size_t)w * LM_REC + i] = B.lm_out[i];
+    rec[(size_t)w * LM_REC + 8] = (double)B.K; rec[(size_t)w * LM_REC + 9] = (double)B.P;
+    rec[(size_t)w * LM_REC + 10] = (double)B.E; rec[(size_t)w * LM_REC + 11] = (double)B.Kf;
+}
+
 extern "C" {
 
 int ygz_hip_ba_set_team_budget(ygz_hip_ctx *ctx, int workgroups)
@@ -917,10 +940,17 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
     YgzAuxScope aux(ctx, 1);
-    YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, LM_HDR, (size_t)n_windows, ctx->stream));         // barrier counters, abort flags
-    YGZ_HIPCHK(ctx, hipMemsetAsync(d_scr, 0xFF, stats_bytes, ctx->stream));                               // iterations = -1 until a team finishes
-    for (int i = window_begin; i < window_begin + n_windows; ++i)                                         // the same in the windows' own records
-        YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->ba[i]->lm_out, 0xFE, sizeof(ygz_ba_stats), ctx->stream));      // (0xFF = never run, ba_carve)
+    // barrier counters and abort flags zeroed, iterations = -1 until a team finishes (0xFF in the launch's statistics, 0xFE in the windows' own
+    // records; 0xFF there = never run, ba_carve): one small launch (a 2-D memset, a memset and one memset per window took 0.15 ms of the
+    // serial tail of an offline run)
+    static const bool reset_memsets = getenv("YGZ_LM_RESET_MEMSETS") != nullptr;       // A/B: the former form
+    if (reset_memsets) {
+        YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, LM_HDR, (size_t)n_windows, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemsetAsync(d_scr, 0xFF, stats_bytes, ctx->stream));
+        for (int i = window_begin; i < window_begin + n_windows; ++i)
+            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->ba[i]->lm_out, 0xFE, sizeof(ygz_ba_stats), ctx->stream));
+    } else
+        YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_reset, dim3(n_windows), dim3(256), A.wins, A.scratch, stride, A.stats);
     YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
@@ -958,14 +988,17 @@ int ygz_hip_ba_get_stats(ygz_hip_ctx *ctx, int window_begin, int n_windows, ygz_
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);
     if (!table) return rc;
-    std::vector<int32_t> hd(8 * (size_t)n_windows);
-    for (int i = 0; i < n_windows; ++i) {
-        if (stats) YGZ_HIPCHK(ctx, hipMemcpyAsync(stats + i, ctx->ba[window_begin + i]->lm_out, sizeof(ygz_ba_stats), hipMemcpyDeviceToHost, ctx->stream));
-        if (dims) YGZ_HIPCHK(ctx, hipMemcpyAsync(hd.data() + 8 * (size_t)i, table + window_begin + i, 7 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    // one gather kernel and ONE copy for the whole range (a copy per window cost 20 us each behind the last LM launch of a run)
+    double *d_rec = nullptr;
+    if ((rc = ygz_scratch(ctx, SCR_GEN_0 + 5, (size_t)n_windows * LM_REC * 8, (void **)&d_rec)) != YGZ_OK) return rc;
+    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_records, dim3(ygz_div_up(n_windows, 64)), dim3(64), table + window_begin, n_windows, d_rec);
+    std::vector<double> hr((size_t)n_windows * LM_REC);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(hr.data(), d_rec, hr.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (dims) for (int i = 0; i < n_windows; ++i) {
-        dims[4 * i] = hd[8 * (size_t)i]; dims[4 * i + 1] = hd[8 * (size_t)i + 1]; dims[4 * i + 2] = hd[8 * (size_t)i + 2]; dims[4 * i + 3] = hd[8 * (size_t)i + 4];
+    for (int i = 0; i < n_windows; ++i) {
+        const double *r = hr.data() + (size_t)i * LM_REC;
+        if (stats) memcpy(stats + i, r, sizeof(ygz_ba_stats));
+        if (dims) { dims[4 * i] = (int32_t)r[8]; dims[4 * i + 1] = (int32_t)r[9]; dims[4 * i + 2] = (int32_t)r[10]; dims[4 * i + 3] = (int32_t)r[11]; }
     }
     if (stats) for (int i = 0; i < n_windows; ++i) if (stats[i].iterations < 0) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return stats[i].lm_trials == -1 ? YGZ_E_STATE : YGZ_E_HIP; }
     return YGZ_OK;
@@ -996,9 +1029,16 @@ int ygz_hip_ba_get_outlier_stats(ygz_hip_ctx *ctx, int window_begin, int n_windo
     if (!ctx || !out || window_begin < 0 || n_windows < 1 || window_begin + n_windows > (int)ctx->ba.size()) return YGZ_E_INVALID;
     for (int i = window_begin; i < window_begin + n_windows; ++i) if (!ctx->ba[i]) return YGZ_E_INVALID;
     { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
-    for (int i = 0; i < n_windows; ++i)
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(out + 4 * (size_t)i, ctx->ba[window_begin + i]->lm_out + 4, 32, hipMemcpyDeviceToHost, ctx->stream));
+    int rc = YGZ_OK;
+    const BaDev *table = ygz_ba_table(ctx, &rc);
+    if (!table) return rc;
+    double *d_rec = nullptr;
+    if ((rc = ygz_scratch(ctx, SCR_GEN_0 + 5, (size_t)n_windows * LM_REC * 8, (void **)&d_rec)) != YGZ_OK) return rc;
+    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_records, dim3(ygz_div_up(n_windows, 64)), dim3(64), table + window_begin, n_windows, d_rec);
+    std::vector<double> hr((size_t)n_windows * LM_REC);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(hr.data(), d_rec, hr.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_windows; ++i) for (int k = 0; k < 4; ++k) out[4 * (size_t)i + k] = hr[(size_t)i * LM_REC + 4 + k];
     return YGZ_OK;
 }
 

@@ -37,6 +37,7 @@ summary.
 
 This module is host logic over the C ABI (ygz_slam_amd._lib); it never touches oracle/.
 """
+import os as _os
 import numpy as np
 
 from . import dist as ydist
@@ -188,14 +189,17 @@ def exchange_rows(buf, owner, world, pg=None, via_host=None):
             buf[rows[r][0]:rows[r][-1] + 1] = g[r, :len(rows[r])]
 
 
-def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
+KF_SMALL = int(_os.environ.get("YGZ_OFF_KF_SMALL", "0"))     # frames of the chunk that ends with a shard's last keyframe (0: not cut; 8: -0.5 ms at 1024 frames, +1 ms at 128 / 512)
+
+
+def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0, kf_small=KF_SMALL, ramp_from=4):
     """[first, last) cut into chunks of `chunk` frames, with a ramp at both ends (chunk / 4, chunk / 2, chunk ... chunk, chunk / 2, chunk / 4)
     when there is room: nothing overlaps the upload of the first chunk or the kernels of the last one, so those two are kept short.
     kf_stride > 0: the frames behind the shard's last keyframe (they complete no BA window) form a chunk of their own at the very end, so
     that every window is complete one chunk earlier and the last resident-LM launch runs beside that chunk instead of after it"""
     n = last - first
     sizes = []
-    if ramp and chunk >= 64 and n >= 4 * chunk:
+    if ramp and chunk >= 64 and n >= ramp_from * chunk:
         head = [chunk // 4, chunk // 2]
         tail = [chunk // 2, chunk // 4]
         body = n - sum(head) - sum(tail)
@@ -211,18 +215,33 @@ def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
         k_last = ((b - 1) // kf_stride) * kf_stride                # the last keyframe of the shard
         if a <= k_last and k_last + 1 < b and k_last + 1 > a:
             out[-1:] = [(a, k_last + 1), (k_last + 1, b)]
+        # the chunk that ENDS with the last keyframe decides when the last resident-LM launch starts (upload of the keyframe -> the chunk's
+        # kernels -> window build -> LM, nothing hides it): kept to kf_small frames -- a chunk of 8 frames passes through the kernels in
+        # 1.6 ms, one of 26 in 2.7 (profiles/r04_offline_timeline_summary.md)
+        for k, (a, b) in enumerate(out):
+            if b == k_last + 1 and kf_small > 0 and b - a > kf_small + kf_small // 2:
+                out[k:k + 1] = [(a, b - kf_small), (b - kf_small, b)]
+                break
     return out
 
 
-def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
-    """The chunks of the shard [first, last) IN PROCESSING ORDER.  Every frame pair is solved from the identity, so the order is free; what it
-    decides is when a BA window is complete (all frames from its anchor to its last keyframe tracked) and therefore where its resident-LM launch
-    -- a latency chain of ~5 ms that uses a fraction of the GPU -- falls.  The frames BEHIND a window's last keyframe (kf_stride - 1 of them, up to
-    the next anchor) complete nothing: for the last `defer` windows that end inside the shard they are taken out of the main pass and processed
-    at the very end, one small chunk per gap, so that the last LM launches run beside them instead of after everything else.  Cost: two more halo
-    frames per deferred gap (the range after a gap and the gap itself each upload their predecessor once more)."""
+DEFER_GROUP = int(_os.environ.get("YGZ_OFF_DEFER_GROUP", "45"))      # frames per deferred chunk (about)
+DEFER_LAST_MAIN = int(_os.environ.get("YGZ_OFF_LAST_MAIN", "0"))     # > 0: the last chunk of the main pass cut to this many frames (16: + 2 ms at 1024 frames -- one more chunk for the host to hand to a busy lane)
+
+
+def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer, group=DEFER_GROUP, last_main=DEFER_LAST_MAIN):
+    """The chunks of the shard [first, last) IN PROCESSING ORDER; a chunk is a tuple of frame ranges ((a, b), ...) -- normally one.  Every
+    frame pair is solved from the identity, so the order is free; what it decides is when a BA window is complete (all frames from its anchor
+    to its last keyframe tracked) and therefore where its resident-LM launch -- a latency chain of ~5 ms that uses a fraction of the GPU --
+    falls.  The frames BEHIND a window's last keyframe (kf_stride - 1 of them, up to the next anchor) complete nothing: for the last `defer`
+    windows that end inside the shard they are taken out of the main pass and processed at the very end, about `group` frames per chunk (a
+    chunk of several short ranges: one small chunk per gap costs a pass of latency-bound kernels each), so that the last LM launch runs
+    beside their uploads and kernels instead of after everything else; the last chunk of the main pass -- the LM waits for its kernels --
+    can be cut to last_main frames (measured slower, off).  Cost: two more halo frames per deferred gap (the range after a gap and the gap itself each upload their
+    predecessor once more)."""
+    plain = [((a, b),) for a, b in chunk_schedule(first, last, chunk, ramp, kf_stride)]
     if defer <= 0:
-        return chunk_schedule(first, last, chunk, ramp, kf_stride)
+        return plain
     inside = [w for w in windows if w[0] >= first and w[-1] < last]
     anchors = sorted(w[0] for w in windows)
     gaps = []
@@ -232,7 +251,7 @@ def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
         if g1 > g0 and g0 > first:
             gaps.append((g0, g1))
     if not gaps:
-        return chunk_schedule(first, last, chunk, ramp, kf_stride)
+        return plain
     main, a = [], first
     for g0, g1 in gaps:
         if g0 > a:
@@ -240,13 +259,34 @@ def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
         a = g1
     if a < last:
         main.append((a, last))
+    # the main pass: the schedule of a shard of n_main frames (ramp at both ends), its intervals mapped back onto the ranges that are left
+    n_main = sum(b - a for a, b in main)
+    virt = chunk_schedule(0, n_main, chunk, ramp, 0, ramp_from=3)
+    if last_main > 0 and virt and virt[-1][1] - virt[-1][0] > last_main + last_main // 2:
+        v0, v1 = virt[-1]
+        virt[-1:] = [(v0, v1 - last_main), (v1 - last_main, v1)]
     out = []
-    for k, (a, b) in enumerate(main):
-        if k == 0 and ramp and chunk >= 64 and b - a < 4 * chunk and b - a > chunk // 2:
-            out.append((a, a + chunk // 4)); a += chunk // 4      # a short first range still starts with a short upload (nothing runs beside it)
-        out += chunk_schedule(a, b, chunk, ramp and k == 0)
-    for g0, g1 in gaps:
-        out += chunk_schedule(g0, g1, chunk, False)
+    for v0, v1 in virt:
+        rs, pos = [], 0
+        for a, b in main:
+            lo, hi = max(v0, pos), min(v1, pos + (b - a))
+            if hi > lo:
+                rs.append((a + lo - pos, a + hi - pos))
+            pos += b - a
+        out.append(tuple(rs))
+    # the deferred gaps: whole gaps (a split gap would need one more halo frame), in n_groups chunks of about `group` frames each
+    tot = sum(b - a for a, b in gaps)
+    n_groups = max(1, int(round(tot / float(max(1, group)))))
+    per = -(-len(gaps) // n_groups)
+    for k in range(0, len(gaps), per):
+        ch = []
+        for g0, g1 in gaps[k:k + per]:
+            while g1 - g0 > chunk:                                 # (a gap longer than a chunk)
+                out.append(((g0, g0 + chunk),)); g0 += chunk
+            ch.append((g0, g1))
+        while sum(b - a for a, b in ch) > chunk:                   # (never more than `chunk` frames per chunk)
+            out.append((ch.pop(0),))
+        out.append(tuple(ch))
     return out
 
 
@@ -322,15 +362,23 @@ class OfflineVO:
         self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
         self.ramp = _os.environ.get("YGZ_OFF_RAMP", "1") != "0"
         self.kf_tail = _os.environ.get("YGZ_OFF_KF_TAIL", "1") != "0"
-        # experiment (measured slower): the keyframe-free frames behind the last keyframe of the last `defer_gaps` windows of
-        # the shard processed at the very end (chunk_plan), so that the last LM launches have company.  The LM tail disappears (4.7 -> 0.3 ms at
-        # 1024 frames) but the tracking grows by more (55.6 -> 60.7 ms): the small chunks are latency-bound, and a resident-LM workgroup needs a
-        # whole CU's registers, so it does not start beside busy tracking kernels anyway
-        self.defer_gaps = int(_os.environ.get("YGZ_OFF_DEFER", "0"))          # the frames behind the last keyframe as a chunk of their own (chunk_schedule)
+        # the keyframe-free frames behind the last keyframe of the last `defer_gaps` windows of the shard are processed at the very end
+        # (chunk_plan), so that the last LM launch has company: on by default for long shards (>= 768 frames: 60.6 -> 59.2 ms at 1024 frames
+        # with 13 gaps; 16 gaps 59.6), off for short ones (512 frames: + 2 ms; 128: + 0.7 ms -- two more halo frames per gap and the ramp of
+        # the main pass cost more than the LM tail they hide).  One chunk PER gap (first form of the experiment) lost 5 ms: latency-bound
+        # small chunks
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
+        self.defer_gaps = int(_os.environ.get("YGZ_OFF_DEFER", "-1"))
+        if self.defer_gaps < 0:
+            self.defer_gaps = 13 if self.count >= 768 else 0
         self.device = device
-        n_slots = min(self.count, chunk) + 1
-        n_lanes = max(1, min(lanes, -(-self.count // chunk)))                     # never more lanes than chunks
+        # the chunks of this shard in processing order (chunk_plan); a chunk's frames and the halo frame in front of each of its ranges take
+        # consecutive slots of a lane
+        self.wins = ba_windows(n_total, kf_stride, window_kfs)
+        self.chunks = chunk_plan(self.start, self.start + self.count, chunk, self.ramp, kf_stride if self.kf_tail else 0, self.wins,
+                                 self.defer_gaps if pipeline_ba else 0)
+        n_slots = max([sum(b - a + (1 if a > 0 else 0) for a, b in ch) for ch in self.chunks] + [2])
+        n_lanes = max(1, min(lanes, len(self.chunks)))                            # never more lanes than chunks
         # `depth` chunks compute at a time; with upload_ahead > 0 there are more contexts than that, and the kernels of chunk i wait for
         # chunk i - depth while its upload (first in its stream) does not: the link runs ahead of the kernels by upload_ahead chunks
         self.depth = n_lanes
@@ -343,7 +391,6 @@ class OfflineVO:
             self.lanes.append(c)
         self.ctx = self.lanes[0]
         # windows, owners; the third context holds the keyframe store and the BA windows of this rank
-        self.wins = ba_windows(n_total, kf_stride, window_kfs)
         self.owner = [frame_owner(w[0], n_total, world) for w in self.wins]
         self.mine = [i for i, o in enumerate(self.owner) if o == rank]
         last = self.start + self.count
@@ -379,8 +426,10 @@ class OfflineVO:
             self.ctx = self.lanes[0]
             self.ba = _Traced(self.ba, self.trace, "ba")
         self.S = 6 * window_kfs + 3 * max_points + 12                             # one window state row: poses | points | K P E its trials chi2_0 chi2 lambda | edges tested, outliers, chi2, chi2 of inliers
-        cap = max(n_slots, 2)
-        self._pin = [dict(sum=_lib.PinnedArray((cap, _lib.SUMMARY_FIELDS), np.float64), cnt=_lib.PinnedArray((cap,), np.int32)) for _ in self.lanes]
+        # page-locked result rows (per-pair summary, keypoint counts), one set per chunk
+        self._pin = [dict(sum=_lib.PinnedArray((max(2, sum(b - a + 1 for a, b in ch)), _lib.SUMMARY_FIELDS), np.float64),
+                          cnt=_lib.PinnedArray((max(2, sum(b - a + 1 for a, b in ch)),), np.int32)) for ch in self.chunks]
+        self.run_ahead = os.environ.get("YGZ_OFF_RUN_AHEAD", "0") != "0"
         self.timing = {}
 
     def close(self):
@@ -405,24 +454,32 @@ class OfflineVO:
         are all in are built and optimised on the third context while the next chunks run (pipeline_ba)."""
         rec = {}
         first, last = self.start, self.start + self.count
-        chunks = chunk_plan(first, last, self.chunk, self.ramp, self.kf_stride if self.kf_tail else 0, self.wins, self.defer_gaps if self.pipeline_ba else 0)
+        chunks = self.chunks
         tracked = np.zeros(self.n_total, bool)
-        pending = [None] * len(self.lanes)
+        pending = []
         self._ba_done, self._ba_built = set(), []
         self._lm_launches = 0
         self._last_upload = None
-        for ci, (c0, c1) in enumerate(chunks):
+        for ci, ranges in enumerate(chunks):
+            # the host hands a lane its next chunk when it has read the results of the lane's previous one: `lanes` chunks are in flight.
+            # (YGZ_OFF_RUN_AHEAD=1 enqueues every chunk at once -- every chunk has its own page-locked result rows, a lane's stream orders
+            # the upload of its next chunk behind the kernels of its previous one.  Measured SLOWER, 63.6 against 59.8 ms per 1024 frames and
+            # 46.7 against 42.1 with gray frames: with everything queued the resident-LM teams and the tracking kernels of three lanes compete
+            # for the CUs -- the LM launch beside the tracking takes 8.6 instead of 5.6 ms and uploads wait behind kernels.)
             li = ci % len(self.lanes)
-            if pending[li] is not None:
-                self._collect(li, pending[li], rec)
-            pending[li] = self._enqueue(li, c0, c1, frame_source, depth_source, block_source, ci)
+            if not self.run_ahead and len(pending) >= len(self.lanes):
+                self._collect(*pending.pop(0), rec)
+            info = self._enqueue(li, ranges, frame_source, depth_source, block_source, ci)
             if self.keep:                                      # parity runs read everything back before the lane moves on
-                self._collect(li, pending[li], rec); pending[li] = None
+                self._collect(li, info, rec)
+            else:
+                pending.append((li, info))
             if self.pipeline_ba:
                 # windows whose keyframes are all in: built at once (a matcher launch and two small kernels); the resident LM is a latency-
                 # bound kernel that takes as long for two windows as for eight, so it is launched per lm_group windows (and for the rest
                 # after the last chunk): its launches then fit beside the tracking of the following chunks instead of queueing up
-                tracked[c0:c1] = True
+                for c0, c1 in ranges:
+                    tracked[c0:c1] = True
                 new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and tracked[self.wins[i][0]:self.wins[i][-1] + 1].all()]
                 self._ba_launch(new, optimize=False)
                 self._ba_built += new
@@ -434,9 +491,8 @@ class OfflineVO:
                     self._ba_optimize(self._ba_built)
                     self._ba_built = []
                     self._lm_launches += 1
-        for li in range(len(self.lanes)):
-            if pending[li] is not None:
-                self._collect(li, pending[li], rec)
+        for li, info in pending:
+            self._collect(li, info, rec)
         return rec
 
     def _lm_next(self):
@@ -445,31 +501,41 @@ class OfflineVO:
             return self.lm_sched[min(self._lm_launches, len(self.lm_sched) - 1)]
         return self.lm_group
 
-    def _enqueue(self, li, c0, c1, frame_source, depth_source, block_source, ci=0):
+    def _enqueue(self, li, ranges, frame_source, depth_source, block_source, ci=0):
+        """one chunk = the frame ranges `ranges`, each with a one-frame halo (its predecessor) in front; the ranges take consecutive slots"""
         c = self.lanes[li]
-        frames = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))      # one-frame halo: the predecessor of the chunk
+        asyn = block_source is not None
+        frames, spans = [], []                                    # spans: (first slot, frames of the range incl. halo)
+        for c0, c1 in ranges:
+            fr = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))
+            spans.append((len(frames), fr)); frames += fr
+        assert len(set(frames)) == len(frames)                    # (ranges of a chunk are not adjacent: chunk_plan merges those)
         slot_of = {f: k for k, f in enumerate(frames)}
         n = len(frames)
-        asyn = block_source is not None
-        if asyn:
-            img, dimg = block_source(frames)
-        else:
-            img = np.ascontiguousarray(np.stack([frame_source(f) for f in frames]))
-            dimg = np.ascontiguousarray(np.stack([self.depth_image(depth_source(f)) for f in frames]))
         if self._last_upload is not None and self.fifo_uploads:
             c.wait_mark(self._last_upload)                     # uploads cross PCIe one after the other, each at the full rate
-        if img.ndim == 3:                                      # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
-            c.upload_gray_batch(0, img, wait=not asyn)
-        else:
-            c.upload_bgr_batch(0, img, wait=not asyn)
-        c.upload_depth_batch(0, dimg, self.depth_scale, wait=not asyn)
+        keep_dimg = []
+        for s0, fr in spans:
+            if asyn:
+                img, dimg = block_source(fr)
+            else:
+                img = np.ascontiguousarray(np.stack([frame_source(f) for f in fr]))
+                dimg = np.ascontiguousarray(np.stack([self.depth_image(depth_source(f)) for f in fr]))
+            if img.ndim == 3:                                  # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
+                c.upload_gray_batch(s0, img, wait=not asyn)
+            else:
+                c.upload_bgr_batch(s0, img, wait=not asyn)
+            c.upload_depth_batch(s0, dimg, self.depth_scale, wait=not asyn)
+            from_bgr = img.ndim != 3
+            if self.keep:
+                keep_dimg.append(dimg)
         c.mark(); self._last_upload = c
         if len(self.lanes) > self.depth and ci >= self.depth:
             c.stream_wait(self.lanes[(ci - self.depth) % len(self.lanes)])      # at most `depth` chunks' kernels share the GPU
-        c.build_pyramid(0, n, from_bgr=img.ndim != 3)
+        c.build_pyramid(0, n, from_bgr=from_bgr)
         c.detect(0, n)
         c.keypoint_depths_from_image(0, n)                     # Feature::_depth / _mappoint of the fresh keypoints
-        pairs = [(f, f - 1) for f in frames if f - 1 in slot_of and f >= c0]
+        pairs = [(f, f - 1) for c0, c1 in ranges for f in range(c0, c1) if f - 1 in slot_of]
         if pairs:
             q = [slot_of[a] for a, _ in pairs]
             t = [slot_of[b] for _, b in pairs]
@@ -482,22 +548,28 @@ class OfflineVO:
             c.track_adopt_pose()
             c.track_direct()
             c.track_pose_only()
-            c.track_get_summary(out=self._pin[li]["sum"].array, wait=False)
-            self.ba.kf_store_put_trel(c, 0, len(pairs), pairs[0][0])
-        c.get_keypoint_counts(0, n, out=self._pin[li]["cnt"].array, wait=False)
-        kf = [f for f in range(c0, c1) if f % self.kf_stride == 0]
+            c.track_get_summary(out=self._pin[ci]["sum"].array, wait=False)
+            p0 = 0
+            while p0 < len(pairs):                             # runs of consecutive frames (one per range)
+                p1 = p0 + 1
+                while p1 < len(pairs) and pairs[p1][0] == pairs[p1 - 1][0] + 1:
+                    p1 += 1
+                self.ba.kf_store_put_trel(c, p0, p1 - p0, pairs[p0][0])
+                p0 = p1
+        c.get_keypoint_counts(0, n, out=self._pin[ci]["cnt"].array, wait=False)
+        kf = [f for c0, c1 in ranges for f in range(c0, c1) if f % self.kf_stride == 0]
         if kf:
             self.ba.kf_store_put(c, [slot_of[f] for f in kf], [f // self.kf_stride for f in kf])
-        return dict(c0=c0, c1=c1, frames=frames, slot_of=slot_of, pairs=pairs, dimg=dimg if self.keep else None)
+        return dict(ranges=ranges, frames=frames, slot_of=slot_of, pairs=pairs, pin=self._pin[ci], dimg=np.concatenate(keep_dimg) if self.keep else None)
 
     def _collect(self, li, info, rec):
         """wait for the lane, then read its chunk's results out of the page-locked buffers"""
         c = self.lanes[li]
         c.synchronize()
-        S = self._pin[li]["sum"].array[:len(info["pairs"])].copy()
-        cnt = self._pin[li]["cnt"].array[:len(info["frames"])].copy()
+        S = info["pin"]["sum"].array[:len(info["pairs"])].copy()
+        cnt = info["pin"]["cnt"].array[:len(info["frames"])].copy()
         slot_of = info["slot_of"]
-        for f in range(info["c0"], info["c1"]):
+        for f in (f for c0, c1 in info["ranges"] for f in range(c0, c1)):
             k = slot_of[f]
             r = dict(n_kp=int(cnt[k]))
             if self.keep:
