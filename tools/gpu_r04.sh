@@ -315,6 +315,13 @@ PY
     bash tools/offline_timeline.sh r04w --mode offline --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
     python tools/offline_timeline_summary.py gpurun_out/r04w_timeline.tsv | grep -v "rocclr\|k_pyr\|k_scharr\|k_track\|k_match\|k_compact\|k_detect\|k_trel" | tail -48
     ;;
+x)  # the per-point phases of the resident LM as one-wavefront tasks per chunk of 64 points, spread over all members of a team
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_offline.py tests/test_gpu_surface.py -m gpu -q -x -k "ba_ or resident or offline or window or surface" > $OUT/pytest.log 2>&1; tail -6 $OUT/pytest.log
+    python tools/lm_insitu.py --frames 256 2>&1 | grep -v amdgpu | tail -8
+    YGZ_LM_DEBUG=1 python tools/lm_insitu.py --frames 128 2>&1 | grep "lm-debug" | tail -2
+    python tools/lm_probe.py 2>&1 | tail -4
+    for F in 128 1024; do timeout 300 python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f$F', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['phases_ms'].items()})"; done
+    ;;
 z)  # round-4 closing batch: full GPU suite, the three rocprofv3 passes of the default command, the SQ pass, the step timeline, the default
     # bench line with its extra blocks, the offline lines per shard size, the kernel statistics and the device timeline of the offline mode
     timeout 900 python -m pytest tests -q -m gpu --no-header -rf 2>&1 | tail -4

@@ -27,7 +27,8 @@
 #define LM_WAVES   (LM_THREADS / 64)
 #define LM_MAXKF   14
 #define LM_MAXN    (6 * LM_MAXKF)
-#define LM_RB      4                                    // rows (edges of a point) whose blocks a lane requests together
+#define LM_RB      4                                    // rows (edges of a point) whose 6 x 3 blocks a lane requests together (8: one round trip for a window of 8 keyframes, but 512 registers and spills)
+#define LM_RC      8                                    // rows whose observation records (5 values) a lane requests together: one round trip for a window of 8 keyframes
 #define LM_LDSK    16                                   // windows of up to 16 poses keep their per-pose tables in LDS
 
 #define lm_wave_sum ygz_wave_sum_d
@@ -87,10 +88,10 @@ __device__ __forceinline__ double lm_point_chi2_pf(const BaDev &B, int il)
     const int lane = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
     const double pt[3] = { B.points[3 * (size_t)il], B.points[3 * (size_t)il + 1], B.points[3 * (size_t)il + 2] };
     double sum = 0.0;
-    for (int c0 = 0; c0 < rows; c0 += LM_RB) {
-        int ipg[LM_RB], eng[LM_RB]; double oxg[LM_RB], oyg[LM_RB], hubg[LM_RB];
+    for (int c0 = 0; c0 < rows; c0 += LM_RC) {
+        int ipg[LM_RC], eng[LM_RC]; double oxg[LM_RC], oyg[LM_RC], hubg[LM_RC];
 #pragma unroll
-        for (int u = 0; u < LM_RB; ++u) {
+        for (int u = 0; u < LM_RC; ++u) {
             const bool in_ = c0 + u < rows;
             const size_t row = (size_t)(row0 + c0 + u);
             ipg[u] = in_ ? B.pose_c[row * 64 + lane] : -1; eng[u] = in_ ? B.enable_c[row * 64 + lane] : 0;
@@ -98,7 +99,7 @@ __device__ __forceinline__ double lm_point_chi2_pf(const BaDev &B, int il)
             hubg[u] = in_ ? B.huber_c[row * 64 + lane] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < LM_RB; ++u) {
+        for (int u = 0; u < LM_RC; ++u) {
             if (ipg[u] < 0 || !eng[u]) continue;
             double p[3], r[2], rho0, rho1;
             ba_project(B, B.posed + BA_POSED * (size_t)ipg[u], pt, oxg[u], oyg[u], p, r);
@@ -253,14 +254,14 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 #define LM_NPAIR  (LM_MAXKF * (LM_MAXKF + 1) / 2)
 #define LM_HDR    1024                         // per-window header of the scratch (zeroed by the launch): barrier counter + abort flag (bar[0..3]), one
                                                // behind-camera count per member (bar[4..4+LM_MAXG)), one arrival counter per pose pair (bar[64..64+LM_NPAIR))
-#define LM_PARTW  (8 + 27 * LM_MAXKF)          // per part: chi2, max |diag|, singular flag, scale, trial chi2, -, -, -, pose sums [Kf][27]
+#define LM_PARTW  (8 + 27 * LM_MAXKF)          // per chunk of 64 points: chi2, max |diag|, singular flag, scale, trial chi2, -, -, -, pose sums [Kf][27]
 #define LM_SPW    42                           // per (pair, part): 36 block entries + 6 of the right-hand side
 static_assert(16 + 4 * LM_MAXG <= 256 && 256 + 4 * LM_NPAIR <= LM_HDR, "scratch header");
 
 struct LmTeamArgs {
     const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
     unsigned char *scratch; size_t stride;     // per window: header (LM_HDR) | xpub | part | Sp | Sfin | private pose state of the G members
-    int Kmax, prio;
+    int Kmax, prio, Qcap;
     long long *dbg;                            // YGZ_LM_DEBUG: [16] wall-clock ticks (10 ns) per phase of member 0 of the first window
 };
 #define LM_TICK(k) do { if (A.dbg && blockIdx.x == 0 && tid == 0) { const long long tn_ = wall_clock64(); s_t[k] += tn_ - t_prev; t_prev = tn_; } } while (0)
@@ -269,6 +270,46 @@ __device__ __forceinline__ double tl_ld(const double *p)
 { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 __device__ __forceinline__ void tl_st(double *p, double v)
 { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// sum (or maximum) over the n chunk records of a window, in chunk order, sixteen loads in flight (a plain loop was a chain of n dependent L2
+// round trips: 12 us per iteration for 31 chunks).  The padding adds + 0.0, which leaves the sum as it is.
+__device__ __forceinline__ double lm_sum_records(const double *p, int n)
+{
+    double t = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    return t;
+}
+// two sums at once (both sets of loads in flight together)
+__device__ __forceinline__ void lm_sum_records2(const double *p, const double *q, int n, double *sp, double *sq)
+{
+    double t = 0.0, w = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 16) {
+        double v[16], x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0; x[u] = c0 + u < n ? q[(size_t)(c0 + u) * LM_PARTW] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { t += v[u]; w += x[u]; }
+    }
+    *sp = t; *sq = w;
+}
+__device__ __forceinline__ double lm_max_records(const double *p, int n)
+{
+    double t = 0.0;
+    for (int c0 = 0; c0 < n; c0 += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t = fmax(t, v[u]);
+    }
+    return t;
+}
 
 // false: a member did not arrive in time (or another member gave up): the caller returns, the host reports YGZ_E_HIP
 __device__ __forceinline__ bool lm_team_barrier(unsigned *bar, unsigned &epoch, int G, int *s_ok)
@@ -465,11 +506,9 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     __shared__ double bs[LM_MAXN], xp[LM_MAXN], dg[LM_MAXN], rdg[LM_MAXN];   // dg / rdg: D of S = L D L^T and its reciprocals
     __shared__ double Tb[LM_MAXN][6];              // the panel of the current block column times D (lm_solve_blocked)
     __shared__ double sH[LM_MAXKF][28];            // Hpp upper triangle (21) + bp (6) of the free poses at the linearisation point
-    __shared__ double redK[LM_MAXKF][LM_WAVES][28];  // per free pose and wavefront: the 27 sums (Hpp upper triangle, bp)
-    __shared__ double s_posed[LM_LDSK][BA_POSED];
+    __shared__ double s_posed[LM_LDSK][BA_POSED], s_posed_bk[LM_LDSK][BA_POSED];   // the prepared poses (q, t, R) ARE the pose state of the loop; backup for pop()
     __shared__ int32_t s_free_idx[LM_LDSK], s_free_pose[LM_LDSK];
     __shared__ uint8_t s_fixed[LM_LDSK];
-    __shared__ double red[LM_WAVES];
     __shared__ int s_fail, s_ok;
     __shared__ long long s_t[16];
     const int G = A.G;
@@ -493,28 +532,35 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     long long t_prev = 0;
     if (A.dbg && blockIdx.x == 0 && tid == 0) { for (int i = 0; i < 16; ++i) s_t[i] = 0; t_prev = wall_clock64(); }
     const int K = B.K, P = B.P, Kf = B.Kf, n = 6 * Kf, Q = B.Q, npairs = Kf * (Kf + 1) / 2;
+    const int wid = wv * G + g, nwv = G * LM_WAVES;            // this wavefront's place among the team's (member-minor: consecutive tasks on different CUs)
     unsigned char *scr = A.scratch + (size_t)w * A.stride;
     unsigned *bar = reinterpret_cast<unsigned *>(scr);
     double *xpub = reinterpret_cast<double *>(scr + LM_HDR);                   // [LM_MAXN + 2]
-    double *part = xpub + LM_MAXN + 2;                                          // [LM_V][LM_PARTW]
-    double *Sp = part + (size_t)LM_V * LM_PARTW;                                // [npairs][LM_V][LM_SPW]
+    double *crec = xpub + LM_MAXN + 2;                                          // [Qcap][LM_PARTW]: one record per chunk of 64 points
+    double *Sp = crec + (size_t)A.Qcap * LM_PARTW;                              // [npairs][LM_V][LM_SPW]
     double *Sfin = Sp + (size_t)LM_NPAIR * LM_V * LM_SPW;                       // [npairs][LM_SPW]: the assembled blocks of the reduced system
-    double *priv = Sfin + (size_t)LM_NPAIR * LM_SPW + (size_t)g * A.Kmax * (6 + 6 + BA_POSED);
+    double *priv = Sfin + (size_t)LM_NPAIR * LM_SPW + (size_t)g * A.Kmax * (6 + 2 * BA_POSED);
     unsigned *pair_cnt = bar + 64;                                              // arrivals per pose pair (monotonic: LM_V per trial)
-    double *my_poses = priv, *my_bk = priv + 6 * (size_t)A.Kmax, *my_posed = my_bk + 6 * (size_t)A.Kmax;
+    double *my_poses = priv, *my_posed = priv + 6 * (size_t)A.Kmax, *posed_bk = my_posed + (size_t)BA_POSED * A.Kmax;
     double *const out_poses = B.poses_w;
     int32_t *const n_behind = B.n_behind;
     B.n_behind = reinterpret_cast<int32_t *>(bar + 4 + g);                     // the member's own count of edges behind the camera
     // the member's private pose state replaces the window's arrays in everything below
     for (int i = tid; i < 6 * K; i += LM_THREADS) my_poses[i] = B.poses[i];
-    B.poses = my_poses; B.poses_w = my_poses; B.poses_bk = my_bk; B.posed = my_posed;
+    B.poses = my_poses; B.poses_w = my_poses; B.poses_bk = my_poses; B.posed = my_posed;
     // the per-pose tables every edge looks up through its pose index (prepared pose, free index, constant flag) live in LDS: in the
     // per-point edge loops they were a dependent global load per edge on top of the edge's own data
     if (K <= LM_LDSK) {
         for (int i = tid; i < K; i += LM_THREADS) { s_free_idx[i] = B.free_idx[i]; s_free_pose[i] = B.free_pose[i]; s_fixed[i] = B.fixed[i]; }
         B.posed = &s_posed[0][0]; B.free_idx = s_free_idx; B.free_pose = s_free_pose; B.fixed = s_fixed;
+        posed_bk = &s_posed_bk[0][0];
     }
     unsigned epoch = 0;
+    __syncthreads();
+    // The pose state of the loop is the PREPARED pose T = (q, t, R): oplus is T <- exp(update) T (VertexSE3Sophus::oplusImpl, G2oTypes.h:38-45,
+    // stores log(exp(update) exp(estimate)) and every later use takes exp of it again -- the same T up to the rounding of log and exp; two
+    // SE3::exp and one SE3::log per trial and pose less on a path every member waits for).  The estimates are written once, at the end.
+    if (tid < K) ba_pose_prep_one(B, tid);
     __syncthreads();
 
     double lambda = 0.0, ni = 2.0, currentChi = 0.0, chi_initial = 0.0;
@@ -523,53 +569,49 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 
     for (int it = 0; it < A.max_iterations; ++it) {
         // ---- computeActiveErrors + buildSystem: per part chi2, max |diag Hll|, the 27 sums of every free pose
-        if (tid < K) ba_pose_prep_one(B, tid);
         if (tid == 0) __hip_atomic_store(B.n_behind, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        for (int v = g; v < LM_V; v += G) {
-            LM_PART_RANGE(v)
-            double chi = 0.0, mx = 0.0;
-            for (int il = p0_ + tid; il < p1_; il += LM_THREADS) {
-                chi += ba_point_edges(B, il);
-                if (it == 0) for (int d = 0; d < 3; ++d) mx = fmax(mx, fabs(BA_PC(B.Hll_c, il, 9, 4 * d)));
-            }
-            chi = lm_block_sum(chi, red);
-            if (it == 0) mx = lm_block_max(mx, red);
-            if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW, chi); if (it == 0) tl_st(part + (size_t)v * LM_PARTW + 1, mx);
-                            tl_st(part + (size_t)v * LM_PARTW + 5, (double)__hip_atomic_load(B.n_behind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                            __hip_atomic_store(B.n_behind, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            __syncthreads();                                               // redK is free (the previous part's sums have been read)
-            for (int a = 0; a < Kf; ++a) {
+        // tasks of ONE WAVEFRONT each: (chunk c of 64 points, -1) = the edges of its points (residuals, Hll / bl, Hpl), (c, a) = the 27 sums of
+        // free pose a over the chunk's points.  Task t goes to wavefront wid = t mod (4 G), member-minor: the Q heavy tasks land on Q
+        // different CUs (one lane per point, a chain of dependent L2 round trips per edge: four chunks on one CU shared its memory pipeline),
+        // the pose tasks fill the other wavefronts -- the helper members idled through this phase before.  Whoever runs a task, its sums are
+        // formed inside one wavefront in a fixed order and combined in chunk order: the result does not depend on G.
+        for (int t = wid; t < Q * (Kf + 1); t += nwv) {
+            const bool heavy = t < Q;
+            const int c = heavy ? t : (t - Q) / Kf, a = heavy ? -1 : (t - Q) - c * Kf;
+            const int il = 64 * c + lane;
+            double *cr = crec + (size_t)c * LM_PARTW;
+            if (heavy) {
+                double chi = 0.0, mx = 0.0;
+                if (il < P) {
+                    chi = ba_point_edges(B, il);
+                    if (it == 0) for (int d = 0; d < 3; ++d) mx = fmax(mx, fabs(BA_PC(B.Hll_c, il, 9, 4 * d)));
+                }
+                chi = lm_wave_sum(chi);
+                if (it == 0) {
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+                }
+                if (lane == 0) { tl_st(cr, chi); if (it == 0) tl_st(cr + 1, mx); }
+            } else {
                 double acc[27];
 #pragma unroll
                 for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-                for (int il = p0_ + tid; il < p1_; il += LM_THREADS) ba_pose_contrib(B, il, a, acc);
+                if (il < P) ba_pose_contrib(B, il, a, acc);
                 int idx;                                                   // all 27 sums of the wavefront in one butterfly (ba_dev.h), fixed order
                 const double tot = ba_reduce32(acc, lane, &idx);
-                if (lane < 32 && idx < 27) redK[a][wv][idx] = tot;
-            }
-            __syncthreads();
-            for (int i = tid; i < 27 * Kf; i += LM_THREADS) {
-                const int a = i / 27, k = i - 27 * a;
-                double t = 0.0;
-                for (int ww = 0; ww < LM_WAVES; ++ww) t += redK[a][ww][k];
-                tl_st(part + (size_t)v * LM_PARTW + 8 + 27 * a + k, t);
+                if (lane < 32 && idx < 27) tl_st(cr + 8 + 27 * a + idx, tot);
             }
         }
         LM_TICK(0);
         if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
         LM_TICK(1);
         {   // every member adds the parts in part order: identical sH, chi2 (and lambda at the first iteration)
-            for (int i = tid; i < 27 * Kf; i += LM_THREADS) {
-                double t = 0.0;
-                for (int v = 0; v < LM_V; ++v) t += part[(size_t)v * LM_PARTW + 8 + i];
-                sH[i / 27][i % 27] = t;
-            }
-            double chi = 0.0, mx = 0.0;
-            for (int v = 0; v < LM_V; ++v) { chi += part[(size_t)v * LM_PARTW]; if (it == 0) mx = fmax(mx, part[(size_t)v * LM_PARTW + 1]); }
-            currentChi = chi;
+            for (int i = tid; i < 27 * Kf; i += LM_THREADS) sH[i / 27][i % 27] = lm_sum_records(crec + 8 + i, Q);
+            double mx = it == 0 ? lm_max_records(crec + 1, Q) : 0.0;
+            currentChi = lm_sum_records(crec, Q);
             __syncthreads();
-            if (g == 0 && tid == LM_THREADS - 1) { double nb = 0.0; for (int v = 0; v < LM_V; ++v) nb += part[(size_t)v * LM_PARTW + 5]; *n_behind = (int)nb; }
+            if (g == 0 && tid == LM_THREADS - 1) { int nb = 0; for (int m = 0; m < G; ++m) nb += (int)__hip_atomic_load(bar + 4 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *n_behind = nb; }
             if (g == 0 && tid < 27 * Kf) {                                     // the window's Hpp / bp as the ABI exposes them
                 const int a = tid / 27, i = tid % 27, k = B.free_pose[a];
                 if (i < 21) { int u = 0, rem = i; while (rem >= 6 - u) { rem -= 6 - u; ++u; } const int vv = u + rem;
@@ -586,16 +628,16 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
         LM_TICK(2);
         do {
             // ---- push(), 1. Dinv, Y = Hpl Dinv for the member's parts
-            for (int i = tid; i < 6 * K; i += LM_THREADS) my_bk[i] = my_poses[i];
+            for (int i = tid; i < BA_POSED * K; i += LM_THREADS) posed_bk[i] = B.posed[i];
             if (tid == 0) s_fail = 0;
             __syncthreads();
             int bad = 0;
-            for (int v = g; v < LM_V; v += G) {
-                LM_PART_RANGE(v)
-                for (int il = p0_ + tid; il < p1_; il += LM_THREADS) {
+            for (int c = wid; c < Q; c += nwv) {                       // one wavefront per chunk of 64 points (see the linearisation)
+                const int il = 64 * c + lane;
+                if (il < P) do {
                     for (int d = 0; d < 3; ++d) B.points_bk[3 * (size_t)il + d] = B.points_w[3 * (size_t)il + d];
                     double *Di = B.Dinv + 9 * (size_t)il;
-                    if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; continue; }
+                    if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; break; }
                     // the blocks of LM_RB rows (edges of the point) are requested together, the first group before the inverse is formed: the
                     // loop was a chain of one L2 round trip per edge (14 us per trial for <= 8 edges), its arithmetic is 54 multiply-adds
                     const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
@@ -625,16 +667,16 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         }
                     }
 #undef LM_LOADG_
-                }
+                } while (0);
+                const bool bad_w = __ballot(bad != 0) != 0ull;             // a singular point block in this chunk: member 0 rejects the trial
+                if (lane == 0) tl_st(crec + (size_t)c * LM_PARTW + 2, bad_w ? 1.0 : 0.0);
+                bad = 0;
             }
-            if (bad) s_fail = 1;
-            __syncthreads();
-            if (tid == 0) for (int v = g; v < LM_V; v += G) tl_st(part + (size_t)v * LM_PARTW + 2, s_fail ? 1.0 : 0.0);
             LM_TICK(3);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
             LM_TICK(4);
             // ---- 2. one wavefront per (pose pair, part): that part's share of sum_l Y_a(l) W_b(l)^T and sum_l Y_a(l) b_l
-            for (int task = g * LM_WAVES + wv; task < npairs * LM_V; task += G * LM_WAVES) {
+            for (int task = wid; task < npairs * LM_V; task += nwv) {          // member-minor like the chunk tasks: 224 tasks leave 7 on every CU, not 8 on three quarters of them
                 const int pr = task / LM_V, v = task - pr * LM_V;
                 LM_PART_RANGE(v)
                 int a = 0, rem = pr;
@@ -718,7 +760,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         else S[(6 * a + y) * n + 6 * b + x] = val[u];
                     }
                 }
-                if (tid == 0) { double f = 0.0; for (int v = 0; v < LM_V; ++v) f += part[(size_t)v * LM_PARTW + 2]; s_fail = f != 0.0; }
+                if (tid == 0) s_fail = lm_sum_records(crec + 2, Q) != 0.0;
                 __syncthreads();
                 LM_TICK(7);
                 lm_factor_blocked(S, dg, rdg, Tb, n, &s_fail);
@@ -737,21 +779,24 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             __syncthreads();
             // ---- 4. x_l, update(x), computeScale; then computeActiveErrors at the trial state -- per part
             if (ok2 && tid < Kf) {
-                const int k = B.free_pose[tid];
-                double pose[6], upd[6];
-                for (int d = 0; d < 6; ++d) { pose[d] = my_poses[6 * (size_t)k + d]; upd[d] = xp[6 * tid + d]; }
-                lm_oplus_pose(pose, upd);
-                for (int d = 0; d < 6; ++d) my_poses[6 * (size_t)k + d] = pose[d];
+                double *o = B.posed + BA_POSED * (size_t)B.free_pose[tid];
+                const double v[6] = { xp[6 * tid + 3], xp[6 * tid + 4], xp[6 * tid + 5], xp[6 * tid], xp[6 * tid + 1], xp[6 * tid + 2] };   // [omega; t] -> [t; omega]
+                Se3 U, T0, T1;
+                se3_exp_d(v, &U);
+                for (int d = 0; d < 4; ++d) T0.q[d] = o[d];
+                for (int d = 0; d < 3; ++d) T0.t[d] = o[4 + d];
+                se3_mul_d(&U, &T0, &T1);
+                for (int d = 0; d < 4; ++d) o[d] = T1.q[d];
+                for (int d = 0; d < 3; ++d) o[4 + d] = T1.t[d];
+                quat_to_R_d(T1.q, o + 7);
             }
             __syncthreads();
-            if (ok2 && tid < K) ba_pose_prep_one(B, tid);
-            __syncthreads();
             LM_TICK(14);
-            for (int v = g; v < LM_V; v += G) {
-                LM_PART_RANGE(v)
+            for (int c = wid; c < Q; c += nwv) {                       // one wavefront per chunk of 64 points
+                const int il = 64 * c + lane;
                 double scale = 0.0, chi = 0.0;
                 if (ok2) {
-                    for (int il = p0_ + tid; il < p1_; il += LM_THREADS) {
+                    if (il < P) {
                         if (B.point_fixed[il]) { B.xl[3 * (size_t)il] = B.xl[3 * (size_t)il + 1] = B.xl[3 * (size_t)il + 2] = 0.0; }
                         else {
                             double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
@@ -785,18 +830,18 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         chi += lm_point_chi2_pf(B, il);                          // the lane's own point at its trial position
                     }
                 }
-                LM_TICK(15);
-                scale = lm_block_sum(scale, red);
-                chi = lm_block_sum(chi, red);
-                if (tid == 0) { tl_st(part + (size_t)v * LM_PARTW + 3, scale); tl_st(part + (size_t)v * LM_PARTW + 4, chi); }
+                scale = lm_wave_sum(scale);
+                chi = lm_wave_sum(chi);
+                if (lane == 0) { tl_st(crec + (size_t)c * LM_PARTW + 3, scale); tl_st(crec + (size_t)c * LM_PARTW + 4, chi); }
             }
+            LM_TICK(15);
             LM_TICK(11);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
             LM_TICK(12);
             double scale = 0.0, tempChi = DBL_MAX;
             if (ok2) {
                 tempChi = 0.0;
-                for (int v = 0; v < LM_V; ++v) { scale += part[(size_t)v * LM_PARTW + 3]; tempChi += part[(size_t)v * LM_PARTW + 4]; }
+                lm_sum_records2(crec + 3, crec + 4, Q, &scale, &tempChi);
                 for (int a = 0; a < Kf; ++a) for (int d = 0; d < 6; ++d) scale += xp[6 * a + d] * (lambda * xp[6 * a + d] + sH[a][21 + d]);
             }
             rho = (currentChi - tempChi) / (scale + 1e-3);
@@ -809,11 +854,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             } else {                                                             // pop(): the member's own points and its pose copy
                 lambda *= ni; ni *= 2;
                 __syncthreads();
-                for (int i = tid; i < 6 * K; i += LM_THREADS) my_poses[i] = my_bk[i];
-                for (int v = g; v < LM_V; v += G) {
-                    LM_PART_RANGE(v)
-                    for (int il = p0_ + tid; il < p1_; il += LM_THREADS)
-                        for (int d = 0; d < 3; ++d) B.points_w[3 * (size_t)il + d] = B.points_bk[3 * (size_t)il + d];
+                for (int i = tid; i < BA_POSED * K; i += LM_THREADS) B.posed[i] = posed_bk[i];
+                for (int c = wid; c < Q; c += nwv) {
+                    const int il = 64 * c + lane;
+                    if (il < P) for (int d = 0; d < 3; ++d) B.points_w[3 * (size_t)il + d] = B.points_bk[3 * (size_t)il + d];
                 }
                 __syncthreads();
                 if (!isfinite(lambda)) break;
@@ -827,7 +871,17 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     if (A.dbg && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 16; ++i) A.dbg[i] = s_t[i];
     if (g == 0) {
         __syncthreads();
-        for (int i = tid; i < 6 * K; i += LM_THREADS) out_poses[i] = my_poses[i];
+        for (int i = tid; i < 6 * K; i += LM_THREADS) out_poses[i] = my_poses[i];          // the constant poses as they came
+        __syncthreads();
+        if (tid < Kf) {                                                                       // the estimates of the free poses: log T, [omega; t]
+            const int k = B.free_pose[tid];
+            const double *o = B.posed + BA_POSED * (size_t)k;
+            Se3 T; double r[6];
+            for (int d = 0; d < 4; ++d) T.q[d] = o[d];
+            for (int d = 0; d < 3; ++d) T.t[d] = o[4 + d];
+            se3_log_d(&T, r);
+            for (int d = 0; d < 3; ++d) { out_poses[6 * (size_t)k + d] = r[3 + d]; out_poses[6 * (size_t)k + 3 + d] = r[d]; }
+        }
         if (tid == 0) {
             ygz_ba_stats st;
             st.iterations = iterations; st.lm_trials = trials; st.chi2_initial = chi_initial; st.chi2_final = currentChi; st.lambda_final = lambda;
@@ -927,15 +981,17 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     // the longest phase of a trial with four wavefronts per member (28 pairs x 8 parts over 32 wavefronts: 7 rounds; over 64: 3.5)
     if (!single) while (G < LM_MAXG && n_windows * (2 * G) <= wg_budget) G *= 2;           // windows x G <= budget
     for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
-    size_t stride = LM_HDR + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)LM_V * LM_PARTW + (size_t)LM_NPAIR * LM_V * LM_SPW + (size_t)LM_NPAIR * LM_SPW
-                                           + (size_t)G * Kmax * (6 + 6 + BA_POSED));
+    int Qcap = 1;
+    for (int i = window_begin; i < window_begin + n_windows; ++i) Qcap = std::max(Qcap, (ctx->ba[i]->P + 63) / 64);      // (host fields: the capacities)
+    size_t stride = LM_HDR + sizeof(double) * ((size_t)LM_MAXN + 2 + (size_t)Qcap * LM_PARTW + (size_t)LM_NPAIR * LM_V * LM_SPW + (size_t)LM_NPAIR * LM_SPW
+                                           + (size_t)G * Kmax * (6 + 2 * BA_POSED));
     stride = (stride + 255) & ~(size_t)255;
     const size_t stats_bytes = (((size_t)n_windows * sizeof(ygz_ba_stats)) + 255) & ~(size_t)255;
     void *d_scr = nullptr;
     if ((rc = ygz_scratch(ctx, SCR_BA_0, stats_bytes + (size_t)n_windows * stride, &d_scr)) != YGZ_OK) return rc;
     LmTeamArgs A;
     A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
-    A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax;
+    A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax; A.Qcap = Qcap;
     A.dbg = nullptr; A.prio = (ctx->wave_prio_mask >> 3) & 1;
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
