@@ -322,6 +322,21 @@ x)  # the per-point phases of the resident LM as one-wavefront tasks per chunk o
     python tools/lm_probe.py 2>&1 | tail -4
     for F in 128 1024; do timeout 300 python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f$F', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['phases_ms'].items()})"; done
     ;;
+y)  # number of deferred gaps once more with the shorter LM (3.2 ms), all shard sizes on the defaults
+    offline() { tag=$1; shift; timeout 300 "$@" > $OUT/$tag.json 2> $OUT/$tag.err; python - $OUT/$tag.json $tag <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-22s %9.1f frames/s  ms %.2f  %s" % (sys.argv[2], d["value"], d["ms_per_step"], {k: round(v,2) for k,v in d["phases_ms"].items()}))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+    }
+    OFF="python bench.py --mode offline --frames 1024 --steps 5 --warmup 2 --no-cpu-baseline"
+    for D in 13 6 9 0 13 9; do YGZ_OFF_DEFER=$D offline f1024_defer$D $OFF; done
+    for F in 512 256 128; do offline f${F} python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline; done
+    YGZ_OFF_DEFER=4 offline f512_defer4 python bench.py --mode offline --frames 512 --steps 5 --warmup 2 --no-cpu-baseline
+    ;;
 z)  # round-4 closing batch: full GPU suite, the three rocprofv3 passes of the default command, the SQ pass, the step timeline, the default
     # bench line with its extra blocks, the offline lines per shard size, the kernel statistics and the device timeline of the offline mode
     timeout 900 python -m pytest tests -q -m gpu --no-header -rf 2>&1 | tail -4

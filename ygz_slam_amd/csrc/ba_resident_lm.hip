@@ -161,15 +161,38 @@ __device__ double lm_errors(const BaDev &B, double *red)
 // bound by the latency of its two dependent loads (edge slot of the point in pose a / b, then the 36 block entries), so every lane
 // keeps TWO points in flight and the slots of the next two are requested before the blocks of the current ones are used.
 // sc_p / sc_l (SC: ceres' Jacobi scaling): W and b_l are taken column-scaled, (Hpl * s_pose) * s_point as the host-loop form does.
-template <bool SC>
+// YM: where Y_a = Hpl_a Dinv comes from.  0: read (Y_c, written by the caller's Dinv phase: k_ba_ceres).  1: formed here from the point's stored
+// inverse.  2: formed here from Hll + lambda I itself (lm_inv3, the same expressions and bits as a separate phase would store): the team
+// kernel then has NO Dinv phase -- 2 MB of Y per trial and window neither written nor read back, one team barrier less per trial.
+template <bool SC, int YM = 0>
 __device__ __forceinline__ void lm_sweep_point(const BaDev &B, int l, int ca, int cb, bool diag, const double *spb, const double *sc_l,
-                                               double *acc /*[36]*/, double *accb /*[6]*/)
+                                               double *acc /*[36]*/, double *accb /*[6]*/, double lambda = 0.0, int *bad = nullptr)
 {
     const bool v = ca >= 0 && cb >= 0;
     const int row0 = v ? B.slot_off[l >> 6] : 0, ln = l & 63;
     double Ya[18], Wb[18];
+    if (YM != 0) {
+        double Wa[18], Dv[9];
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { Ya[i] = v ? BA_EC(B.Y_c, row0 + ca, 18, i, ln) : 0.0; Wb[i] = v ? BA_EC(B.Hpl_c, row0 + cb, 18, i, ln) : 0.0; }
+        for (int i = 0; i < 18; ++i) { Wa[i] = v ? BA_EC(B.Hpl_c, row0 + ca, 18, i, ln) : 0.0; Wb[i] = v ? BA_EC(B.Hpl_c, row0 + cb, 18, i, ln) : 0.0; }
+        if (YM == 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Dv[i] = v ? B.Dinv[9 * (size_t)l + i] : 0.0;
+        } else {
+            double D[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) D[i] = v ? BA_PC(B.Hll_c, l, 9, i) : ((i % 4 == 0) ? 1.0 : 0.0);
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            if (!lm_inv3(D, Dv)) { if (v && !B.point_fixed[l]) *bad = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) Ya[3 * r + cc] = Wa[3 * r] * Dv[cc] + Wa[3 * r + 1] * Dv[3 + cc] + Wa[3 * r + 2] * Dv[6 + cc];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) { Ya[i] = v ? BA_EC(B.Y_c, row0 + ca, 18, i, ln) : 0.0; Wb[i] = v ? BA_EC(B.Hpl_c, row0 + cb, 18, i, ln) : 0.0; }
+    }
     double s0 = 1.0, s1 = 1.0, s2 = 1.0;
     if (SC && v) { s0 = sc_l[3 * (size_t)l]; s1 = sc_l[3 * (size_t)l + 1]; s2 = sc_l[3 * (size_t)l + 2]; }
     if (SC) {
@@ -271,17 +294,18 @@ __device__ __forceinline__ double tl_ld(const double *p)
 __device__ __forceinline__ void tl_st(double *p, double v)
 { __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// sum (or maximum) over the n chunk records of a window, in chunk order, sixteen loads in flight (a plain loop was a chain of n dependent L2
+#define LM_NB 32
+// sum (or maximum) over the n chunk records of a window, in chunk order, LM_NB loads in flight (one round trip for a window of up to 2048 points) (a plain loop was a chain of n dependent L2
 // round trips: 12 us per iteration for 31 chunks).  The padding adds + 0.0, which leaves the sum as it is.
 __device__ __forceinline__ double lm_sum_records(const double *p, int n)
 {
     double t = 0.0;
-    for (int c0 = 0; c0 < n; c0 += 16) {
-        double v[16];
+    for (int c0 = 0; c0 < n; c0 += LM_NB) {
+        double v[LM_NB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0;
+        for (int u = 0; u < LM_NB; ++u) v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t += v[u];
+        for (int u = 0; u < LM_NB; ++u) t += v[u];
     }
     return t;
 }
@@ -289,24 +313,24 @@ __device__ __forceinline__ double lm_sum_records(const double *p, int n)
 __device__ __forceinline__ void lm_sum_records2(const double *p, const double *q, int n, double *sp, double *sq)
 {
     double t = 0.0, w = 0.0;
-    for (int c0 = 0; c0 < n; c0 += 16) {
-        double v[16], x[16];
+    for (int c0 = 0; c0 < n; c0 += LM_NB) {
+        double v[LM_NB], x[LM_NB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0; x[u] = c0 + u < n ? q[(size_t)(c0 + u) * LM_PARTW] : 0.0; }
+        for (int u = 0; u < LM_NB; ++u) { v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0; x[u] = c0 + u < n ? q[(size_t)(c0 + u) * LM_PARTW] : 0.0; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { t += v[u]; w += x[u]; }
+        for (int u = 0; u < LM_NB; ++u) { t += v[u]; w += x[u]; }
     }
     *sp = t; *sq = w;
 }
 __device__ __forceinline__ double lm_max_records(const double *p, int n)
 {
     double t = 0.0;
-    for (int c0 = 0; c0 < n; c0 += 16) {
-        double v[16];
+    for (int c0 = 0; c0 < n; c0 += LM_NB) {
+        double v[LM_NB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0;
+        for (int u = 0; u < LM_NB; ++u) v[u] = c0 + u < n ? p[(size_t)(c0 + u) * LM_PARTW] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) t = fmax(t, v[u]);
+        for (int u = 0; u < LM_NB; ++u) t = fmax(t, v[u]);
     }
     return t;
 }
@@ -627,62 +651,23 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
         double rho = 0.0; int qmax = 0;
         LM_TICK(2);
         do {
-            // ---- push(), 1. Dinv, Y = Hpl Dinv for the member's parts
+            // ---- push() (poses; the points are saved where they are updated).  There is no Dinv phase: the sweep inverts the point blocks itself
             for (int i = tid; i < BA_POSED * K; i += LM_THREADS) posed_bk[i] = B.posed[i];
             if (tid == 0) s_fail = 0;
             __syncthreads();
-            int bad = 0;
-            for (int c = wid; c < Q; c += nwv) {                       // one wavefront per chunk of 64 points (see the linearisation)
-                const int il = 64 * c + lane;
-                if (il < P) do {
-                    for (int d = 0; d < 3; ++d) B.points_bk[3 * (size_t)il + d] = B.points_w[3 * (size_t)il + d];
-                    double *Di = B.Dinv + 9 * (size_t)il;
-                    if (B.point_fixed[il]) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; break; }
-                    // the blocks of LM_RB rows (edges of the point) are requested together, the first group before the inverse is formed: the
-                    // loop was a chain of one L2 round trip per edge (14 us per trial for <= 8 edges), its arithmetic is 54 multiply-adds
-                    const int ln = il & 63, row0 = B.slot_off[il >> 6], rows = B.slot_off[(il >> 6) + 1] - row0;
-                    double Wg[LM_RB][18]; int ipg[LM_RB];
-#define LM_LOADG_(c0_)                                                                                                   \
-                    _Pragma("unroll") for (int u = 0; u < LM_RB; ++u) {                                                   \
-                        const bool in_ = (c0_) + u < rows;                                                               \
-                        ipg[u] = in_ ? B.pose_c[(size_t)(row0 + (c0_) + u) * 64 + ln] : -1;                                \
-                        _Pragma("unroll") for (int i = 0; i < 18; ++i) Wg[u][i] = in_ ? BA_EC(B.Hpl_c, row0 + (c0_) + u, 18, i, ln) : 0.0; }
-                    LM_LOADG_(0)
-                    double D[9], Dv[9];
-                    for (int i = 0; i < 9; ++i) D[i] = BA_PC(B.Hll_c, il, 9, i);
-                    D[0] += lambda; D[4] += lambda; D[8] += lambda;
-                    if (!lm_inv3(D, Dv)) { bad = 1; for (int i = 0; i < 9; ++i) Dv[i] = 0.0; }
-                    for (int i = 0; i < 9; ++i) Di[i] = Dv[i];
-                    for (int c0 = 0; c0 < rows; c0 += LM_RB) {
-                        if (c0 > 0) LM_LOADG_(c0)
-#pragma unroll
-                        for (int u = 0; u < LM_RB; ++u) {
-                            if (c0 + u >= rows || ipg[u] < 0) continue;
-                            const int row = row0 + c0 + u;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                                for (int cc = 0; cc < 3; ++cc)
-                                    BA_EC(B.Y_c, row, 18, 3 * r + cc, ln) = Wg[u][3 * r] * Dv[cc] + Wg[u][3 * r + 1] * Dv[3 + cc] + Wg[u][3 * r + 2] * Dv[6 + cc];
-                        }
-                    }
-#undef LM_LOADG_
-                } while (0);
-                const bool bad_w = __ballot(bad != 0) != 0ull;             // a singular point block in this chunk: member 0 rejects the trial
-                if (lane == 0) tl_st(crec + (size_t)c * LM_PARTW + 2, bad_w ? 1.0 : 0.0);
-                bad = 0;
-            }
             LM_TICK(3);
-            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
-            LM_TICK(4);
             // ---- 2. one wavefront per (pose pair, part): that part's share of sum_l Y_a(l) W_b(l)^T and sum_l Y_a(l) b_l
             for (int task = wid; task < npairs * LM_V; task += nwv) {          // member-minor like the chunk tasks: 224 tasks leave 7 on every CU, not 8 on three quarters of them
-                const int pr = task / LM_V, v = task - pr * LM_V;
+                // tasks in the order diagonal pairs, first off-diagonal, second ...: the pairs near the diagonal share the most points and take
+                // the longest, so the first round of tasks (one per wavefront) holds the long ones and the second the short ones
+                const int ks = task / LM_V, v = task - ks * LM_V;
                 LM_PART_RANGE(v)
-                int a = 0, rem = pr;
-                while (rem >= Kf - a) { rem -= Kf - a; ++a; }
-                const int b = a + rem;
+                int dd = 0, a = ks;
+                while (a >= Kf - dd) { a -= Kf - dd; ++dd; }
+                const int b = a + dd;
+                const int pr = a * Kf - a * (a - 1) / 2 + dd;              // the pair's place in the a-major enumeration (Sp, Sfin, arrival counters)
                 double acc[36], accb[6];
+                int bad = 0;
 #pragma unroll
                 for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 #pragma unroll
@@ -693,10 +678,11 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 for (int base = p0_; base < p1_; base += 128, l += 128) {
                     const int na0 = l + 128 < p1_ ? B.ppc[(size_t)(l + 128) * Kf + a] : -1, nb0 = l + 128 < p1_ ? B.ppc[(size_t)(l + 128) * Kf + b] : -1;
                     const int na1 = l + 192 < p1_ ? B.ppc[(size_t)(l + 192) * Kf + a] : -1, nb1 = l + 192 < p1_ ? B.ppc[(size_t)(l + 192) * Kf + b] : -1;
-                    lm_sweep_point<false>(B, l, ca0, cb0, a == b, nullptr, nullptr, acc, accb);
-                    lm_sweep_point<false>(B, l + 64, ca1, cb1, a == b, nullptr, nullptr, acc, accb);
+                    lm_sweep_point<false, 2>(B, l, ca0, cb0, a == b, nullptr, nullptr, acc, accb, lambda, &bad);
+                    lm_sweep_point<false, 2>(B, l + 64, ca1, cb1, a == b, nullptr, nullptr, acc, accb, lambda, &bad);
                     ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
                 }
+                if (__ballot(bad != 0) != 0ull && lane == 0) tl_st(xpub + LM_MAXN + 1, 1.0);     // a singular point block: member 0 rejects the trial
                 // the 42 sums of the wavefront in one butterfly, one coalesced store; the wavefront that delivers the LAST part of a pair
                 // adds the parts -- in part order, whoever it is -- and leaves the finished block of S (and of the right-hand side) in Sfin
                 double all[LM_SPW];
@@ -760,7 +746,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         else S[(6 * a + y) * n + 6 * b + x] = val[u];
                     }
                 }
-                if (tid == 0) s_fail = lm_sum_records(crec + 2, Q) != 0.0;
+                if (tid == 0) { s_fail = xpub[LM_MAXN + 1] != 0.0; tl_st(xpub + LM_MAXN + 1, 0.0); }   // (the next sweep starts two team barriers later)
                 __syncthreads();
                 LM_TICK(7);
                 lm_factor_blocked(S, dg, rdg, Tb, n, &s_fail);
@@ -797,6 +783,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 double scale = 0.0, chi = 0.0;
                 if (ok2) {
                     if (il < P) {
+                        for (int d = 0; d < 3; ++d) B.points_bk[3 * (size_t)il + d] = B.points_w[3 * (size_t)il + d];
                         if (B.point_fixed[il]) { B.xl[3 * (size_t)il] = B.xl[3 * (size_t)il + 1] = B.xl[3 * (size_t)il + 2] = 0.0; }
                         else {
                             double r3[3] = { BA_PC(B.bl_c, il, 3, 0), BA_PC(B.bl_c, il, 3, 1), BA_PC(B.bl_c, il, 3, 2) };
@@ -818,7 +805,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                                     for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 6; ++r) r3[cc] -= Wg[u][3 * r + cc] * xp[6 * a + r];
                                 }
                             }
-                            const double *Di = B.Dinv + 9 * (size_t)il;
+                            double D[9], Di[9];                                // the inverse the sweep used (the same expressions)
+                            for (int i = 0; i < 9; ++i) D[i] = BA_PC(B.Hll_c, il, 9, i);
+                            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+                            if (!lm_inv3(D, Di)) { for (int i = 0; i < 9; ++i) Di[i] = 0.0; chi += __longlong_as_double(0x7FF8000000000000ll); }   // (a point no pose pair covers: the trial is rejected through its chi2)
                             double x3[3];
                             for (int cc = 0; cc < 3; ++cc) x3[cc] = Di[3 * cc] * r3[0] + Di[3 * cc + 1] * r3[1] + Di[3 * cc + 2] * r3[2];
                             for (int cc = 0; cc < 3; ++cc) {
@@ -855,7 +845,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                 lambda *= ni; ni *= 2;
                 __syncthreads();
                 for (int i = tid; i < BA_POSED * K; i += LM_THREADS) B.posed[i] = posed_bk[i];
-                for (int c = wid; c < Q; c += nwv) {
+                for (int c = wid; ok2 && c < Q; c += nwv) {                         // (a trial whose system could not be solved did not touch the points)
                     const int il = 64 * c + lane;
                     if (il < P) for (int d = 0; d < 3; ++d) B.points_w[3 * (size_t)il + d] = B.points_bk[3 * (size_t)il + d];
                 }
@@ -935,6 +925,7 @@ __global__ __launch_bounds__(256) void k_ba_lm_reset(const BaDev *__restrict__ w
     reinterpret_cast<uint32_t *>(scratch + (size_t)w * stride)[tid] = 0u;
     if (tid < 4) reinterpret_cast<unsigned long long *>(stats + w)[tid] = ~0ull;
     else if (tid < 8) reinterpret_cast<unsigned long long *>(wins[w].lm_out)[tid - 4] = 0xFEFEFEFEFEFEFEFEull;
+    else if (tid == 8) reinterpret_cast<double *>(scratch + (size_t)w * stride + LM_HDR)[LM_MAXN + 1] = 0.0;   // "a point block was singular" (set by the sweep, cleared by member 0)
 }
 
 // the per-window records of a range in one piece: lm_out[0..8) (statistics of the last resident run, outlier record) and the sizes of the
@@ -999,14 +990,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     // barrier counters and abort flags zeroed, iterations = -1 until a team finishes (0xFF in the launch's statistics, 0xFE in the windows' own
     // records; 0xFF there = never run, ba_carve): one small launch (a 2-D memset, a memset and one memset per window took 0.15 ms of the
     // serial tail of an offline run)
-    static const bool reset_memsets = getenv("YGZ_LM_RESET_MEMSETS") != nullptr;       // A/B: the former form
-    if (reset_memsets) {
-        YGZ_HIPCHK(ctx, hipMemset2DAsync(A.scratch, stride, 0, LM_HDR, (size_t)n_windows, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemsetAsync(d_scr, 0xFF, stats_bytes, ctx->stream));
-        for (int i = window_begin; i < window_begin + n_windows; ++i)
-            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->ba[i]->lm_out, 0xFE, sizeof(ygz_ba_stats), ctx->stream));
-    } else
-        YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_reset, dim3(n_windows), dim3(256), A.wins, A.scratch, stride, A.stats);
+    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_reset, dim3(n_windows), dim3(256), A.wins, A.scratch, stride, A.stats);
     YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
