@@ -272,8 +272,10 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 // a team must be resident: the launch keeps windows x G <= half of the CUs (a CU holds one of these; ygz_hip_ba_set_team_budget), every wait is bounded and a
 // timeout aborts the whole team with YGZ_E_HIP.  blockIdx -> (XCD slot, team member): the members of a team share an XCD / L2
 // when the dispatcher places block b on XCD b % 8 (speed only).
+#ifndef LM_V
 #define LM_V      8
-#define LM_MAXG   (4 * LM_V)                   // members of a team (the launch never picks more)
+#endif
+#define LM_MAXG   32                           // members of a team (the launch never picks more)
 #define LM_NPAIR  (LM_MAXKF * (LM_MAXKF + 1) / 2)
 #define LM_HDR    1024                         // per-window header of the scratch (zeroed by the launch): barrier counter + abort flag (bar[0..3]), one
                                                // behind-camera count per member (bar[4..4+LM_MAXG)), one arrival counter per pose pair (bar[64..64+LM_NPAIR))
