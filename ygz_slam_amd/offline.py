@@ -33,7 +33,8 @@ The run is driven from ONE host thread: every call on the tracking path is async
 or three contexts ("lanes") take the chunks in turn so that the H2D copy of one chunk runs under the kernels of another (three: the
 copy of the next chunk is already queued when a copy ends, PCIe never waits for the host), one more context owns the keyframe
 store and the BA windows; the host blocks only when it re-uses a lane and reads that lane's 32-double-per-pair
-summary.
+summary.  The ORDER of the chunks is free (chunk_plan): a chunk is a tuple of frame ranges, each with its halo frame, and on long
+shards the keyframe-free frames behind the last windows are processed at the very end, beside the last resident-LM launch.
 
 This module is host logic over the C ABI (ygz_slam_amd._lib); it never touches oracle/.
 """
