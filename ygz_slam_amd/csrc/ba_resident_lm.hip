@@ -684,7 +684,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                     lm_sweep_point<false, 2>(B, l + 64, ca1, cb1, a == b, nullptr, nullptr, acc, accb, lambda, &bad);
                     ca0 = na0; cb0 = nb0; ca1 = na1; cb1 = nb1;
                 }
-                if (__ballot(bad != 0) != 0ull && lane == 0) tl_st(xpub + LM_MAXN + 1, 1.0);     // a singular point block: member 0 rejects the trial
+                if (__ballot(bad != 0) != 0ull && lane == 0) tl_st(xpub + LM_MAXN + 1, (double)(trials + 1));   // a singular point block: every member rejects this trial (the trial's number: nobody has to clear it)
                 // the 42 sums of the wavefront in one butterfly, one coalesced store; the wavefront that delivers the LAST part of a pair
                 // adds the parts -- in part order, whoever it is -- and leaves the finished block of S (and of the right-hand side) in Sfin
                 double all[LM_SPW];
@@ -727,8 +727,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             LM_TICK(5);
             if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
             LM_TICK(6);
-            // ---- 3. member 0: the blocks of S from Sfin, L D L^T by block columns, substitutions, publish x_p
-            if (g == 0) {
+            // ---- 3. EVERY member: the blocks of S from Sfin, L D L^T by block columns, substitutions -- the same 1176 values and the same
+            //         arithmetic everywhere, so x_p needs no publishing and no team barrier (member 0 alone solved while 31 members waited for
+            //         it and then for the barrier behind it: the wait was the same, the barrier came on top)
+            {
                 // (plain loads: the team barrier has made the finished blocks visible like every other array the members share)
                 for (int i0 = tid; i0 < npairs * LM_SPW; i0 += 6 * LM_THREADS) {   // six loads in flight per thread (n = 42: 1176 values, one round)
                     double val[6];
@@ -748,23 +750,19 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
                         else S[(6 * a + y) * n + 6 * b + x] = val[u];
                     }
                 }
-                if (tid == 0) { s_fail = xpub[LM_MAXN + 1] != 0.0; tl_st(xpub + LM_MAXN + 1, 0.0); }   // (the next sweep starts two team barriers later)
+                if (tid == 0) s_fail = xpub[LM_MAXN + 1] == (double)(trials + 1);      // a sweep task of THIS trial met a singular point block
                 __syncthreads();
                 LM_TICK(7);
                 lm_factor_blocked(S, dg, rdg, Tb, n, &s_fail);
                 LM_TICK(8);
                 lm_subst_blocked(S, bs, rdg, n);
-                if (wv == 0) {
-                    for (int i = lane; i < n; i += 64) tl_st(xpub + i, bs[i]);
-                    if (lane == 0) tl_st(xpub + LM_MAXN, s_fail ? 1.0 : 0.0);
-                }
             }
             LM_TICK(9);
-            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
-            LM_TICK(10);
-            for (int i = tid; i < n; i += LM_THREADS) xp[i] = xpub[i];
-            const bool ok2 = xpub[LM_MAXN] == 0.0;
             __syncthreads();
+            for (int i = tid; i < n; i += LM_THREADS) xp[i] = bs[i];
+            const bool ok2 = s_fail == 0;
+            __syncthreads();
+            LM_TICK(10);
             // ---- 4. x_l, update(x), computeScale; then computeActiveErrors at the trial state -- per part
             if (ok2 && tid < Kf) {
                 double *o = B.posed + BA_POSED * (size_t)B.free_pose[tid];
