@@ -1,20 +1,18 @@
 // SURVEY 8f-1 -- the whole Levenberg-Marquardt loop of ba::LocalBAG2O (src/Algorithm/BA.cpp:390-395,501-502: g2o
 // OptimizationAlgorithmLevenberg + BlockSolver_6_3 with marginalised points + a Cholesky solve of the reduced pose system)
-// resident on the GPU: a team of 1-8 workgroups per BA window (k_ba_lm_team, see there) runs linearisation, Schur complement,
-// Cholesky, back-substitution, state update, trial evaluation and the lambda policy without a host round trip; hundreds of
-// windows optimise concurrently (one per CU), a handful use eight CUs each.  The host-loop form (ba_lm.hip::ygz_hip_ba_optimize) keeps the same arithmetic with the reduced system on the
-// CPU; oracle/ceres_ba.c::yo_g2o_lm restates it for the tests [frozen spec of g2o, see there].
+// resident on the GPU: a team of 1-32 workgroups per BA window (k_ba_lm_team, see there) runs linearisation, Schur complement,
+// L D L^T, back-substitution, state update, trial evaluation and the lambda policy without a host round trip; hundreds of
+// windows optimise concurrently (one workgroup each), a handful use 32 CUs each.  The host-loop form (ba_lm.hip::ygz_hip_ba_optimize) keeps
+// the same arithmetic with the reduced system on the CPU; oracle/ceres_ba.c::yo_g2o_lm restates it for the tests [frozen spec of g2o, see there].
 //
 // Per LM trial and window (K <= 16 poses, 14 of them free; P points; E edges):
-//   1. Dinv_l = (Hll_l + lambda I)^-1 and Y_e = Hpl_e Dinv_l per point (lane = point).
-//   2. S = blockdiag(Hpp + lambda I) - sum_l Y_a(l) Hpl_b(l)^T: one wavefront per (pose pair a <= b, part of the points) sweeps
-//      its points 128 at a time through the (point, pose) -> edge table, accumulates the 6x6 block in registers and reduces it
-//      in a fixed order (no floating-point atomics); S lives in LDS (84 x 84 doubles).
-//   3. right-looking Cholesky in LDS (the same subtraction order per element as the host's left-looking loop), column-oriented
-//      forward / backward substitution inside one wavefront.
-//   4. x_l = Dinv_l (b_l - sum_e Hpl_e^T x_p) (lane = point), oplus on the poses (lane = pose), trial chi2, rho, lambda.
-// the per-edge blocks (Hpl, residuals) are re-read three times per trial by the same few CUs: plain stores keep them in L2 (the
-// streaming stores of the one-shot linearisation, ba.hip, would send every re-read to HBM)
+//   1. S = blockdiag(Hpp + lambda I) - sum_l Y_a(l) Hpl_b(l)^T with Y_a(l) = Hpl_a(l) (Hll_l + lambda I)^-1: one wavefront per (pose pair
+//      a <= b, part of the points) sweeps its points 128 at a time through the (point, pose) -> edge table, inverts the point blocks it
+//      meets, accumulates the 6x6 block in registers and reduces it in a fixed order (no floating-point atomics).
+//   2. S = L D L^T by 6x6 block columns in LDS (<= 84 x 84 doubles), the two triangular solves inside one wavefront.
+//   3. x_l = Dinv_l (b_l - sum_e Hpl_e^T x_p) (lane = point), T <- exp(x_p) T on the poses (lane = pose), trial chi2, rho, lambda.
+// The per-edge blocks (Hpl, residuals) are re-read twice per trial by the same few CUs: plain stores keep them in L2 (the
+// streaming stores of the one-shot linearisation, ba.hip, would send every re-read to HBM).
 #define YGZ_BA_PLAIN_STORES
 #include "ba_dev.h"
 #include <stdio.h>
@@ -69,19 +67,7 @@ __device__ __forceinline__ bool lm_inv3(const double *m, double *r)
     return true;
 }
 
-// VertexSE3Sophus::oplusImpl (G2oTypes.h:38-45): estimate order [omega; t], Sophus order [t; omega]
-__device__ void lm_oplus_pose(double pose[6], const double upd[6])
-{
-    const double v[6] = { upd[3], upd[4], upd[5], upd[0], upd[1], upd[2] };
-    const double est[6] = { pose[3], pose[4], pose[5], pose[0], pose[1], pose[2] };
-    Se3 A, Bm, Cm; double r[6];
-    se3_exp_d(v, &A); se3_exp_d(est, &Bm);
-    se3_mul_d(&A, &Bm, &Cm);
-    se3_log_d(&Cm, r);
-    pose[0] = r[3]; pose[1] = r[4]; pose[2] = r[5]; pose[3] = r[0]; pose[4] = r[1]; pose[5] = r[2];
-}
-
-// ba_point_chi2 with the inputs of LM_RB rows requested together: in the resident loop a thread owns one point and its
+// ba_point_chi2 with the inputs of LM_RC rows requested together: in the resident loop a thread owns one point and its
 // edge loop is a chain of dependent round trips to L2 (measured: 53 us per trial for 16 such iterations), not arithmetic
 __device__ __forceinline__ double lm_point_chi2_pf(const BaDev &B, int il)
 {
@@ -257,21 +243,26 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 }
 
 // =====================================================================================================================================
-// The same Levenberg-Marquardt loop by a TEAM of G workgroups per window.  One workgroup per window leaves 255 of the 256 CUs idle
+// The Levenberg-Marquardt loop by a TEAM of G workgroups per window.  One workgroup per window leaves 255 of the 256 CUs idle
 // when a launch holds a handful of windows (the BA round of the offline run) and is bound by what ONE CU can read: the Schur sweep
-// alone moves 16 MB per trial through one vector memory pipeline.  Here the points of a window are cut into LM_V = 8 fixed PARTS
-// (whole 64-point chunks); a part is always reduced by one workgroup in one fixed order and the parts are combined in part order,
-// so the result does not depend on G (1, 2, 4 or 8 workgroups: the launch picks G from the number of windows, and a sharded and an
-// unsharded offline run stay bit-identical).  Per trial: every workgroup inverts the point blocks of its parts (Y = Hpl Dinv) |
-// barrier | one wavefront per (pose pair, part) forms that part's share of the Schur complement | barrier | workgroup 0 assembles S,
-// factors it and publishes x_p | barrier | every workgroup back-substitutes its points, applies the update and evaluates the errors
-// of the trial state | barrier (partials of scale / chi2) | every workgroup takes the same accept / reject decision.  The pose state
-// is private to a workgroup (identical copies): a shared copy updated by everybody would be a read-modify-write race.
-// Barriers: one monotonic counter per window, lane 0 releases at agent scope before it arrives and acquires after the wait
-// (MI355X: per-CU L1 and per-XCD L2 are not coherent); what members exchange is written with agent-scope stores and read with plain loads after the barrier's acquire (the parts of a pose pair, read by whoever delivers the last one without a barrier in between: agent-scope loads).  All blocks of
-// a team must be resident: the launch keeps windows x G <= half of the CUs (a CU holds one of these; ygz_hip_ba_set_team_budget), every wait is bounded and a
-// timeout aborts the whole team with YGZ_E_HIP.  blockIdx -> (XCD slot, team member): the members of a team share an XCD / L2
-// when the dispatcher places block b on XCD b % 8 (speed only).
+// alone moves 16 MB per trial through one vector memory pipeline.  Work is dealt out in units whose arithmetic does not depend on who
+// runs them, so the result is the same for every G (1 ... 32: the launch picks G from the number of windows; a sharded and an unsharded
+// offline run stay bit-identical, and a window whose team timed out is solved again by one workgroup to the same bits):
+//   * per-point work (linearisation, point update, trial chi2) = one WAVEFRONT per chunk of 64 points; a chunk leaves a record (chi2,
+//     scale, the 27 sums of every free pose: (chunk, pose) tasks of their own) and everybody adds the records in chunk order;
+//   * the Schur sweep = one wavefront per (pose pair, PART of the points), LM_V = 8 fixed parts of whole chunks; the wavefront that
+//     delivers the last part of a pair adds the parts in part order (an arrival counter per pair).
+// Tasks go to wavefront (task mod 4 G), member-minor: consecutive tasks run on different CUs.  Per iteration: linearise | barrier |
+// combine.  Per trial: sweep | barrier | EVERY member loads the finished blocks, factors S and substitutes (identical arithmetic: x_p is not
+// published) | pose update, point update, trial errors | barrier (chunk records: scale, chi2) | every member takes the same accept /
+// reject decision.  The pose state -- the prepared poses T = (q, t, R) -- is private to a workgroup (identical copies): a shared copy
+// updated by everybody would be a read-modify-write race.
+// Barriers: one monotonic counter per window, lane 0 releases at agent scope before it arrives and acquires after the wait (MI355X: per-CU
+// L1 and per-XCD L2 are not coherent); what members exchange is written with agent-scope stores and read with plain loads after the
+// barrier's acquire (the parts of a pose pair, read by whoever delivers the last one without a barrier in between: agent-scope loads).
+// All blocks of a team must be resident: the launch keeps windows x G <= half of the CUs (a CU holds one of these;
+// ygz_hip_ba_set_team_budget), every wait is bounded and a timeout aborts the whole team with YGZ_E_HIP.  blockIdx -> (XCD slot, team
+// member): the members of a team share an XCD / L2 when the dispatcher places block b on XCD b % 8 (speed only).
 #ifndef LM_V
 #define LM_V      8
 #endif
@@ -594,7 +585,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 #define LM_PART_RANGE(v) const int p0_ = 64 * (int)(((long long)(v) * Q) / LM_V), p1_ = min(P, 64 * (int)(((long long)((v) + 1) * Q) / LM_V));
 
     for (int it = 0; it < A.max_iterations; ++it) {
-        // ---- computeActiveErrors + buildSystem: per part chi2, max |diag Hll|, the 27 sums of every free pose
+        // ---- computeActiveErrors + buildSystem: per chunk chi2, max |diag Hll|, the 27 sums of every free pose
         if (tid == 0) __hip_atomic_store(B.n_behind, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         // tasks of ONE WAVEFRONT each: (chunk c of 64 points, -1) = the edges of its points (residuals, Hll / bl, Hpl), (c, a) = the 27 sums of
@@ -632,7 +623,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
         LM_TICK(0);
         if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
         LM_TICK(1);
-        {   // every member adds the parts in part order: identical sH, chi2 (and lambda at the first iteration)
+        {   // every member adds the chunk records in chunk order: identical sH, chi2 (and lambda at the first iteration)
             for (int i = tid; i < 27 * Kf; i += LM_THREADS) sH[i / 27][i % 27] = lm_sum_records(crec + 8 + i, Q);
             double mx = it == 0 ? lm_max_records(crec + 1, Q) : 0.0;
             currentChi = lm_sum_records(crec, Q);
@@ -763,7 +754,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             const bool ok2 = s_fail == 0;
             __syncthreads();
             LM_TICK(10);
-            // ---- 4. x_l, update(x), computeScale; then computeActiveErrors at the trial state -- per part
+            // ---- 4. update(x): T <- exp(x_p) T, x_l per point; computeScale; then computeActiveErrors at the trial state -- per chunk
             if (ok2 && tid < Kf) {
                 double *o = B.posed + BA_POSED * (size_t)B.free_pose[tid];
                 const double v[6] = { xp[6 * tid + 3], xp[6 * tid + 4], xp[6 * tid + 5], xp[6 * tid], xp[6 * tid + 1], xp[6 * tid + 2] };   // [omega; t] -> [t; omega]
@@ -963,13 +954,13 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     int rc = YGZ_OK;
     const BaDev *table = ygz_ba_table(ctx, &rc);
     if (!table) return rc;
-    // team size: windows x G <= a quarter of the device's CUs (every member spins at the team barriers, so all of them must be
+    // team size: windows x G <= half of the device's CUs by default (every member spins at the team barriers, so all of them must be
     // resident together -- also beside the kernels of other streams and of the offline run's tracking lanes), G a power of two
     int G = 1, Kmax = 1;
     static const bool single = [] { const char *e = getenv("YGZ_BA_LM_TEAM"); return e && e[0] == '1' && e[1] == 0; }();   // A/B switch: one workgroup per window
     const int wg_budget = ctx->lm_team_budget > 0 ? ctx->lm_team_budget : (ctx->n_cu / 2 > 8 ? ctx->n_cu / 2 : 8);
-    // up to 4 x LM_V members: the members beyond LM_V own no part of the points -- they only take (pose pair, part) tasks of the Schur sweep,
-    // the longest phase of a trial with four wavefronts per member (28 pairs x 8 parts over 32 wavefronts: 7 rounds; over 64: 3.5)
+    // up to LM_MAXG members: every phase is a pool of one-wavefront tasks (chunks of points, (chunk, pose) sums, (pose pair, part) sweeps:
+    // 28 pairs x 8 parts over the 128 wavefronts of 32 members are 1.75 rounds of the longest phase of a trial)
     if (!single) while (G < LM_MAXG && n_windows * (2 * G) <= wg_budget) G *= 2;           // windows x G <= budget
     for (int i = window_begin; i < window_begin + n_windows; ++i) Kmax = ctx->ba[i]->K > Kmax ? ctx->ba[i]->K : Kmax;
     int Qcap = 1;
