@@ -373,6 +373,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     need, n_frames, count = R["need"], R["n_frames"], R["count"]
     gray_in = upload == "gray"                                # the caller hands gray frames over (cv::cvtColor's fixed-point weights, on the host)
     chunk = min(chunk, max(32, -(-count // 4)))               # a shard is cut into >= 4 chunks: uploads, kernels and the BA windows of a rank overlap
+    chunk = int(os.environ.get("YGZ_OFF_CHUNK", chunk))        # (experiment)
     if lanes is None:
         # BGR frames: the run is PCIe-bound, three lanes keep the link busy (four: 57.1 against 56.0 ms of tracking per 1024 frames);
         # gray frames: kernel-bound, a fourth lane fills more of the GPU (38.6 against 40.1 ms)

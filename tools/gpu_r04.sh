@@ -337,6 +337,11 @@ PY
     for F in 512 256 128; do offline f${F} python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline; done
     YGZ_OFF_DEFER=4 offline f512_defer4 python bench.py --mode offline --frames 512 --steps 5 --warmup 2 --no-cpu-baseline
     ;;
+c2) # chunk size and lanes of a short shard (what one rank of an 8-rank run does)
+    for CH in 32 16 24 48 64; do for LN in 3 4; do
+        YGZ_OFF_CHUNK=$CH timeout 120 python bench.py --mode offline --frames 128 --lanes $LN --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f128 chunk $CH lanes $LN', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['phases_ms'].items()})"
+    done; done
+    ;;
 z)  # round-4 closing batch: full GPU suite, the three rocprofv3 passes of the default command, the SQ pass, the step timeline, the default
     # bench line with its extra blocks, the offline lines per shard size, the kernel statistics and the device timeline of the offline mode
     timeout 900 python -m pytest tests -q -m gpu --no-header -rf 2>&1 | tail -4
