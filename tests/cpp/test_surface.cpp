@@ -13,7 +13,14 @@ static std::vector<double> slurp_f64(const std::string &p) { auto b = slurp(p); 
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: %s in_dir out_file\n", argv[0]); return 2; }
+    if (argc >= 2 && std::string(argv[1]) == "config") {
+        // `test_surface config [file] -- key ...`: ygz::Config alone (no device): the built-in defaults, or what SetParameterFile reads
+        int i = 2;
+        if (i < argc && std::string(argv[i]) != "--") { if (!Config::SetParameterFile(argv[i])) return 3; ++i; }
+        for (++i; i < argc; ++i) printf("%s %s %.17g\n", argv[i], Config::Raw(argv[i]).c_str(), Config::Get<double>(argv[i]));
+        return 0;
+    }
+    if (argc < 3) { fprintf(stderr, "usage: %s in_dir out_file | %s config [file] -- key ...\n", argv[0], argv[0]); return 2; }
     const std::string in = argv[1];
     FILE *out = fopen(argv[2], "w");
     Config::SetParameterFile(in + "/default.yaml");
