@@ -236,6 +236,54 @@ def test_offline_chunk_schedule_and_depth_images():
     assert np.abs(got - full).max() < 6.0                           # (a coarse prior: neighbouring samples of a random map differ)
 
 
+def test_offline_chunk_plan_properties_random():
+    """offline.chunk_plan on random sequences / shards / window shapes: every frame of the shard in exactly one range, ranges of a chunk sorted
+    and apart, no frame twice among a chunk's frames and halo frames (they share a lane's slots), at most `chunk` frames per chunk, every window
+    that ends inside the shard complete before the first deferred chunk, and shards of all ranks together cover the sequence"""
+    rng = np.random.default_rng(123)
+    for _ in range(300):
+        kf_stride = int(rng.choice([2, 4, 8, 8, 8, 16]))
+        window_kfs = int(rng.integers(2, 9))
+        n_total = int(rng.integers(kf_stride * window_kfs + 1, 1500))
+        world = int(rng.choice([1, 1, 2, 3, 4, 8]))
+        chunk = int(rng.choice([16, 24, 32, 64, 128]))
+        defer = int(rng.choice([0, 1, 2, 5, 13, 40]))
+        ramp = bool(rng.integers(0, 2))
+        wins = offline.ba_windows(n_total, kf_stride, window_kfs)
+        covered = np.zeros(n_total, int)
+        for rank in range(world):
+            first, count, _halo = ydist.shard_frames(n_total, rank, world)
+            if count <= 0:
+                continue
+            last = first + count
+            plan = offline.chunk_plan(first, last, chunk, ramp, kf_stride, wins, defer)
+            seen = np.zeros(n_total, int)
+            for ch in plan:
+                assert len(ch) >= 1 and 0 < sum(b - a for a, b in ch) <= chunk, (ch, chunk)
+                assert all(first <= a < b <= last for a, b in ch) and all(x[1] < y[0] for x, y in zip(ch, ch[1:])), ch
+                frames = [f for a, b in ch for f in (range(a - 1, b) if a > 0 else range(a, b))]
+                assert len(set(frames)) == len(frames), ch                          # halo frames included
+                for a, b in ch:
+                    seen[a:b] += 1
+            assert np.all(seen[first:last] == 1) and seen.sum() == count
+            covered += seen
+            inside = [w for w in wins if w[0] >= first and w[-1] < last]
+            plain = offline.chunk_plan(first, last, chunk, ramp, kf_stride, wins, 0)
+            if plan != plain:                                                       # some gaps are deferred: find the first chunk made of gap frames only
+                in_window = np.zeros(n_total, bool)
+                for w in wins:
+                    in_window[w[0]:w[-1] + 1] = True
+                k = len(plan)
+                while k > 0 and not any(in_window[a:b].any() for a, b in plan[k - 1]):
+                    k -= 1
+                done = np.zeros(n_total, bool)
+                for ch in plan[:k]:
+                    for a, b in ch:
+                        done[a:b] = True
+                assert k < len(plan) and all(done[w[0]:w[-1] + 1].all() for w in inside)
+        assert np.all(covered == 1)
+
+
 def test_offline_chain_matches_the_interpreter_form():
     rng = np.random.default_rng(5)
     T_rel = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(300)])
