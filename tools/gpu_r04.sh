@@ -342,6 +342,11 @@ c2) # chunk size and lanes of a short shard (what one rank of an 8-rank run does
         YGZ_OFF_CHUNK=$CH timeout 120 python bench.py --mode offline --frames 128 --lanes $LN --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f128 chunk $CH lanes $LN', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['phases_ms'].items()})"
     done; done
     ;;
+ra) # limited run-ahead of the host: N chunks enqueued beyond one per lane before the oldest chunk's records are read
+    for F in 1024 128; do for RA in 0 1 2 3 0 1; do
+        YGZ_OFF_RUN_AHEAD=$RA timeout 120 python bench.py --mode offline --frames $F --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f$F ahead $RA', round(d['value'],1), round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['phases_ms'].items()})"
+    done; done
+    ;;
 z)  # round-4 closing batch: full GPU suite, the three rocprofv3 passes of the default command, the SQ pass, the step timeline, the default
     # bench line with its extra blocks, the offline lines per shard size, the kernel statistics and the device timeline of the offline mode
     timeout 900 python -m pytest tests -q -m gpu --no-header -rf 2>&1 | tail -4

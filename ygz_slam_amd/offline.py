@@ -430,7 +430,7 @@ class OfflineVO:
         # page-locked result rows (per-pair summary, keypoint counts), one set per chunk
         self._pin = [dict(sum=_lib.PinnedArray((max(2, sum(b - a + 1 for a, b in ch)), _lib.SUMMARY_FIELDS), np.float64),
                           cnt=_lib.PinnedArray((max(2, sum(b - a + 1 for a, b in ch)),), np.int32)) for ch in self.chunks]
-        self.run_ahead = os.environ.get("YGZ_OFF_RUN_AHEAD", "0") != "0"
+        self.run_ahead = int(os.environ.get("YGZ_OFF_RUN_AHEAD", "0"))          # chunks enqueued beyond one per lane before the oldest is collected (experiment; 99 = all)
         self.timing = {}
 
     def close(self):
@@ -463,12 +463,12 @@ class OfflineVO:
         self._last_upload = None
         for ci, ranges in enumerate(chunks):
             # the host hands a lane its next chunk when it has read the results of the lane's previous one: `lanes` chunks are in flight.
-            # (YGZ_OFF_RUN_AHEAD=1 enqueues every chunk at once -- every chunk has its own page-locked result rows, a lane's stream orders
+            # (YGZ_OFF_RUN_AHEAD=99 enqueues every chunk at once -- every chunk has its own page-locked result rows, a lane's stream orders
             # the upload of its next chunk behind the kernels of its previous one.  Measured SLOWER, 63.6 against 59.8 ms per 1024 frames and
             # 46.7 against 42.1 with gray frames: with everything queued the resident-LM teams and the tracking kernels of three lanes compete
             # for the CUs -- the LM launch beside the tracking takes 8.6 instead of 5.6 ms and uploads wait behind kernels.)
             li = ci % len(self.lanes)
-            if not self.run_ahead and len(pending) >= len(self.lanes):
+            while len(pending) >= len(self.lanes) + self.run_ahead:
                 self._collect(*pending.pop(0), rec)
             info = self._enqueue(li, ranges, frame_source, depth_source, block_source, ci)
             if self.keep:                                      # parity runs read everything back before the lane moves on
