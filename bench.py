@@ -380,8 +380,11 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
         lanes = 4 if gray_in else 3
     pin = _lib.PinnedArray((len(need), H_, W_) if gray_in else (len(need), H_, W_, 3), np.uint8)
     dpin = _lib.PinnedArray((len(need), H_ // DEPTH_DIV, W_ // DEPTH_DIV), np.uint16)
+    # the DRIVER is C++ (ygz_slam_amd/host/ygz_offline.cpp in libygz_host.so; collectives = RCCL called from there): this function only fills
+    # page-locked buffers, calls ygz_offline_run through the binding and prints what came back
     vo = offline.OfflineVO(W_, H_, n_frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
-                           exchange_on_device=not one_dev, depth_div=DEPTH_DIV, depth_dtype=np.uint16, depth_scale=DEPTH_SCALE, overlap=overlap, lm_group=lm_group, lanes=lanes)
+                           exchange_on_device=not one_dev, depth_div=DEPTH_DIV, depth_dtype=np.uint16, depth_scale=DEPTH_SCALE, overlap=overlap, lm_group=lm_group, lanes=lanes,
+                           gray=gray_in)
     for k, (i, b, d) in enumerate(R["rendered"]):
         assert i == need[k]
         if gray_in:
@@ -419,17 +422,6 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     barrier()
     dt = time.perf_counter() - t0
     probe_ms, probe_n = vo.ctx.probe_end()
-    if vo.trace is not None and rank == 0:                   # YGZ_OFFLINE_TRACE=1: where the host thread spent the timed region
-        tr = [e for e in vo.trace if e[1] >= t0]
-        agg = {}
-        for name, a_, b_ in tr:
-            g = agg.setdefault(name, [0, 0.0, 0.0]); g[0] += 1; g[1] += b_ - a_; g[2] = max(g[2], b_ - a_)
-        print("[offline trace] host time inside ABI calls %.1f ms of %.1f ms" % (sum(v[1] for v in agg.values()) * 1e3, dt * 1e3), file=sys.stderr)
-        for name, (cnt, tot, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
-            print("[offline trace] %-36s calls %4d total %8.2f ms max %7.2f ms" % (name, cnt, tot * 1e3, mx * 1e3), file=sys.stderr)
-        for name, a_, b_ in tr:                               # the host's side of the LAST run: uploads, waits, BA launches (ms from the start of the run)
-            if a_ >= t_run and (name.split(".")[1] in ("upload_bgr_batch", "upload_gray_batch", "synchronize", "ba_optimize_resident", "ba_build_windows") or b_ - a_ > 2e-4):
-                print("[offline host] %8.2f  %-34s %6.2f ms" % ((a_ - t_run) * 1e3, name, (b_ - a_) * 1e3), file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -458,7 +450,8 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
                                       "(+ a quarter-resolution uint16 depth image) and D2H of the results inside the timed region"
                                       % (n_frames, W_, H_),
                           "frames_total": n_frames, "frames_per_gpu": count, "chunk": chunk, "keypoints_per_frame": n_kp,
-                          "parallelism": "frames sharded x%d" % world, "frames_cross_pcie_as": upload, "lanes": len(vo.lanes), "windows_per_lm_launch": vo.lm_group,
+                          "parallelism": "frames sharded x%d" % world, "frames_cross_pcie_as": upload, "lanes": len(vo.lanes), "lm_launches_per_run": vo.lm_launches,
+                          "host_driver": "C++ (libygz_host.so: ygz_offline_run), one ABI call per run", "exchange_backend": vo.backend,
                           "h2d_bytes_per_frame": frame_bytes, "h2d_GBps": frame_bytes * count * steps / dt / 1e9},
                "phases_ms": med, "render_s_outside_timed_region": R["render_s"],
                "result_check": {"pairs": len(pairs), "mean_pose_only_inliers": float(np.mean([r["po_inliers"] for r in pairs])),

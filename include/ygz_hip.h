@@ -36,6 +36,12 @@ extern "C" {
 
 #define YGZ_MAX_LEVELS      8
 
+/* Bumped whenever an exported function changes its argument list under the same name (C has no mangling: a caller built against an older
+ * header would still link).  Bindings compare ygz_hip_abi_version() with the header they were written against at load time
+ * (ygz_slam_amd/_lib.py, include/ygz/hip/Runtime.h).  5: ygz_hip_kf_row_bytes / ygz_hip_kf_store_create / ygz_hip_ba_build_windows
+ * gained their trailing int (round 4); ygz_hip_get_stream / device_alloc / copy added (round 5). */
+#define YGZ_HIP_ABI_VERSION 5
+
 typedef struct ygz_hip_ctx ygz_hip_ctx;
 
 typedef struct {
@@ -75,6 +81,17 @@ int  ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable);
 const char *ygz_hip_error_string(int code);
 int  ygz_hip_last_hip_error(const ygz_hip_ctx *ctx);
 int  ygz_hip_max_keypoints(const ygz_hip_ctx *ctx);     /* = number of grid cells */
+int  ygz_hip_abi_version(void);                         /* YGZ_HIP_ABI_VERSION of the library that is loaded */
+/* plumbing for host code that drives several contexts and a collective library (ygz_slam_amd/host/ygz_offline.cpp; no reference
+ * counterpart -- the reference is single-GPU): the context's hipStream_t as an opaque pointer (RCCL calls are enqueued on it), its device
+ * ordinal / CU count, zero-filled device memory for exchange buffers, and a copy ordered on the stream (kind 0: host -> device, 1: device ->
+ * host, 2: device -> device; wait == 0 needs page-locked host memory) */
+int  ygz_hip_get_stream(ygz_hip_ctx *ctx, void **stream);
+int  ygz_hip_get_device(const ygz_hip_ctx *ctx, int *device, int *compute_units);
+int  ygz_hip_make_current(ygz_hip_ctx *ctx);            /* hipSetDevice(the context's device) for the calling thread, left that way */
+int  ygz_hip_device_alloc(ygz_hip_ctx *ctx, void **out, size_t bytes);
+int  ygz_hip_device_free(ygz_hip_ctx *ctx, void *p);
+int  ygz_hip_copy(ygz_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int kind, int wait);
 /* HIP-event timing on the context's stream (bench.py roofline leg) */
 int  ygz_hip_timer_begin(ygz_hip_ctx *ctx);
 int  ygz_hip_timer_end(ygz_hip_ctx *ctx, float *elapsed_ms);   /* synchronises */

@@ -70,3 +70,45 @@ def test_header_is_plain_c_and_matches_the_loader():
     declared = set(re.findall(r"\b(ygz_hip_[a-z0-9_]+)\s*\(", open(hdr).read()))
     from ygz_slam_amd import _lib
     assert declared == set(_lib.ABI_SYMBOLS), (sorted(declared - set(_lib.ABI_SYMBOLS)), sorted(set(_lib.ABI_SYMBOLS) - declared))
+
+
+def test_offline_header_is_plain_c_and_the_host_library_exports_it():
+    """include/ygz_offline.h (the C++ offline driver's boundary, libygz_host.so) compiles as C99, every function it declares is exported and
+    bound by ygz_slam_amd/offline.py, and the ctypes mirror of its parameter block has the header's defaults and size"""
+    import subprocess
+    from ygz_slam_amd import offline
+    hdr = os.path.join(ROOT, "include", "ygz_offline.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I", os.path.join(ROOT, "include"), hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    declared = set(re.findall(r"\b(ygz_offline_[a-z0-9_]+)\s*\(", txt)) - {"ygz_offline_chunk_fn"}
+    assert declared == set(offline.OFFLINE_SYMBOLS), (sorted(declared - set(offline.OFFLINE_SYMBOLS)), sorted(set(offline.OFFLINE_SYMBOLS) - declared))
+    lib = offline.host_lib()
+    for n in declared:
+        assert hasattr(lib, n), "libygz_host.so does not export " + n
+    p = offline.OffParams()
+    lib.ygz_offline_default_params(ctypes.byref(p))
+    assert (p.width, p.height, p.levels, p.chunk, p.kf_stride, p.window_kfs, p.max_points, p.ba_iterations, p.lanes) == (1280, 720, 3, 128, 8, 8, 2000, 20, 3)
+    assert (p.obs_mode, p.ba_rounds, p.frame_channels, p.depth_kind, p.pipeline_ba, p.defer_gaps, p.ramp, p.kf_tail) == (1, 1, 3, 1, 1, -1, 1, 1)
+    assert abs(p.outlier_chi2 - 5.991) < 1e-12 and abs(p.depth_scale - 1 / 5000.0) < 1e-15
+    # sizeof through a C probe: the mirror has the header's layout
+    src = '#include "ygz_offline.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu", sizeof(ygz_offline_params), sizeof(ygz_offline_results), sizeof(ygz_offline_exchange));return 0;}'
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [ctypes.sizeof(offline.OffParams), ctypes.sizeof(offline.OffResults), ctypes.sizeof(offline.OffExchange)]
+    # bad arguments are refused before any device is touched
+    h = ctypes.c_void_p()
+    p.world, p.rank = 2, 0
+    assert lib.ygz_offline_create(ctypes.byref(h), ctypes.byref(p), None, None) == -1 and not h          # world > 1 needs an id or a hook
+    p.world, p.window_kfs = 1, 1
+    assert lib.ygz_offline_create(ctypes.byref(h), ctypes.byref(p), None, None) == -1 and not h
+
+
+def test_abi_version_is_checked_at_load(hip_lib):
+    lib = hip_lib.load()
+    assert lib.ygz_hip_abi_version() == hip_lib.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "ygz_hip.h")).read()
+    assert int(re.search(r"#define YGZ_HIP_ABI_VERSION\s+(\d+)", hdr).group(1)) == hip_lib.ABI_VERSION

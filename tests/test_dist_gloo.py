@@ -82,7 +82,7 @@ def test_world_size_2_gloo(oracle):
     assert list(ret["nmatch"]) == exp
 
 
-# ---- host logic of the offline run (ygz_slam_amd/offline.py); its GPU half is tests/test_gpu_offline.py ------------------
+# ---- host logic of the offline run (ygz_slam_amd/host/ygz_offline.cpp, bound by ygz_slam_amd/offline.py); its GPU half is tests/test_gpu_offline.py ------------------
 def test_offline_windows_and_owners():
     assert offline.keyframes(17, 8) == [0, 8, 16]
     assert offline.ba_windows(1024, 8, 8) == [list(range(64 * w, 64 * w + 64, 8)) for w in range(16)]
@@ -125,19 +125,21 @@ def test_offline_se3_helpers_match_the_oracle(oracle):
 def _exchange_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    owner = [0, 0, 1, 1, 1]                                      # 5 BA windows, contiguous ownership
-    buf = torch.zeros((5, 7), dtype=torch.float64)
-    for i, o in enumerate(owner):
-        if o == rank:
-            buf[i] = torch.arange(7, dtype=torch.float64) + 10 * i + 0.5
-    offline.exchange_rows(buf, owner, world)
-    # trajectory gather of ragged shards (5 frames: 3 + 2) followed by the chain, as OfflineVO.gather does
+    # the exchange of the C++ driver (ygz_offline_ragged_all_gather in libygz_host.so) over gloo: 5 BA windows with contiguous ownership
+    # [0, 0, 1, 1, 1] -- rows of 7 doubles here, 48 KB state rows in a run -- ...
+    counts = [2, 3]
+    first = sum(counts[:rank])
+    mine = np.stack([np.arange(7, dtype=np.float64) + 10 * (first + i) + 0.5 for i in range(counts[rank])])
+    buf = offline.ragged_all_gather(mine, counts)
+    # ... and the relative poses of ragged shards (5 frames: 3 + 2), followed by the chain, as ygz_offline_gather does
     n = 5
     rng = np.random.default_rng(9)
     T_rel_all = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(n)])
     s, c, _ = ydist.shard_frames(n, rank, world)
-    got = ydist.gather_trajectories(T_rel_all[s:s + c], n, rank, world)
-    ret[rank] = (buf.numpy().copy(), got)
+    got = offline.ragged_all_gather(T_rel_all[s:s + c], [ydist.shard_frames(n, r, world)[1] for r in range(world)])
+    # a rank that owns nothing contributes an empty block
+    lone = offline.ragged_all_gather(np.arange(6, dtype=np.int32).reshape(2, 3) if rank == 1 else np.zeros((0, 3), np.int32), [0, 2])
+    ret[rank] = (buf, got, lone)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -150,14 +152,62 @@ def test_offline_exchange_world_size_2_gloo():
     rng = np.random.default_rng(9)
     T_rel_all = np.stack([synth.se3_exp(rng.normal(0, 0.05, 6)) for _ in range(5)])
     for r in range(2):
-        buf, got = ret[r]
+        buf, got, lone = ret[r]
         assert np.array_equal(buf, exp)                          # every rank holds every owner's rows
         assert np.array_equal(got, T_rel_all)
         assert np.array_equal(offline.chain(got), offline.chain(T_rel_all))
+        assert np.array_equal(lone, np.arange(6, dtype=np.int32).reshape(2, 3))
+
+
+def test_offline_driver_partition_equals_the_python_statement():
+    """the C++ driver's own partition (ygz_offline_shard) and plan (ygz_offline_plan for a parameter block) against dist.shard_frames and
+    the plan built from this module's window list"""
+    import ctypes as C
+    lib = offline.host_lib()
+    for n in (1, 7, 8, 128, 1024, 1000):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                a, b, c = C.c_int(), C.c_int(), C.c_int()
+                assert lib.ygz_offline_shard(n, r, world, C.byref(a), C.byref(b), C.byref(c)) == 0
+                assert (a.value, b.value, c.value) == ydist.shard_frames(n, r, world)
+    for n, world, chunk, stride, wk, defer in ((1024, 1, 128, 8, 8, -1), (1024, 8, 32, 8, 8, -1), (128, 2, 24, 8, 6, 2), (16, 2, 5, 2, 3, 0), (900, 1, 128, 8, 8, -1)):
+        wins = offline.ba_windows(n, stride, wk)
+        for r in range(world):
+            p = offline.OffParams()
+            lib.ygz_offline_default_params(C.byref(p))
+            p.n_frames, p.rank, p.world, p.chunk, p.kf_stride, p.window_kfs, p.defer_gaps = n, r, world, chunk, stride, wk, defer
+            out = np.zeros((4096, 3), np.int32); k = C.c_int(0)
+            assert lib.ygz_offline_plan(C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)), 4096, C.byref(k)) == 0
+            s, c, _ = ydist.shard_frames(n, r, world)
+            d = (13 if c >= 768 else 0) if defer < 0 else defer
+            exp = offline.chunk_plan(s, s + c, chunk, True, stride, wins, d)
+            got = {}
+            for ci, a, b in out[:k.value].tolist():
+                got.setdefault(ci, []).append((a, b))
+            assert [tuple(got[i]) for i in sorted(got)] == exp
+
+
+def test_offline_plan_equals_the_python_restatement():
+    """chunk_schedule / chunk_plan of ygz_offline.cpp against their round-4 interpreter form (tests/plan_ref.py) on random shards"""
+    import plan_ref
+    rng = np.random.default_rng(77)
+    for _ in range(400):
+        kf_stride = int(rng.choice([2, 4, 8, 8, 8, 16]))
+        window_kfs = int(rng.integers(2, 9))
+        n_total = int(rng.integers(kf_stride * window_kfs + 1, 1500))
+        world = int(rng.choice([1, 1, 2, 3, 4, 8]))
+        chunk = int(rng.choice([5, 16, 24, 32, 64, 128]))
+        defer = int(rng.choice([0, 1, 2, 5, 13, 40]))
+        ramp = bool(rng.integers(0, 2))
+        kft = int(rng.choice([0, kf_stride]))
+        wins = offline.ba_windows(n_total, kf_stride, window_kfs)
+        first, count, _ = ydist.shard_frames(n_total, int(rng.integers(0, world)), world)
+        assert offline.chunk_plan(first, first + count, chunk, ramp, kft, wins, defer) == plan_ref.chunk_plan(first, first + count, chunk, ramp, kft, wins, defer)
+        assert offline.chunk_schedule(first, first + count, chunk, ramp, kft) == plan_ref.chunk_schedule(first, first + count, chunk, ramp, kft)
 
 
 def test_offline_chunk_schedule_and_depth_images():
-    """host logic of the offline pipeline: the ramped chunk schedule covers the shard exactly, and the host restatement of the device's depth
+    """host logic of the offline driver (ygz_offline.cpp through ygz_offline_plan_range): the ramped chunk schedule covers the shard exactly, and the host restatement of the device's depth
     look-up (offline.depth_at) samples what the docstring says for every depth-image format"""
     for first, last, chunk in ((0, 1024, 128), (128, 256, 32), (0, 512, 128), (0, 16, 5), (8, 16, 16), (0, 600, 128), (3, 4, 128), (0, 1024, 64)):
         for ramp in (True, False):
@@ -167,26 +217,13 @@ def test_offline_chunk_schedule_and_depth_images():
             if ramp and chunk >= 64 and last - first >= 4 * chunk:
                 assert c[0][1] - c[0][0] == chunk // 4 and c[-1][1] - c[-1][0] == chunk // 4     # short first upload, short last kernels
             # with a keyframe stride the frames behind the shard's last keyframe form the last chunk (no BA window waits for them)
-            k = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8, kf_small=0)
+            k = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8)
             assert k[0][0] == first and k[-1][1] == last and all(a[1] == b[0] for a, b in zip(k, k[1:])) and all(0 < b - a <= chunk for a, b in k)
             k_last = ((last - 1) // 8) * 8
             if first <= k_last < last - 1 and c[-1][0] <= k_last:
                 assert k[-1] == (k_last + 1, last) and k[:-2] == c[:-1] and k[-2] == (c[-1][0], k_last + 1)
             else:
                 assert k == c
-            # ... and the chunk that ends WITH the last keyframe is short (the last LM launch waits for its kernels): at most 12 frames, cut
-            # from the end of the chunk that held the keyframe; everything else as before
-            s8 = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8, kf_small=8)
-            assert s8[0][0] == first and s8[-1][1] == last and all(a[1] == b[0] for a, b in zip(s8, s8[1:])) and all(0 < b - a <= chunk for a, b in s8)
-            ends = [(a, b) for a, b in s8 if b == k_last + 1]
-            if ends and ends[0] in k and ends[0][1] - ends[0][0] <= 12:
-                assert s8 == k
-            elif ends:
-                assert ends[0][1] - ends[0][0] == 8
-                i = s8.index(ends[0])
-                assert s8[:i - 1] + [(s8[i - 1][0], ends[0][1])] + s8[i + 1:] == k
-            else:
-                assert s8 == k
     # the plan with deferred gaps (a chunk = a tuple of frame ranges): every frame of the shard exactly once, the frames behind the last
     # keyframes of the last windows at the end -- grouped, about 45 frames per chunk --, every window complete (anchor .. last keyframe) before the
     # first deferred chunk is processed, never more than `chunk` frames per chunk
@@ -211,8 +248,6 @@ def test_offline_chunk_schedule_and_depth_images():
         if gap_frames:                                                              # grouped: whole gaps, about 45 frames per chunk, at the very end
             assert all(all(r in gaps for r in ch) for ch in plan[len(plan) - n_tail:]), (plan, gaps)
             assert n_tail <= max(1, int(round(len(gap_frames) / 45.0))) + (1 if chunk < 45 else 0), (plan, gaps)
-            cut = offline.chunk_plan(first, last, chunk, True, 8, wins, defer, last_main=16)       # (option: a short last chunk of the main pass)
-            assert sum(b - a for a, b in cut[len(cut) - n_tail - 1]) <= 24 and cut[len(cut) - n_tail:] == plan[len(plan) - n_tail:]
         done = np.zeros(1024, bool)
         for ch in plan[:len(plan) - n_tail]:
             for a, b in ch:
@@ -237,7 +272,7 @@ def test_offline_chunk_schedule_and_depth_images():
 
 
 def test_offline_chunk_plan_properties_random():
-    """offline.chunk_plan on random sequences / shards / window shapes: every frame of the shard in exactly one range, ranges of a chunk sorted
+    """the C++ driver's chunk_plan (through offline.chunk_plan -> ygz_offline_plan_range) on random sequences / shards / window shapes: every frame of the shard in exactly one range, ranges of a chunk sorted
     and apart, no frame twice among a chunk's frames and halo frames (they share a lane's slots), at most `chunk` frames per chunk, every window
     that ends inside the shard complete before the first deferred chunk, and shards of all ranks together cover the sequence"""
     rng = np.random.default_rng(123)

@@ -1,6 +1,8 @@
-"""GPU tests (pytest -m gpu) of the offline run of BASELINE configs[4] (ygz_slam_amd/offline.py) and of the stages it adds
-to the C ABI: the M3 / M6 match filters, the TrackRefFrame -> TrackLocalMap hand-over on the device, pose-only BA on resident
-tracks.  The sharded run (2 ranks, gloo, both on the one GPU of the test box) must reproduce the unsharded run exactly."""
+"""GPU tests (pytest -m gpu) of the offline run of BASELINE configs[4] -- the C++ driver ygz_slam_amd/host/ygz_offline.cpp in
+libygz_host.so, bound by ygz_slam_amd/offline.py -- and of the stages it adds to the C ABI: the M3 / M6 match filters, the TrackRefFrame ->
+TrackLocalMap hand-over on the device, pose-only BA on resident tracks.  The sharded run (2 ranks, both on the one GPU of the test box, the
+driver's exchange hook over gloo because RCCL refuses two ranks on one device) must reproduce the unsharded run exactly; the RCCL path of the
+driver is run with a communicator of one rank."""
 import os
 import pickle
 import socket
@@ -340,22 +342,38 @@ def test_degenerate_window_is_reported_not_optimised(hip_lib):
 
 
 def test_timed_out_window_is_rebuilt_and_solved_by_one_workgroup(hip_lib):
-    """the retry path of a resident-LM team that timed out at a barrier (simulated: the statistics of one window read as "no result"): the
-    window is rebuilt and solved by a single workgroup -- bit-identical to the team's result, because the points are reduced in fixed parts
-    whatever the team size"""
+    """the retry path of a resident-LM team that timed out at a barrier (ygz_offline_retry_windows, what the driver calls for every window
+    whose statistics read "no result"): the window is rebuilt and solved by a single workgroup -- bit-identical to the team's result, because
+    the points are reduced in fixed parts whatever the team size"""
     n = 10
     seq = synth.Sequence(n, 640, 480, seed=3, step=0.2)
     vo = offline.OfflineVO(640, 480, n, chunk=n, kf_stride=2, window_kfs=4, max_points=700)
     res = vo.run(seq.frame, seq.depth)
     before = vo.ba.ba_pack_states(0, 1, vo.S)
-    assert before[0, -12 + 3] >= 1 and not hasattr(vo, "lm_retries")
-    real = vo.ba.ba_lm_iterations
-    calls = []
-    vo.ba.ba_lm_iterations = lambda a, b: ([-1] * b if not calls.append(1) and len(calls) == 1 else real(a, b))
-    vo._retry_timed_out()
+    assert before[0, -12 + 3] >= 1 and vo.lm_retries == 0
+    assert np.array_equal(before[0], res["windows"][0]["state"])
+    vo.retry_windows([0])
     after = vo.ba.ba_pack_states(0, 1, vo.S)
     assert vo.lm_retries == 1 and np.array_equal(before, after)
     vo.close()
+
+
+def test_rccl_path_with_a_communicator_of_one_rank(hip_lib):
+    """the driver's RCCL path (librccl.so.1 bound at run time, ncclCommInitRank, device exchange buffers, k_ba_pack straight into the send
+    buffer, ncclAllGather on the BA context's stream) on the ONE GPU of the test box: a communicator of one rank must give the bits of the
+    plain single-rank run"""
+    n = 12
+    seq = synth.Sequence(n, 640, 480, seed=3, step=0.2)
+    out = []
+    for single in (False, True):
+        vo = offline.OfflineVO(640, 480, n, chunk=5, kf_stride=2, window_kfs=3, max_points=700, rccl_single=single)
+        res = vo.run(seq.frame, seq.depth)
+        out.append((res, vo.backend))
+        vo.close()
+    assert [b for _, b in out] == ["single rank", "rccl"]
+    for k in ("T_rel", "trajectory", "windows", "built", "records"):
+        _same(out[0][0][k], out[1][0][k], k)
+    assert len(out[0][0]["windows"]) == 2 and out[0][0]["windows"][0]["lm"]["iterations"] >= 1
 
 
 N_LONG = 128
@@ -369,8 +387,6 @@ def _render_long(i):
 def _run_long(rank, world, port, outdir, defer=None):
     import sys
     sys.path.insert(0, ROOT)
-    if defer is not None:
-        os.environ["YGZ_OFF_DEFER"] = str(defer)                 # read by OfflineVO: the plan of the shard's chunks (offline.chunk_plan)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -384,12 +400,10 @@ def _run_long(rank, world, port, outdir, defer=None):
     bgr.array[:] = np.load(os.path.join(outdir, "bgr.npy"), mmap_mode="r")[base:base + cnt + halo]
     dimg.array[:] = np.load(os.path.join(outdir, "depth.npy"), mmap_mode="r")[base:base + cnt + halo]
     vo = offline.OfflineVO(1280, 720, N_LONG, rank=rank, world=world, device=0, chunk=24, kf_stride=8, window_kfs=6, max_points=2000,
-                           exchange_on_device=False, depth_div=4, depth_dtype=np.uint16)
+                           exchange_on_device=False, depth_div=4, depth_dtype=np.uint16, defer_gaps=defer)      # defer: the plan of the shard's chunks (chunk_plan)
     block = lambda frames: (bgr.array[frames[0] - base:frames[-1] + 1 - base], dimg.array[frames[0] - base:frames[-1] + 1 - base])   # page-locked: every copy is asynchronous
     res = vo.run(None, None, block)
     vo.close()
-    if defer is not None:
-        del os.environ["YGZ_OFF_DEFER"]
     with open(os.path.join(outdir, "long_r%d_of_%d%s.pkl" % (rank, world, "" if defer is None else "_defer%d" % defer)), "wb") as f:
         pickle.dump({k: res[k] for k in ("T_rel", "trajectory", "windows", "keyframe_pose", "built")}, f)
     if world > 1:

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libygz_hip.so")
 MAX_LEVELS = 8
 
 OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5
+ABI_VERSION = 5                     # YGZ_HIP_ABI_VERSION of include/ygz_hip.h this file mirrors
 
 
 class YgzHipError(RuntimeError):
@@ -101,6 +102,7 @@ ABI_SYMBOLS = [
     "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_se3_chain", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
     "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
     "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states", "ygz_hip_ba_mark_outliers", "ygz_hip_ba_get_outlier_stats", "ygz_hip_bow_orientation", "ygz_hip_bow_orientation_slots", "ygz_hip_ba_last_path",
+    "ygz_hip_abi_version", "ygz_hip_get_stream", "ygz_hip_get_device", "ygz_hip_make_current", "ygz_hip_device_alloc", "ygz_hip_device_free", "ygz_hip_copy",
 ]
 
 SUMMARY_FIELDS = 32
@@ -125,6 +127,11 @@ def load():
             except ImportError:
                 pass
         _lib = C.CDLL(LIB_PATH)
+        # C has no name mangling: a library built from an older header would still load.  Refuse it here.
+        if not hasattr(_lib, "ygz_hip_abi_version") or _lib.ygz_hip_abi_version() != ABI_VERSION:
+            got = _lib.ygz_hip_abi_version() if hasattr(_lib, "ygz_hip_abi_version") else None
+            _lib = None
+            raise ImportError("libygz_hip.so has ABI version %r, this binding was written for %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')" % (got, ABI_VERSION))
         _lib.ygz_hip_error_string.restype = C.c_char_p
         _lib.ygz_hip_kf_row_bytes.restype = C.c_size_t
     return _lib
@@ -192,14 +199,29 @@ class HipContext:
         self.width, self.height, self.levels, self.max_frames = width, height, levels, max_frames
         self.cells = self.lib.ygz_hip_max_keypoints(self._ctx)
 
+    @classmethod
+    def from_handle(cls, ptr, width, height, levels=3):
+        """a NON-OWNING view of a context somebody else created (the lanes / BA context of the C++ offline driver): close() leaves it alone"""
+        self = cls.__new__(cls)
+        self.lib = load()
+        p = Params()
+        self.lib.ygz_hip_default_params(C.byref(p))
+        p.image_width, p.image_height, p.pyramid_levels = width, height, levels
+        self.params = p
+        self._ctx = C.c_void_p(ptr)
+        self._borrowed = True
+        self.width, self.height, self.levels, self.max_frames = width, height, levels, 0
+        self.cells = self.lib.ygz_hip_max_keypoints(self._ctx)
+        return self
+
     def _chk(self, rc, what):
         if rc != OK:
             raise YgzHipError(rc, what, self.lib.ygz_hip_last_hip_error(self._ctx))
 
     def close(self):
-        if self._ctx:
+        if self._ctx and not getattr(self, "_borrowed", False):
             self.lib.ygz_hip_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+        self._ctx = C.c_void_p()
 
     def __del__(self):
         try:

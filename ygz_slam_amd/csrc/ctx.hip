@@ -284,6 +284,67 @@ int ygz_hip_wait_mark(ygz_hip_ctx *waiter, ygz_hip_ctx *signaler)
     return YGZ_OK;
 }
 
+// ---- plumbing for host code that drives several contexts and a collective library (ygz_slam_amd/host/ygz_offline.cpp): the context's
+// stream as an opaque pointer (what ncclAllGather is enqueued on), device memory for exchange buffers, copies ordered on the stream
+int ygz_hip_abi_version(void) { return YGZ_HIP_ABI_VERSION; }
+
+int ygz_hip_get_stream(ygz_hip_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return YGZ_E_INVALID;
+    *stream = (void *)ctx->stream;
+    return YGZ_OK;
+}
+
+int ygz_hip_get_device(const ygz_hip_ctx *ctx, int *device, int *compute_units)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    if (device) *device = ctx->device;
+    if (compute_units) *compute_units = ctx->n_cu;
+    return YGZ_OK;
+}
+
+// hipSetDevice(ctx's device) for the calling thread and left that way: what a collective library expects of the thread that calls it
+int ygz_hip_make_current(ygz_hip_ctx *ctx)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    YGZ_HIPCHK(ctx, hipSetDevice(ctx->device));
+    return YGZ_OK;
+}
+
+int ygz_hip_device_alloc(ygz_hip_ctx *ctx, void **out, size_t bytes)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !out || bytes == 0) return YGZ_E_INVALID;
+    *out = nullptr;
+    YGZ_HIPCHK(ctx, hipMalloc(out, bytes));
+    YGZ_HIPCHK(ctx, hipMemsetAsync(*out, 0, bytes, ctx->stream));
+    return YGZ_OK;
+}
+
+int ygz_hip_device_free(ygz_hip_ctx *ctx, void *p)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx) return YGZ_E_INVALID;
+    if (!p) return YGZ_OK;
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    YGZ_HIPCHK(ctx, hipFree(p));
+    return YGZ_OK;
+}
+
+// kind 0: host -> device, 1: device -> host, 2: device -> device; on the context's stream.  wait == 0 needs page-locked host memory that
+// stays valid until the next synchronising call.
+int ygz_hip_copy(ygz_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int kind, int wait)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !dst || !src || kind < 0 || kind > 2) return YGZ_E_INVALID;
+    if (bytes == 0) return YGZ_OK;
+    { int rj = ygz_join(ctx); if (rj != YGZ_OK) return rj; }
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+    if (wait) YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return YGZ_OK;
+}
+
 int ygz_hip_timer_begin(ygz_hip_ctx *ctx)
 {
     YgzDeviceGuard dg_(ctx);

@@ -426,6 +426,11 @@ int ygz_hip_kf_store_put(ygz_hip_ctx *store, ygz_hip_ctx *src, int n, const int3
     { int rj = ygz_join(src); if (rj != YGZ_OK) return rj; }
     for (int i = 0; i < n; ++i)
         if (src_slot[i] < 0 || src_slot[i] >= src->prm.max_frames || kf_index[i] < 0 || kf_index[i] >= store->kfs->n_kf) return YGZ_E_INVALID;
+    if (store->kfs->with_images) {
+        // every precondition of the image copy is checked BEFORE the first launch: the call either fails cleanly or enqueues all n rows
+        if (src->prm.pyramid_levels != store->prm.pyramid_levels || src->lw[0] != store->lw[0] || src->lh[0] != store->lh[0]) return YGZ_E_STATE;
+        for (int i = 0; i < n; ++i) if (!src->pyr_valid[src_slot[i]]) return YGZ_E_STATE;
+    }
     for (int b = 0; b < n; b += KF_PUT_MAX) {
         KfPutArgs A;
         A.V = kf_view(store); A.n = n - b < KF_PUT_MAX ? n - b : KF_PUT_MAX;
@@ -433,7 +438,6 @@ int ygz_hip_kf_store_put(ygz_hip_ctx *store, ygz_hip_ctx *src, int n, const int3
         for (int i = 0; i < KF_PUT_MAX; ++i) { A.slot[i] = i < A.n ? src_slot[b + i] : 0; A.kf[i] = i < A.n ? kf_index[b + i] : 0; }
         YGZ_LAUNCH(src, KID_WINDOW, k_kf_put, dim3(ygz_div_up(src->cells, 256), A.n), dim3(256), A);
         if (store->kfs->with_images) {
-            if (src->prm.pyramid_levels != store->prm.pyramid_levels || src->lw[0] != store->lw[0] || src->lh[0] != store->lh[0]) return YGZ_E_STATE;
             KfImgArgs I;
             size_t mx = 0;
             for (int L = 0; L < YGZ_MAX_LEVELS; ++L) {
@@ -443,7 +447,6 @@ int ygz_hip_kf_store_put(ygz_hip_ctx *store, ygz_hip_ctx *src, int n, const int3
             }
             I.rows = store->kfs->rows; I.row_bytes = store->kfs->row_bytes;
             for (int i = 0; i < KF_PUT_MAX; ++i) { I.slot[i] = A.slot[i]; I.kf[i] = A.kf[i]; }
-            for (int i = 0; i < A.n; ++i) if (!src->pyr_valid[I.slot[i]]) return YGZ_E_STATE;
             YGZ_LAUNCH(src, KID_WINDOW, k_kf_put_img, dim3((unsigned)((mx / 16 + 255) / 256 + 1), A.n, store->prm.pyramid_levels), dim3(256), I);
         }
     }

@@ -1,43 +1,33 @@
-"""Batched offline visual odometry (BASELINE.json configs[4]): a sequence of N frames sharded over `world` GPUs in
-contiguous chunks with a one-frame halo, the per-frame hot path run for every consecutive pair, a local-BA round per
-window of keyframes, and the two exchanges SURVEY 8e names: the refined BA-window states (map points + keyframe poses) from
-their owners to every rank, and the all-gather of per-shard trajectories.
+"""Python binding of the batched offline run (BASELINE.json configs[4]) -- the DRIVER is C++: ygz_slam_amd/host/ygz_offline.cpp in
+libygz_host.so (include/ygz_offline.h), which owns the shard, the chunk plan, the lanes, window readiness, the resident-LM launches and the
+two exchanges (RCCL directly; a host hook over gloo where two test ranks share one GPU).  This module is harness code for tests/ and
+bench.py: it renders or hands over page-locked frame buffers, calls ygz_offline_run through ctypes and turns the result arrays into the
+dictionaries the tests compare.  Rounds 2-4 drove the run from an interpreter loop here (864 lines, a dozen ABI calls per chunk through
+ctypes); that loop is gone.
 
-What runs per frame pair (cur = i, ref = i - 1), all pairs of a chunk per launch, mirrors VisualOdometry::AddFrame in state
-VO_GOOD (src/Module/VisualOdometry.cpp:62-93):
+What runs per frame pair (cur = i, ref = i - 1), all pairs of a chunk per launch, mirrors VisualOdometry::AddFrame in state VO_GOOD
+(src/Module/VisualOdometry.cpp:62-93):
     Frame::InitFrame + FeatureDetector::Detect                  (Frame.cpp:22-40, FeatureDetector.cpp:345-444)
     cv::BFMatcher(crossCheck) + the good-match filter           (test/test_orb_match.cpp:86-104)
     Tracker::TrackKLT from the reference keypoints              (Tracker.cpp:65-113)
     TrackRefFrame = Matcher::SparseImageAlignment               (VisualOdometry.cpp:281-302, Matcher.cpp:468-492)
     TrackLocalMap = FindCandidates + ProjectMapPoints (FindDirectProjection) + OptimizeCurrentPoseOnly
                                                                 (LocalMapping.cpp:24-146, BA.cpp:188-264)
-Every pair starts from T_ref = identity, so its result T_rel (pose of cur in the frame of ref) is a function of the two
-frames alone: a shard needs no pose from its neighbour, and the global trajectory T[i] = T_rel[i] * T[i-1] is chained
-after the all-gather, identically on every rank.  The reference gets Feature::_depth from map points made by its
-initialiser / triangulation (out of scope); here the sequence supplies a depth image per frame (RGB-D style),
-sampled at the keypoints ON THE DEVICE (ygz_hip_keypoint_depths_from_image).
+Every pair starts from T_ref = identity, so its result T_rel (pose of cur in the frame of ref) is a function of the two frames alone: a
+shard needs no pose from its neighbour, and the global trajectory T[i] = T_rel[i] * T[i-1] is chained after the all-gather, identically
+on every rank.  The reference gets Feature::_depth from map points made by its initialiser / triangulation (out of scope);
+here the sequence supplies a depth image per frame (RGB-D style), sampled at the keypoints ON THE DEVICE.
 
-BA round (LocalMapping::LocalBA -> ba::LocalBAG2O, LocalMapping.cpp:149-208, BA.cpp:386-543): keyframes are every
-`kf_stride`-th frame, a window = `window_kfs` consecutive keyframes owned by the rank that owns its first keyframe (the
-anchor, held fixed like keyframe 0 at BA.cpp:404); map points = the anchor's features with depth; observations (obs_mode "direct",
-the default since round 4) = what LocalMapping::ProjectMapPoints leaves in a keyframe (LocalMapping.cpp:47-120): the map point projected
-with the tracked pose, kept if in view (FindCandidates), refined to sub-pixel by Matcher::FindDirectProjection from the anchor's image --
-the keyframe rows carry the pyramids for that -- or (obs_mode "match", rounds 2-3) the good cross-checked Hamming matches of the anchor's
-descriptors in the other keyframes; after optimize(20) the edges with chi2 > 5.991 are counted as BA.cpp:503-515 does.  The windows are built ON
-THE DEVICE from a store of keyframe rows (csrc/window.hip), in the gauge of their anchor (anchor pose = identity, the other
-vertices chained from the frames' relative poses), so a window depends on its own frames only: it is built and optimised as soon
-as the chunk holding its last keyframe has been enqueued -- beside the uploads and kernels of the following chunks -- and the
-sharded run reproduces the unsharded one bit for bit.
+BA round (LocalMapping::LocalBA -> ba::LocalBAG2O, LocalMapping.cpp:149-208, BA.cpp:386-543): keyframes are every `kf_stride`-th frame, a
+window = `window_kfs` consecutive keyframes owned by the rank that owns its first keyframe (the anchor, held fixed like keyframe 0 at
+BA.cpp:404); map points = the anchor's features with depth; observations (obs_mode "direct") = what LocalMapping::ProjectMapPoints leaves in
+a keyframe (LocalMapping.cpp:47-120) or (obs_mode "match") the good cross-checked Hamming matches of the anchor's descriptors; after
+optimize(20) the edges with chi2 > 5.991 are counted as BA.cpp:503-515 does.  Windows are built ON THE DEVICE from a store of keyframe rows
+(csrc/window.hip) in the gauge of their anchor, as soon as the chunk holding their last keyframe has been enqueued.
 
-The run is driven from ONE host thread: every call on the tracking path is asynchronous (page-locked buffers, staged tables), two
-or three contexts ("lanes") take the chunks in turn so that the H2D copy of one chunk runs under the kernels of another (three: the
-copy of the next chunk is already queued when a copy ends, PCIe never waits for the host), one more context owns the keyframe
-store and the BA windows; the host blocks only when it re-uses a lane and reads that lane's 32-double-per-pair
-summary.  The ORDER of the chunks is free (chunk_plan): a chunk is a tuple of frame ranges, each with its halo frame, and on long
-shards the keyframe-free frames behind the last windows are processed at the very end, beside the last resident-LM launch.
-
-This module is host logic over the C ABI (ygz_slam_amd._lib); it never touches oracle/.
+This module never touches oracle/.
 """
+import ctypes as C
 import os as _os
 import numpy as np
 
@@ -169,128 +159,6 @@ def frame_owner(frame, n_total, world):
     raise ValueError(frame)
 
 
-def exchange_rows(buf, owner, world, pg=None, via_host=None):
-    """The map exchange: row i of `buf` (a torch tensor, in HBM on the GPU box) is owned by rank owner[i] -- owners hold contiguous
-    row ranges, windows being ordered by anchor frame --; afterwards every rank holds every owner's rows.  ONE collective
-    (all-gather of fixed-shape blocks; RCCL over xGMI with backend nccl, gloo on host copies in the CPU tests)."""
-    if world == 1:
-        return
-    import torch.distributed as dist
-    rank = dist.get_rank(pg)
-    rows = [[i for i, o in enumerate(owner) if o == r] for r in range(world)]
-    for r in rows:
-        assert r == list(range(r[0], r[-1] + 1)) if r else True
-    mine = rows[rank]
-    local = buf[mine[0]:mine[-1] + 1] if mine else buf[:0]
-    if via_host is None:
-        via_host = buf.device.type == "cpu" or dist.get_backend(pg) == "gloo"
-    g = ydist.all_gather_rows(local, [len(r) for r in rows], pg, via_host)
-    for r in range(world):
-        if r != rank and rows[r]:
-            buf[rows[r][0]:rows[r][-1] + 1] = g[r, :len(rows[r])]
-
-
-KF_SMALL = int(_os.environ.get("YGZ_OFF_KF_SMALL", "0"))     # frames of the chunk that ends with a shard's last keyframe (0: not cut; 8: -0.5 ms at 1024 frames, +1 ms at 128 / 512)
-
-
-def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0, kf_small=KF_SMALL, ramp_from=4):
-    """[first, last) cut into chunks of `chunk` frames, with a ramp at both ends (chunk / 4, chunk / 2, chunk ... chunk, chunk / 2, chunk / 4)
-    when there is room: nothing overlaps the upload of the first chunk or the kernels of the last one, so those two are kept short.
-    kf_stride > 0: the frames behind the shard's last keyframe (they complete no BA window) form a chunk of their own at the very end, so
-    that every window is complete one chunk earlier and the last resident-LM launch runs beside that chunk instead of after it"""
-    n = last - first
-    sizes = []
-    if ramp and chunk >= 64 and n >= ramp_from * chunk:
-        head = [chunk // 4, chunk // 2]
-        tail = [chunk // 2, chunk // 4]
-        body = n - sum(head) - sum(tail)
-        sizes = head + [chunk] * (body // chunk) + ([body % chunk] if body % chunk else []) + tail
-    else:
-        sizes = [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
-    out, c0 = [], first
-    for s_ in sizes:
-        out.append((c0, c0 + s_)); c0 += s_
-    assert c0 == last or n <= 0
-    if kf_stride > 0 and out:
-        a, b = out[-1]
-        k_last = ((b - 1) // kf_stride) * kf_stride                # the last keyframe of the shard
-        if a <= k_last and k_last + 1 < b and k_last + 1 > a:
-            out[-1:] = [(a, k_last + 1), (k_last + 1, b)]
-        # the chunk that ENDS with the last keyframe decides when the last resident-LM launch starts (upload of the keyframe -> the chunk's
-        # kernels -> window build -> LM, nothing hides it): kept to kf_small frames -- a chunk of 8 frames passes through the kernels in
-        # 1.6 ms, one of 26 in 2.7 (profiles/r04_offline_timeline_summary.md)
-        for k, (a, b) in enumerate(out):
-            if b == k_last + 1 and kf_small > 0 and b - a > kf_small + kf_small // 2:
-                out[k:k + 1] = [(a, b - kf_small), (b - kf_small, b)]
-                break
-    return out
-
-
-DEFER_GROUP = int(_os.environ.get("YGZ_OFF_DEFER_GROUP", "45"))      # frames per deferred chunk (about)
-DEFER_LAST_MAIN = int(_os.environ.get("YGZ_OFF_LAST_MAIN", "0"))     # > 0: the last chunk of the main pass cut to this many frames (16: + 2 ms at 1024 frames -- one more chunk for the host to hand to a busy lane)
-
-
-def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer, group=DEFER_GROUP, last_main=DEFER_LAST_MAIN):
-    """The chunks of the shard [first, last) IN PROCESSING ORDER; a chunk is a tuple of frame ranges ((a, b), ...) -- normally one.  Every
-    frame pair is solved from the identity, so the order is free; what it decides is when a BA window is complete (all frames from its anchor
-    to its last keyframe tracked) and therefore where its resident-LM launch -- a latency chain of ~5 ms that uses a fraction of the GPU --
-    falls.  The frames BEHIND a window's last keyframe (kf_stride - 1 of them, up to the next anchor) complete nothing: for the last `defer`
-    windows that end inside the shard they are taken out of the main pass and processed at the very end, about `group` frames per chunk (a
-    chunk of several short ranges: one small chunk per gap costs a pass of latency-bound kernels each), so that the last LM launch runs
-    beside their uploads and kernels instead of after everything else; the last chunk of the main pass -- the LM waits for its kernels --
-    can be cut to last_main frames (measured slower, off).  Cost: two more halo frames per deferred gap (the range after a gap and the gap itself each upload their
-    predecessor once more)."""
-    plain = [((a, b),) for a, b in chunk_schedule(first, last, chunk, ramp, kf_stride)]
-    if defer <= 0:
-        return plain
-    inside = [w for w in windows if w[0] >= first and w[-1] < last]
-    anchors = sorted(w[0] for w in windows)
-    gaps = []
-    for w in inside[-defer:]:
-        nxt = [a for a in anchors if a > w[-1]]
-        g0, g1 = w[-1] + 1, min(last, nxt[0] if nxt else last)
-        if g1 > g0 and g0 > first:
-            gaps.append((g0, g1))
-    if not gaps:
-        return plain
-    main, a = [], first
-    for g0, g1 in gaps:
-        if g0 > a:
-            main.append((a, g0))
-        a = g1
-    if a < last:
-        main.append((a, last))
-    # the main pass: the schedule of a shard of n_main frames (ramp at both ends), its intervals mapped back onto the ranges that are left
-    n_main = sum(b - a for a, b in main)
-    virt = chunk_schedule(0, n_main, chunk, ramp, 0, ramp_from=3)
-    if last_main > 0 and virt and virt[-1][1] - virt[-1][0] > last_main + last_main // 2:
-        v0, v1 = virt[-1]
-        virt[-1:] = [(v0, v1 - last_main), (v1 - last_main, v1)]
-    out = []
-    for v0, v1 in virt:
-        rs, pos = [], 0
-        for a, b in main:
-            lo, hi = max(v0, pos), min(v1, pos + (b - a))
-            if hi > lo:
-                rs.append((a + lo - pos, a + hi - pos))
-            pos += b - a
-        out.append(tuple(rs))
-    # the deferred gaps: whole gaps (a split gap would need one more halo frame), in n_groups chunks of about `group` frames each
-    tot = sum(b - a for a, b in gaps)
-    n_groups = max(1, int(round(tot / float(max(1, group)))))
-    per = -(-len(gaps) // n_groups)
-    for k in range(0, len(gaps), per):
-        ch = []
-        for g0, g1 in gaps[k:k + per]:
-            while g1 - g0 > chunk:                                 # (a gap longer than a chunk)
-                out.append(((g0, g0 + chunk),)); g0 += chunk
-            ch.append((g0, g1))
-        while sum(b - a for a, b in ch) > chunk:                   # (never more than `chunk` frames per chunk)
-            out.append((ch.pop(0),))
-        out.append(tuple(ch))
-    return out
-
-
 def depth_image(d, div=1, dtype=np.float64, scale=1.0 / 5000.0):
     """depth map of the sequence (metres) -> the image the device samples: every div-th sample as float64 / float32 metres or, for
     uint16, round(depth / scale) (TUM RGB-D: scale = 1 / 5000)"""
@@ -311,134 +179,251 @@ def depth_at(dimg, px, w, h, scale=1.0 / 5000.0):
     return np.where(d > 0, d, 0.0)
 
 
-class _Traced:
-    """debug aid (YGZ_OFFLINE_TRACE=1): times every ABI call of a context on the host -- a call that blocks shows up here"""
+# ---- the chunk plan: host logic of the C++ driver (ygz_offline_plan_range), exposed for the CPU tests ------------------------------------
+def _plan_range(first, last, chunk, ramp, kf_stride, windows, defer):
+    lib = host_lib()
+    wfl = np.ascontiguousarray([[w[0], w[-1]] for w in windows], np.int32).reshape(-1, 2)
+    cap = max(64, 2 * (last - first) + 64)
+    out = np.zeros((cap, 3), np.int32)
+    n = C.c_int(0)
+    rc = lib.ygz_offline_plan_range(int(first), int(last), int(chunk), int(bool(ramp)), int(kf_stride), wfl.ctypes.data_as(C.POINTER(C.c_int32)), len(wfl),
+                                    int(defer), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("ygz_offline_plan_range failed: %d" % rc)
+    plan = {}
+    for ci, a, b in out[:n.value].tolist():
+        plan.setdefault(ci, []).append((a, b))
+    return [tuple(plan[k]) for k in sorted(plan)]
 
-    def __init__(self, obj, log, tag):
-        object.__setattr__(self, "_o", obj); object.__setattr__(self, "_log", log); object.__setattr__(self, "_tag", tag)
 
-    def __getattr__(self, name):
-        a = getattr(self._o, name)
-        if not callable(a):
-            return a
-        import time
+def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
+    """[first, last) in chunks of `chunk` frames with short chunks at both ends; kf_stride > 0: the frames behind the last keyframe form the
+    last chunk (ygz_offline.cpp: chunk_schedule)"""
+    return [ch[0] for ch in _plan_range(first, last, chunk, ramp, kf_stride, [], 0)]
 
-        def call(*args, **kw):
-            args = tuple(x._o if isinstance(x, _Traced) else x for x in args)
-            t0 = time.perf_counter()
-            r = a(*args, **kw)
-            self._log.append((self._tag + "." + name, t0, time.perf_counter()))
-            return r
-        return call
+
+def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
+    """the chunks of the shard [first, last) in processing order, a chunk = a tuple of frame ranges (ygz_offline.cpp: chunk_plan)"""
+    return _plan_range(first, last, chunk, ramp, kf_stride, windows, defer)
+
+
+# ---- ctypes mirror of include/ygz_offline.h ------------------------------------------------------------------------------------------------
+class OffParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("levels", C.c_int), ("n_frames", C.c_int), ("rank", C.c_int), ("world", C.c_int),
+                ("device", C.c_int), ("chunk", C.c_int), ("kf_stride", C.c_int), ("window_kfs", C.c_int), ("max_points", C.c_int),
+                ("ba_iterations", C.c_int), ("lanes", C.c_int), ("lm_group", C.c_int), ("obs_mode", C.c_int), ("ba_rounds", C.c_int),
+                ("outlier_chi2", C.c_double), ("frame_channels", C.c_int), ("depth_w", C.c_int), ("depth_h", C.c_int), ("depth_kind", C.c_int),
+                ("depth_scale", C.c_double), ("pipeline_ba", C.c_int), ("defer_gaps", C.c_int), ("ramp", C.c_int), ("kf_tail", C.c_int),
+                ("stage_overlap", C.c_int), ("bg_team_budget", C.c_int)]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+SEND_RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int)
+CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32))
+
+
+class OffExchange(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", ALL_GATHER_FN), ("send_recv", SEND_RECV_FN)]
+
+
+class OffResults(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("first_frame", C.c_int), ("n_own", C.c_int), ("T_rel", C.POINTER(C.c_double)), ("trajectory", C.POINTER(C.c_double)),
+                ("summary", C.POINTER(C.c_double)), ("n_kp", C.POINTER(C.c_int32)), ("n_windows", C.c_int), ("state_doubles", C.c_int),
+                ("window_state", C.POINTER(C.c_double)), ("window_owner", C.POINTER(C.c_int32)), ("window_kfs", C.POINTER(C.c_int32)),
+                ("n_chunks", C.c_int), ("lm_launches", C.c_int), ("lm_retries", C.c_int), ("n_degenerate", C.c_int),
+                ("ms_track", C.c_double), ("ms_gather", C.c_double), ("ms_ba_tail", C.c_double), ("ms_exchange", C.c_double), ("backend", C.c_int)]
+
+
+OFFLINE_SYMBOLS = ["ygz_offline_default_params", "ygz_offline_shard", "ygz_offline_plan", "ygz_offline_plan_range", "ygz_offline_ragged_all_gather",
+                   "ygz_offline_rccl_unique_id", "ygz_offline_create", "ygz_offline_destroy", "ygz_offline_last_error", "ygz_offline_run", "ygz_offline_track",
+                   "ygz_offline_gather", "ygz_offline_ba_round", "ygz_offline_get_results", "ygz_offline_set_chunk_callback", "ygz_offline_contexts",
+                   "ygz_offline_owned_windows", "ygz_offline_build_windows", "ygz_offline_retry_windows"]
+HOST_LIB_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libygz_host.so")
+_host = None
+
+
+def host_lib():
+    """libygz_host.so (the C++ class surfaces + the offline driver); raises if it has not been built"""
+    global _host
+    if _host is None:
+        from . import _lib
+        _lib.load()                                            # libygz_hip.so first (and torch's HIP runtime before it, see _lib.load)
+        if not _os.path.exists(HOST_LIB_PATH):
+            raise ImportError("libygz_host.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _host = C.CDLL(HOST_LIB_PATH)
+        _host.ygz_offline_last_error.restype = C.c_char_p
+        _host.ygz_offline_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _host.ygz_offline_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        for f in ("ygz_offline_gather", "ygz_offline_ba_round"):
+            getattr(_host, f).argtypes = [C.c_void_p]
+        _host.ygz_offline_destroy.argtypes = [C.c_void_p]
+        _host.ygz_offline_destroy.restype = None
+        _host.ygz_offline_last_error.argtypes = [C.c_void_p]
+        _host.ygz_offline_get_results.argtypes = [C.c_void_p, C.POINTER(OffResults)]
+        _host.ygz_offline_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(OffParams), C.c_void_p, C.POINTER(OffExchange)]
+        _host.ygz_offline_set_chunk_callback.argtypes = [C.c_void_p, CHUNK_FN, C.c_void_p]
+        _host.ygz_offline_contexts.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+        _host.ygz_offline_owned_windows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]
+        _host.ygz_offline_build_windows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _host.ygz_offline_retry_windows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+        _host.ygz_offline_ragged_all_gather.argtypes = [C.POINTER(OffExchange), C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_size_t, C.c_void_p, C.c_void_p]
+        _host.ygz_offline_rccl_unique_id.argtypes = [C.c_void_p]
+    return _host
+
+
+def gloo_exchange(pg=None):
+    """the two exchange primitives of include/ygz_offline.h over torch.distributed on host memory (gloo): what the tests hand to the C++
+    driver where RCCL cannot run (two ranks on one GPU, no GPU at all).  Returns (OffExchange, keep-alive tuple)."""
+    import torch
+    import torch.distributed as dist
+
+    def _view(ptr, n):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)))
+
+    def all_gather(_user, send, recv, nbytes):
+        try:
+            world = dist.get_world_size(pg)
+            dist.all_gather(list(_view(recv, nbytes * world).view(world, nbytes).unbind(0)), _view(send, nbytes), group=pg)
+            return 0
+        except Exception as e:                                   # an exception must not cross the C boundary
+            print("gloo_exchange.all_gather: %r" % (e,))
+            return 1
+
+    def send_recv(_user, buf, nbytes, src, dst):
+        try:
+            t = _view(buf, nbytes)
+            if dist.get_rank(pg) == src:
+                dist.send(t, dst, group=pg)
+            else:
+                dist.recv(t, src, group=pg)
+            return 0
+        except Exception as e:
+            print("gloo_exchange.send_recv: %r" % (e,))
+            return 1
+    ag, sr = ALL_GATHER_FN(all_gather), SEND_RECV_FN(send_recv)
+    return OffExchange(None, ag, sr), (ag, sr)
+
+
+def ragged_all_gather(local, counts, pg=None):
+    """ygz_offline_ragged_all_gather over gloo: rank r contributes counts[r] rows (`local`, a C-contiguous numpy array [counts[rank], ...]);
+    returns the concatenation in rank order.  One collective of blocks padded to max(counts) rows -- the exchange the C++ driver performs
+    for T_rel and for the window states."""
+    import torch.distributed as dist
+    hook, keep = gloo_exchange(pg)
+    rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+    local = np.ascontiguousarray(local)
+    row_bytes = int(np.prod(local.shape[1:])) * local.dtype.itemsize
+    cnt = np.ascontiguousarray(counts, np.int32)
+    assert len(cnt) == world and local.shape[0] == cnt[rank]
+    full = np.zeros((int(cnt.sum()),) + tuple(local.shape[1:]), local.dtype)
+    rc = host_lib().ygz_offline_ragged_all_gather(C.byref(hook), rank, world, cnt.ctypes.data_as(C.POINTER(C.c_int32)), row_bytes,
+                                                 C.c_void_p(local.ctypes.data), C.c_void_p(full.ctypes.data))
+    if rc != 0:
+        raise RuntimeError("ygz_offline_ragged_all_gather failed: %d" % rc)
+    del keep
+    return full
+
+
+_DEPTH_KIND = {np.dtype(np.float32): 0, np.dtype(np.uint16): 1, np.dtype(np.float64): 2}
 
 
 class OfflineVO:
-    """One rank of the offline run.  frame_source(i) -> BGR uint8 [h, w, 3] (or gray [h, w]); depth_source(i) -> depth map [h, w]
-    (metres).  block_source(frames) -> (frames [n, h, w, 3] or [n, h, w] uint8, depth images [n, dh, dw]) replaces the per-frame
-    sources when the caller holds the sequence in page-locked memory in the form the ABI uploads (then every copy is asynchronous).
-    depth_div / depth_dtype: the depth image handed to the device is depth_source(i)[::depth_div, ::depth_div] as float64 / float32
-    metres or, for uint16, round(depth / depth_scale) (TUM RGB-D: depth_scale = 1 / 5000)."""
+    """One rank of the offline run: a handle of the C++ driver (ygz_offline_create) plus the page-locked frame buffers it reads.
+    frame_source(i) -> BGR uint8 [h, w, 3] (or gray [h, w] with gray=True); depth_source(i) -> depth map [h, w] (metres): rendered into
+    page-locked memory before the run.  block_source(frames) -> (frames [n, h, w(, 3)] uint8, depth images [n, dh, dw]) replaces them when the
+    caller already holds the sequence in page-locked memory in the form the ABI uploads: it is asked ONCE for all frames this rank needs and
+    must return views of contiguous page-locked arrays.  keep=True: after every chunk everything a parity test wants to look at is read from
+    the chunk's lane through the C ABI (ygz_offline_set_chunk_callback)."""
 
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
                  max_points=2000, ba_iterations=20, overlap=False, process_group=None, exchange_on_device=True, keep=False, lanes=3,
-                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None, upload_ahead=0,
-                 obs_mode="direct", ba_rounds=1, outlier_chi2=5.991):
+                 depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None,
+                 obs_mode="direct", ba_rounds=1, outlier_chi2=5.991, gray=False, defer_gaps=None, bg_team_budget=0, rccl_single=False):
         from . import _lib
-        self.lib = _lib
-        self.w, self.h, self.levels = width, height, levels
-        self.n_total, self.rank, self.world = n_total, rank, world
-        self.chunk, self.kf_stride, self.window_kfs = chunk, kf_stride, window_kfs
-        self.max_points, self.ba_iterations = max_points, ba_iterations
-        self.overlap, self.pg, self.exchange_on_device, self.keep = overlap, process_group, exchange_on_device, keep
-        self.depth_div, self.depth_dtype, self.depth_scale = depth_div, np.dtype(depth_dtype), depth_scale
-        self.pipeline_ba, self.lm_group = pipeline_ba, lm_group
-        # observations of a window's map points in its keyframes: "direct" = what LocalMapping::ProjectMapPoints leaves in a keyframe
-        # (projection with the tracked pose + FindDirectProjection from the anchor's image, LocalMapping.cpp:47-120) -- the keyframe rows
-        # then carry the images; "match" = good cross-checked Hamming matches of the anchor's descriptors (rounds 2-3).  After the LM the
-        # edges above outlier_chi2 are counted (BA.cpp:503-515); ba_rounds = 2 switches them off and optimises once more (what the next
-        # LocalBAG2O of the reference sees after Feature::_bad was set).
+        self.lib, self.h_lib = _lib, host_lib()
         assert obs_mode in ("direct", "match") and ba_rounds in (1, 2)
-        self.obs_mode, self.ba_rounds, self.outlier_chi2 = obs_mode, ba_rounds, outlier_chi2
-        import os as _os
-        self.fifo_uploads = _os.environ.get("YGZ_OFF_FIFO", "1") != "0"
-        self.ramp = _os.environ.get("YGZ_OFF_RAMP", "1") != "0"
-        self.kf_tail = _os.environ.get("YGZ_OFF_KF_TAIL", "1") != "0"
-        # the keyframe-free frames behind the last keyframe of the last `defer_gaps` windows of the shard are processed at the very end
-        # (chunk_plan), so that the last LM launch has company: on by default for long shards (>= 768 frames: 60.6 -> 59.2 ms at 1024 frames
-        # with 13 gaps; 16 gaps 59.6), off for short ones (512 frames: + 2 ms; 128: + 0.7 ms -- two more halo frames per gap and the ramp of
-        # the main pass cost more than the LM tail they hide).  One chunk PER gap (first form of the experiment) lost 5 ms: latency-bound
-        # small chunks
+        self.w, self.h, self.levels = width, height, levels
+        self.n_total, self.rank, self.world, self.device = n_total, rank, world, device
+        self.chunk, self.kf_stride, self.window_kfs, self.max_points = chunk, kf_stride, window_kfs, max_points
+        self.pg, self.keep, self.gray, self.obs_mode = process_group, keep, gray, obs_mode
+        self.depth_div, self.depth_dtype, self.depth_scale = depth_div, np.dtype(depth_dtype), depth_scale
         self.start, self.count, self.halo = ydist.shard_frames(n_total, rank, world)
-        self.defer_gaps = int(_os.environ.get("YGZ_OFF_DEFER", "-1"))
-        if self.defer_gaps < 0:
-            self.defer_gaps = 13 if self.count >= 768 else 0
-        self.device = device
-        # the chunks of this shard in processing order (chunk_plan); a chunk's frames and the halo frame in front of each of its ranges take
-        # consecutive slots of a lane
         self.wins = ba_windows(n_total, kf_stride, window_kfs)
-        self.chunks = chunk_plan(self.start, self.start + self.count, chunk, self.ramp, kf_stride if self.kf_tail else 0, self.wins,
-                                 self.defer_gaps if pipeline_ba else 0)
-        n_slots = max([sum(b - a + (1 if a > 0 else 0) for a, b in ch) for ch in self.chunks] + [2])
-        n_lanes = max(1, min(lanes, len(self.chunks)))                            # never more lanes than chunks
-        # `depth` chunks compute at a time; with upload_ahead > 0 there are more contexts than that, and the kernels of chunk i wait for
-        # chunk i - depth while its upload (first in its stream) does not: the link runs ahead of the kernels by upload_ahead chunks
-        self.depth = n_lanes
-        if n_lanes == lanes:
-            n_lanes += max(0, int(_os.environ.get("YGZ_OFF_AHEAD", upload_ahead)))
-        self.lanes = []
-        for _ in range(n_lanes):
-            c = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(n_slots, 2), device=device)
-            c.set_overlap(overlap)
-            self.lanes.append(c)
-        self.ctx = self.lanes[0]
-        # windows, owners; the third context holds the keyframe store and the BA windows of this rank
         self.owner = [frame_owner(w[0], n_total, world) for w in self.wins]
         self.mine = [i for i, o in enumerate(self.owner) if o == rank]
-        last = self.start + self.count
-        self.local = [i for i in self.mine if self.wins[i][-1] < last]            # every keyframe tracked by this rank
-        self.any_cross = any(frame_owner(w[-1], n_total, world) != o for w, o in zip(self.wins, self.owner))
-        self.n_kf = len(keyframes(n_total, kf_stride))
-        K1 = max(1, window_kfs - 1)
-        self.build_group = max(1, min(len(self.mine), 16))                       # windows per build call (matcher rows: group x (K - 1) pairs)
-        if self.lm_group is None:
-            # windows per resident-LM launch.  A launch takes 8-9 ms whether it holds one window or eight (latency-bound) and the launches
-            # queue on one stream, so they only hide behind the tracking of the following chunks if there are few of them: half of this
-            # rank's windows per launch (at most 8) on a long shard, all of them in one launch on a short one
-            self.lm_group = min(8, len(self.mine) // 2) if self.count > 256 else min(8, len(self.mine))
-        self.lm_group = max(1, self.lm_group)
-        self.bg_team_budget = int(_os.environ.get("YGZ_OFF_BG_BUDGET", "0"))
-        self.lm_sched = [max(1, int(x)) for x in _os.environ.get("YGZ_OFF_LM_SCHED", "").split(",") if x.strip()]
-        self.ba = _lib.HipContext(width=width, height=height, levels=levels, max_frames=max(8, self.build_group * K1), device=device)
-        self.rows_t = None
-        if world > 1 and self.any_cross:                                          # rows of other ranks arrive by a collective: torch owns the memory
-            import torch
-            rb = self.ba.kf_row_bytes(self.obs_mode == "direct")
-            self.rows_t = torch.zeros((self.n_kf + self.build_group) * rb, dtype=torch.uint8, device=torch.device("cuda", device))
-            self.ba.kf_store_create(self.n_kf, n_total, self.build_group, self.rows_t.data_ptr(), self.rows_t.numel(), with_images=self.obs_mode == "direct")
-        else:
-            self.ba.kf_store_create(self.n_kf, n_total, self.build_group, with_images=self.obs_mode == "direct")
-        if self.mine:
-            self.ba.ba_reserve_windows(0, len(self.mine), window_kfs, max_points)
-        self.trace = None
-        import os
-        if os.environ.get("YGZ_OFFLINE_TRACE") == "1":
-            self.trace = []
-            self.lanes = [_Traced(c, self.trace, "lane%d" % i) for i, c in enumerate(self.lanes)]
-            self.ctx = self.lanes[0]
-            self.ba = _Traced(self.ba, self.trace, "ba")
-        self.S = 6 * window_kfs + 3 * max_points + 12                             # one window state row: poses | points | K P E its trials chi2_0 chi2 lambda | edges tested, outliers, chi2, chi2 of inliers
-        # page-locked result rows (per-pair summary, keypoint counts), one set per chunk
-        self._pin = [dict(sum=_lib.PinnedArray((max(2, sum(b - a + 1 for a, b in ch)), _lib.SUMMARY_FIELDS), np.float64),
-                          cnt=_lib.PinnedArray((max(2, sum(b - a + 1 for a, b in ch)),), np.int32)) for ch in self.chunks]
-        self.run_ahead = int(os.environ.get("YGZ_OFF_RUN_AHEAD", "0"))          # chunks enqueued beyond one per lane before the oldest is collected (experiment; 99 = all)
-        self.timing = {}
+        self.dh, self.dw = -(-height // depth_div), -(-width // depth_div)
+        p = OffParams()
+        self.h_lib.ygz_offline_default_params(C.byref(p))
+        p.width, p.height, p.levels, p.n_frames, p.rank, p.world, p.device = width, height, levels, n_total, rank, world, device
+        p.chunk, p.kf_stride, p.window_kfs, p.max_points, p.ba_iterations = chunk, kf_stride, window_kfs, max_points, ba_iterations
+        p.lanes, p.lm_group, p.obs_mode, p.ba_rounds, p.outlier_chi2 = lanes, int(lm_group or 0), 1 if obs_mode == "direct" else 0, ba_rounds, outlier_chi2
+        p.frame_channels, p.depth_w, p.depth_h, p.depth_kind, p.depth_scale = (1 if gray else 3), self.dw, self.dh, _DEPTH_KIND[self.depth_dtype], depth_scale
+        p.pipeline_ba, p.defer_gaps, p.stage_overlap, p.bg_team_budget = int(pipeline_ba), (-1 if defer_gaps is None else int(defer_gaps)), int(overlap), int(bg_team_budget)
+        self.params = p
+        self._keepalive = []
+        hook_p, rccl_id = None, None
+        if world > 1:
+            import torch.distributed as dist
+            if exchange_on_device:
+                # RCCL directly from the C++ driver; torch.distributed only carries the 128-byte ncclUniqueId from rank 0 to the others (bootstrap)
+                ident = [None]
+                if rank == 0:
+                    buf = C.create_string_buffer(128)
+                    rc = self.h_lib.ygz_offline_rccl_unique_id(buf)
+                    if rc != 0:
+                        raise RuntimeError("ygz_offline_rccl_unique_id failed: %d (librccl.so.1 not loadable?)" % rc)
+                    ident = [bytes(buf.raw)]
+                dist.broadcast_object_list(ident, src=0, group=process_group)
+                rccl_id = C.create_string_buffer(ident[0], 128)
+            else:
+                hook, ka = gloo_exchange(process_group)
+                self._keepalive += [hook, ka]
+                hook_p = C.byref(hook)
+        elif rccl_single:                                         # a communicator of one rank: the RCCL path of the driver on a single GPU (tests)
+            rccl_id = C.create_string_buffer(128)
+            rc = self.h_lib.ygz_offline_rccl_unique_id(rccl_id)
+            if rc != 0:
+                raise RuntimeError("ygz_offline_rccl_unique_id failed: %d (librccl.so.1 not loadable?)" % rc)
+        self._h = C.c_void_p()
+        rc = self.h_lib.ygz_offline_create(C.byref(self._h), C.byref(p), rccl_id, hook_p)
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise _lib.YgzHipError(rc, "ygz_offline_create")
+        ba, nl = C.c_void_p(), C.c_int(0)
+        lanes_p = (C.c_void_p * 16)()
+        self._chk(self.h_lib.ygz_offline_contexts(self._h, C.byref(ba), lanes_p, 16, C.byref(nl)), "contexts")
+        mk = lambda ptr: _lib.HipContext.from_handle(ptr, width, height, levels)
+        self.ba = mk(ba.value)
+        self.lanes = [mk(lanes_p[i]) for i in range(nl.value)]
+        self.ctx = self.lanes[0]
+        self.S = 6 * window_kfs + 3 * max_points + 12
+        self.lm_group = lm_group
+        self.timing, self.degenerate_windows, self.lm_retries = {}, [], 0
+        self._pin = None
+        self._rec_extra = {}
+        if keep:
+            self._cb = CHUNK_FN(self._on_chunk)
+            self._chk(self.h_lib.ygz_offline_set_chunk_callback(self._h, self._cb, None), "set_chunk_callback")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.h_lib.ygz_offline_last_error(self._h) if self._h else b""
+            raise RuntimeError("ygz_offline %s failed: %d (%s)" % (what, rc, (msg or b"").decode()))
 
     def close(self):
-        for c in self.lanes:
-            c.close()
-        self.ba.close()
-        for p in self._pin:
-            p["sum"].free(); p["cnt"].free()
+        if self._h:
+            self.h_lib.ygz_offline_destroy(self._h)
+            self._h = C.c_void_p()
+        if self._pin is not None:
+            for a in self._pin:
+                a.free()
+            self._pin = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ depth images
     def depth_image(self, d):
@@ -447,310 +432,137 @@ class OfflineVO:
     def depth_at(self, dimg, px):
         return depth_at(dimg, px, self.w, self.h, self.depth_scale)
 
-    # ------------------------------------------------------------------ phase 1: the hot path over this shard (+ the BA windows it completes)
-    def track_shard(self, frame_source, depth_source, block_source=None):
-        """The hot path over the frames this rank owns, chunk by chunk on alternating lanes; returns per-frame records.  Per chunk:
-        one upload of the frames and depth images, the batched kernels, the keyframes' rows and the pairs' relative poses into the
-        store (device to device), one download of the per-pair summary -- no host round trip in between.  Windows whose keyframes
-        are all in are built and optimised on the third context while the next chunks run (pipeline_ba)."""
-        rec = {}
-        first, last = self.start, self.start + self.count
-        chunks = self.chunks
-        tracked = np.zeros(self.n_total, bool)
-        pending = []
-        self._ba_done, self._ba_built = set(), []
-        self._lm_launches = 0
-        self._last_upload = None
-        for ci, ranges in enumerate(chunks):
-            # the host hands a lane its next chunk when it has read the results of the lane's previous one: `lanes` chunks are in flight.
-            # (YGZ_OFF_RUN_AHEAD=99 enqueues every chunk at once -- every chunk has its own page-locked result rows, a lane's stream orders
-            # the upload of its next chunk behind the kernels of its previous one.  Measured SLOWER, 63.6 against 59.8 ms per 1024 frames and
-            # 46.7 against 42.1 with gray frames: with everything queued the resident-LM teams and the tracking kernels of three lanes compete
-            # for the CUs -- the LM launch beside the tracking takes 8.6 instead of 5.6 ms and uploads wait behind kernels.)
-            li = ci % len(self.lanes)
-            while len(pending) >= len(self.lanes) + self.run_ahead:
-                self._collect(*pending.pop(0), rec)
-            info = self._enqueue(li, ranges, frame_source, depth_source, block_source, ci)
-            if self.keep:                                      # parity runs read everything back before the lane moves on
-                self._collect(li, info, rec)
-            else:
-                pending.append((li, info))
-            if self.pipeline_ba:
-                # windows whose keyframes are all in: built at once (a matcher launch and two small kernels); the resident LM is a latency-
-                # bound kernel that takes as long for two windows as for eight, so it is launched per lm_group windows (and for the rest
-                # after the last chunk): its launches then fit beside the tracking of the following chunks instead of queueing up
-                for c0, c1 in ranges:
-                    tracked[c0:c1] = True
-                new = [i for i in self.local if i not in self._ba_done and i not in self._ba_built and tracked[self.wins[i][0]:self.wins[i][-1] + 1].all()]
-                self._ba_launch(new, optimize=False)
-                self._ba_built += new
-                all_built = len(self._ba_done) + len(self._ba_built) == len(self.local)     # nothing more will come: the last launch need not wait for the last chunk
-                if self._ba_built and (len(self._ba_built) >= self._lm_next() or ci == len(chunks) - 1 or all_built):
-                    # beside the tracking of the next chunks a launch keeps to a few CUs (its members each own one, and wait for it while a
-                    # tracking workgroup drains); the last launch, which nothing runs beside, takes the default half of the device
-                    self.ba.ba_set_team_budget(self.bg_team_budget if ci < len(chunks) - 1 and not all_built else 0)
-                    self._ba_optimize(self._ba_built)
-                    self._ba_built = []
-                    self._lm_launches += 1
-        for li, info in pending:
-            self._collect(li, info, rec)
-        return rec
+    # ------------------------------------------------------------------ frame buffers
+    def _buffers(self, frame_source, depth_source, block_source):
+        """(frames, depth images, sequence index of row 0): page-locked arrays covering [start - halo, start + count)"""
+        need = list(range(self.start - self.halo, self.start + self.count))
+        if block_source is not None:
+            img, dimg = block_source(need)
+            assert img.flags["C_CONTIGUOUS"] and dimg.flags["C_CONTIGUOUS"] and img.dtype == np.uint8 and dimg.dtype == self.depth_dtype
+            assert img.shape == ((len(need), self.h, self.w) if self.gray else (len(need), self.h, self.w, 3)) and dimg.shape == (len(need), self.dh, self.dw)
+            return img, dimg, need[0]
+        if self._pin is None:
+            self._pin = [self.lib.PinnedArray((len(need), self.h, self.w) if self.gray else (len(need), self.h, self.w, 3), np.uint8),
+                         self.lib.PinnedArray((len(need), self.dh, self.dw), self.depth_dtype)]
+        for k, f in enumerate(need):
+            self._pin[0].array[k] = frame_source(f)
+            self._pin[1].array[k] = self.depth_image(depth_source(f))
+        return self._pin[0].array, self._pin[1].array, need[0]
 
-    def _lm_next(self):
-        """windows the next resident-LM launch waits for: lm_group, or the k-th entry of the schedule (YGZ_OFF_LM_SCHED, experiment)"""
-        if self.lm_sched:
-            return self.lm_sched[min(self._lm_launches, len(self.lm_sched) - 1)]
-        return self.lm_group
-
-    def _enqueue(self, li, ranges, frame_source, depth_source, block_source, ci=0):
-        """one chunk = the frame ranges `ranges`, each with a one-frame halo (its predecessor) in front; the ranges take consecutive slots"""
-        c = self.lanes[li]
-        asyn = block_source is not None
-        frames, spans = [], []                                    # spans: (first slot, frames of the range incl. halo)
-        for c0, c1 in ranges:
-            fr = list(range(c0 - 1, c1)) if c0 > 0 else list(range(c0, c1))
-            spans.append((len(frames), fr)); frames += fr
-        assert len(set(frames)) == len(frames)                    # (ranges of a chunk are not adjacent: chunk_plan merges those)
-        slot_of = {f: k for k, f in enumerate(frames)}
-        n = len(frames)
-        if self._last_upload is not None and self.fifo_uploads:
-            c.wait_mark(self._last_upload)                     # uploads cross PCIe one after the other, each at the full rate
-        keep_dimg = []
-        for s0, fr in spans:
-            if asyn:
-                img, dimg = block_source(fr)
-            else:
-                img = np.ascontiguousarray(np.stack([frame_source(f) for f in fr]))
-                dimg = np.ascontiguousarray(np.stack([self.depth_image(depth_source(f)) for f in fr]))
-            if img.ndim == 3:                                  # [n, h, w]: the caller converted to gray (a third of the PCIe bytes)
-                c.upload_gray_batch(s0, img, wait=not asyn)
-            else:
-                c.upload_bgr_batch(s0, img, wait=not asyn)
-            c.upload_depth_batch(s0, dimg, self.depth_scale, wait=not asyn)
-            from_bgr = img.ndim != 3
-            if self.keep:
-                keep_dimg.append(dimg)
-        c.mark(); self._last_upload = c
-        if len(self.lanes) > self.depth and ci >= self.depth:
-            c.stream_wait(self.lanes[(ci - self.depth) % len(self.lanes)])      # at most `depth` chunks' kernels share the GPU
-        c.build_pyramid(0, n, from_bgr=from_bgr)
-        c.detect(0, n)
-        c.keypoint_depths_from_image(0, n)                     # Feature::_depth / _mappoint of the fresh keypoints
-        pairs = [(f, f - 1) for c0, c1 in ranges for f in range(c0, c1) if f - 1 in slot_of]
-        if pairs:
-            q = [slot_of[a] for a, _ in pairs]
-            t = [slot_of[b] for _, b in pairs]
-            ident = np.tile(I7, (len(pairs), 1))
-            c.match_slots(q, t, 1)
-            c.match_postfilter()
-            c.track_begin(q, t, ident, ident, predict=False)
-            c.track_sparse_align()
-            c.track_klt()
-            c.track_adopt_pose()
-            c.track_direct()
-            c.track_pose_only()
-            c.track_get_summary(out=self._pin[ci]["sum"].array, wait=False)
-            p0 = 0
-            while p0 < len(pairs):                             # runs of consecutive frames (one per range)
-                p1 = p0 + 1
-                while p1 < len(pairs) and pairs[p1][0] == pairs[p1 - 1][0] + 1:
-                    p1 += 1
-                self.ba.kf_store_put_trel(c, p0, p1 - p0, pairs[p0][0])
-                p0 = p1
-        c.get_keypoint_counts(0, n, out=self._pin[ci]["cnt"].array, wait=False)
-        kf = [f for c0, c1 in ranges for f in range(c0, c1) if f % self.kf_stride == 0]
-        if kf:
-            self.ba.kf_store_put(c, [slot_of[f] for f in kf], [f // self.kf_stride for f in kf])
-        return dict(ranges=ranges, frames=frames, slot_of=slot_of, pairs=pairs, pin=self._pin[ci], dimg=np.concatenate(keep_dimg) if self.keep else None)
-
-    def _collect(self, li, info, rec):
-        """wait for the lane, then read its chunk's results out of the page-locked buffers"""
-        c = self.lanes[li]
-        c.synchronize()
-        S = info["pin"]["sum"].array[:len(info["pairs"])].copy()
-        cnt = info["pin"]["cnt"].array[:len(info["frames"])].copy()
-        slot_of = info["slot_of"]
-        for f in (f for c0, c1 in info["ranges"] for f in range(c0, c1)):
-            k = slot_of[f]
-            r = dict(n_kp=int(cnt[k]))
-            if self.keep:
+    # ------------------------------------------------------------------ keep=True: everything a parity test wants to look at, per chunk
+    def _on_chunk(self, _user, lane_ptr, _chunk, n_frames, frames_p, n_pairs, pairs_p):
+        try:
+            c = self.lib.HipContext.from_handle(lane_ptr, self.w, self.h, self.levels)
+            frames = [frames_p[i] for i in range(n_frames)]
+            proper = {pairs_p[2 * p] for p in range(n_pairs)} | {0}    # a frame of the chunk proper is the `cur` of a pair (or frame 0); the others are halo frames
+            for k, f in enumerate(frames):
                 kp = c.get_keypoints(k)
                 kp["depth"], has_mp = c.get_keypoint_depths(k)
-                assert np.array_equal(kp["depth"], self.depth_at(info["dimg"][k], kp["px"])) and np.array_equal(has_mp, kp["depth"] > 0)   # the device's look-up
-                r["kp"] = kp
-            rec[f] = r
-        for p, (cur, ref) in enumerate(info["pairs"]):
-            r = rec[cur]
-            r.update(T_sa=S[p, 0:7].copy(), sa_n_meas=int(S[p, 7]), T_rel=S[p, 24:31].copy(), po_inliers=int(S[p, 14]),
-                     po_rounds=int(S[p, 15]), n_match=int(S[p, 16]), n_good=int(S[p, 17]), min_dis=float(S[p, 18]),
-                     n_klt=int(S[p, 19]), n_fdp=int(S[p, 20]))
-            if self.keep:                      # everything a parity test wants to look at
+                assert np.array_equal(kp["depth"], self.depth_at(self._dimg[f - self._base], kp["px"])) and np.array_equal(has_mp, kp["depth"] > 0)   # the device's look-up
+                if f in proper:
+                    self._rec_extra.setdefault(f, {})["kp"] = kp
+            for p in range(n_pairs):
+                cur = pairs_p[2 * p]
                 n_meas, T_sa, iters = c.track_get_pose(p)
                 po = c.track_get_pose_only(p)
                 good, n_good, min_dis = c.get_good_matches(p)
                 idx, dist_ = c.get_matches(p)
                 pts, st, err = c.track_get_klt(p)
                 ok, pxd, lvl = c.track_get_direct(p)
-                assert np.array_equal(T_sa, r["T_sa"]) and np.array_equal(po["T"], r["T_rel"]) and n_good == r["n_good"]
-                assert int(st.astype(bool).sum()) == r["n_klt"] and int(ok.sum()) == r["n_fdp"] and int((idx >= 0).sum()) == r["n_match"]
-                r.update(sa_iters=iters, m_idx=idx, m_dist=dist_, m_good=good, klt_pts=pts, klt_status=st, klt_err=err,
-                         fdp_ok=ok, fdp_px=pxd, fdp_level=lvl, po_bad=po["bad"], po_pose=po["pose"])
+                self._rec_extra.setdefault(cur, {}).update(
+                    sa_iters=iters, m_idx=idx, m_dist=dist_, m_good=good, klt_pts=pts, klt_status=st, klt_err=err, fdp_ok=ok, fdp_px=pxd,
+                    fdp_level=lvl, po_bad=po["bad"], po_pose=po["pose"],
+                    _chk=(T_sa, po["T"], n_good, int(st.astype(bool).sum()), int(ok.sum()), int((idx >= 0).sum())))
+        except BaseException as e:                                # (an exception must not cross the C boundary: re-raised after the run)
+            self._cb_error = e
 
-    # ------------------------------------------------------------------ phase 2: trajectory all-gather
-    def gather(self, rec):
-        """all-gather of the per-shard relative poses -> the chained global trajectory, identical on every rank"""
-        local = np.stack([rec[f].get("T_rel", I7) for f in range(self.start, self.start + self.count)]) if self.count else np.zeros((0, 7))
-        if self.world > 1:
-            dev = self._torch_device() if self.exchange_on_device else None
-            T_rel = ydist.gather_trajectories(local, self.n_total, self.rank, self.world, device=dev)
-        else:
-            T_rel = local
-        T_rel[0] = I7
-        return T_rel, chain(T_rel)
+    # ------------------------------------------------------------------ results
+    def _results(self):
+        r = OffResults()
+        self._chk(self.h_lib.ygz_offline_get_results(self._h, C.byref(r)), "get_results")
+        n, nw, S = r.n_frames, r.n_windows, r.state_doubles
+        arr = lambda p, shape, dt: np.ctypeslib.as_array(p, shape=shape).astype(dt, copy=True) if int(np.prod(shape)) else np.zeros(shape, dt)
+        return dict(r=r, T_rel=arr(r.T_rel, (n, 7), np.float64), trajectory=arr(r.trajectory, (n, 7), np.float64), summary=arr(r.summary, (n, 32), np.float64),
+                    n_kp=arr(r.n_kp, (n,), np.int32), state=arr(r.window_state, (nw, S), np.float64), owner=arr(r.window_owner, (nw,), np.int32),
+                    kfs=arr(r.window_kfs, (nw, self.window_kfs), np.int32))
 
-    def gather_keyframes(self):
-        """keyframe rows (pixels, levels, descriptors, depths: fixed-size rows of the device store) of every keyframe on every
-        rank: ONE all-gather on the store's memory -- needed only when a window straddles a shard boundary"""
-        if self.world == 1 or not self.any_cross:
-            return
-        import torch
-        rb = self.ba.kf_row_bytes(self.obs_mode == "direct")
-        rows = self.rows_t[:self.n_kf * rb].view(self.n_kf, rb)
-        own = [[k for k, f in enumerate(keyframes(self.n_total, self.kf_stride)) if frame_owner(f, self.n_total, self.world) == r]
-               for r in range(self.world)]
-        mine = own[self.rank]
-        local = rows[mine[0]:mine[-1] + 1] if mine else rows[:0]
-        torch.cuda.synchronize(self._torch_device())
-        g = ydist.all_gather_rows(local, [len(o) for o in own], self.pg, via_host=not self.exchange_on_device)
-        for r in range(self.world):
-            if r != self.rank and own[r]:
-                rows[own[r][0]:own[r][-1] + 1] = g[r, :len(own[r])]
-        torch.cuda.synchronize(self._torch_device())           # torch's stream wrote the rows, the ABI context has its own
-        self.ba.kf_store_refresh()
+    def _records(self, R):
+        rec = {}
+        for f in range(self.start, self.start + self.count):
+            r = dict(n_kp=int(R["n_kp"][f]))
+            if f > 0:
+                S = R["summary"][f]
+                r.update(T_sa=S[0:7].copy(), sa_n_meas=int(S[7]), T_rel=S[24:31].copy(), po_inliers=int(S[14]), po_rounds=int(S[15]), n_match=int(S[16]),
+                         n_good=int(S[17]), min_dis=float(S[18]), n_klt=int(S[19]), n_fdp=int(S[20]))
+            ex = self._rec_extra.get(f)
+            if ex:
+                ex = dict(ex)
+                chk = ex.pop("_chk", None)
+                if chk is not None:                               # the 32-field summary equals the per-stage getters
+                    assert np.array_equal(chk[0], r["T_sa"]) and np.array_equal(chk[1], r["T_rel"]) and chk[2] == r["n_good"]
+                    assert chk[3] == r["n_klt"] and chk[4] == r["n_fdp"] and chk[5] == r["n_match"]
+                r.update(ex)
+            rec[f] = r
+        return rec
 
-    def _torch_device(self):
-        import torch
-        return torch.device("cuda", self.device)
+    def _begin(self, frame_source, depth_source, block_source):
+        img, dimg, base = self._buffers(frame_source, depth_source, block_source)
+        self._img, self._dimg, self._base = img, dimg, base
+        self._rec_extra, self._cb_error = {}, None
+        return C.c_void_p(img.ctypes.data), C.c_void_p(dimg.ctypes.data), base
 
-    # ------------------------------------------------------------------ phase 3: BA round
-    def _ba_optimize(self, wis):
-        """the resident LM on windows that are built (consecutive owned windows), asynchronous"""
-        if wis:
-            assert wis == list(range(wis[0], wis[-1] + 1))
-            self._lm(self.mine.index(wis[0]), len(wis))
-            self._ba_done.update(wis)
+    def _after(self):
+        if getattr(self, "_cb_error", None) is not None:
+            raise self._cb_error
 
-    def _lm(self, slot0, n):
-        """optimize(20) + the inlier test of BA.cpp:503-515 (+ a second optimisation without the outliers when ba_rounds == 2), asynchronous"""
-        self.ba.ba_optimize_resident(slot0, n, self.ba_iterations, want_stats=False)
-        self.ba.ba_mark_outliers(slot0, n, self.outlier_chi2, disable=self.ba_rounds == 2)
-        if self.ba_rounds == 2:
-            self.ba.ba_optimize_resident(slot0, n, self.ba_iterations, want_stats=False)
-            self.ba.ba_mark_outliers(slot0, n, self.outlier_chi2, disable=False)
+    # ------------------------------------------------------------------ phases
+    def track_shard(self, frame_source, depth_source, block_source=None):
+        """phase 1 only (ygz_offline_track): the hot path over this shard + the windows it completes; returns the per-frame records"""
+        fp, dp, base = self._begin(frame_source, depth_source, block_source)
+        self._chk(self.h_lib.ygz_offline_track(self._h, fp, dp, base), "track")
+        self._after()
+        return self._records(self._results())
 
     def _ba_launch(self, wis, optimize=True):
-        """build (+ optimise) the given (owned) windows on the BA context, behind everything the lanes have enqueued so far"""
-        if not wis:
-            return
-        for c in self.lanes:
-            self.ba.stream_wait(c)
-        K = self.window_kfs
-        for g0 in range(0, len(wis), self.build_group):
-            grp = wis[g0:g0 + self.build_group]
-            assert grp == list(range(grp[0], grp[-1] + 1))
-            kfi = np.zeros((len(grp), K), np.int32); kff = np.zeros((len(grp), K), np.int32)
-            for a, wi in enumerate(grp):
-                w = self.wins[wi]
-                kff[a, :len(w)] = w
-                kfi[a, :len(w)] = [f // self.kf_stride for f in w]
-            slot0 = self.mine.index(grp[0])
-            self.ba.ba_build_windows(slot0, kfi, kff, [len(self.wins[wi]) for wi in grp], obs_mode=1 if self.obs_mode == "direct" else 0)
-            if optimize:
-                self._lm(slot0, len(grp))
-        if optimize:
-            self._ba_done.update(wis)
+        """build (+ optimise) the given owned windows now (ygz_offline_build_windows)"""
+        if wis:
+            assert list(wis) == list(range(wis[0], wis[-1] + 1))
+            self._chk(self.h_lib.ygz_offline_build_windows(self._h, self.mine.index(wis[0]), len(wis), int(optimize)), "build_windows")
 
-    def ba_round(self, T_rel):
-        """the windows this rank owns that are not optimised yet (those straddling a shard boundary; all of them without
-        pipeline_ba), then the exchange: every owner's refined window states to every rank in one all-gather"""
-        import time
-        t0 = time.perf_counter()
-        rest = [i for i in self.mine if i not in self._ba_done]
-        if rest:
-            if self.world > 1:                                 # relative poses of the frames other ranks tracked
-                self.ba.kf_store_set_trel(0, T_rel)
-            self.ba.ba_set_team_budget(0)
-            self._ba_launch(rest)
-        self.ba.synchronize()
-        self._retry_timed_out()
-        t1 = time.perf_counter()
-        n_w, S = len(self.wins), self.S
-        if self.world == 1:
-            host = self.ba.ba_pack_states(0, n_w, S) if n_w else np.zeros((0, S))
-        else:
-            import torch
-            dev = self._torch_device()
-            state = torch.zeros((n_w, S), dtype=torch.float64, device=dev)
-            # the zero fill runs on torch's current stream, k_ba_pack on the BA context's own (non-blocking) stream: without this wait the
-            # fill may land after the packed rows and zero them (gather_keyframes guards its buffer the same way)
-            torch.cuda.synchronize(dev)
-            if self.mine:
-                self.ba.ba_pack_states(0, len(self.mine), S, dst_ptr=state[self.mine[0]].data_ptr(), wait=True)
-            exchange_rows(state, self.owner, self.world, self.pg, via_host=not self.exchange_on_device)
-            host = state.cpu().numpy()
-        t2 = time.perf_counter()
-        self.ba_timing = {"tail_after_tracking": (t1 - t0) * 1e3, "exchange_download": (t2 - t1) * 1e3}
-        K, P = self.window_kfs, self.max_points
-        out, dims = [], {}
-        for wi, w in enumerate(self.wins):
-            tail = host[wi, 6 * K + 3 * P:]
-            if tail[3] < 0:
-                raise RuntimeError("BA window %d: the resident LM did not finish (team barrier time-out)" % wi)
-            dims[wi] = (int(tail[0]), int(tail[1]), int(tail[2]))
-            if dims[wi][1] == 0 or dims[wi][2] == 0:            # no map point of the anchor was observed in another keyframe: the window was not optimised
-                self.degenerate_windows = getattr(self, "degenerate_windows", []) + [wi]
-            out.append(dict(kfs=w, owner=self.owner[wi], poses=host[wi, :len(w) * 6].reshape(len(w), 6).copy(), state=host[wi].copy(),
-                            stats=np.array([tail[5], tail[6], tail[3], tail[2]]),
-                            inliers=dict(edges=int(tail[8]), outliers=int(tail[9]), chi2=float(tail[10]), chi2_inliers=float(tail[11])),
-                            lm=dict(iterations=int(tail[3]), trials=int(tail[4]), degenerate=bool(dims[wi][1] == 0 or dims[wi][2] == 0))))
-        return out, dims
+    def retry_windows(self, slots):
+        """rebuild the owned windows in BA slots `slots` and solve each with ONE workgroup (the retry of a timed-out LM team)"""
+        a = np.ascontiguousarray(slots, np.int32)
+        self._chk(self.h_lib.ygz_offline_retry_windows(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), len(a)), "retry_windows")
+        self.lm_retries = self._results()["r"].lm_retries
 
-    def _retry_timed_out(self):
-        """A resident-LM team whose members were not co-resident within the spin bound of a team barrier (possible beside the tracking
-        kernels of several lanes) leaves without a result.  Its window is rebuilt (the loop updates the points in place) and solved once more
-        by ONE workgroup, which needs no co-residency; a second failure raises."""
-        if not self.mine:
-            return
-        bad = [k for k, it in enumerate(self.ba.ba_lm_iterations(0, len(self.mine))) if it < 0 and self.mine[k] in self._ba_done]
-        if not bad:
-            return
-        self.lm_retries = getattr(self, "lm_retries", 0) + len(bad)
-        self.ba.ba_set_team_budget(1)                          # G = 1: one workgroup per window
-        done = set(self._ba_done)
-        for k in bad:
-            self._ba_launch([self.mine[k]])
-        self._ba_done = done
-        self.ba.ba_set_team_budget(0)
-        self.ba.synchronize()
-        still = [self.mine[k] for k in bad if self.ba.ba_lm_iterations(k, 1)[0] < 0]
-        if still:
-            raise RuntimeError("BA windows %s: the resident LM did not finish even with one workgroup per window" % still)
-
-    # ------------------------------------------------------------------ whole run
     def run(self, frame_source, depth_source, block_source=None):
-        import time
-        t0 = time.perf_counter()
-        rec = self.track_shard(frame_source, depth_source, block_source)
-        t1 = time.perf_counter()
-        T_rel, traj = self.gather(rec)
-        self.gather_keyframes()
-        t2 = time.perf_counter()
-        windows, dims = self.ba_round(T_rel)
-        t3 = time.perf_counter()
-        self.timing = {"track_shard": (t1 - t0) * 1e3, "gather": (t2 - t1) * 1e3, "ba_round": (t3 - t2) * 1e3}
-        self.timing.update({"ba_" + k: v for k, v in getattr(self, "ba_timing", {}).items()})
-        res = dict(records=rec, T_rel=T_rel, trajectory=traj, windows=windows, built=dims)
-        res["keyframe_pose"] = _LazyKeyframePoses(windows, traj)
+        """the whole run in ONE call of the C++ driver"""
+        fp, dp, base = self._begin(frame_source, depth_source, block_source)
+        self._chk(self.h_lib.ygz_offline_run(self._h, fp, dp, base), "run")
+        self._after()
+        R = self._results()
+        r = R["r"]
+        self.timing = {"track_shard": r.ms_track, "gather": r.ms_gather, "ba_round": r.ms_ba_tail + r.ms_exchange, "ba_tail_after_tracking": r.ms_ba_tail,
+                       "ba_exchange_download": r.ms_exchange}
+        self.lm_retries, self.backend = r.lm_retries, {0: "single rank", 1: "rccl", 2: "host hook (gloo)"}[r.backend]
+        self.lm_launches, self.n_chunks = r.lm_launches, r.n_chunks
+        K, P = self.window_kfs, self.max_points
+        windows, dims, self.degenerate_windows = [], {}, []
+        for wi, w in enumerate(self.wins):
+            assert list(R["kfs"][wi][:len(w)]) == w and int(R["owner"][wi]) == self.owner[wi]        # the driver's windows are this module's
+            st = R["state"][wi]
+            tail = st[6 * K + 3 * P:]
+            dims[wi] = (int(tail[0]), int(tail[1]), int(tail[2]))
+            degenerate = bool(dims[wi][1] == 0 or dims[wi][2] == 0)
+            if degenerate:
+                self.degenerate_windows.append(wi)
+            windows.append(dict(kfs=w, owner=self.owner[wi], poses=st[:len(w) * 6].reshape(len(w), 6).copy(), state=st.copy(),
+                                stats=np.array([tail[5], tail[6], tail[3], tail[2]]),
+                                inliers=dict(edges=int(tail[8]), outliers=int(tail[9]), chi2=float(tail[10]), chi2_inliers=float(tail[11])),
+                                lm=dict(iterations=int(tail[3]), trials=int(tail[4]), degenerate=degenerate)))
+        assert r.n_degenerate == len(self.degenerate_windows)
+        res = dict(records=self._records(R), T_rel=R["T_rel"], trajectory=R["trajectory"], windows=windows, built=dims)
+        res["keyframe_pose"] = _LazyKeyframePoses(windows, R["trajectory"])
         return res
 
 
