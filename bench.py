@@ -298,6 +298,182 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- surface mode: the drop-in path, one frame at a time
+SURF_KF_STRIDE, SURF_LOCAL_KFS = 8, 3                         # keyframe every 8th frame; LocalMapping.local_keyframes: 3 (config/default.yaml)
+
+
+def _surface_local(n_kfs):
+    """indices of the local keyframes: keyframe 0 + the newest SURF_LOCAL_KFS - 1 (tests/cpp/bench_surface.cpp says why)"""
+    return sorted(set([0] + list(range(max(0, n_kfs - (SURF_LOCAL_KFS - 1)), n_kfs))))
+
+
+def surface_sequence(n):
+    """n VGA frames of a smooth synthetic sequence + the depth images of its keyframes + ground-truth poses (frame 0 = world)"""
+    from ygz_slam_amd import synth
+    seq = synth.Sequence(n, W, H, seed=21, step=0.05)
+    bgr = np.stack([seq.frame(i) for i in range(n)])
+    kfd = np.stack([seq.depth(i).astype(np.float32) for i in range(0, n, SURF_KF_STRIDE)])
+    return bgr, kfd, seq.poses.copy()
+
+
+def surface_gpu(bgr, kfd):
+    """tests/cpp/bench_surface.cpp through ctypes: the reference-shaped loop over the ygz:: class surfaces (libygz_host.so), one frame at a time"""
+    import ctypes as C
+    from ygz_slam_amd import _lib
+    _lib.load()
+    lib = C.CDLL(os.path.join(ROOT, "tests", "cpp", "libbench_surface.so"))
+    n = len(bgr)
+    nk = len(kfd)
+    ms = np.zeros(n); T = np.zeros((n, 7)); cnt = np.zeros((n, 4), np.int32); ba = np.zeros((nk, 4)); stage = np.zeros(8)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib.ygz_bench_surface(p(bgr, C.c_uint8), p(kfd, C.c_float), n, W, H, SURF_KF_STRIDE, SURF_LOCAL_KFS, p(ms, C.c_double), p(T, C.c_double),
+                               p(cnt, C.c_int32), p(ba, C.c_double), p(stage, C.c_double))
+    if rc != 0:
+        raise RuntimeError("ygz_bench_surface failed")
+    names = ("InitFrame", "SparseImageAlignment", "ProjectMapPoints", "OptimizeCurrentPoseOnly", "Detect", "keyframe bookkeeping", "LocalBAG2O", "delete frame")
+    return dict(ms=ms, T=T, counts=cnt, ba=ba, stage_ms_per_frame={k: float(v) / n for k, v in zip(names, stage)})
+
+
+def surface_cpu(bgr, kfd, budget_s=14.0):
+    """The SAME loop on the oracle (scalar restatement, one core): InitFrame -> SparseImageAlignment -> FindCandidates + ProjectMapPoints ->
+    OptimizeCurrentPoseOnly -> Detect, keyframe + LocalBAG2O every 8th frame; stops after budget_s (whole frames)."""
+    from oracle.pyoracle import Oracle
+    from ygz_slam_amd import offline as off, synth
+    try:
+        o = Oracle(variant="o3")
+    except Exception:
+        o = Oracle()
+    prm = o.default_params(W, H, LEVELS)
+    fx, fy, cx, cy = synth.FX, synth.FY, synth.CX, synth.CY
+    cols = -(-W // prm.cell_size)
+    mp_pos = np.zeros((0, 3)); mp_nobs = np.zeros(0, np.int64)
+    kfs, ref = [], None
+    ms, Ts, cnts, bas = [], [], [], []
+    t_start = time.perf_counter()
+    for i in range(len(bgr)):
+        t0 = time.perf_counter()
+        lv = o.pyramid(o.bgr2gray(bgr[i]), LEVELS)
+        cur = dict(lv=lv, T=off.I7.copy(), px=np.zeros((0, 2)), level=np.zeros(0, np.int32), mp=np.zeros(0, np.int64), depth=np.zeros(0), bad=np.zeros(0, bool))
+        n_sa = n_proj = n_inl = 0
+        if ref is not None:
+            has = ref["mp"] >= 0
+            n_sa = int(has.sum())
+            _, T, _ = o.sparse_align(ref["lv"], ref["T"], lv, ref["T"], ref["px"], ref["depth"], has.astype(np.uint8))
+            loc = [kfs[j] for j in _surface_local(len(kfs))]
+            ids = [k["mp"][(k["mp"] >= 0) & ~k["bad"]] for k in loc]
+            pts = np.unique(np.concatenate(ids)) if ids else np.zeros(0, np.int64)
+            if len(pts):
+                cp, ck, cpx, cl = [], [], [], []
+                for j, k in enumerate(loc):
+                    m = (k["mp"] >= 0) & ~k["bad"]
+                    cp.append(np.searchsorted(pts, k["mp"][m])); ck.append(np.full(int(m.sum()), j)); cpx.append(k["px"][m]); cl.append(k["level"][m])
+                cp, ck, cpx, cl = np.concatenate(cp), np.concatenate(ck), np.concatenate(cpx), np.concatenate(cl)
+                order = np.lexsort((ck, cp))
+                n_proj, in_view, _, match, px_m, lvl_m = o.track_local_map([k["lv"] for k in loc], [k["T"] for k in loc], lv, T, mp_pos[pts], None,
+                                                                           cp[order], ck[order], cpx[order], cl[order])
+                g = match >= 0
+                cur.update(px=px_m[g], level=lvl_m[g].astype(np.int32), mp=pts[g].astype(np.int64))
+            if len(cur["px"]):
+                th = o.se3_log(T)
+                pose, bad, depth, n_inl, _ = o.optimize_current_pose_only(np.concatenate([T[4:], th[3:]]), cur["px"], mp_pos[cur["mp"]])
+                T = np.concatenate([o.se3_exp(np.concatenate([np.zeros(3), pose[3:]]))[:4], pose[:3]])
+                cur["mp"] = np.where(bad.astype(bool), -1, cur["mp"])
+                cur["depth"] = np.where(bad.astype(bool), -1.0, depth)
+                cur["bad"] = bad.astype(bool)
+            cur["T"] = T
+        occ = np.zeros(prm.image_height // prm.cell_size * cols + cols, np.uint8)[: -(-prm.image_height // prm.cell_size) * cols]
+        if len(cur["px"]):
+            occ[(cur["px"][:, 1] // prm.cell_size).astype(int) * cols + (cur["px"][:, 0] // prm.cell_size).astype(int)] = 1
+        kp = o.detect(lv, prm, occ if ref is not None else None)
+        nd = len(kp)
+        cur["px"] = np.concatenate([cur["px"], np.stack([kp["px"], kp["py"]], 1).astype(np.float64)])
+        cur["level"] = np.concatenate([cur["level"], kp["level"].astype(np.int32)])
+        cur["mp"] = np.concatenate([cur["mp"], np.full(nd, -1, np.int64)])
+        cur["depth"] = np.concatenate([cur["depth"], np.full(nd, -1.0)])
+        cur["bad"] = np.concatenate([cur["bad"], np.zeros(nd, bool)])
+        if i % SURF_KF_STRIDE == 0:
+            D = kfd[i // SURF_KF_STRIDE]
+            old = (cur["mp"] >= 0) & ~cur["bad"]
+            mp_nobs[cur["mp"][old]] += 1
+            d = D[cur["px"][:, 1].astype(int), cur["px"][:, 0].astype(int)].astype(np.float64)
+            new = np.nonzero((cur["mp"] < 0) & (d > 0))[0]
+            pc = np.stack([(cur["px"][new, 0] - cx) * d[new] / fx, (cur["px"][new, 1] - cy) * d[new] / fy, d[new]], 1)
+            cur["mp"][new] = len(mp_pos) + np.arange(len(new)); cur["depth"][new] = d[new]
+            mp_pos = np.concatenate([mp_pos, off.se3_act(off.se3_inv(cur["T"]), pc)]); mp_nobs = np.concatenate([mp_nobs, np.ones(len(new), np.int64)])
+            kfs.append(cur)
+            loc = _surface_local(len(kfs))
+            ba_rec = [0, 0, 0.0, 0.0]
+            ids = np.unique(np.concatenate([kfs[j]["mp"][(kfs[j]["mp"] >= 0) & ~kfs[j]["bad"]] for j in loc]))
+            ids = ids[mp_nobs[ids] >= 2]
+            if len(loc) >= 2 and len(ids):
+                tb = time.perf_counter()
+                pose_of, poses, fixed, ep, el, ob, who = {}, [], [], [], [], [], []
+                for j in loc:                                  # local keyframes first (keyframe 0 constant, BA.cpp:404), then whoever else sees the points
+                    pose_of[j] = len(poses); poses.append(off.se3_log_g2o(kfs[j]["T"])); fixed.append(1 if j == 0 else 0)
+                for j, k in enumerate(kfs):
+                    m = (k["mp"] >= 0) & ~k["bad"] & np.isin(k["mp"], ids)
+                    if not m.any():
+                        continue
+                    if j not in pose_of:
+                        pose_of[j] = len(poses); poses.append(off.se3_log_g2o(k["T"])); fixed.append(1)
+                    f = np.nonzero(m)[0]
+                    ep.append(np.full(len(f), pose_of[j])); el.append(np.searchsorted(ids, k["mp"][f])); ob.append(k["px"][f]); who += [(j, f)]
+                ep, el, ob = np.concatenate(ep), np.concatenate(el), np.concatenate(ob)
+                order = np.lexsort((ep, el))
+                P2, X2, st = o.g2o_lm(np.stack(poses), np.array(fixed, np.uint8), mp_pos[ids], ep[order], el[order], ob[order])
+                lin = o.ba_linearize(P2, np.array(fixed, np.uint8), X2, ep, el, ob)             # the inlier test of BA.cpp:503-515
+                e2 = (lin["err"] ** 2).sum(1)
+                a = 0
+                for j, f in who:
+                    kfs[j]["bad"][f[e2[a:a + len(f)] > 5.991]] = True; a += len(f)
+                for j in loc:
+                    if j != 0:
+                        kfs[j]["T"] = off.se3_exp_g2o(P2[pose_of[j]])
+                mp_pos[ids] = X2
+                ba_rec = [int(st.get("iterations", 0)), len(ids), float(st.get("chi2_final", 0.0)), (time.perf_counter() - tb) * 1e3]
+            bas.append(ba_rec)
+        Ts.append(cur["T"].copy()); cnts.append((n_sa, n_proj, n_inl, len(cur["px"])))
+        ref = cur
+        ms.append((time.perf_counter() - t0) * 1e3)
+        if time.perf_counter() - t_start > budget_s and i >= 2 * SURF_KF_STRIDE and (i + 1) % SURF_KF_STRIDE == 0:
+            break
+    return dict(ms=np.array(ms), T=np.stack(Ts), counts=np.array(cnts, np.int32), ba=np.array(bas))
+
+
+def surface_block(n_frames=204, cpu_budget_s=14.0, want_cpu=True):
+    """The `surface` block of the driver line: frames/s of the DROP-IN path -- the reference-shaped loop, one frame at a time, through
+    ygz::Frame / FeatureDetector / Matcher / ba:: (test/test_vo_track.cpp:100-113 -> VisualOdometry::AddFrame) -- and the oracle on the same loop."""
+    from ygz_slam_amd import offline as off
+    bgr, kfd, gt = surface_sequence(n_frames)
+    surface_gpu(bgr[:3 * SURF_KF_STRIDE], kfd[:3])                      # warm-up: context, allocations, first launches
+    g = surface_gpu(bgr, kfd)
+    gt0 = np.stack([off.se3_mul(gt[i], off.se3_inv(gt[0])) for i in range(n_frames)])
+    ms = g["ms"][1:]
+    kf = np.arange(1, n_frames) % SURF_KF_STRIDE == 0
+    out = {"what": "one frame at a time through the class surfaces (libygz_host.so): Frame::InitFrame -> Matcher::SparseImageAlignment -> "
+                   "Matcher::ProjectMapPoints (FindCandidates + FindDirectProjection) -> ba::OptimizeCurrentPoseOnly -> FeatureDetector::Detect; "
+                   "keyframe + ba::LocalBAG2O (keyframe 0 + the newest %d keyframes) every %dth frame; host clock around every frame, every surface call synchronous"
+                   % (SURF_LOCAL_KFS - 1, SURF_KF_STRIDE),
+           "frames": int(n_frames), "size": "%dx%d" % (W, H), "frames_per_s": float((n_frames - 1) / (ms.sum() * 1e-3)),
+           "ms_per_frame": {"median": float(np.median(ms)), "p10": float(np.percentile(ms, 10)), "p90": float(np.percentile(ms, 90)),
+                            "median_plain_frame": float(np.median(ms[~kf])), "median_keyframe": float(np.median(ms[kf]))},
+           "host_ms_per_frame_by_surface_call": g["stage_ms_per_frame"],
+           "local_ba_ms_median": float(np.median(g["ba"][g["ba"][:, 3] > 0, 3])) if (g["ba"][:, 3] > 0).any() else None,
+           "mean_map_points_aligned_projected_inliers_features": [float(v) for v in g["counts"][1:].mean(0)],
+           "max_abs_pose_error_vs_ground_truth": float(np.abs(g["T"] - gt0).max())}
+    if want_cpu:
+        c = surface_cpu(bgr, kfd, cpu_budget_s)
+        m = len(c["ms"])
+        cms = c["ms"][1:]
+        out["cpu_oracle_same_loop"] = {"frames": m, "frames_per_s": float((m - 1) / (cms.sum() * 1e-3)), "cores": 1, "kind": "port",
+                                       "ms_per_frame_median": float(np.median(cms)),
+                                       "mean_map_points_aligned_projected_inliers_features": [float(v) for v in c["counts"][1:].mean(0)],
+                                       "max_abs_pose_error_vs_ground_truth": float(np.abs(c["T"] - gt0[:m]).max()),
+                                       "max_abs_pose_difference_gpu_vs_oracle": float(np.abs(c["T"] - g["T"][:m]).max())}
+        out["vs_cpu_1core"] = out["frames_per_s"] / out["cpu_oracle_same_loop"]["frames_per_s"]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- offline mode (configs[4])
 _SEQ = None
 OFF_W, OFF_H = 1280, 720                                      # BASELINE configs[4] frame size
@@ -363,7 +539,7 @@ def cpu_offline_baseline(bgr, dimg, vo, budget_s=12.0):
 
 
 def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=1, chunk=128, probe="k_klt", one_dev=False, cpu_baseline_s=0.0,
-                overlap=False, lm_group=None, lanes=None):
+                overlap=False, lm_group=None, lanes=None, defer=None, bg_budget=0):
     """BASELINE configs[4] on the frames offline_render produced: one sequence sharded over the ranks (strong scaling).  A step = one
     complete offline run; the timed region holds every upload, kernel, result copy, collective and the BA round.  Returns the result
     dict on rank 0 (None elsewhere)."""
@@ -384,7 +560,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     # page-locked buffers, calls ygz_offline_run through the binding and prints what came back
     vo = offline.OfflineVO(W_, H_, n_frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
                            exchange_on_device=not one_dev, depth_div=DEPTH_DIV, depth_dtype=np.uint16, depth_scale=DEPTH_SCALE, overlap=overlap, lm_group=lm_group, lanes=lanes,
-                           gray=gray_in)
+                           gray=gray_in, defer_gaps=defer, bg_team_budget=bg_budget)
     for k, (i, b, d) in enumerate(R["rendered"]):
         assert i == need[k]
         if gray_in:
@@ -496,7 +672,7 @@ def main_offline(a):
         dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world)
     chunk = a.batch if a.batch != 512 else 128
     out = offline_run(R, rank, world, local_rank, dist, upload=a.upload, steps=a.steps, warmup=a.warmup, chunk=chunk, probe=a.probe, one_dev=one_dev,
-                      cpu_baseline_s=0.0 if a.no_cpu_baseline else 12.0, overlap=a.lane_overlap, lm_group=a.lm_group, lanes=a.lanes)
+                      cpu_baseline_s=0.0 if a.no_cpu_baseline else 12.0, overlap=a.lane_overlap, lm_group=a.lm_group, lanes=a.lanes, defer=a.defer, bg_budget=a.bg_budget)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -517,7 +693,7 @@ def main():
                     help="two resident batches per GPU, consecutive steps alternate between them so that the latency-bound tail of "
                          "one step overlaps the extraction of the next (+4.5 %% frames/s; off by default because the probed kernel "
                          "then shares the GPU with the other batch and its launch duration no longer measures the kernel alone)")
-    ap.add_argument("--mode", default="step", choices=["step", "stream", "offline"],
+    ap.add_argument("--mode", default="step", choices=["step", "stream", "offline", "surface"],
                     help="step (default): the hot path over a batch resident in HBM = BASELINE.json's metric; stream: the same step with the "
                          "frames coming from page-locked host memory every step (double-buffered H2D under compute) and the keypoints + per-pair "
                          "results copied back and read by the host; offline: BASELINE configs[4], a --frames long 1280x720 sequence sharded over "
@@ -528,6 +704,8 @@ def main():
                                                                "and the BA context already fill the GPU and the hardware queues)")
     ap.add_argument("--lanes", type=int, default=None, help="offline mode: tracking contexts that take the chunks in turn (default: 3 with BGR frames, 4 with gray frames)")
     ap.add_argument("--lm-group", type=int, default=None, help="offline mode: BA windows per resident-LM launch")
+    ap.add_argument("--defer", type=int, default=None, help="offline mode: keyframe-free gaps behind the last windows of a shard processed at the very end (ygz_offline_params::defer_gaps; default: the driver's rule)")
+    ap.add_argument("--bg-budget", type=int, default=0, help="offline mode: workgroups a resident-LM launch may hold while tracking chunks follow (0: library default)")
     ap.add_argument("--no-extras", action="store_true", help="default mode: skip the `offline` and `stream` blocks (the timed region is the same either way)")
     ap.add_argument("--upload", default="bgr", choices=["bgr", "gray"], help="stream mode: what crosses PCIe per frame (3 or 1 byte per pixel)")
     ap.add_argument("--size", default=None, choices=["vga", "720p"],
@@ -540,6 +718,9 @@ def main():
         W, H = 1280, 720
     if a.mode == "offline":
         return main_offline(a)
+    if a.mode == "surface":                                    # the drop-in path alone (the `surface` block of the default line)
+        print(json.dumps({"surface": surface_block(n_frames=a.frames if a.frames != 1024 else 204, want_cpu=not a.no_cpu_baseline)}))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -734,6 +915,10 @@ def main():
                 res["value_with_transfers"] = res["stream"]["bgr"]["value"]       # every step: H2D of the BGR frames, the same hot path, D2H of the results
             except Exception as e:
                 res["stream"] = {"error": repr(e)}
+            try:                                            # the drop-in path: one frame at a time through the class surfaces, and the oracle on the same loop
+                res["surface"] = surface_block(want_cpu=not a.no_cpu_baseline)
+            except Exception as e:
+                res["surface"] = {"error": repr(e)}
         done.set()
     if rank == 0:
         print(json.dumps(res))

@@ -9,6 +9,7 @@
 #define YGZ_COMMON_INCLUDE_H_
 
 #include <vector>
+#include <array>
 #include <list>
 #include <memory>
 #include <string>
@@ -163,7 +164,11 @@ public:
     void create(int r, int c, int type)
     {
         rows = r; cols = c; type_ = type; step = (size_t)c * elemSize();
-        buf_ = std::shared_ptr<uint8_t>(new uint8_t[(size_t)r * step + 64], std::default_delete<uint8_t[]>());
+        const size_t bytes = (size_t)r * step;
+        if (bytes <= 64) {                                   // a descriptor row (Feature::_desc, 32 bytes): block and control block in ONE allocation
+            auto blk = std::make_shared<std::array<uint8_t, 128>>();
+            buf_ = std::shared_ptr<uint8_t>(blk, blk->data());
+        } else buf_ = std::shared_ptr<uint8_t>(new uint8_t[bytes + 64], std::default_delete<uint8_t[]>());
         data = buf_.get();
     }
     size_t elemSize() const { return type_ == CV_8UC3 ? 3 : (type_ == CV_32F ? 4 : 1); }

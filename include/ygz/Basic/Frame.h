@@ -1,6 +1,8 @@
 // ygz::Frame -- the hot-path part of include/ygz/Basic/Frame.h:20-166 (the covisibility graph is out of scope,
-// SURVEY 2.1 #1).  InitFrame() uploads the image to an HBM slot of the process-wide ygz_hip context,
-// builds the pyramid on the GPU and mirrors the levels into _pyramid for host readers.
+// SURVEY 2.1 #1).  InitFrame() uploads the image to an HBM slot of the process-wide ygz_hip context and
+// builds the pyramid on the GPU.  _pyramid keeps the reference's spelling (_pyramid[L], .size(), .empty()): it is
+// a LAZY host mirror -- level L crosses PCIe the first time somebody indexes it (round 5: InitFrame used to
+// drag all levels, 400 KB per VGA frame, back to the host whether or not anybody read them).
 #ifndef YGZ_FRAME_H_
 #define YGZ_FRAME_H_
 #include "ygz/Basic/Common.h"
@@ -8,6 +10,26 @@ namespace ygz {
 class PinholeCamera;
 struct MapPoint;
 struct Feature;
+struct Frame;
+namespace hip {
+// what `vector<cv::Mat> _pyramid` (Basic/Frame.h:138) is for the callers -- indexable, sized -- with the download deferred to the first
+// access of a level.  The levels themselves live in HBM (ygz::hip::Runtime).
+class PyramidMirror {
+public:
+    size_t size() const { return lv_.size(); }
+    bool empty() const { return lv_.empty(); }
+    void clear() { lv_.clear(); have_.clear(); }
+    cv::Mat &operator[](size_t L) { fetch(L); return lv_[L]; }
+    const cv::Mat &operator[](size_t L) const { const_cast<PyramidMirror *>(this)->fetch(L); return lv_[L]; }
+    bool fetched(size_t L) const { return L < have_.size() && have_[L]; }
+    void reset(Frame *owner, size_t levels) { owner_ = owner; lv_.assign(levels, cv::Mat()); have_.assign(levels, 0); }
+private:
+    void fetch(size_t L);                   // ygz_host.cpp: ygz_hip_download_level of the owner's slot (re-uploading an evicted frame first)
+    Frame *owner_ = nullptr;
+    std::vector<cv::Mat> lv_;
+    std::vector<char> have_;
+};
+}
 struct Frame {
     struct Option { int _pyramid_level = 3; } _option;
     Frame() {}
@@ -37,7 +59,7 @@ struct Frame {
     bool   _is_keyframe = false;
     vector<Feature *> _features;
     Mat    _color, _depth;                  // _color: CV_8UC3 (BGR) or CV_8UC1
-    vector<Mat> _pyramid;                   // host mirror of the HBM levels
+    hip::PyramidMirror _pyramid;            // lazy host mirror of the HBM levels (Basic/Frame.h:138: vector<cv::Mat>)
     static PinholeCamera *_camera;
     static ORBVocabulary *_vocab;
     DBoW3::BowVector _bow_vec;
@@ -45,7 +67,7 @@ struct Frame {
     Frame *_ref_keyframe = nullptr;
     bool   _bad = false;
     int    _hip_slot = -1;                  // HBM slot of this frame (managed by ygz::hip::Runtime)
-    void CreateImagePyramid();
+    void CreateImagePyramid();              // fetches every level into the host mirror now
 };
 }
 #endif

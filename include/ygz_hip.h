@@ -360,6 +360,11 @@ typedef struct {
 } ygz_ba_stats;
 int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                          int max_iterations, ygz_ba_stats *stats);
+/* The same plus the inlier pass that follows optimize() in ba::LocalBAG2O (src/Algorithm/BA.cpp:503-515): chi2_edge [n_edges] = every edge's chi2 at
+ * the optimised state (what ygz_hip_ba_linearize would return for it), from one more linearisation of the window that is still resident --
+ * no second upload of the graph.  chi2_edge == NULL: exactly ygz_hip_ba_optimize. */
+int  ygz_hip_ba_optimize_chi2(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io, int max_iterations,
+                              ygz_ba_stats *stats, double *chi2_edge);
 /* Which loop the last ygz_hip_ba_optimize / ygz_hip_ba_solve_ceres of the context ran.  Both route to the resident kernels
  * (ygz_hip_ba_optimize_resident / ygz_hip_ba_solve_ceres_resident) when the window has at most 14 free poses and no repeated (point, pose)
  * edge; otherwise the linearisations run on the GPU and the reduced system on the host -- the same results, about ten times slower.

@@ -1,0 +1,133 @@
+// The reference-shaped loop, ONE FRAME AT A TIME, through the ygz:: class surfaces -- what the unchanged callers of the reference do
+// (test/test_vo_track.cpp:100-113 -> VisualOdometry::AddFrame, src/Module/VisualOdometry.cpp:38-107, state VO_GOOD):
+//
+//     Frame::InitFrame                                   (src/Basic/Frame.cpp:22-40)
+//     _curr->_TCW = _ref->_TCW; TrackRefFrame            (VisualOdometry.cpp:66-67,281-302: Matcher::SparseImageAlignment)
+//     TrackLocalMap                                      (LocalMapping.cpp:24-45: FindCandidates + ProjectMapPoints + OptimizeCurrent =
+//                                                         ba::OptimizeCurrentPoseOnly)
+//     FeatureDetector::Detect(frame, false)              (extraction on every frame -- the metric's "extract"; the reference detects on
+//                                                         keyframes only, VisualOdometry.cpp:SetKeyframe)
+//     every kf_stride-th frame: keyframe + ba::LocalBAG2O over keyframe 0 + the newest `local_kfs` - 1 keyframes and the map points they observe
+//                                                         (LocalMapping.cpp:149-208,301-336)
+//
+// New map points come from a depth image at the keyframes (the stand-in for the initialiser / triangulation, as in the offline run).
+// Built as a shared object: bench.py (`surface` block) and tests/test_gpu_surface.py call ygz_bench_surface through ctypes and run the oracle
+// on the same loop for the CPU side.  This file is test / bench infrastructure: the product is libygz_host.so behind the headers it includes.
+#include "ygz/Basic.h"
+#include "ygz/Algorithm.h"
+#include <chrono>
+#include <deque>
+using namespace ygz;
+
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}
+
+extern "C" {
+
+// bgr [n][h][w][3]; kf_depth [ceil(n / kf_stride)][h][w] float metres (depth image of frames 0, kf_stride, 2 kf_stride ...).
+// Outputs: ms [n] host clock per frame (whole iteration, keyframe work included); T_out [n][7] the pose each frame ended with; counts [n][4] =
+// map points used by the sparse alignment of this frame (features of the reference frame with a map point), features ProjectMapPoints created,
+// features left after the pose-only inlier test, features after Detect; ba [n_kf][4] = iterations, map points, final chi2, ms of every LocalBAG2O.
+// Returns 0, or 1 when an exception crossed a surface (message on stderr).
+// stage_ms [8] (may be NULL): host clock summed over the frames: InitFrame, SparseImageAlignment, ProjectMapPoints, OptimizeCurrentPoseOnly, Detect,
+// keyframe bookkeeping, LocalBAG2O, frame deletion.
+int ygz_bench_surface(const uint8_t *bgr, const float *kf_depth, int n, int w, int h, int kf_stride, int local_kfs, double *ms, double *T_out,
+                      int32_t *counts, double *ba, double *stage_ms)
+{
+    double st_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define STAGE(k, code) { const double ts_ = now_ms(); code; st_[k] += now_ms() - ts_; }
+    try {
+        Config::Set("image.width", std::to_string(w)); Config::Set("image.height", std::to_string(h));
+        PinholeCamera cam;
+        Frame::SetCamera(&cam);
+        FeatureDetector detector;
+        detector.LoadParams();
+        Matcher matcher;
+        Memory::Clean();
+        std::deque<Frame *> kf_order;
+        std::vector<Frame *> all_kfs;
+        std::vector<MapPoint *> all_mps;
+        std::set<Frame *> local_keyframes;
+        std::set<MapPoint *> local_map_points;
+        Frame *ref = nullptr;
+        const size_t fb = (size_t)w * h * 3;
+        for (int i = 0; i < n; ++i) {
+            const double t0 = now_ms();
+            Frame *cur = new Frame;
+            cur->_id = (unsigned long)i;
+            cur->_color = cv::Mat(h, w, CV_8UC3, const_cast<uint8_t *>(bgr + (size_t)i * fb));
+            STAGE(0, cur->InitFrame())
+            int n_sa = 0, n_proj = 0, n_inl = 0;
+            if (ref) {
+                cur->_TCW = ref->_TCW;                                             // VisualOdometry.cpp:66
+                for (Feature *f : ref->_features) n_sa += f->_mappoint != nullptr;
+                STAGE(1, matcher.SparseImageAlignment(ref, cur))                   // TrackRefFrame
+                STAGE(2, n_proj = matcher.ProjectMapPoints(cur, local_keyframes, local_map_points))      // TrackLocalMap: FindCandidates + ProjectMapPoints
+                if (!cur->_features.empty()) STAGE(3, ba::OptimizeCurrentPoseOnly(cur))     // LocalMapping::OptimizeCurrent
+                // an outlier of the pose-only BA stops being an observation of its map point (the reference keeps the pointer and a depth of -1,
+                // which its next SparseImageAlignment would back-project: Feature.h:23, SparseImageAlign.cpp:78-83)
+                for (Feature *f : cur->_features) { if (f->_bad) f->_mappoint = nullptr; else ++n_inl; }
+            }
+            STAGE(4, detector.Detect(cur, ref == nullptr))                         // new features where no tracked feature sits (SetExistingFeatures)
+            const double t_kf = now_ms();
+            double t_ba = 0;
+            if (i % kf_stride == 0) {
+                // SetKeyframe: the frame enters the map; features without a map point get one from the depth image
+                Memory::RegisterKeyFrame(cur);
+                all_kfs.push_back(cur);
+                const float *D = kf_depth + (size_t)(i / kf_stride) * w * h;
+                for (Feature *f : cur->_features) {
+                    if (f->_mappoint) { if (!f->_bad) f->_mappoint->_obs[cur->_keyframe_id] = f; continue; }
+                    const double d = D[(size_t)(int)f->_pixel[1] * w + (int)f->_pixel[0]];
+                    if (!(d > 0)) continue;
+                    MapPoint *mp = Memory::CreateMapPoint();
+                    all_mps.push_back(mp);
+                    mp->_pos_world = cam.Pixel2World(f->_pixel, cur->_TCW, d);
+                    mp->_obs[cur->_keyframe_id] = f;
+                    mp->_first_seen = mp->_last_seen = cur->_keyframe_id;
+                    f->_mappoint = mp; f->_depth = d;
+                }
+                kf_order.push_back(cur);
+                // the local map = keyframe 0 + the newest local_kfs - 1 keyframes.  The reference picks local keyframes by covisibility; the camera of the
+                // synthetic sequence hovers around its first pose, so keyframe 0 stays covisible -- and Matcher::GetWarpAffineMatrix (Matcher.cpp:424-431,
+                // reproduced as written) is only right for a reference keyframe at the origin: with keyframe 0 first in candidate order most map points
+                // keep being matched for the whole sequence instead of for its first 3 keyframes
+                if ((int)kf_order.size() > local_kfs) kf_order.erase(kf_order.begin() + 1);
+                local_keyframes = std::set<Frame *>(kf_order.begin(), kf_order.end());
+                local_map_points.clear();
+                std::set<MapPoint *> ba_points;                                   // a point seen by one keyframe only constrains nothing: it is tracked, not optimised
+                for (Frame *kf : kf_order) for (Feature *f : kf->_features) if (f->_mappoint && !f->_mappoint->_bad && !f->_bad) {
+                    local_map_points.insert(f->_mappoint);
+                    if (f->_mappoint->_obs.size() >= 2) ba_points.insert(f->_mappoint);
+                }
+                double *b = ba + 4 * (size_t)(i / kf_stride);
+                b[0] = b[1] = b[2] = b[3] = 0;
+                if (kf_order.size() >= 2 && !ba_points.empty()) {
+                    ba::LocalBAStats st;
+                    const double tb = now_ms();
+                    ba::LocalBAG2O(local_keyframes, ba_points, &st);
+                    b[0] = st.iterations; b[1] = (double)ba_points.size(); b[2] = st.chi2_final; b[3] = now_ms() - tb; t_ba = b[3];
+                }
+            }
+            st_[5] += now_ms() - t_kf - t_ba; st_[6] += t_ba;
+            cur->_TCW.to7(T_out + 7 * (size_t)i);
+            counts[4 * i] = n_sa; counts[4 * i + 1] = n_proj; counts[4 * i + 2] = n_inl; counts[4 * i + 3] = (int32_t)cur->_features.size();
+            STAGE(7, if (ref && !ref->_is_keyframe) delete ref)                    // VisualOdometry.cpp:88-89
+            ref = cur;
+            ms[i] = now_ms() - t0;
+        }
+        if (ref && !ref->_is_keyframe) delete ref;
+        for (Frame *kf : all_kfs) delete kf;
+        for (MapPoint *mp : all_mps) delete mp;
+        Memory::Clean();
+        Frame::SetCamera(nullptr);
+        if (stage_ms) for (int k = 0; k < 8; ++k) stage_ms[k] = st_[k];
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ygz_bench_surface: %s\n", e.what());
+        return 1;
+    }
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 // conflict-free), gradients are re-derived from it instead of being stored; current-image
 // pixels come straight from HBM/L2 (9x9 window per iteration, one new column per step).
 #include "ygz_internal.h"
+#include <cstring>
 #include "../../include/ygz_exp.h"
 #include "se3_dev.h"
 
@@ -523,19 +524,17 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     int32_t *d_kfs = (int32_t *)(d_candpx + 2 * Cs), *d_cp = d_kfs + Ks, *d_ck = d_cp + Cs, *d_cl = d_ck + Cs, *d_mc = d_cl + Cs,
             *d_ml = d_mc + Ps, *d_csl = d_ml + Ps;
     uint8_t *d_bad = (uint8_t *)(d_csl + Cs), *d_vis = d_bad + Ps, *d_cok = d_vis + Ps;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_T, T_cur, 56, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pw, m->pos_world, Ps * 24, hipMemcpyHostToDevice, ctx->stream));
-    if (m->point_bad) YGZ_HIPCHK(ctx, hipMemcpyAsync(d_bad, m->point_bad, Ps, hipMemcpyHostToDevice, ctx->stream));
-    if (K) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_kfT, m->kf_T, Ks * 56, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_kfs, m->kf_slot, Ks * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    if (Cn) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cpx, m->cand_px_ref, Cs * 16, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cp, m->cand_point, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_ck, m->cand_kf, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_cl, m->cand_level, Cs * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
+    // inputs packed into the page-locked mirror of the scratch block at the device offsets: ONE copy up (and one down below) instead of nine + five
+    uint8_t *hb = nullptr;
+    if ((rc = ygz_scratch_mirror(ctx, SCR_LMAP, (void **)&hb)) != YGZ_OK) return rc;
+    const size_t total = nd * 8 + ni * 4 + nb;
+#define H_(dptr) (hb + ((const uint8_t *)(dptr) - buf))
+    memcpy(H_(d_T), T_cur, 56);
+    memcpy(H_(d_pw), m->pos_world, Ps * 24);
+    if (m->point_bad) memcpy(H_(d_bad), m->point_bad, Ps);
+    if (K) { memcpy(H_(d_kfT), m->kf_T, Ks * 56); memcpy(H_(d_kfs), m->kf_slot, Ks * 4); }
+    if (Cn) { memcpy(H_(d_cpx), m->cand_px_ref, Cs * 16); memcpy(H_(d_cp), m->cand_point, Cs * 4); memcpy(H_(d_ck), m->cand_kf, Cs * 4); memcpy(H_(d_cl), m->cand_level, Cs * 4); }
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf, hb, total, hipMemcpyHostToDevice, ctx->stream));
     LmapArgs A;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; A.F.sstride[L] = (size_t)ctx->lw[L] * ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 0;
@@ -551,12 +550,11 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     if (Cn) YGZ_LAUNCH(ctx, KID_LMAP_MATCH, k_lmap_match, dim3(ygz_div_up(Cn, 64)), dim3(64), A);
     YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_gather, dim3(ygz_div_up(P, 256)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(in_view, d_vis, Ps, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_proj, d_proj, Ps * 16, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(match_cand, d_mc, Ps * 4, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_match, d_pm, Ps * 16, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(match_level, d_ml, Ps * 4, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(hb, buf, total, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(in_view, H_(d_vis), Ps); memcpy(px_proj, H_(d_proj), Ps * 16); memcpy(match_cand, H_(d_mc), Ps * 4);
+    memcpy(px_match, H_(d_pm), Ps * 16); memcpy(match_level, H_(d_ml), Ps * 4);
+#undef H_
     if (n_matched) { int n = 0; for (int p = 0; p < P; ++p) n += match_cand[p] >= 0; *n_matched = n; }
     return YGZ_OK;
 }

@@ -228,6 +228,20 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
     return YGZ_OK;
 }
 
+// ba::LocalBAG2O's optimize(20) AND its inlier pass (BA.cpp:501-515) in one call: the window the loop ran on is still resident, so the
+// per-edge chi2 at the final state is one more linearisation and ONE array back -- the class surface used to upload the whole graph a
+// second time through ygz_hip_ba_linearize for it
+extern "C" int ygz_hip_ba_optimize_chi2(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io, int max_iterations,
+                                        ygz_ba_stats *stats, double *chi2_edge)
+{
+    int rc = ygz_hip_ba_optimize(ctx, pb, poses_io, points_io, max_iterations, stats);
+    if (rc != YGZ_OK || !chi2_edge) return rc;
+    const int W = 1022;                                       // the window ygz_hip_ba_optimize uploaded
+    if (ygz_hip_ba_last_path(ctx) != YGZ_BA_PATH_RESIDENT && (rc = ygz_hip_ba_set_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;   // (the host loop leaves its last TRIAL state there)
+    if ((rc = ygz_hip_ba_linearize_resident(ctx, W, 1)) != YGZ_OK) return rc;
+    return ygz_hip_ba_download(ctx, W, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, chi2_edge, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // B6/B7 -- ceres::Solve with the reference's (default) options: trust-region Levenberg-Marquardt
 // [frozen spec of ceres-solver 1.13 trust_region_minimizer.cc / levenberg_marquardt_strategy.cc, restated in

@@ -274,10 +274,18 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 #define LM_SPW    42                           // per (pair, part): 36 block entries + 6 of the right-hand side
 static_assert(16 + 4 * LM_MAXG <= 256 && 256 + 4 * LM_NPAIR <= LM_HDR, "scratch header");
 
+// The per-pair hand-off of the Schur sweep (parts as relaxed agent-scope = write-through stores, s_waitcnt vmcnt(0), a workgroup-scope fence for
+// the compiler, a relaxed agent-scope arrival counter; the last arriver re-reads the parts with agent-scope loads) is NOT a release / acquire
+// pair in the HSA memory model: it relies on two properties of gfx942 / gfx950 -- stores are counted by vmcnt (there is no separate vscnt)
+// and sc1 stores / loads go through to the device-coherent level.  On any other target this must be rewritten, not recompiled.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "ba_resident_lm.hip: the hand-off protocol of the Schur sweep is written for gfx942 / gfx950 (vmcnt counts stores, sc1 write-through)"
+#endif
 struct LmTeamArgs {
     const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
     unsigned char *scratch; size_t stride;     // per window: header (LM_HDR) | xpub | part | Sp | Sfin | private pose state of the G members
     int Kmax, prio, Qcap;
+    int xcd_barrier;                           // 1: teams whose members share an XCD take the barrier without the L2 write-back (YGZ_LM_XCD_BARRIER=0: never)
     long long *dbg;                            // YGZ_LM_DEBUG: [16] wall-clock ticks (10 ns) per phase of member 0 of the first window
 };
 #define LM_TICK(k) do { if (A.dbg && blockIdx.x == 0 && tid == 0) { const long long tn_ = wall_clock64(); s_t[k] += tn_ - t_prev; t_prev = tn_; } } while (0)
@@ -329,14 +337,19 @@ __device__ __forceinline__ double lm_max_records(const double *p, int n)
 }
 
 // false: a member did not arrive in time (or another member gave up): the caller returns, the host reports YGZ_E_HIP
-__device__ __forceinline__ bool lm_team_barrier(unsigned *bar, unsigned &epoch, int G, int *s_ok)
+// same_xcd: every member of the team runs on ONE XCD (checked at run time, see k_ba_lm_team).  Then they share that XCD's L2: a member's
+// stores are visible to the others once they are acknowledged (vmcnt) and the reader has dropped its CU's L1 (the acquire below), so the
+// RELEASE -- buffer_wbl2 sc1, which writes every dirty line of the XCD's L2 back to memory, those of the kernels that share the XCD
+// included: 96 MB written per launch for an 11 MB working set (profiles/r04_lm_pmc.md), and the tracking kernels of an offline run slowed
+// down beside it -- is not needed.  Members on different XCDs (the L2s are not coherent with each other) keep the full form.
+__device__ __forceinline__ bool lm_team_barrier(unsigned *bar, unsigned &epoch, int G, int *s_ok, bool same_xcd)
 {
     if (G == 1) { __syncthreads(); return true; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every wavefront drains its own stores
     __syncthreads();
     ++epoch;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!same_xcd) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = epoch * (unsigned)G;
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     __shared__ double s_posed[LM_LDSK][BA_POSED], s_posed_bk[LM_LDSK][BA_POSED];   // the prepared poses (q, t, R) ARE the pose state of the loop; backup for pop()
     __shared__ int32_t s_free_idx[LM_LDSK], s_free_pose[LM_LDSK];
     __shared__ uint8_t s_fixed[LM_LDSK];
-    __shared__ int s_fail, s_ok;
+    __shared__ int s_fail, s_ok, s_same;
     __shared__ long long s_t[16];
     const int G = A.G;
     const int xslot = blockIdx.x & 7, j = blockIdx.x >> 3, g = j % G, w = (j / G) * 8 + xslot;
@@ -573,6 +586,17 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
         posed_bk = &s_posed_bk[0][0];
     }
     unsigned epoch = 0;
+    bool same_xcd = false;
+    if (G > 1 && A.xcd_barrier && tid == 0) {
+        // which XCD this member runs on (bar[2] = max id + 1, bar[3] = max (255 - id) + 1 over the members: equal ids <=> one XCD).  The
+        // launch deals members of a team to blocks b, b + 8, b + 16 ... and the dispatcher deals block b to XCD b % 8 -- observed, not
+        // promised: the light barrier is only taken when the register says so
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 255u;
+        __hip_atomic_fetch_max(bar + 2, x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(bar + 3, 256u - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     // The pose state of the loop is the PREPARED pose T = (q, t, R): oplus is T <- exp(update) T (VertexSE3Sophus::oplusImpl, G2oTypes.h:38-45,
     // stores log(exp(update) exp(estimate)) and every later use takes exp of it again -- the same T up to the rounding of log and exp; two
@@ -621,7 +645,12 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             }
         }
         LM_TICK(0);
-        if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+        if (!lm_team_barrier(bar, epoch, G, &s_ok, same_xcd)) return;
+        if (it == 0 && G > 1 && A.xcd_barrier) {                  // behind the first (full) barrier every member has published its XCD
+            if (tid == 0) s_same = __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 257u;
+            __syncthreads();
+            same_xcd = s_same != 0;
+        }
         LM_TICK(1);
         {   // every member adds the chunk records in chunk order: identical sH, chi2 (and lambda at the first iteration)
             for (int i = tid; i < 27 * Kf; i += LM_THREADS) sH[i / 27][i % 27] = lm_sum_records(crec + 8 + i, Q);
@@ -716,7 +745,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             // (two pairs per wavefront walking the points together -- to overlap their load chains -- needs 84 accumulators: 110 spilled
             // registers, 2040 instead of 1680 us per 24 sweeps)
             LM_TICK(5);
-            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            if (!lm_team_barrier(bar, epoch, G, &s_ok, same_xcd)) return;
             LM_TICK(6);
             // ---- 3. EVERY member: the blocks of S from Sfin, L D L^T by block columns, substitutions -- the same 1176 values and the same
             //         arithmetic everywhere, so x_p needs no publishing and no team barrier (member 0 alone solved while 31 members waited for
@@ -817,7 +846,7 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             }
             LM_TICK(15);
             LM_TICK(11);
-            if (!lm_team_barrier(bar, epoch, G, &s_ok)) return;
+            if (!lm_team_barrier(bar, epoch, G, &s_ok, same_xcd)) return;
             LM_TICK(12);
             double scale = 0.0, tempChi = DBL_MAX;
             if (ok2) {
@@ -975,6 +1004,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
     A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax; A.Qcap = Qcap;
     A.dbg = nullptr; A.prio = (ctx->wave_prio_mask >> 3) & 1;
+    { static const bool xb = [] { const char *e = getenv("YGZ_LM_XCD_BARRIER"); return !(e && e[0] == '0'); }(); A.xcd_barrier = xb ? 1 : 0; }
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
     YgzAuxScope aux(ctx, 1);

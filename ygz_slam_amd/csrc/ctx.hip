@@ -50,6 +50,18 @@ int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out)
     return YGZ_OK;
 }
 
+int ygz_scratch_mirror(ygz_hip_ctx *ctx, int id, void **host)
+{
+    if (id < 0 || id >= YGZ_N_SCRATCH || !ctx->scratch[id]) return YGZ_E_INVALID;
+    if (ctx->scratch_host_bytes[id] < ctx->scratch_bytes[id]) {
+        if (ctx->scratch_host[id]) { YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->scratch_host[id]); ctx->scratch_host[id] = nullptr; ctx->scratch_host_bytes[id] = 0; }
+        YGZ_HIPCHK(ctx, hipHostMalloc(&ctx->scratch_host[id], ctx->scratch_bytes[id], hipHostMallocDefault));
+        ctx->scratch_host_bytes[id] = ctx->scratch_bytes[id];
+    }
+    *host = ctx->scratch_host[id];
+    return YGZ_OK;
+}
+
 void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes)
 {
     bytes = (bytes + 63) & ~(size_t)63;
@@ -194,7 +206,7 @@ void ygz_hip_destroy(ygz_hip_ctx *ctx)
                      ctx->pair_T, ctx->kp_depth, ctx->kp_has_mp, ctx->klt_pts, ctx->klt_err, ctx->klt_status, ctx->fdp_px,
                      ctx->fdp_level, ctx->fdp_ok, ctx->sa_out, ctx->sa_work, ctx->fdp_cand, ctx->po_pw, ctx->po_pose, ctx->po_T, ctx->po_depth, ctx->po_bad, ctx->po_cnt };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < YGZ_N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (int i = 0; i < YGZ_N_SCRATCH; ++i) { if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]); if (ctx->scratch_host[i]) (void)hipHostFree(ctx->scratch_host[i]); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);

@@ -21,6 +21,7 @@
 //  k_describe     one wavefront per keypoint: 39x39 neighbourhood in LDS, integer moments by
 //                 wave reduction, cv::fastAtan2 polynomial, 256 tests = 4 ballots of 64 lanes.
 #include "ygz_internal.h"
+#include <cstring>
 #include <stdlib.h>
 #include <stdio.h>
 #include "../../include/ygz_orb_pattern.h"
@@ -587,8 +588,12 @@ int ygz_hip_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots, const uint8_t 
     if (!ctx || slot_begin < 0 || n_slots < 1 || slot_begin + n_slots > ctx->prm.max_frames) return YGZ_E_INVALID;
     for (int s = slot_begin; s < slot_begin + n_slots; ++s) if (!ctx->pyr_valid[s]) return YGZ_E_STATE;
     const size_t Cn = (size_t)ctx->cells;
-    if (occupied) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->occupied + (size_t)slot_begin * Cn, occupied, (size_t)n_slots * Cn,
-                                                  hipMemcpyHostToDevice, ctx->stream));
+    if (occupied) {                                           // through the page-locked arena: the caller's array may be pageable and short-lived
+        void *st = ygz_stage(ctx, (size_t)n_slots * Cn);
+        if (!st) return YGZ_E_HIP;
+        memcpy(st, occupied, (size_t)n_slots * Cn);
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->occupied + (size_t)slot_begin * Cn, st, (size_t)n_slots * Cn, hipMemcpyHostToDevice, ctx->stream));
+    }
     { const int rc = detect_clear(ctx, slot_begin, n_slots, occupied == nullptr); if (rc != YGZ_OK) return rc; }
     return ygz_launch_detect(ctx, slot_begin, n_slots);
 }
@@ -606,21 +611,31 @@ int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capa
 {
     YgzDeviceGuard dg_(ctx);
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
-    if (!ctx || !out || !n_out || slot < 0 || slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
-    int n = 0;
-    int rc = ygz_hip_keypoint_count(ctx, slot, &n);
-    if (rc != YGZ_OK) return rc;
+    if (!ctx || !out || !n_out || slot < 0 || slot >= ctx->prm.max_frames || capacity < 0) return YGZ_E_INVALID;
+    // the count and `rows` rows of every requested field into ONE page-locked slice, one wait (the count is not known on the host yet, so
+    // min(capacity, cells) rows are fetched: 184 KB for a whole VGA grid -- microseconds of link time against a wait + a staged pageable copy per field)
+    const size_t o = (size_t)slot * ctx->cells, rows = (size_t)(capacity < ctx->cells ? capacity : ctx->cells);
+    const size_t b_px = out->px ? rows * 16 : 0, b_lv = out->level ? rows * 4 : 0, b_sc = out->score ? rows * 4 : 0, b_an = out->angle ? rows * 4 : 0,
+                 b_de = out->desc ? rows * 32 : 0;
+    uint8_t *st = (uint8_t *)ygz_stage(ctx, 64 + b_px + b_lv + b_sc + b_an + b_de);
+    if (!st) return YGZ_E_HIP;
+    uint8_t *h_px = st + 64, *h_lv = h_px + b_px, *h_sc = h_lv + b_lv, *h_an = h_sc + b_sc, *h_de = h_an + b_an;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(st, ctx->n_kp + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (b_px) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_px, ctx->kp_px + 2 * o, b_px, hipMemcpyDeviceToHost, ctx->stream));
+    if (b_lv) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_lv, ctx->kp_level + o, b_lv, hipMemcpyDeviceToHost, ctx->stream));
+    if (b_sc) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_sc, ctx->kp_score + o, b_sc, hipMemcpyDeviceToHost, ctx->stream));
+    if (b_an) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_an, ctx->kp_angle + o, b_an, hipMemcpyDeviceToHost, ctx->stream));
+    if (b_de) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_de, ctx->kp_desc + 8 * o, b_de, hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = *reinterpret_cast<const int32_t *>(st);
     *n_out = n;
     if (n > capacity) return YGZ_E_CAPACITY;
-    const size_t o = (size_t)slot * ctx->cells;
-    if (n > 0) {
-        if (out->px) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->px, ctx->kp_px + 2 * o, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->level) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->level, ctx->kp_level + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->score) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->score, ctx->kp_score + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->angle) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->angle, ctx->kp_angle + o, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (out->desc) YGZ_HIPCHK(ctx, hipMemcpyAsync(out->desc, ctx->kp_desc + 8 * o, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    const size_t N = (size_t)n;
+    if (out->px) memcpy(out->px, h_px, N * 16);
+    if (out->level) memcpy(out->level, h_lv, N * 4);
+    if (out->score) memcpy(out->score, h_sc, N * 4);
+    if (out->angle) memcpy(out->angle, h_an, N * 4);
+    if (out->desc) memcpy(out->desc, h_de, N * 32);
     return YGZ_OK;
 }
 

@@ -14,6 +14,7 @@
 // fails behind the camera (CeresReprojectionErrorPoseOnly.h:48-51), which makes the solver reject that step (or give up at
 // iteration zero, leaving the pose as it was).
 #include "ygz_internal.h"
+#include <cstring>
 #include "se3_dev.h"
 
 #define PO_THREADS 256
@@ -314,22 +315,25 @@ extern "C" int ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const 
     A.fx = (double)ctx->prm.fx; A.fy = (double)ctx->prm.fy; A.cx = (double)ctx->prm.cx; A.cy = (double)ctx->prm.cy;
     ygz_hip_ceres_default_options(&A.opt);
     A.opt.fail_behind_camera = 1;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync((void *)A.d.off, frame_off, b_off, hipMemcpyHostToDevice, ctx->stream));
-    if (n > 0) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_px, px, n * 16, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(d_pw, pw, n * 24, hipMemcpyHostToDevice, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(A.d.depth, depth, n * 8, hipMemcpyHostToDevice, ctx->stream));     // outliers keep their value
-    }
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(A.d.poses, poses_io, b_pose, hipMemcpyHostToDevice, ctx->stream));
+    // one copy up, one down: the arrays are packed into the page-locked mirror of the blob at the device offsets
+    uint8_t *hb = nullptr;
+    if ((rc = ygz_scratch_mirror(ctx, SCR_GEN_0, (void **)&hb)) != YGZ_OK) return rc;
+    const uint8_t *b0 = (const uint8_t *)blob;
+    const size_t total = (size_t)((const uint8_t *)A.d.bad + b_bad - b0);
+#define H_(dptr) (hb + ((const uint8_t *)(dptr) - b0))
+    memcpy(H_(A.d.off), frame_off, b_off);
+    if (n > 0) { memcpy(H_(d_px), px, n * 16); memcpy(H_(d_pw), pw, n * 24); memcpy(H_(A.d.depth), depth, n * 8); }     // outliers keep their depth
+    memcpy(H_(A.d.poses), poses_io, b_pose);
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(blob, hb, total, hipMemcpyHostToDevice, ctx->stream));
     YGZ_LAUNCH(ctx, KID_POSE_ONLY, k_pose_only_ba, dim3(n_frames), dim3(PO_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(poses_io, A.d.poses, b_pose, hipMemcpyDeviceToHost, ctx->stream));
-    if (n > 0) {
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(bad, A.d.bad, n, hipMemcpyDeviceToHost, ctx->stream));
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(depth, A.d.depth, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (inliers) YGZ_HIPCHK(ctx, hipMemcpyAsync(inliers, A.d.inliers, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (rounds) YGZ_HIPCHK(ctx, hipMemcpyAsync(rounds, A.d.rounds, (size_t)n_frames * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const size_t out0 = (size_t)((const uint8_t *)A.d.poses - b0);                 // poses | depth | counts | bad are the tail of the blob
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(hb + out0, (uint8_t *)blob + out0, total - out0, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(poses_io, H_(A.d.poses), b_pose);
+    if (n > 0) { memcpy(bad, H_(A.d.bad), n); memcpy(depth, H_(A.d.depth), n * 8); }
+    if (inliers) memcpy(inliers, H_(A.d.inliers), (size_t)n_frames * 4);
+    if (rounds) memcpy(rounds, H_(A.d.rounds), (size_t)n_frames * 4);
+#undef H_
     return YGZ_OK;
 }

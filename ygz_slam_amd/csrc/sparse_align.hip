@@ -13,6 +13,7 @@
 //   one lane of wave 1 solves the 6x6 LDLT and forms T * exp(-x) meanwhile; lane 0 takes the accept / stop decision.
 // No host round trip per iteration (the reference solves ~30 6x6 systems per frame pair).
 #include "ygz_internal.h"
+#include <cstring>
 #include "se3_dev.h"
 #include "ldlt6.h"
 #include <stdlib.h>
@@ -1196,15 +1197,21 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     int rc = ygz_track_set_pairs(ctx, &cur_slot, &ref_slot, T_cur, T_ref, 1);
     if (rc != YGZ_OK) return rc;
     const size_t N = (size_t)n;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, depth, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_has_mp, has_mappoint, N, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->sa_out, T_cur, 7 * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // inputs through the page-locked arena (no wait before the launch: the slices live until the next ygz_hip_synchronize), the 16 result
+    // doubles back into it: ONE wait per call instead of two around five pageable copies
+    uint8_t *st = (uint8_t *)ygz_stage(ctx, N * 25 + 64 + 56 + 8 + 128);
+    if (!st) return YGZ_E_HIP;
+    double *h_px = (double *)st, *h_dep = h_px + 2 * N, *h_T = h_dep + N, *h_out = h_T + 7;
+    int32_t *h_n = (int32_t *)(h_out + 16);
+    uint8_t *h_mp = (uint8_t *)(h_n + 2);
+    memcpy(h_px, px, N * 16); memcpy(h_dep, depth, N * 8); memcpy(h_mp, has_mappoint, N); memcpy(h_T, T_cur, 56); *h_n = n;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, h_px, N * 16, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, h_dep, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_has_mp, h_mp, N, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, h_n, 4, hipMemcpyHostToDevice, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->sa_out, h_T, 7 * 8, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = ygz_launch_sparse_align(ctx, 1, max_level, min_level, n_iter)) != YGZ_OK) return rc;
-    double h_out[16];
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, sizeof(h_out), hipMemcpyDeviceToHost, ctx->stream));
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 7; ++k) T_cur[k] = h_out[k];
     if (n_meas_out) *n_meas_out = (int)(h_out[7] / 16);        // run() returns n_meas_/patch_area_ (:49)

@@ -100,6 +100,11 @@ struct ygz_hip_ctx {
     // growable scratch buffers
     void  *scratch[YGZ_N_SCRATCH] = {nullptr};
     size_t scratch_bytes[YGZ_N_SCRATCH] = {0};
+    // page-locked host mirrors of scratch buffers (ygz_scratch_mirror): an entry point that moves many small arrays packs them into the
+    // mirror at the device offsets and crosses PCIe with ONE copy per direction (the single-frame class-surface calls: a pageable
+    // hipMemcpyAsync per array cost 36 staged copies per frame)
+    void  *scratch_host[YGZ_N_SCRATCH] = {nullptr};
+    size_t scratch_host_bytes[YGZ_N_SCRATCH] = {0};
 
     // resident BA windows
     struct Vocab;
@@ -179,6 +184,8 @@ enum { SCR_MATCH_Q = 0, SCR_MATCH_T, SCR_ALIGN_IN, SCR_ALIGN_OUT, SCR_SA_IN, SCR
        SCR_KLT_PTS, SCR_KLT_OUT, SCR_BA_0, SCR_BOW, SCR_LMAP, SCR_WIN, SCR_GEN_0 = 16 };
 
 int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
+// page-locked host memory of (at least) the capacity of scratch buffer `id` (call after ygz_scratch); valid until the scratch grows
+int ygz_scratch_mirror(ygz_hip_ctx *ctx, int id, void **host);
 // `bytes` of page-locked host memory that stay valid until the next ygz_hip_synchronize (nullptr: allocation failed)
 void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes);
 // the brute-force matcher over descriptor sets desc + s * set_stride (u32 units), sizes set_count[s], pairs (pair_q[p], pair_t[p]): device

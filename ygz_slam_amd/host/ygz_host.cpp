@@ -109,7 +109,7 @@ void Runtime::Release(Frame *f)
 }
 void Runtime::RegisterLevels(Frame *f)
 {
-    for (size_t L = 0; L < f->_pyramid.size(); ++L) p_->level_of[f->_pyramid[L].data] = std::make_pair(f, (int)L);
+    for (size_t L = 0; L < f->_pyramid.size(); ++L) if (f->_pyramid.fetched(L)) p_->level_of[f->_pyramid[L].data] = std::make_pair(f, (int)L);
 }
 bool Runtime::FindLevel(const uint8_t *data, Frame **f, int *level)
 {
@@ -131,9 +131,19 @@ int Runtime::Resident(Frame *f)
         p_->owner[slot]->_hip_slot = -1;
     }
     p_->owner[slot] = f; p_->stamp[slot] = ++p_->clock; f->_hip_slot = slot;
-    if (!f->_pyramid.empty() && !f->_pyramid[0].empty()) {
+    if (!f->_pyramid.empty() && !f->_color.empty()) {                 // an initialised frame that lost its slot: the image goes up again (Frame.cpp:22-40 on the GPU)
+        if (f->_color.channels() == 3) {
+            check(ygz_hip_upload_bgr(c, slot, f->_color.data, (int)f->_color.step), "upload_bgr");
+            check(ygz_hip_build_pyramid(c, slot, 1, 1), "build_pyramid");
+        } else {
+            check(ygz_hip_upload_gray(c, slot, f->_color.data, (int)f->_color.step), "upload_gray");
+            check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
+        }
+    } else if (!f->_pyramid.empty() && f->_pyramid.fetched(0)) {      // _color was released by the caller: level 0 of the host mirror, if somebody fetched it
         check(ygz_hip_upload_gray(c, slot, f->_pyramid[0].data, (int)f->_pyramid[0].step), "upload_gray");
         check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
+    } else if (!f->_pyramid.empty()) {
+        throw std::runtime_error("ygz::hip::Runtime: an evicted frame has neither _color nor a fetched level 0 to be uploaded again (raise YGZ_HIP_MAX_FRAMES)");
     }
     return slot;
 }
@@ -143,6 +153,21 @@ int Runtime::Resident(Frame *f)
 PinholeCamera *Frame::_camera = nullptr;
 ORBVocabulary *Frame::_vocab = nullptr;
 Frame::~Frame() { if (!_features.empty()) CleanAllFeatures(); hip::Runtime::Get().Release(this); }
+
+void hip::PyramidMirror::fetch(size_t L)
+{   // the first reader of a level pays for its copy (and nobody else pays for levels nobody reads)
+    if (L >= lv_.size()) throw std::out_of_range("Frame::_pyramid: level out of range");
+    if (have_[L] || !owner_) return;
+    Runtime &rt = Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    int w = 0, h = 0;
+    check(ygz_hip_level_size(c, (int)L, &w, &h), "level_size");
+    lv_[L].create(h, w, CV_8UC1);
+    have_[L] = 1;                                    // (before Resident: a re-upload of an evicted frame must not recurse into this level)
+    const int slot = rt.Resident(owner_);
+    check(ygz_hip_download_level(c, slot, (int)L, lv_[L].data), "download_level");
+    rt.RegisterLevels(owner_);
+}
 
 void Frame::InitFrame()
 {
@@ -161,21 +186,13 @@ void Frame::InitFrame()
         hip::check(ygz_hip_upload_gray(c, slot, _color.data, (int)_color.step), "upload_gray");
         hip::check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
     }
-    CreateImagePyramid();
+    _pyramid.reset(this, (size_t)_option._pyramid_level);      // levels are fetched when somebody indexes them
 }
 
 void Frame::CreateImagePyramid()
-{   // host mirror of the levels (callers read frame->_pyramid[L])
-    hip::Runtime &rt = hip::Runtime::Get();
-    ygz_hip_ctx *c = rt.ctx();
-    _pyramid.resize(_option._pyramid_level);
-    for (int L = 0; L < _option._pyramid_level; ++L) {
-        int w = 0, h = 0;
-        hip::check(ygz_hip_level_size(c, L, &w, &h), "level_size");
-        _pyramid[L].create(h, w, CV_8UC1);
-        hip::check(ygz_hip_download_level(c, _hip_slot, L, _pyramid[L].data), "download_level");
-    }
-    rt.RegisterLevels(this);
+{   // every level into the host mirror now (callers that walk frame->_pyramid[L] get them one by one anyway)
+    if (_pyramid.size() != (size_t)_option._pyramid_level) _pyramid.reset(this, (size_t)_option._pyramid_level);
+    for (size_t L = 0; L < _pyramid.size(); ++L) (void)_pyramid[L];
 }
 
 Mat Frame::GetAllDescriptors()
@@ -639,6 +656,8 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
     vector<MapPoint *> mps(local_map_points.begin(), local_map_points.end());
     vector<double> pos; vector<uint8_t> bad;
     vector<int32_t> cp, ck, cl; vector<double> cpx; vector<Feature *> cfea;
+    { const size_t P0 = mps.size(), C0 = P0 * kfs.size();
+      pos.reserve(3 * P0); bad.reserve(P0); cp.reserve(C0); ck.reserve(C0); cl.reserve(C0); cpx.reserve(2 * C0); cfea.reserve(C0); }
     for (size_t p = 0; p < mps.size(); ++p) {
         MapPoint *mp = mps[p];
         pos.push_back(mp->_pos_world[0]); pos.push_back(mp->_pos_world[1]); pos.push_back(mp->_pos_world[2]);
@@ -670,6 +689,7 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
         mp->_cnt_visible++;                                            // :64
         if (match[p] < 0) continue;
         Feature *src = cfea[match[p]];
+        if (current->_features.capacity() < current->_features.size() + (size_t)n) current->_features.reserve(current->_features.size() + (size_t)n);
         Feature *feature = new Feature(Vector2d(px_match[2 * p], px_match[2 * p + 1]), level[p], src->_score);   // :104-111
         feature->_frame = current;
         feature->_mappoint = mp;
@@ -781,10 +801,9 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     pb.fx = cam->fx(); pb.fy = cam->fy(); pb.cx = cam->cx(); pb.cy = cam->cy();      // EdgeSophusSE3ProjectXYZ::setCamera
     pb.huber_delta = 5.991; pb.formulation = 0;                                       // BA.cpp:451
     ygz_ba_stats st;
-    hip::check(ygz_hip_ba_optimize(rt.ctx(), &pb, poses.data(), points.data(), 20, &st), "ba_optimize");
-    // inlier test on the optimised state: chi2 > 5.991 -> Feature::_bad (BA.cpp:504-515)
+    // optimize(20), then the inlier test on the optimised state: chi2 > 5.991 -> Feature::_bad (BA.cpp:501-515) -- one call, the graph is uploaded once
     std::vector<double> chi2_edge(pb.n_edges);
-    hip::check(ygz_hip_ba_linearize(rt.ctx(), &pb, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, chi2_edge.data(), nullptr), "ba_linearize");
+    hip::check(ygz_hip_ba_optimize_chi2(rt.ctx(), &pb, poses.data(), points.data(), 20, &st, chi2_edge.data()), "ba_optimize_chi2");
     int cntOutlier = 0;
     for (size_t i = 0; i < features.size(); ++i) if (chi2_edge[i] > 5.991) { cntOutlier++; features[i]->_bad = true; }
     for (Frame *frame : local_keyframes) {             // BA.cpp:520-531

@@ -229,6 +229,7 @@ struct ygz_offline {
     int lm_launches = 0, lm_retries = 0, n_degenerate = 0;
     double ms_track = 0, ms_gather = 0, ms_ba_tail = 0, ms_exchange = 0;
     ygz_offline_chunk_fn cb = nullptr; void *cb_user = nullptr;
+    bool trace = false; double t_run0 = 0;         // YGZ_OFFLINE_TRACE=1: where the host thread spends a run (stderr)
     std::string err;
 };
 
@@ -329,8 +330,14 @@ int exchange_rows(ygz_offline *o)
 }
 
 // ---- one chunk: uploads, the batched kernels, keyframe rows and relative poses into the store, result rows -- all asynchronous ------------
+void trace_line(const ygz_offline *o, const char *what, int ci, double t0)
+{
+    if (o->trace) fprintf(stderr, "[offline host] %8.3f  %-10s chunk %2d  %6.3f ms\n", t0 - o->t_run0, what, ci, now_ms() - t0);
+}
+
 int enqueue_chunk(ygz_offline *o, int ci)
 {
+    const double t_enq = now_ms();
     Chunk &c = o->chunks[ci];
     ygz_hip_ctx *L = o->lanes[ci % o->lanes.size()];
     const ygz_offline_params &p = o->p;
@@ -367,6 +374,7 @@ int enqueue_chunk(ygz_offline *o, int ci)
     }
     OCHK(o, ygz_hip_get_keypoint_counts(L, 0, n, c.pin_cnt, 0), "get_keypoint_counts");
     if (!c.kf_slot.empty()) OCHK(o, ygz_hip_kf_store_put(o->ba, L, (int)c.kf_slot.size(), c.kf_slot.data(), c.kf_row.data()), "kf_store_put");
+    trace_line(o, "enqueue", ci, t_enq);
     return YGZ_OK;
 }
 
@@ -375,7 +383,9 @@ int collect_chunk(ygz_offline *o, int ci)
 {
     Chunk &c = o->chunks[ci];
     ygz_hip_ctx *L = o->lanes[ci % o->lanes.size()];
+    const double t_col = now_ms();
     OCHK(o, ygz_hip_synchronize(L), "synchronize");
+    trace_line(o, "wait", ci, t_col);
     for (size_t si = 0; si < c.spans.size(); ++si) {                          // the frames of the chunk proper (a halo frame belongs to another chunk)
         const int k0 = c.spans[si].first + (c.ranges[si].first > 0 ? 1 : 0);
         for (int k = k0; k < c.spans[si].first + c.spans[si].second; ++k) o->n_kp[c.frames[k]] = c.pin_cnt[k];
@@ -717,6 +727,7 @@ int ygz_offline_track(ygz_offline *o, const uint8_t *frames, const void *depth, 
     const Plan &P = o->plan;
     if (first_in_buffer > P.start - P.halo) { o->err = "the frame buffer starts behind the shard's halo frame"; return YGZ_E_INVALID; }
     const double t0 = now_ms();
+    o->trace = getenv("YGZ_OFFLINE_TRACE") != nullptr; o->t_run0 = t0;
     o->frames = frames; o->depth = (const uint8_t *)depth; o->first_in_buffer = first_in_buffer;
     o->tracked.assign(o->p.n_frames, 0); o->ba_done.assign(o->mine.size(), 0); o->ba_built.clear();
     o->lm_launches = 0; o->lm_retries = 0; o->n_degenerate = 0; o->last_upload = nullptr;
@@ -745,12 +756,14 @@ int ygz_offline_track(ygz_offline *o, const uint8_t *frames, const void *depth, 
             if ((int)k != s_lo + s_n) { o->err = "windows become ready out of order"; return YGZ_E_STATE; }
             ++s_n;
         }
-        if (s_n) { if ((rc = ba_launch(o, s_lo, s_n, false)) != YGZ_OK) return rc; for (int k = s_lo; k < s_lo + s_n; ++k) o->ba_built.push_back(k); }
+        if (s_n) { const double tb = now_ms(); if ((rc = ba_launch(o, s_lo, s_n, false)) != YGZ_OK) return rc; for (int k = s_lo; k < s_lo + s_n; ++k) o->ba_built.push_back(k); trace_line(o, "build", ci, tb); }
         const bool all_built = n_done + o->ba_built.size() == o->local.size();     // nothing more will come: the last launch need not wait for the last chunk
         if (!o->ba_built.empty() && ((int)o->ba_built.size() >= lm_next(o) || ci == n_chunks - 1 || all_built)) {
             // beside the tracking of the next chunks a launch may be held to a few CUs; the last launch, which nothing runs beside, takes the default
             OCHK(o, ygz_hip_ba_set_team_budget(o->ba, (ci < n_chunks - 1 && !all_built) ? o->p.bg_team_budget : 0), "ba_set_team_budget");
+            const double tl = now_ms();
             if ((rc = lm(o, o->ba_built.front(), (int)o->ba_built.size())) != YGZ_OK) return rc;
+            trace_line(o, "lm", ci, tl);
             for (int k : o->ba_built) o->ba_done[k] = 1;
             n_done += o->ba_built.size();
             o->ba_built.clear();
