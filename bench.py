@@ -54,8 +54,6 @@ class Pipeline:
         self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device, stream=stream)
         self.frames, self.poses, self.depths, self.ba = inputs if inputs is not None else build_inputs(batch, rank)
         self.from_bgr = True
-        self.klt_prepare = os.environ.get("YGZ_BENCH_KLT_PREPARE", "0") == "1"
-        self.ba_early = os.environ.get("YGZ_BENCH_BA_EARLY", "0") == "1"
 
     def setup_stream(self, upload):
         """stream mode: the batch lives in page-locked host memory and crosses PCIe every step; so do the results"""
@@ -140,15 +138,10 @@ class Pipeline:
         # alignment and the HBM / FP64-bound BA build then share the CUs with the VALU-bound extractor, LK and matcher.
         # (Issuing the BA build -- it depends on no image -- before the extractor was measured slower: 3.64 against 3.55 ms.)
         c.build_pyramid(0, self.B, from_bgr=self.from_bgr)    # A1  InitFrame
-        if self.klt_prepare:
-            c.track_klt_prepare()                             # LK's working images on a side stream, beside the extractor
-        if self.ba_early:
-            c.ba_linearize_resident(0, self.B)
         c.detect(0, self.B)                                   # A2-A7 FeatureDetector::Detect
         c.track_reload(True)                                  # track sets from the fresh keypoints
         c.track_sparse_align()                                # L3  SparseImgAlign::run
-        if not self.ba_early:
-            c.ba_linearize_resident(0, self.B)                # B1-B5 one Jacobian/JtJ build per frame
+        c.ba_linearize_resident(0, self.B)                    # B1-B5 one Jacobian/JtJ build per frame
         c.match_slots_again(1)                                # M1-M3 BFMatcher(crossCheck) vs predecessor
         c.track_direct()                                      # L1-L2 FindDirectProjection / Align2D (side stream, beside LK)
         c.track_klt()                                         # L4  Tracker::TrackKLT
@@ -237,7 +230,7 @@ def cpu_baseline(pipe, budget_s=12.0):
 
 def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
     """VALU issue roofline of k_klt3 (the probed launches of the timed region, and alone) and the matrix-core roofline of the
-    matcher k_hamming_mfma (probed here, outside the timed region): wave64 VALU instructions per launch (profiles/valu_counts.json: SQ_INSTS_VALU of a counter pass, scaled to this batch and
+    matcher k_hamming_f4 (probed here, outside the timed region): wave64 VALU instructions per launch (profiles/valu_counts.json: SQ_INSTS_VALU of a counter pass, scaled to this batch and
     keypoint count) / launch time / SIMDs, against the issue ceiling of the kernel's opcode mix (profiles/valu_mix.json from
     tools/valu_mix.py + the per-opcode rates measured by tools/ubench/valu_peak, profiles/r02_valu_peak.txt)."""
     base = os.path.join(ROOT, "profiles")
@@ -284,7 +277,7 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
     if n:
         ops = 2.0 * 256.0 * n_kp * n_kp * a.batch            # per launch: every pair of the batch, one direction
         t = ms / n * 1e-3
-        form = {"1": "k_hamming_mfma (int8 32x32x32)"}.get(os.environ.get("YGZ_HAMMING_FORM", "0"), "k_hamming_f4 (FP4 32x32x64, block scale 2^6)")
+        form = "k_hamming_f4 (FP4 32x32x64, block scale 2^6)"
         out["mfma"] = {"kernel": form, "bound": "mfma", "unit": "TOP/s", "ops_per_launch": ops, "avg_launch_us": t * 1e6,
                        "achieved": ops / t / 1e12, "peak": 10000.0, "peak_int8": 5000.0, "peak_measured_here_fp4": 7630.0, "peak_measured_here_int8": 4392.0,
                        "frac": ops / t / 1e12 / 10000.0,
@@ -549,7 +542,6 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     need, n_frames, count = R["need"], R["n_frames"], R["count"]
     gray_in = upload == "gray"                                # the caller hands gray frames over (cv::cvtColor's fixed-point weights, on the host)
     chunk = min(chunk, max(32, -(-count // 4)))               # a shard is cut into >= 4 chunks: uploads, kernels and the BA windows of a rank overlap
-    chunk = int(os.environ.get("YGZ_OFF_CHUNK", chunk))        # (experiment)
     if lanes is None:
         # BGR frames: the run is PCIe-bound, three lanes keep the link busy (four: 57.1 against 56.0 ms of tracking per 1024 frames);
         # gray frames: kernel-bound, a fourth lane fills more of the GPU (38.6 against 40.1 ms)
@@ -934,8 +926,7 @@ def stream_block(pipe, a, local_rank, rank, steps=18, warmup=3):
     current one ends, so PCIe never waits for the host), the stages of a batch on one stream (side streams of three contexts would
     share the hardware queues)"""
     import torch
-    n_buf = int(os.environ.get("YGZ_STREAM_BUFS", "3"))
-    side = os.environ.get("YGZ_STREAM_OVERLAP", "0") == "1"
+    n_buf, side = 3, False
     streams = [torch.cuda.Stream() for _ in range(n_buf - 1)]
     pipes = [pipe]
     for st in streams:
@@ -950,7 +941,7 @@ def stream_block(pipe, a, local_rank, rank, steps=18, warmup=3):
         for q in pipes:
             q.setup_stream(upload)
         k = 0
-        fifo = os.environ.get("YGZ_STREAM_FIFO", "1") != "0"
+        fifo = True
         for _ in range(warmup):
             pipes[k % n_buf].stream_step(pipes[(k - 1) % n_buf] if fifo and k else None); k += 1
         for q in pipes:

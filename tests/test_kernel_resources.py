@@ -20,11 +20,8 @@ BUDGET = {
     "k_scharr": ("klt", 8, 0),
     "k_klt_pad": ("klt", 8, 0),
     "k_hamming_f4ILi2E": ("hamming", 3, 0),        # the default matcher: 162 VGPRs, accumulators in VGPRs
-    "k_hamming_mfma7HamArgs": ("hamming", 3, 0),
-    "k_sparse_alignILi256E": ("sparse_align", 1, 0),   # one wavefront per SIMD by design (256 + 30 registers)
-    "k_sparse_alignILi512E": ("sparse_align", 2, 256),  # 512 lanes: 256 registers per lane, loop-invariant pointers live in scratch
-    "k_sparse_align2ILi256ELb0E": ("sparse_align", 1, 0),   # the default form: 256 + <= 72 registers (more, and the matcher no longer fits beside it in the step)
-    "k_sparse_align2ILi512ELb0E": ("sparse_align", 2, 384), # 720p problems: capped at 256 registers per lane
+    "k_sparse_align2ILi256EE": ("sparse_align", 1, 0),      # the batch form: 256 + <= 72 registers (more, and the matcher no longer fits beside it in the step)
+    "k_sparse_align2ILi512EE": ("sparse_align", 2, 384),    # 720p problems and single-frame calls: capped at 256 registers per lane
     "k_fast_select": ("detect", 8, 0),
     "k_describe": ("detect", 8, 0),
     "k_ba_points": ("ba", 3, 0),
@@ -70,7 +67,7 @@ def test_hot_kernels_keep_their_register_budget():
                             % (k, v["Occupancy"], min_occ, v["VGPRs"], v["AGPRs"], v["ScratchSize"], max_scratch))
     # the resident sparse alignment shares every SIMD with the matcher (168 registers) and one LK wavefront: beyond 344 registers per lane
     # the matcher no longer fits beside it and the step gets 10 % slower (measured with 382)
-    (k, v), = [(k, v) for k, v in per_file["sparse_align"].items() if "k_sparse_align2ILi256ELb0E" in k]
+    (k, v), = [(k, v) for k, v in per_file["sparse_align"].items() if "k_sparse_align2ILi256EE" in k]
     if v["VGPRs"] + v["AGPRs"] > 344:
         problems.append("%s: %d + %d registers per lane (budget 344)" % (k, v["VGPRs"], v["AGPRs"]))
     assert not problems, "\n".join(problems)

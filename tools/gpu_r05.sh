@@ -73,4 +73,16 @@ g)  # the resident LM with the same-XCD barrier (no L2 write-back): parity, time
     timeout 300 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; python -c "
 import json; d=json.load(open('$OUT/surface.json'))['surface']; d.pop('what'); print(json.dumps(d))"
     ;;
+h)  # the whole GPU suite + the default bench line (after the pruning of the experiment forms)
+    timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
+    timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python - $OUT/bench_default.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value %.0f ms/step %.3f" % (d["value"], d["ms_per_step"]), d.get("step_ms"))
+print("roofline", {k: d["roofline"][k] for k in ("achieved","frac","avg_launch_us") if k in d["roofline"]})
+print("offline", d["offline"].get("value"), d["offline"].get("ms_per_step"), d["offline"].get("config",{}).get("exchange_backend"))
+print("surface", {k: d["surface"].get(k) for k in ("frames_per_s","vs_cpu_1core","ms_per_frame")})
+print("stages", d["stage_ms_per_batch"])
+PY
+    ;;
 esac

@@ -127,8 +127,6 @@ int ygz_hip_create(ygz_hip_ctx **out, int device, const ygz_hip_params *prm, voi
     ctx->prm = *prm;
     ctx->device = device;
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->n_cu = ncu; }
-    { const char *e = getenv("YGZ_WAVE_PRIO"); if (e) ctx->wave_prio_mask = atoi(e); }
-    { const char *e = getenv("YGZ_DESCRIBE_ASIDE"); if (e) ctx->describe_aside = atoi(e) != 0; }
     int rc = YGZ_OK;
     do {
         if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
@@ -224,17 +222,8 @@ int ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable)
     if (rc != YGZ_OK) return rc;
     if (enable && !ctx->aux[0]) {
         YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        int prio_lo = 0, prio_hi = 0;                       // numerically greatest = lowest priority
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        // experiment switch: "low" = every side stream below the main stream; or one letter per side stream (sparse alignment, BA,
-        // matcher + direct projection): h = highest, l = lowest priority, anything else = default
-        const char *pe = getenv("YGZ_AUX_PRIORITY");
-        const bool all_low = pe && strcmp(pe, "low") == 0;
         for (int i = 0; i < 3; ++i) {
-            const char c = all_low ? 'l' : (pe && strlen(pe) > (size_t)i ? pe[i] : 'n');
-            if (c == 'l') YGZ_HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_lo));
-            else if (c == 'h') YGZ_HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux[i], hipStreamNonBlocking, prio_hi));
-            else YGZ_HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+            YGZ_HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
             YGZ_HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
         }
     }

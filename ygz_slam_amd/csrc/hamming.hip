@@ -111,189 +111,26 @@ __global__ __launch_bounds__(256) void k_hamming_nn(HamArgs A)
     }
 }
 
-// ---- the same nearest-neighbour search on the matrix cores --------------------------------------------------------------------------
-// With a' = 1 - 2a in {+1, -1}:  popcount(a ^ b) = |a| + a'.b  (a'.b = |b| - 2 a.b): the 1000 x 1000 distance matrix of a frame pair is
-// an int8 GEMM with K = 256 (2.6e8 multiply-adds) plus a term that is constant along a row, so the search runs on
-// v_mfma_i32_32x32x32_i8 and the VALU only has to (a) turn bits into bytes and (b) keep the running minimum.
-//  (a) bit i of a byte stays where it is: the B operand's byte is w & (1 << i) = b 2^i (ONE v_and per 4 bytes), the A operand's byte
-//      is a' 2^(6 - i), every product is 64 a' b.  Bit 7 would be the sign bit: it is read as (w >> 1) & 0x40 against A's a'.
-//      K-step s of lane (l31, half) covers byte-bit i = 4 (s & 1) + {0..3} of dword 4 half + (s >> 1): a lane touches 16 bytes of
-//      its row.  Any bijection bit -> k shared by the two operands gives the same dot product.
-//  (b) the accumulator chain of a tile STARTS from the tile index t (C operand = splat(t), 16 registers shared by all chains of the
-//      wavefront, bumped once per tile) and ends as 64 (dist - |a|) + t: ordered by distance, then by tile, so the running minimum
-//      is ONE v_min_i32 per accumulator and the first minimum wins as in the reference's scan.  The minima are per (row, column
-//      mod 32); every 64 tiles (and at the end) they are folded into 32-bit keys (dist - |a| + 512) << 16 | column, reduced over the
-//      32 lanes once, and |a| is added.  Columns past the end of B exist only in the last tile: they get a bias no real column has.
-// A wavefront owns 32 RG rows of set A -- expanded once, 32 RG VGPRs -- and walks set B in tiles of 32 rows, every expanded B
-// operand feeding RG independent accumulator chains.  tools/ubench/mfma_valu_mix (profiles/r02_mfma_valu_mix.txt): a SIMD hides about
-// four VALU instructions behind one of these MFMAs and serialises the rest, so the VALU work per MFMA decides the speed: RG = 3
-// gives 24 MFMAs against ~100 VALU instructions per tile and 232 VGPRs (two wavefronts per SIMD), RG = 2 gives 16 against ~70 at 168 VGPRs (three):
-// the start of a wavefront (two dependent memory latencies before its first MFMA) is a quarter of the kernel, and the third wavefront
-// hides more of it than the better ratio buys (102 against 106 microseconds per 512 pairs).  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
-// + 4 (lane >> 5).
+// ---- the nearest-neighbour search on the matrix cores ---------------------------------------------------------------------------------------
+// With a' = 1 - 2a in {+1, -1}:  popcount(a ^ b) = |a| + a'.b  (a'.b = |b| - 2 a.b): the 1000 x 1000 distance matrix of a frame pair is a GEMM
+// with K = 256 (2.6e8 multiply-adds) plus a term that is constant along a row, so the search runs on an MFMA and the VALU only has to (a) turn
+// bits into operand elements and (b) keep the running minimum.  The accumulator chain of a tile STARTS from the tile index t and ends as
+// 64 (dist - |a|) + t: ordered by distance, then by tile, so the running minimum is ONE v_min per accumulator and the first minimum wins as in
+// the reference's scan.  The minima are per (row, column mod 32); every 64 tiles (and at the end) they are folded into 32-bit keys
+// (dist - |a| + 512) << 16 | column, reduced over the 32 lanes once, and |a| is added.  Columns past the end of B exist only in the last tile:
+// they get a bias no real column has.  A wavefront owns 32 RG rows of set A -- expanded once -- and walks set B in tiles of 32 rows, every
+// expanded B operand feeding RG independent accumulator chains.  C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2)
+// + 4 (lane >> 5).  (Rounds 1-2 ran this on v_mfma_i32_32x32x32_i8, 102 us per 512 pairs, also with the expanded B tiles shared through LDS,
+// 120 us; both forms were removed in round 5 -- DESIGN.md Appendix B keeps their measurements.)
 typedef int hm_v4i __attribute__((ext_vector_type(4)));
 typedef int hm_v16i __attribute__((ext_vector_type(16)));
-#ifndef HM_RG
-#define HM_RG 2                                                      // row groups of 32 per wavefront
-#endif
-
-__device__ __forceinline__ hm_v4i hm_expand_a(uint32_t w, int hi)
-{   // byte-bits 4 hi + {0..3} of the 4 bytes of w -> +2^(6 - i) for a clear bit, -2^(6 - i) for a set bit (bit 7: +-1)
-    // per byte: bit b -> mask t = 255 b; (m ^ t) + b is m for b = 0 and 256 - m for b = 1 (1 <= m <= 64: no carry leaves the byte)
-    hm_v4i r;
-    const uint32_t x = w >> (4 * hi);
-    const int sh = 6 - 4 * hi;                                       // i = 4 hi + q -> shift 6 - i = sh - q ; the last one (i = 7) is 0
-#define HM_PM(q_, m_) { const uint32_t b_ = (x >> (q_)) & 0x01010101u; o_ = (int)((((m_)) ^ ((b_ << 8) - b_)) + b_); }
-    int o_;
-    HM_PM(0, 0x01010101u << sh) r.x = o_;
-    HM_PM(1, 0x01010101u << (sh - 1)) r.y = o_;
-    HM_PM(2, 0x01010101u << (sh - 2)) r.z = o_;
-    HM_PM(3, hi ? 0x01010101u : (0x01010101u << (sh - 3))) r.w = o_;
-#undef HM_PM
-    return r;
-}
-
-__device__ __forceinline__ hm_v4i hm_expand_b(uint32_t w, int hi)
-{   // byte-bits 4 hi + {0..3} of the 4 bytes of w -> 2^i (bit 7: 2^6)
-    hm_v4i r;
-    if (hi == 0) { r.x = (int)(w & 0x01010101u); r.y = (int)(w & 0x02020202u); r.z = (int)(w & 0x04040404u); r.w = (int)(w & 0x08080808u); }
-    else         { r.x = (int)(w & 0x10101010u); r.y = (int)(w & 0x20202020u); r.z = (int)(w & 0x40404040u); r.w = (int)((w >> 1) & 0x40404040u); }
-    return r;
-}
-
-__global__ __launch_bounds__(64) void k_hamming_mfma(HamArgs A)
-{
-    const int p = blockIdx.x, lane = threadIdx.x;
-    const int sa = A.pair_a[p], sb = A.pair_b[p];
-    const int nA = A.set_count[sa], nB = A.set_count[sb];
-    const int r0 = blockIdx.y * (32 * HM_RG);
-    if (r0 >= nA) return;
-    const uint32_t *da = A.desc + (size_t)sa * A.set_stride, *db = A.desc + (size_t)sb * A.set_stride;
-    const int half = lane >> 5, l31 = lane & 31;
-    // every load the wavefront starts with goes out before anything is computed: the A rows and the first three B tiles (one
-    // memory latency at the start of a wavefront instead of two)
-#define HM_LDB(dst_, j_) { dst_ = make_uint4(0, 0, 0, 0); if ((j_) < nB) dst_ = reinterpret_cast<const uint4 *>(db + 8 * (size_t)(j_))[half]; }
-    uint4 a_raw[HM_RG], b, bn1, bn2;
-#pragma unroll
-    for (int g = 0; g < HM_RG; ++g) {
-        a_raw[g] = make_uint4(0, 0, 0, 0);
-        const int row = r0 + 32 * g + l31;
-        if (row < nA) a_raw[g] = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[half];
-    }
-    HM_LDB(b, l31) HM_LDB(bn1, l31 + 32) HM_LDB(bn2, l31 + 64)
-    // ---- this wavefront's rows of A: lane (l31, half) holds dwords [4 half, 4 half + 4) of rows r0 + 32 g + l31
-    hm_v4i Aop[HM_RG][8];
-    int pa[HM_RG];                                                   // |a| of row r0 + 32 g + l31
-#pragma unroll
-    for (int g = 0; g < HM_RG; ++g) {
-        const uint4 a = a_raw[g];
-        const uint32_t w[4] = { a.x, a.y, a.z, a.w };
-        int pc = 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) Aop[g][s] = hm_expand_a(w[s >> 1], s & 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pc += __popc(w[q]);
-        pa[g] = pc + __shfl_xor(pc, 32);
-    }
-    // folded keys (dist - |a| + 512) << 16 | column, [accumulator][lane]: a lane's own column of LDS, written once per 64 tiles
-    // (as registers they would cost a wavefront per SIMD) and read TRANSPOSED at the end: the 32 lanes of one half hold the 32
-    // column classes of the same matrix row, so the row's minimum is the minimum of 32 consecutive dwords
-    __shared__ uint32_t fin[HM_RG * 16][64];
-    int run[HM_RG][16];                                              // 64 (dist - |a|) + tile of the current block of 64 tiles
-#pragma unroll
-    for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) run[g][r] = 0x7fffffff;
-    const int n_tiles = (nB + 31) >> 5;
-    // software pipeline: the rows of the next three tiles are in flight (an L2 hit takes longer than one tile of MFMAs)
-    hm_v16i cinit = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };                // splat(tile index inside the block of 64)
-    bool folded = false;
-    for (int t = 0; t < n_tiles; ++t) {
-        const uint32_t w[4] = { b.x, b.y, b.z, b.w };
-        b = bn1; bn1 = bn2;
-        HM_LDB(bn2, 32 * t + l31 + 96)
-        hm_v16i acc[HM_RG];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const hm_v4i Bop = hm_expand_b(w[s >> 1], s & 1);
-#pragma unroll
-            for (int g = 0; g < HM_RG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[g][s], Bop, s == 0 ? cinit : acc[g], 0, 0, 0);
-        }
-        if (t == n_tiles - 1 && 32 * t + l31 >= nB) {                // the ragged end of B (its rows are zero: they would win)
-#pragma unroll
-            for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[g][r] = 0x7fffffff;
-        }
-#pragma unroll
-        for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) run[g][r] = min(run[g][r], acc[g][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cinit[r] += 1;
-        if ((t & 63) == 63 || t == n_tiles - 1) {                    // fold the block of 64 tiles into the 32-bit keys
-            const int tb = t & ~63;
-#pragma unroll
-            for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int v = run[g][r];
-                    uint32_t key = ((uint32_t)((v >> 6) + 512) << 16) | (uint32_t)(32 * (tb + (v & 63)) + l31);
-                    key = v != 0x7fffffff ? key : 0xffffffffu;
-                    if (folded) key = min(key, fin[16 * g + r][lane]);                   // (wave-uniform: sets beyond 2048 rows only)
-                    fin[16 * g + r][lane] = key;
-                    run[g][r] = 0x7fffffff;
-                }
-            folded = true;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cinit[r] = 0;
-        }
-    }
-#undef HM_LDB
-    if (!folded) {
-#pragma unroll
-        for (int k = 0; k < HM_RG * 16; ++k) fin[k][lane] = 0xffffffffu;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- lane q takes matrix row q of the wavefront (and q + 64 in a second pass): accumulator reg = (q & 3) + 4 ((q & 31) >> 3),
-    // half = (q >> 2) & 1  [C/D map: row = (reg & 3) + 8 (reg >> 2) + 4 half]; its 32 keys are 8 x 16 bytes, read in a lane-rotated
-    // order so that the 64 lanes do not all start on the same LDS banks
-#pragma unroll
-    for (int pass = 0; pass < (32 * HM_RG + 63) / 64; ++pass) {
-        const int q = 64 * pass + lane, g = q >> 5, rowl = q & 31;
-        const bool live = q < 32 * HM_RG;
-        const int reg = (rowl & 3) + 4 * (rowl >> 3), hq = (rowl >> 2) & 1;
-        uint32_t key = 0xffffffffu;
-        if (live) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(&fin[16 * g + reg][32 * hq]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint4 v = src[(j + lane) & 7];
-                key = min(key, min(min(v.x, v.y), min(v.z, v.w)));
-            }
-        }
-        int pa_row = 0;                                               // |a| of row q lives in lane rowl of group g; every lane takes part
-#pragma unroll
-        for (int gg = 0; gg < HM_RG; ++gg) { const int v = __shfl(pa[gg], rowl); pa_row = (g == gg) ? v : pa_row; }
-        const int row = r0 + q;
-        if (live && row < nA) {
-            int idx = -1, dist = 0x7FFFFFFF;
-            if (nB > 0) { idx = (int)(key & 0xffffu); dist = (int)(key >> 16) - 512 + pa_row; }
-            const size_t o = (size_t)p * A.out_stride + row;
-            A.out_idx[o] = idx; A.out_dist[o] = dist;
-            if (A.scatter_key && idx >= 0)
-                atomicMin(&A.scatter_key[(size_t)p * A.out_stride + idx], ((unsigned long long)(uint32_t)dist << 32) | (uint32_t)row);
-        }
-    }
-}
 
 // ---- the same search on the FP4 matrix path of gfx950 ----------------------------------------------------------------------------------------
 // v_mfma_scale_f32_32x32x64_f8f6f4 with E2M1 operands takes K = 64 per instruction at the issue cost of the 32x32x32 int8 MFMA
 // (tools/ubench/mfma_f4_probe: 33 against 34 cycles, 7.6 against 3.75 P-op/s): the 256-bit rows need FOUR K-steps instead of eight, and
 // bit -> nibble is half the expansion of bit -> byte.  Everything is exact: the operands are 0, +-0.5, +-1, +-2 (FP4 codes), every product
 // is 0 or +-1, the block scale 2^6 of the A operand makes it 0 or +-64, and the FP32 accumulator chain starts from (float)tile index, so
-// an accumulator ends as the INTEGER 64 (dist - |a|) + t exactly as in k_hamming_mfma (|value| < 2^15) and the running minimum is one
+// an accumulator ends as the INTEGER 64 (dist - |a|) + t (|value| < 2^15) and the running minimum is one
 // v_min_f32.  Encoding: a set bit at nibble position q of a B dword is the FP4 code 0.5 (q = 0), 1 (q = 1) or 2 (q = 2): w & 0x1111.., w &
 // 0x2222.., w & 0x4444.. are operand registers as they stand; position 3 would be the sign bit, so it is read as (w >> 1) & 0x4444.. (= 2).
 // The A side holds a' = 1 - 2a as +-2, +-1, +-0.5, +-0.5 for the four position classes, so every product is +-1.  Lane (l31, half) holds the
@@ -437,153 +274,6 @@ __global__ __launch_bounds__(64) void k_hamming_f4(HamArgs A)
     }
 }
 
-// ---- the same search with the expanded B tiles SHARED by the four wavefronts of a workgroup -------------------------------------------------
-// In k_hamming_mfma every wavefront expands every B tile itself: 33 of its ~86 VALU instructions per tile, and a SIMD hides only about four
-// VALU instructions behind one 32x32x32 MFMA (profiles/r02_mfma_valu_mix.txt), so the loop runs at 3.3 of the 4.4 POP/s the matrix cores
-// sustain for this shape.  Here a workgroup of four wavefronts walks set B together: wavefront q expands K-steps 2q and 2q + 1 of the tile
-// (ONE dword of every row: 9 VALU instructions) into LDS, all four read the eight operands back with ds_read_b128 (the LDS pipe issues
-// beside the VALU), one barrier per tile, two LDS buffers.  Per tile and wavefront: 16 MFMAs against 9 + 8 (C operand) + 32 (running
-// minima) + a handful of VALU instructions -- under the four per MFMA that hide.  Everything else (A operands, C = splat(tile), folding,
-// the transposed final reduction, the cross-check scatter) is k_hamming_mfma's; results are bit-identical.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_hamming_mfma_wg(HamArgs A)
-{
-    __shared__ uint4 Bsh[2][8][64];                                  // [buffer][K-step][lane]: the B operand of the lane, 16 bytes
-    __shared__ uint32_t fin_all[4][HM_RG * 16][64];
-    const int p = blockIdx.x, wq = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int sa = A.pair_a[p], sb = A.pair_b[p];
-    const int nA = A.set_count[sa], nB = A.set_count[sb];
-    if ((int)blockIdx.y * (4 * 32 * HM_RG) >= nA) return;            // block-uniform
-    const int r0 = ((int)blockIdx.y * 4 + wq) * (32 * HM_RG);
-    const bool have_rows = r0 < nA;                                  // wave-uniform: a wavefront without rows still expands its share of B
-    const uint32_t *da = A.desc + (size_t)sa * A.set_stride, *db = A.desc + (size_t)sb * A.set_stride;
-    const int half = lane >> 5, l31 = lane & 31;
-    uint32_t (*fin)[64] = fin_all[wq];
-    // this wavefront's dword of every B row: dword 4 half + wq of row 32 t + l31 feeds K-steps 2 wq and 2 wq + 1
-#define HM_LDW(dst_, j_) { dst_ = 0u; if ((j_) < nB) dst_ = db[8 * (size_t)(j_) + 4 * half + wq]; }
-    uint4 a_raw[HM_RG];
-    uint32_t w0, w1, w2;
-#pragma unroll
-    for (int g = 0; g < HM_RG; ++g) {
-        a_raw[g] = make_uint4(0, 0, 0, 0);
-        const int row = r0 + 32 * g + l31;
-        if (row < nA) a_raw[g] = reinterpret_cast<const uint4 *>(da + 8 * (size_t)row)[half];
-    }
-    HM_LDW(w0, l31) HM_LDW(w1, l31 + 32) HM_LDW(w2, l31 + 64)
-    hm_v4i Aop[HM_RG][8];
-    int pa[HM_RG];
-#pragma unroll
-    for (int g = 0; g < HM_RG; ++g) {
-        const uint4 a = a_raw[g];
-        const uint32_t w[4] = { a.x, a.y, a.z, a.w };
-        int pc = 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) Aop[g][s] = hm_expand_a(w[s >> 1], s & 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pc += __popc(w[q]);
-        pa[g] = pc + __shfl_xor(pc, 32);
-    }
-    int run[HM_RG][16];
-#pragma unroll
-    for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) run[g][r] = 0x7fffffff;
-    const int n_tiles = (nB + 31) >> 5;
-    hm_v16i cinit = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    bool folded = false;
-    // tile 0 into buffer 0
-    { const hm_v4i e0 = hm_expand_b(w0, 0), e1 = hm_expand_b(w0, 1);
-      Bsh[0][2 * wq][lane] = make_uint4((uint32_t)e0.x, (uint32_t)e0.y, (uint32_t)e0.z, (uint32_t)e0.w);
-      Bsh[0][2 * wq + 1][lane] = make_uint4((uint32_t)e1.x, (uint32_t)e1.y, (uint32_t)e1.z, (uint32_t)e1.w); }
-    w0 = w1; w1 = w2;
-    HM_LDW(w2, l31 + 96)
-    __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) {                                       // tile t + 1 into the other buffer (its readers finished at the last barrier)
-            const hm_v4i e0 = hm_expand_b(w0, 0), e1 = hm_expand_b(w0, 1);
-            Bsh[buf ^ 1][2 * wq][lane] = make_uint4((uint32_t)e0.x, (uint32_t)e0.y, (uint32_t)e0.z, (uint32_t)e0.w);
-            Bsh[buf ^ 1][2 * wq + 1][lane] = make_uint4((uint32_t)e1.x, (uint32_t)e1.y, (uint32_t)e1.z, (uint32_t)e1.w);
-        }
-        w0 = w1; w1 = w2;
-        HM_LDW(w2, 32 * t + l31 + 128)
-        if (have_rows) {
-            hm_v16i acc[HM_RG];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const uint4 bq = Bsh[buf][s][lane];
-                const hm_v4i Bop = { (int)bq.x, (int)bq.y, (int)bq.z, (int)bq.w };
-#pragma unroll
-                for (int g = 0; g < HM_RG; ++g) acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Aop[g][s], Bop, s == 0 ? cinit : acc[g], 0, 0, 0);
-            }
-            if (t == n_tiles - 1 && 32 * t + l31 >= nB) {            // the ragged end of B (its rows are zero: they would win)
-#pragma unroll
-                for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[g][r] = 0x7fffffff;
-            }
-#pragma unroll
-            for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) run[g][r] = min(run[g][r], acc[g][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cinit[r] += 1;
-            if ((t & 63) == 63 || t == n_tiles - 1) {                // fold the block of 64 tiles into the 32-bit keys
-                const int tb = t & ~63;
-#pragma unroll
-                for (int g = 0; g < HM_RG; ++g)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int v = run[g][r];
-                        uint32_t key = ((uint32_t)((v >> 6) + 512) << 16) | (uint32_t)(32 * (tb + (v & 63)) + l31);
-                        key = v != 0x7fffffff ? key : 0xffffffffu;
-                        if (folded) key = min(key, fin[16 * g + r][lane]);
-                        fin[16 * g + r][lane] = key;
-                        run[g][r] = 0x7fffffff;
-                    }
-                folded = true;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cinit[r] = 0;
-            }
-        }
-        __syncthreads();
-    }
-#undef HM_LDW
-    if (!have_rows) return;
-    if (!folded) {
-#pragma unroll
-        for (int k = 0; k < HM_RG * 16; ++k) fin[k][lane] = 0xffffffffu;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int pass = 0; pass < (32 * HM_RG + 63) / 64; ++pass) {
-        const int q = 64 * pass + lane, g = q >> 5, rowl = q & 31;
-        const bool live = q < 32 * HM_RG;
-        const int reg = (rowl & 3) + 4 * (rowl >> 3), hq = (rowl >> 2) & 1;
-        uint32_t key = 0xffffffffu;
-        if (live) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(&fin[16 * g + reg][32 * hq]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint4 v = src[(j + lane) & 7];
-                key = min(key, min(min(v.x, v.y), min(v.z, v.w)));
-            }
-        }
-        int pa_row = 0;
-#pragma unroll
-        for (int gg = 0; gg < HM_RG; ++gg) { const int v = __shfl(pa[gg], rowl); pa_row = (g == gg) ? v : pa_row; }
-        const int row = r0 + q;
-        if (live && row < nA) {
-            int idx = -1, dist = 0x7FFFFFFF;
-            if (nB > 0) { idx = (int)(key & 0xffffu); dist = (int)(key >> 16) - 512 + pa_row; }
-            const size_t o = (size_t)p * A.out_stride + row;
-            A.out_idx[o] = idx; A.out_dist[o] = dist;
-            if (A.scatter_key && idx >= 0)
-                atomicMin(&A.scatter_key[(size_t)p * A.out_stride + idx], ((unsigned long long)(uint32_t)dist << 32) | (uint32_t)row);
-        }
-    }
-}
-
 // cross_check 1: decode the scatter keys; cross_check 2: mutual test qi -> tq
 __global__ __launch_bounds__(256) void k_match_finalize(const int32_t *__restrict__ set_count, const int32_t *__restrict__ pair_q,
                                                         size_t out_stride, int mode, const unsigned long long *__restrict__ key,
@@ -615,25 +305,15 @@ int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, con
     const dim3 grid(n_pairs, ygz_div_up(max_rows, 256)), block(256), grid_f(ygz_div_up(max_rows, 256), n_pairs);
     const dim3 grid_s(n_pairs, ygz_div_up(max_rows, 256 * HM_ROWS));
     const bool wide = max_rows > 0xFFFF;              // the <false> kernel packs (distance, row) into one 32-bit key
-    static const bool valu_only = [] { const char *e = getenv("YGZ_HAMMING_VALU"); return e && e[0] == '1'; }();   // A/B switch: the VALU form
-    static const bool wg_form = [] { const char *e = getenv("YGZ_HAMMING_WG"); return e && e[0] == '1'; }();       // A/B switch: B tiles shared by a workgroup
-    const dim3 grid_w(n_pairs, ygz_div_up(max_rows, 4 * 32 * HM_RG)), block_w(256);
-    static const int mfma_form = [] { const char *e = getenv("YGZ_HAMMING_FORM"); return e ? atoi(e) : 0; }();   // 0: FP4 (default), 1: int8, A/B switch
-    static const int f4_rg = [] { const char *e = getenv("YGZ_HAMMING_RG"); const int v = e ? atoi(e) : 2; return v == 3 || v == 4 ? v : 2; }();   // row groups of 32 per wavefront (FP4 form)
-    const dim3 grid_f4(n_pairs, ygz_div_up(max_rows, 32 * f4_rg));
-#define HM_LAUNCH_F4() do { if (f4_rg == 2) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_f4<2>, grid_f4, block_m, A);        \
-                            else if (f4_rg == 3) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_f4<3>, grid_f4, block_m, A);   \
-                            else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_f4<4>, grid_f4, block_m, A); } while (0)
-    const dim3 grid_m(n_pairs, ygz_div_up(max_rows, 32 * HM_RG)), block_m(64);
+    static const bool valu_only = [] { const char *e = getenv("YGZ_HAMMING_VALU"); return e && e[0] == '1'; }();   // A/B switch: the VALU form (also what second-best / > 65535-row searches use)
+    const dim3 grid_f4(n_pairs, ygz_div_up(max_rows, 32 * 2)), block_m(64);
     if (cross_check == 0 || cross_check == 2) {       // query -> train
         A.pair_a = pair_q; A.pair_b = pair_t;
         A.out_idx = ctx->m_idx; A.out_dist = ctx->m_dist; A.out_dist2 = want_second ? ctx->m_dist2 : nullptr;
         A.scatter_key = nullptr;
         if (want_second || wide) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<true, 1>), grid, block, A);
         else if (valu_only) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
-        else if (wg_form) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma_wg, grid_w, block_w, A);
-        else if (mfma_form == 1) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block_m, A);
-        else HM_LAUNCH_F4();
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_f4<2>, grid_f4, block_m, A);
     }
     if (cross_check == 1 || cross_check == 2) {       // train -> query
         if (cross_check == 1)
@@ -643,9 +323,7 @@ int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, con
         A.scatter_key = (cross_check == 1) ? ctx->m_key : nullptr;
         if (wide) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<true, 1>), grid, block, A);
         else if (valu_only) YGZ_LAUNCH(ctx, KID_HAMMING_NN, (k_hamming_nn<false, HM_ROWS>), grid_s, block, A);
-        else if (wg_form) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma_wg, grid_w, block_w, A);
-        else if (mfma_form == 1) YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_mfma, grid_m, block_m, A);
-        else HM_LAUNCH_F4();
+        else YGZ_LAUNCH(ctx, KID_HAMMING_NN, k_hamming_f4<2>, grid_f4, block_m, A);
         YGZ_LAUNCH(ctx, KID_MATCH_FINALIZE, k_match_finalize, grid_f, block, set_count, pair_q, Cn, cross_check,
                            ctx->m_key, ctx->m_tq, ctx->m_idx, ctx->m_dist);
     }

@@ -232,17 +232,15 @@ int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int f
     if (rc != YGZ_OK) return rc;
     const unsigned npix = (unsigned)ctx->lw[0] * (unsigned)ctx->lh[0];
     // the tracker's framed copies are written along with the levels once its buffers exist (first LK call): no copy kernel per step
-    static const int fuse_env = [] { const char *e = getenv("YGZ_PAD_FUSE"); return e ? atoi(e) : 1; }();
     int fuse_levels = 0;                                    // the leading levels that have a framed buffer (the tracker allocates the levels it uses)
-    while (fuse_env != 0 && fuse_levels < up_to_level && ctx->klt_pad[fuse_levels]) ++fuse_levels;
+    while (fuse_levels < up_to_level && ctx->klt_pad[fuse_levels]) ++fuse_levels;
     const bool fuse = fuse_levels > 0;
     // level 0 comes framed out of k_bgr2gray16 when its 16-pixel groups line up with the rows and the frame is one reflection away;
     // level L >= 1 out of k_pyr_down when both its sides exceed the frame (one reflection reaches every frame pixel); k_klt_frame does the rest
     // (small levels; level 0 of a gray upload: interior + frame)
-    static const int frame_env = [] { const char *e = getenv("YGZ_FRAME_FUSE"); return e ? atoi(e) : 1; }();      // 0: every frame by k_klt_frame (A/B)
-    const bool l0_framed = fuse && frame_env && from_bgr && (npix & 15u) == 0 && (ctx->lw[0] & 15) == 0 && ctx->lw[0] >= 64 && ctx->lh[0] >= 2 * KLT_B + 2;
+    const bool l0_framed = fuse && from_bgr && (npix & 15u) == 0 && (ctx->lw[0] & 15) == 0 && ctx->lw[0] >= 64 && ctx->lh[0] >= 2 * KLT_B + 2;
     bool framed[YGZ_MAX_LEVELS];
-    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) framed[L] = L == 0 ? l0_framed : (L < fuse_levels && frame_env && ctx->lw[L] > KLT_B + 1 && ctx->lh[L] > KLT_B + 1);
+    for (int L = 0; L < YGZ_MAX_LEVELS; ++L) framed[L] = L == 0 ? l0_framed : (L < fuse_levels && ctx->lw[L] > KLT_B + 1 && ctx->lh[L] > KLT_B + 1);
     if (from_bgr) {
         if ((npix & 15u) == 0)
             YGZ_LAUNCH(ctx, KID_BGR2GRAY, k_bgr2gray16, dim3(ygz_div_up((int)(npix / 16), 256), n_slots), dim3(256),

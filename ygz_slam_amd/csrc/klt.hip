@@ -593,24 +593,10 @@ static int launch_klt_impl(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *
     A.pair_q = ctx->pair_q; A.pair_t = ctx->pair_t; A.trk_n = ctx->trk_n; A.trk_px = ctx->trk_px;
     A.next_pts = ctx->klt_pts; A.status = ctx->klt_status; A.err = ctx->klt_err;
     A.dbg = nullptr;
-    if (getenv("YGZ_KLT_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_KLT_OUT, (size_t)n_pairs * ctx->cells * 32, &d) == YGZ_OK) { A.dbg = (long long *)d; (void)hipMemsetAsync(d, 0, (size_t)n_pairs * ctx->cells * 32, ctx->stream); } }
-    {   // experiment switch (schedule): the LK kernel waits for the side-stream stages in the mask (bit 0 sparse alignment, 1 BA build, 2 matcher / direct projection)
-        static const int join_mask = [] { const char *e = getenv("YGZ_KLT_JOIN"); return e ? atoi(e) & 7 : 0; }();
-        if (join_mask) { const int rj = ygz_join(ctx, ~(unsigned)join_mask & 7u); if (rj != YGZ_OK) return rj; }
-    }
-    if (A.win == KLT_MAXWIN && !A.dbg && !getenv("YGZ_KLT_ONE_POINT")) YGZ_LAUNCH(ctx, KID_KLT, k_klt3, dim3(ygz_div_up(ctx->cells, 12), ygz_round_up8(n_pairs)), dim3(256), A);
-    else if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt<true>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
+    // 21 x 21 (the reference's window, Tracker.h:25): three points per wavefront; any other window size: one point per wavefront
+    if (A.win == KLT_MAXWIN) YGZ_LAUNCH(ctx, KID_KLT, k_klt3, dim3(ygz_div_up(ctx->cells, 12), ygz_round_up8(n_pairs)), dim3(256), A);
     else YGZ_LAUNCH(ctx, KID_KLT, k_klt<false>, dim3(ygz_div_up(ctx->cells, KLT_WPB), ygz_round_up8(n_pairs)), dim3(64 * KLT_WPB), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    if (A.dbg) {
-        const size_t nn = (size_t)n_pairs * ctx->cells;
-        std::vector<long long> h(4 * nn);
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(h.data(), A.dbg, nn * 32, hipMemcpyDeviceToHost, ctx->stream));
-        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        double tot = 0, ni = 0, np = 0;
-        for (size_t i = 0; i < nn; ++i) if (h[4 * i] > 0) { tot += h[4 * i]; ni += h[4 * i + 3]; np += 1; }
-        if (np > 0) fprintf(stderr, "[klt-debug] points %.0f: cycles/point %.0f, iterations/point %.1f\n", np, tot / np, ni / np);
-    }
     return YGZ_OK;
 }
 

@@ -72,81 +72,13 @@ __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &
     t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
 }
 
-// -DYGZ_SA_CAP2 (experiment): at most 256 registers, so that two 256-lane problems share a CU (with YGZ_SA_LDS <= 832):
-// the stage alone drops from 1.09 to 0.86 ms per 512 pairs, the step gets SLOWER (5.95 -> 6.15 ms): the second problem takes the CU's
-// registers and LDS from the LK and matcher wavefronts that would otherwise run beside the first.
-#ifdef YGZ_SA_CAP2
-#define SA_MIN_WAVES 2
-#else
-#define SA_MIN_WAVES 1
-#endif
-template <int SA_THREADS>
-__global__ __launch_bounds__(SA_THREADS, SA_MIN_WAVES) void k_sparse_align(SaArgs A)
-{
-    __shared__ double red[SA_THREADS / 64][28];
-    __shared__ Se3 sT;
-    __shared__ int s_ctl;                 // 0 continue, 1 leave level
-    __shared__ int s_nmeas_w[SA_THREADS / 64];
-    __shared__ float s_chi2;
-    __shared__ double s_ldlt[36 + 6 + 6];       // lane-0 solver workspace (LDS instead of private scratch)
-    __shared__ int s_tr[6];
-    __shared__ Se3 s_Tn;                        // candidate model of the iteration
-    __shared__ double s_nmx;
-    __shared__ int s_solve_ok;
-    __shared__ double s_H[21];                  // H of the current level (updated by the change per iteration)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int pair = blockIdx.x;
-    ygz_raise_prio(A.prio);
-    const int n = A.trk_n[pair];
-    double *out = A.out + 16 * (size_t)pair;
-    if (n <= 0) {                                      // run() returns 0 and leaves the pose (:25-29)
-        if (tid == 0) { out[7] = 0; for (int l = 0; l < YGZ_MAX_LEVELS; ++l) out[8 + l] = 0; }
-        return;
-    }
-    const int ref_slot = A.pair_t[pair], cur_slot = A.pair_q[pair];
-    const double *px = A.trk_px + 2 * (size_t)pair * A.cells, *depth = A.trk_depth + (size_t)pair * A.cells;
-    const uint8_t *has_mp = A.trk_has_mp + (size_t)pair * A.cells;
-    uint8_t *wk = A.work + (size_t)pair * A.work_stride;
-    // Per level and feature (entry-major: coalesced over features).  The reference keeps 16 Jacobian columns per feature
-    // (jacobian_cache_, 768 B) and re-reads them every iteration; here the feature's contribution to H = sum J J^T, which does
-    // not depend on the iterate, is summed ONCE per level in the reference's own order (Hf), and what J^T res needs is kept
-    // factored: J = (dx * fj_row0 + dy * fj_row1) * fl  ->  16 x (dx, dy) floats + the 2x6 frame Jacobian.
-    double *Hf = (double *)wk;                                          // [cells][21] upper triangle of sum_px J J^T
-    float *dxy = (float *)(Hf + 33 * (size_t)A.cells);                  // [cells][32] dx[16], dy[16] (the 12 doubles per cell before it are unused)
-    uint8_t *prev_used = (uint8_t *)(dxy + 32 * (size_t)A.cells);       // [cells] the feature is part of the running H
-    float *patch_cache = (float *)((double *)wk + 96 * (size_t)A.cells);   // [cells][16]
-    float *r2 = patch_cache + 16 * (size_t)A.cells;                     // [4][cells] float4: the squared residuals (chain terms)
-    float *ctot = r2 + 16 * (size_t)A.cells;                            // [cells / 64] sum of the squares of a chunk of 64 features (binade prediction only)
-    float *pre = ctot + A.cells;                                        // [cells] the same for the features before f in its chunk
-    int4 *fmap = reinterpret_cast<int4 *>(pre + A.cells);               // [cells] 16-term parity map of the feature: t0, t1, E, bad | head << 1
-    int2 *pmap = reinterpret_cast<int2 *>(fmap + A.cells);              // [cells] map of the features from the head of f's segment to f
-    uint8_t *visible = (uint8_t *)(pmap + A.cells);                     // [cells]
-    // The per-iteration scratch of the first A.lcap features lives in LDS (dynamic, ~92 bytes per feature): the squared residuals are
-    // written by the residual pass and read twice (map build, wave 0's walk), the maps once each -- 250 of the ~480 bytes a feature
-    // moved per iteration went through L2 / MALL for data only this workgroup ever sees.  Features beyond lcap use the global arrays.
-    extern __shared__ __attribute__((aligned(16))) unsigned char sa_dyn[];
-    const int LC = A.lcap;
-    float4 *const l_r2 = reinterpret_cast<float4 *>(sa_dyn);                              // [4][LC]
-    int4 *const l_fmap = reinterpret_cast<int4 *>(l_r2 + 4 * (size_t)LC);                  // [LC]
-    int2 *const l_pmap = reinterpret_cast<int2 *>(l_fmap + LC);                            // [LC]
-    float *const l_pre = reinterpret_cast<float *>(l_pmap + LC);                           // [LC]
-    float *const l_ctot = l_pre + LC;                                                      // [LC / 64]
+// accessors of the per-iteration scratch: the first LC features in LDS, the rest in the global arrays (features beyond the LDS capacity:
+// 720p and larger grids)
 #define SA_R2(q_, f_) (*((f_) < LC ? l_r2 + (size_t)(q_) * LC + (f_) : reinterpret_cast<float4 *>(r2) + (size_t)(q_) * A.cells + (f_)))
 #define SA_FMAP(f_) (*((f_) < LC ? l_fmap + (f_) : fmap + (f_)))
 #define SA_PMAP(f_) (*((f_) < LC ? l_pmap + (f_) : pmap + (f_)))
 #define SA_PRE(f_) (*((f_) < LC ? l_pre + (f_) : pre + (f_)))
 #define SA_CTOT(c_) (*((c_) * 64 < LC ? l_ctot + (c_) : ctot + (c_)))
-    uint8_t *used = visible + A.cells;                                  // [cells] feature contributes this iteration
-    Se3 T_ref;
-    for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
-    for (int k = 0; k < 3; ++k) T_ref.t[k] = A.pair_T[14 * (size_t)pair + 4 + k];
-    // thread-0 solver state (NLLSSolver::reset, NLSSolver_impl.hpp:283-293)
-    double chi2_ = 1e10; bool stop_ = false;
-    Se3 old_model;
-    int n_meas_last = 0;
-#ifdef YGZ_SA_TIMERS
-    long long tph[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = clock64();
-#endif
 #ifdef YGZ_SA_TIMERS
 #define SA_PHASE(k) do { if (tid == 0) { const long long tn_ = clock64(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 #define SA_COUNT(k, v) do { if (tid == 0) tph[k] += (v); } while (0)
@@ -155,395 +87,9 @@ __global__ __launch_bounds__(SA_THREADS, SA_MIN_WAVES) void k_sparse_align(SaArg
 #define SA_COUNT(k, v) do { } while (0)
 #endif
 
-    if (tid == 0) {
-        Se3 T_cur, Tri;
-        for (int k = 0; k < 4; ++k) T_cur.q[k] = out[k];
-        for (int k = 0; k < 3; ++k) T_cur.t[k] = out[4 + k];
-        se3_inv_d(&T_ref, &Tri);
-        se3_mul_d(&T_cur, &Tri, &sT);                   // T_cur_from_ref (SparseImageAlign.cpp:37)
-        for (int l = 0; l < YGZ_MAX_LEVELS; ++l) out[8 + l] = 0;
-    }
-    for (int f = tid; f < n; f += SA_THREADS) visible[f] = 0;
-    for (int f = tid; f < n; f += SA_THREADS)
-        for (int pc = 0; pc < 16; ++pc) patch_cache[16 * (size_t)f + pc] = 0.f;
-    __syncthreads();
-
-    for (int level = A.max_level; level >= A.min_level; --level) {
-        const int cols = A.w[level], rows = A.h[level];
-        const uint8_t *ref_img = A.lvl[level] + (size_t)ref_slot * cols * rows;
-        const uint8_t *cur_img = A.lvl[level] + (size_t)cur_slot * cols * rows;
-        const float scale = 1.0f / (float)(1 << level);
-        const int border = 3;
-        // jacobian_cache_.setZero(); have_ref_patch_cache_ = false (:42-43): each lane clears the
-        // cache rows of the features it owns (the rows it does not refill below stay zero)
-        // precomputeReferencePatches (:59-122)
-        const double focal = (double)((A.fx + A.fy) / 2);
-        for (int f = tid; f < n; f += SA_THREADS) {
-            const double pxx = px[2 * f], pxy = px[2 * f + 1];
-            const float u_ref = (float)(pxx * scale), v_ref = (float)(pxy * scale);
-            const int ui = (int)floorf(u_ref), vi = (int)floorf(v_ref);
-            prev_used[f] = 0;
-            if (!has_mp[f] || ui - border < 0 || vi - border < 0 || ui + border >= cols || vi + border >= rows) {
-                for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = 0.0;       // a zero Jacobian column block (:42)
-                if (visible[f]) {                                                 // visible from a coarser level (visible_fts_ is never reset, :35):
-                    float4 *z4 = reinterpret_cast<float4 *>(dxy + 32 * (size_t)f);   // the residual pass still visits it, so its gradients must be
-                    for (int k = 0; k < 8; ++k) z4[k] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero columns setZero() left, not the previous level's
-                }
-                continue;
-            }
-            visible[f] = 1;
-            const double dep = depth[f];
-            const double x = (pxx - A.cx) * dep / A.fx, y = (pxy - A.cy) * dep / A.fy;
-            const double z_inv = 1. / dep, z_inv_2 = z_inv * z_inv;
-            double fj[12];      // cvutils::JacobXYZ2Cam (CVUtils.h:77-99)
-            fj[0] = -z_inv; fj[1] = 0.0; fj[2] = x * z_inv_2; fj[3] = y * fj[2]; fj[4] = -(1.0 + x * fj[2]); fj[5] = y * z_inv;
-            fj[6] = 0.0; fj[7] = -z_inv; fj[8] = y * z_inv_2; fj[9] = 1.0 + y * fj[8]; fj[10] = -fj[3]; fj[11] = -x * z_inv;
-            const float su = __fsub_rn(u_ref, (float)ui), sv = __fsub_rn(v_ref, (float)vi);
-            const float w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv)), w_tr = (float)((double)su * (1.0 - (double)sv));
-            const float w_bl = (float)((1.0 - (double)su) * (double)sv), w_br = __fmul_rn(su, sv);
-            const double fl = focal / (double)(1 << level);
-            double hf[21];
-#pragma unroll
-            for (int k = 0; k < 21; ++k) hf[k] = 0.0;
-            // the 7x7 reference window rows vi-3..vi+3, columns ui-3..ui+3: W(r, c) = byte c of row r
-            uint32_t wl[7], wh[7];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) ygz_load8(ref_img + (size_t)(vi - 3 + r) * cols + (ui - 3), wl[r], wh[r]);
-#define W(r, c) YGZ_BYTE(wl[r], wh[r], c)
-#define BIL(a, b, c, d) __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w_tl, (float)(a)), __fmul_rn(w_tr, (float)(b))), __fmul_rn(w_bl, (float)(c))), __fmul_rn(w_br, (float)(d)))
-            float pv[16], dxv[16], dyv[16];
-#pragma unroll
-            for (int yy = 0; yy < 4; ++yy) {
-#pragma unroll
-                for (int xx = 0; xx < 4; ++xx) {
-                    const int pc = 4 * yy + xx;          // p = &W(yy + 1, xx + 1)
-                    pv[pc] = BIL(W(yy + 1, xx + 1), W(yy + 1, xx + 2), W(yy + 2, xx + 1), W(yy + 2, xx + 2));
-                    const float dx = __fmul_rn(0.5f, __fsub_rn(BIL(W(yy + 1, xx + 2), W(yy + 1, xx + 3), W(yy + 2, xx + 2), W(yy + 2, xx + 3)),
-                                                                BIL(W(yy + 1, xx), W(yy + 1, xx + 1), W(yy + 2, xx), W(yy + 2, xx + 1))));
-                    const float dy = __fmul_rn(0.5f, __fsub_rn(BIL(W(yy + 2, xx + 1), W(yy + 2, xx + 2), W(yy + 3, xx + 1), W(yy + 3, xx + 2)),
-                                                                BIL(W(yy, xx + 1), W(yy, xx + 2), W(yy + 1, xx + 1), W(yy + 1, xx + 2))));
-                    dxv[pc] = dx; dyv[pc] = dy;
-                    double J[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) J[k] = ((double)dx * fj[k] + (double)dy * fj[6 + k]) * fl;      // jacobian_cache_.col (:116-117)
-                    int q = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                        for (int b = a; b < 6; ++b) hf[q++] += J[a] * J[b];                                    // H_ += J J^T (:209), pixel order
-                    }
-                }
-            }
-#undef W
-            float4 *o4 = reinterpret_cast<float4 *>(patch_cache + 16 * (size_t)f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o4[k] = make_float4(pv[4 * k], pv[4 * k + 1], pv[4 * k + 2], pv[4 * k + 3]);
-            o4 = reinterpret_cast<float4 *>(dxy + 32 * (size_t)f);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { o4[k] = make_float4(dxv[4 * k], dxv[4 * k + 1], dxv[4 * k + 2], dxv[4 * k + 3]);
-                                          o4[4 + k] = make_float4(dyv[4 * k], dyv[4 * k + 1], dyv[4 * k + 2], dyv[4 * k + 3]); }
-#pragma unroll
-            for (int k = 0; k < 21; ++k) Hf[21 * (size_t)f + k] = hf[k];
-        }
-        if (tid < 21) s_H[tid] = 0.0;
-        __syncthreads();          // caches visible to the whole workgroup (global writes + barrier, same CU)
-        if (tid == 0) old_model = sT;
-        int it = 0;
-        for (; it < A.n_iter; ++it) {
-            SA_PHASE(0);      // precompute / loop overhead
-            // ---- computeResiduals(model, linearize=true) (:124-223), split in two passes:
-            // pass R (all lanes): warp + bilinear + residuals of the lane's features -> res[f][16] (0 when skipped)
-            const Se3 T = sT;
-            int my_meas = 0;
-            // Jres (6) and the CHANGE of H (21 unique) accumulate in FP64 registers of the lane that owns the feature: H only
-            // changes when a feature enters or leaves the image (first iteration of a level: every used feature enters).
-            double acc[27];
-#pragma unroll
-            for (int k = 21; k < 27; ++k) acc[k] = 0.0;
-            uint32_t chg_mask = 0u, add_mask = 0u;                  // per lane: which of its features (f0_ / SA_THREADS) entered / left this iteration
-            const double fl = (double)((A.fx + A.fy) / 2) / (double)(1 << level);
-#pragma unroll 1
-            for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {             // uniform trip count: the chunk scan below needs whole wavefronts
-                const int f = f0_ + tid;
-                float sq = 0.f;
-                if (f < n) {
-                float res[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) res[k] = 0.f;
-                // everything that does not depend on the iterate is fetched up front, unconditionally and in one batch (one memory
-                // latency instead of one per dependent branch below): the feature's flags, pixel, depth, reference patch and gradients
-                const uint8_t vis_f = visible[f], pu_f = prev_used[f];
-                const double pxx = px[2 * f], pxy = px[2 * f + 1], dep = depth[f];
-                const float4 *pcp = reinterpret_cast<const float4 *>(patch_cache + 16 * (size_t)f);
-                const float4 c0 = pcp[0], c1 = pcp[1], c2 = pcp[2], c3 = pcp[3];
-                const float4 *gp = reinterpret_cast<const float4 *>(dxy + 32 * (size_t)f);
-                const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2], g3 = gp[3], g4 = gp[4], g5 = gp[5], g6 = gp[6], g7 = gp[7];
-                bool use = vis_f != 0;
-                if (use) {
-                    const double xyz_ref[3] = { (pxx - A.cx) * dep / A.fx, (pxy - A.cy) * dep / A.fy, dep };
-                    double xyz_cur[3];
-                    se3_act_d(&T, xyz_ref, xyz_cur);
-                    const double pu = A.fx * xyz_cur[0] / xyz_cur[2] + A.cx, pv = A.fy * xyz_cur[1] / xyz_cur[2] + A.cy;
-                    const float u_cur = __fmul_rn((float)pu, scale), v_cur = __fmul_rn((float)pv, scale);
-                    const int ui = (int)floorf(u_cur), vi = (int)floorf(v_cur);
-                    if (u_cur != u_cur || v_cur != v_cur || ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 ||
-                        ui + border >= cols || vi + border >= rows) use = false;
-                    else {
-                        const float su = __fsub_rn(u_cur, (float)ui), sv = __fsub_rn(v_cur, (float)vi);
-                        const float w_tl = (float)((1.0 - (double)su) * (1.0 - (double)sv)), w_tr = (float)((double)su * (1.0 - (double)sv));
-                        const float w_bl = (float)((1.0 - (double)su) * (double)sv), w_br = __fmul_rn(su, sv);
-                        const float refp[16] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w };
-                        uint32_t wl[5], wh[5];            // rows vi-2..vi+2, columns ui-2..ui+2
-#pragma unroll
-                        for (int r = 0; r < 5; ++r) ygz_load5(cur_img + (size_t)(vi - 2 + r) * cols + (ui - 2), wl[r], wh[r]);
-#pragma unroll
-                        for (int yy = 0; yy < 4; ++yy) {
-#pragma unroll
-                            for (int xx = 0; xx < 4; ++xx) {
-                                const float ic = BIL(YGZ_BYTE(wl[yy], wh[yy], xx), YGZ_BYTE(wl[yy], wh[yy], xx + 1),
-                                                     YGZ_BYTE(wl[yy + 1], wh[yy + 1], xx), YGZ_BYTE(wl[yy + 1], wh[yy + 1], xx + 1));
-                                res[4 * yy + xx] = __fsub_rn(ic, refp[4 * yy + xx]);
-                            }
-                        }
-                    }
-                }
-                float xs[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);      // the chain terms, quarter-major
-                used[f] = use ? 1 : 0;
-                const bool pu = pu_f != 0;
-                if (use != pu) {                                     // rare after the first iteration of a level: H changes by +-Hf, added in the
-                    prev_used[f] = use ? 1 : 0;                      // second loop below (same feature order per lane, same sums) so that the 21
-                    chg_mask |= 1u << (f0_ / SA_THREADS);            // FP64 accumulators are not live across the residual arithmetic
-                    if (use) add_mask |= 1u << (f0_ / SA_THREADS);
-                }
-                if (use) {
-                    my_meas += 16;
-                    double gA = 0.0, gB = 0.0;
-                    const float gxv[16] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w };
-                    const float gyv[16] = { g4.x, g4.y, g4.z, g4.w, g5.x, g5.y, g5.z, g5.w, g6.x, g6.y, g6.z, g6.w, g7.x, g7.y, g7.z, g7.w };
-#pragma unroll
-                    for (int pc = 0; pc < 16; ++pc) {
-                        gA += (double)gxv[pc] * (double)res[pc];
-                        gB += (double)gyv[pc] * (double)res[pc];
-                    }
-                    // the 2x6 frame Jacobian is recomputed (a dozen FP64 operations from the values above, the same expressions
-                    // as in the set-up) instead of fetched: 96 bytes less per feature and iteration
-                    const double jx = (pxx - A.cx) * dep / A.fx, jy = (pxy - A.cy) * dep / A.fy;
-                    const double z_inv = 1. / dep, z_inv_2 = z_inv * z_inv;
-                    double fj[12];      // cvutils::JacobXYZ2Cam (CVUtils.h:77-99)
-                    fj[0] = -z_inv; fj[1] = 0.0; fj[2] = jx * z_inv_2; fj[3] = jy * fj[2]; fj[4] = -(1.0 + jx * fj[2]); fj[5] = jy * z_inv;
-                    fj[6] = 0.0; fj[7] = -z_inv; fj[8] = jy * z_inv_2; fj[9] = 1.0 + jy * fj[8]; fj[10] = -fj[3]; fj[11] = -jx * z_inv;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)                                          // Jres_ -= J * res (:210), J = (dx fj0 + dy fj1) fl
-                        acc[21 + k] -= (fj[k] * gA + fj[6 + k] * gB) * fl;
-                }
-                }   // f < n
-                // approximate value of the chi2 chain at the start of the feature, relative to its chunk of 64 (= this wavefront)
-                const float incl = ygz_wave_scan_f(sq);
-                if (f < n) SA_PRE(f) = incl - sq;
-                if (lane == 63) SA_CTOT(f >> 6) = incl;
-            }
-#undef BIL
-#pragma unroll
-            for (int k = 0; k < 21; ++k) acc[k] = 0.0;
-            if (__ballot(chg_mask != 0u) != 0ull) {                 // wave-uniform skip: no feature of this wavefront changed state
-#pragma unroll 1
-                for (int c = 0; c * SA_THREADS < n; ++c) {
-                    if (!((chg_mask >> c) & 1u)) continue;
-                    const int f = c * SA_THREADS + tid;
-                    const bool add = (add_mask >> c) & 1u;
-#pragma unroll
-                    for (int k = 0; k < 21; ++k) { const double h = Hf[21 * (size_t)f + k]; acc[k] += add ? h : -h; }
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
-            {
-                int m = my_meas;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) m += __shfl_xor(m, off);
-                if (lane == 0) s_nmeas_w[wv] = m;
-            }
-            __syncthreads();
-            SA_PHASE(1);      // residual pass
-            // ---- chain, step 1 (all lanes, lane = feature, wavefront = chunk of 64): the 16-term map of every feature for its
-            // predicted binade (integer ALU only), then a SEGMENTED scan of the maps along the chunk: a segment = a run of
-            // features with the same predicted binade and usable maps; after the scan a lane holds the map of everything from
-            // the head of its segment up to itself ((A then B)(p) = A(p) + B((p + A(p)) & 1), associative).
-            for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {
-                const int chunk = (f0_ >> 6) + wv;
-                if (64 * chunk >= n) continue;                                // wave-uniform
-                const int f = f0_ + tid, cnt = min(64, n - 64 * chunk);
-                float part = 0.f;
-                for (int c2 = lane; c2 < chunk; c2 += 64) part += SA_CTOT(c2);
-                const float base = ygz_wave_sum_f(part);
-                int t0 = 0, t1 = 0, bad = 0, E = 0;
-                if (f < n) {
-                    const float4 a0 = SA_R2(0, f), a1 = SA_R2(1, f), a2 = SA_R2(2, f), a3 = SA_R2(3, f);
-                    const float x[16] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
-                    E = (int)(__float_as_uint(base + SA_PRE(f)) >> 23);
-                    bad = !(E > 0 && E < 255);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) sa_chain_term(__float_as_uint(x[k]), E, t0, t1, bad);
-                }
-                if (lane >= cnt) E = __builtin_amdgcn_readlane(E, cnt - 1);   // past the end: the empty map in the last feature's binade
-                const int prev = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, E | (bad << 16));
-                const int head = (lane == 0) | (prev != (E | (bad << 16))) | bad;      // bad features stand alone
-                int p0 = t0, p1 = t1, hd = head;
-#define SA_SCAN(ctrl, rmask, valid)                                                                                  \
-                { const int l0_ = __builtin_amdgcn_update_dpp(0, p0, (ctrl), (rmask), 0xF, false),                   \
-                            l1_ = __builtin_amdgcn_update_dpp(0, p1, (ctrl), (rmask), 0xF, false),                   \
-                            lh_ = __builtin_amdgcn_update_dpp(0, hd, (ctrl), (rmask), 0xF, false);                   \
-                  if (valid) { if (!hd) { const int n0_ = l0_ + ((l0_ & 1) ? p1 : p0), n1_ = l1_ + (((1 + l1_) & 1) ? p1 : p0); \
-                                          p0 = min(n0_, 0x10000000); p1 = min(n1_, 0x10000000); }                    \
-                               hd |= lh_; } }
-                SA_SCAN(0x111, 0xF, (lane & 15) >= 1) SA_SCAN(0x112, 0xF, (lane & 15) >= 2)
-                SA_SCAN(0x114, 0xF, (lane & 15) >= 4) SA_SCAN(0x118, 0xF, (lane & 15) >= 8)
-                SA_SCAN(0x142, 0xA, (lane & 16) != 0)                          // row_bcast:15 -> rows 1, 3
-                SA_SCAN(0x143, 0xC, lane >= 32)                                // row_bcast:31 -> rows 2, 3
-#undef SA_SCAN
-                if (f < n) { SA_FMAP(f) = make_int4(t0, t1, E, bad | (head << 1)); SA_PMAP(f) = make_int2(p0, p1); }
-            }
-            __syncthreads();
-            SA_PHASE(13);     // maps + scan
-            if (wv == 0) {
-                // ---- wave 0: chi2 = the reference's FLOAT sum of res*res in feature/pixel order (a skipped feature contributes
-                // 0.0f + ... exactly), walked segment by segment: if c is in the segment's binade and the whole segment stays in it,
-                // ONE integer add replaces 16 x (features of the segment) dependent float adds; if the segment leaves the binade the
-                // crossing feature is found with one ballot (increments are monotone), the features before it are taken at once,
-                // and only its own 16 terms are added one by one in hardware floats.  Either way the result is the reference's float.
-                uint32_t cb = 0u;                                            // bits of c, wave-uniform
-                const int J = (n + 63) >> 6;
-                float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: chunk j + 1 is in flight
-                int4 nm = make_int4(0, 0, 0, 0); int2 np = make_int2(0, 0);
-                if (lane < n) {
-                    n0 = SA_R2(0, lane); n1 = SA_R2(1, lane); n2 = SA_R2(2, lane); n3 = SA_R2(3, lane); nm = SA_FMAP(lane); np = SA_PMAP(lane);
-                }
-#define SA_TRY(m0_, m1_, mE_, mbad_, taken)                                                                            \
-                    { taken = false;                                                                                   \
-                      if (!(mbad_) && (int)(cb >> 23) == (mE_)) {                                                      \
-                          const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u, mn_ = m_ + (uint32_t)((m_ & 1u) ? (m1_) : (m0_)); \
-                          if (mn_ < 0x1000000u) { cb = (cb & 0xff800000u) | (mn_ & 0x7fffffu); taken = true; } } }
-                for (int j = 0; j < J; ++j) {
-                    SA_PHASE(12);
-                    const float x[16] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w };
-                    const int f0 = nm.x, f1 = nm.y, E = nm.z, bad = nm.w & 1, p0 = np.x, p1 = np.y;
-                    const int cnt = min(64, n - 64 * j);
-                    const unsigned long long H = __ballot(((nm.w >> 1) & 1) && lane < cnt);
-                    {
-                        const int fn = 64 * (j + 1) + lane;
-                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nm = make_int4(0, 0, 0, 0); np = make_int2(0, 0);
-                        if (fn < n) {
-                            n0 = SA_R2(0, fn); n1 = SA_R2(1, fn); n2 = SA_R2(2, fn); n3 = SA_R2(3, fn); nm = SA_FMAP(fn); np = SA_PMAP(fn);
-                        }
-                    }
-                    SA_PHASE(9);
-                    int pos = 0;
-                    while (pos < cnt) {
-                        bool taken;
-                        if ((H >> pos) & 1ull) {
-                            const unsigned long long rest = pos < 63 ? (H >> (pos + 1)) : 0ull;
-                            const int e = rest ? pos + (int)__builtin_ctzll(rest) : cnt - 1;        // last feature of the segment
-                            const int sE = __builtin_amdgcn_readlane(E, pos), sbad = __builtin_amdgcn_readlane(bad, pos);
-                            SA_TRY(__builtin_amdgcn_readlane(p0, e), __builtin_amdgcn_readlane(p1, e), sE, sbad, taken)
-                            if (taken) { pos = e + 1; continue; }
-                            if (!sbad && (int)(cb >> 23) == sE) {
-                                // the segment leaves the binade: the first feature whose prefix does (the prefixes are monotone)
-                                const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u;
-                                const int inc = (m_ & 1u) ? p1 : p0;
-                                unsigned long long over = __ballot(m_ + (uint32_t)inc >= 0x1000000u);
-                                over &= (~0ull << pos) & (e < 63 ? ((2ull << e) - 1ull) : ~0ull);
-                                if (over) {
-                                    const int jx = (int)__builtin_ctzll(over);
-                                    if (jx > pos) {
-                                        SA_TRY(__builtin_amdgcn_readlane(p0, jx - 1), __builtin_amdgcn_readlane(p1, jx - 1), sE, 0, taken)
-                                        pos = jx;
-                                    }
-                                }
-                            }
-                        }
-                        // one feature: its own map if c is in its binade and stays there, else its 16 terms in hardware floats
-                        SA_TRY(__builtin_amdgcn_readlane(f0, pos), __builtin_amdgcn_readlane(f1, pos), __builtin_amdgcn_readlane(E, pos),
-                               __builtin_amdgcn_readlane(bad, pos), taken)
-                        if (!taken) {
-                            SA_COUNT(7, 1);
-                            float cc = __uint_as_float(cb);
-#pragma unroll
-                            for (int k = 0; k < 16; ++k)
-                                cc = __fadd_rn(cc, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[k]), pos)));
-                            cb = __builtin_amdgcn_readfirstlane(__float_as_uint(cc));
-                        }
-                        ++pos;
-                    }
-                    SA_PHASE(11);
-                }
-#undef SA_TRY
-                const float c = __uint_as_float(cb);
-                if (lane == 0) s_chi2 = c;
-                SA_COUNT(2, clock64() - tlast); SA_COUNT(5, 1);
-            } else if (tid == 64) {
-                // ---- meanwhile, one lane of wave 1: the 6x6 solve and the candidate model (NLSSolver_impl.hpp:40-52, 66-75).  The
-                // Gauss-Newton step does not depend on chi2; only the accept / stop decision below does.
-                double Hm[36], Jr[6], x[6];
-                int q = 0;
-                for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) {
-                    double sm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) sm += red[w2][q];
-                    sm = s_H[q] + sm; s_H[q] = sm;                // running H of the level
-                    Hm[6 * a + b] = sm; Hm[6 * b + a] = sm; ++q;
-                }
-                for (int a = 0; a < 6; ++a) { double sm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) sm += red[w2][21 + a]; Jr[a] = sm; }
-                const bool okx = ldlt6_solve_ws(Hm, Jr, x, s_ldlt, s_ldlt + 36, s_ldlt + 42, s_tr);
-                double mx[6]; for (int k = 0; k < 6; ++k) mx[k] = -x[k];
-                Se3 E, Tn;
-                se3_exp_d(mx, &E);
-                se3_mul_d(&T, &E, &Tn);
-                double nmx = -1; for (int k = 0; k < 6; ++k) if (fabs(x[k]) > nmx) nmx = fabs(x[k]);
-                s_Tn = Tn; s_nmx = nmx; s_solve_ok = okx ? 1 : 0;
-            }
-            __syncthreads();
-            SA_PHASE(3);      // chain || accumulation
-            // ---- lane 0: accept / stop decision (NLSSolver_impl.hpp:53-63, 85-87)
-            if (tid == 0) {
-                int nm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) nm += s_nmeas_w[w2];
-                n_meas_last = nm;
-                const double new_chi2 = (double)__fdiv_rn(s_chi2, (float)nm);
-                if (!s_solve_ok) stop_ = true;
-                int ctl = 0;
-                if ((it > 0 && new_chi2 > chi2_) || stop_) { sT = old_model; ctl = 1; }
-                else {
-                    old_model = T; sT = s_Tn;
-                    chi2_ = new_chi2;
-                    if (s_nmx <= 0.000001) ctl = 2;        // eps_ (SparseImageAlign.cpp:18)
-                }
-                s_ctl = ctl;
-            }
-            __syncthreads();
-            const int ctl = s_ctl;
-            SA_PHASE(4);      // solve + update
-            __syncthreads();
-            if (ctl == 2) { ++it; break; }
-            if (ctl == 1) break;
-        }
-        if (tid == 0 && level < YGZ_MAX_LEVELS) out[8 + level] = (double)it;
-    }
-    if (tid == 0) {
-        Se3 o; se3_mul_d(&sT, &T_ref, &o);                 // cur->_TCW = T_cur_from_ref * ref->_TCW (:48)
-        for (int k = 0; k < 4; ++k) out[k] = o.q[k];
-        for (int k = 0; k < 3; ++k) out[4 + k] = o.t[k];
-        out[7] = (double)n_meas_last;
-#ifdef YGZ_SA_TIMERS
-        if (A.dbg) for (int k = 0; k < 16; ++k) A.dbg[16 * (size_t)pair + k] = (double)tph[k];
-#endif
-    }
-}
-
-
 // =====================================================================================================================
-// Second form of the kernel (default since round 4; YGZ_SA_FORM=0 selects the first form above for A/B runs -- both give
-// the same bits).  What changed, each measured:
+// The kernel (second form, round 4; the first form -- chain maps by integer arithmetic, patches and Hf in HBM, one workgroup per problem: 1.09 ms
+// per 512 VGA pairs against 0.77 -- was removed in round 5, DESIGN.md Appendix B keeps its numbers).  What the second form changed, each measured:
 //   * the 16-term parity map of a feature comes from the float adder itself: the chain started at 2^E (even mantissa) and at
 //     2^E + ulp (odd mantissa) and pushed through the 16 terms gives the two increments as differences of bit patterns --
 //     2 x 16 v_add_f32 instead of 16 x ~20 integer instructions (sa_chain_term) per feature and iteration;
@@ -569,25 +115,8 @@ __device__ __forceinline__ void sa_frame_jacobian(double x, double y, double dep
 // With f = fj_row0, g = fj_row1:  J_a J_b = fl^2 (dx^2 f_a f_b + dx dy (f_a g_b + g_a f_b) + dy^2 g_a g_b), so the 16 outer products collapse
 // into three sums over the patch (Sxx, Sxy, Syy; the products of two floats are exact in double) and 21 combinations: ~360 instead of
 // ~1060 FP64 operations per feature and level.  Same quantity, different rounding (1e-16 relative; the pose tolerance of the path is 1e-9).
-// YGZ_SA_HF_PIXELWISE keeps the pixel-by-pixel form of the first kernel (bit-identical to it).
 __device__ __forceinline__ void sa_feature_h(const double fj[12], double fl, const float dxv[16], const float dyv[16], double hf[21])
 {
-#ifdef YGZ_SA_HF_PIXELWISE
-#pragma unroll
-    for (int k = 0; k < 21; ++k) hf[k] = 0.0;
-#pragma unroll
-    for (int pc = 0; pc < 16; ++pc) {
-        double J[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) J[k] = ((double)dxv[pc] * fj[k] + (double)dyv[pc] * fj[6 + k]) * fl;
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int b = a; b < 6; ++b) hf[q++] += J[a] * J[b];
-        }
-    }
-#else
     double sxx = 0.0, sxy = 0.0, syy = 0.0;
 #pragma unroll
     for (int pc = 0; pc < 16; ++pc) {
@@ -603,7 +132,6 @@ __device__ __forceinline__ void sa_feature_h(const double fj[12], double fl, con
         for (int b = a; b < 6; ++b)
             hf[q++] = sxx * (fj[a] * fj[b]) + sxy * (fj[a] * fj[6 + b] + fj[6 + a] * fj[b]) + syy * (fj[6 + a] * fj[6 + b]);
     }
-#endif
 }
 
 // computeResiduals for one feature (SparseImageAlign.cpp:147-207): warp, bounds, bilinear window of the current image, residuals.
@@ -658,7 +186,7 @@ __device__ __forceinline__ void sa_feature_jres(const double fj[12], double fl, 
 // H_INLINE: the fused pass adds the block of a used feature to H while its gradients are in registers (96 more live registers: fine for
 // 256 lanes with 512 registers each, spills at 512 lanes); otherwise it only marks the feature and the loop that handles entering /
 // leaving features recomputes the block from the gradients it just stored (same bits).
-template <int SA_THREADS, bool H_INLINE>
+template <int SA_THREADS>
 __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
 {
     __shared__ double red[SA_THREADS / 64][28];
@@ -812,20 +340,13 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
-                        flags[f] = (uint8_t)((vis ? 1 : 0) | (use ? 2 : 0) | (!H_INLINE && use && refill ? 12 : 0));
+                        flags[f] = (uint8_t)((vis ? 1 : 0) | (use ? 2 : 0) | (use && refill ? 12 : 0));
                         if (use) {
                             my_meas += 16;
                             double fj[12];
                             sa_frame_jacobian(xr, yr, dep, fj);
                             sa_feature_jres(fj, L.fl, dxv, dyv, res, acc + 21);
-                            if (refill) {
-                                if (H_INLINE) {
-                                    double hf[21];
-                                    sa_feature_h(fj, L.fl, dxv, dyv, hf);
-#pragma unroll
-                                    for (int k = 0; k < 21; ++k) acc[k] += hf[k];
-                                } else any_chg = true;
-                            }
+                            if (refill) any_chg = true;        // (its block of H is added by the enter / leave loop below: keeping the blocks in registers here made the kernel faster alone and the step slower)
                         }
                     }
                     const float incl = ygz_wave_scan_f(sq);
@@ -1082,19 +603,11 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
 // beside a kernel of small workgroups (LK: four wavefronts of 112 registers, refilled as fast as they retire) it starves -- the device
 // timeline of the step showed the alignment stretched from 1.1 to 4.8 ms, ending after everything else.  Resident workgroups that loop
 // over their problems (gridDim.x = CUs) keep the slot they got when the GPU was empty.
-template <int SA_THREADS, bool H_INLINE>
+template <int SA_THREADS>
 __global__ __launch_bounds__(SA_THREADS, 1) void k_sparse_align2(SaArgs A)
 {
     for (int pair = blockIdx.x; pair < A.n_pairs; pair += gridDim.x) {
-        sa2_problem<SA_THREADS, H_INLINE>(A, pair);
-        __syncthreads();
-    }
-}
-// experiment (YGZ_SA_REGS=288): the 256-lane kernel held to 288 registers per lane (the rest spilled), so that two LK wavefronts fit beside it on a SIMD
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(144))) void k_sparse_align2_r288(SaArgs A)
-{
-    for (int pair = blockIdx.x; pair < A.n_pairs; pair += gridDim.x) {
-        sa2_problem<256, false>(A, pair);
+        sa2_problem<SA_THREADS>(A, pair);
         __syncthreads();
     }
 }
@@ -1109,23 +622,19 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
     A.dbg = nullptr; A.prio = ctx->wave_prio_mask & 1; A.n_pairs = n_pairs;
-    if (getenv("YGZ_SA_DEBUG")) { void *d = nullptr; if (ygz_scratch(ctx, SCR_SA_OUT, (size_t)n_pairs * 128, &d) == YGZ_OK) A.dbg = (double *)d; }
+    // a problem gets 512 lanes when the launch leaves CUs idle anyway (few pairs: the single-frame surface calls) or when the grid is too big
+    // for the per-lane feature loop of the 256-lane form; else 256 (one wavefront per SIMD: the VALU-bound stages of other streams fill its
+    // idle issue slots)
+    // (YGZ_SA_THREADS=256 / 512 pins the shape where the grid allows both: how the tests reach the 256-lane form with a handful of pairs)
     const char *env_t = getenv("YGZ_SA_THREADS");
-    int threads = env_t ? atoi(env_t) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
-    static const int form = [] { const char *e = getenv("YGZ_SA_FORM"); return e ? atoi(e) : 1; }();      // 0: the first form of the kernel (A/B)
-    // the first form keeps one bit per feature of a lane for its deferred H update (32 bits): up to 32 x lanes features per problem; the second
-    // form marks entering / leaving features in their flags byte: any number of grid cells
+    int threads = env_t ? (atoi(env_t) == 256 ? 256 : 512) : (2 * n_pairs <= ctx->n_cu ? 512 : 256);
     if (ctx->cells > 32 * 256) threads = 512;
-    if (form == 0 && ctx->cells > 32 * 512) return YGZ_E_CAPACITY;
-    // per-iteration scratch of the first lcap features in LDS: 4 x 16 (r2) + 16 (fmap) + 8 (pmap) + 4 (pre) bytes each + chunk totals;
-    // second form: + 64 bytes (the reference patch) for the first pcap features, from what the scratch leaves
+    // per-iteration scratch of the first lcap features in LDS: 4 x 16 (r2) + 16 (fmap) + 8 (pmap) + 4 (pre) bytes each + chunk totals, then
+    // 64 bytes (the reference patch) for the first pcap features from what the scratch leaves
     // (a 512-lane problem owns its CU -- nothing else fits beside 512 x 256 registers -- so it may take nearly all of the LDS)
-    static const int lcap_env = [] { const char *e = getenv("YGZ_SA_LDS"); return e ? atoi(e) : -1; }();
-    static const int pcap_env = [] { const char *e = getenv("YGZ_SA_PLDS"); return e ? atoi(e) : -1; }();
     const int cells64 = (ctx->cells + 63) / 64 * 64;
-    const int lcap_want = lcap_env >= 0 ? lcap_env : (threads == 512 ? 1600 : 1024);
+    const int lcap_want = threads == 512 ? 1600 : 1024;
     A.lcap = ((lcap_want < ctx->cells ? lcap_want : ctx->cells) + 63) / 64 * 64;
-    if (A.lcap < 0) A.lcap = 0;
     int lim = 64 * 1024;      // dynamic + static LDS must fit the device's per-block limit (static: < 3 KB, see -Rpass-analysis=kernel-resource-usage)
     (void)hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
     {
@@ -1133,50 +642,26 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
         if (A.lcap > room) A.lcap = room > 0 ? room / 64 * 64 : 0;
     }
     size_t dyn = (size_t)A.lcap * 92 + (size_t)(A.lcap / 64 + 1) * 4 + 16;
-    A.pcap = 0;
-    if (form != 0) {
-        dyn = (dyn + 15) & ~(size_t)15;
+    dyn = (dyn + 15) & ~(size_t)15;
+    {
         const long left = (long)lim - 4096 - 16 - (long)dyn;
         int pc = left > 0 ? (int)(left / 64) / 64 * 64 : 0;
         if (pc > cells64) pc = cells64;
-        if (pcap_env >= 0 && pcap_env / 64 * 64 < pc) pc = pcap_env / 64 * 64;
         A.pcap = pc;
         dyn += (size_t)pc * 64;
     }
-    void (*const k2_512)(SaArgs) = k_sparse_align2<512, false>;
-    void (*const k2_256)(SaArgs) = k_sparse_align2<256, true>;
-    void (*const k2_256b)(SaArgs) = k_sparse_align2<256, false>;
-    static const int h_inline = [] { const char *e = getenv("YGZ_SA_HINLINE"); return e ? atoi(e) : 0; }();      // 1: the 256-lane form with the in-register H blocks (faster alone: 0.915 against 0.94 ms per 512 pairs; 126 instead of 58 AGPRs make the STEP 10 % slower: the matcher no longer fits beside it)
+    void (*const k2_512)(SaArgs) = k_sparse_align2<512>;
+    void (*const k2_256)(SaArgs) = k_sparse_align2<256>;
     if (!ctx->sa_attr_set) {                                                       // function attributes are per device: once per context
-        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k2_512), hipFuncAttributeMaxDynamicSharedMemorySize, lim - 4096));
         YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k2_256), hipFuncAttributeMaxDynamicSharedMemorySize, lim - 4096));
-        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k2_256b), hipFuncAttributeMaxDynamicSharedMemorySize, lim - 4096));
-        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_align2_r288), hipFuncAttributeMaxDynamicSharedMemorySize, lim - 4096));
         ctx->sa_attr_set = true;
     }
-    if (form != 0) {
-        static const int persist = [] { const char *e = getenv("YGZ_SA_PERSIST"); return e ? atoi(e) : 1; }();      // 0: one workgroup per problem (A/B)
-        static const int grid_env = [] { const char *e = getenv("YGZ_SA_GRID"); return e ? atoi(e) : 0; }();        // resident workgroups of a launch (default: one per CU)
-        static const int regs_env = [] { const char *e = getenv("YGZ_SA_REGS"); return e ? atoi(e) : 0; }();
-        const int res = grid_env > 0 ? grid_env : ctx->n_cu;
-        const int grid = persist && n_pairs > res ? res : n_pairs;
-        if (threads == 512) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_512, dim3(grid), dim3(512), dyn, A);
-        else if (regs_env == 288) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align2_r288, dim3(grid), dim3(256), dyn, A);
-        else if (h_inline) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_256, dim3(grid), dim3(256), dyn, A);
-        else YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_256b, dim3(grid), dim3(256), dyn, A);
-    } else {
-        if (threads == 512) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align<512>, dim3(n_pairs), dim3(512), dyn, A);
-        else YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k_sparse_align<256>, dim3(n_pairs), dim3(256), dyn, A);
-    }
+    // resident workgroups: one per CU, each loops over its problems (see k_sparse_align2)
+    const int grid = n_pairs > ctx->n_cu ? ctx->n_cu : n_pairs;
+    if (threads == 512) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_512, dim3(grid), dim3(512), dyn, A);
+    else YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_256, dim3(grid), dim3(256), dyn, A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    if (A.dbg) {
-        double h[16];
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        fprintf(stderr, "[sa-debug] pair0 shader cycles: overhead %.0f residual %.0f wave0-chain %.0f (unused %.0f) chain phase %.0f solve %.0f; GN iterations %.0f, chain groups added term by term %.0f; chain: prefix+maps %.0f, per pass: unpack %.0f compose %.0f walk %.0f loop %.0f\n", h[0], h[1], h[2], h[6], h[3], h[4], h[5], h[7], h[13], h[9], h[10], h[11], h[12]);
-    }
     return YGZ_OK;
 }
 

@@ -230,7 +230,6 @@ int ygz_hip_track_reload(ygz_hip_ctx *ctx, int predict)
     if (!ctx || ctx->n_pairs < 1 || !ctx->trk_alloc) return YGZ_E_STATE;
     int rc = launch_load(ctx, predict);
     if (rc != YGZ_OK) return rc;
-    { const char *e = getenv("YGZ_KLT_PREP"); if (e && e[0] == 'e') rc = ygz_klt_prepare_early(ctx); }      // experiment switch (schedule)
     return rc;
 }
 

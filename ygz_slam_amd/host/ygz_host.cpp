@@ -413,7 +413,9 @@ float Tracker::MeanDisparity() const
 SparseImgAlign::SparseImgAlign(int max_level, int min_level, int n_iter, Method method, bool, bool)
     : max_level_(max_level), min_level_(min_level), n_iter_(n_iter)
 {
-    if (method != GaussNewton) LOG(WARNING) << "SparseImgAlign: only GaussNewton is provided (the live path, Matcher.cpp:18)" << endl;
+    // NLLSSolver::optimizeLevenbergMarquardt (NLSSolver_impl.hpp:91-212) is not provided: the only caller of the reference constructs the aligner
+    // with GaussNewton (Matcher.cpp:18).  Asking for it is an ERROR, not a silent Gauss-Newton run under another name.
+    if (method != GaussNewton) throw std::invalid_argument("ygz::SparseImgAlign: method LevenbergMarquardt is not provided (only GaussNewton, the reference's live path, Matcher.cpp:18)");
 }
 
 size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
@@ -866,6 +868,11 @@ struct CeresArrays {
 void TwoViewBACeres(const SE3 &ref, SE3 &curr, const vector<Vector2d> px_ref, const vector<Vector2d> px_curr,
                     vector<bool> &inlier, vector<Vector3d> &pts_ref)
 {   // BA.cpp:11-89
+    // The reference asks ceres for trust_region_strategy_type = DOGLEG here (BA.cpp:58-62); this library restates ceres' LEVENBERG_MARQUARDT strategy
+    // only (oracle/ceres_ba.c, k_ba_ceres).  Both end in a stationary point of the same cost (tests/test_oracle_witness.py holds the LM end point
+    // against scipy's dogbox), the iterates differ: said once per process, loudly, instead of silently.
+    static bool told = false;
+    if (!told) { told = true; LOG(WARNING) << "ba::TwoViewBACeres: the reference's DOGLEG strategy (BA.cpp:59) is solved with ceres' LEVENBERG_MARQUARDT restatement" << endl; }
     assert(px_ref.size() == px_curr.size());
     PinholeCamera *cam = Frame::GetCamera();
     assert(cam != nullptr);
