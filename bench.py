@@ -258,6 +258,8 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
         out["kernels"]["k_klt3"] = entry("k_klt3", counts["kernels"]["k_klt3"]["valu_per_unit"], n_kp / kp_ref, probe_avg_s, "HIP events inside the timed region")
     c = pipe.ctx
     c.synchronize()
+    if a.profile_part == "step":
+        return out
     if probe_kernel == "k_klt":                               # the same launch with the GPU to itself (in the step it shares the CUs with the side streams)
         c.probe_begin("k_klt", 64)
         for _ in range(3):
@@ -698,6 +700,9 @@ def main():
     ap.add_argument("--lm-group", type=int, default=None, help="offline mode: BA windows per resident-LM launch")
     ap.add_argument("--defer", type=int, default=None, help="offline mode: keyframe-free gaps behind the last windows of a shard processed at the very end (ygz_offline_params::defer_gaps; default: the driver's rule)")
     ap.add_argument("--bg-budget", type=int, default=0, help="offline mode: workgroups a resident-LM launch may hold while tracking chunks follow (0: library default)")
+    ap.add_argument("--profile-part", default=None, choices=["step", "alone"],
+                    help="for rocprofv3 runs (tools/collect_r05_profiles.sh): 'step' = the warm-up and timed steps only (no stage-alone timings, no "
+                         "extra blocks), so that a kernel table of the run holds IN-STEP launches only; 'alone' = every stage run by itself only")
     ap.add_argument("--no-extras", action="store_true", help="default mode: skip the `offline` and `stream` blocks (the timed region is the same either way)")
     ap.add_argument("--upload", default="bgr", choices=["bgr", "gray"], help="stream mode: what crosses PCIe per frame (3 or 1 byte per pixel)")
     ap.add_argument("--size", default=None, choices=["vga", "720p"],
@@ -719,7 +724,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # extra blocks of the default line (measured after the timed region, so that the driver's record carries them): BASELINE configs[4]
     # (the offline run, sharded over the same ranks) and, at one GPU, the transfer-inclusive stream mode
-    extras = a.mode == "step" and a.size == "vga" and not a.no_extras and os.environ.get("YGZ_BENCH_EXTRAS", "1") != "0"
+    extras = a.mode == "step" and a.size == "vga" and not a.no_extras and a.profile_part is None and os.environ.get("YGZ_BENCH_EXTRAS", "1") != "0"
     R_off = offline_render(a.offline_frames, rank, world) if extras else None      # host cores, before the GPU runtime is touched
     import torch
     dist = None
@@ -771,6 +776,12 @@ def main():
         else:
             q.step()
 
+    if a.profile_part == "alone":                             # a profiler run of the stages by themselves: nothing of the step in its kernel table but one warm-up pass
+        one_step(); barrier()
+        st = pipe.stage_times(reps=5)
+        if rank == 0:
+            print(json.dumps({"profile_part": "alone", "stage_ms_per_batch": st, "frames_per_gpu_per_step": a.batch}))
+        return
     for _ in range(a.warmup):
         one_step()
     barrier()
@@ -811,7 +822,7 @@ def main():
         dist.all_gather_object(ranks, me)
     if rank == 0:
         frames = a.batch * a.steps * world
-        stages = pipe.stage_times()
+        stages = pipe.stage_times() if a.profile_part is None else {}
         n_kp = float(np.mean([len(k["level"]) for k in pipe.kps]))
         # dominant kernel (see profiles/): algorithmic bytes per launch (DESIGN.md "Measurement") / HIP-event duration
         n_px = sum((W >> L) * (H >> L) for L in range(LEVELS))
@@ -842,6 +853,13 @@ def main():
                     "traffic_collected_on_other_kernel_sources": traffic_stale,
                     "note": "frac is the HBM fraction (algorithmic bytes / launch time / 8 TB/s); the kernel is VALU-issue bound, see roofline_valu"}
         roofline_valu = valu_roofline(pipe, a, probe_kernel, avg_s, n_kp)
+        alone = roofline_valu.get("kernels", {}).get(roofline["kernel"], {}).get("alone") if isinstance(roofline_valu, dict) else None
+        if alone:                                             # the same kernel with the GPU to itself (in the step its launch shares the CUs with three side streams)
+            roofline["avg_launch_us_alone"] = alone["avg_launch_us"]
+            roofline["achieved_alone"] = alg / (alone["avg_launch_us"] * 1e-6) / 1e9
+            roofline["frac_alone"] = roofline["achieved_alone"] / 8000.0
+            roofline["how"] = ("frac: HIP events around every launch of the kernel inside the timed steps (profiles/r05_step_kernel_stats.md holds the same launches); "
+                               "frac_alone: 3 runs of the LK stage by itself after the timed region (profiles/r05_alone_kernel_stats.md)")
         step_ms = None
         if step_ev is not None:
             per = np.array([step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(a.steps)])
