@@ -534,7 +534,7 @@ def cpu_offline_baseline(bgr, dimg, vo, budget_s=12.0):
 
 
 def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=1, chunk=128, probe="k_klt", one_dev=False, cpu_baseline_s=0.0,
-                overlap=False, lm_group=None, lanes=None, defer=None, bg_budget=0):
+                overlap=False, lm_group=None, lanes=None, defer=None, bg_budget=0, bg_spread=True):
     """BASELINE configs[4] on the frames offline_render produced: one sequence sharded over the ranks (strong scaling).  A step = one
     complete offline run; the timed region holds every upload, kernel, result copy, collective and the BA round.  Returns the result
     dict on rank 0 (None elsewhere)."""
@@ -554,7 +554,7 @@ def offline_run(R, rank, world, local_rank, dist, upload="bgr", steps=3, warmup=
     # page-locked buffers, calls ygz_offline_run through the binding and prints what came back
     vo = offline.OfflineVO(W_, H_, n_frames, rank=rank, world=world, device=local_rank, chunk=chunk, kf_stride=8, window_kfs=8, max_points=2000,
                            exchange_on_device=not one_dev, depth_div=DEPTH_DIV, depth_dtype=np.uint16, depth_scale=DEPTH_SCALE, overlap=overlap, lm_group=lm_group, lanes=lanes,
-                           gray=gray_in, defer_gaps=defer, bg_team_budget=bg_budget)
+                           gray=gray_in, defer_gaps=defer, bg_team_budget=bg_budget, bg_team_spread=bg_spread)
     for k, (i, b, d) in enumerate(R["rendered"]):
         assert i == need[k]
         if gray_in:
@@ -666,7 +666,7 @@ def main_offline(a):
         dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world)
     chunk = a.batch if a.batch != 512 else 128
     out = offline_run(R, rank, world, local_rank, dist, upload=a.upload, steps=a.steps, warmup=a.warmup, chunk=chunk, probe=a.probe, one_dev=one_dev,
-                      cpu_baseline_s=0.0 if a.no_cpu_baseline else 12.0, overlap=a.lane_overlap, lm_group=a.lm_group, lanes=a.lanes, defer=a.defer, bg_budget=a.bg_budget)
+                      cpu_baseline_s=0.0 if a.no_cpu_baseline else 12.0, overlap=a.lane_overlap, lm_group=a.lm_group, lanes=a.lanes, defer=a.defer, bg_budget=a.bg_budget, bg_spread=not a.bg_compact)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
@@ -699,6 +699,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=None, help="offline mode: tracking contexts that take the chunks in turn (default: 3 with BGR frames, 4 with gray frames)")
     ap.add_argument("--lm-group", type=int, default=None, help="offline mode: BA windows per resident-LM launch")
     ap.add_argument("--defer", type=int, default=None, help="offline mode: keyframe-free gaps behind the last windows of a shard processed at the very end (ygz_offline_params::defer_gaps; default: the driver's rule)")
+    ap.add_argument("--bg-compact", action="store_true", help="offline mode: resident-LM launches that chunks still follow keep the compact placement (one XCD per window) instead of spreading over the XCDs")
     ap.add_argument("--bg-budget", type=int, default=0, help="offline mode: workgroups a resident-LM launch may hold while tracking chunks follow (0: library default)")
     ap.add_argument("--profile-part", default=None, choices=["step", "alone"],
                     help="for rocprofv3 runs (tools/collect_r05_profiles.sh): 'step' = the warm-up and timed steps only (no stage-alone timings, no "

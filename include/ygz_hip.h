@@ -382,6 +382,11 @@ int  ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_wind
  * pipeline that runs the LM beside other kernels lowers it for those launches (a member that waits for a CU to drain keeps the
  * members already placed spinning) and restores it for the launch nothing else runs beside.  Clamped to [1, CUs]. */
 int  ygz_hip_ba_set_team_budget(ygz_hip_ctx *ctx, int workgroups);
+/* Where the members of a team run.  0 (default): one XCD per window -- its 32 CUs for the whole launch, the team barrier without an L2
+ * write-back (fastest alone); 1: four CUs of every XCD -- the launch leaves seven eighths of every XCD to the kernels of other streams (a
+ * pipeline that runs the LM BESIDE other work wants this: every kernel has workgroups on every XCD and waits for the one a team owns).
+ * Results are bit-identical either way. */
+int  ygz_hip_ba_set_team_placement(ygz_hip_ctx *ctx, int spread);
 int  ygz_hip_ba_get_state(ygz_hip_ctx *ctx, int window, double *poses, double *points);
 /* statistics of the last ygz_hip_ba_optimize_resident run on each window of the range (it may have been asynchronous) and the graph
  * sizes dims [n][4] = poses, points, edges, free poses; either output may be NULL.  YGZ_E_HIP: a team of workgroups timed out at a

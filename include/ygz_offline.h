@@ -50,10 +50,11 @@ typedef struct {
     int depth_w, depth_h, depth_kind; /* depth image per frame (ygz_hip_upload_depth_batch: kind 0 f32 m, 1 u16 * depth_scale, 2 f64 m) */
     double depth_scale;
     int pipeline_ba;                  /* 1: windows are built and optimised as soon as their last keyframe is tracked; 0: after the tracking */
-    int defer_gaps;                   /* keyframe-free gaps behind the last windows processed at the very end (chunk plan); -1: 13 on a shard of >= 768 frames, else 0 */
+    int defer_gaps;                   /* keyframe-free gaps behind the last windows processed at the very end (chunk plan); -1: 13 on a shard of >= 768 frames, every gap on a shard of <= 160 frames, else 0 */
     int ramp, kf_tail;                /* chunk plan: short chunks at both ends (1); the frames behind the shard's last keyframe as the last chunk (1) */
     int stage_overlap;                /* ygz_hip_set_overlap on the lanes (0) */
     int bg_team_budget;               /* workgroups a resident-LM launch may hold while tracking chunks follow (0: library default) */
+    int bg_team_spread;               /* 1 (default): such a launch spreads its teams over the XCDs (ygz_hip_ba_set_team_placement); the last launch of a run, which nothing follows, is compact */
 } ygz_offline_params;
 
 /* The two exchange primitives, on HOST memory.  NULL hook + world > 1: RCCL on device buffers (the product path).  A hook replaces RCCL

@@ -179,7 +179,8 @@ def test_offline_driver_partition_equals_the_python_statement():
             out = np.zeros((4096, 3), np.int32); k = C.c_int(0)
             assert lib.ygz_offline_plan(C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int32)), 4096, C.byref(k)) == 0
             s, c, _ = ydist.shard_frames(n, r, world)
-            d = (13 if c >= 768 else 0) if defer < 0 else defer
+            inside = sum(1 for w in wins if w[0] >= s and w[-1] < s + c)
+            d = (13 if c >= 768 else (inside if c <= 160 else 0)) if defer < 0 else defer      # the driver's rule (ygz_offline.cpp: make_plan)
             exp = offline.chunk_plan(s, s + c, chunk, True, stride, wins, d)
             got = {}
             for ci, a, b in out[:k.value].tolist():

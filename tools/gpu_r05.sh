@@ -85,4 +85,36 @@ print("surface", {k: d["surface"].get(k) for k in ("frames_per_s","vs_cpu_1core"
 print("stages", d["stage_ms_per_batch"])
 PY
     ;;
+i)  # does the resident LM with the same-XCD barrier still slow the tracking beside it?  (batch b measured + 2.4 ms with the full barrier)
+    for f in 128 256; do
+      benchline off${f}_g0 $OFF --frames $f
+      benchline off${f}_g1 $OFF --frames $f --lm-group 1
+      benchline off${f}_g1_d2 $OFF --frames $f --lm-group 1 --defer 2
+      benchline off${f}_g1_bg32 $OFF --frames $f --lm-group 1 --bg-budget 32
+      benchline off${f}_g1_bg64 $OFF --frames $f --lm-group 1 --bg-budget 64
+    done
+    ;;
+j)  # device timeline of a 128-frame shard with the LM launched per window (what does the tracking do while the first LM runs?)
+    bash tools/offline_timeline.sh r05_f128g1 --mode offline --frames 128 --steps 2 --warmup 1 --no-cpu-baseline --lm-group 1
+    cp gpurun_out/r05_f128g1_timeline.tsv $OUT/
+    YGZ_OFFLINE_TRACE=1 python bench.py --mode offline --steps 2 --warmup 1 --no-cpu-baseline --frames 128 --lm-group 1 2> $OUT/trace128g1.txt > /dev/null; grep "offline host" $OUT/trace128g1.txt | tail -16
+    ;;
+k)  # team placement: a resident-LM launch beside tracking chunks spread over the XCDs (4 CUs of each) instead of owning one XCD
+    timeout 600 python -m pytest tests/test_gpu_offline.py -x -q -k "sharded or 128 or rccl or degenerate" > $OUT/pytest.log 2>&1; grep -n "passed\|failed" $OUT/pytest.log | tail -2
+    for f in 128 256 512 1024; do
+      benchline off${f}_default $OFF --frames $f
+      benchline off${f}_compact $OFF --frames $f --bg-compact
+    done
+    for f in 128 256; do
+      for d in 2 4; do
+        benchline off${f}_d${d} $OFF --frames $f --defer $d
+        benchline off${f}_d${d}_g1 $OFF --frames $f --defer $d --lm-group 1
+        benchline off${f}_d${d}_bg16 $OFF --frames $f --defer $d --bg-budget 16
+      done
+      benchline off${f}_g1 $OFF --frames $f --lm-group 1
+    done
+    benchline off1024_g2 $OFF --frames 1024 --lm-group 2
+    benchline off1024_g4 $OFF --frames 1024 --lm-group 4
+    benchline off1024_d0 $OFF --frames 1024 --defer 0
+    ;;
 esac

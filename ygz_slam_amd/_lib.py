@@ -102,7 +102,7 @@ ABI_SYMBOLS = [
     "ygz_hip_get_keypoint_counts", "ygz_hip_get_keypoint_depths", "ygz_hip_upload_depth_batch", "ygz_hip_keypoint_depths_from_image", "ygz_hip_ba_get_stats", "ygz_hip_se3_chain", "ygz_hip_stream_wait", "ygz_hip_mark", "ygz_hip_wait_mark",
     "ygz_hip_kf_row_bytes", "ygz_hip_kf_store_create", "ygz_hip_kf_store_info", "ygz_hip_kf_store_put", "ygz_hip_kf_store_put_trel",
     "ygz_hip_kf_store_set_trel", "ygz_hip_kf_store_refresh", "ygz_hip_ba_reserve_windows", "ygz_hip_ba_build_windows", "ygz_hip_ba_pack_states", "ygz_hip_ba_mark_outliers", "ygz_hip_ba_get_outlier_stats", "ygz_hip_bow_orientation", "ygz_hip_bow_orientation_slots", "ygz_hip_ba_last_path",
-    "ygz_hip_abi_version", "ygz_hip_ba_optimize_chi2", "ygz_hip_get_stream", "ygz_hip_get_device", "ygz_hip_make_current", "ygz_hip_device_alloc", "ygz_hip_device_free", "ygz_hip_copy",
+    "ygz_hip_abi_version", "ygz_hip_ba_optimize_chi2", "ygz_hip_ba_set_team_placement", "ygz_hip_get_stream", "ygz_hip_get_device", "ygz_hip_make_current", "ygz_hip_device_alloc", "ygz_hip_device_free", "ygz_hip_copy",
 ]
 
 SUMMARY_FIELDS = 32
@@ -929,6 +929,9 @@ class HipContext:
         """(resident?, reasons) of the last ba_optimize / ba_solve_ceres: the resident kernel, or the ~10x slower host loop and why"""
         v = int(self.lib.ygz_hip_ba_last_path(self._ctx))
         return bool(v & 1), [n for b, n in ((16, "more than 14 free poses"), (32, "repeated (point, pose) edges"), (64, "YGZ_BA_HOST_LOOP=1")) if v & b]
+
+    def ba_set_team_placement(self, spread):
+        self._chk(self.lib.ygz_hip_ba_set_team_placement(self._ctx, int(spread)), "ba_set_team_placement")
 
     def ba_set_team_budget(self, workgroups):
         self._chk(self.lib.ygz_hip_ba_set_team_budget(self._ctx, int(workgroups)), "ba_set_team_budget")

@@ -285,6 +285,7 @@ struct LmTeamArgs {
     const BaDev *wins; int n_windows, G, max_iterations; ygz_ba_stats *stats;
     unsigned char *scratch; size_t stride;     // per window: header (LM_HDR) | xpub | part | Sp | Sfin | private pose state of the G members
     int Kmax, prio, Qcap;
+    int spread;                                // team placement, see k_ba_lm_team
     int xcd_barrier;                           // 1: teams whose members share an XCD take the barrier without the L2 write-back (YGZ_LM_XCD_BARRIER=0: never)
     long long *dbg;                            // YGZ_LM_DEBUG: [16] wall-clock ticks (10 ns) per phase of member 0 of the first window
 };
@@ -542,7 +543,15 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
     __shared__ int s_fail, s_ok, s_same;
     __shared__ long long s_t[16];
     const int G = A.G;
-    const int xslot = blockIdx.x & 7, j = blockIdx.x >> 3, g = j % G, w = (j / G) * 8 + xslot;
+    // Placement of a team (the dispatcher deals block b to XCD b % 8 -- observed, not promised; nothing below depends on it for correctness):
+    //   compact (default): the members of window w are blocks xslot + 8 j: ONE XCD -> the barrier without the L2 write-back, 10 % faster alone;
+    //                      but the team then owns all 32 CUs of that XCD for the whole launch (a member's four wavefronts take a CU's
+    //                      registers), and every kernel of another stream has workgroups dealt to that XCD: beside a team the tracking
+    //                      kernels of the offline run made NO progress until the LM was done (profiles/r05_offline128_g1_timeline.md);
+    //   spread (ygz_hip_ba_set_team_placement): consecutive blocks = consecutive members: four CUs of every XCD, the others stay free.
+    int g, w;
+    if (A.spread) { g = (int)(blockIdx.x % (unsigned)G); w = (int)(blockIdx.x / (unsigned)G); }
+    else { const int xslot = blockIdx.x & 7, j = blockIdx.x >> 3; g = j % G; w = (j / G) * 8 + xslot; }
     if (w >= A.n_windows) return;
     ygz_raise_prio(A.prio);                                 // a latency chain of barriers and short phases on a few CUs
     BaDev B = A.wins[w];
@@ -970,6 +979,13 @@ int ygz_hip_ba_set_team_budget(ygz_hip_ctx *ctx, int workgroups)
     return YGZ_OK;
 }
 
+int ygz_hip_ba_set_team_placement(ygz_hip_ctx *ctx, int spread)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    ctx->lm_spread = spread != 0;
+    return YGZ_OK;
+}
+
 int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windows, int max_iterations, ygz_ba_stats *stats)
 {
     YgzDeviceGuard dg_(ctx);
@@ -1003,7 +1019,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     LmTeamArgs A;
     A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
     A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax; A.Qcap = Qcap;
-    A.dbg = nullptr; A.prio = (ctx->wave_prio_mask >> 3) & 1;
+    A.dbg = nullptr; A.prio = (ctx->wave_prio_mask >> 3) & 1; A.spread = ctx->lm_spread ? 1 : 0;
     { static const bool xb = [] { const char *e = getenv("YGZ_LM_XCD_BARRIER"); return !(e && e[0] == '0'); }(); A.xcd_barrier = xb ? 1 : 0; }
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
@@ -1012,7 +1028,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     // records; 0xFF there = never run, ba_carve): one small launch (a 2-D memset, a memset and one memset per window took 0.15 ms of the
     // serial tail of an offline run)
     YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_reset, dim3(n_windows), dim3(256), A.wins, A.scratch, stride, A.stats);
-    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
+    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(A.spread ? G * n_windows : 8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         long long h[16];

@@ -130,6 +130,7 @@ struct ygz_hip_ctx {
     hipEvent_t ev_prep = nullptr;            // end of the LK working images built ahead on a side stream (ygz_hip_track_klt_prepare)
     bool klt_prep_pending = false;           // ... and nobody has waited for it yet
     int  ba_last_path = 0;                   // ygz_hip_ba_last_path
+    bool lm_spread = false;                  // resident-LM teams spread over the XCDs instead of one XCD each (ygz_hip_ba_set_team_placement)
     int  lm_team_budget = 0;                 // workgroups a resident-LM launch may hold (0: half of the CUs), ygz_hip_ba_set_team_budget
     bool match_aux_reads_track = false;      // a direct projection (reads the track sets) is pending on the matcher's side stream
     bool describe_aside = false;             // ygz_hip_detect leaves the descriptor kernel on the matcher's side stream (YGZ_DESCRIBE_ASIDE=1)

@@ -153,7 +153,15 @@ int make_plan(const ygz_offline_params &p, Plan &P)
     if (p.n_frames < 1 || p.world < 1 || p.rank < 0 || p.rank >= p.world || p.chunk < 1 || p.kf_stride < 1 || p.window_kfs < 2) return YGZ_E_INVALID;
     shard_frames(p.n_frames, p.rank, p.world, P.start, P.count, P.halo);
     P.wins = ba_windows(p.n_frames, p.kf_stride, p.window_kfs);
-    P.defer = p.defer_gaps < 0 ? (P.count >= 768 ? 13 : 0) : p.defer_gaps;
+    if (p.defer_gaps >= 0) P.defer = p.defer_gaps;
+    else {
+        // measured (tools/gpu_r05.sh k): a long shard hides its last LM launch beside 13 deferred gaps (59.2 against 60.6 ms per
+        // 1024 frames); a SHORT shard (one rank of an 8-rank job: 128 frames, two windows) defers every gap -- its one LM launch, spread over the
+        // XCDs, then runs beside the gap chunk (11.6 against 12.3 ms); in between the two extra halo frames per gap cost more than they hide
+        int inside = 0;
+        for (const auto &w : P.wins) if (w[0] >= P.start && w.back() < P.start + P.count) ++inside;
+        P.defer = P.count >= 768 ? 13 : (P.count <= 160 ? inside : 0);
+    }
     P.chunks = chunk_plan(P.start, P.start + P.count, p.chunk, p.ramp != 0, p.kf_tail ? p.kf_stride : 0, P.wins, p.pipeline_ba ? P.defer : 0);
     return YGZ_OK;
 }
@@ -477,7 +485,7 @@ void ygz_offline_default_params(ygz_offline_params *p)
     p->chunk = 128; p->kf_stride = 8; p->window_kfs = 8; p->max_points = 2000; p->ba_iterations = 20;
     p->lanes = 3; p->lm_group = 0; p->obs_mode = 1; p->ba_rounds = 1; p->outlier_chi2 = 5.991;
     p->frame_channels = 3; p->depth_w = 320; p->depth_h = 180; p->depth_kind = 1; p->depth_scale = 1.0 / 5000.0;
-    p->pipeline_ba = 1; p->defer_gaps = -1; p->ramp = 1; p->kf_tail = 1; p->stage_overlap = 0; p->bg_team_budget = 0;
+    p->pipeline_ba = 1; p->defer_gaps = -1; p->ramp = 1; p->kf_tail = 1; p->stage_overlap = 0; p->bg_team_budget = 0; p->bg_team_spread = 1;
 }
 
 int ygz_offline_shard(int n_frames, int rank, int world, int *first, int *count, int *halo)
@@ -760,7 +768,11 @@ int ygz_offline_track(ygz_offline *o, const uint8_t *frames, const void *depth, 
         const bool all_built = n_done + o->ba_built.size() == o->local.size();     // nothing more will come: the last launch need not wait for the last chunk
         if (!o->ba_built.empty() && ((int)o->ba_built.size() >= lm_next(o) || ci == n_chunks - 1 || all_built)) {
             // beside the tracking of the next chunks a launch may be held to a few CUs; the last launch, which nothing runs beside, takes the default
-            OCHK(o, ygz_hip_ba_set_team_budget(o->ba, (ci < n_chunks - 1 && !all_built) ? o->p.bg_team_budget : 0), "ba_set_team_budget");
+            // placement: a launch that chunks still follow must not own an XCD (every tracking kernel has workgroups there and would wait for
+            // the whole LM: measured): spread over the XCDs, and held to bg_team_budget workgroups if that is set
+            const bool company = ci < n_chunks - 1;
+            OCHK(o, ygz_hip_ba_set_team_budget(o->ba, company ? o->p.bg_team_budget : 0), "ba_set_team_budget");
+            OCHK(o, ygz_hip_ba_set_team_placement(o->ba, company && o->p.bg_team_spread), "ba_set_team_placement");
             const double tl = now_ms();
             if ((rc = lm(o, o->ba_built.front(), (int)o->ba_built.size())) != YGZ_OK) return rc;
             trace_line(o, "lm", ci, tl);
@@ -818,6 +830,7 @@ int ygz_offline_ba_round(ygz_offline *o)
         if (r0 + rn != (int)o->mine.size()) { o->err = "the windows left for the BA round are not the last ones"; return YGZ_E_STATE; }
         if (W > 1) OCHK(o, ygz_hip_kf_store_set_trel(o->ba, 0, o->p.n_frames, o->T_rel.data()), "kf_store_set_trel");   // relative poses of the frames other ranks tracked
         OCHK(o, ygz_hip_ba_set_team_budget(o->ba, 0), "ba_set_team_budget");
+        OCHK(o, ygz_hip_ba_set_team_placement(o->ba, 0), "ba_set_team_placement");
         const int rc = ba_launch(o, r0, rn, true);
         if (rc != YGZ_OK) return rc;
     }

@@ -214,7 +214,7 @@ class OffParams(C.Structure):
                 ("ba_iterations", C.c_int), ("lanes", C.c_int), ("lm_group", C.c_int), ("obs_mode", C.c_int), ("ba_rounds", C.c_int),
                 ("outlier_chi2", C.c_double), ("frame_channels", C.c_int), ("depth_w", C.c_int), ("depth_h", C.c_int), ("depth_kind", C.c_int),
                 ("depth_scale", C.c_double), ("pipeline_ba", C.c_int), ("defer_gaps", C.c_int), ("ramp", C.c_int), ("kf_tail", C.c_int),
-                ("stage_overlap", C.c_int), ("bg_team_budget", C.c_int)]
+                ("stage_overlap", C.c_int), ("bg_team_budget", C.c_int), ("bg_team_spread", C.c_int)]
 
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -338,7 +338,7 @@ class OfflineVO:
     def __init__(self, width, height, n_total, rank=0, world=1, device=0, chunk=128, levels=3, kf_stride=8, window_kfs=8,
                  max_points=2000, ba_iterations=20, overlap=False, process_group=None, exchange_on_device=True, keep=False, lanes=3,
                  depth_div=1, depth_dtype=np.float64, depth_scale=1.0 / 5000.0, pipeline_ba=True, lm_group=None,
-                 obs_mode="direct", ba_rounds=1, outlier_chi2=5.991, gray=False, defer_gaps=None, bg_team_budget=0, rccl_single=False):
+                 obs_mode="direct", ba_rounds=1, outlier_chi2=5.991, gray=False, defer_gaps=None, bg_team_budget=0, rccl_single=False, bg_team_spread=True):
         from . import _lib
         self.lib, self.h_lib = _lib, host_lib()
         assert obs_mode in ("direct", "match") and ba_rounds in (1, 2)
@@ -359,6 +359,7 @@ class OfflineVO:
         p.lanes, p.lm_group, p.obs_mode, p.ba_rounds, p.outlier_chi2 = lanes, int(lm_group or 0), 1 if obs_mode == "direct" else 0, ba_rounds, outlier_chi2
         p.frame_channels, p.depth_w, p.depth_h, p.depth_kind, p.depth_scale = (1 if gray else 3), self.dw, self.dh, _DEPTH_KIND[self.depth_dtype], depth_scale
         p.pipeline_ba, p.defer_gaps, p.stage_overlap, p.bg_team_budget = int(pipeline_ba), (-1 if defer_gaps is None else int(defer_gaps)), int(overlap), int(bg_team_budget)
+        p.bg_team_spread = int(bool(bg_team_spread))
         self.params = p
         self._keepalive = []
         hook_p, rccl_id = None, None
