@@ -988,6 +988,17 @@ def test_ba_optimize_resident_team_size_invariance(hip_lib):
         pg, tg = ctx.ba_get_state(0, len(w["poses"]), len(w["points"]))
         assert (st.iterations, st.lm_trials, st.chi2_initial, st.chi2_final, st.lambda_final, pg.tobytes(), tg.tobytes()) == ref, budget
     ctx.ba_set_team_budget(0)
+    # ... and through the team's PLACEMENT (ygz_hip_ba_set_team_placement, round 5): compact = one XCD per window, the barrier without the L2
+    # write-back; spread = four CUs of every XCD, the full barrier -- 1 window (team of 32) and 10 windows (teams of 8)
+    for spread in (1, 0):
+        ctx.ba_set_team_placement(spread)
+        for n_launch in (1, 10):
+            ctx.ba_set_state(0, w["poses"], w["points"])
+            for i in range(1, n_launch):
+                ctx.ba_set_state(i, others["poses"], others["points"])
+            st = ctx.ba_optimize_resident(0, n_launch, iterations=20)[0]
+            pg, tg = ctx.ba_get_state(0, len(w["poses"]), len(w["points"]))
+            assert (st.iterations, st.lm_trials, st.chi2_initial, st.chi2_final, st.lambda_final, pg.tobytes(), tg.tobytes()) == ref, (spread, n_launch)
     ctx.close()
 
 

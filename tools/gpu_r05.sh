@@ -117,4 +117,15 @@ k)  # team placement: a resident-LM launch beside tracking chunks spread over th
     benchline off1024_g4 $OFF --frames 1024 --lm-group 4
     benchline off1024_d0 $OFF --frames 1024 --defer 0
     ;;
+l)  # k_fast_select pass 1a: four pixels per lane, packed 16-bit compares -- parity (score / NMS maps, keypoints, both tie rules, odd sizes) and time
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_switches.py -x -q -k "fast or detect or pyramid or describe or pipeline or switch or alternate" > $OUT/pytest.log 2>&1; grep -n "passed\|failed" $OUT/pytest.log | tail -2
+    python tools/stage_bench.py detect --batch 512 --reps 5 --probe k_fast_select,k_describe
+    benchline step python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras
+    ;;
+m)  # smoke() with the offline driver, the placement invariance test, the surface loop again
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+    timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface.py -x -q -k "team_size or surface or loop" > $OUT/pytest.log 2>&1; grep -n "passed\|failed" $OUT/pytest.log | tail -2
+    timeout 300 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; python -c "
+import json; d=json.load(open('$OUT/surface.json'))['surface']; d.pop('what'); print(json.dumps(d))"
+    ;;
 esac

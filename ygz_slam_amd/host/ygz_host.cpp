@@ -648,13 +648,16 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
 {
     hip::Runtime &rt = hip::Runtime::Get();
     vector<Frame *> kfs(local_keyframes.begin(), local_keyframes.end());
-    map<Frame *, int> kf_index;
     vector<int32_t> kf_slot; vector<double> kf_T;
     for (Frame *f : kfs) {
-        kf_index[f] = (int)kf_slot.size();
         kf_slot.push_back(rt.Resident(f));
         double t7[7]; f->_TCW.to7(t7); kf_T.insert(kf_T.end(), t7, t7 + 7);
     }
+    // which local keyframe a feature belongs to: a handful of keyframes (LocalMapping.local_keyframes: 3) -- a linear scan of the pointer array,
+    // not a std::map look-up per observation (thousands per frame)
+    const int n_kfs = (int)kfs.size();
+    Frame *const *kfp = kfs.data();
+    auto kf_of = [&](const Frame *f) { for (int k = 0; k < n_kfs; ++k) if (kfp[k] == f) return k; return -1; };
     vector<MapPoint *> mps(local_map_points.begin(), local_map_points.end());
     vector<double> pos; vector<uint8_t> bad;
     vector<int32_t> cp, ck, cl; vector<double> cpx; vector<Feature *> cfea;
@@ -667,9 +670,9 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
         if (mp->_bad) continue;
         for (auto &obs : mp->_obs) {                                   // LocalMapping.cpp:66-75
             Feature *fea = obs.second;
-            auto it = fea ? kf_index.find(fea->_frame) : kf_index.end();
-            if (it == kf_index.end()) continue;
-            cp.push_back((int32_t)p); ck.push_back(it->second); cl.push_back(fea->_level);
+            const int k = fea ? kf_of(fea->_frame) : -1;
+            if (k < 0) continue;
+            cp.push_back((int32_t)p); ck.push_back(k); cl.push_back(fea->_level);
             cpx.push_back(fea->_pixel[0]); cpx.push_back(fea->_pixel[1]); cfea.push_back(fea);
         }
     }
