@@ -128,4 +128,13 @@ m)  # smoke() with the offline driver, the placement invariance test, the surfac
     timeout 300 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; python -c "
 import json; d=json.load(open('$OUT/surface.json'))['surface']; d.pop('what'); print(json.dumps(d))"
     ;;
+n)  # extraction kernels with less index arithmetic: k_describe (scalar keypoint data, 8-byte row pieces, moments by v_dot4, float pattern table,
+    # eight keypoints per wavefront in batches), k_fast_select (staging without divisions, compass pass by rows with one append per wavefront, ring
+    # masks by sign bits, occupied flags prefetched, two wavefronts per tile)
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_switches.py tests/test_gpu_surface.py -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed" $OUT/pytest.log | tail -2
+    python tools/stage_bench.py detect --batch 512 --reps 5 --probe k_fast_select,k_describe 2>&1 | tail -3
+    benchline step python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras
+    timeout 300 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; python -c "
+import json; d=json.load(open('$OUT/surface.json'))['surface']; d.pop('what'); print(json.dumps(d))"
+    ;;
 esac

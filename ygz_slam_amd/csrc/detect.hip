@@ -27,9 +27,15 @@
 #include "../../include/ygz_orb_pattern.h"
 
 #define FT_W    64
+#ifndef FT_H
 #define FT_H    32
+#endif
+#ifndef FT_NT
+#define FT_NT   128                // threads per tile (two wavefronts: 0.496 ms per 512 VGA frames; 256 threads 0.520, 64 x 16 tiles of 128 threads 0.510, 64 x 8 of 64 0.637)
+#endif
+#define FT_NW   (FT_NT / 64)
 #define FT_LW   80                 // staged columns: x in [x0-8, x0+72)
-#define FT_LH   42                 // staged rows:    y in [y0-5, y0+37)
+#define FT_LH   (FT_H + 10)        // staged rows:    y in [y0-5, y0+FT_H+5)
 #define FT_X0   8                  // tile column of x0
 #define FT_Y0   5                  // tile row of y0
 #define R1_W    (FT_W + 2)         // corner-test region = interior + 1
@@ -45,6 +51,7 @@ struct FastArgs {
     int thr, tie;
     int img_cols, img_rows;        // level-0 size (Frame::_color)
     int cell, grid_cols, cells;
+    uint32_t cell_magic;           // ceil(2^32 / cell) (0: cell == 1): v / cell == umulhi(v, cell_magic) for v < 2^16
     uint32_t *cell_first;
     unsigned long long *cell_best;
     const uint8_t *occupied;
@@ -68,6 +75,7 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
     __shared__ __attribute__((aligned(16))) uint8_t sc[R1_H][R1_LW];      // 0 = no corner, else score+1
     __shared__ uint16_t list[R1_W * R1_H], cand[R1_W * R1_H];
     __shared__ int n_list, n_cand;
+    __shared__ uint8_t occ_l[16][32];                                      // the occupied flags of the grid cells under the tile
 
     const int slot = A.slot_begin + so_;
     const size_t npix = (size_t)A.w * A.h;
@@ -93,14 +101,45 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
 #define FS_COUNT(n) do { } while (0)
 #endif
     if (tid == 0) { n_list = 0; n_cand = 0; }
-    for (int i = tid; i < R1_H * R1_LW / 4; i += 256) reinterpret_cast<uint32_t *>(&sc[0][0])[i] = 0u;
+    for (int i = tid; i < R1_H * R1_LW / 4; i += FT_NT) reinterpret_cast<uint32_t *>(&sc[0][0])[i] = 0u;
+    // grid cell of a level pixel coordinate: (v * 2^level) / cell (FeatureDetector.cpp:383-386) without the integer division
+    const int scale = 1 << A.level;
+    auto cell_of = [&](const int v) { return A.cell_magic ? (int)__umulhi((uint32_t)(v * scale), A.cell_magic) : v * scale; };
+    // the occupied flags step 3 needs are requested now, with the tile (a global load behind the NMS was a second memory latency per tile)
+    const int gx0 = cell_of(x0), gy0 = cell_of(y0);
+    const bool occ_fits = cell_of(x0 + FT_W - 1) - gx0 < 32 && cell_of(y0 + FT_H - 1) - gy0 < 16;
+    constexpr int FT_RP = FT_NT / 32, OCC_PS = 16 / FT_RP;                  // rows per pass of the (row, 32 columns) thread mapping
+    uint8_t occ_v[OCC_PS];
+#pragma unroll
+    for (int ps = 0; ps < OCC_PS; ++ps) occ_v[ps] = 1;
+    if (occ_fits) {
+#pragma unroll
+        for (int ps = 0; ps < OCC_PS; ++ps) {
+            const int k = (gy0 + (tid >> 5) + FT_RP * ps) * A.grid_cols + gx0 + (tid & 31);
+            if (k >= 0 && k < A.cells) occ_v[ps] = A.occupied[(size_t)slot * A.cells + k];
+        }
+    }
     const bool aligned = (A.w & 3) == 0;
+    if (aligned && x0 - FT_X0 >= 0 && x0 - FT_X0 + FT_LW <= A.w && y0 - FT_Y0 >= 0 && y0 - FT_Y0 + FT_LH <= A.h) {
+        // the staged rectangle lies inside the level (every tile but those along the level's edges): thread = (dword column of 20, row),
+        // passes of FT_RP rows -- no bounds per item, no index division; all loads go out before the first LDS store
+        const int c = tid & 31, r = tid >> 5;
+        constexpr int ST_PS = (FT_LH + FT_RP - 1) / FT_RP;
+        if (c < FT_LW / 4) {
+            const uint8_t *p = img + (size_t)(y0 - FT_Y0 + r) * A.w + (x0 - FT_X0 + 4 * c);
+            uint32_t tv[ST_PS];
+#pragma unroll
+            for (int ps = 0; ps < ST_PS; ++ps) { tv[ps] = 0u; if (FT_RP * (ps + 1) <= FT_LH || r + FT_RP * ps < FT_LH) tv[ps] = *reinterpret_cast<const uint32_t *>(p + (size_t)(FT_RP * ps) * A.w); }
+#pragma unroll
+            for (int ps = 0; ps < ST_PS; ++ps) if (FT_RP * (ps + 1) <= FT_LH || r + FT_RP * ps < FT_LH) *reinterpret_cast<uint32_t *>(&tile[r + FT_RP * ps][4 * c]) = tv[ps];
+        }
+    } else {
     // all of a thread's tile loads go out before the first LDS store (rolled, the loop was a chain of four dependent memory latencies)
-    constexpr int FT_TOT = FT_LH * (FT_LW / 4), FT_LN = (FT_TOT + 255) / 256;
+    constexpr int FT_TOT = FT_LH * (FT_LW / 4), FT_LN = (FT_TOT + FT_NT - 1) / FT_NT;
     uint32_t tv[FT_LN];
 #pragma unroll
     for (int k4 = 0; k4 < FT_LN; ++k4) {
-        const int i = tid + 256 * k4;
+        const int i = tid + FT_NT * k4;
         const int r = i / (FT_LW / 4), c4 = (i % (FT_LW / 4)) * 4;
         const int y = y0 - FT_Y0 + r, x = x0 - FT_X0 + c4;
         uint32_t v = 0;
@@ -116,9 +155,12 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
     }
 #pragma unroll
     for (int k4 = 0; k4 < FT_LN; ++k4) {
-        const int i = tid + 256 * k4;
+        const int i = tid + FT_NT * k4;
         if (i < FT_TOT) *reinterpret_cast<uint32_t *>(&tile[i / (FT_LW / 4)][(i % (FT_LW / 4)) * 4]) = tv[k4];
     }
+    }
+#pragma unroll
+    for (int ps = 0; ps < OCC_PS; ++ps) occ_l[(tid >> 5) + FT_RP * ps][tid & 31] = occ_v[ps];
     __syncthreads();
     FS_PHASE(0);
 
@@ -126,33 +168,63 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
     //      1a every pixel: the 4 compass pixels.  A 10-arc of the 16-ring always contains two ADJACENT compass pixels, so a
     //         corner needs an adjacent pair that is brighter than p + t (or darker than p - t); survivors go to an LDS list.
     //      1b list entries: full 16-pixel ring -> bright / dark masks -> 10 contiguous bits.
-    for (int i = tid; i < R1_W * R1_H; i += 256) {
-        const int ry = i / R1_W, rx = i - ry * R1_W;
-        const int x = x0 - 1 + rx, y = y0 - 1 + ry;
-        if (x < 3 || y < 3 || x >= A.w - 3 || y >= A.h - 3) continue;
-        const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
-        const int p = *c, hi = p + A.thr, lo = p - A.thr;
-        const int v0 = c[3 * FT_LW], v4 = c[3], v8 = c[-3 * FT_LW], v12 = c[-3];
-        const bool b0 = v0 > hi, b4 = v4 > hi, b8 = v8 > hi, b12 = v12 > hi;
-        const bool d0 = v0 < lo, d4 = v4 < lo, d8 = v8 < lo, d12 = v12 < lo;
-        if (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) {        // some adjacent compass pair agrees
-            const int pos = atomicAdd(&n_cand, 1);
-            cand[pos] = (uint16_t)i;
+    // (a pixel of the region is named (ry << 7) | rx in the lists.)  1a: wavefront = row, lane = interior column, the two ring columns in a
+    // pass of their own: the row test is scalar, the column test loop-invariant, every LDS address the same register + a constant
+    {
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        auto compass = [&](const int ry, const int rx) {
+            const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
+            const int p = *c, hi = p + A.thr, lo = p - A.thr;
+            const int v0 = c[3 * FT_LW], v4 = c[3], v8 = c[-3 * FT_LW], v12 = c[-3];
+            const bool b0 = v0 > hi, b4 = v4 > hi, b8 = v8 > hi, b12 = v12 > hi;
+            const bool d0 = v0 < lo, d4 = v4 < lo, d8 = v8 < lo, d12 = v12 < lo;
+            return (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) != 0;        // some adjacent compass pair agrees
+        };
+        const int xl = x0 + lane;                                              // rx = 1 + lane
+        const bool xok = xl >= 3 && xl < A.w - 3;
+        // every row's flag first (the LDS reads of the nine rows are independent: one round trip), then ONE append per wavefront
+        constexpr int FT_CI = (R1_H + FT_NW - 1) / FT_NW;                   // rows per wavefront
+        uint32_t cm = 0u;
+#pragma unroll
+        for (int it = 0; it < FT_CI; ++it) {
+            const int ry = wv + FT_NW * it, y = y0 - 1 + ry;
+            const bool t = compass(min(ry, R1_H - 1), 1 + lane);
+            if (ry < R1_H && y >= 3 && y < A.h - 3 && xok && t) cm |= 1u << it;
         }
+        const int rry = min(tid >> 1, R1_H - 1), rrx = (tid & 1) ? R1_W - 1 : 0;
+        {
+            const int x = x0 - 1 + rrx, y = y0 - 1 + rry;
+            const bool t = compass(rry, rrx);
+            if (tid < 2 * R1_H && x >= 3 && y >= 3 && x < A.w - 3 && y < A.h - 3 && t) cm |= 1u << FT_CI;
+        }
+        const int cnt = __popc(cm);
+        int incl = cnt;
+#define FS_SCAN(ctrl, rmask) incl += __builtin_amdgcn_update_dpp(0, incl, (ctrl), (rmask), 0xF, false)
+        FS_SCAN(0x111, 0xF); FS_SCAN(0x112, 0xF); FS_SCAN(0x114, 0xF); FS_SCAN(0x118, 0xF); FS_SCAN(0x142, 0xA); FS_SCAN(0x143, 0xC);
+#undef FS_SCAN
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int base = 0;
+        if (lane == 0 && total) base = atomicAdd(&n_cand, total);
+        int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+#pragma unroll
+        for (int it = 0; it < FT_CI; ++it) if ((cm >> it) & 1u) cand[pos++] = (uint16_t)(((wv + FT_NW * it) << 7) | (1 + lane));
+        if ((cm >> FT_CI) & 1u) cand[pos] = (uint16_t)((rry << 7) | rrx);
     }
     __syncthreads();
     const int nc = n_cand;
-    for (int ci = tid; ci < nc; ci += 256) {
+    for (int ci = tid; ci < nc; ci += FT_NT) {
         const int i = cand[ci];
-        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const int ry = i >> 7, rx = i & 127;
         const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
         const int p = *c, hi = p + A.thr, lo = p - A.thr;
+        // the sign bit of (hi - v) / (v - lo) shifted in from the right: two instructions per ring pixel and polarity.  The masks come out
+        // mirrored (ring pixel 0 in bit 15), which a test for ten contiguous bits on a circle does not see
         uint32_t bright = 0, dark = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int v = c[c_circ_dy[k] * FT_LW + c_circ_dx[k]];
-            bright |= (uint32_t)(v > hi) << k;
-            dark |= (uint32_t)(v < lo) << k;
+            bright = __builtin_amdgcn_alignbit(bright, (uint32_t)(hi - v), 31);
+            dark = __builtin_amdgcn_alignbit(dark, (uint32_t)(v - lo), 31);
         }
         if (ring10(bright) || ring10(dark)) {
             const int pos = atomicAdd(&n_list, 1);
@@ -164,9 +236,9 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
     const int n = n_list;
 
     // ---- 2) score in closed form: max over 10-arcs of min(v-p) (bright) / min(p-v) (dark), minus 1
-    for (int li = tid; li < n; li += 256) {
+    for (int li = tid; li < n; li += FT_NT) {
         const int i = list[li];
-        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const int ry = i >> 7, rx = i & 127;
         const uint8_t *c = &tile[ry + FT_Y0 - 1][rx + FT_X0 - 1];
         const int p = *c;
         int d[16];
@@ -192,12 +264,11 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
     // ---- 3) NMS + border + Shi-Tomasi + per-cell winner, in two passes so that the 64-pixel Shi-Tomasi window runs on dense
     //         lanes: 3a (lane = corner) keeps the corners that survive NMS, the InFrame test and the occupied-cell test in an LDS
     //         list; 3b gives every survivor 4 lanes (2 window rows each), sums in exact int32 and reduces inside the quad.
-    const int scale = 1 << A.level;
     if (tid == 0) n_cand = 0;                                   // the candidate list of step 1 is free: reuse it for the survivors
     __syncthreads();
-    for (int li = tid; li < n; li += 256) {
+    for (int li = tid; li < n; li += FT_NT) {
         const int i = list[li];
-        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const int ry = i >> 7, rx = i & 127;
         if (rx < 1 || rx > FT_W || ry < 1 || ry > FT_H) continue;        // ring pixels belong to neighbours
         const int x = x0 - 1 + rx, y = y0 - 1 + ry;
         const int s = sc[ry][rx];
@@ -215,17 +286,17 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
         if (A.dbg_nms) A.dbg_nms[(size_t)slot * npix + (size_t)y * A.w + x] = 1;
         // Frame::InFrame(px,20,L) with level coords divided by 2^L again (Basic/Frame.h:67-71)
         if (!(x >= 20 * scale && x < (A.img_cols - 20) * scale && y >= 20 * scale && y < (A.img_rows - 20) * scale)) continue;
-        const int gy = (y * scale) / A.cell, gx = (x * scale) / A.cell;
+        const int gy = cell_of(y), gx = cell_of(x);
         const int k = gy * A.grid_cols + gx;
         if (k < 0 || k >= A.cells) continue;
-        if (A.occupied[(size_t)slot * A.cells + k]) continue;
+        if (occ_fits ? occ_l[gy - gy0][gx - gx0] : A.occupied[(size_t)slot * A.cells + k]) continue;
         cand[atomicAdd(&n_cand, 1)] = (uint16_t)i;
     }
     __syncthreads();
     const int n_sel = n_cand;
-    for (int t = tid; t < 4 * n_sel; t += 256) {
+    for (int t = tid; t < 4 * n_sel; t += FT_NT) {
         const int i = cand[t >> 2], part = t & 3;
-        const int ry = i / R1_W, rx = i - ry * R1_W;
+        const int ry = i >> 7, rx = i & 127;
         const int x = x0 - 1 + rx, y = y0 - 1 + ry;
         // FeatureDetector::ShiTomasiScore (:467-507) on the LDS tile.  Every partial sum is an integer below 2^24 (|dx| <= 255,
         // 64 terms), so the reference's float accumulation is exact in any order: accumulate in int32, convert once
@@ -256,7 +327,7 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
                                          __fmul_rn(4.0f, __fsub_rn(__fmul_rn(dXX, dYY), __fmul_rn(dXY, dXY))));
             score = __fmul_rn(0.5f, __fsub_rn(tr, ygz_sqrtf_cr(disc)));
         }
-        const int gy = (y * scale) / A.cell, gx = (x * scale) / A.cell;
+        const int gy = cell_of(y), gx = cell_of(x);
         const int k = gy * A.grid_cols + gx;
         const uint32_t visit = ((uint32_t)A.level << 28) | ((uint32_t)y << 14) | (uint32_t)x;
         const bool isnan_ = score != score;
@@ -275,7 +346,7 @@ static __device__ __forceinline__ void fast_select_body(const FastArgs &A, const
 // levels only meet in the per-cell atomicMax, which does not care about order); three launches cost two launch gaps and two tails.
 struct FastArgsAll { FastArgs lv[YGZ_MAX_LEVELS]; int n_levels; int tiles_x[YGZ_MAX_LEVELS]; int tile_end[YGZ_MAX_LEVELS]; };
 
-__global__ __launch_bounds__(256) void k_fast_select(FastArgsAll AA)
+__global__ __launch_bounds__(FT_NT) void k_fast_select(FastArgsAll AA)
 {
     int t_, y_, so_;
     if (!ygz_xcd_remap3(AA.lv[0].n_slots, t_, y_, so_)) return;      // frame pinned to one XCD's L2 (block-uniform)
@@ -334,7 +405,6 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
 #define DP_N   (DP_W * DP_W)
 
 // canonical ORB half-widths umax[|v|] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 } (packed as nibbles in k_describe)
-static __device__ const signed char c_pattern[1024] = { YGZ_ORB_PATTERN_VALUES };
 
 struct DescArgs {
     const uint8_t *lvl[YGZ_MAX_LEVELS];
@@ -393,100 +463,137 @@ __device__ __forceinline__ void ygz_sincos_small(double x, double *sn, double *c
 }
 
 #define DP_P   40          // LDS row pitch of the patch (bytes): rows start dword-aligned
+#define DP_KPW 8           // keypoints per wavefront (0.334 / 0.276 / 0.260 ms per 512 VGA frames with 1 / 4 / 8)
+
+// IC_Angle as byte dot products (round 5).  lane = (row v = lane / 2 - 15, half hh of the row): the 16 bytes of the half row are columns
+// u = -15 .. 0 (hh = 0) or 1 .. 16 (hh = 1).  Table entry of the lane: four dwords |u| of the columns inside the circle (umax[|v|], 0 elsewhere) and
+// four dwords of ones for the same columns: m10 = +- sum |u| I = v_dot4_u32_u8 x 4, the row sum for m01 likewise.  Lanes 62, 63: zero.
+struct DescIcTab { uint32_t v[64][8]; };
+constexpr DescIcTab desc_make_ic()
+{
+    DescIcTab t{};
+    const int umax[16] = { 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3 };
+    for (int l = 0; l < 62; ++l) {
+        const int v = (l >> 1) - 15, hh = l & 1, av = v < 0 ? -v : v, um = umax[av];
+        for (int k = 0; k < 16; ++k) {
+            const int au = hh ? 1 + k : 15 - k;
+            if (au <= um && au <= 15) { t.v[l][k >> 2] |= (uint32_t)au << (8 * (k & 3)); t.v[l][4 + (k >> 2)] |= 1u << (8 * (k & 3)); }
+        }
+    }
+    return t;
+}
+static __device__ const DescIcTab c_desc_ic __attribute__((aligned(16))) = desc_make_ic();
+// the sampling pattern as floats (x0, y0, x1, y1 per bit): one 16-byte load per lane and bit instead of a dword and four byte -> float conversions
+struct DescPatF { float v[1024]; };
+constexpr DescPatF desc_make_patf()
+{
+    const signed char p[1024] = { YGZ_ORB_PATTERN_VALUES };
+    DescPatF t{};
+    for (int i = 0; i < 1024; ++i) t.v[i] = (float)p[i];
+    return t;
+}
+static __device__ const DescPatF c_desc_patf __attribute__((aligned(16))) = desc_make_patf();
+
+// KPW keypoints per wavefront, one after the other (the grid covers every grid cell of every frame and two thirds of them hold no keypoint:
+// fewer, longer workgroups leave fewer empty ones to dispatch)
+template <int KPW>
 __global__ __launch_bounds__(256) void k_describe(DescArgs A)
 {
-    __shared__ uint32_t patch_all[4][DP_W * DP_P / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t patch_all[4][DP_W * DP_P / 4 + 6];
     int bx, so;
     if (!ygz_xcd_remap(A.n_slots, bx, so)) return;
     const int slot = A.slot_begin + so;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int kp = bx * 4 + wv;
-    if (kp >= A.n_kp[slot]) return;                 // wave-uniform
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int nk = A.n_kp[slot];
     uint32_t *patch32 = patch_all[wv];
     const uint8_t *patch = reinterpret_cast<const uint8_t *>(patch32);
-    const size_t o = (size_t)slot * A.cells + kp;
-    const int L = A.kp_level[o];
-    const int w = A.w[L], h = A.h[L];
-    const uint8_t *img = A.lvl[L] + (size_t)slot * w * h;
-    const double sc = (double)(1 << L);
-    // cvRound(pixel / 2^L): round half to even (FeatureDetector.cpp:514,547)
-    const int cx = (int)rint(A.kp_px[2 * o] / sc), cy = (int)rint(A.kp_px[2 * o + 1] / sc);
-    const int n = w * h;
-    // 39 x 39 neighbourhood, linear addressing as center[dy*step+dx] (reads outside the level buffer are 0): 39 rows x 10
-    // dwords, each ONE unaligned dword load (a wave-wide byte gather costs as much as a dword load)
-    // The lane's seven items are requested as ONE batch (14 loads in flight) and written to LDS afterwards: as a rolled loop this
-    // was a chain of seven dependent memory latencies per keypoint, most of the kernel's time.
-    constexpr int DP_ITEMS = DP_W * 10, DP_LN = (DP_ITEMS + 63) / 64;
-    uint32_t w_lo[DP_LN], w_hi[DP_LN], w_sh[DP_LN];
-    bool w_in[DP_LN];
+    // what a lane needs for every keypoint: its entry of the moment table, its four pattern pairs
+    const uint4 ic_w = reinterpret_cast<const uint4 *>(c_desc_ic.v[lane])[0], ic_1 = reinterpret_cast<const uint4 *>(c_desc_ic.v[lane])[1];
+    const float4 *patf = reinterpret_cast<const float4 *>(c_desc_patf.v) + lane;
+    const float4 pt0 = patf[0], pt1 = patf[64], pt2 = patf[128], pt3 = patf[192];
+    for (int it = 0; it < KPW; ++it) {
+        const int kp = (bx * KPW + it) * 4 + wv;
+        if (kp >= nk) return;                       // wave-uniform (kp grows with it)
+        const size_t o = (size_t)slot * A.cells + kp;
+        const int L = A.kp_level[o];
+        const int w = A.w[L], h = A.h[L];
+        const uint8_t *img = A.lvl[L] + (size_t)slot * w * h;
+        // cvRound(pixel / 2^L): round half to even (FeatureDetector.cpp:514,547); the division by a power of two as the exact product with 2^-L
+        const double inv_sc = __hiloint2double((1023 - L) << 20, 0);
+        const int cx = __builtin_amdgcn_readfirstlane((int)rint(A.kp_px[2 * o] * inv_sc)), cy = __builtin_amdgcn_readfirstlane((int)rint(A.kp_px[2 * o + 1] * inv_sc));
+        const int n = w * h;
+        // 39 x 39 neighbourhood, linear addressing as center[dy*step+dx] (reads outside the level buffer are 0), rows of 40 bytes in LDS
+        const int base = (cy - DP_R) * w + (cx - DP_R);
+        if (base >= 0 && base + (DP_W - 1) * w + DP_P <= n) {
+            // the whole window lies inside the level (all but the keypoints next to the first / last rows): lane = (row of eight, 8-byte piece of
+            // five), five passes of eight rows, no per-item bounds, no index division
+            const int rr = lane >> 3, j2 = lane & 7;
+            if (j2 < 5) {
+                const uint8_t *p = img + base + rr * w + 8 * j2;
+                uint32_t lo[5], hi[5];
 #pragma unroll
-    for (int k = 0; k < DP_LN; ++k) {
-        const int item = lane + 64 * k;
-        const int r = item / 10, j = item - 10 * r;
-        const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
-        w_in[k] = item < DP_ITEMS && idx0 >= 0 && idx0 + 4 <= n;
-        w_lo[k] = *(ygz_gptr32u)reinterpret_cast<uintptr_t>(img + (w_in[k] ? idx0 : 0));      // one unaligned dword (rounds 1-3: two aligned loads + v_alignbyte)
-        w_hi[k] = 0u; w_sh[k] = 0u;
-    }
+                for (int ps = 0; ps < 5; ++ps) { lo[ps] = 0u; hi[ps] = 0u; if (ps < 4 || rr < 7) ygz_load8(p + (size_t)(8 * ps) * w, lo[ps], hi[ps]); }
+                uint2 *q = reinterpret_cast<uint2 *>(patch32 + rr * (DP_P / 4) + 2 * j2);
 #pragma unroll
-    for (int k = 0; k < DP_LN; ++k) {
-        const int item = lane + 64 * k;
-        if (item >= DP_ITEMS) continue;
-        uint32_t v = w_lo[k];
-        if (!w_in[k]) {                             // the window leaves the level buffer: byte by byte, zeros outside (rare)
-            const int r = item / 10, j = item - 10 * r;
-            const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
-            v = 0;
-            for (int kk = 0; kk < 4; ++kk) { const int idx = idx0 + kk; if (idx >= 0 && idx < n) v |= (uint32_t)img[idx] << (8 * kk); }
+                for (int ps = 0; ps < 5; ++ps) if (ps < 4 || rr < 7) q[ps * 8 * (DP_P / 8)] = make_uint2(lo[ps], hi[ps]);
+            }
+        } else {
+            // 39 rows x 10 dwords, each ONE unaligned dword load where it lies inside the buffer, byte by byte with zeros outside where it does not
+            constexpr int DP_ITEMS = DP_W * 10, DP_LN = (DP_ITEMS + 63) / 64;
+#pragma unroll 1
+            for (int k = 0; k < DP_LN; ++k) {
+                const int item = lane + 64 * k;
+                if (item >= DP_ITEMS) continue;
+                const int r = item / 10, j = item - 10 * r;
+                const int idx0 = (cy + r - DP_R) * w + (cx - DP_R) + 4 * j;
+                uint32_t v = 0u;
+                if (idx0 >= 0 && idx0 + 4 <= n) v = *(ygz_gptr32u)reinterpret_cast<uintptr_t>(img + idx0);
+                else for (int kk = 0; kk < 4; ++kk) { const int idx = idx0 + kk; if (idx >= 0 && idx < n) v |= (uint32_t)img[idx] << (8 * kk); }
+                patch32[item] = v;                      // item == r * (DP_P / 4) + j
+            }
         }
-        patch32[item] = v;                          // item == r * (DP_P / 4) + j
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    // IC_Angle (:509-537): integer moments over the circular patch.  lane = (row v, half of the row): 4 aligned LDS dwords,
-    // u in [-15, 0] or [1, 15]; half-widths umax[|v|] packed as nibbles {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
-    int m10 = 0, m01 = 0;
-    if (lane < 62) {
-        const int v = (lane >> 1) - 15, hh = lane & 1, av = v < 0 ? -v : v;
-        const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15);
-        const uint32_t *rowp = patch32 + (v + DP_R) * (DP_P / 4) + 1 + 4 * hh;        // column 4 (u = -15) or 20 (u = 1)
-        const uint32_t d[4] = { rowp[0], rowp[1], rowp[2], rowp[3] };
-        const int u0 = hh ? 1 : -15;
-        int srow = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int u = u0 + k, au = u < 0 ? -u : u;
-            const int I = (int)((d[k >> 2] >> (8 * (k & 3))) & 255u);
-            if (au <= um && au <= 15) { m10 += u * I; srow += I; }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // IC_Angle (:509-537): integer moments over the circular patch, lane = (row v, half of the row): 4 LDS dwords against the lane's table entry
+        int m10, m01;
+        {
+            const int v = (lane >> 1) - 15, hh = lane & 1;
+            const uint32_t *rowp = patch32 + (v + DP_R) * (DP_P / 4) + 1 + 4 * hh;        // column 4 (u = -15) or 20 (u = 1)
+            const uint32_t d0 = rowp[0], d1 = rowp[1], d2 = rowp[2], d3 = rowp[3];
+            uint32_t sw = __builtin_amdgcn_udot4(d0, ic_w.x, 0u, false), s1 = __builtin_amdgcn_udot4(d0, ic_1.x, 0u, false);
+            sw = __builtin_amdgcn_udot4(d1, ic_w.y, sw, false); s1 = __builtin_amdgcn_udot4(d1, ic_1.y, s1, false);
+            sw = __builtin_amdgcn_udot4(d2, ic_w.z, sw, false); s1 = __builtin_amdgcn_udot4(d2, ic_1.z, s1, false);
+            sw = __builtin_amdgcn_udot4(d3, ic_w.w, sw, false); s1 = __builtin_amdgcn_udot4(d3, ic_1.w, s1, false);
+            m10 = hh ? (int)sw : -(int)sw;
+            m01 = v * (int)s1;
         }
-        m01 = v * srow;
-    }
-    m10 = ygz_wave_sum_i(m10); m01 = ygz_wave_sum_i(m01);
-    const float angle = A.given_angle ? A.kp_angle[o] : fast_atan2_deg((float)m01, (float)m10);
-    // ComputeOrbDescriptor (:539-578)
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float ang = __fmul_rn(angle, factorPI);
-    double sn, cs;
-    ygz_sincos_small((double)ang, &sn, &cs);
-    const float a = (float)cs, b = (float)sn;
-    unsigned long long bits[4];
+        m10 = ygz_wave_sum_i(m10); m01 = ygz_wave_sum_i(m01);
+        const float angle = A.given_angle ? A.kp_angle[o] : fast_atan2_deg((float)m01, (float)m10);
+        // ComputeOrbDescriptor (:539-578)
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float ang = __fmul_rn(angle, factorPI);
+        double sn, cs;
+        ygz_sincos_small((double)ang, &sn, &cs);
+        const float a = (float)cs, b = (float)sn;
+        unsigned long long bits[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const signed char *pt = &c_pattern[4 * (64 * j + lane)];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int t0 = patch[(dy0 + DP_R) * DP_P + dx0 + DP_R];
-        const int t1 = patch[(dy1 + DP_R) * DP_P + dx1 + DP_R];
-        bits[j] = __ballot(t0 < t1);
-    }
-    if (lane == 0) {
-        A.kp_angle[o] = angle;
-        uint4 *d = reinterpret_cast<uint4 *>(A.kp_desc + 8 * o);
-        d[0] = make_uint4((uint32_t)bits[0], (uint32_t)(bits[0] >> 32), (uint32_t)bits[1], (uint32_t)(bits[1] >> 32));
-        d[1] = make_uint4((uint32_t)bits[2], (uint32_t)(bits[2] >> 32), (uint32_t)bits[3], (uint32_t)(bits[3] >> 32));
+        for (int j = 0; j < 4; ++j) {
+            const float4 pt = j == 0 ? pt0 : j == 1 ? pt1 : j == 2 ? pt2 : pt3;
+            const int dx0 = __float2int_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+            const int dy0 = __float2int_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+            const int dx1 = __float2int_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+            const int dy1 = __float2int_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+            const int t0 = patch[(dy0 + DP_R) * DP_P + dx0 + DP_R];
+            const int t1 = patch[(dy1 + DP_R) * DP_P + dx1 + DP_R];
+            bits[j] = __ballot(t0 < t1);
+        }
+        if (lane == 0) {
+            A.kp_angle[o] = angle;
+            uint4 *d = reinterpret_cast<uint4 *>(A.kp_desc + 8 * o);
+            d[0] = make_uint4((uint32_t)bits[0], (uint32_t)(bits[0] >> 32), (uint32_t)bits[1], (uint32_t)(bits[1] >> 32));
+            d[1] = make_uint4((uint32_t)bits[2], (uint32_t)(bits[2] >> 32), (uint32_t)bits[3], (uint32_t)(bits[3] >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();            // the next keypoint's rows overwrite the patch: after every lane has read its bytes
     }
 }
 
@@ -525,6 +632,7 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
         A.thr = ctx->prm.fast_threshold; A.tie = ctx->prm.nms_tie_suppress;
         A.img_cols = ctx->lw[0]; A.img_rows = ctx->lh[0];
         A.cell = ctx->prm.cell_size; A.grid_cols = ctx->grid_cols; A.cells = ctx->cells;
+        A.cell_magic = ctx->prm.cell_size >= 2 ? (uint32_t)((((unsigned long long)1 << 32) + (unsigned)ctx->prm.cell_size - 1) / (unsigned)ctx->prm.cell_size) : 0u;
         A.cell_first = ctx->cell_first; A.cell_best = ctx->cell_best; A.occupied = ctx->occupied;
         A.dbg_score = ctx->prm.debug_maps ? ctx->dbg_score[L] : nullptr;
         A.dbg_nms = ctx->prm.debug_maps ? ctx->dbg_nms[L] : nullptr;
@@ -538,7 +646,7 @@ int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots)
         AA.tile_end[L] = tiles;
     }
     for (int L = ctx->prm.pyramid_levels; L < YGZ_MAX_LEVELS; ++L) { AA.lv[L] = AA.lv[0]; AA.tiles_x[L] = 1; AA.tile_end[L] = tiles; }
-    YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(tiles, 1, ygz_round_up8(n_slots)), dim3(256), AA);
+    YGZ_LAUNCH(ctx, KID_FAST_SELECT, k_fast_select, dim3(tiles, 1, ygz_round_up8(n_slots)), dim3(FT_NT), AA);
     YGZ_LAUNCH(ctx, KID_COMPACT, k_compact, dim3(n_slots), dim3(1024), ctx->cell_first, ctx->cell_best, ctx->cells,
                        ctx->kp_px, ctx->kp_level, ctx->kp_score, ctx->n_kp, slot_begin);
     YGZ_HIPCHK(ctx, hipGetLastError());
@@ -572,7 +680,9 @@ static int launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int gi
     D.n_levels = ctx->prm.pyramid_levels; D.cells = ctx->cells;
     D.kp_px = ctx->kp_px; D.kp_level = ctx->kp_level; D.n_kp = ctx->n_kp;
     D.kp_angle = ctx->kp_angle; D.kp_desc = ctx->kp_desc; D.slot_begin = slot_begin; D.n_slots = n_slots; D.given_angle = given_angle;
-    YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_slots)), dim3(256), D);
+    // batches: DP_KPW keypoints per wavefront; a few frames (the single-frame calls): one each, the launch is latency, not throughput
+    if (n_slots >= 16) YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe<DP_KPW>, dim3(ygz_div_up(ctx->cells, 4 * DP_KPW), ygz_round_up8(n_slots)), dim3(256), D);
+    else YGZ_LAUNCH(ctx, KID_DESCRIBE, k_describe<1>, dim3(ygz_div_up(ctx->cells, 4), ygz_round_up8(n_slots)), dim3(256), D);
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
