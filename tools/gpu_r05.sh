@@ -137,4 +137,13 @@ n)  # extraction kernels with less index arithmetic: k_describe (scalar keypoint
     timeout 300 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; python -c "
 import json; d=json.load(open('$OUT/surface.json'))['surface']; d.pop('what'); print(json.dumps(d))"
     ;;
+o)  # BA linearise / pose-only BA with one division per edge (reciprocal products): the whole GPU suite, stage times, step, surface, offline
+    timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed" $OUT/pytest.log | tail -2
+    python tools/stage_bench.py ba --batch 512 --reps 5 --probe k_ba_points 2>&1 | tail -2
+    benchline step python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras
+    benchline off1024 $OFF --frames 1024
+    benchline off128 $OFF --frames 128
+    timeout 300 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; python -c "
+import json; d=json.load(open('$OUT/surface.json'))['surface']; d.pop('what'); print(json.dumps(d))"
+    ;;
 esac

@@ -111,12 +111,16 @@ __device__ __forceinline__ void ba_pose_prep_one(const BaDev &B, int k)
     quat_to_R_d(T.q, o + 7);
 }
 
+// Divisions (round 5): an edge divides by its camera depth ONCE (zi = 1 / z, IEEE); the quotients x / z, y / z, 1 / z, . / z^2 of the reference's
+// expressions (G2oTypes.h:119-144) are products with zi.  A quotient differs from the reference's by at most one more rounding (1e-16 relative;
+// the path's bar is 1e-5, the tests hold 1e-9) -- an FP64 division is ~28 instructions at half rate, and the two passes over an edge
+// (point blocks, pose blocks) held sixteen of them.
 // pd = the prepared pose (q, t, R, J_l), read only by formulation 2
-__device__ __forceinline__ void ba_pose_jac(int formulation, double x, double y, double z, double fx, double fy,
+__device__ __forceinline__ void ba_pose_jac(int formulation, double x, double y, double z, double zi, double fx, double fy,
                                             const double *__restrict__ pd, double Jx[12])
 {
     if (formulation == 2) {          // d r / d [t; aa] of the ceres functor: [-A, A [R p]x J_l]
-        const double zi = 1. / z, xz = x * zi * zi, yz = y * zi * zi;
+        const double xz = x * zi * zi, yz = y * zi * zi;
         const double a = x - pd[4], b = y - pd[5], c = z - pd[6];           // R p_w = p_c - t
         const double *Jl = pd + 16;
         double M[9];                                                         // [R p]x J_l
@@ -129,13 +133,13 @@ __device__ __forceinline__ void ba_pose_jac(int formulation, double x, double y,
         Jx[6] = 0.0; Jx[7] = -zi; Jx[8] = yz;
         for (int j = 0; j < 3; ++j) { Jx[3 + j] = zi * M[j] - xz * M[6 + j]; Jx[9 + j] = zi * M[3 + j] - yz * M[6 + j]; }
     } else if (formulation == 0) {          // G2oTypes.h:119-131, columns [rot(3), trans(3)]
-        const double z_2 = z * z;
-        Jx[0] = x * y / z_2 * fx;          Jx[1] = -(1 + (x * x / z_2)) * fx;  Jx[2] = y / z * fx;
-        Jx[3] = -1. / z * fx;              Jx[4] = 0;                          Jx[5] = x / z_2 * fx;
-        Jx[6] = (1 + y * y / z_2) * fy;    Jx[7] = -x * y / z_2 * fy;          Jx[8] = -x / z * fy;
-        Jx[9] = 0;                         Jx[10] = -1. / z * fy;              Jx[11] = y / z_2 * fy;
+        const double zi2 = zi * zi, xz = x * zi, yz = y * zi;
+        Jx[0] = x * y * zi2 * fx;          Jx[1] = -(1 + (x * x * zi2)) * fx;  Jx[2] = yz * fx;
+        Jx[3] = -zi * fx;                  Jx[4] = 0;                          Jx[5] = x * zi2 * fx;
+        Jx[6] = (1 + y * y * zi2) * fy;    Jx[7] = -x * y * zi2 * fy;          Jx[8] = -xz * fy;
+        Jx[9] = 0;                         Jx[10] = -zi * fy;                  Jx[11] = y * zi2 * fy;
     } else {                         // g2o_types.h:72-84 (== cvutils::JacobXYZ2Cam), columns [trans, rot]
-        const double z_inv = 1. / z, z_inv_2 = z_inv * z_inv;
+        const double z_inv = zi, z_inv_2 = z_inv * z_inv;
         Jx[0] = -z_inv;  Jx[1] = 0.0;     Jx[2] = x * z_inv_2;  Jx[3] = y * Jx[2];
         Jx[4] = -(1.0 + x * Jx[2]);       Jx[5] = y * z_inv;
         Jx[6] = 0.0;     Jx[7] = -z_inv;  Jx[8] = y * z_inv_2;  Jx[9] = 1.0 + y * Jx[8];
@@ -144,9 +148,9 @@ __device__ __forceinline__ void ba_pose_jac(int formulation, double x, double y,
 }
 
 
-// camera-frame point of map point pt seen from prepared pose pd, and the residual against obs (computeError)
-__device__ __forceinline__ void ba_project(const BaDev &B, const double *__restrict__ pd, const double pt[3], double ox, double oy,
-                                           double p[3], double r[2])
+// camera-frame point of map point pt seen from prepared pose pd, the reciprocal of its depth, and the residual against obs (computeError)
+__device__ __forceinline__ double ba_project_zi(const BaDev &B, const double *__restrict__ pd, const double pt[3], double ox, double oy,
+                                                double p[3], double r[2])
 {
     const double *R = pd + 7;
     if (B.formulation == 2) {
@@ -156,15 +160,20 @@ __device__ __forceinline__ void ba_project(const BaDev &B, const double *__restr
         quat_rotate_d(q, pt, p);
     }
     p[0] += pd[4]; p[1] += pd[5]; p[2] += pd[6];
+    const double zi = 1.0 / p[2];
     if (B.formulation == 0) {
-        const double proj0 = p[0] / p[2], proj1 = p[1] / p[2];             // camProject, G2oTypes.h:134-144
+        const double proj0 = p[0] * zi, proj1 = p[1] * zi;                 // camProject, G2oTypes.h:134-144
         r[0] = ox - (proj0 * B.fx + B.cx);
         r[1] = oy - (proj1 * B.fy + B.cy);
     } else {                                                               // formulations 1 and 2 share the residual
-        r[0] = ox - p[0] / p[2];
-        r[1] = oy - p[1] / p[2];
+        r[0] = ox - p[0] * zi;
+        r[1] = oy - p[1] * zi;
     }
+    return zi;
 }
+__device__ __forceinline__ void ba_project(const BaDev &B, const double *__restrict__ pd, const double pt[3], double ox, double oy,
+                                           double p[3], double r[2])
+{ (void)ba_project_zi(B, pd, pt, ox, oy, p, r); }
 
 // RobustKernelHuber::robustify == ceres::HuberLoss + Corrector
 __device__ __forceinline__ void ba_robust(double e2, double hub, double *rho0, double *rho1)
@@ -214,16 +223,16 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
         const double *pd = B.posed + BA_POSED * (size_t)ip;
         const double *R = pd + 7;
         double p[3], r[2], Jp[6];
-        ba_project(B, pd, pt, ox, oy, p, r);
+        const double zi = ba_project_zi(B, pd, pt, ox, oy, p, r);
         const double x = p[0], y = p[1], z = p[2];
         if (B.formulation == 0) {
-            const double tmp[6] = { B.fx, 0, -x / z * B.fx, 0, B.fy, -y / z * B.fy };
+            const double tmp[6] = { B.fx, 0, -(x * zi) * B.fx, 0, B.fy, -(y * zi) * B.fy };
             double s[6];
-            for (int i = 0; i < 6; ++i) s[i] = -1. / z * tmp[i];
+            for (int i = 0; i < 6; ++i) s[i] = -zi * tmp[i];
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b)
                 Jp[3 * a + b] = s[3 * a] * R[b] + s[3 * a + 1] * R[3 + b] + s[3 * a + 2] * R[6 + b];
         } else {                                                             // formulations 1 and 2 share the point Jacobian
-            const double z_inv = 1. / z, z_inv_2 = z_inv * z_inv;
+            const double z_inv = zi, z_inv_2 = z_inv * z_inv;
             const double tmp[6] = { z_inv, 0, -x * z_inv_2, 0, z_inv, -y * z_inv_2 };
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b)
                 Jp[3 * a + b] = -tmp[3 * a] * R[b] + -tmp[3 * a + 1] * R[3 + b] + -tmp[3 * a + 2] * R[6 + b];
@@ -247,7 +256,7 @@ __device__ __forceinline__ double ba_point_edges(const BaDev &B, int il)
         if (B.fixed[ip]) { for (int i = 0; i < 18; ++i) BA_EC(B.Hpl_c, row, 18, i, lane) = 0.0; }
         else {
             double Jx[12];
-            ba_pose_jac(B.formulation, x, y, z, B.fx, B.fy, pd, Jx);
+            ba_pose_jac(B.formulation, x, y, z, zi, B.fx, B.fy, pd, Jx);
             for (int a = 0; a < 6; ++a) for (int b = 0; b < 3; ++b)
                 BA_ST(&BA_EC(B.Hpl_c, row, 18, 3 * a + b, lane), rho1 * (Jx[a] * Jp[b] + Jx[6 + a] * Jp[3 + b]));
         }
@@ -273,9 +282,9 @@ __device__ __forceinline__ void ba_pose_contrib(const BaDev &B, int il, int a, d
         const int row = row0 + c;
         if (!B.enable_c[(size_t)row * 64 + lane]) continue;
         double p[3], r[2], rho0, rho1, Jx[12];
-        ba_project(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
+        const double zi = ba_project_zi(B, pd, pt, BA_EC(B.obs_c, row, 2, 0, lane), BA_EC(B.obs_c, row, 2, 1, lane), p, r);
         ba_robust(r[0] * r[0] + r[1] * r[1], B.huber_c[(size_t)row * 64 + lane], &rho0, &rho1);
-        ba_pose_jac(B.formulation, p[0], p[1], p[2], B.fx, B.fy, pd, Jx);
+        ba_pose_jac(B.formulation, p[0], p[1], p[2], zi, B.fx, B.fy, pd, Jx);
         int q = 0;
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
