@@ -13,6 +13,7 @@
 //   one lane of wave 1 solves the 6x6 LDLT and forms T * exp(-x) meanwhile; lane 0 takes the accept / stop decision.
 // No host round trip per iteration (the reference solves ~30 6x6 systems per frame pair).
 #include "ygz_internal.h"
+#include <algorithm>
 #include <cstring>
 #include "se3_dev.h"
 #include "ldlt6.h"
@@ -72,13 +73,36 @@ __device__ __forceinline__ void sa_chain_term(uint32_t xb, int E, int &t0, int &
     t1 += (int)a + (up | (tie & ((1 + t1 + (int)a) & 1)));
 }
 
-// accessors of the per-iteration scratch: the first LC features in LDS, the rest in the global arrays (features beyond the LDS capacity:
-// 720p and larger grids)
-#define SA_R2(q_, f_) (*((f_) < LC ? l_r2 + (size_t)(q_) * LC + (f_) : reinterpret_cast<float4 *>(r2) + (size_t)(q_) * A.cells + (f_)))
-#define SA_FMAP(f_) (*((f_) < LC ? l_fmap + (f_) : fmap + (f_)))
-#define SA_PMAP(f_) (*((f_) < LC ? l_pmap + (f_) : pmap + (f_)))
-#define SA_PRE(f_) (*((f_) < LC ? l_pre + (f_) : pre + (f_)))
-#define SA_CTOT(c_) (*((c_) * 64 < LC ? l_ctot + (c_) : ctot + (c_)))
+// The per-iteration scratch of a feature lives in LDS (the first LC features; the reference patch of the first PC) or in the pair's global work
+// arrays (features beyond: 720p and larger grids).  LC and PC are multiples of 64 and a wavefront always handles 64 consecutive features, so the
+// choice is wave-uniform: a BRANCH with a pure LDS path (ds_read / ds_write) and a pure global path.  Round 4 selected the POINTER per lane
+// ((f < LC ? lds : global)[..]), which makes every access a flat instruction -- a flat load from LDS takes several times a ds_read, and the
+// chain walk, which waits for six of them per chunk of 64 features, spent 36 of the 85 thousand cycles of a Gauss-Newton iteration there.
+// (explicit address spaces: with generic pointers the compiler folds the two paths back into one flat access of a selected pointer)
+typedef float sa_v4f __attribute__((ext_vector_type(4)));
+typedef int sa_v4i __attribute__((ext_vector_type(4)));
+typedef int sa_v2i __attribute__((ext_vector_type(2)));
+#define SA_LDS(T, p) ((__attribute__((address_space(3))) T *)(p))
+#define SA_GLB(T, p) ((__attribute__((address_space(1))) T *)(p))
+#define SA_F4(v) make_float4((v).x, (v).y, (v).z, (v).w)
+#define SA_V4(v) ((sa_v4f){ (v).x, (v).y, (v).z, (v).w })
+__device__ __forceinline__ void sa_ld4(bool in_lds, const float4 *lp, size_t ls, const float4 *gp, size_t gs, float4 v[4])
+{
+    sa_v4f t0, t1, t2, t3;
+    if (in_lds) { const __attribute__((address_space(3))) sa_v4f *q = SA_LDS(const sa_v4f, lp); t0 = *q; t1 = *(q + ls); t2 = *(q + 2 * ls); t3 = *(q + 3 * ls); }
+    else { const __attribute__((address_space(1))) sa_v4f *q = SA_GLB(const sa_v4f, gp); t0 = *q; t1 = *(q + gs); t2 = *(q + 2 * gs); t3 = *(q + 3 * gs); }
+    v[0] = SA_F4(t0); v[1] = SA_F4(t1); v[2] = SA_F4(t2); v[3] = SA_F4(t3);
+}
+__device__ __forceinline__ void sa_st4(bool in_lds, float4 *lp, size_t ls, float4 *gp, size_t gs, const float4 v[4])
+{
+    const sa_v4f t0 = SA_V4(v[0]), t1 = SA_V4(v[1]), t2 = SA_V4(v[2]), t3 = SA_V4(v[3]);
+    if (in_lds) { __attribute__((address_space(3))) sa_v4f *q = SA_LDS(sa_v4f, lp); *q = t0; *(q + ls) = t1; *(q + 2 * ls) = t2; *(q + 3 * ls) = t3; }
+    else { __attribute__((address_space(1))) sa_v4f *q = SA_GLB(sa_v4f, gp); *q = t0; *(q + gs) = t1; *(q + 2 * gs) = t2; *(q + 3 * gs) = t3; }
+}
+#define SA_R2_LD(in_, f_, v_) sa_ld4((in_), l_r2 + (f_), (size_t)LC, reinterpret_cast<const float4 *>(r2) + (f_), (size_t)A.cells, (v_))
+#define SA_R2_ST(in_, f_, v_) sa_st4((in_), l_r2 + (f_), (size_t)LC, reinterpret_cast<float4 *>(r2) + (f_), (size_t)A.cells, (v_))
+#define SA_PATCH_LD(in_, f_, v_) sa_ld4((in_), l_patch + (f_), (size_t)PC, reinterpret_cast<const float4 *>(patch_g) + 4 * (size_t)(f_), (size_t)1, (v_))
+#define SA_PATCH_ST(in_, f_, v_) sa_st4((in_), l_patch + (f_), (size_t)PC, reinterpret_cast<float4 *>(patch_g) + 4 * (size_t)(f_), (size_t)1, (v_))
 #ifdef YGZ_SA_TIMERS
 #define SA_PHASE(k) do { if (tid == 0) { const long long tn_ = clock64(); tph[k] += tn_ - tlast; tlast = tn_; } } while (0)
 #define SA_COUNT(k, v) do { if (tid == 0) tph[k] += (v); } while (0)
@@ -217,8 +241,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
     float *dxy = (float *)((double *)wk + 33 * (size_t)A.cells);       // [cells][32] dx[16], dy[16]
     float *patch_g = (float *)((double *)wk + 96 * (size_t)A.cells);    // [cells][16] reference patches of the features beyond pcap
     float *r2 = patch_g + 16 * (size_t)A.cells;                         // the per-iteration scratch of the features beyond lcap: see the first form
-    float *ctot = r2 + 16 * (size_t)A.cells;
-    float *pre = ctot + A.cells;
+    float *pre = r2 + 16 * (size_t)A.cells + A.cells;                    // (the chunk totals of the first form lay in between)
     int4 *fmap = reinterpret_cast<int4 *>(pre + A.cells);
     int2 *pmap = reinterpret_cast<int2 *>(fmap + A.cells);
     uint8_t *flags = (uint8_t *)(pmap + A.cells);                       // [cells] bit 0: visible (visible_fts_, never reset: :35), bit 1: part of the running H
@@ -228,9 +251,8 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
     int4 *const l_fmap = reinterpret_cast<int4 *>(l_r2 + 4 * (size_t)LC);                  // [LC]
     int2 *const l_pmap = reinterpret_cast<int2 *>(l_fmap + LC);                            // [LC]
     float *const l_pre = reinterpret_cast<float *>(l_pmap + LC);                           // [LC]
-    float *const l_ctot = l_pre + LC;                                                      // [LC / 64 + 1]
-    float4 *const l_patch = reinterpret_cast<float4 *>(sa_dyn + (((size_t)LC * 92 + (size_t)(LC / 64 + 1) * 4 + 15) & ~(size_t)15));   // [4][PC]
-#define SA_PATCH(q_, f_) (*((f_) < PC ? l_patch + (size_t)(q_) * PC + (f_) : reinterpret_cast<float4 *>(patch_g) + 4 * (size_t)(f_) + (q_)))
+    float *const l_ctot = l_pre + LC;                                                      // [chunks + 1]: the totals of EVERY chunk of 64 features (lanes of one wavefront read across the tiers)
+    float4 *const l_patch = reinterpret_cast<float4 *>(sa_dyn + (((size_t)LC * 92 + (size_t)((A.cells + 63) / 64 + 1) * 4 + 15) & ~(size_t)15));   // [4][PC]
     Se3 T_ref;
     for (int k = 0; k < 4; ++k) T_ref.q[k] = A.pair_T[14 * (size_t)pair + k];
     for (int k = 0; k < 3; ++k) T_ref.t[k] = A.pair_T[14 * (size_t)pair + 4 + k];
@@ -251,7 +273,8 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
     }
     for (int f = tid; f < n; f += SA_THREADS) {          // a lane only ever touches the flags, patches and gradients of its own features
         flags[f] = 0;
-        for (int q4 = 0; q4 < 4; ++q4) SA_PATCH(q4, f) = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 z4[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f) };
+        SA_PATCH_ST((f & ~63) < PC, f, z4);
     }
     __syncthreads();
 
@@ -281,6 +304,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
 #pragma unroll 1
                 for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {
                     const int f = f0_ + tid;
+                    const bool in_l = f0_ + 64 * wv < LC, in_p = f0_ + 64 * wv < PC;      // wave-uniform
                     float sq = 0.f;
                     if (f < n) {
                         const uint8_t fl0 = flags[f], hm = has_mp[f];
@@ -316,13 +340,16 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                                 }
                             }
 #undef W
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) SA_PATCH(k, f) = make_float4(pv[4 * k], pv[4 * k + 1], pv[4 * k + 2], pv[4 * k + 3]);
+                            const float4 p4[4] = { make_float4(pv[0], pv[1], pv[2], pv[3]), make_float4(pv[4], pv[5], pv[6], pv[7]),
+                                                   make_float4(pv[8], pv[9], pv[10], pv[11]), make_float4(pv[12], pv[13], pv[14], pv[15]) };
+                            SA_PATCH_ST(in_p, f, p4);
                         } else if (fl0 & 1) {
                             // visible from a coarser level (visible_fts_ is never reset, :35): the residual pass still visits it with the
                             // patch of that level and the zero columns setZero() left
+                            float4 c4[4];
+                            SA_PATCH_LD(in_p, f, c4);
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) { const float4 c = SA_PATCH(k, f); pv[4 * k] = c.x; pv[4 * k + 1] = c.y; pv[4 * k + 2] = c.z; pv[4 * k + 3] = c.w; }
+                            for (int k = 0; k < 4; ++k) { pv[4 * k] = c4[k].x; pv[4 * k + 1] = c4[k].y; pv[4 * k + 2] = c4[k].z; pv[4 * k + 3] = c4[k].w; }
                         }
                         if (vis) {
                             float4 *o4 = reinterpret_cast<float4 *>(dxy + 32 * (size_t)f);
@@ -338,8 +365,9 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         float xs[16];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
+                        const float4 x4[4] = { make_float4(xs[0], xs[1], xs[2], xs[3]), make_float4(xs[4], xs[5], xs[6], xs[7]),
+                                               make_float4(xs[8], xs[9], xs[10], xs[11]), make_float4(xs[12], xs[13], xs[14], xs[15]) };
+                        SA_R2_ST(in_l, f, x4);
                         flags[f] = (uint8_t)((vis ? 1 : 0) | (use ? 2 : 0) | (use && refill ? 12 : 0));
                         if (use) {
                             my_meas += 16;
@@ -350,8 +378,8 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         }
                     }
                     const float incl = ygz_wave_scan_f(sq);
-                    if (f < n) SA_PRE(f) = incl - sq;
-                    if (lane == 63) SA_CTOT(f >> 6) = incl;
+                    if (f < n) { if (in_l) *SA_LDS(float, l_pre + f) = incl - sq; else *SA_GLB(float, pre + f) = incl - sq; }
+                    if (lane == 63) l_ctot[f >> 6] = incl;
                 }
             } else {
                 // ---- computeResiduals(model, linearize=true) (:124-223) of a later iteration: everything that does not depend on the
@@ -359,11 +387,14 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
 #pragma unroll 1
                 for (int f0_ = 0; f0_ < n; f0_ += SA_THREADS) {
                     const int f = f0_ + tid;
+                    const bool in_l = f0_ + 64 * wv < LC, in_p = f0_ + 64 * wv < PC;      // wave-uniform
                     float sq = 0.f;
                     if (f < n) {
                         const uint8_t fl0 = flags[f];
                         const double xr = xy[2 * f], yr = xy[2 * f + 1], dep = depth[f];
-                        const float4 c0 = SA_PATCH(0, f), c1 = SA_PATCH(1, f), c2 = SA_PATCH(2, f), c3 = SA_PATCH(3, f);
+                        float4 c4[4];
+                        SA_PATCH_LD(in_p, f, c4);
+                        const float4 c0 = c4[0], c1 = c4[1], c2 = c4[2], c3 = c4[3];
                         const float4 *gp = reinterpret_cast<const float4 *>(dxy + 32 * (size_t)f);
                         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0, g3 = g0, g4 = g0, g5 = g0, g6 = g0, g7 = g0;
                         if (fl0 & 1) { g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; g3 = gp[3]; g4 = gp[4]; g5 = gp[5]; g6 = gp[6]; g7 = gp[7]; }
@@ -376,8 +407,9 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         float xs[16];
 #pragma unroll
                         for (int k = 0; k < 16; ++k) { xs[k] = __fmul_rn(__fmul_rn(res[k], res[k]), 1.0f); sq += xs[k]; }      // res*res*weight (:213)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) SA_R2(k, f) = make_float4(xs[4 * k], xs[4 * k + 1], xs[4 * k + 2], xs[4 * k + 3]);
+                        const float4 x4[4] = { make_float4(xs[0], xs[1], xs[2], xs[3]), make_float4(xs[4], xs[5], xs[6], xs[7]),
+                                               make_float4(xs[8], xs[9], xs[10], xs[11]), make_float4(xs[12], xs[13], xs[14], xs[15]) };
+                        SA_R2_ST(in_l, f, x4);
                         const bool pu = (fl0 & 2) != 0;
                         if (use != pu) {                                     // rare: H changes by +-(the feature's block), added in the second loop below
                             flags[f] = (uint8_t)((fl0 & 1) | (use ? 2 : 0) | 4 | (use ? 8 : 0));
@@ -393,10 +425,11 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         }
                     }
                     const float incl = ygz_wave_scan_f(sq);
-                    if (f < n) SA_PRE(f) = incl - sq;
-                    if (lane == 63) SA_CTOT(f >> 6) = incl;
+                    if (f < n) { if (in_l) *SA_LDS(float, l_pre + f) = incl - sq; else *SA_GLB(float, pre + f) = incl - sq; }
+                    if (lane == 63) l_ctot[f >> 6] = incl;
                 }
             }
+            SA_PHASE(8);      // feature loop
             if (__ballot(any_chg) != 0ull) {                        // wave-uniform skip: no feature of this wavefront changed state
 #pragma unroll 1
                 for (int c = 0; c * SA_THREADS < n; ++c) {
@@ -417,16 +450,34 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                     for (int k = 0; k < 21; ++k) acc[k] += add ? hf[k] : -hf[k];
                 }
             }
+            SA_PHASE(9);      // enter / leave blocks
+            // the 27 wavefront sums, stage by stage over ALL values (27 independent chains per stage instead of 27 sums one after the other, each a
+            // chain of dependent FP64 adds: 6.2 of the 85 thousand cycles of an iteration).  Same additions in the same order as ygz_wave_sum_d --
+            // inside the rows of 16, then ((r0 + r1) + r2) + r3 -- the last three through row broadcasts into rows 1, 2, 3 (disabled rows add -0.0):
+            // lanes 48..63 end up with the totals
+            {
+#define SA_SUM_STAGE(ctrl, rmask)                                                                                                       \
+                _Pragma("unroll") for (int k = 0; k < 27; ++k) {                                                                        \
+                    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(acc[k]), (ctrl), (rmask), 0xF, false);                 \
+                    const int hi_ = __builtin_amdgcn_update_dpp((int)0x80000000, __double2hiint(acc[k]), (ctrl), (rmask), 0xF, false);   \
+                    acc[k] += __hiloint2double(hi_, lo_); }
+                SA_SUM_STAGE(0xB1, 0xF) SA_SUM_STAGE(0x4E, 0xF) SA_SUM_STAGE(0x141, 0xF) SA_SUM_STAGE(0x140, 0xF)
+                SA_SUM_STAGE(0x142, 0x2) SA_SUM_STAGE(0x143, 0x4) SA_SUM_STAGE(0x142, 0x8)
+#undef SA_SUM_STAGE
+                if (lane == 63) {
 #pragma unroll
-            for (int k = 0; k < 27; ++k) { const double sum = wave_sum_d(acc[k]); if (lane == 0) red[wv][k] = sum; }
+                    for (int k = 0; k < 27; ++k) red[wv][k] = acc[k];
+                }
+            }
             {
                 int m = my_meas;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) m += __shfl_xor(m, off);
                 if (lane == 0) s_nmeas_w[wv] = m;
             }
+            SA_PHASE(10);     // wave sums
             __syncthreads();
-            SA_PHASE(1);      // residual pass
+            SA_PHASE(1);      // barrier behind the residual pass
             // ---- chain, step 1 (all lanes, lane = feature, wavefront = chunk of 64): the 16-term map of every feature for its
             // predicted binade, then a SEGMENTED scan of the maps along the chunk (see the first form).  The map itself comes from
             // the float adder: starting at 2^E (m even) and at 2^E + ulp (m odd), 16 round-to-nearest-even adds ARE the increments
@@ -436,14 +487,19 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                 const int chunk = (f0_ >> 6) + wv;
                 if (64 * chunk >= n) continue;                                // wave-uniform
                 const int f = f0_ + tid, cnt = min(64, n - 64 * chunk);
+                const bool in_l = 64 * chunk < LC;                             // wave-uniform
                 float part = 0.f;
-                for (int c2 = lane; c2 < chunk; c2 += 64) part += SA_CTOT(c2);
+                for (int c2 = lane; c2 < chunk; c2 += 64) part += l_ctot[c2];
                 const float base = ygz_wave_sum_f(part);
                 int t0 = 0, t1 = 0, bad = 0, E = 0;
                 if (f < n) {
-                    const float4 a0 = SA_R2(0, f), a1 = SA_R2(1, f), a2 = SA_R2(2, f), a3 = SA_R2(3, f);
+                    float4 a4[4];
+                    SA_R2_LD(in_l, f, a4);
+                    const float4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
                     const float x[16] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
-                    E = (int)(__float_as_uint(base + SA_PRE(f)) >> 23);
+                    float pre_f;
+                    if (in_l) pre_f = *SA_LDS(float, l_pre + f); else pre_f = *SA_GLB(float, pre + f);
+                    E = (int)(__float_as_uint(base + pre_f) >> 23);
                     bad = !(E > 0 && E < 255);
                     const uint32_t e0 = (uint32_t)E << 23;
                     float ce = __uint_as_float(e0), co = __uint_as_float(e0 | 1u);
@@ -469,7 +525,11 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                 SA_SCAN(0x142, 0xA, (lane & 16) != 0)                          // row_bcast:15 -> rows 1, 3
                 SA_SCAN(0x143, 0xC, lane >= 32)                                // row_bcast:31 -> rows 2, 3
 #undef SA_SCAN
-                if (f < n) { SA_FMAP(f) = make_int4(t0, t1, E, bad | (head << 1)); SA_PMAP(f) = make_int2(p0, p1); }
+                if (f < n) {
+                    const sa_v4i fm = { t0, t1, E, bad | (head << 1) }; const sa_v2i pm = { p0, p1 };
+                    if (in_l) { *SA_LDS(sa_v4i, l_fmap + f) = fm; *SA_LDS(sa_v2i, l_pmap + f) = pm; }
+                    else { *SA_GLB(sa_v4i, fmap + f) = fm; *SA_GLB(sa_v2i, pmap + f) = pm; }
+                }
             }
             __syncthreads();
             SA_PHASE(13);     // maps + scan
@@ -480,7 +540,12 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                 float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: chunk j + 1 is in flight
                 int4 nm = make_int4(0, 0, 0, 0); int2 np = make_int2(0, 0);
                 if (lane < n) {
-                    n0 = SA_R2(0, lane); n1 = SA_R2(1, lane); n2 = SA_R2(2, lane); n3 = SA_R2(3, lane); nm = SA_FMAP(lane); np = SA_PMAP(lane);
+                    float4 v4[4];
+                    SA_R2_LD(0 < LC, lane, v4);
+                    n0 = v4[0]; n1 = v4[1]; n2 = v4[2]; n3 = v4[3];
+                    sa_v4i fm; sa_v2i pm;
+                    if (0 < LC) { fm = *SA_LDS(const sa_v4i, l_fmap + lane); pm = *SA_LDS(const sa_v2i, l_pmap + lane); } else { fm = *SA_GLB(const sa_v4i, fmap + lane); pm = *SA_GLB(const sa_v2i, pmap + lane); }
+                    nm = make_int4(fm.x, fm.y, fm.z, fm.w); np = make_int2(pm.x, pm.y);
                 }
 #define SA_TRY(m0_, m1_, mE_, mbad_, taken)                                                                            \
                     { taken = false;                                                                                   \
@@ -496,7 +561,13 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                         const int fn = 64 * (j + 1) + lane;
                         n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nm = make_int4(0, 0, 0, 0); np = make_int2(0, 0);
                         if (fn < n) {
-                            n0 = SA_R2(0, fn); n1 = SA_R2(1, fn); n2 = SA_R2(2, fn); n3 = SA_R2(3, fn); nm = SA_FMAP(fn); np = SA_PMAP(fn);
+                            const bool nl = 64 * (j + 1) < LC;                 // wave-uniform
+                            float4 v4[4];
+                            SA_R2_LD(nl, fn, v4);
+                            n0 = v4[0]; n1 = v4[1]; n2 = v4[2]; n3 = v4[3];
+                            sa_v4i fm; sa_v2i pm;
+                            if (nl) { fm = *SA_LDS(const sa_v4i, l_fmap + fn); pm = *SA_LDS(const sa_v2i, l_pmap + fn); } else { fm = *SA_GLB(const sa_v4i, fmap + fn); pm = *SA_GLB(const sa_v2i, pmap + fn); }
+                            nm = make_int4(fm.x, fm.y, fm.z, fm.w); np = make_int2(pm.x, pm.y);
                         }
                     }
                     int pos = 0;
@@ -594,7 +665,6 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
         if (A.dbg) for (int k = 0; k < 16; ++k) A.dbg[16 * (size_t)pair + k] = (double)tph[k];
 #endif
     }
-#undef SA_PATCH
 }
 #undef SA_BIL
 
@@ -622,6 +692,9 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
     A.dbg = nullptr; A.prio = ctx->wave_prio_mask & 1; A.n_pairs = n_pairs;
+#ifdef YGZ_SA_TIMERS
+    { void *dd = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 1, (size_t)n_pairs * 16 * 8, &dd) == YGZ_OK) A.dbg = (double *)dd; }
+#endif
     // a problem gets 512 lanes when the launch leaves CUs idle anyway (few pairs: the single-frame surface calls) or when the grid is too big
     // for the per-lane feature loop of the 256-lane form; else 256 (one wavefront per SIMD: the VALU-bound stages of other streams fill its
     // idle issue slots)
@@ -633,15 +706,17 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     // 64 bytes (the reference patch) for the first pcap features from what the scratch leaves
     // (a 512-lane problem owns its CU -- nothing else fits beside 512 x 256 registers -- so it may take nearly all of the LDS)
     const int cells64 = (ctx->cells + 63) / 64 * 64;
-    const int lcap_want = threads == 512 ? 1600 : 1024;
+    // (a single-frame call knows its feature count: scratch for exactly those, the rest of the LDS for their patches)
+    const int lcap_want = ctx->sa_n_hint > 0 ? std::min(1600, std::max(64, ctx->sa_n_hint)) : (threads == 512 ? 1600 : 1024);
     A.lcap = ((lcap_want < ctx->cells ? lcap_want : ctx->cells) + 63) / 64 * 64;
     int lim = 64 * 1024;      // dynamic + static LDS must fit the device's per-block limit (static: < 3 KB, see -Rpass-analysis=kernel-resource-usage)
     (void)hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
+    const size_t ctot_b = (size_t)(cells64 / 64 + 1) * 4;
     {
-        const int room = (lim - 4096 - 16) / 96;                                   // 92 bytes per feature + 4 per 64 features
+        const int room = (int)(((long)lim - 4096 - 16 - (long)ctot_b) / 92);       // 92 bytes per feature
         if (A.lcap > room) A.lcap = room > 0 ? room / 64 * 64 : 0;
     }
-    size_t dyn = (size_t)A.lcap * 92 + (size_t)(A.lcap / 64 + 1) * 4 + 16;
+    size_t dyn = (size_t)A.lcap * 92 + ctot_b + 16;
     dyn = (dyn + 15) & ~(size_t)15;
     {
         const long left = (long)lim - 4096 - 16 - (long)dyn;
@@ -662,6 +737,14 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     if (threads == 512) YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_512, dim3(grid), dim3(512), dyn, A);
     else YGZ_LAUNCH_DYN(ctx, KID_SPARSE_ALIGN, k2_256, dim3(grid), dim3(256), dyn, A);
     YGZ_HIPCHK(ctx, hipGetLastError());
+#ifdef YGZ_SA_TIMERS
+    if (A.dbg) {                                                                   // cycles of lane 0 per phase, problem 0 (a -DYGZ_SA_TIMERS build only)
+        double h[16];
+        (void)hipMemcpyAsync(h, A.dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream); (void)hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[sa-timers] %d lanes: loop top %.0f; feature loop %.0f; enter / leave %.0f; wave sums %.0f; barrier %.0f; maps + scan %.0f; walk %.0f (of chain || solve %.0f); decide %.0f; walks %.0f, float-chain features %.0f\n",
+                threads, h[0], h[8], h[9], h[10], h[1], h[13], h[2], h[3], h[4], h[5], h[7]);
+    }
+#endif
     return YGZ_OK;
 }
 
@@ -695,7 +778,10 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_has_mp, h_mp, N, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, h_n, 4, hipMemcpyHostToDevice, ctx->stream));
     YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->sa_out, h_T, 7 * 8, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = ygz_launch_sparse_align(ctx, 1, max_level, min_level, n_iter)) != YGZ_OK) return rc;
+    ctx->sa_n_hint = n;
+    rc = ygz_launch_sparse_align(ctx, 1, max_level, min_level, n_iter);
+    ctx->sa_n_hint = 0;
+    if (rc != YGZ_OK) return rc;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 7; ++k) T_cur[k] = h_out[k];
