@@ -41,9 +41,11 @@ python $R/tools/make_traffic.py $OUT/pmc_fetch.md $OUT/pmc_write.md $OUT/traffic
 bash $R/tools/pmc_one_pass.sh > /dev/null 2>&1
 cp $R/gpurun_out/sq_counters.md $OUT/sq_counters_raw.md
 cd $R
-timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
-NKP=$(python -c "import json; print(json.loads(open('$OUT/bench_default.json').read().strip().splitlines()[-1])['config']['keypoints_per_frame'])")
+# the two tables the default line reads, in place BEFORE the line is recorded (so that it carries counters of these very kernel sources)
+NKP=$(timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['config']['keypoints_per_frame'])")
 python tools/make_valu_counts.py $OUT/sq_counters_raw.md $OUT/valu_counts.json 256 $NKP
+cp $OUT/traffic.json $OUT/valu_counts.json $R/profiles/
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 for f in 1024 512 256 128; do timeout 300 python bench.py --mode offline --frames $f --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_offline_f$f.json 2> $OUT/off_$f.err; done
 timeout 300 python bench.py --mode offline --frames 1024 --steps 5 --warmup 2 --no-cpu-baseline --upload gray > $OUT/bench_offline_f1024_gray.json 2> $OUT/off_gray.err
 YGZ_OFFLINE_TRACE=1 timeout 300 python bench.py --mode offline --frames 128 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 > /dev/null | grep "offline host" | tail -14 > $OUT/offline128_trace.txt
