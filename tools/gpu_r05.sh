@@ -32,9 +32,7 @@ b)  # plan sweep on short shards (what one rank of an 8 / 4-rank job sees): defe
       for d in 0 2 4; do for g in 0 1; do
         benchline off${f}_d${d}_g${g} $OFF --frames $f --defer $d --lm-group $g
       done; done
-      YGZ_OFF_CHUNK=64 benchline off${f}_c64_d2_g1 $OFF --frames $f --defer 2 --lm-group 1
-      YGZ_OFF_CHUNK=48 benchline off${f}_c48_d2_g1 $OFF --frames $f --defer 2 --lm-group 1
-      YGZ_OFF_CHUNK=24 benchline off${f}_c24_d2_g1 $OFF --frames $f --defer 2 --lm-group 1
+      # (the chunk sizes 64 / 48 / 24 of this sweep were set through a switch of the Python driver that went with it: ygz_offline_params::chunk now)
       benchline off${f}_d2_g1_bg16 $OFF --frames $f --defer 2 --lm-group 1 --bg-budget 16
       benchline off${f}_d2_g1_l4 $OFF --frames $f --defer 2 --lm-group 1 --lanes 4
     done

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run the resident step of bench.py once on a small batch and dump what its kernels produced (sparse-alignment poses and iteration
-counts, LK tracks, direct projections, matches) to an .npz -- two runs under different experiment switches (YGZ_SA_FORM, YGZ_PAD_FUSE,
-...) must give identical files: `tools/step_dump.py --compare a.npz b.npz`.
+counts, LK tracks, direct projections, matches) to an .npz -- two runs under one of the library's switches (YGZ_SA_THREADS, YGZ_HAMMING_VALU, ...: tests/test_gpu_switches.py) or with two builds of
+libygz_hip.so must give identical files: `tools/step_dump.py --compare a.npz b.npz`.
 usage: tools/step_dump.py out.npz [--batch 16] [--size vga|720p]"""
 import argparse, os, sys
 import numpy as np
