@@ -534,43 +534,39 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
             __syncthreads();
             SA_PHASE(13);     // maps + scan
             if (wv == 0) {
-                // ---- wave 0: the walk over the segments (see the first form)
+                // ---- wave 0: the walk over the segments (see the first form).  Per chunk of 64 features it needs the maps only (fmap, pmap: 24 bytes
+                // per lane, the next chunk's in flight); the 16 terms of a feature are fetched when a feature has to be added term by term (about
+                // ten per iteration), as one broadcast read.  A chunk that is ONE segment in the running sum's binade and stays inside it -- most
+                // chunks -- is taken by a short straight-line test before the general loop.
                 uint32_t cb = 0u;                                            // bits of c, wave-uniform
                 const int J = (n + 63) >> 6;
-                float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0, n2 = n0, n3 = n0;      // software pipeline: chunk j + 1 is in flight
                 int4 nm = make_int4(0, 0, 0, 0); int2 np = make_int2(0, 0);
-                if (lane < n) {
-                    float4 v4[4];
-                    SA_R2_LD(0 < LC, lane, v4);
-                    n0 = v4[0]; n1 = v4[1]; n2 = v4[2]; n3 = v4[3];
-                    sa_v4i fm; sa_v2i pm;
-                    if (0 < LC) { fm = *SA_LDS(const sa_v4i, l_fmap + lane); pm = *SA_LDS(const sa_v2i, l_pmap + lane); } else { fm = *SA_GLB(const sa_v4i, fmap + lane); pm = *SA_GLB(const sa_v2i, pmap + lane); }
-                    nm = make_int4(fm.x, fm.y, fm.z, fm.w); np = make_int2(pm.x, pm.y);
-                }
+#define SA_LOAD_MAPS(j_)                                                                                                  \
+                { const int fn_ = 64 * (j_) + lane;                                                                        \
+                  nm = make_int4(0, 0, 0, 0); np = make_int2(0, 0);                                                        \
+                  if (fn_ < n) {                                                                                           \
+                      sa_v4i fm_; sa_v2i pm_;                                                                              \
+                      if (64 * (j_) < LC) { fm_ = *SA_LDS(const sa_v4i, l_fmap + fn_); pm_ = *SA_LDS(const sa_v2i, l_pmap + fn_); } \
+                      else { fm_ = *SA_GLB(const sa_v4i, fmap + fn_); pm_ = *SA_GLB(const sa_v2i, pmap + fn_); }           \
+                      nm = make_int4(fm_.x, fm_.y, fm_.z, fm_.w); np = make_int2(pm_.x, pm_.y); } }
+                SA_LOAD_MAPS(0)
 #define SA_TRY(m0_, m1_, mE_, mbad_, taken)                                                                            \
                     { taken = false;                                                                                   \
                       if (!(mbad_) && (int)(cb >> 23) == (mE_)) {                                                      \
                           const uint32_t m_ = (cb & 0x7fffffu) | 0x800000u, mn_ = m_ + (uint32_t)((m_ & 1u) ? (m1_) : (m0_)); \
                           if (mn_ < 0x1000000u) { cb = (cb & 0xff800000u) | (mn_ & 0x7fffffu); taken = true; } } }
                 for (int j = 0; j < J; ++j) {
-                    const float x[16] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w };
                     const int f0 = nm.x, f1 = nm.y, E = nm.z, bad = nm.w & 1, p0 = np.x, p1 = np.y;
                     const int cnt = min(64, n - 64 * j);
                     const unsigned long long H = __ballot(((nm.w >> 1) & 1) && lane < cnt);
-                    {
-                        const int fn = 64 * (j + 1) + lane;
-                        n0 = make_float4(0.f, 0.f, 0.f, 0.f); n1 = n0; n2 = n0; n3 = n0; nm = make_int4(0, 0, 0, 0); np = make_int2(0, 0);
-                        if (fn < n) {
-                            const bool nl = 64 * (j + 1) < LC;                 // wave-uniform
-                            float4 v4[4];
-                            SA_R2_LD(nl, fn, v4);
-                            n0 = v4[0]; n1 = v4[1]; n2 = v4[2]; n3 = v4[3];
-                            sa_v4i fm; sa_v2i pm;
-                            if (nl) { fm = *SA_LDS(const sa_v4i, l_fmap + fn); pm = *SA_LDS(const sa_v2i, l_pmap + fn); } else { fm = *SA_GLB(const sa_v4i, fmap + fn); pm = *SA_GLB(const sa_v2i, pmap + fn); }
-                            nm = make_int4(fm.x, fm.y, fm.z, fm.w); np = make_int2(pm.x, pm.y);
-                        }
-                    }
+                    SA_LOAD_MAPS(j + 1)
                     int pos = 0;
+                    if (H == 1ull) {                                         // one segment (lane 0 is always a head): the first step of the loop below, alone
+                        bool taken;
+                        SA_TRY(__builtin_amdgcn_readlane(p0, cnt - 1), __builtin_amdgcn_readlane(p1, cnt - 1), __builtin_amdgcn_readlane(E, 0),
+                               __builtin_amdgcn_readlane(bad, 0), taken)
+                        if (taken) continue;
+                    }
                     while (pos < cnt) {
                         bool taken;
                         if ((H >> pos) & 1ull) {
@@ -599,15 +595,19 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                                __builtin_amdgcn_readlane(bad, pos), taken)
                         if (!taken) {
                             SA_COUNT(7, 1);
+                            float4 v4[4];                                   // every lane reads the feature's 16 terms (one address: a broadcast)
+                            SA_R2_LD(64 * j < LC, 64 * j + pos, v4);
+                            const float x[16] = { v4[0].x, v4[0].y, v4[0].z, v4[0].w, v4[1].x, v4[1].y, v4[1].z, v4[1].w,
+                                                  v4[2].x, v4[2].y, v4[2].z, v4[2].w, v4[3].x, v4[3].y, v4[3].z, v4[3].w };
                             float cc = __uint_as_float(cb);
 #pragma unroll
-                            for (int k = 0; k < 16; ++k)
-                                cc = __fadd_rn(cc, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[k]), pos)));
+                            for (int k = 0; k < 16; ++k) cc = __fadd_rn(cc, x[k]);
                             cb = __builtin_amdgcn_readfirstlane(__float_as_uint(cc));
                         }
                         ++pos;
                     }
                 }
+#undef SA_LOAD_MAPS
 #undef SA_TRY
                 const float c = __uint_as_float(cb);
                 if (lane == 0) s_chi2 = c;
