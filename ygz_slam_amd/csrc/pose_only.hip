@@ -94,9 +94,15 @@ __device__ bool po_eval(const PoArgs &A, int beg, int n, const double *pose /*LD
         for (int u = 0; u < 6; ++u) acc[21 + u] += -(Jx[u] * r0 + Jx[6 + u] * r1);
     }
     const int first = full ? 0 : 27;
-    for (int i = first; i < PO_NV; ++i) {
-        const double v = ygz_wave_sum_d(acc[i]);
-        if (lane == 0) red[wv][i] = v;
+    if (full) {                                                 // all 28 sums stage by stage (ygz_wave_sums_d: same additions, 28 independent chains per stage)
+        ygz_wave_sums_d(acc);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < PO_NV; ++i) red[wv][i] = acc[i];
+        }
+    } else {
+        const double v = ygz_wave_sum_d(acc[27]);
+        if (lane == 0) red[wv][27] = v;
     }
     const int any_behind = __syncthreads_or(behind);
     if (tid >= first && tid < PO_NV) sum[tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];

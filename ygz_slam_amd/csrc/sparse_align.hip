@@ -451,23 +451,12 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                 }
             }
             SA_PHASE(9);      // enter / leave blocks
-            // the 27 wavefront sums, stage by stage over ALL values (27 independent chains per stage instead of 27 sums one after the other, each a
-            // chain of dependent FP64 adds: 6.2 of the 85 thousand cycles of an iteration).  Same additions in the same order as ygz_wave_sum_d --
-            // inside the rows of 16, then ((r0 + r1) + r2) + r3 -- the last three through row broadcasts into rows 1, 2, 3 (disabled rows add -0.0):
-            // lanes 48..63 end up with the totals
-            {
-#define SA_SUM_STAGE(ctrl, rmask)                                                                                                       \
-                _Pragma("unroll") for (int k = 0; k < 27; ++k) {                                                                        \
-                    const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(acc[k]), (ctrl), (rmask), 0xF, false);                 \
-                    const int hi_ = __builtin_amdgcn_update_dpp((int)0x80000000, __double2hiint(acc[k]), (ctrl), (rmask), 0xF, false);   \
-                    acc[k] += __hiloint2double(hi_, lo_); }
-                SA_SUM_STAGE(0xB1, 0xF) SA_SUM_STAGE(0x4E, 0xF) SA_SUM_STAGE(0x141, 0xF) SA_SUM_STAGE(0x140, 0xF)
-                SA_SUM_STAGE(0x142, 0x2) SA_SUM_STAGE(0x143, 0x4) SA_SUM_STAGE(0x142, 0x8)
-#undef SA_SUM_STAGE
-                if (lane == 63) {
+            // the 27 wavefront sums, stage by stage over all values (ygz_wave_sums_d: the additions of ygz_wave_sum_d, 27 independent chains per
+            // stage; one after the other they were 6.2 of the 85 thousand cycles of an iteration): lanes 48..63 end up with the totals
+            ygz_wave_sums_d(acc);
+            if (lane == 63) {
 #pragma unroll
-                    for (int k = 0; k < 27; ++k) red[wv][k] = acc[k];
-                }
+                for (int k = 0; k < 27; ++k) red[wv][k] = acc[k];
             }
             {
                 int m = my_meas;

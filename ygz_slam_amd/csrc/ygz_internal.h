@@ -351,6 +351,22 @@ __device__ __forceinline__ double ygz_wave_sum_d(double v)
     const double r3 = __hiloint2double(__builtin_amdgcn_readlane(h, 48), __builtin_amdgcn_readlane(l, 48));
     return ((r0 + r1) + r2) + r3;
 }
+// N FP64 sums over the 64 lanes at once, stage by stage over ALL values: N independent chains per stage instead of N sums one after the other, each
+// a chain of dependent FP64 adds with exec-mask changes in between.  The additions and their order are those of ygz_wave_sum_d (inside the rows of
+// 16, then ((r0 + r1) + r2) + r3, the last three through row broadcasts into rows 1, 2, 3; disabled rows add -0.0): bit-identical totals, which
+// lanes 48..63 hold on return.
+template <int N>
+__device__ __forceinline__ void ygz_wave_sums_d(double (&v)[N])
+{
+#define YGZ_SUMS_STAGE_(ctrl, rmask)                                                                                                \
+    _Pragma("unroll") for (int k_ = 0; k_ < N; ++k_) {                                                                              \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v[k_]), (ctrl), (rmask), 0xF, false);                          \
+        const int hi_ = __builtin_amdgcn_update_dpp((int)0x80000000, __double2hiint(v[k_]), (ctrl), (rmask), 0xF, false);            \
+        v[k_] += __hiloint2double(hi_, lo_); }
+    YGZ_SUMS_STAGE_(0xB1, 0xF) YGZ_SUMS_STAGE_(0x4E, 0xF) YGZ_SUMS_STAGE_(0x141, 0xF) YGZ_SUMS_STAGE_(0x140, 0xF)
+    YGZ_SUMS_STAGE_(0x142, 0x2) YGZ_SUMS_STAGE_(0x143, 0x4) YGZ_SUMS_STAGE_(0x142, 0x8)
+#undef YGZ_SUMS_STAGE_
+}
 // correctly rounded float sqrt: the native v_sqrt_f32 path is 1 ulp; sqrt in double then one rounding is
 // exact for float inputs (53 >= 2*24+2 bits)
 __device__ __forceinline__ float ygz_sqrtf_cr(float x) { return (float)sqrt((double)x); }
