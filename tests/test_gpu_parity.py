@@ -169,8 +169,15 @@ def test_hamming_edge_cases_and_golden(hip_lib, oracle):
     assert np.all(idx == -1) and np.all(d == 2 ** 31 - 1)
     idx, d = ctx.hamming_match(e, g["t"], 1)
     assert len(idx) == 0
-    with pytest.raises(hip_lib.YgzHipError):             # capacity: more rows than grid cells
+    with pytest.raises(hip_lib.YgzHipError):             # capacity: more rows than the result buffers hold (grid cells x max_frames)
         ctx.hamming_match(fixtures.random_descriptors(4000, 1), g["t"], 0)
+    c4 = make_ctx(hip_lib, max_frames=4)                  # ... and with four frames' worth of rows a 4000 x 9000 search fits
+    q4, t4 = fixtures.random_descriptors(4000, 1), fixtures.random_descriptors(9000, 2)
+    for cc in (0, 1):
+        idx, d = c4.hamming_match(q4, t4, cc)
+        oi, od, _ = oracle.bf_match(q4, t4, cc)
+        assert np.array_equal(idx, oi) and np.array_equal(d, od), cc
+    c4.close()
     z = np.zeros((5, 32), np.uint8); f = np.full((4, 32), 255, np.uint8)
     idx, d = ctx.hamming_match(z, f, 0)
     assert np.all(d == 256) and np.all(idx == 0)         # maximum distance, first index on ties
@@ -249,6 +256,40 @@ def test_find_direct_projection_bit_exact(hip_lib, oracle):
         if T_ref_case is poses[0]:
             assert ok.mean() > 0.5
         ctx.close()
+
+
+def test_single_call_entry_points_take_more_rows_than_grid_cells(hip_lib, oracle):
+    """ygz_hip_find_direct_projection / ygz_hip_klt_track(_filtered) serve any number of candidates / points (the reference's
+    Matcher::FindDirectProjection and cv::calcOpticalFlowPyrLK have no limit): in pieces of `cells` rows inside the call, equal to the caller's
+    own pieces."""
+    imgs, poses, depths = _frames(2, 320, 240, seed=9, step=0.5)
+    ctx = make_ctx(hip_lib, width=320, height=240, max_frames=2)
+    for s_ in range(2):
+        ctx.upload_gray(s_, imgs[s_])
+    ctx.build_pyramid(0, 2)
+    cells = ctx.cells
+    n = 2 * cells + 37
+    rng = np.random.default_rng(3)
+    px_ref = np.stack([rng.uniform(30, 290, n), rng.uniform(30, 210, n)], 1)
+    depth = depths[0][px_ref[:, 1].astype(int), px_ref[:, 0].astype(int)].astype(np.float64)
+    level = rng.integers(0, 3, n).astype(np.int32)
+    pred = px_ref + rng.uniform(-3, 3, px_ref.shape)
+    ok, px, sl = ctx.find_direct_projection(0, poses[0], 1, poses[1], px_ref, depth, level, pred)
+    for b in range(0, n, cells):
+        e = min(n, b + cells)
+        ok_p, px_p, sl_p = ctx.find_direct_projection(0, poses[0], 1, poses[1], px_ref[b:e], depth[b:e], level[b:e], pred[b:e])
+        assert np.array_equal(ok[b:e], ok_p) and np.array_equal(px[b:e], px_p, equal_nan=True) and np.array_equal(sl[b:e], sl_p)
+    assert ok.sum() > n // 4
+    pts = px_ref.astype(np.float32)
+    out, st, err = ctx.klt_track(0, 1, pts, pts)
+    out_f, st_f, err_f, keep, n_keep = ctx.klt_track_filtered(0, 1, pts, pts, border=20)
+    assert np.array_equal(out, out_f, equal_nan=True) and np.array_equal(st, st_f) and n_keep == int(keep.sum())
+    for b in range(0, n, cells):
+        e = min(n, b + cells)
+        o_p, s_p, e_p = ctx.klt_track(0, 1, pts[b:e], pts[b:e])
+        assert np.array_equal(out[b:e], o_p, equal_nan=True) and np.array_equal(st[b:e], s_p) and np.array_equal(err[b:e], e_p, equal_nan=True)
+    assert st.sum() > n // 2
+    ctx.close()
 
 
 def _local_map_fixture(oracle, imgs, poses, depths, n_kf, per_kf, rng):

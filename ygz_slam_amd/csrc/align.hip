@@ -437,7 +437,8 @@ int ygz_launch_win_project(ygz_hip_ctx *ctx, const YgzWinProject &P)
 
 extern "C" {
 
-// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
+// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair -- in pieces of `cells` candidates (the track set's size;
+// candidates are independent, so any n is served: Matcher::FindDirectProjection has no limit either)
 int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair, const double *px_ref, const double *depth_ref,
                                    const int32_t *level_ref, double *px_cur, int32_t *search_level, uint8_t *ok, int n)
 {
@@ -446,24 +447,26 @@ int ygz_hip_find_direct_projection(ygz_hip_ctx *ctx, const ygz_align_pair *pair,
     if (n == 0) return YGZ_OK;
     if (!px_ref || !depth_ref || !level_ref || !px_cur || !search_level || !ok) return YGZ_E_INVALID;
     if (pair->ref_slot < 0 || pair->ref_slot >= ctx->prm.max_frames || pair->cur_slot < 0 || pair->cur_slot >= ctx->prm.max_frames) return YGZ_E_INVALID;
-    if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[pair->ref_slot] || !ctx->pyr_valid[pair->cur_slot]) return YGZ_E_STATE;
     for (int i = 0; i < n; ++i) if (level_ref[i] < 0 || level_ref[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
     int rc = ygz_track_set_pairs(ctx, &pair->cur_slot, &pair->ref_slot, pair->T_cur, pair->T_ref, 1);
     if (rc != YGZ_OK) return rc;
-    const size_t N = (size_t)n;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px_ref, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, depth_ref, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_level, level_ref, N * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->fdp_px, px_cur, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->fdp_cand, 1, N, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = ygz_launch_fdp(ctx, 1)) != YGZ_OK) return rc;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(px_cur, ctx->fdp_px, N * 16, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(search_level, ctx->fdp_level, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ok, ctx->fdp_ok, N, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int base = 0; base < n; base += ctx->cells) {
+        const int m = n - base < ctx->cells ? n - base : ctx->cells;
+        const size_t N = (size_t)m;
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px_ref + 2 * (size_t)base, N * 16, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, depth_ref + base, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_level, level_ref + base, N * 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->fdp_px, px_cur + 2 * (size_t)base, N * 16, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->fdp_cand, 1, N, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &m, 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = ygz_launch_fdp(ctx, 1)) != YGZ_OK) return rc;
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(px_cur + 2 * (size_t)base, ctx->fdp_px, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(search_level + base, ctx->fdp_level, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ok + base, ctx->fdp_ok, N, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return YGZ_OK;
 }
 

@@ -317,7 +317,7 @@ int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, con
     }
     if (cross_check == 1 || cross_check == 2) {       // train -> query
         if (cross_check == 1)
-            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->m_key, 0xFF, (size_t)n_pairs * Cn * 8, ctx->stream));
+            YGZ_HIPCHK(ctx, hipMemsetAsync(ctx->m_key, 0xFF, ((size_t)n_pairs * Cn > (size_t)max_rows ? (size_t)n_pairs * Cn : (size_t)max_rows) * 8, ctx->stream));   // (one pair may use the rows of all pairs: ygz_hip_hamming_match)
         A.pair_a = pair_t; A.pair_b = pair_q;
         A.out_idx = ctx->m_tq; A.out_dist = ctx->m_td; A.out_dist2 = nullptr;
         A.scatter_key = (cross_check == 1) ? ctx->m_key : nullptr;
@@ -392,7 +392,8 @@ int ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (!ctx || nq < 0 || nt < 0 || (nq > 0 && !q) || (nt > 0 && !t) || cross_check < 0 || cross_check > 2) return YGZ_E_INVALID;
     if (dist2 && cross_check != 0) return YGZ_E_INVALID;
-    if (nq > ctx->cells || nt > ctx->cells) return YGZ_E_CAPACITY;        // result rows live in the per-pair buffers
+    // result rows live in the per-pair buffers ([max_frames][cells]); this one pair may use all of them
+    if ((size_t)nq > (size_t)ctx->cells * ctx->prm.max_frames || (size_t)nt > (size_t)ctx->cells * ctx->prm.max_frames) return YGZ_E_CAPACITY;
     if (nq == 0) return YGZ_OK;
     const size_t stride_u32 = (size_t)(nq > nt ? nq : nt) * 8 + 8;
     uint8_t *buf = nullptr;

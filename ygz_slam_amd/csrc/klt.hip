@@ -627,7 +627,8 @@ __global__ __launch_bounds__(256) void k_klt_keep(const float *__restrict__ pts,
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_keep, c);
 }
 
-// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair
+// single pair, host arrays: fills track set 0 and runs the batched kernel with one pair -- in pieces of `cells` points (the track set's size; points
+// are independent, so any n is served: cv::calcOpticalFlowPyrLK has no limit either)
 static int klt_track_host(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts, int n,
                           const ygz_klt_params *prm, uint8_t *status, float *err, int border, uint8_t *keep, int *n_keep)
 {
@@ -636,34 +637,39 @@ static int klt_track_host(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const f
     if (n_keep) *n_keep = 0;
     if (n == 0) return YGZ_OK;
     if (!prev_pts || !next_pts || !status) return YGZ_E_INVALID;
-    if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[prev_slot] || !ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
     const double I7[7] = { 0, 0, 0, 1, 0, 0, 0 };
     int rc = ygz_track_set_pairs(ctx, &cur_slot, &prev_slot, I7, I7, 1);
     if (rc != YGZ_OK) return rc;
-    std::vector<double> px((size_t)n * 2);
-    for (int i = 0; i < 2 * n; ++i) px[i] = (double)prev_pts[i];
-    const size_t N = (size_t)n;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px.data(), N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_pts, next_pts, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = ygz_launch_klt(ctx, 1, prm)) != YGZ_OK) return rc;
-    if (keep) {
-        uint8_t *d_keep = nullptr;
-        if ((rc = ygz_scratch(ctx, SCR_KLT_OUT, N + 64, (void **)&d_keep)) != YGZ_OK) return rc;
-        int32_t *d_cnt = reinterpret_cast<int32_t *>(d_keep + ((N + 15) & ~(size_t)15));
-        YGZ_HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
-        YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_klt_keep, dim3(ygz_div_up(n, 256)), dim3(256), ctx->klt_pts, ctx->klt_status, n, ctx->lw[0], ctx->lh[0],
-                   border, d_keep, d_cnt);
-        YGZ_HIPCHK(ctx, hipGetLastError());
-        YGZ_HIPCHK(ctx, hipMemcpyAsync(keep, d_keep, N, hipMemcpyDeviceToHost, ctx->stream));
-        if (n_keep) YGZ_HIPCHK(ctx, hipMemcpyAsync(n_keep, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> px;
+    for (int base = 0; base < n; base += ctx->cells) {
+        const int m = n - base < ctx->cells ? n - base : ctx->cells;
+        const size_t N = (size_t)m;
+        px.resize(N * 2);
+        for (int i = 0; i < 2 * m; ++i) px[i] = (double)prev_pts[2 * (size_t)base + i];
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, px.data(), N * 16, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_pts, next_pts + 2 * (size_t)base, N * 8, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, &m, 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = ygz_launch_klt(ctx, 1, prm)) != YGZ_OK) return rc;
+        int kept = 0;
+        if (keep) {
+            uint8_t *d_keep = nullptr;
+            if ((rc = ygz_scratch(ctx, SCR_KLT_OUT, N + 64, (void **)&d_keep)) != YGZ_OK) return rc;
+            int32_t *d_cnt = reinterpret_cast<int32_t *>(d_keep + ((N + 15) & ~(size_t)15));
+            YGZ_HIPCHK(ctx, hipMemsetAsync(d_cnt, 0, 4, ctx->stream));
+            YGZ_LAUNCH(ctx, KID_TRACK_AUX, k_klt_keep, dim3(ygz_div_up(m, 256)), dim3(256), ctx->klt_pts, ctx->klt_status, m, ctx->lw[0], ctx->lh[0],
+                       border, d_keep, d_cnt);
+            YGZ_HIPCHK(ctx, hipGetLastError());
+            YGZ_HIPCHK(ctx, hipMemcpyAsync(keep + base, d_keep, N, hipMemcpyDeviceToHost, ctx->stream));
+            if (n_keep) YGZ_HIPCHK(ctx, hipMemcpyAsync(&kept, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(next_pts + 2 * (size_t)base, ctx->klt_pts, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(status + base, ctx->klt_status, N, hipMemcpyDeviceToHost, ctx->stream));
+        if (err) YGZ_HIPCHK(ctx, hipMemcpyAsync(err + base, ctx->klt_err, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (n_keep) *n_keep += kept;
     }
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(next_pts, ctx->klt_pts, N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(status, ctx->klt_status, N, hipMemcpyDeviceToHost, ctx->stream));
-    if (err) YGZ_HIPCHK(ctx, hipMemcpyAsync(err, ctx->klt_err, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return YGZ_OK;
 }
 

@@ -584,7 +584,7 @@ int Matcher::BruteForceMatch(Frame *frame1, Frame *frame2, vector<DMatch> &match
 {
     hip::Runtime &rt = hip::Runtime::Get();
     Mat d1 = frame1->GetAllDescriptors(), d2 = frame2->GetAllDescriptors();
-    if (d1.rows > rt.cells() || d2.rows > rt.cells()) throw std::runtime_error("BruteForceMatch: more descriptors than grid cells");
+    // (the ABI takes up to grid cells x resident frames rows per set and reports YGZ_E_CAPACITY beyond: hip::check throws)
     vector<int32_t> idx(d1.rows), dist(d1.rows);
     hip::check(ygz_hip_hamming_match(rt.ctx(), d1.data, d1.rows, d2.data, d2.rows, cross_check ? 1 : 0, idx.data(), dist.data(), nullptr), "hamming_match");
     matches.clear();
