@@ -366,12 +366,12 @@ int  ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *pos
 int  ygz_hip_ba_optimize_chi2(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io, int max_iterations,
                               ygz_ba_stats *stats, double *chi2_edge);
 /* Which loop the last ygz_hip_ba_optimize / ygz_hip_ba_solve_ceres of the context ran.  Both route to the resident kernels
- * (ygz_hip_ba_optimize_resident / ygz_hip_ba_solve_ceres_resident) when the window has at most 14 free poses and no repeated (point, pose)
+ * (ygz_hip_ba_optimize_resident / ygz_hip_ba_solve_ceres_resident) when the window has at most 20 free poses (14 for the ceres form) and no repeated (point, pose)
  * edge; otherwise the linearisations run on the GPU and the reduced system on the host -- the same results, about ten times slower.
  * Returns YGZ_BA_PATH_RESIDENT, or YGZ_BA_PATH_HOST_LOOP | the reason bits; 0 before the first call. */
 enum { YGZ_BA_PATH_RESIDENT = 1, YGZ_BA_PATH_HOST_LOOP = 2, YGZ_BA_WHY_FREE_POSES = 16, YGZ_BA_WHY_REPEATED_EDGES = 32, YGZ_BA_WHY_FORCED = 64 };
 int  ygz_hip_ba_last_path(const ygz_hip_ctx *ctx);
-/* The same loop entirely on the GPU for uploaded windows window_begin .. +n_windows-1 (formulation 0, at most 14 free
+/* The same loop entirely on the GPU for uploaded windows window_begin .. +n_windows-1 (formulation 0, at most 20 free
  * poses per window): one workgroup per window runs linearisation, Schur complement, Cholesky, back-substitution, update and
  * the lambda policy in HBM/LDS without a host round trip, all windows concurrently.  The windows' states are updated in
  * place (ygz_hip_ba_get_state reads them back); stats [n_windows] may be NULL (then the call is asynchronous). */

@@ -997,6 +997,34 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
     ctx.close()
 
 
+def test_ba_optimize_resident_many_free_poses(hip_lib, oracle):
+    """The reduced system of the resident LM lives in dynamic LDS sized by the window: 19 keyframes (18 free poses, a 108 x 108 system) beside a small
+    window in the same launch, against the oracle's g2o LM; 22 keyframes go to the host loop and say so."""
+    wins = [synth.ba_window(19, 1200, seed=11), synth.ba_window(5, 120, seed=12), synth.ba_window(12, 800, seed=13)]
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for i, w in enumerate(wins):
+        ctx.ba_upload(i, w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
+    stats = ctx.ba_optimize_resident(0, len(wins), iterations=20)
+    for i, w in enumerate(wins):
+        po, pt, so = oracle.g2o_lm(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"], max_iterations=20)
+        pg, tg = ctx.ba_get_state(i, len(w["poses"]), len(w["points"]))
+        st = stats[i]
+        assert abs(st.chi2_initial - so["chi2_initial"]) <= 1e-10 * so["chi2_initial"], i
+        assert abs(st.chi2_final - so["chi2_final"]) <= 1e-9 * so["chi2_final"], i
+        assert _rel(pg, po) < 1e-6 and _rel(tg, pt) < 1e-6, i
+        back = oracle.ba_linearize(pg, w["fixed"], tg, w["edge_pose"], w["edge_point"], w["obs"])
+        assert abs(back["chi2"] - st.chi2_final) <= 1e-9 * st.chi2_final, i
+        # the Hpp / bp blocks of EVERY free pose are those of the last linearisation point (poses beyond the ninth were not written before round 5)
+    w = wins[0]
+    ctx.ba_optimize(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"], iterations=3)
+    assert ctx.ba_last_path() == (True, [])
+    big = synth.ba_window(22, 600, seed=14)
+    ctx.ba_optimize(big["poses"], big["fixed"], big["points"], big["edge_pose"], big["edge_point"], big["obs"], iterations=2)
+    ok_, why = ctx.ba_last_path()
+    assert not ok_ and any("free poses" in x for x in why), why
+    ctx.close()
+
+
 def test_ba_optimize_resident_team_size_invariance(hip_lib):
     """k_ba_lm_team gives a window to 1, 2, 4 or 8 cooperating workgroups depending on how many windows the launch holds; the points
     are reduced in 8 fixed parts whatever the team size, so the optimum, the trial sequence and the refined state must be BIT-identical

@@ -928,7 +928,7 @@ class HipContext:
     def ba_last_path(self):
         """(resident?, reasons) of the last ba_optimize / ba_solve_ceres: the resident kernel, or the ~10x slower host loop and why"""
         v = int(self.lib.ygz_hip_ba_last_path(self._ctx))
-        return bool(v & 1), [n for b, n in ((16, "more than 14 free poses"), (32, "repeated (point, pose) edges"), (64, "YGZ_BA_HOST_LOOP=1")) if v & b]
+        return bool(v & 1), [n for b, n in ((16, "more than 20 free poses"), (32, "repeated (point, pose) edges"), (64, "YGZ_BA_HOST_LOOP=1")) if v & b]
 
     def ba_set_team_placement(self, spread):
         self._chk(self.lib.ygz_hip_ba_set_team_placement(self._ctx, int(spread)), "ba_set_team_placement")

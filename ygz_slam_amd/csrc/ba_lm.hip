@@ -153,9 +153,9 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
         const char *force = getenv("YGZ_BA_HOST_LOOP");
         const bool dup = ygz_ba_window_has_dup(ctx, W), forced = force && force[0] == '1';
         // which loop ran and why, for ygz_hip_ba_last_path: the host loop is ~10x slower and the caller should be able to tell
-        ctx->ba_last_path = (Kfree <= 14 && !forced && !dup) ? YGZ_BA_PATH_RESIDENT
-                            : (YGZ_BA_PATH_HOST_LOOP | (Kfree > 14 ? YGZ_BA_WHY_FREE_POSES : 0) | (dup ? YGZ_BA_WHY_REPEATED_EDGES : 0) | (forced ? YGZ_BA_WHY_FORCED : 0));
-        if (Kfree <= 14 && !forced && !dup) {      // repeated (point, pose) pairs: host-side Schur sums them per edge
+        ctx->ba_last_path = (Kfree <= 20 && !forced && !dup) ? YGZ_BA_PATH_RESIDENT
+                            : (YGZ_BA_PATH_HOST_LOOP | (Kfree > 20 ? YGZ_BA_WHY_FREE_POSES : 0) | (dup ? YGZ_BA_WHY_REPEATED_EDGES : 0) | (forced ? YGZ_BA_WHY_FORCED : 0));
+        if (Kfree <= 20 && !forced && !dup) {      // (20 free poses: LM_MAXKF of ba_resident_lm.hip)  repeated (point, pose) pairs: host-side Schur sums them per edge
             ygz_ba_stats st;
             if ((rc = ygz_hip_ba_optimize_resident(ctx, W, 1, max_iterations, &st)) != YGZ_OK) return rc;
             if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;

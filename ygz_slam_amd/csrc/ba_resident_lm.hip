@@ -23,8 +23,10 @@
 
 #define LM_THREADS 256
 #define LM_WAVES   (LM_THREADS / 64)
-#define LM_MAXKF   14
+#define LM_MAXKF   20                                   // free poses of a window of k_ba_lm_team: its reduced system ((6 Kf)^2 doubles) is DYNAMIC LDS, sized by the launch's largest window
 #define LM_MAXN    (6 * LM_MAXKF)
+#define LM_CERES_MAXKF 14                               // k_ba_ceres keeps its reduced system in static LDS
+#define LM_CERES_MAXN  (6 * LM_CERES_MAXKF)
 #define LM_RB      4                                    // rows (edges of a point) whose 6 x 3 blocks a lane requests together (8: one round trip for a window of 8 keyframes, but 512 registers and spills)
 #define LM_RC      8                                    // rows whose observation records (5 values) a lane requests together: one round trip for a window of 8 keyframes
 #define LM_LDSK    16                                   // windows of up to 16 poses keep their per-pose tables in LDS
@@ -268,7 +270,7 @@ __device__ __forceinline__ void lm_pair_sweep(const BaDev &B, double *S, double 
 #endif
 #define LM_MAXG   32                           // members of a team (the launch never picks more)
 #define LM_NPAIR  (LM_MAXKF * (LM_MAXKF + 1) / 2)
-#define LM_HDR    1024                         // per-window header of the scratch (zeroed by the launch): barrier counter + abort flag (bar[0..3]), one
+#define LM_HDR    2048                         // per-window header of the scratch (zeroed by the launch): barrier counter + abort flag (bar[0..3]), one
                                                // behind-camera count per member (bar[4..4+LM_MAXG)), one arrival counter per pose pair (bar[64..64+LM_NPAIR))
 #define LM_PARTW  (8 + 27 * LM_MAXKF)          // per chunk of 64 points: chi2, max |diag|, singular flag, scale, trial chi2, -, -, -, pose sums [Kf][27]
 #define LM_SPW    42                           // per (pair, part): 36 block entries + 6 of the right-hand side
@@ -533,7 +535,8 @@ __device__ __forceinline__ void lm_subst_blocked(const double *S, double *bs, co
 
 __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
 {
-    __shared__ double S[LM_MAXN * LM_MAXN];
+    extern __shared__ __attribute__((aligned(16))) double lm_dyn_S[];          // the reduced system, [n][n] with n = 6 Kf of THIS window (the launch sizes it for its largest)
+    double *const S = lm_dyn_S;
     __shared__ double bs[LM_MAXN], xp[LM_MAXN], dg[LM_MAXN], rdg[LM_MAXN];   // dg / rdg: D of S = L D L^T and its reciprocals
     __shared__ double Tb[LM_MAXN][6];              // the panel of the current block column times D (lm_solve_blocked)
     __shared__ double sH[LM_MAXKF][28];            // Hpp upper triangle (21) + bp (6) of the free poses at the linearisation point
@@ -667,8 +670,8 @@ __global__ __launch_bounds__(LM_THREADS) void k_ba_lm_team(LmTeamArgs A)
             currentChi = lm_sum_records(crec, Q);
             __syncthreads();
             if (g == 0 && tid == LM_THREADS - 1) { int nb = 0; for (int m = 0; m < G; ++m) nb += (int)__hip_atomic_load(bar + 4 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *n_behind = nb; }
-            if (g == 0 && tid < 27 * Kf) {                                     // the window's Hpp / bp as the ABI exposes them
-                const int a = tid / 27, i = tid % 27, k = B.free_pose[a];
+            if (g == 0) for (int ti = tid; ti < 27 * Kf; ti += LM_THREADS) {   // the window's Hpp / bp as the ABI exposes them
+                const int a = ti / 27, i = ti % 27, k = B.free_pose[a];
                 if (i < 21) { int u = 0, rem = i; while (rem >= 6 - u) { rem -= 6 - u; ++u; } const int vv = u + rem;
                               B.Hpp[36 * (size_t)k + 6 * u + vv] = sH[a][i]; B.Hpp[36 * (size_t)k + 6 * vv + u] = sH[a][i]; }
                 else B.bp[6 * (size_t)k + (i - 21)] = sH[a][i];
@@ -949,9 +952,9 @@ __global__ __launch_bounds__(256) void k_ba_outliers(OutlierArgs A)
 __global__ __launch_bounds__(256) void k_ba_lm_reset(const BaDev *__restrict__ wins, unsigned char *__restrict__ scratch, size_t stride,
                                                        ygz_ba_stats *__restrict__ stats)
 {
-    static_assert(LM_HDR == 256 * 4 && sizeof(ygz_ba_stats) == 32, "one dword per thread; four 8-byte words per record");
+    static_assert(LM_HDR % (256 * 4) == 0 && sizeof(ygz_ba_stats) == 32, "whole dwords per thread; four 8-byte words per record");
     const int w = blockIdx.x, tid = threadIdx.x;
-    reinterpret_cast<uint32_t *>(scratch + (size_t)w * stride)[tid] = 0u;
+    for (int i = tid; i < LM_HDR / 4; i += 256) reinterpret_cast<uint32_t *>(scratch + (size_t)w * stride)[i] = 0u;
     if (tid < 4) reinterpret_cast<unsigned long long *>(stats + w)[tid] = ~0ull;
     else if (tid < 8) reinterpret_cast<unsigned long long *>(wins[w].lm_out)[tid - 4] = 0xFEFEFEFEFEFEFEFEull;
     else if (tid == 8) reinterpret_cast<double *>(scratch + (size_t)w * stride + LM_HDR)[LM_MAXN + 1] = 0.0;   // "a point block was singular" (set by the sweep, cleared by member 0)
@@ -1028,7 +1031,17 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     // records; 0xFF there = never run, ba_carve): one small launch (a 2-D memset, a memset and one memset per window took 0.15 ms of the
     // serial tail of an offline run)
     YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_reset, dim3(n_windows), dim3(256), A.wins, A.scratch, stride, A.stats);
-    YGZ_LAUNCH(ctx, KID_BA_LM, k_ba_lm_team, dim3(A.spread ? G * n_windows : 8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), A);
+    // the reduced system of the launch's largest window as dynamic LDS: 14 KB for the 7 free poses of an offline window (the static 56 KB of
+    // rounds 3-4 held 14 poses whatever the window had; beside a team other kernels now find that much more LDS on its CUs), 115 KB for 20
+    int nmax = 6;
+    for (int i = window_begin; i < window_begin + n_windows; ++i) nmax = std::max(nmax, 6 * ctx->ba[i]->Kf);     // (host field: the capacity)
+    const size_t dyn_lds = (size_t)nmax * nmax * sizeof(double);
+    void (*const k_team)(LmTeamArgs) = k_ba_lm_team;
+    if (!ctx->lm_attr_set) {
+        YGZ_HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_team), hipFuncAttributeMaxDynamicSharedMemorySize, LM_MAXN * LM_MAXN * (int)sizeof(double)));
+        ctx->lm_attr_set = true;
+    }
+    YGZ_LAUNCH_DYN(ctx, KID_BA_LM, k_team, dim3(A.spread ? G * n_windows : 8 * G * ((n_windows + 7) / 8)), dim3(LM_THREADS), dyn_lds, A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if (A.dbg) {
         long long h[16];
@@ -1160,8 +1173,8 @@ __device__ __forceinline__ double ce_point_cost(const BaDev &B, int il, int *beh
 
 __global__ __launch_bounds__(LM_THREADS) void k_ba_ceres(const BaDev *__restrict__ wins, ygz_ceres_options o, ygz_ceres_summary *__restrict__ sums)
 {
-    __shared__ double S[LM_MAXN * LM_MAXN];
-    __shared__ double bs[LM_MAXN], xp[LM_MAXN];
+    __shared__ double S[LM_CERES_MAXN * LM_CERES_MAXN];
+    __shared__ double bs[LM_CERES_MAXN], xp[LM_CERES_MAXN];
     __shared__ double red27[LM_WAVES][28];
     __shared__ double red[LM_WAVES];
     __shared__ double dxp[16 * 6];
@@ -1396,7 +1409,7 @@ extern "C" int ygz_hip_ba_solve_ceres_resident(ygz_hip_ctx *ctx, int window_begi
     for (int i = window_begin; i < window_begin + n_windows; ++i) {
         if (!ctx->ba[i]) return YGZ_E_INVALID;
         if (ctx->ba[i]->formulation != 2) return YGZ_E_INVALID;      // the ceres functors
-        if (ctx->ba[i]->Kf > LM_MAXKF || ctx->ba[i]->K > 16) return YGZ_E_CAPACITY;
+        if (ctx->ba[i]->Kf > LM_CERES_MAXKF || ctx->ba[i]->K > 16) return YGZ_E_CAPACITY;
         if (ctx->ba[i]->has_dup) return YGZ_E_INVALID;
     }
     ygz_ceres_options opt;
