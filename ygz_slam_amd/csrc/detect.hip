@@ -31,9 +31,10 @@
 #define FT_H    32
 #endif
 #ifndef FT_NT
-#define FT_NT   128                // threads per tile (two wavefronts: 0.496 ms per 512 VGA frames; 256 threads 0.520, 64 x 16 tiles of 128 threads 0.510, 64 x 8 of 64 0.637)
+#define FT_NT   128                // threads per tile (two wavefronts: 0.496 ms per 512 VGA frames; 256 threads 0.520, 64 x 16 tiles of 128 threads 0.510, 64 x 8 of 64 0.637, 64 x 64 of 256 0.521)
 #endif
 #define FT_NW   (FT_NT / 64)
+static_assert(2 * (FT_H + 2) <= FT_NT && (FT_H + 2 + FT_NW - 1) / FT_NW < 31, "the two ring columns are one thread each; a lane's row flags are bits of one dword");
 #define FT_LW   80                 // staged columns: x in [x0-8, x0+72)
 #define FT_LH   (FT_H + 10)        // staged rows:    y in [y0-5, y0+FT_H+5)
 #define FT_X0   8                  // tile column of x0
@@ -463,7 +464,7 @@ __device__ __forceinline__ void ygz_sincos_small(double x, double *sn, double *c
 }
 
 #define DP_P   40          // LDS row pitch of the patch (bytes): rows start dword-aligned
-#define DP_KPW 8           // keypoints per wavefront (0.334 / 0.276 / 0.260 ms per 512 VGA frames with 1 / 4 / 8)
+#define DP_KPW 8           // keypoints per wavefront (0.334 / 0.276 / 0.260 / 0.258 ms per 512 VGA frames with 1 / 4 / 8 / 16)
 
 // IC_Angle as byte dot products (round 5).  lane = (row v = lane / 2 - 15, half hh of the row): the 16 bytes of the half row are columns
 // u = -15 .. 0 (hh = 0) or 1 .. 16 (hh = 1).  Table entry of the lane: four dwords |u| of the columns inside the circle (umax[|v|], 0 elsewhere) and
