@@ -143,7 +143,8 @@ int  ygz_hip_match_slots_again(ygz_hip_ctx *ctx, int cross_check);
 int  ygz_hip_get_matches(ygz_hip_ctx *ctx, int pair, int32_t *train_idx /*[nq]*/, int32_t *dist /*[nq]*/,
                          int capacity, int *nq);
 /* stand-alone form on host descriptor arrays (uploads, matches, downloads).  dist2 (second-best
- * distance, Matcher::SearchByBoW :242-246 ratio test) may be NULL and needs cross_check==0. */
+ * distance, Matcher::SearchByBoW :242-246 ratio test) may be NULL and needs cross_check==0.
+ * nq, nt <= grid cells x max_frames (the result rows of all pairs of the context), YGZ_E_CAPACITY beyond. */
 int  ygz_hip_hamming_match(ygz_hip_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt,
                            int cross_check, int32_t *train_idx, int32_t *dist, int32_t *dist2);
 
@@ -223,7 +224,7 @@ typedef struct {
     int use_initial_flow;             /* OPTFLOW_USE_INITIAL_FLOW */
 } ygz_klt_params;
 void ygz_hip_default_klt_params(ygz_klt_params *p);
-/* level-0 images of prev_slot/cur_slot; prev_pts [n][2], next_pts [n][2] in/out, status [n], err [n] */
+/* level-0 images of prev_slot/cur_slot; prev_pts [n][2], next_pts [n][2] in/out, status [n], err [n]; any n (served in pieces of grid-cell size) */
 int  ygz_hip_klt_track(ygz_hip_ctx *ctx, int prev_slot, int cur_slot, const float *prev_pts, float *next_pts,
                        int n, const ygz_klt_params *prm, uint8_t *status, float *err);
 
