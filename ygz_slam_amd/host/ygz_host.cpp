@@ -660,9 +660,9 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
     auto kf_of = [&](const Frame *f) { for (int k = 0; k < n_kfs; ++k) if (kfp[k] == f) return k; return -1; };
     vector<MapPoint *> mps(local_map_points.begin(), local_map_points.end());
     vector<double> pos; vector<uint8_t> bad;
-    vector<int32_t> cp, ck, cl; vector<double> cpx; vector<Feature *> cfea;
+    vector<int32_t> cp, ck, cl; vector<double> cpx, cscore;              // (the candidate's score rides along: reading it from the matched Feature later is a cache miss per match)
     { const size_t P0 = mps.size(), C0 = P0 * kfs.size();
-      pos.reserve(3 * P0); bad.reserve(P0); cp.reserve(C0); ck.reserve(C0); cl.reserve(C0); cpx.reserve(2 * C0); cfea.reserve(C0); }
+      pos.reserve(3 * P0); bad.reserve(P0); cp.reserve(C0); ck.reserve(C0); cl.reserve(C0); cpx.reserve(2 * C0); cscore.reserve(C0); }
     for (size_t p = 0; p < mps.size(); ++p) {
         MapPoint *mp = mps[p];
         pos.push_back(mp->_pos_world[0]); pos.push_back(mp->_pos_world[1]); pos.push_back(mp->_pos_world[2]);
@@ -673,7 +673,7 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
             const int k = fea ? kf_of(fea->_frame) : -1;
             if (k < 0) continue;
             cp.push_back((int32_t)p); ck.push_back(k); cl.push_back(fea->_level);
-            cpx.push_back(fea->_pixel[0]); cpx.push_back(fea->_pixel[1]); cfea.push_back(fea);
+            cpx.push_back(fea->_pixel[0]); cpx.push_back(fea->_pixel[1]); cscore.push_back(fea->_score);
         }
     }
     const int P = (int)mps.size();
@@ -693,9 +693,8 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
         if (!in_view[p]) { mp->_track_in_view = false; continue; }     // :59-62
         mp->_cnt_visible++;                                            // :64
         if (match[p] < 0) continue;
-        Feature *src = cfea[match[p]];
         if (current->_features.capacity() < current->_features.size() + (size_t)n) current->_features.reserve(current->_features.size() + (size_t)n);
-        Feature *feature = new Feature(Vector2d(px_match[2 * p], px_match[2 * p + 1]), level[p], src->_score);   // :104-111
+        Feature *feature = new Feature(Vector2d(px_match[2 * p], px_match[2 * p + 1]), level[p], cscore[match[p]]);   // :104-111
         feature->_frame = current;
         feature->_mappoint = mp;
         current->_features.push_back(feature);
