@@ -7,6 +7,9 @@ struct Frame;
 struct MapPoint;
 struct Feature {
     Feature(const Vector2d &pixel, const int &level = 0, const double &score = 0) : _pixel(pixel), _level(level), _score(score) {}
+    // `new Feature` / `delete` of the callers, served from a fixed-size block pool (Common.h: ygz::pool)
+    static void *operator new(size_t n) { return n == sizeof(Feature) ? pool::FixedPool<(sizeof(Feature) + 15) / 16 * 16>::alloc() : ::operator new(n); }
+    static void operator delete(void *p, size_t n) { if (!p) return; if (n == sizeof(Feature)) pool::FixedPool<(sizeof(Feature) + 15) / 16 * 16>::release(p); else ::operator delete(p); }
     Vector2d  _pixel = Vector2d(0, 0);
     double    _depth = -1;
     Vector3d  _normal = Vector3d(0, 0, 0);
