@@ -84,6 +84,68 @@ void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes)
     return r;
 }
 
+// ---- packed transfers of single-frame calls (ygz_internal.h)
+__global__ __launch_bounds__(256) void k_copy_segs(YgzPackSegs S)
+{
+    const int seg = blockIdx.y;
+    if (seg >= S.n) return;
+    const uint32_t bytes = S.bytes[seg];
+    const uint8_t *src = S.src[seg]; uint8_t *dst = S.dst[seg];
+    const bool dwords = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) == 0;
+    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < bytes; i += gridDim.x * 1024u) {
+        if (dwords && i + 4 <= bytes) *reinterpret_cast<uint32_t *>(dst + i) = *reinterpret_cast<const uint32_t *>(src + i);
+        else for (uint32_t k = i; k < bytes && k < i + 4; ++k) dst[k] = src[k];
+    }
+}
+int ygz_pack_begin(ygz_hip_ctx *ctx, YgzPack *pk, size_t capacity_bytes, int scratch_id)
+{
+    capacity_bytes += 64 * YGZ_PACK_MAX;
+    pk->host = (uint8_t *)ygz_stage(ctx, capacity_bytes);
+    if (!pk->host) return YGZ_E_HIP;
+    void *d = nullptr;
+    const int rc = ygz_scratch(ctx, scratch_id, capacity_bytes, &d);
+    if (rc != YGZ_OK) return rc;
+    pk->dev = (uint8_t *)d; pk->used = 0; pk->cap = capacity_bytes; pk->segs.n = 0;
+    return YGZ_OK;
+}
+void *ygz_pack_add(YgzPack *pk, const void *device_ptr, size_t bytes)
+{
+    if (pk->segs.n >= YGZ_PACK_MAX || pk->used + bytes > pk->cap) return nullptr;
+    const int k = pk->segs.n++;
+    pk->segs.src[k] = pk->dev + pk->used;                 // upload: staging -> array (ygz_pack_fetch swaps the roles)
+    pk->segs.dst[k] = (uint8_t *)const_cast<void *>(device_ptr);
+    pk->segs.bytes[k] = (uint32_t)bytes;
+    void *h = pk->host + pk->used;
+    pk->used = (pk->used + bytes + 63) & ~(size_t)63;
+    return h;
+}
+static int pack_launch(ygz_hip_ctx *ctx, const YgzPackSegs &S)
+{
+    uint32_t mx = 0;
+    for (int k = 0; k < S.n; ++k) mx = S.bytes[k] > mx ? S.bytes[k] : mx;
+    if (S.n == 0 || mx == 0) return YGZ_OK;
+    const unsigned gx = (mx + 1023) / 1024 > 64 ? 64 : (mx + 1023) / 1024;
+    hipLaunchKernelGGL(k_copy_segs, dim3(gx, S.n), dim3(256), 0, ctx->stream, S);
+    YGZ_HIPCHK(ctx, hipGetLastError());
+    return YGZ_OK;
+}
+int ygz_pack_upload(ygz_hip_ctx *ctx, YgzPack *pk)
+{
+    if (pk->used == 0) return YGZ_OK;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(pk->dev, pk->host, pk->used, hipMemcpyHostToDevice, ctx->stream));
+    return pack_launch(ctx, pk->segs);
+}
+int ygz_pack_fetch(ygz_hip_ctx *ctx, YgzPack *pk)
+{
+    if (pk->used == 0) return YGZ_OK;
+    YgzPackSegs S = pk->segs;
+    for (int k = 0; k < S.n; ++k) { const uint8_t *stg = S.src[k]; S.src[k] = S.dst[k]; S.dst[k] = const_cast<uint8_t *>(stg); }
+    const int rc = pack_launch(ctx, S);
+    if (rc != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipMemcpyAsync(pk->host, pk->dev, pk->used, hipMemcpyDeviceToHost, ctx->stream));
+    return YGZ_OK;
+}
+
 int ygz_join(ygz_hip_ctx *ctx, unsigned skip_mask)
 {
     for (int i = 0; i < 3; ++i)

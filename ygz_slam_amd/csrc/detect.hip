@@ -728,15 +728,16 @@ int ygz_hip_get_keypoints(ygz_hip_ctx *ctx, int slot, ygz_kpt_soa *out, int capa
     const size_t o = (size_t)slot * ctx->cells, rows = (size_t)(capacity < ctx->cells ? capacity : ctx->cells);
     const size_t b_px = out->px ? rows * 16 : 0, b_lv = out->level ? rows * 4 : 0, b_sc = out->score ? rows * 4 : 0, b_an = out->angle ? rows * 4 : 0,
                  b_de = out->desc ? rows * 32 : 0;
-    uint8_t *st = (uint8_t *)ygz_stage(ctx, 64 + b_px + b_lv + b_sc + b_an + b_de);
-    if (!st) return YGZ_E_HIP;
-    uint8_t *h_px = st + 64, *h_lv = h_px + b_px, *h_sc = h_lv + b_lv, *h_an = h_sc + b_sc, *h_de = h_an + b_an;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(st, ctx->n_kp + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (b_px) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_px, ctx->kp_px + 2 * o, b_px, hipMemcpyDeviceToHost, ctx->stream));
-    if (b_lv) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_lv, ctx->kp_level + o, b_lv, hipMemcpyDeviceToHost, ctx->stream));
-    if (b_sc) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_sc, ctx->kp_score + o, b_sc, hipMemcpyDeviceToHost, ctx->stream));
-    if (b_an) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_an, ctx->kp_angle + o, b_an, hipMemcpyDeviceToHost, ctx->stream));
-    if (b_de) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_de, ctx->kp_desc + 8 * o, b_de, hipMemcpyDeviceToHost, ctx->stream));
+    // (one gather kernel + ONE copy back: six copies on the stream before)
+    YgzPack pk;
+    int rc = ygz_pack_begin(ctx, &pk, 64 + b_px + b_lv + b_sc + b_an + b_de, SCR_GEN_0 + 7);
+    if (rc != YGZ_OK) return rc;
+    uint8_t *st = (uint8_t *)ygz_pack_add(&pk, ctx->n_kp + slot, 4);
+    uint8_t *h_px = b_px ? (uint8_t *)ygz_pack_add(&pk, ctx->kp_px + 2 * o, b_px) : nullptr, *h_lv = b_lv ? (uint8_t *)ygz_pack_add(&pk, ctx->kp_level + o, b_lv) : nullptr;
+    uint8_t *h_sc = b_sc ? (uint8_t *)ygz_pack_add(&pk, ctx->kp_score + o, b_sc) : nullptr, *h_an = b_an ? (uint8_t *)ygz_pack_add(&pk, ctx->kp_angle + o, b_an) : nullptr;
+    uint8_t *h_de = b_de ? (uint8_t *)ygz_pack_add(&pk, ctx->kp_desc + 8 * o, b_de) : nullptr;
+    if (!st || (b_px && !h_px) || (b_lv && !h_lv) || (b_sc && !h_sc) || (b_an && !h_an) || (b_de && !h_de)) return YGZ_E_CAPACITY;
+    if ((rc = ygz_pack_fetch(ctx, &pk)) != YGZ_OK) return rc;
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int n = *reinterpret_cast<const int32_t *>(st);
     *n_out = n;

@@ -751,22 +751,22 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     if (!px || !depth || !has_mappoint) return YGZ_E_INVALID;
     if (n > ctx->cells) return YGZ_E_CAPACITY;
     if (!ctx->pyr_valid[ref_slot] || !ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
-    int rc = ygz_track_set_pairs(ctx, &cur_slot, &ref_slot, T_cur, T_ref, 1);
-    if (rc != YGZ_OK) return rc;
+    // everything the call uploads -- the pair tables and the reference features -- as ONE packed transfer + one scatter kernel (ygz_pack_*: nine
+    // copies on the stream before), the 16 result doubles back into the page-locked arena: one wait per call
     const size_t N = (size_t)n;
-    // inputs through the page-locked arena (no wait before the launch: the slices live until the next ygz_hip_synchronize), the 16 result
-    // doubles back into it: ONE wait per call instead of two around five pageable copies
-    uint8_t *st = (uint8_t *)ygz_stage(ctx, N * 25 + 64 + 56 + 8 + 128);
-    if (!st) return YGZ_E_HIP;
-    double *h_px = (double *)st, *h_dep = h_px + 2 * N, *h_T = h_dep + N, *h_out = h_T + 7;
-    int32_t *h_n = (int32_t *)(h_out + 16);
-    uint8_t *h_mp = (uint8_t *)(h_n + 2);
+    YgzPack pk;
+    int rc = ygz_pack_begin(ctx, &pk, N * 25 + 64 + 14 * 8 + 16 + (size_t)ctx->prm.max_frames * 8 + 64, SCR_GEN_0 + 6);
+    if (rc != YGZ_OK) return rc;
+    if ((rc = ygz_track_set_pairs(ctx, &cur_slot, &ref_slot, T_cur, T_ref, 1, &pk)) != YGZ_OK) return rc;
+    double *h_px = (double *)ygz_pack_add(&pk, ctx->trk_px, N * 16), *h_dep = (double *)ygz_pack_add(&pk, ctx->trk_depth, N * 8);
+    uint8_t *h_mp = (uint8_t *)ygz_pack_add(&pk, ctx->trk_has_mp, N);
+    int32_t *h_n = (int32_t *)ygz_pack_add(&pk, ctx->trk_n, 4);
+    double *h_T = (double *)ygz_pack_add(&pk, ctx->sa_out, 7 * 8);
+    if (!h_px || !h_dep || !h_mp || !h_n || !h_T) return YGZ_E_CAPACITY;
     memcpy(h_px, px, N * 16); memcpy(h_dep, depth, N * 8); memcpy(h_mp, has_mappoint, N); memcpy(h_T, T_cur, 56); *h_n = n;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_px, h_px, N * 16, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_depth, h_dep, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_has_mp, h_mp, N, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->trk_n, h_n, 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->sa_out, h_T, 7 * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ygz_pack_upload(ctx, &pk)) != YGZ_OK) return rc;
+    double *h_out = (double *)ygz_stage(ctx, 16 * 8);
+    if (!h_out) return YGZ_E_HIP;
     ctx->sa_n_hint = n;
     rc = ygz_launch_sparse_align(ctx, 1, max_level, min_level, n_iter);
     ctx->sa_n_hint = 0;

@@ -37,7 +37,7 @@ int ygz_track_ensure(ygz_hip_ctx *ctx)
 }
 
 int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
-                        const double *T_ref, int n_pairs)
+                        const double *T_ref, int n_pairs, YgzPack *pk)
 {
     if (ctx) { int rj_ = ygz_join(ctx); if (rj_ != YGZ_OK) return rj_; }
     if (n_pairs < 1 || n_pairs > ctx->prm.max_frames) return YGZ_E_CAPACITY;
@@ -47,16 +47,26 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
     if (rc != YGZ_OK) return rc;
     const int F = ctx->prm.max_frames;
     // page-locked copies of the caller's tables (ygz_stage): no wait for the stream, the call can be enqueued behind running work
-    uint8_t *st = (uint8_t *)ygz_stage(ctx, (size_t)n_pairs * (8 + 14 * 8) + (size_t)F * 8);
-    if (!st) return YGZ_E_HIP;
-    int32_t *h_q = (int32_t *)st, *h_t = h_q + n_pairs, *h_lst = h_t + n_pairs;
-    double *T = (double *)(st + (((size_t)n_pairs * 8 + (size_t)F * 8 + 7) & ~(size_t)7));
+    if (!ctx->klt_slots) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_slots, (size_t)F * 8));
+    int32_t *h_q, *h_t, *h_lst; double *T;
+    if (pk) {                                                    // slices of the caller's packed upload (a single-frame call: one transfer for everything)
+        h_q = (int32_t *)ygz_pack_add(pk, ctx->pair_q, (size_t)n_pairs * 4); h_t = (int32_t *)ygz_pack_add(pk, ctx->pair_t, (size_t)n_pairs * 4);
+        T = (double *)ygz_pack_add(pk, ctx->pair_T, (size_t)n_pairs * 14 * 8); h_lst = (int32_t *)ygz_pack_add(pk, ctx->klt_slots, (size_t)F * 8);
+        if (!h_q || !h_t || !T || !h_lst) return YGZ_E_CAPACITY;
+    } else {
+        uint8_t *st = (uint8_t *)ygz_stage(ctx, (size_t)n_pairs * (8 + 14 * 8) + (size_t)F * 8);
+        if (!st) return YGZ_E_HIP;
+        h_q = (int32_t *)st; h_t = h_q + n_pairs; h_lst = h_t + n_pairs;
+        T = (double *)(st + (((size_t)n_pairs * 8 + (size_t)F * 8 + 7) & ~(size_t)7));
+    }
     memcpy(h_q, cur_slot, (size_t)n_pairs * 4); memcpy(h_t, ref_slot, (size_t)n_pairs * 4);
     for (int i = 0; i < n_pairs; ++i)
         for (int k = 0; k < 7; ++k) { T[14 * i + k] = T_ref[7 * i + k]; T[14 * i + 7 + k] = T_cur[7 * i + k]; }
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, h_q, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, h_t, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_T, T, (size_t)n_pairs * 14 * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!pk) {
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_q, h_q, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_t, h_t, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+        YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->pair_T, T, (size_t)n_pairs * 14 * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     {   // distinct slots of the table (a frame is usually the current frame of one pair and the reference of the next): the
         // tracker prepares its working images once per slot
         std::vector<uint8_t> any(F, 0), isref(F, 0);
@@ -66,8 +76,7 @@ int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t
         ctx->n_klt_slots = n;
         for (int s = 0; s < F; ++s) if (isref[s]) h_lst[n++] = s;
         ctx->n_klt_refs = n - ctx->n_klt_slots;
-        if (!ctx->klt_slots) YGZ_HIPCHK(ctx, hipMalloc((void **)&ctx->klt_slots, (size_t)F * 8));
-        if (n > 0) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_slots, h_lst, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (n > 0 && !pk) YGZ_HIPCHK(ctx, hipMemcpyAsync(ctx->klt_slots, h_lst, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         ctx->klt_slots_host.assign(h_lst, h_lst + ctx->n_klt_slots);
     }
     ctx->n_pairs = n_pairs;

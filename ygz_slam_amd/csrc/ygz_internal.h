@@ -191,6 +191,17 @@ int ygz_scratch(ygz_hip_ctx *ctx, int id, size_t bytes, void **out);
 int ygz_scratch_mirror(ygz_hip_ctx *ctx, int id, void **host);
 // `bytes` of page-locked host memory that stay valid until the next ygz_hip_synchronize (nullptr: allocation failed)
 void *ygz_stage(ygz_hip_ctx *ctx, size_t bytes);
+// Several small arrays of a single-frame call in ONE transfer: the host fills slices of a page-locked block (ygz_pack_add returns the slice of a
+// device destination), ygz_pack_upload copies the block to a device staging area and ONE kernel scatters the slices; ygz_pack_fetch is the mirror
+// image for results (one gather kernel, one copy back; the caller waits and reads the slices).  A pageable or even page-locked hipMemcpyAsync per
+// array is a blit kernel of ~4 us on the stream each: the nine of a single-frame sparse alignment were 36 us in front of a 300 us kernel.
+#define YGZ_PACK_MAX 12
+struct YgzPackSegs { const uint8_t *src[YGZ_PACK_MAX]; uint8_t *dst[YGZ_PACK_MAX]; uint32_t bytes[YGZ_PACK_MAX]; int n; };
+struct YgzPack { uint8_t *host = nullptr, *dev = nullptr; size_t used = 0, cap = 0; YgzPackSegs segs; };
+int   ygz_pack_begin(ygz_hip_ctx *ctx, YgzPack *pk, size_t capacity_bytes, int scratch_id);
+void *ygz_pack_add(YgzPack *pk, const void *device_ptr, size_t bytes);        // the host slice of that device array (nullptr: full)
+int   ygz_pack_upload(ygz_hip_ctx *ctx, YgzPack *pk);                          // host slices -> their device arrays (asynchronous)
+int   ygz_pack_fetch(ygz_hip_ctx *ctx, YgzPack *pk);                           // device arrays -> host slices (asynchronous: synchronise before reading)
 // the brute-force matcher over descriptor sets desc + s * set_stride (u32 units), sizes set_count[s], pairs (pair_q[p], pair_t[p]): device
 // arrays; results in ctx->m_idx / m_dist [n_pairs][cells] (hamming.hip)
 int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, const int32_t *set_count, const int32_t *pair_q,
@@ -229,8 +240,9 @@ int ygz_launch_gray_pyramid(ygz_hip_ctx *ctx, int slot_begin, int n_slots, int f
 int ygz_launch_detect(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
 int ygz_launch_describe(ygz_hip_ctx *ctx, int slot_begin, int n_slots);
 int ygz_track_ensure(ygz_hip_ctx *ctx);                      // allocates the resident tracking state
+struct YgzPack;
 int ygz_track_set_pairs(ygz_hip_ctx *ctx, const int32_t *cur_slot, const int32_t *ref_slot, const double *T_cur,
-                        const double *T_ref, int n_pairs);
+                        const double *T_ref, int n_pairs, YgzPack *pk = nullptr);      // pk: the tables join the caller's packed upload instead of being copied one by one
 int ygz_launch_klt(ygz_hip_ctx *ctx, int n_pairs, const ygz_klt_params *prm);
 int ygz_klt_prepare_early(ygz_hip_ctx *ctx);
 int ygz_launch_fdp(ygz_hip_ctx *ctx, int n_pairs);
