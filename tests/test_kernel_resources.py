@@ -21,7 +21,7 @@ BUDGET = {
     "k_klt_pad": ("klt", 8, 0),
     "k_hamming_f4ILi2E": ("hamming", 3, 0),        # the default matcher: 162 VGPRs, accumulators in VGPRs
     "k_sparse_align2ILi256EE": ("sparse_align", 1, 0),      # the batch form: 256 + <= 72 registers (more, and the matcher no longer fits beside it in the step)
-    "k_sparse_align2ILi512EE": ("sparse_align", 2, 384),    # 720p problems and single-frame calls: capped at 256 registers per lane
+    "k_sparse_align2ILi512EE": ("sparse_align", 2, 288),    # 720p problems and single-frame calls: capped at 256 registers per lane
     "k_fast_select": ("detect", 5, 0),            # two wavefronts per 64 x 32 tile, 15 KB of LDS: ten tiles per CU (measured faster than four wavefronts at eight per SIMD)
     "k_describeILi8E": ("detect", 7, 0),          # batches: eight keypoints per wavefront (the pattern pairs stay in registers)
     "k_describeILi1E": ("detect", 8, 0),          # single-frame calls
