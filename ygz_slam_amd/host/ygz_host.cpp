@@ -774,6 +774,24 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     for (Frame *frame : local_keyframes) add_pose(frame, frame->_keyframe_id == 0);
     std::vector<MapPoint *> pts; std::vector<double> points;
     std::vector<int32_t> edge_pose, edge_point; std::vector<double> obs; std::vector<Feature *> features;
+    // keyframe id -> vertex, resolved once per keyframe (a window has a handful): per edge the reference walks three trees (Memory::GetKeyFrame,
+    // local_keyframes.find, the vertex map) -- 9000 look-ups per local BA of the surface loop
+    struct KfSeen { unsigned long id; int vertex; };
+    std::vector<KfSeen> seen;
+    auto vertex_of = [&](unsigned long kf_id) {
+        for (const KfSeen &k : seen) if (k.id == kf_id) return k.vertex;
+        Frame *frame = Memory::GetKeyFrame(kf_id);
+        assert(frame != nullptr);
+        if (local_keyframes.find(frame) == local_keyframes.end()) {
+            // keyframes that see local map points but are not local: fixed (BA.cpp:458-477)
+            auto it = pose_index.find(frame->_keyframe_id);
+            if (it == pose_index.end()) add_pose(frame, true);
+            else fixed[it->second] = 1;
+        }
+        const int v = pose_index[frame->_keyframe_id];
+        seen.push_back({ kf_id, v });
+        return v;
+    };
     for (MapPoint *mp : local_map_points) {
         if (mp->_bad) continue;
         const int il = (int)pts.size();
@@ -781,15 +799,7 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
         for (int i = 0; i < 3; ++i) points.push_back(mp->_pos_world[i]);
         for (auto &obs_pair : mp->_obs) {
             if (obs_pair.second->_bad) continue;
-            Frame *frame = Memory::GetKeyFrame(obs_pair.first);
-            assert(frame != nullptr);
-            if (local_keyframes.find(frame) == local_keyframes.end()) {
-                // keyframes that see local map points but are not local: fixed (BA.cpp:458-477)
-                auto it = pose_index.find(frame->_keyframe_id);
-                if (it == pose_index.end()) add_pose(frame, true);
-                else fixed[it->second] = 1;
-            }
-            edge_pose.push_back(pose_index[frame->_keyframe_id]);
+            edge_pose.push_back(vertex_of(obs_pair.first));
             edge_point.push_back(il);
             obs.push_back(obs_pair.second->_pixel[0]); obs.push_back(obs_pair.second->_pixel[1]);
             features.push_back(obs_pair.second);
