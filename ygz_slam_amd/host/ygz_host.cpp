@@ -289,8 +289,10 @@ void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
         for (int k = 0; k < cells; ++k) occ[k] = _old_features[k] ? 1 : 0;
     }
     hip::check(ygz_hip_detect(c, slot, 1, occ.empty() ? nullptr : occ.data()), "detect");
-    std::vector<double> px(2 * (size_t)cells); std::vector<int32_t> lvl(cells); std::vector<float> sc(cells), ang(cells);
-    std::vector<uint8_t> desc(32 * (size_t)cells);
+    // (result buffers of a whole grid, kept between calls: 180 KB that would otherwise be allocated and zeroed per frame)
+    static thread_local std::vector<double> px; static thread_local std::vector<int32_t> lvl; static thread_local std::vector<float> sc, ang;
+    static thread_local std::vector<uint8_t> desc;
+    if ((int)lvl.size() < cells) { px.resize(2 * (size_t)cells); lvl.resize(cells); sc.resize(cells); ang.resize(cells); desc.resize(32 * (size_t)cells); }
     ygz_kpt_soa soa = { px.data(), lvl.data(), sc.data(), ang.data(), desc.data() };
     int n = 0;
     hip::check(ygz_hip_get_keypoints(c, slot, &soa, cells, &n), "get_keypoints");
