@@ -311,22 +311,25 @@ def surface_sequence(n):
     return bgr, kfd, seq.poses.copy()
 
 
-def surface_gpu(bgr, kfd):
-    """tests/cpp/bench_surface.cpp through ctypes: the reference-shaped loop over the ygz:: class surfaces (libygz_host.so), one frame at a time"""
+def surface_gpu(bgr, kfd, caller=0):
+    """tests/cpp/bench_surface.cpp through ctypes: the reference-shaped loop over the ygz:: class surfaces (libygz_host.so), one frame at a time.
+    caller 0: TrackLocalMap through the batch method Matcher::ProjectMapPoints; 1: through reference-named methods only (FindCandidates + one
+    Matcher::FindDirectProjection per candidate, LocalMapping.cpp:47-120); 2: as 1 without the speculative launch; 3: as 1, every call verified."""
     import ctypes as C
     from ygz_slam_amd import _lib
     _lib.load()
     lib = C.CDLL(os.path.join(ROOT, "tests", "cpp", "libbench_surface.so"))
     n = len(bgr)
     nk = len(kfd)
-    ms = np.zeros(n); T = np.zeros((n, 7)); cnt = np.zeros((n, 4), np.int32); ba = np.zeros((nk, 4)); stage = np.zeros(8)
+    ms = np.zeros(n); T = np.zeros((n, 7)); cnt = np.zeros((n, 4), np.int32); ba = np.zeros((nk, 4)); stage = np.zeros(8); memo = np.zeros(6)
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    rc = lib.ygz_bench_surface(p(bgr, C.c_uint8), p(kfd, C.c_float), n, W, H, SURF_KF_STRIDE, SURF_LOCAL_KFS, p(ms, C.c_double), p(T, C.c_double),
-                               p(cnt, C.c_int32), p(ba, C.c_double), p(stage, C.c_double))
+    rc = lib.ygz_bench_surface2(p(bgr, C.c_uint8), p(kfd, C.c_float), n, W, H, SURF_KF_STRIDE, SURF_LOCAL_KFS, int(caller), p(ms, C.c_double), p(T, C.c_double),
+                                p(cnt, C.c_int32), p(ba, C.c_double), p(stage, C.c_double), p(memo, C.c_double))
     if rc != 0:
         raise RuntimeError("ygz_bench_surface failed")
     names = ("InitFrame", "SparseImageAlignment", "ProjectMapPoints", "OptimizeCurrentPoseOnly", "Detect", "keyframe bookkeeping", "LocalBAG2O", "delete frame")
-    return dict(ms=ms, T=T, counts=cnt, ba=ba, stage_ms_per_frame={k: float(v) / n for k, v in zip(names, stage)})
+    return dict(ms=ms, T=T, counts=cnt, ba=ba, stage_ms_per_frame={k: float(v) / n for k, v in zip(names, stage)},
+                memo=dict(zip(("hits", "single", "launches", "speculated", "calls", "mismatches"), (int(x) for x in memo))))
 
 
 def surface_cpu(bgr, kfd, budget_s=14.0):
@@ -456,6 +459,28 @@ def surface_block(n_frames=204, cpu_budget_s=14.0, want_cpu=True):
            "local_ba_ms_median": float(np.median(g["ba"][g["ba"][:, 3] > 0, 3])) if (g["ba"][:, 3] > 0).any() else None,
            "mean_map_points_aligned_projected_inliers_features": [float(v) for v in g["counts"][1:].mean(0)],
            "max_abs_pose_error_vs_ground_truth": float(np.abs(g["T"] - gt0).max())}
+    # the same loop with TrackLocalMap written the way the reference's UNCHANGED caller performs it -- LocalMapping::FindCandidates + one
+    # Matcher::FindDirectProjection per candidate (src/Module/LocalMapping.cpp:47-120), reference-named methods only -- and, on fewer frames, what
+    # those calls cost as one n = 1 launch each (the speculative launch behind FindDirectProjection switched off)
+    u = surface_gpu(bgr, kfd, caller=1)
+    ums = u["ms"][1:]
+    n1 = min(n_frames, 5 * SURF_KF_STRIDE + 1)
+    s1 = surface_gpu(bgr[:n1], kfd[:(n1 + SURF_KF_STRIDE - 1) // SURF_KF_STRIDE], caller=2)
+    out["unchanged"] = {"what": "TrackLocalMap as src/Module/LocalMapping.cpp:47-120 has it: FindCandidates, then Matcher::FindDirectProjection(ref, curr, MapPoint*, px, level) "
+                                "once per candidate; the first call of a frame that misses runs one speculative launch over the candidates of the keyframes in use and "
+                                "the calls that follow are answered from it when their inputs are bit-equal (ygz_host.cpp: FdpMemo)",
+                        "frames_per_s": float((n_frames - 1) / (ums.sum() * 1e-3)),
+                        "ms_per_frame": {"median": float(np.median(ums)), "median_plain_frame": float(np.median(ums[~kf])), "median_keyframe": float(np.median(ums[kf]))},
+                        "host_ms_per_frame_by_surface_call": u["stage_ms_per_frame"],
+                        "find_direct_projection_calls_per_frame": u["memo"]["calls"] / float(n_frames - 1),
+                        "answered_from_the_speculative_launch": u["memo"]["hits"], "n1_launches": u["memo"]["single"],
+                        "speculative_launches_per_frame": u["memo"]["launches"] / float(n_frames - 1),
+                        "candidates_evaluated_per_frame": u["memo"]["speculated"] / float(n_frames - 1),
+                        "mean_map_points_aligned_projected_inliers_features": [float(v) for v in u["counts"][1:].mean(0)],
+                        "max_abs_pose_error_vs_ground_truth": float(np.abs(u["T"] - gt0).max()),
+                        "every_call_its_own_launch": {"frames": int(n1), "frames_per_s": float((n1 - 1) / (s1["ms"][1:].sum() * 1e-3)),
+                                                      "ms_per_frame_median": float(np.median(s1["ms"][1:])),
+                                                      "ProjectMapPoints_ms_per_frame": s1["stage_ms_per_frame"]["ProjectMapPoints"]}}
     if want_cpu:
         c = surface_cpu(bgr, kfd, cpu_budget_s)
         m = len(c["ms"])
@@ -466,6 +491,7 @@ def surface_block(n_frames=204, cpu_budget_s=14.0, want_cpu=True):
                                        "max_abs_pose_error_vs_ground_truth": float(np.abs(c["T"] - gt0[:m]).max()),
                                        "max_abs_pose_difference_gpu_vs_oracle": float(np.abs(c["T"] - g["T"][:m]).max())}
         out["vs_cpu_1core"] = out["frames_per_s"] / out["cpu_oracle_same_loop"]["frames_per_s"]
+        out["unchanged"]["vs_cpu_1core"] = out["unchanged"]["frames_per_s"] / out["cpu_oracle_same_loop"]["frames_per_s"]
     return out
 
 

@@ -1,5 +1,5 @@
-// ygz::Frame -- the hot-path part of include/ygz/Basic/Frame.h:20-166 (the covisibility graph is out of scope,
-// SURVEY 2.1 #1).  InitFrame() uploads the image to an HBM slot of the process-wide ygz_hip context and
+// ygz::Frame -- include/ygz/Basic/Frame.h:20-166: the hot-path part, and (round 6) the covisibility members src/Module reads
+// (UpdateConnections, GetBestCovisibilityKeyframes, ...: host bookkeeping over std::map, src/Basic/Frame.cpp:73-176).  InitFrame() uploads the image to an HBM slot of the process-wide ygz_hip context and
 // builds the pyramid on the GPU.  _pyramid keeps the reference's spelling (_pyramid[L], .size(), .empty()): it is
 // a LAZY host mirror -- level L crosses PCIe the first time somebody indexes it (round 5: InitFrame used to
 // drag all levels, 400 KB per VGA frame, back to the host whether or not anybody read them).
@@ -51,6 +51,11 @@ struct Frame {
           && pixel[1] / (1 << level) >= boarder && pixel[1] / (1 << level) < _color.rows - boarder; }
     Vector3d GetCamCenter() const { return _TCW.inverse().translation(); }
     bool GetMeanAndMinDepth(double &mean_depth, double &min_depth);      // src/Basic/Frame.cpp:42-72
+    vector<Frame *> GetBestCovisibilityKeyframes(const int &N = 10);     // src/Basic/Frame.cpp:73-78: the first N of _cov_keyframes
+    bool IsInFrustum(MapPoint *mp, float viewingCosLimit = 0.5);         // src/Basic/Frame.cpp:80-84 (always true in the reference)
+    void AddConnection(Frame *kf, const int &weight);                    // src/Basic/Frame.cpp:154-160
+    void UpdateConnections();                                            // src/Basic/Frame.cpp:86-152
+    void UpdateBestCovisibles();                                         // src/Basic/Frame.cpp:162-176
     cv::Mat GetAllDescriptors();                                // src/Basic/Frame.cpp:178-188
     void CleanAllFeatures();                                    // src/Basic/Frame.cpp:203-210
     unsigned long _id = 0, _keyframe_id = 0;
@@ -66,6 +71,9 @@ struct Frame {
     DBoW3::FeatureVector _feature_vec;
     Frame *_ref_keyframe = nullptr;
     bool   _bad = false;
+    map<Frame *, int> _connected_keyframe_weights;      // keyframes that share map points with this one -> number shared (Frame.h:147)
+    vector<Frame *> _cov_keyframes;                     // the same, heaviest first (Frame.h:150-151)
+    vector<int> _cov_weights;
     int    _hip_slot = -1;                  // HBM slot of this frame (managed by ygz::hip::Runtime)
     void CreateImagePyramid();              // fetches every level into the host mirror now
 };

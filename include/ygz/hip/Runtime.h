@@ -25,7 +25,17 @@ private:
     struct Impl;
     Impl *p_;
 };
-void check(int rc, const char *what);
+// status of an ABI call, the reference's way (SURVEY 8b "error conventions": bool / count returns and a glog line, no exceptions): YGZ_OK -> true;
+// anything else -> LOG(ERROR) with the ABI's message and false, and the surface that called returns its failure value (false / 0 / unchanged
+// outputs).  Only a missing device -- there is no CPU path to fall back to -- throws (Runtime::ctx).
+bool check(int rc, const char *what);
+// Matcher::FindDirectProjection behind per-candidate callers (ygz_host.cpp: FdpMemo): one speculative launch per current frame, answers handed out
+// only on bit-equal inputs.  Environment YGZ_FDP_MEMO=0 (or SetFdpSpeculation(false)) makes every call its own n = 1 launch.
+struct FdpMemoStats { unsigned long long hits = 0, single = 0, launches = 0, speculated = 0; };
+void SetFdpSpeculation(bool on);
+void SetFdpBypass(bool on);             // true: calls take their own n = 1 launch and leave the memo as it is (to compare the two inside one loop)
+FdpMemoStats GetFdpMemoStats();
+void ResetFdpMemoStats();
 }
 }
 #endif

@@ -201,6 +201,20 @@ typedef struct {
 int  ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
                              uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level,
                              int32_t *n_matched);
+/* ---- the call the reference's UNCHANGED caller makes: bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector2d &px_curr,
+ * int &search_level) (src/Algorithm/Matcher.cpp:356-383), once per candidate from LocalMapping::ProjectMapPoints (src/Module/LocalMapping.cpp:88-118).
+ * n independent candidates over K resident reference keyframes in ONE launch, every candidate evaluated (no first-success rule): candidate i =
+ * map point pos_world[i] seen in keyframe cand_kf[i] at px_ref[i] / level_ref[i] (the Feature mp->_obs[ref->_keyframe_id]); depth =
+ * World2Camera(pos_world, ref->_TCW)[2], sign not tested (as the reference).  px_in [n][2]: the caller's predictions; NULL: the prediction is
+ * LocalMapping::FindCandidates' projection Camera2Pixel(World2Camera(pos_world, T_cur)) (LocalMapping.cpp:58-59), written to px_proj [n][2] with
+ * in_view [n] = !(z < 0) && InFrame(px, 20); candidates out of view are not evaluated (ok = 0, px_cur undefined).  ok [n] = the bool returned,
+ * px_cur [n][2] = refined pixel (level 0), search_level [n].  Host arrays; synchronises.  The class surface memoises one such launch per
+ * current frame behind the per-candidate method (ygz_host.cpp: FdpMemo), bit-identical to n = 1 calls. */
+int  ygz_hip_find_direct_projection_mp(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], int n_keyframes, const int32_t *kf_slot,
+                                       const double *kf_T /*[K][7]*/, int n, const int32_t *cand_kf, const double *pos_world /*[n][3]*/,
+                                       const double *px_ref, const int32_t *level_ref, const double *px_in /*or NULL*/,
+                                       uint8_t *in_view /*may be NULL with px_in*/, double *px_proj /*may be NULL with px_in*/,
+                                       uint8_t *ok, double *px_cur, int32_t *search_level);
 /* bare cvutils::Align2D on host-provided patches against level `level` of `cur_slot`:
  * pwb [n][100], patch [n][64], uv [n][2] in/out (level pixels), ok [n], chi2 [n] (may be NULL) */
 int  ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pwb, const uint8_t *patch,

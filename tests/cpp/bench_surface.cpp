@@ -15,12 +15,71 @@
 // on the same loop for the CPU side.  This file is test / bench infrastructure: the product is libygz_host.so behind the headers it includes.
 #include "ygz/Basic.h"
 #include "ygz/Algorithm.h"
+#include "ygz/hip/Runtime.h"
 #include <chrono>
 #include <deque>
 using namespace ygz;
 
 namespace {
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- TrackLocalMap's first two steps the way the reference's UNCHANGED caller performs them: LocalMapping::FindCandidates and
+// LocalMapping::ProjectMapPoints (src/Module/LocalMapping.cpp:47-120), with reference-named methods only -- one Matcher::FindDirectProjection
+// (MapPoint overload) per candidate.  Same containers as the caller: candidates in a std::map keyed by Feature* (visited in heap-address order),
+// the matched map points in a std::set.
+struct UnchangedCaller {
+    Matcher *_matcher;
+    std::set<Frame *> *_local_keyframes;
+    std::set<MapPoint *> *_local_map_points;
+    bool _verify = false;                                 // every FindDirectProjection call repeated as its own n = 1 launch and compared bit for bit
+    long _calls = 0, _mismatches = 0;
+
+    std::map<Feature *, Vector2d> FindCandidates(Frame *current)
+    {
+        std::map<Feature *, Vector2d> candidates;
+        for (MapPoint *map_point : *_local_map_points) {
+            if (map_point->_bad) continue;
+            const Vector3d pt_curr = current->_camera->World2Camera(map_point->_pos_world, current->_TCW);
+            const Vector2d px_curr = current->_camera->Camera2Pixel(pt_curr);
+            if (pt_curr[2] < 0 || !current->InFrame(px_curr, 20)) { map_point->_track_in_view = false; continue; }
+            map_point->_cnt_visible++;
+            for (auto &obs_pair : map_point->_obs)
+                if (_local_keyframes->find(obs_pair.second->_frame) != _local_keyframes->end()) candidates[obs_pair.second] = px_curr;
+        }
+        return candidates;
+    }
+    int ProjectMapPoints(Frame *current, std::map<Feature *, Vector2d> &candidates)
+    {
+        std::set<MapPoint *> matched_mps;
+        for (auto &candidate : candidates) {
+            MapPoint *mp = candidate.first->_mappoint;
+            if (matched_mps.find(mp) != matched_mps.end()) continue;
+            int level = 0;
+            const Vector2d px_in = candidate.second;
+            const bool ret = _matcher->FindDirectProjection(candidate.first->_frame, current, mp, candidate.second, level);
+            ++_calls;
+            if (_verify) {
+                Vector2d px2 = px_in; int level2 = 0;
+                hip::SetFdpBypass(true);
+                const bool ret2 = _matcher->FindDirectProjection(candidate.first->_frame, current, mp, px2, level2);
+                hip::SetFdpBypass(false);
+                if (ret2 != ret || level2 != level || memcmp(px2.data(), candidate.second.data(), 16) != 0) ++_mismatches;
+            }
+            if (!ret) continue;
+            matched_mps.insert(mp);
+            Feature *feature = new Feature(candidate.second, level, candidate.first->_score);
+            feature->_frame = current;
+            feature->_mappoint = mp;
+            current->_features.push_back(feature);
+        }
+        return (int)matched_mps.size();
+    }
+    int TrackLocalMap(Frame *current)                     // LocalMapping.cpp:24-33 (the pose-only BA that follows is the loop's next stage)
+    {
+        std::map<Feature *, Vector2d> candidates = FindCandidates(current);
+        return ProjectMapPoints(current, candidates);
+    }
+};
 }
 
 extern "C" {
@@ -32,8 +91,14 @@ extern "C" {
 // Returns 0, or 1 when an exception crossed a surface (message on stderr).
 // stage_ms [8] (may be NULL): host clock summed over the frames: InitFrame, SparseImageAlignment, ProjectMapPoints, OptimizeCurrentPoseOnly, Detect,
 // keyframe bookkeeping, LocalBAG2O, frame deletion.
-int ygz_bench_surface(const uint8_t *bgr, const float *kf_depth, int n, int w, int h, int kf_stride, int local_kfs, double *ms, double *T_out,
-                      int32_t *counts, double *ba, double *stage_ms)
+// caller: 0 = TrackLocalMap through the batch method Matcher::ProjectMapPoints (one launch; a method the reference does not have);
+//         1 = through reference-named methods only: FindCandidates + one Matcher::FindDirectProjection per candidate (UnchangedCaller above);
+//         2 = as 1 with the speculative launch behind FindDirectProjection switched off (every call its own n = 1 launch);
+//         3 = as 1, and every call is repeated as its own n = 1 launch and compared bit for bit (memo [5] counts the differences).
+// memo [6] (may be NULL): FindDirectProjection calls answered from the speculative launch, calls that took an n = 1 launch, speculative launches,
+// candidates they evaluated, calls the caller made, calls whose memoised answer differed from the n = 1 launch (caller 3).
+int ygz_bench_surface2(const uint8_t *bgr, const float *kf_depth, int n, int w, int h, int kf_stride, int local_kfs, int caller, double *ms, double *T_out,
+                       int32_t *counts, double *ba, double *stage_ms, double *memo)
 {
     double st_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #define STAGE(k, code) { const double ts_ = now_ms(); code; st_[k] += now_ms() - ts_; }
@@ -44,12 +109,17 @@ int ygz_bench_surface(const uint8_t *bgr, const float *kf_depth, int n, int w, i
         FeatureDetector detector;
         detector.LoadParams();
         Matcher matcher;
+        UnchangedCaller lm = { &matcher, nullptr, nullptr };
+        lm._verify = caller == 3;
+        hip::SetFdpSpeculation(caller != 2);
+        hip::ResetFdpMemoStats();
         Memory::Clean();
         std::deque<Frame *> kf_order;
         std::vector<Frame *> all_kfs;
         std::vector<MapPoint *> all_mps;
         std::set<Frame *> local_keyframes;
         std::set<MapPoint *> local_map_points;
+        lm._local_keyframes = &local_keyframes; lm._local_map_points = &local_map_points;
         Frame *ref = nullptr;
         const size_t fb = (size_t)w * h * 3;
         for (int i = 0; i < n; ++i) {
@@ -63,7 +133,8 @@ int ygz_bench_surface(const uint8_t *bgr, const float *kf_depth, int n, int w, i
                 cur->_TCW = ref->_TCW;                                             // VisualOdometry.cpp:66
                 for (Feature *f : ref->_features) n_sa += f->_mappoint != nullptr;
                 STAGE(1, matcher.SparseImageAlignment(ref, cur))                   // TrackRefFrame
-                STAGE(2, n_proj = matcher.ProjectMapPoints(cur, local_keyframes, local_map_points))      // TrackLocalMap: FindCandidates + ProjectMapPoints
+                if (caller == 0) STAGE(2, n_proj = matcher.ProjectMapPoints(cur, local_keyframes, local_map_points))      // TrackLocalMap: FindCandidates + ProjectMapPoints
+                else STAGE(2, n_proj = lm.TrackLocalMap(cur))
                 if (!cur->_features.empty()) STAGE(3, ba::OptimizeCurrentPoseOnly(cur))     // LocalMapping::OptimizeCurrent
                 // an outlier of the pose-only BA stops being an observation of its map point (the reference keeps the pointer and a depth of -1,
                 // which its next SparseImageAlignment would back-project: Feature.h:23, SparseImageAlign.cpp:78-83)
@@ -123,11 +194,19 @@ int ygz_bench_surface(const uint8_t *bgr, const float *kf_depth, int n, int w, i
         Memory::Clean();
         Frame::SetCamera(nullptr);
         if (stage_ms) for (int k = 0; k < 8; ++k) stage_ms[k] = st_[k];
+        if (memo) { const hip::FdpMemoStats ms_ = hip::GetFdpMemoStats(); memo[0] = (double)ms_.hits; memo[1] = (double)ms_.single; memo[2] = (double)ms_.launches; memo[3] = (double)ms_.speculated;
+                    memo[4] = (double)lm._calls; memo[5] = (double)lm._mismatches; }
+        hip::SetFdpSpeculation(true);
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "ygz_bench_surface: %s\n", e.what());
+        hip::SetFdpSpeculation(true);
         return 1;
     }
 }
+
+int ygz_bench_surface(const uint8_t *bgr, const float *kf_depth, int n, int w, int h, int kf_stride, int local_kfs, double *ms, double *T_out,
+                      int32_t *counts, double *ba, double *stage_ms)
+{ return ygz_bench_surface2(bgr, kf_depth, n, w, h, kf_stride, local_kfs, 0, ms, T_out, counts, ba, stage_ms, nullptr); }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 // side can compare it with the oracle.  Usage: test_surface <in_dir> <out_file>
 #include "ygz/Basic.h"
 #include "ygz/Algorithm.h"
+#include "ygz/hip/Runtime.h"
 #include <fstream>
 #include <cstdio>
 using namespace ygz;
@@ -20,7 +21,44 @@ int main(int argc, char **argv)
         for (++i; i < argc; ++i) printf("%s %s %.17g\n", argv[i], Config::Raw(argv[i]).c_str(), Config::Get<double>(argv[i]));
         return 0;
     }
-    if (argc < 3) { fprintf(stderr, "usage: %s in_dir out_file | %s config [file] -- key ...\n", argv[0], argv[0]); return 2; }
+    if (argc >= 2 && std::string(argv[1]) == "covis") {
+        // `test_surface covis`: the covisibility members of ygz::Frame (src/Basic/Frame.cpp:73-176) on a hand-made map, no device.
+        // keyframes 0..3; keyframe 3 shares 20 map points with keyframe 0, 16 with keyframe 1, 5 with keyframe 2 (one of those bad -> 4 counted + ...)
+        Memory::Clean();
+        std::vector<Frame *> kf;
+        for (int i = 0; i < 4; ++i) { Frame *fr = new Frame; Memory::RegisterKeyFrame(fr); kf.push_back(fr); }
+        auto share = [&](int a, int b, int n, bool bad) {
+            for (int i = 0; i < n; ++i) {
+                MapPoint *mp = Memory::CreateMapPoint(); mp->_bad = bad;
+                for (int k : { a, b }) { Feature *fe = new Feature(Vector2d(10 + i, 20 + k)); fe->_frame = kf[k]; fe->_mappoint = mp; kf[k]->_features.push_back(fe); mp->_obs[kf[k]->_keyframe_id] = fe; }
+            }
+        };
+        share(3, 0, 20, false); share(3, 1, 16, false); share(3, 2, 5, false); share(3, 2, 7, true); share(2, 0, 3, false);
+        { Feature *lone = new Feature(Vector2d(1, 1)); lone->_frame = kf[3]; kf[3]->_features.push_back(lone); }      // no map point
+        kf[3]->UpdateConnections();
+        printf("kf3 cov");
+        for (size_t i = 0; i < kf[3]->_cov_keyframes.size(); ++i) printf(" %lu:%d", kf[3]->_cov_keyframes[i]->_keyframe_id, kf[3]->_cov_weights[i]);
+        printf(" | connected");
+        for (int i = 0; i < 4; ++i) if (kf[3]->_connected_keyframe_weights.count(kf[i])) printf(" %d:%d", i, kf[3]->_connected_keyframe_weights[kf[i]]);
+        printf(" | best1 %zu:%lu best10 %zu\n", kf[3]->GetBestCovisibilityKeyframes(1).size(), kf[3]->GetBestCovisibilityKeyframes(1)[0]->_keyframe_id,
+               kf[3]->GetBestCovisibilityKeyframes().size());
+        // keyframe 2: nothing reaches the threshold of 15 -> the single best neighbour is kept, and told (AddConnection)
+        kf[2]->UpdateConnections();
+        printf("kf2 cov");
+        for (size_t i = 0; i < kf[2]->_cov_keyframes.size(); ++i) printf(" %lu:%d", kf[2]->_cov_keyframes[i]->_keyframe_id, kf[2]->_cov_weights[i]);
+        printf(" | kf3 now sees kf2 with %d | in frustum %d\n", kf[3]->_connected_keyframe_weights[kf[2]], (int)kf[2]->IsInFrustum(nullptr));
+        // a second call replaces the sorted lists; UpdateBestCovisibles appends every connection, heaviest first
+        kf[3]->UpdateConnections();
+        const size_t n_before = kf[3]->_cov_keyframes.size();
+        kf[3]->UpdateBestCovisibles();
+        printf("kf3 again %zu then", n_before);
+        for (size_t i = n_before; i < kf[3]->_cov_keyframes.size(); ++i) printf(" %lu:%d", kf[3]->_cov_keyframes[i]->_keyframe_id, kf[3]->_cov_weights[i]);
+        Frame none;
+        none.UpdateConnections();
+        printf(" | empty %zu %zu\n", none._cov_keyframes.size(), none.GetBestCovisibilityKeyframes(5).size());
+        return 0;
+    }
+    if (argc < 3) { fprintf(stderr, "usage: %s in_dir out_file | %s config [file] -- key ... | %s covis\n", argv[0], argv[0], argv[0]); return 2; }
     const std::string in = argv[1];
     FILE *out = fopen(argv[2], "w");
     Config::SetParameterFile(in + "/default.yaml");
@@ -47,6 +85,25 @@ int main(int argc, char **argv)
             fprintf(out, "%.17g %.17g %d %.9g %.9g", fe->_pixel[0], fe->_pixel[1], fe->_level, fe->_score, fe->_angle);
             for (int k = 0; k < 32; ++k) fprintf(out, " %d", (int)fe->_desc.data[k]);
             fprintf(out, "\n");
+        }
+    }
+    // --- FeatureDetector::ComputeAngleAndDescriptor(Frame*) and ComputeDescriptor(Feature*) (FeatureDetector.cpp:580-594)
+    {
+        const size_t n = f[0]._features.size();
+        std::vector<double> ang(n); std::vector<std::array<uint8_t, 32>> desc(n);
+        for (size_t i = 0; i < n; ++i) { Feature *fe = f[0]._features[i]; ang[i] = fe->_angle; memcpy(desc[i].data(), fe->_desc.data, 32); fe->_angle = -1; memset(fe->_desc.data, 0, 32); }
+        detector.ComputeAngleAndDescriptor(&f[0]);
+        size_t same = 0;
+        for (size_t i = 0; i < n; ++i) { const Feature *fe = f[0]._features[i]; same += fe->_angle == ang[i] && memcmp(fe->_desc.data, desc[i].data(), 32) == 0; }
+        fprintf(out, "cad %zu %zu\n", same, n);
+        for (size_t i = 0; i < 40 && i < n; ++i) {              // the caller's own angle: the descriptor follows it, the angle stays
+            Feature *fe = f[0]._features[i];
+            fe->_angle = fmod(ang[i] + 33.25 * (double)(i + 1), 360.0);
+            detector.ComputeDescriptor(fe);
+            fprintf(out, "cd %zu %.17g", i, fe->_angle);
+            for (int k = 0; k < 32; ++k) fprintf(out, " %d", (int)fe->_desc.data[k]);
+            fprintf(out, "\n");
+            fe->_angle = ang[i]; memcpy(fe->_desc.data, desc[i].data(), 32);
         }
     }
     Matcher matcher;
@@ -141,6 +198,49 @@ int main(int argc, char **argv)
         for (size_t i = n_before; i < f[1]._features.size(); ++i) delete f[1]._features[i];
         f[1]._features.resize(n_before);
         mps[2]->_bad = false;
+    }
+    // --- the call LocalMapping::ProjectMapPoints makes once per candidate (LocalMapping.cpp:98): Matcher::FindDirectProjection, MapPoint overload,
+    // answered from ONE speculative launch -- against the same call as its own n = 1 launch, and (Python side) against Matcher::ProjectMapPoints above
+    {
+        hip::ResetFdpMemoStats();
+        for (MapPoint *mp : mps) {
+            const Vector3d pc = cam->World2Camera(mp->_pos_world, f[1]._TCW);
+            const Vector2d px_in = cam->Camera2Pixel(pc);
+            if (pc[2] < 0 || !f[1].InFrame(px_in, 20)) { fprintf(out, "fdpmp -1 0 0 0 -1 0 0 0\n"); continue; }      // FindCandidates drops it (:60-63)
+            Vector2d p1 = px_in, p2 = px_in; int l1 = 0, l2 = 0;
+            const bool o1 = matcher.FindDirectProjection(&f[0], &f[1], mp, p1, l1);
+            hip::SetFdpBypass(true);
+            const bool o2 = matcher.FindDirectProjection(&f[0], &f[1], mp, p2, l2);
+            hip::SetFdpBypass(false);
+            fprintf(out, "fdpmp %d %d %.17g %.17g %d %d %.17g %.17g\n", (int)o1, l1, p1[0], p1[1], (int)o2, l2, p2[0], p2[1]);
+        }
+        hip::FdpMemoStats st = hip::GetFdpMemoStats();
+        fprintf(out, "fdpmp_stats %llu %llu %llu %llu\n", st.hits, st.single, st.launches, st.speculated);
+        // inputs the speculation cannot have seen take the n = 1 launch: another prediction, a moved map point; then the keyframe moves (as after a
+        // local BA) and the frame is asked about again: a new speculative launch, no stale answer
+        MapPoint *mp = mps[5];
+        Vector2d pa = cam->World2Pixel(mp->_pos_world, f[1]._TCW) + Vector2d(0.75, -0.5), pb = pa; int la = 0, lb = 0;
+        const bool oa = matcher.FindDirectProjection(&f[0], &f[1], mp, pa, la);
+        hip::SetFdpBypass(true); const bool ob = matcher.FindDirectProjection(&f[0], &f[1], mp, pb, lb); hip::SetFdpBypass(false);
+        fprintf(out, "fdpmp_other %d %d %.17g %.17g %d %d %.17g %.17g\n", (int)oa, la, pa[0], pa[1], (int)ob, lb, pb[0], pb[1]);
+        const Vector3d keep = mp->_pos_world;
+        mp->_pos_world = keep + Vector3d(0.002, -0.001, 0.003);
+        pa = pb = cam->World2Pixel(mp->_pos_world, f[1]._TCW);
+        const bool oc = matcher.FindDirectProjection(&f[0], &f[1], mp, pa, la);
+        hip::SetFdpBypass(true); const bool od = matcher.FindDirectProjection(&f[0], &f[1], mp, pb, lb); hip::SetFdpBypass(false);
+        fprintf(out, "fdpmp_moved %d %d %.17g %.17g %d %d %.17g %.17g\n", (int)oc, la, pa[0], pa[1], (int)od, lb, pb[0], pb[1]);
+        mp->_pos_world = keep;
+        st = hip::GetFdpMemoStats();
+        const SE3 T0 = f[0]._TCW;
+        Vector6d d6; d6[0] = 1e-3; d6[4] = 5e-4;
+        f[0]._TCW = SE3::exp(d6) * T0;
+        pa = pb = cam->World2Pixel(mps[7]->_pos_world, f[1]._TCW);
+        const bool oe = matcher.FindDirectProjection(&f[0], &f[1], mps[7], pa, la);
+        hip::SetFdpBypass(true); const bool of = matcher.FindDirectProjection(&f[0], &f[1], mps[7], pb, lb); hip::SetFdpBypass(false);
+        const hip::FdpMemoStats st2 = hip::GetFdpMemoStats();
+        fprintf(out, "fdpmp_kfmoved %d %d %.17g %.17g %d %d %.17g %.17g %llu %llu %llu\n", (int)oe, la, pa[0], pa[1], (int)of, lb, pb[0], pb[1],
+                st.single, st2.launches - st.launches, st2.hits - st.hits);
+        f[0]._TCW = T0;
     }
     // cvutils::Align2D on a host patch against a pyramid level of frame 1
     { uint8_t pwb[100], patch[64];

@@ -112,3 +112,18 @@ def test_abi_version_is_checked_at_load(hip_lib):
     assert lib.ygz_hip_abi_version() == hip_lib.ABI_VERSION
     hdr = open(os.path.join(ROOT, "include", "ygz_hip.h")).read()
     assert int(re.search(r"#define YGZ_HIP_ABI_VERSION\s+(\d+)", hdr).group(1)) == hip_lib.ABI_VERSION
+
+
+def test_frame_covisibility_members():
+    """ygz::Frame::UpdateConnections / GetBestCovisibilityKeyframes / AddConnection / UpdateBestCovisibles (src/Basic/Frame.cpp:73-176; what
+    src/Module/LocalMapping.cpp:256,345,378,586 reads) on a hand-made map -- host bookkeeping, no device (tests/cpp/test_surface covis)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "test_surface")
+    assert os.path.exists(exe), "tests/cpp/test_surface is not built (run __graft_entry__.build())"
+    out = subprocess.check_output([exe, "covis"], timeout=60).decode().strip().split("\n")
+    # keyframe 3 shares 20 / 16 / 5 good map points with keyframes 0 / 1 / 2 (7 bad ones with keyframe 2 do not count): threshold 15, heaviest first
+    assert out[0] == "kf3 cov 0:20 1:16 | connected 0:20 1:16 2:5 | best1 1:0 best10 2"
+    # keyframe 2 (5 with keyframe 3, 3 with keyframe 0): below the threshold everywhere -> the single best neighbour, which is told about it
+    assert out[1] == "kf2 cov 3:5 | kf3 now sees kf2 with 5 | in frustum 1"
+    # a second UpdateConnections replaces the lists; UpdateBestCovisibles appends all connections, heaviest first; no map points: nothing
+    assert out[2] == "kf3 again 2 then 0:20 1:16 2:5 | empty 0 0"

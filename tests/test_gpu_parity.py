@@ -137,6 +137,89 @@ def test_describe_arbitrary_pixels(hip_lib, oracle):
     ctx.close()
 
 
+def test_find_direct_projection_per_candidate_bit_exact(hip_lib, oracle):
+    """ygz_hip_find_direct_projection_mp: the call LocalMapping::ProjectMapPoints makes once per candidate (Matcher::FindDirectProjection, MapPoint
+    overload, Matcher.cpp:356-383), n candidates over 3 keyframes in one launch, against the oracle one candidate at a time -- with the
+    FindCandidates projection made by the launch, with the caller's predictions, and as n = 1 calls (what the class surface falls back to)"""
+    imgs, poses, depths = _frames(4, 640, 480, seed=8, step=0.5)
+    rng = np.random.default_rng(4)
+    pos, cp, ck, cx, cl = _local_map_fixture(oracle, imgs, poses, depths, 3, 300, rng)
+    pos[3] = [0.0, 0.0, -5.0]; pos[4] = [50.0, 0.0, 2.0]
+    T_cur = oracle.se3_mul(synth.se3_exp([0.004, -0.003, 0.002, 0.001, -0.001, 0.0015]), poses[3])
+    ctx = make_ctx(hip_lib, max_frames=4)
+    for s in range(4):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 4)
+    lv = [oracle.pyramid(imgs[s], 3) for s in range(4)]
+    kfT = np.stack([poses[0], poses[1], poses[2]])
+    r = ctx.find_direct_projection_mp(3, T_cur, [0, 1, 2], kfT, ck, pos[cp], cx, cl)
+    # FindCandidates' projection and in-view test, per candidate (LocalMapping.cpp:58-63)
+    _, ovis, oproj, omatch, opxm, olvl = oracle.track_local_map(lv[:3], poses[:3], lv[3], T_cur, pos, None, cp, ck, cx, cl)
+    assert np.array_equal(r["in_view"], ovis[cp].astype(bool)) and not r["in_view"].all()
+    v = r["in_view"]
+    assert np.array_equal(r["px_proj"][v], oproj[cp][v])
+    assert not r["ok"][~v].any()
+    n_ok = 0
+    for c in np.nonzero(v)[0]:
+        o_ok, o_px, o_sl = oracle.find_direct_projection_mp(lv[ck[c]], poses[ck[c]], lv[3], T_cur, pos[cp[c]], cx[c], int(cl[c]), oproj[cp[c]])
+        assert bool(o_ok) == bool(r["ok"][c]) and o_sl == r["level"][c] and np.array_equal(np.asarray(o_px), r["px"][c]), c
+        n_ok += bool(o_ok)
+    assert 500 < n_ok < v.sum() - 500                                          # successes and failures both occur (sub-pixel offsets, other levels)
+    # the first success per point in candidate order is what ProjectMapPoints keeps
+    for p_ in np.unique(cp):
+        cs = np.nonzero((cp == p_) & r["ok"])[0]
+        assert omatch[p_] == (cs[0] if len(cs) else -1)
+        if len(cs):
+            assert np.array_equal(opxm[p_], r["px"][cs[0]]) and olvl[p_] == r["level"][cs[0]]
+    # the caller's predictions instead of the projection (they need not be in view): same answers where they coincide ...
+    idx = np.nonzero(v)[0]
+    g = ctx.find_direct_projection_mp(3, T_cur, [0, 1, 2], kfT, ck[idx], pos[cp[idx]], cx[idx], cl[idx], px_in=r["px_proj"][idx])
+    assert np.array_equal(g["ok"], r["ok"][idx]) and np.array_equal(g["px"], r["px"][idx]) and np.array_equal(g["level"], r["level"][idx])
+    # ... other predictions against the oracle, and one candidate per launch == the batch
+    pin = r["px_proj"][idx[:60]] + rng.uniform(-1.5, 1.5, (60, 2))
+    g = ctx.find_direct_projection_mp(3, T_cur, [0, 1, 2], kfT, ck[idx[:60]], pos[cp[idx[:60]]], cx[idx[:60]], cl[idx[:60]], px_in=pin)
+    for j, c in enumerate(idx[:60]):
+        o_ok, o_px, o_sl = oracle.find_direct_projection_mp(lv[ck[c]], poses[ck[c]], lv[3], T_cur, pos[cp[c]], cx[c], int(cl[c]), pin[j])
+        assert bool(o_ok) == bool(g["ok"][j]) and o_sl == g["level"][j] and np.array_equal(np.asarray(o_px), g["px"][j])
+        one = ctx.find_direct_projection_mp(3, T_cur, [int(ck[c])], kfT[ck[c]][None], [0], pos[cp[c]][None], cx[c][None], cl[c:c + 1], px_in=pin[j][None])
+        assert one["ok"][0] == g["ok"][j] and one["level"][0] == g["level"][j] and np.array_equal(one["px"][0], g["px"][j])
+    # nothing to do / refused inputs
+    e = ctx.find_direct_projection_mp(3, T_cur, [0], kfT[:1], [], np.zeros((0, 3)), np.zeros((0, 2)), [])
+    assert len(e["ok"]) == 0
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.find_direct_projection_mp(3, T_cur, [0], kfT[:1], [0], pos[:1], cx[:1], [7])
+    ctx.close()
+
+
+def test_describe_given_angle(hip_lib, oracle):
+    """ygz_hip_describe_given_angle (what FeatureDetector::ComputeDescriptor(Feature*) calls, FeatureDetector.cpp:588-594): the rotated BRIEF with the
+    angles the caller supplies -- border pixels, half-to-even pixels and arbitrary angles -- against ComputeOrbDescriptor of the oracle"""
+    imgs, _, _ = _frames(1, 640, 480, seed=4)
+    rng = np.random.default_rng(1)
+    n = 500
+    level = rng.integers(0, 3, n).astype(np.int32)
+    px = np.stack([rng.uniform(0, 640, n), rng.uniform(0, 480, n)], 1)
+    px[:20] = np.floor(px[:20]) + 0.5
+    angle = rng.uniform(0, 360, n).astype(np.float32)
+    angle[:8] = [0.0, 90.0, 180.0, 270.0, 359.99997, 45.0, 1e-3, 123.456]
+    ctx = make_ctx(hip_lib, max_frames=1)
+    ctx.upload_gray(0, imgs[0]); ctx.build_pyramid(0, 1)
+    ctx.describe_given_angle(0, px, level, angle)
+    kp = ctx.get_keypoints(0)
+    lv = oracle.pyramid(imgs[0], 3)
+    want = np.stack([oracle.orb_descriptor(lv[level[i]], px[i, 0], px[i, 1], int(level[i]), float(angle[i])) for i in range(n)])
+    assert np.array_equal(kp["desc"], want)
+    assert np.array_equal(kp["angle"], angle)                                  # the angles are kept as given
+    # with the intensity-centroid angles of ygz_hip_describe it is the same descriptor as ygz_hip_describe's
+    ctx.describe(0, px, level)
+    k0 = ctx.get_keypoints(0)
+    ctx.describe_given_angle(0, px, level, k0["angle"])
+    assert np.array_equal(ctx.get_keypoints(0)["desc"], k0["desc"])
+    dev, cus = ctx.get_device()
+    assert dev == 0 and cus == 256                                             # MI355X: 256 CUs
+    ctx.close()
+
+
 # ------------------------------------------------------------------------------------- M1-M3
 @pytest.mark.parametrize("nq,nt", [(1000, 1000), (70, 53), (1, 1), (257, 3), (3, 700), (3072, 3072)])
 def test_hamming_bit_exact_indices(hip_lib, oracle, nq, nt):
@@ -603,6 +686,23 @@ def test_ba_window_10x2000(hip_lib, oracle):
         ctx.ba_set_state(0, poses, pts)
         ctx.ba_linearize_resident(0, 1)
         _ba_close(ctx.ba_download(0, K, P, E), oracle.ba_linearize(poses, f["fixed"], pts, f["edge_pose"], f["edge_point"], f["obs"]))
+    # ygz_hip_ba_set_enable: edges switched off in the resident graph (what an inlier test between rounds does) == the oracle on the edges left
+    en = (rng.random(E) < 0.8).astype(np.uint8)
+    ctx.ba_set_enable(0, en)
+    ctx.ba_linearize_resident(0, 1)
+    m = en.astype(bool)
+    gd = ctx.ba_download(0, K, P, E)
+    rs = oracle.ba_linearize(poses, f["fixed"], pts, f["edge_pose"][m], f["edge_point"][m], f["obs"][m])
+    for k in ("Hpp", "bp", "Hll", "bl"):
+        assert np.all(np.abs(gd[k] - rs[k]) <= 1e-9 * max(1.0, np.abs(rs[k]).max())), k
+    assert abs(gd["chi2"] - rs["chi2"]) <= 1e-9 * rs["chi2"]
+    for k in ("Hpl", "err", "chi2_edge"):
+        assert np.all(np.abs(gd[k][m] - rs[k]) <= 1e-9 * max(1.0, np.abs(rs[k]).max())), k
+    ctx.ba_set_enable(0, np.ones(E, np.uint8))               # ... and on again
+    ctx.ba_linearize_resident(0, 1)
+    _ba_close(ctx.ba_download(0, K, P, E), oracle.ba_linearize(poses, f["fixed"], pts, f["edge_pose"], f["edge_point"], f["obs"]))
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.ba_set_enable(5, en)                             # no such window
     # Huber off
     g3 = ctx.ba_linearize(f["poses"], f["fixed"], f["points"], f["edge_pose"], f["edge_point"], f["obs"], huber_delta=0.0)
     assert abs(g3["chi2"] - g3["chi2_edge"].sum()) < 1e-6 * g3["chi2"]

@@ -82,6 +82,14 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
         assert np.array_equal(k[:, 0], ks[i]["px"]) and np.array_equal(k[:, 1], ks[i]["py"]) and np.array_equal(k[:, 2], ks[i]["level"])
         assert np.allclose(k[:, 3], ks[i]["score"], rtol=1e-7) and np.allclose(k[:, 4], ks[i]["angle"], rtol=1e-7)
         assert np.array_equal(k[:, 5:].astype(np.uint8), ks[i]["desc"])
+    # FeatureDetector::ComputeAngleAndDescriptor(Frame*): the frame's angles and descriptors again, bit for bit; ComputeDescriptor(Feature*): the
+    # rotated BRIEF at the angle the caller left in the Feature (FeatureDetector.cpp:580-594)
+    assert r["cad"][0][0] == r["cad"][0][1] == str(len(ks[0]))
+    assert len(r["cd"]) == 40
+    for row in r["cd"]:
+        i, a = int(row[0]), float(row[1])
+        want = oracle.orb_descriptor(lv[0][ks[0]["level"][i]], ks[0]["px"][i], ks[0]["py"][i], int(ks[0]["level"][i]), float(np.float32(a)))
+        assert np.array_equal(np.array(row[2:], dtype=np.uint8), want), i
     # BFMatcher(crossCheck) + DescriptorDistance
     oi, od, n = oracle.bf_match(ks[0]["desc"], ks[1]["desc"], 1)
     q = np.nonzero(oi >= 0)[0]
@@ -142,6 +150,27 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     assert np.array_equal(lm[:, 0].astype(int), ovis.astype(int))                   # _cnt_visible went 0 -> 1 exactly for the in-view points
     assert np.array_equal(lm[:, 1].astype(int), (omatch >= 0).astype(int))
     assert np.array_equal(lm[:, 2].astype(int), olvl) and np.array_equal(lm[:, 3:5], opx)
+    # the per-candidate call of the reference's unchanged caller (LocalMapping.cpp:98): Matcher::FindDirectProjection(ref, curr, MapPoint*, px, level)
+    # answered from one speculative launch == the same call as its own n = 1 launch == what the batch method kept, bit for bit
+    fm = np.array(r["fdpmp"], dtype=np.float64)
+    assert len(fm) == len(lm)
+    assert np.array_equal(fm[:, :4], fm[:, 4:])                                      # memoised answer == n = 1 launch
+    seen = fm[:, 0] >= 0
+    chk = np.ones(len(lm), bool); chk[2] = False                                    # (map point 2 was bad while ProjectMapPoints ran)
+    assert np.array_equal(seen[chk], ovis.astype(bool)[chk])
+    assert np.array_equal(fm[seen & chk, 0].astype(int), lm[seen & chk, 1].astype(int))
+    hit = seen & chk & (fm[:, 0] == 1)
+    assert np.array_equal(fm[hit, 1].astype(int), lm[hit, 2].astype(int)) and np.array_equal(fm[hit, 2:4], lm[hit, 3:5]) and hit.sum() == on
+    for i in np.nonzero(seen)[0][::11]:                                              # ... and the oracle, failures included
+        o_ok, o_px, o_sl = oracle.find_direct_projection_mp(lv[0], poses[0], lv[1], poses[1], lm[i, 5:8], px0[mp_idx[i]], int(ks[0]["level"][mp_idx[i]]),
+                                                            synth.project(poses[1], lm[i, 5:8][None])[0][0])
+        assert int(o_ok) == int(fm[i, 0]) and o_sl == int(fm[i, 1])
+    hits, single, launches, speculated = [int(x) for x in r["fdpmp_stats"][0]]
+    assert launches == 1 and single == 0 and hits == seen.sum() and speculated == len(lm)    # ONE launch served every call of the frame
+    for tag in ("fdpmp_other", "fdpmp_moved", "fdpmp_kfmoved"):                      # inputs the launch did not see: n = 1, same answer as a fresh call
+        v = [float(x) for x in r[tag][0]]
+        assert v[:4] == v[4:8], tag
+    assert [int(x) for x in r["fdpmp_kfmoved"][0][8:]] == [2, 1, 1]                  # two n = 1 calls before; the moved keyframe costs one new launch, then hits
     pwb = lv[0][0][195:205, 295:305].copy()
     o_ok, u, v, _, _ = oracle.align2d(lv[0][0], pwb, pwb[1:9, 1:9].copy(), 301.2, 199.1)
     assert [float(x) for x in r["align2d"][0]] == [float(o_ok), u, v]
@@ -225,6 +254,34 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     m = o_bad == 0
     assert np.allclose(rows[m, 1], o_dep[m], rtol=1e-9) and np.all(rows[~m, 1] == -1)
     assert np.array_equal(rows[:, 2].astype(int), (o_bad == 0).astype(int))          # _cnt_found++ for the inliers
+
+
+def test_unchanged_caller_loop(hip_lib, oracle):
+    """The loop of tests/cpp/bench_surface.cpp with TrackLocalMap written the way the reference's UNCHANGED caller performs it
+    (LocalMapping::FindCandidates + one Matcher::FindDirectProjection per candidate, src/Module/LocalMapping.cpp:47-120; reference-named methods only):
+    every one of its ~40 000 calls is repeated as its own n = 1 launch and compared bit for bit (0 differences), nearly all of them are answered
+    from one speculative launch per frame, and the loop tracks as the batch method's loop does."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    n = 34
+    bgr, kfd, gt = bench.surface_sequence(n)
+    v = bench.surface_gpu(bgr, kfd, caller=3)
+    m = v["memo"]
+    assert m["calls"] > 20000 and m["mismatches"] == 0
+    assert m["hits"] + m["single"] == m["calls"] and m["hits"] >= 0.995 * m["calls"], m
+    assert m["launches"] <= 2 * (n - 1), m                                           # ~one launch per frame (a second when a keyframe joins the local set)
+    g = bench.surface_gpu(bgr, kfd, caller=0)
+    # the same tracking as the batch method's loop up to the order of a point's candidates: the batch method takes them in _obs (keyframe id) order,
+    # the caller in heap-address order of the Features (std::map<Feature*, ...>), and with Matcher::GetWarpAffineMatrix reproduced as written
+    # (Matcher.cpp:424-431) a candidate of a keyframe away from the origin often fails or lands a fraction of a pixel off -> a few per cent fewer
+    # inliers, never a lost frame
+    assert np.array_equal(v["counts"][:, 0][:9], g["counts"][:, 0][:9]) and np.array_equal(v["counts"][:9, 3], g["counts"][:9, 3])
+    assert np.abs(v["counts"].astype(int) - g["counts"].astype(int)).max() <= 60
+    assert np.abs(v["T"] - g["T"]).max() < 1e-3
+    from ygz_slam_amd import offline as off
+    gt0 = np.stack([off.se3_mul(gt[i], off.se3_inv(gt[0])) for i in range(n)])
+    assert np.abs(v["T"] - gt0).max() < 2e-3 and v["counts"][1:, 2].min() > 800
 
 
 def test_ba_optimize_converges_to_ground_truth(hip_lib, oracle):

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): tools/gpu_r06.sh <batch-name> -- the measurement batches of round 6, one case per batch.
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+B=${1:-a}
+OUT=gpurun_out/r06$B
+mkdir -p $OUT
+surf() { python - "$1" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))['surface']; c=d.pop('cpu_oracle_same_loop',{}); d.pop('what'); u=d.pop('unchanged',{}); u.pop('what',None)
+print("batch    ", json.dumps(d)); print("unchanged", json.dumps(u)); print("oracle   ", c.get('frames_per_s'))
+PY
+}
+case $B in
+a)  # the unchanged caller: per-candidate FindDirectProjection behind one speculative launch -- tests, then the surface block with `unchanged`
+    timeout 900 python -m pytest tests/test_gpu_surface.py -x -q > $OUT/pytest_surface.log 2>&1; tail -15 $OUT/pytest_surface.log
+    timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "per_candidate or given_angle or 10x2000 or track_local_map" > $OUT/pytest_new.log 2>&1; tail -15 $OUT/pytest_new.log
+    timeout 400 python bench.py --mode surface > $OUT/surface.json 2> $OUT/surface.err; tail -3 $OUT/surface.err; surf $OUT/surface.json
+    ;;
+h)  # the whole GPU suite + the default bench line
+    timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
+    timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python - $OUT/bench_default.json <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value %.0f ms/step %.3f" % (d["value"], d["ms_per_step"]), d.get("step_ms"))
+print("roofline", {k: d["roofline"][k] for k in ("achieved","frac","avg_launch_us") if k in d["roofline"]})
+s=d.get("surface",{}); print("surface", s.get("frames_per_s"), s.get("vs_cpu_1core"), "unchanged", s.get("unchanged",{}).get("frames_per_s"), s.get("unchanged",{}).get("vs_cpu_1core"))
+PY
+    ;;
+esac

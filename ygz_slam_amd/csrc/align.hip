@@ -11,6 +11,7 @@
 // pixels come straight from HBM/L2 (9x9 window per iteration, one new column per step).
 #include "ygz_internal.h"
 #include <cstring>
+#include <vector>
 #include "../../include/ygz_exp.h"
 #include "se3_dev.h"
 
@@ -283,6 +284,7 @@ struct LmapArgs {
     const int32_t *cand_point, *cand_kf, *cand_level; const double *cand_px_ref;      // [C]
     uint8_t *in_view; double *px_proj; int32_t *match_cand; double *px_match; int32_t *match_level;   // [P]
     double *cand_px; int32_t *cand_sl; uint8_t *cand_ok;             // [C]
+    int given_px;                                  // != 0: px_proj holds the caller's predictions and every point counts as in view (no FindCandidates step)
 };
 
 // FindCandidates (:47-79), lane = map point: World2Camera, Camera2Pixel, z < 0 or !InFrame(px, 20) -> not in view
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(256) void k_lmap_project(LmapArgs A)
     if (p >= A.P) return;
     A.match_cand[p] = 0x7fffffff; A.match_level[p] = 0;
     A.px_match[2 * p] = 0.0; A.px_match[2 * p + 1] = 0.0;
+    if (A.given_px) { A.in_view[p] = 1; return; }
     double px[2] = { 0.0, 0.0 };
     bool vis = false;
     if (!(A.point_bad && A.point_bad[p])) {
@@ -498,9 +501,15 @@ int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pw
     return YGZ_OK;
 }
 
-// SURVEY 8f-3: one call = LocalMapping::FindCandidates + ProjectMapPoints for the current frame against K resident keyframes
-int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
-                            uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level, int32_t *n_matched)
+}  // extern "C"
+
+// per-candidate outputs of the local-map run (what k_lmap_match leaves for EVERY candidate, not only a point's first success)
+struct LmapCandOut { uint8_t *ok; double *px; int32_t *sl; const double *px_given; };
+
+// one run = LocalMapping::FindCandidates + ProjectMapPoints for the current frame against K resident keyframes
+static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
+                    uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level, int32_t *n_matched,
+                    const LmapCandOut *co)
 {
     YgzDeviceGuard dg_(ctx);
     if (!ctx || !T_cur || !m || m->n_points < 0 || m->n_keyframes < 0 || m->n_candidates < 0) return YGZ_E_INVALID;
@@ -509,7 +518,8 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     const int P = m->n_points, K = m->n_keyframes, Cn = m->n_candidates;
     if (n_matched) *n_matched = 0;
     if (P == 0) return YGZ_OK;
-    if (!m->pos_world || !in_view || !px_proj || !match_cand || !px_match || !match_level) return YGZ_E_INVALID;
+    if (!m->pos_world || !in_view || !px_proj) return YGZ_E_INVALID;
+    if (!co && (!match_cand || !px_match || !match_level)) return YGZ_E_INVALID;
     if (K > 0 && (!m->kf_slot || !m->kf_T)) return YGZ_E_INVALID;
     if (Cn > 0 && (!m->cand_point || !m->cand_kf || !m->cand_level || !m->cand_px_ref || K == 0)) return YGZ_E_INVALID;
     for (int i = 0; i < K; ++i) {
@@ -537,6 +547,7 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     if (m->point_bad) memcpy(H_(d_bad), m->point_bad, Ps);
     if (K) { memcpy(H_(d_kfT), m->kf_T, Ks * 56); memcpy(H_(d_kfs), m->kf_slot, Ks * 4); }
     if (Cn) { memcpy(H_(d_cpx), m->cand_px_ref, Cs * 16); memcpy(H_(d_cp), m->cand_point, Cs * 4); memcpy(H_(d_ck), m->cand_kf, Cs * 4); memcpy(H_(d_cl), m->cand_level, Cs * 4); }
+    if (co && co->px_given) memcpy(H_(d_proj), co->px_given, Ps * 16);
     YGZ_HIPCHK(ctx, hipMemcpyAsync(buf, hb, total, hipMemcpyHostToDevice, ctx->stream));
     LmapArgs A;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; A.F.sstride[L] = (size_t)ctx->lw[L] * ctx->lh[L]; }
@@ -549,17 +560,54 @@ int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7
     A.cand_point = d_cp; A.cand_kf = d_ck; A.cand_level = d_cl; A.cand_px_ref = d_cpx;
     A.in_view = d_vis; A.px_proj = d_proj; A.match_cand = d_mc; A.px_match = d_pm; A.match_level = d_ml;
     A.cand_px = d_candpx; A.cand_sl = d_csl; A.cand_ok = d_cok;
+    A.given_px = co && co->px_given ? 1 : 0;
     YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_project, dim3(ygz_div_up(P, 256)), dim3(256), A);
     if (Cn) YGZ_LAUNCH(ctx, KID_LMAP_MATCH, k_lmap_match, dim3(ygz_div_up(Cn, 64)), dim3(64), A);
-    YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_gather, dim3(ygz_div_up(P, 256)), dim3(256), A);
+    if (!co) YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_gather, dim3(ygz_div_up(P, 256)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     YGZ_HIPCHK(ctx, hipMemcpyAsync(hb, buf, total, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(in_view, H_(d_vis), Ps); memcpy(px_proj, H_(d_proj), Ps * 16); memcpy(match_cand, H_(d_mc), Ps * 4);
-    memcpy(px_match, H_(d_pm), Ps * 16); memcpy(match_level, H_(d_ml), Ps * 4);
+    memcpy(in_view, H_(d_vis), Ps); memcpy(px_proj, H_(d_proj), Ps * 16);
+    if (co) {
+        if (Cn) { memcpy(co->ok, H_(d_cok), Cs); memcpy(co->px, H_(d_candpx), Cs * 16); memcpy(co->sl, H_(d_csl), Cs * 4); }
+        return YGZ_OK;
+    }
+    memcpy(match_cand, H_(d_mc), Ps * 4); memcpy(px_match, H_(d_pm), Ps * 16); memcpy(match_level, H_(d_ml), Ps * 4);
 #undef H_
     if (n_matched) { int n = 0; for (int p = 0; p < P; ++p) n += match_cand[p] >= 0; *n_matched = n; }
     return YGZ_OK;
+}
+
+extern "C" {
+
+// SURVEY 8f-3: one call = LocalMapping::FindCandidates + ProjectMapPoints for the current frame against K resident keyframes
+int ygz_hip_track_local_map(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
+                            uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level, int32_t *n_matched)
+{
+    return lmap_run(ctx, cur_slot, T_cur, m, in_view, px_proj, match_cand, px_match, match_level, n_matched, nullptr);
+}
+
+// Matcher::FindDirectProjection, MapPoint overload (Matcher.cpp:356-383), for C independent candidates over K resident reference keyframes in one
+// launch -- the per-candidate call LocalMapping::ProjectMapPoints makes (LocalMapping.cpp:98), every candidate evaluated, none skipped.
+int ygz_hip_find_direct_projection_mp(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], int n_keyframes, const int32_t *kf_slot, const double *kf_T,
+                                      int n, const int32_t *cand_kf, const double *pos_world, const double *px_ref, const int32_t *level_ref,
+                                      const double *px_in, uint8_t *in_view, double *px_proj, uint8_t *ok, double *px_cur, int32_t *search_level)
+{
+    if (!ctx || n < 0) return YGZ_E_INVALID;
+    if (n == 0) return YGZ_OK;
+    if (!cand_kf || !pos_world || !px_ref || !level_ref || !ok || !px_cur || !search_level) return YGZ_E_INVALID;
+    if (!px_in && (!in_view || !px_proj)) return YGZ_E_INVALID;
+    std::vector<int32_t> iota((size_t)n);
+    for (int i = 0; i < n; ++i) iota[i] = i;
+    std::vector<uint8_t> vis; std::vector<double> proj;
+    if (!in_view) { vis.resize((size_t)n); in_view = vis.data(); }
+    if (!px_proj) { proj.resize(2 * (size_t)n); px_proj = proj.data(); }
+    ygz_local_map m;
+    m.n_points = n; m.pos_world = pos_world; m.point_bad = nullptr;
+    m.n_keyframes = n_keyframes; m.kf_slot = kf_slot; m.kf_T = kf_T;
+    m.n_candidates = n; m.cand_point = iota.data(); m.cand_kf = cand_kf; m.cand_level = level_ref; m.cand_px_ref = px_ref;
+    LmapCandOut co = { ok, px_cur, search_level, px_in };
+    return lmap_run(ctx, cur_slot, T_cur, &m, in_view, px_proj, nullptr, nullptr, nullptr, nullptr, &co);
 }
 
 }  // extern "C"

@@ -79,7 +79,12 @@ struct Runtime::Impl {
 Runtime &Runtime::Get() { static Runtime r; return r; }
 Runtime::Runtime() : p_(new Impl) {}
 Runtime::~Runtime() { if (p_->ctx) ygz_hip_destroy(p_->ctx); delete p_; }
-void check(int rc, const char *what) { if (rc != YGZ_OK) throw std::runtime_error(std::string(what) + ": " + ygz_hip_error_string(rc)); }
+bool check(int rc, const char *what)
+{
+    if (rc == YGZ_OK) return true;
+    LOG(ERROR) << "ygz::hip: " << what << ": " << ygz_hip_error_string(rc) << endl;
+    return false;
+}
 ygz_hip_ctx *Runtime::ctx()
 {
     if (!p_->ctx) {
@@ -94,15 +99,18 @@ ygz_hip_ctx *Runtime::ctx()
         const char *mf = getenv("YGZ_HIP_MAX_FRAMES");
         prm.max_frames = mf ? atoi(mf) : 64;
         const char *dev = getenv("YGZ_HIP_DEVICE");
-        check(ygz_hip_create(&p_->ctx, dev ? atoi(dev) : 0, &prm, nullptr), "ygz_hip_create");
+        const int rc = ygz_hip_create(&p_->ctx, dev ? atoi(dev) : 0, &prm, nullptr);
+        if (rc != YGZ_OK) throw std::runtime_error(std::string("ygz::hip::Runtime: no usable gfx950 device (ygz_hip_create: ") + ygz_hip_error_string(rc) + "); there is no CPU path");
         p_->max_frames = prm.max_frames; p_->levels = prm.pyramid_levels; p_->cells = ygz_hip_max_keypoints(p_->ctx);
         p_->owner.assign(prm.max_frames, nullptr); p_->stamp.assign(prm.max_frames, 0);
     }
     return p_->ctx;
 }
 int Runtime::cells() { ctx(); return p_->cells; }
+void fdp_memo_forget(const Frame *f);
 void Runtime::Release(Frame *f)
 {
+    fdp_memo_forget(f);
     for (auto it = p_->level_of.begin(); it != p_->level_of.end();) { if (it->second.first == f) it = p_->level_of.erase(it); else ++it; }
     if (f->_hip_slot >= 0 && f->_hip_slot < (int)p_->owner.size() && p_->owner[f->_hip_slot] == f) p_->owner[f->_hip_slot] = nullptr;
     f->_hip_slot = -1;
@@ -131,20 +139,18 @@ int Runtime::Resident(Frame *f)
         p_->owner[slot]->_hip_slot = -1;
     }
     p_->owner[slot] = f; p_->stamp[slot] = ++p_->clock; f->_hip_slot = slot;
+    bool up = true;
     if (!f->_pyramid.empty() && !f->_color.empty()) {                 // an initialised frame that lost its slot: the image goes up again (Frame.cpp:22-40 on the GPU)
-        if (f->_color.channels() == 3) {
-            check(ygz_hip_upload_bgr(c, slot, f->_color.data, (int)f->_color.step), "upload_bgr");
-            check(ygz_hip_build_pyramid(c, slot, 1, 1), "build_pyramid");
-        } else {
-            check(ygz_hip_upload_gray(c, slot, f->_color.data, (int)f->_color.step), "upload_gray");
-            check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
-        }
+        const int bgr = f->_color.channels() == 3;
+        up = check(bgr ? ygz_hip_upload_bgr(c, slot, f->_color.data, (int)f->_color.step) : ygz_hip_upload_gray(c, slot, f->_color.data, (int)f->_color.step), "upload")
+             && check(ygz_hip_build_pyramid(c, slot, 1, bgr), "build_pyramid");
     } else if (!f->_pyramid.empty() && f->_pyramid.fetched(0)) {      // _color was released by the caller: level 0 of the host mirror, if somebody fetched it
-        check(ygz_hip_upload_gray(c, slot, f->_pyramid[0].data, (int)f->_pyramid[0].step), "upload_gray");
-        check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
+        up = check(ygz_hip_upload_gray(c, slot, f->_pyramid[0].data, (int)f->_pyramid[0].step), "upload_gray") && check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
     } else if (!f->_pyramid.empty()) {
-        throw std::runtime_error("ygz::hip::Runtime: an evicted frame has neither _color nor a fetched level 0 to be uploaded again (raise YGZ_HIP_MAX_FRAMES)");
+        LOG(ERROR) << "ygz::hip::Runtime: an evicted frame has neither _color nor a fetched level 0 to be uploaded again (raise YGZ_HIP_MAX_FRAMES)" << endl;
+        up = false;
     }
+    if (!up) { p_->owner[slot] = nullptr; f->_hip_slot = -1; return -1; }       // the ABI refuses slot -1 (YGZ_E_INVALID): the surface that asked reports failure
     return slot;
 }
 }  // namespace hip
@@ -156,16 +162,19 @@ Frame::~Frame() { if (!_features.empty()) CleanAllFeatures(); hip::Runtime::Get(
 
 void hip::PyramidMirror::fetch(size_t L)
 {   // the first reader of a level pays for its copy (and nobody else pays for levels nobody reads)
-    if (L >= lv_.size()) throw std::out_of_range("Frame::_pyramid: level out of range");
+    if (L >= lv_.size()) throw std::out_of_range("Frame::_pyramid: level out of range");      // (vector::operator[] of the reference: undefined)
     if (have_[L] || !owner_) return;
     Runtime &rt = Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
-    int w = 0, h = 0;
-    check(ygz_hip_level_size(c, (int)L, &w, &h), "level_size");
-    lv_[L].create(h, w, CV_8UC1);
-    have_[L] = 1;                                    // (before Resident: a re-upload of an evicted frame must not recurse into this level)
+    // the level counts as fetched only once its pixels are here: a re-upload of an evicted frame (Resident) must never take a level that is still
+    // being fetched for the frame image, and a failed download must not leave uninitialised pixels marked valid
     const int slot = rt.Resident(owner_);
-    check(ygz_hip_download_level(c, slot, (int)L, lv_[L].data), "download_level");
+    int w = 0, h = 0;
+    if (slot < 0 || !check(ygz_hip_level_size(c, (int)L, &w, &h), "level_size")) return;       // lv_[L] stays empty()
+    cv::Mat img(h, w, CV_8UC1);
+    if (!check(ygz_hip_download_level(c, slot, (int)L, img.data), "download_level")) return;
+    lv_[L] = img;
+    have_[L] = 1;
     rt.RegisterLevels(owner_);
 }
 
@@ -175,17 +184,16 @@ void Frame::InitFrame()
     ygz_hip_ctx *c = rt.ctx();
     int w = 0, h = 0;
     ygz_hip_level_size(c, 0, &w, &h);
-    if (_color.empty() || _color.cols != w || _color.rows != h) throw std::runtime_error("Frame::InitFrame: _color does not match image.width/height");
     rt.Release(this);
     _pyramid.clear();
-    const int slot = rt.Resident(this);                 // no pyramid yet: slot only
-    if (_color.channels() == 3) {                       // cv::cvtColor(CV_BGR2GRAY) + pyrDown on the GPU (Frame.cpp:27,38)
-        hip::check(ygz_hip_upload_bgr(c, slot, _color.data, (int)_color.step), "upload_bgr");
-        hip::check(ygz_hip_build_pyramid(c, slot, 1, 1), "build_pyramid");
-    } else {
-        hip::check(ygz_hip_upload_gray(c, slot, _color.data, (int)_color.step), "upload_gray");
-        hip::check(ygz_hip_build_pyramid(c, slot, 1, 0), "build_pyramid");
+    if (_color.empty() || _color.cols != w || _color.rows != h) {
+        LOG(ERROR) << "Frame::InitFrame: _color (" << _color.cols << " x " << _color.rows << ") does not match image.width/height (" << w << " x " << h << "); no pyramid" << endl;
+        return;
     }
+    const int slot = rt.Resident(this);                 // no pyramid yet: slot only
+    const int bgr = _color.channels() == 3;             // cv::cvtColor(CV_BGR2GRAY) + pyrDown on the GPU (Frame.cpp:27,38)
+    if (!hip::check(bgr ? ygz_hip_upload_bgr(c, slot, _color.data, (int)_color.step) : ygz_hip_upload_gray(c, slot, _color.data, (int)_color.step), "upload")
+        || !hip::check(ygz_hip_build_pyramid(c, slot, 1, bgr), "build_pyramid")) { rt.Release(this); return; }
     _pyramid.reset(this, (size_t)_option._pyramid_level);      // levels are fetched when somebody indexes them
 }
 
@@ -222,6 +230,58 @@ bool Frame::GetMeanAndMinDepth(double &mean_depth, double &min_depth)
     mean_depth = n ? sum / n : 0.0;
     min_depth = n ? lo : 0.0;
     return n > 0;
+}
+
+
+// ---- covisibility graph (src/Basic/Frame.cpp:73-176): which keyframes see the map points this one sees, and how many of them
+vector<Frame *> Frame::GetBestCovisibilityKeyframes(const int &N)
+{
+    if ((int)_cov_keyframes.size() < N) return _cov_keyframes;
+    return vector<Frame *>(_cov_keyframes.begin(), _cov_keyframes.begin() + N);
+}
+bool Frame::IsInFrustum(MapPoint *, float) { return true; }
+void Frame::AddConnection(Frame *kf, const int &weight) { _connected_keyframe_weights[kf] = weight; }
+
+namespace {
+// (weight, keyframe) heaviest first; equal weights by descending pointer -- what sorting pair<int, Frame*> ascending and reading it backwards gives
+void heaviest_first(vector<pair<int, Frame *>> &wk, vector<Frame *> &kfs, vector<int> &ws)
+{
+    std::sort(wk.begin(), wk.end(), [](const pair<int, Frame *> &a, const pair<int, Frame *> &b) { return b < a; });
+    for (const auto &p : wk) { kfs.push_back(p.second); ws.push_back(p.first); }
+}
+}
+void Frame::UpdateConnections()
+{
+    map<Frame *, int> shared;                         // other keyframe -> map points in common
+    for (const Feature *fea : _features) {
+        const MapPoint *mp = fea->_mappoint;
+        if (!mp || mp->_bad) continue;
+        for (const auto &ob : mp->_obs) if (ob.first != _keyframe_id) shared[Memory::GetKeyFrame(ob.first)]++;
+    }
+    if (shared.empty()) return;
+    const int th = 15;                                // a connection needs 15 points in common; failing that, the single best keyframe is kept
+    vector<pair<int, Frame *>> wk;
+    wk.reserve(shared.size());
+    pair<int, Frame *> best(0, nullptr);
+    for (const auto &kv : shared) {
+        if (kv.second > best.first) best = make_pair(kv.second, kv.first);
+        if (kv.second >= th) wk.push_back(make_pair(kv.second, kv.first));
+    }
+    if (wk.empty()) {
+        wk.push_back(best);
+        best.second->AddConnection(this, best.first);
+    }
+    _connected_keyframe_weights = shared;
+    _cov_keyframes.clear(); _cov_weights.clear();
+    heaviest_first(wk, _cov_keyframes, _cov_weights);
+    LOG(INFO) << "convisible keyframes: " << _cov_keyframes.size() << endl;
+}
+void Frame::UpdateBestCovisibles()
+{   // appends (the reference does not clear first, Frame.cpp:162-176)
+    vector<pair<int, Frame *>> wk;
+    wk.reserve(_connected_keyframe_weights.size());
+    for (const auto &kv : _connected_keyframe_weights) wk.push_back(make_pair(kv.second, kv.first));
+    heaviest_first(wk, _cov_keyframes, _cov_weights);
 }
 
 // ------------------------------------------------------------------------------------------ Memory
@@ -277,7 +337,7 @@ void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
     hip::Runtime &rt = hip::Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
     const int cells = rt.cells();
-    if ((int)_old_features.size() != cells) throw std::runtime_error("FeatureDetector: grid does not match the context (call LoadParams())");
+    if ((int)_old_features.size() != cells) { LOG(ERROR) << "FeatureDetector::Detect: grid does not match the context (call LoadParams())" << endl; return; }
     const int slot = rt.Resident(frame);
     std::vector<uint8_t> occ;
     if (overwrite_existing_features) {
@@ -288,14 +348,14 @@ void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
         occ.resize(cells);
         for (int k = 0; k < cells; ++k) occ[k] = _old_features[k] ? 1 : 0;
     }
-    hip::check(ygz_hip_detect(c, slot, 1, occ.empty() ? nullptr : occ.data()), "detect");
+    if (!hip::check(ygz_hip_detect(c, slot, 1, occ.empty() ? nullptr : occ.data()), "detect")) return;
     // (result buffers of a whole grid, kept between calls: 180 KB that would otherwise be allocated and zeroed per frame)
     static thread_local std::vector<double> px; static thread_local std::vector<int32_t> lvl; static thread_local std::vector<float> sc, ang;
     static thread_local std::vector<uint8_t> desc;
     if ((int)lvl.size() < cells) { px.resize(2 * (size_t)cells); lvl.resize(cells); sc.resize(cells); ang.resize(cells); desc.resize(32 * (size_t)cells); }
     ygz_kpt_soa soa = { px.data(), lvl.data(), sc.data(), ang.data(), desc.data() };
     int n = 0;
-    hip::check(ygz_hip_get_keypoints(c, slot, &soa, cells, &n), "get_keypoints");
+    if (!hip::check(ygz_hip_get_keypoints(c, slot, &soa, cells, &n), "get_keypoints")) return;
     LOG(INFO) << "old features: " << frame->_features.size() << endl;
     for (int i = 0; i < n; ++i) {
         Feature *fea = new Feature(Vector2d(px[2 * i], px[2 * i + 1]), lvl[i], sc[i]);
@@ -317,12 +377,11 @@ static void describe_features(Frame *frame, const vector<Feature *> &feas, bool 
         const int n = (int)std::min((size_t)cells, feas.size() - base);
         std::vector<double> px(2 * (size_t)n); std::vector<int32_t> lvl(n); std::vector<float> ang(n);
         for (int i = 0; i < n; ++i) { const Feature *f = feas[base + i]; px[2 * i] = f->_pixel[0]; px[2 * i + 1] = f->_pixel[1]; lvl[i] = f->_level; ang[i] = (float)f->_angle; }
-        if (given_angle) hip::check(ygz_hip_describe_given_angle(c, slot, px.data(), lvl.data(), ang.data(), n), "describe");
-        else hip::check(ygz_hip_describe(c, slot, px.data(), lvl.data(), n), "describe");
+        if (!hip::check(given_angle ? ygz_hip_describe_given_angle(c, slot, px.data(), lvl.data(), ang.data(), n) : ygz_hip_describe(c, slot, px.data(), lvl.data(), n), "describe")) return;
         std::vector<float> oang(n); std::vector<uint8_t> desc(32 * (size_t)n);
         ygz_kpt_soa soa = { nullptr, nullptr, nullptr, oang.data(), desc.data() };
         int m = 0;
-        hip::check(ygz_hip_get_keypoints(c, slot, &soa, n, &m), "get_keypoints");
+        if (!hip::check(ygz_hip_get_keypoints(c, slot, &soa, n, &m), "get_keypoints")) return;
         for (int i = 0; i < n; ++i) { Feature *f = feas[base + i]; if (!given_angle) f->_angle = oang[i]; memcpy(f->_desc.data, &desc[32 * (size_t)i], 32); }
     }
 }
@@ -386,8 +445,8 @@ void Tracker::TrackKLT()
     for (int base = 0; base < n; base += cells) {
         const int m = std::min(cells, n - base);
         int kept = 0;
-        hip::check(ygz_hip_klt_track_filtered(c, rs, cs, &_tracks.ref_px[2 * base], &_tracks.cur_px[2 * base], m, &prm, 20, &status[base], &err[base],
-                                              &keep[base], &kept), "klt_track_filtered");
+        if (!hip::check(ygz_hip_klt_track_filtered(c, rs, cs, &_tracks.ref_px[2 * base], &_tracks.cur_px[2 * base], m, &prm, 20, &status[base], &err[base],
+                                                   &keep[base], &kept), "klt_track_filtered")) return;      // tracks as they were
     }
     size_t w = 0;
     for (int i = 0; i < n; ++i) {
@@ -426,7 +485,7 @@ size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
     hip::Runtime &rt = hip::Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
     const int n = (int)ref_frame->_features.size();
-    if (n > rt.cells()) throw std::runtime_error("SparseImgAlign::run: more features than grid cells");
+    if (n > rt.cells()) { LOG(ERROR) << "SparseImgAlign::run: " << n << " features, more than grid cells (" << rt.cells() << ")" << endl; return 0; }
     vector<double> px(2 * (size_t)n), depth(n); vector<uint8_t> has(n);
     for (int i = 0; i < n; ++i) {
         const Feature *f = ref_frame->_features[i];
@@ -436,7 +495,7 @@ size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
     ref_frame->_TCW.to7(Tr); cur_frame->_TCW.to7(Tc);
     int n_meas = 0;
     const int rs = rt.Resident(ref_frame), cs = rt.Resident(cur_frame);
-    hip::check(ygz_hip_sparse_align(c, rs, Tr, cs, Tc, px.data(), depth.data(), has.data(), n, max_level_, min_level_, n_iter_, &n_meas, iters_), "sparse_align");
+    if (!hip::check(ygz_hip_sparse_align(c, rs, Tr, cs, Tc, px.data(), depth.data(), has.data(), n, max_level_, min_level_, n_iter_, &n_meas, iters_), "sparse_align")) return 0;
     cur_frame->_TCW = SE3::from7(Tc);
     return (size_t)n_meas;
 }
@@ -468,7 +527,7 @@ void Vocabulary::transform(const std::vector<cv::Mat> &features, BowVector &v, F
     std::vector<uint8_t> desc((size_t)n * 32);
     for (int i = 0; i < n; ++i) memcpy(&desc[32 * (size_t)i], features[i].data, 32);
     std::vector<int32_t> word(n), node(n); std::vector<double> weight(n);
-    ygz::hip::check(ygz_hip_bow_transform(ygz::hip::Runtime::Get().ctx(), desc.data(), n, levelsup, word.data(), weight.data(), node.data()), "bow_transform");
+    if (!ygz::hip::check(ygz_hip_bow_transform(ygz::hip::Runtime::Get().ctx(), desc.data(), n, levelsup, word.data(), weight.data(), node.data()), "bow_transform")) return;
     for (int i = 0; i < n; ++i) {
         if (!(weight[i] > 0) || word[i] < 0) continue;          // stopped word
         v[(WordId)word[i]] += weight[i];                         // BowVector::addWeight
@@ -522,8 +581,8 @@ int Matcher::CheckFrameDescriptors(Frame *frame1, Frame *frame2, list<pair<int, 
         ++r;
     }
     int n_good = 0, best = 0;
-    hip::check(ygz_hip_check_descriptor_pairs(hip::Runtime::Get().ctx(), d1.data(), d2.data(), (int)n, _options.init_low, _options.init_high,
-                                              _options.initMatchRatio, nullptr, keep.data(), &n_good, &best), "check_descriptor_pairs");
+    if (!hip::check(ygz_hip_check_descriptor_pairs(hip::Runtime::Get().ctx(), d1.data(), d2.data(), (int)n, _options.init_low, _options.init_high,
+                                                   _options.initMatchRatio, nullptr, keep.data(), &n_good, &best), "check_descriptor_pairs")) return 0;
     LOG(INFO) << "best dist = " << best << ", kept " << n_good << " of " << n << endl;
     r = 0;
     matches.remove_if([&](const pair<int, int> &) { return keep[r++] == 0; });
@@ -550,8 +609,8 @@ int Matcher::SearchByBoW(Frame *kf1, Frame *kf2, map<int, int> &matches)
     bow_arrays(kf1, d1, n1, p1); bow_arrays(kf2, d2, n2, p2);
     std::vector<int32_t> m(std::max<size_t>(n1.size(), 1), -1);
     int cnt = 0;
-    hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 0, d1.data(), n1.data(), nullptr, (int)n1.size(), d2.data(), n2.data(), nullptr,
-                                     (int)n2.size(), nullptr, _options.th_low, _options.knnRatio, 0.0, m.data(), &cnt), "search_by_bow");
+    if (!hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 0, d1.data(), n1.data(), nullptr, (int)n1.size(), d2.data(), n2.data(), nullptr,
+                                          (int)n2.size(), nullptr, _options.th_low, _options.knnRatio, 0.0, m.data(), &cnt), "search_by_bow")) return 0;
     for (size_t i = 0; i < n1.size(); ++i) if (m[i] >= 0) matches[(int)i] = m[i];
     if (_options.checkOrientation && !n1.empty()) {
         // Matcher.cpp:247-256, 271-289: the rotation histogram only lowers the returned count (the matches outside the three fullest bins stay in
@@ -559,8 +618,8 @@ int Matcher::SearchByBoW(Frame *kf1, Frame *kf2, map<int, int> &matches)
         std::vector<double> a1(n1.size()), a2(std::max<size_t>(n2.size(), 1));
         for (size_t i = 0; i < n1.size(); ++i) a1[i] = kf1->_features[i]->_angle;
         for (size_t i = 0; i < n2.size(); ++i) a2[i] = kf2->_features[i]->_angle;
-        hip::check(ygz_hip_bow_orientation(hip::Runtime::Get().ctx(), a1.data(), (int)n1.size(), a2.data(), (int)n2.size(), m.data(), &cnt, nullptr, nullptr),
-                   "bow_orientation");
+        if (!hip::check(ygz_hip_bow_orientation(hip::Runtime::Get().ctx(), a1.data(), (int)n1.size(), a2.data(), (int)n2.size(), m.data(), &cnt, nullptr, nullptr),
+                        "bow_orientation")) return 0;
     }
     return cnt;
 }
@@ -574,10 +633,11 @@ int Matcher::SearchForTriangulation(Frame *kf1, Frame *kf2, const Matrix3d &E12,
     bow_arrays(kf1, d1, n1, p1); bow_arrays(kf2, d2, n2, p2);
     std::vector<int32_t> m(std::max<size_t>(n1.size(), 1), -1);
     int cnt = 0;
-    hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 1, d1.data(), n1.data(), p1.data(), (int)n1.size(), d2.data(), n2.data(), p2.data(),
-                                     (int)n2.size(), E12.m, _options.th_low, _options.knnRatio, _options._epipolar_dsqr, m.data(), &cnt),
-               "search_for_triangulation");
-    matched_points.clear(); matched_points.reserve(cnt);
+    matched_points.clear();
+    if (!hip::check(ygz_hip_search_by_bow(hip::Runtime::Get().ctx(), 1, d1.data(), n1.data(), p1.data(), (int)n1.size(), d2.data(), n2.data(), p2.data(),
+                                          (int)n2.size(), E12.m, _options.th_low, _options.knnRatio, _options._epipolar_dsqr, m.data(), &cnt),
+                    "search_for_triangulation")) return 0;
+    matched_points.reserve(cnt);
     for (size_t i = 0; i < n1.size(); ++i) if (m[i] >= 0) matched_points.push_back(make_pair((int)i, (int)m[i]));
     return cnt;
 }
@@ -586,13 +646,156 @@ int Matcher::BruteForceMatch(Frame *frame1, Frame *frame2, vector<DMatch> &match
 {
     hip::Runtime &rt = hip::Runtime::Get();
     Mat d1 = frame1->GetAllDescriptors(), d2 = frame2->GetAllDescriptors();
-    // (the ABI takes up to grid cells x resident frames rows per set and reports YGZ_E_CAPACITY beyond: hip::check throws)
+    // (the ABI takes up to grid cells x resident frames rows per set and reports YGZ_E_CAPACITY beyond: logged, 0 matches)
     vector<int32_t> idx(d1.rows), dist(d1.rows);
-    hip::check(ygz_hip_hamming_match(rt.ctx(), d1.data, d1.rows, d2.data, d2.rows, cross_check ? 1 : 0, idx.data(), dist.data(), nullptr), "hamming_match");
     matches.clear();
+    if (!hip::check(ygz_hip_hamming_match(rt.ctx(), d1.data, d1.rows, d2.data, d2.rows, cross_check ? 1 : 0, idx.data(), dist.data(), nullptr), "hamming_match")) return 0;
     for (int i = 0; i < d1.rows; ++i) if (idx[i] >= 0) { DMatch m; m.queryIdx = i; m.trainIdx = idx[i]; m.distance = (float)dist[i]; matches.push_back(m); }
     return (int)matches.size();
 }
+
+
+// ------------------------------------------------------------------------------------------ FindDirectProjection behind its per-candidate callers
+// LocalMapping::ProjectMapPoints calls Matcher::FindDirectProjection once per candidate (src/Module/LocalMapping.cpp:88-118, 1000-3800 calls per
+// frame) and CreateNewMapPoints once per matched feature pair (:447).  One call = upload, launch, download, synchronise: ~40 us, i.e. tens of
+// milliseconds per frame.  FindDirectProjection is a pure function of (both images, both poses, the reference observation, the map point's
+// position / the feature's depth, the prediction), so the first call of a current frame that misses runs ONE launch over every candidate the caller
+// can be expected to ask about (below) and keeps the answers; the calls that follow are a table look-up.  An answer is handed out only when every
+// input of the call equals the memoised one BIT FOR BIT -- anything else takes the n = 1 launch --, so results are identical to n = 1 calls
+// (tests/test_gpu_surface.py: the per-candidate loop with YGZ_FDP_MEMO=0 against the default).
+//
+// What is speculated, MapPoint overload: for the keyframe `ref` of the call and every keyframe the previous current frame asked about, every
+// feature of the keyframe that observes a good map point (mp->_obs[ref->_keyframe_id]), with the prediction FindCandidates makes
+// (Camera2Pixel(World2Camera(mp->_pos_world, curr->_TCW)), LocalMapping.cpp:58-59, evaluated by the launch itself and compared with the caller's).
+// A keyframe that was not covered gets its own launch on its first miss.  Feature overload: the matches the same Matcher object's last
+// SearchForTriangulation(ref, curr, ...) returned, with the depth and prediction CreateNewMapPoints forms from them (LocalMapping.cpp:416-446).
+namespace {
+inline bool same7(const SE3 &T, const double t7[7])
+{ return memcmp(T.so3_.q_, t7, 32) == 0 && memcmp(T.t_, t7 + 4, 24) == 0; }
+inline bool env_on(const char *name, bool dflt) { const char *e = getenv(name); return e ? atoi(e) != 0 : dflt; }
+
+struct FdpMemo {
+    struct Ref { Frame *f; double T[7]; };
+    struct Entry {                                     // inputs (compared on every look-up) and outputs of one candidate
+        const Frame *ref; const void *key;             // key: the MapPoint (MapPoint overload) or the reference Feature (Feature overload)
+        double a[3];                                   // mp->_pos_world | (fea->_depth, 0, 0)
+        double px_ref[2]; int32_t level;
+        double px_in[2], px_out[2]; int32_t sl; uint8_t ok;
+    };
+    Frame *curr = nullptr;
+    double T_cur[7];
+    std::vector<Ref> refs;
+    std::vector<Entry> entries;
+    std::vector<int32_t> table;                        // open addressing over (ref, key), -1 = free
+    std::vector<Frame *> asked, asked_prev;            // keyframes the calls of this / the previous current frame named
+    hip::FdpMemoStats st;
+    bool enabled = env_on("YGZ_FDP_MEMO", true);
+    bool bypass = false;                               // calls take the n = 1 launch and leave the memo alone (A/B inside one loop)
+
+    static size_t hash(const Frame *ref, const void *key)
+    { uint64_t h = (uint64_t)(uintptr_t)key * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)ref * 0xC2B2AE3D27D4EB4Full; return (size_t)(h ^ (h >> 29)); }
+    void clear() { curr = nullptr; refs.clear(); entries.clear(); table.clear(); }
+    void begin(Frame *c)
+    {   // a new current frame (or the same one with another pose): the answers of the last one are void, the keyframes it named are the guess
+        if (!asked.empty()) asked_prev.swap(asked);
+        asked.clear();
+        clear();
+        curr = c; c->_TCW.to7(T_cur);
+    }
+    bool valid_for(Frame *c) const { return curr == c && same7(c->_TCW, T_cur); }
+    const Ref *ref_of(const Frame *f) const { for (const Ref &r : refs) if (r.f == f) return &r; return nullptr; }
+    void note_asked(Frame *f) { for (Frame *a : asked) if (a == f) return; asked.push_back(f); }
+    void rebuild_table()
+    {
+        size_t cap = 64;
+        while (cap < 2 * entries.size() + 2) cap <<= 1;
+        table.assign(cap, -1);
+        for (size_t i = 0; i < entries.size(); ++i) {
+            size_t h = hash(entries[i].ref, entries[i].key) & (cap - 1);
+            while (table[h] >= 0) h = (h + 1) & (cap - 1);
+            table[h] = (int32_t)i;
+        }
+    }
+    const Entry *find(const Frame *ref, const void *key) const
+    {
+        if (table.empty()) return nullptr;
+        const size_t mask = table.size() - 1;
+        for (size_t h = hash(ref, key) & mask; table[h] >= 0; h = (h + 1) & mask) {
+            const Entry &e = entries[table[h]];
+            if (e.ref == ref && e.key == key) return &e;
+        }
+        return nullptr;
+    }
+};
+FdpMemo &fdp_memo() { static FdpMemo m; return m; }
+}  // namespace
+void hip::fdp_memo_forget(const Frame *f)
+{   // a frame that is (re)initialised or deleted takes every answer that involves it along
+    FdpMemo &M = fdp_memo();
+    auto drop = [&](std::vector<Frame *> &v) { v.erase(std::remove(v.begin(), v.end(), f), v.end()); };
+    drop(M.asked); drop(M.asked_prev);
+    if (M.curr == f || M.ref_of(f)) M.clear();
+}
+void hip::SetFdpSpeculation(bool on) { fdp_memo().enabled = on; if (!on) fdp_memo().clear(); }
+void hip::SetFdpBypass(bool on) { fdp_memo().bypass = on; }
+hip::FdpMemoStats hip::GetFdpMemoStats() { return fdp_memo().st; }
+void hip::ResetFdpMemoStats() { fdp_memo().st = hip::FdpMemoStats(); }
+
+namespace {
+// the candidates of `batch` (keyframes that hold an image) against `curr` in one launch, appended to the memo
+void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    const int levels = curr->_option._pyramid_level;
+    std::vector<Frame *> kfs;
+    for (Frame *r : batch) if (r != curr && !r->_pyramid.empty() && !M.ref_of(r) && std::find(kfs.begin(), kfs.end(), r) == kfs.end()) kfs.push_back(r);
+    if (kfs.empty() || curr->_pyramid.empty()) return;
+    const int cs = rt.Resident(curr);
+    std::vector<int32_t> kf_slot; std::vector<double> kf_T;
+    for (Frame *r : kfs) { kf_slot.push_back(rt.Resident(r)); double t7[7]; r->_TCW.to7(t7); kf_T.insert(kf_T.end(), t7, t7 + 7); }
+    if (curr->_hip_slot != cs) return;                                 // (more keyframes than HBM slots: no speculation)
+    for (size_t k = 0; k < kfs.size(); ++k) if (kfs[k]->_hip_slot != kf_slot[k]) return;
+    std::vector<int32_t> ck, cl; std::vector<double> pos, cpx; std::vector<const MapPoint *> cmp;
+    for (size_t k = 0; k < kfs.size(); ++k) {
+        Frame *r = kfs[k];
+        const size_t n0 = r->_features.size();
+        ck.reserve(ck.size() + n0); cl.reserve(cl.size() + n0); pos.reserve(pos.size() + 3 * n0); cpx.reserve(cpx.size() + 2 * n0); cmp.reserve(cmp.size() + n0);
+        for (const Feature *f : r->_features) {
+            const MapPoint *mp = f->_mappoint;
+            if (!mp || mp->_bad) continue;
+            auto it = mp->_obs.find(r->_keyframe_id);                  // the Feature the method reads (Matcher.cpp:361)
+            if (it == mp->_obs.end() || it->second != f) continue;
+            if (f->_level < 0 || f->_level >= levels) continue;
+            ck.push_back((int32_t)k); cl.push_back(f->_level); cmp.push_back(mp);
+            pos.push_back(mp->_pos_world[0]); pos.push_back(mp->_pos_world[1]); pos.push_back(mp->_pos_world[2]);
+            cpx.push_back(f->_pixel[0]); cpx.push_back(f->_pixel[1]);
+        }
+    }
+    const size_t first_ref = M.refs.size();
+    for (size_t k = 0; k < kfs.size(); ++k) { FdpMemo::Ref R; R.f = kfs[k]; memcpy(R.T, &kf_T[7 * k], 56); M.refs.push_back(R); }
+    const int n = (int)ck.size();
+    if (n == 0) return;
+    std::vector<uint8_t> vis(n), ok(n); std::vector<double> proj(2 * (size_t)n), out(2 * (size_t)n); std::vector<int32_t> sl(n);
+    if (ygz_hip_find_direct_projection_mp(rt.ctx(), cs, M.T_cur, (int)kfs.size(), kf_slot.data(), kf_T.data(), n, ck.data(), pos.data(), cpx.data(),
+                                          cl.data(), nullptr, vis.data(), proj.data(), ok.data(), out.data(), sl.data()) != YGZ_OK) {
+        M.refs.resize(first_ref);                                      // nothing learnt; the calls take the n = 1 path (and report the error there)
+        return;
+    }
+    M.st.launches++; M.st.speculated += n;
+    M.entries.reserve(M.entries.size() + n);
+    for (int i = 0; i < n; ++i) {
+        if (!vis[i]) continue;                                         // FindCandidates drops it (LocalMapping.cpp:60-63): nobody asks
+        FdpMemo::Entry e;
+        e.ref = kfs[ck[i]]; e.key = cmp[i];
+        e.a[0] = pos[3 * i]; e.a[1] = pos[3 * i + 1]; e.a[2] = pos[3 * i + 2];
+        e.px_ref[0] = cpx[2 * i]; e.px_ref[1] = cpx[2 * i + 1]; e.level = cl[i];
+        e.px_in[0] = proj[2 * i]; e.px_in[1] = proj[2 * i + 1];
+        e.px_out[0] = out[2 * i]; e.px_out[1] = out[2 * i + 1]; e.sl = sl[i]; e.ok = ok[i];
+        M.entries.push_back(e);
+    }
+    M.rebuild_table();
+}
+}  // namespace
 
 int Matcher::FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Feature *> &feas, vector<Vector2d> &px_curr,
                                        vector<int> &search_level, vector<bool> &ok)
@@ -614,7 +817,7 @@ int Matcher::FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Fea
             pr[2 * i] = f->_pixel[0]; pr[2 * i + 1] = f->_pixel[1]; dep[i] = f->_depth; lvl[i] = f->_level;
             pc[2 * i] = px_curr[base + i][0]; pc[2 * i + 1] = px_curr[base + i][1];
         }
-        hip::check(ygz_hip_find_direct_projection(rt.ctx(), &pair, pr.data(), dep.data(), lvl.data(), pc.data(), sl.data(), o.data(), m), "find_direct_projection");
+        if (!hip::check(ygz_hip_find_direct_projection(rt.ctx(), &pair, pr.data(), dep.data(), lvl.data(), pc.data(), sl.data(), o.data(), m), "find_direct_projection")) return good;
         for (int i = 0; i < m; ++i) {
             px_curr[base + i] = Vector2d(pc[2 * i], pc[2 * i + 1]); search_level[base + i] = sl[i]; ok[base + i] = o[i] != 0; good += o[i] != 0;
         }
@@ -633,17 +836,43 @@ bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, Feature *fea_ref, Ve
 }
 
 bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector2d &px_curr, int &search_level)
-{
+{   // Matcher.cpp:356-383.  The reference does not test the sign of the depth in this overload; neither does the kernel (k_lmap_match)
     Feature *fea = mp->_obs[ref->_keyframe_id];
-    Feature tmp(fea->_pixel, fea->_level);               // same pixel/level, depth from the map point (Matcher.cpp:361-363)
-    tmp._depth = ref->_camera->World2Camera(mp->_pos_world, ref->_TCW)[2];
-    tmp._frame = ref;
-    // NB the reference does not test the depth in this overload; the ABI returns false for depth < 0 (a map point
-    // behind the reference camera), which is the only input on which the two differ.
-    vector<Vector2d> px(1, px_curr); vector<int> sl; vector<bool> ok;
-    FindDirectProjectionBatch(ref, curr, vector<Feature *>(1, &tmp), px, sl, ok);
-    px_curr = px[0]; search_level = sl[0];
-    return ok[0];
+    FdpMemo &M = fdp_memo();
+    if (M.enabled && !M.bypass) {
+        if (!M.valid_for(curr)) M.begin(curr);
+        M.note_asked(ref);
+        for (int pass = 0; pass < 2; ++pass) {
+            const FdpMemo::Ref *R = M.ref_of(ref);
+            if (R && !same7(ref->_TCW, R->T)) { Frame *c = curr; M.clear(); M.curr = c; c->_TCW.to7(M.T_cur); R = nullptr; }   // the keyframe moved (local BA)
+            if (R) {
+                const FdpMemo::Entry *e = M.find(ref, mp);
+                if (e && e->a[0] == mp->_pos_world[0] && e->a[1] == mp->_pos_world[1] && e->a[2] == mp->_pos_world[2]
+                      && e->px_ref[0] == fea->_pixel[0] && e->px_ref[1] == fea->_pixel[1] && e->level == fea->_level
+                      && e->px_in[0] == px_curr[0] && e->px_in[1] == px_curr[1]) {
+                    M.st.hits++;
+                    px_curr = Vector2d(e->px_out[0], e->px_out[1]); search_level = e->sl;
+                    return e->ok != 0;
+                }
+                break;                                                  // covered keyframe, unknown or changed candidate: n = 1
+            }
+            if (pass == 0) {
+                std::vector<Frame *> batch(1, ref);
+                if (M.refs.empty()) batch.insert(batch.end(), M.asked_prev.begin(), M.asked_prev.end());
+                fdp_speculate_mp(M, curr, batch);
+            }
+        }
+        M.st.single++;
+    }
+    hip::Runtime &rt = hip::Runtime::Get();
+    const int32_t kf_slot = rt.Resident(ref), cs = rt.Resident(curr), ck = 0, lvl = fea->_level;
+    double Tr[7], Tc[7]; ref->_TCW.to7(Tr); curr->_TCW.to7(Tc);
+    double out[2] = { 0, 0 }; const double pin[2] = { px_curr[0], px_curr[1] };
+    int32_t sl = 0; uint8_t ok = 0;
+    if (!hip::check(ygz_hip_find_direct_projection_mp(rt.ctx(), cs, Tc, 1, &kf_slot, Tr, 1, &ck, mp->_pos_world.data(), fea->_pixel.data(), &lvl, pin,
+                                                      nullptr, nullptr, &ok, out, &sl), "find_direct_projection_mp")) return false;
+    px_curr = Vector2d(out[0], out[1]); search_level = sl;
+    return ok != 0;
 }
 
 int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_keyframes, const std::set<MapPoint *> &local_map_points)
@@ -687,15 +916,15 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
     vector<uint8_t> in_view(P); vector<double> px_proj(2 * (size_t)P), px_match(2 * (size_t)P); vector<int32_t> match(P), level(P);
     double Tc[7]; current->_TCW.to7(Tc);
     int32_t n = 0;
-    hip::check(ygz_hip_track_local_map(rt.ctx(), rt.Resident(current), Tc, &m, in_view.data(), px_proj.data(), match.data(), px_match.data(),
-                                       level.data(), &n), "track_local_map");
+    if (!hip::check(ygz_hip_track_local_map(rt.ctx(), rt.Resident(current), Tc, &m, in_view.data(), px_proj.data(), match.data(), px_match.data(),
+                                            level.data(), &n), "track_local_map")) return 0;
+    current->_features.reserve(current->_features.size() + (size_t)n);
     for (int p = 0; p < P; ++p) {
         MapPoint *mp = mps[p];
         if (mp->_bad) continue;
         if (!in_view[p]) { mp->_track_in_view = false; continue; }     // :59-62
         mp->_cnt_visible++;                                            // :64
         if (match[p] < 0) continue;
-        if (current->_features.capacity() < current->_features.size() + (size_t)n) current->_features.reserve(current->_features.size() + (size_t)n);
         Feature *feature = new Feature(Vector2d(px_match[2 * p], px_match[2 * p + 1]), level[p], cscore[match[p]]);   // :104-111
         feature->_frame = current;
         feature->_mappoint = mp;
@@ -724,12 +953,12 @@ int Align2DBatch(const cv::Mat &cur_img, const uint8_t *pwb, int n, const int n_
 {
     hip::Runtime &rt = hip::Runtime::Get();
     Frame *f = nullptr; int level = 0;
-    if (!rt.FindLevel(cur_img.data, &f, &level)) throw std::runtime_error("cvutils::Align2D: cur_img is not a pyramid level of an initialised Frame");
+    ok.assign(n, false);
+    if (!rt.FindLevel(cur_img.data, &f, &level)) { LOG(ERROR) << "cvutils::Align2D: cur_img is not a pyramid level of an initialised Frame" << endl; return 0; }
     const int slot = rt.Resident(f);
     vector<double> uv(2 * (size_t)n); vector<uint8_t> o(n);
     for (int i = 0; i < n; ++i) { uv[2 * i] = px[i][0]; uv[2 * i + 1] = px[i][1]; }
-    hip::check(ygz_hip_align2d(rt.ctx(), slot, level, pwb, nullptr, uv.data(), o.data(), nullptr, n, n_iter), "align2d");
-    ok.assign(n, false);
+    if (!hip::check(ygz_hip_align2d(rt.ctx(), slot, level, pwb, nullptr, uv.data(), o.data(), nullptr, n, n_iter), "align2d")) return 0;
     int good = 0;
     for (int i = 0; i < n; ++i) { px[i] = Vector2d(uv[2 * i], uv[2 * i + 1]); ok[i] = o[i] != 0; good += o[i] != 0; }
     return good;
@@ -819,7 +1048,7 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     ygz_ba_stats st;
     // optimize(20), then the inlier test on the optimised state: chi2 > 5.991 -> Feature::_bad (BA.cpp:501-515) -- one call, the graph is uploaded once
     std::vector<double> chi2_edge(pb.n_edges);
-    hip::check(ygz_hip_ba_optimize_chi2(rt.ctx(), &pb, poses.data(), points.data(), 20, &st, chi2_edge.data()), "ba_optimize_chi2");
+    if (!hip::check(ygz_hip_ba_optimize_chi2(rt.ctx(), &pb, poses.data(), points.data(), 20, &st, chi2_edge.data()), "ba_optimize_chi2")) return;      // the map as it was
     int cntOutlier = 0;
     for (size_t i = 0; i < features.size(); ++i) if (chi2_edge[i] > 5.991) { cntOutlier++; features[i]->_bad = true; }
     for (Frame *frame : local_keyframes) {             // BA.cpp:520-531
@@ -872,7 +1101,7 @@ struct CeresArrays {
         pb.edge_pose = edge_pose.data(); pb.edge_point = edge_point.data(); pb.obs = obs.data();
         pb.edge_huber = any_huber ? huber.data() : nullptr; pb.formulation = 2;
         ygz_ceres_summary s;
-        hip::check(ygz_hip_ba_solve_ceres(hip::Runtime::Get().ctx(), &pb, poses.data(), points.data(), nullptr, &s), "ba_solve_ceres");
+        if (!hip::check(ygz_hip_ba_solve_ceres(hip::Runtime::Get().ctx(), &pb, poses.data(), points.data(), nullptr, &s), "ba_solve_ceres")) return false;
         if (sum) *sum = s;
         return s.termination != YGZ_CERES_FAILURE;
     }
@@ -959,8 +1188,8 @@ void OptimizeCurrentPoseOnlyBatch(const vector<Frame *> &frames)
     }
     std::vector<uint8_t> bad(std::max<size_t>(depth.size(), 1));
     if (depth.empty()) depth.push_back(0);
-    hip::check(ygz_hip_optimize_pose_only(hip::Runtime::Get().ctx(), (int)frames.size(), off.data(), px.data(), pw.data(), poses.data(),
-                                          bad.data(), depth.data(), nullptr, nullptr), "optimize_pose_only");
+    if (!hip::check(ygz_hip_optimize_pose_only(hip::Runtime::Get().ctx(), (int)frames.size(), off.data(), px.data(), pw.data(), poses.data(),
+                                               bad.data(), depth.data(), nullptr, nullptr), "optimize_pose_only")) return;
     size_t g = 0;
     for (size_t fi = 0; fi < frames.size(); ++fi) {
         Frame *f = frames[fi];
