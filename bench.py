@@ -54,6 +54,9 @@ class Pipeline:
         self.ctx = _lib.HipContext(width=W, height=H, levels=LEVELS, max_frames=batch, device=device, stream=stream)
         self.frames, self.poses, self.depths, self.ba = inputs if inputs is not None else build_inputs(batch, rank)
         self.from_bgr = True
+        # LK's working images (framed copies + Scharr images) right behind the pyramid, on a side stream beside the extractor: measured -1 % of the
+        # step in round 5 (5.07 -> 5.005 ms) and adopted in round 6; YGZ_BENCH_EARLY_IMAGES=0 gives the round-5 order back
+        self.early_images = bool(overlap) and os.environ.get("YGZ_BENCH_EARLY_IMAGES", "1") != "0"
 
     def setup_stream(self, upload):
         """stream mode: the batch lives in page-locked host memory and crosses PCIe every step; so do the results"""
@@ -138,6 +141,8 @@ class Pipeline:
         # alignment and the HBM / FP64-bound BA build then share the CUs with the VALU-bound extractor, LK and matcher.
         # (Issuing the BA build -- it depends on no image -- before the extractor was measured slower: 3.64 against 3.55 ms.)
         c.build_pyramid(0, self.B, from_bgr=self.from_bgr)    # A1  InitFrame
+        if self.early_images:
+            c.track_klt_prepare()                             # LK's Scharr images on a side stream, beside the extractor (they depend on the pyramid only)
         c.detect(0, self.B)                                   # A2-A7 FeatureDetector::Detect
         c.track_reload(True)                                  # track sets from the fresh keypoints
         c.track_sparse_align()                                # L3  SparseImgAlign::run
@@ -293,6 +298,91 @@ def valu_roofline(pipe, a, probe_kernel, probe_avg_s, n_kp):
     return out
 
 
+
+def kernel_table(pipe, a, n_kp):
+    """`roofline_valu.step_kernels`: EVERY kernel of the step, timed with HIP events around each of its launches -- inside two extra steps (beside
+    whatever shares the GPU with it there) and with its stage issued alone --, with the algorithmic bytes of SURVEY 8d, the HBM bytes of the counter
+    passes (profiles/traffic.json) and the wave64 VALU instructions of the SQ pass (profiles/valu_counts.json), so that each fraction DESIGN.md
+    section 4 quotes can be recomputed from this line and profiles/ alone.  Runs after the timed region."""
+    import torch
+    c = pipe.ctx
+    base = os.path.join(ROOT, "profiles")
+    try:
+        counts = json.load(open(os.path.join(base, "valu_counts.json")))
+    except Exception:
+        counts = {"kernels": {}, "keypoints_per_frame": n_kp}
+    try:
+        tj = json.load(open(os.path.join(base, "traffic.json")))
+    except Exception:
+        tj = {"kernels": {}, "batch": 0}
+    n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    B = a.batch
+    n_px = sum((W >> L) * (H >> L) for L in range(LEVELS))
+    klt_px = 0
+    w, h = W, H
+    for _ in range(5):                                        # LK's five levels (maxLevel 4)
+        klt_px += w * h; w, h = (w + 1) // 2, (h + 1) // 2
+    edges = float(len(pipe.ba["obs"]))
+    # probe id -> (name in the profiler tables, stage call that issues it, algorithmic bytes per STEP of B frames or None)
+    rows = [("k_bgr2gray", "k_bgr2gray16", lambda: c.build_pyramid(0, B, from_bgr=True), B * 4.0 * W * H, "cvtColor: 3 B read + 1 B written per pixel"),
+            ("k_pyr_down", "k_pyr_down", lambda: c.build_pyramid(0, B, from_bgr=True), B * 480000.0 * (W * H) / 307200.0, "SURVEY 8d: 480 000 B per VGA frame"),
+            ("k_fast_select", "k_fast_select", lambda: c.detect(0, B), B * (n_px + 8 * 3000 + 100 * 3000), "every pyramid pixel once + 108 B per NMS corner"),
+            ("k_compact", "k_compact", lambda: c.detect(0, B), None, None),
+            ("k_describe", "k_describe", lambda: c.detect(0, B), B * n_kp * 997.0, "961 B window + 36 B written per keypoint"),
+            ("k_track_load", "k_track_load", lambda: c.track_reload(True), None, None),
+            ("k_sparse_align", "k_sparse_align2", c.track_sparse_align, B * n_kp * 3 * 80.0, "80 B per feature and level per linearisation (one linearisation counted)"),
+            ("k_ba_pose_prep", "k_ba_pose_prep", lambda: c.ba_linearize_resident(0, B), None, None),
+            ("k_ba_points", "k_ba_points", lambda: c.ba_linearize_resident(0, B), B * edges * 170.0, "170 B per edge"),
+            ("k_ba_final", "k_ba_final", lambda: c.ba_linearize_resident(0, B), None, None),
+            ("k_hamming_nn", "k_hamming_f4", lambda: c.match_slots_again(1), B * 72000.0 * 0.5, "72 000 B per cross-checked frame pair, two launches"),
+            ("k_match_finalize", "k_match_finalize", lambda: c.match_slots_again(1), None, None),
+            ("k_find_direct_projection", "k_find_direct_projection", c.track_direct, B * n_kp * 220.0, "220 B per candidate"),
+            ("k_scharr", "k_scharr", c.track_klt, B * klt_px * 5.0, "1 B read + 4 B written per pixel of LK's five levels"),
+            ("k_klt", "k_klt3", c.track_klt, B * n_kp * 5 * 2 * 23 * 23, "23 x 23 B window, 2 images, 5 levels per point")]
+    kp_scale = n_kp / max(counts.get("keypoints_per_frame", n_kp), 1.0)
+    out = {}
+    for kid, name, stage, alg, alg_note in rows:
+        try:
+            c.synchronize()
+            c.probe_begin(kid, 256)
+            for _ in range(2):
+                pipe.step()
+            ms_in, n_in = c.probe_end()
+            c.probe_begin(kid, 256)
+            for _ in range(2):
+                stage()
+            ms_al, n_al = c.probe_end()
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+            continue
+        if not n_in:
+            continue
+        per_step = n_in / 2.0                                  # launches per step
+        t_in = ms_in / 2.0 * 1e-3                              # seconds of this kernel per step, inside the step
+        t_al = ms_al / 2.0 * 1e-3 if n_al else None
+        e = {"launches_per_step": per_step, "ms_in_step": t_in * 1e3, "ms_alone": None if t_al is None else t_al * 1e3}
+        if alg:
+            e["algorithmic_bytes_per_step"] = alg
+            e["algorithmic_bytes_are"] = alg_note
+            e["hbm_frac_in_step"] = alg / t_in / 8e12
+            if t_al:
+                e["hbm_frac_alone"] = alg / t_al / 8e12
+        tk = tj.get("kernels", {}).get(name)
+        if tk and tj.get("batch") == B:
+            e["counter_hbm_bytes_per_step"] = tk["hbm_bytes"] * per_step
+        vk = counts.get("kernels", {}).get(name)
+        if vk:
+            scale = kp_scale if name in ("k_describe", "k_sparse_align2", "k_hamming_f4", "k_find_direct_projection", "k_klt3") else 1.0
+            instr = vk["valu_per_unit"] * B * scale * per_step      # per_unit = mean per dispatch / frames of the counter pass
+            e["valu_wave64_instr_per_step"] = instr
+            e["valu_frac_of_guide_peak_in_step"] = instr / n_simd / t_in / 1e9 / 1.2
+            if t_al:
+                e["valu_frac_of_guide_peak_alone"] = instr / n_simd / t_al / 1e9 / 1.2
+        out[name] = e
+    c.synchronize()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- surface mode: the drop-in path, one frame at a time
 SURF_KF_STRIDE, SURF_LOCAL_KFS = 8, 3                         # keyframe every 8th frame; LocalMapping.local_keyframes: 3 (config/default.yaml)
 
@@ -321,7 +411,7 @@ def surface_gpu(bgr, kfd, caller=0):
     lib = C.CDLL(os.path.join(ROOT, "tests", "cpp", "libbench_surface.so"))
     n = len(bgr)
     nk = len(kfd)
-    ms = np.zeros(n); T = np.zeros((n, 7)); cnt = np.zeros((n, 4), np.int32); ba = np.zeros((nk, 4)); stage = np.zeros(8); memo = np.zeros(6)
+    ms = np.zeros(n); T = np.zeros((n, 7)); cnt = np.zeros((n, 4), np.int32); ba = np.zeros((nk, 4)); stage = np.zeros(8); memo = np.zeros(9)
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
     rc = lib.ygz_bench_surface2(p(bgr, C.c_uint8), p(kfd, C.c_float), n, W, H, SURF_KF_STRIDE, SURF_LOCAL_KFS, int(caller), p(ms, C.c_double), p(T, C.c_double),
                                 p(cnt, C.c_int32), p(ba, C.c_double), p(stage, C.c_double), p(memo, C.c_double))
@@ -329,7 +419,8 @@ def surface_gpu(bgr, kfd, caller=0):
         raise RuntimeError("ygz_bench_surface failed")
     names = ("InitFrame", "SparseImageAlignment", "ProjectMapPoints", "OptimizeCurrentPoseOnly", "Detect", "keyframe bookkeeping", "LocalBAG2O", "delete frame")
     return dict(ms=ms, T=T, counts=cnt, ba=ba, stage_ms_per_frame={k: float(v) / n for k, v in zip(names, stage)},
-                memo=dict(zip(("hits", "single", "launches", "speculated", "calls", "mismatches"), (int(x) for x in memo))))
+                memo=dict(zip(("hits", "single", "launches", "speculated", "calls", "mismatches", "find_candidates_ms", "fdp_calls_ms", "speculate_ms"),
+                              [int(x) for x in memo[:6]] + [float(x) for x in memo[6:]])))
 
 
 def surface_cpu(bgr, kfd, budget_s=14.0):
@@ -481,6 +572,12 @@ def surface_block(n_frames=204, cpu_budget_s=14.0, want_cpu=True):
                         "every_call_its_own_launch": {"frames": int(n1), "frames_per_s": float((n1 - 1) / (s1["ms"][1:].sum() * 1e-3)),
                                                       "ms_per_frame_median": float(np.median(s1["ms"][1:])),
                                                       "ProjectMapPoints_ms_per_frame": s1["stage_ms_per_frame"]["ProjectMapPoints"]}}
+    d4 = surface_gpu(bgr[:n1], kfd[:(n1 + SURF_KF_STRIDE - 1) // SURF_KF_STRIDE], caller=4)["memo"]
+    out["unchanged"]["TrackLocalMap_ms_per_frame_where"] = {
+        "FindCandidates (the caller's std::map<Feature*, Vector2d>)": d4["find_candidates_ms"] / (n1 - 1),
+        "inside the FindDirectProjection calls": d4["fdp_calls_ms"] / (n1 - 1),
+        "of which the speculative launch (gather, launch, table)": d4["speculate_ms"] / (n1 - 1),
+        "note": "a separate run of %d frames with the host clock around every call (~0.1 ms per frame of clock reads included)" % n1}
     if want_cpu:
         c = surface_cpu(bgr, kfd, cpu_budget_s)
         m = len(c["ms"])
@@ -880,6 +977,15 @@ def main():
                     "traffic_collected_on_other_kernel_sources": traffic_stale,
                     "note": "frac is the HBM fraction (algorithmic bytes / launch time / 8 TB/s); the kernel is VALU-issue bound, see roofline_valu"}
         roofline_valu = valu_roofline(pipe, a, probe_kernel, avg_s, n_kp)
+        if a.profile_part is None and a.mode == "step" and isinstance(roofline_valu, dict):
+            try:
+                roofline_valu["step_kernels"] = kernel_table(pipe, a, n_kp)
+                roofline_valu["step_kernels_note"] = ("every kernel of the step: HIP events around each of its launches in two extra steps (ms_in_step: beside the side "
+                                                      "streams) and with its stage issued alone (ms_alone); hbm_frac = algorithmic bytes (SURVEY 8d) / time / 8 TB/s; "
+                                                      "counter bytes from profiles/traffic.json, VALU instructions from profiles/valu_counts.json (guide peak: 1.2 G wave64 "
+                                                      "instructions / s / SIMD).  The events serialise nothing but add ~2 us per launch")
+            except Exception as e:
+                roofline_valu["step_kernels"] = {"error": repr(e)}
         alone = roofline_valu.get("kernels", {}).get(roofline["kernel"], {}).get("alone") if isinstance(roofline_valu, dict) else None
         if alone:                                             # the same kernel with the GPU to itself (in the step its launch shares the CUs with three side streams)
             roofline["avg_launch_us_alone"] = alone["avg_launch_us"]

@@ -31,7 +31,7 @@ private:
 bool check(int rc, const char *what);
 // Matcher::FindDirectProjection behind per-candidate callers (ygz_host.cpp: FdpMemo): one speculative launch per current frame, answers handed out
 // only on bit-equal inputs.  Environment YGZ_FDP_MEMO=0 (or SetFdpSpeculation(false)) makes every call its own n = 1 launch.
-struct FdpMemoStats { unsigned long long hits = 0, single = 0, launches = 0, speculated = 0; };
+struct FdpMemoStats { unsigned long long hits = 0, single = 0, launches = 0, speculated = 0; double speculate_ms = 0; };
 void SetFdpSpeculation(bool on);
 void SetFdpBypass(bool on);             // true: calls take their own n = 1 launch and leave the memo as it is (to compare the two inside one loop)
 FdpMemoStats GetFdpMemoStats();

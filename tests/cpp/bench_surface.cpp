@@ -33,6 +33,8 @@ struct UnchangedCaller {
     std::set<MapPoint *> *_local_map_points;
     bool _verify = false;                                 // every FindDirectProjection call repeated as its own n = 1 launch and compared bit for bit
     long _calls = 0, _mismatches = 0;
+    bool _clock = false;                                  // (diagnostic run: host clock around FindCandidates and around every FindDirectProjection call)
+    double _t_find = 0, _t_calls = 0;
 
     std::map<Feature *, Vector2d> FindCandidates(Frame *current)
     {
@@ -56,7 +58,9 @@ struct UnchangedCaller {
             if (matched_mps.find(mp) != matched_mps.end()) continue;
             int level = 0;
             const Vector2d px_in = candidate.second;
+            const double tc_ = _clock ? now_ms() : 0;
             const bool ret = _matcher->FindDirectProjection(candidate.first->_frame, current, mp, candidate.second, level);
+            if (_clock) _t_calls += now_ms() - tc_;
             ++_calls;
             if (_verify) {
                 Vector2d px2 = px_in; int level2 = 0;
@@ -76,7 +80,9 @@ struct UnchangedCaller {
     }
     int TrackLocalMap(Frame *current)                     // LocalMapping.cpp:24-33 (the pose-only BA that follows is the loop's next stage)
     {
+        const double t0_ = _clock ? now_ms() : 0;
         std::map<Feature *, Vector2d> candidates = FindCandidates(current);
+        if (_clock) _t_find += now_ms() - t0_;
         return ProjectMapPoints(current, candidates);
     }
 };
@@ -94,9 +100,11 @@ extern "C" {
 // caller: 0 = TrackLocalMap through the batch method Matcher::ProjectMapPoints (one launch; a method the reference does not have);
 //         1 = through reference-named methods only: FindCandidates + one Matcher::FindDirectProjection per candidate (UnchangedCaller above);
 //         2 = as 1 with the speculative launch behind FindDirectProjection switched off (every call its own n = 1 launch);
-//         3 = as 1, and every call is repeated as its own n = 1 launch and compared bit for bit (memo [5] counts the differences).
-// memo [6] (may be NULL): FindDirectProjection calls answered from the speculative launch, calls that took an n = 1 launch, speculative launches,
-// candidates they evaluated, calls the caller made, calls whose memoised answer differed from the n = 1 launch (caller 3).
+//         3 = as 1, and every call is repeated as its own n = 1 launch and compared bit for bit (memo [5] counts the differences);
+//         4 = as 1 with the host clock around FindCandidates and every FindDirectProjection call (memo [6..8]; the clock reads cost ~0.1 ms per frame).
+// memo [9] (may be NULL): FindDirectProjection calls answered from the speculative launch, calls that took an n = 1 launch, speculative launches,
+// candidates they evaluated, calls the caller made, calls whose memoised answer differed from the n = 1 launch (caller 3), ms in FindCandidates
+// (the caller's own containers), ms inside the FindDirectProjection calls, of which ms in the speculative launches (gather + launch + table).
 int ygz_bench_surface2(const uint8_t *bgr, const float *kf_depth, int n, int w, int h, int kf_stride, int local_kfs, int caller, double *ms, double *T_out,
                        int32_t *counts, double *ba, double *stage_ms, double *memo)
 {
@@ -110,7 +118,7 @@ int ygz_bench_surface2(const uint8_t *bgr, const float *kf_depth, int n, int w, 
         detector.LoadParams();
         Matcher matcher;
         UnchangedCaller lm = { &matcher, nullptr, nullptr };
-        lm._verify = caller == 3;
+        lm._verify = caller == 3; lm._clock = caller == 4;
         hip::SetFdpSpeculation(caller != 2);
         hip::ResetFdpMemoStats();
         Memory::Clean();
@@ -195,7 +203,7 @@ int ygz_bench_surface2(const uint8_t *bgr, const float *kf_depth, int n, int w, 
         Frame::SetCamera(nullptr);
         if (stage_ms) for (int k = 0; k < 8; ++k) stage_ms[k] = st_[k];
         if (memo) { const hip::FdpMemoStats ms_ = hip::GetFdpMemoStats(); memo[0] = (double)ms_.hits; memo[1] = (double)ms_.single; memo[2] = (double)ms_.launches; memo[3] = (double)ms_.speculated;
-                    memo[4] = (double)lm._calls; memo[5] = (double)lm._mismatches; }
+                    memo[4] = (double)lm._calls; memo[5] = (double)lm._mismatches; memo[6] = lm._t_find; memo[7] = lm._t_calls; memo[8] = ms_.speculate_ms; }
         hip::SetFdpSpeculation(true);
         return 0;
     } catch (const std::exception &e) {

@@ -10,6 +10,7 @@
 #include <fstream>
 #include <stdexcept>
 #include <cstdlib>
+#include <chrono>
 
 int ygz_log::verbosity = 0;
 
@@ -745,6 +746,8 @@ namespace {
 // the candidates of `batch` (keyframes that hold an image) against `curr` in one launch, appended to the memo
 void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch)
 {
+    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
     hip::Runtime &rt = hip::Runtime::Get();
     const int levels = curr->_option._pyramid_level;
     std::vector<Frame *> kfs;
@@ -763,8 +766,8 @@ void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch
         for (const Feature *f : r->_features) {
             const MapPoint *mp = f->_mappoint;
             if (!mp || mp->_bad) continue;
-            auto it = mp->_obs.find(r->_keyframe_id);                  // the Feature the method reads (Matcher.cpp:361)
-            if (it == mp->_obs.end() || it->second != f) continue;
+            // (whether f is the Feature the method reads, mp->_obs[ref->_keyframe_id] (Matcher.cpp:361), is settled at look-up time by comparing
+            // pixel and level: a tree look-up per feature here was a third of the gather)
             if (f->_level < 0 || f->_level >= levels) continue;
             ck.push_back((int32_t)k); cl.push_back(f->_level); cmp.push_back(mp);
             pos.push_back(mp->_pos_world[0]); pos.push_back(mp->_pos_world[1]); pos.push_back(mp->_pos_world[2]);
