@@ -386,6 +386,10 @@ int  ygz_hip_ba_optimize_chi2(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double
  * Returns YGZ_BA_PATH_RESIDENT, or YGZ_BA_PATH_HOST_LOOP | the reason bits; 0 before the first call. */
 enum { YGZ_BA_PATH_RESIDENT = 1, YGZ_BA_PATH_HOST_LOOP = 2, YGZ_BA_WHY_FREE_POSES = 16, YGZ_BA_WHY_REPEATED_EDGES = 32, YGZ_BA_WHY_FORCED = 64 };
 int  ygz_hip_ba_last_path(const ygz_hip_ctx *ctx);
+/* The resident LM's teams synchronise through a barrier in HBM; members that share an XCD take a light form of it (no L2 write-back).  The light
+ * form is self-tested once per context before the first team launch (a message-passing litmus through the barrier itself): 1 = passed and in use,
+ * 0 = failed on this device / partition mode (every barrier takes the full form), -1 = no team launch yet.  YGZ_LM_XCD_BARRIER=0 / 1 overrides. */
+int  ygz_hip_ba_light_barrier(const ygz_hip_ctx *ctx);
 /* The same loop entirely on the GPU for uploaded windows window_begin .. +n_windows-1 (formulation 0, at most 20 free
  * poses per window): one workgroup per window runs linearisation, Schur complement, Cholesky, back-substitution, update and
  * the lambda policy in HBM/LDS without a host round trip, all windows concurrently.  The windows' states are updated in

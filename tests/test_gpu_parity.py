@@ -2,6 +2,7 @@
 (ygz_slam_amd._lib -> libygz_hip.so) against the CPU oracle and the committed golden vectors.
 Integer / byte / index stages: bit-exact.  Float stages: the tolerance is written at the assert
 (north_star: LK tracks and BA residuals within 1e-5 relative)."""
+import os
 import numpy as np
 import pytest
 import fixtures
@@ -1061,7 +1062,10 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
     ctx = make_ctx(hip_lib, max_frames=1)
     for i, w in enumerate(wins):
         ctx.ba_upload(i, w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
+    assert ctx.ba_light_barrier() == -1                      # no team launch yet
     stats = ctx.ba_optimize_resident(0, len(wins), iterations=20)
+    # the same-XCD barrier (no L2 write-back) is only used after its message-passing self-test passed on this device: it does on an MI355X in SPX mode
+    assert ctx.ba_light_barrier() == (int(os.environ["YGZ_LM_XCD_BARRIER"] != "0") if "YGZ_LM_XCD_BARRIER" in os.environ else 1)
     for i, w in enumerate(wins):
         po, pt, so = oracle.g2o_lm(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"], max_iterations=20)
         pg, tg = ctx.ba_get_state(i, len(w["poses"]), len(w["points"]))

@@ -57,6 +57,7 @@ def _run(tmp_path, name, env):
 SWITCHES = {"valu_matcher": ({"YGZ_HAMMING_VALU": "1"}, ("match",)),
             "lm_single_workgroup": ({"YGZ_BA_LM_TEAM": "1"}, ("lm",)),
             "lm_full_team_barrier": ({"YGZ_LM_XCD_BARRIER": "0"}, ("lm",)),
+            "copy_engine_transfers": ({"YGZ_ZERO_COPY": "0"}, ("match", "sa", "lm")),      # small transfers through hipMemcpyAsync instead of kernels that read / write the page-locked staging memory
             "sparse_align_256_lanes": ({"YGZ_SA_THREADS": "256"}, ("sa~",))}     # the shape a launch of many pairs takes (default here: 512 lanes for two pairs); "~": the
                                                                                  # FP64 sums of H and J^T r run over 4 instead of 8 wavefronts -> same Gauss-Newton trajectory, pose to 1e-12
 
@@ -76,7 +77,9 @@ def test_alternate_paths_give_identical_results(tmp_path):
     # product sources is one of these
     import re
     known = {"YGZ_HAMMING_VALU", "YGZ_BA_LM_TEAM", "YGZ_LM_XCD_BARRIER", "YGZ_SA_THREADS", "YGZ_BA_HOST_LOOP", "YGZ_LM_DEBUG", "YGZ_FAST_DEBUG", "YGZ_HIP_DEVICE",
-             "YGZ_HIP_MAX_FRAMES", "YGZ_OFFLINE_TRACE", "YGZ_OFFLINE_VERBOSE"}
+             "YGZ_HIP_MAX_FRAMES", "YGZ_OFFLINE_TRACE", "YGZ_OFFLINE_VERBOSE", "YGZ_ZERO_COPY", "YGZ_HOST_TRACE"}
+    # (ygz_host.cpp reads YGZ_FDP_MEMO and YGZ_HOST_TRACE through its env_on() helper: the per-candidate FindDirectProjection memo -- tests/test_gpu_surface.py
+    # compares it with the n = 1 launches call by call -- and a host clock per phase of LocalBAG2O)
     found = set()
     for sub in ("csrc", "host"):
         d = os.path.join(ROOT, "ygz_slam_amd", sub)

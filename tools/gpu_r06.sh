@@ -17,6 +17,14 @@ a)  # the unchanged caller: per-candidate FindDirectProjection behind one specul
     timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "per_candidate or given_angle or 10x2000 or track_local_map" > $OUT/pytest_new.log 2>&1; tail -15 $OUT/pytest_new.log
     timeout 400 python bench.py --mode surface > $OUT/surface.json 2> $OUT/surface.err; tail -3 $OUT/surface.err; surf $OUT/surface.json
     ;;
+p)  # pose-only BA with the lane's features in registers: parity, then the surface loop (OptimizeCurrentPoseOnly per frame) and its kernel table
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface.py tests/test_gpu_offline.py -x -q -k "pose_only or surface or handover or unchanged" > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+    timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; tail -3 $OUT/surface.err; surf $OUT/surface.json
+    ;;
+k)  # kernel time inside the surface loop (rocprofv3 kernel trace of bench.py --mode surface)
+    bash tools/stats_cmd.sh r06_surface --mode surface --no-cpu-baseline
+    cp gpurun_out/r06_surface_kernel_stats.md $OUT/; head -24 $OUT/r06_surface_kernel_stats.md
+    ;;
 h)  # the whole GPU suite + the default bench line
     timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
     timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python - $OUT/bench_default.json <<'PY'

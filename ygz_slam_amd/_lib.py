@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_klt_prepare", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
-    "ygz_hip_ba_optimize_resident", "ygz_hip_ba_set_team_budget", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
+    "ygz_hip_ba_optimize_resident", "ygz_hip_ba_set_team_budget", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ba_light_barrier", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
     "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map", "ygz_hip_find_direct_projection_mp",
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_match_sets", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
@@ -965,6 +965,10 @@ class HipContext:
         """(resident?, reasons) of the last ba_optimize / ba_solve_ceres: the resident kernel, or the ~10x slower host loop and why"""
         v = int(self.lib.ygz_hip_ba_last_path(self._ctx))
         return bool(v & 1), [n for b, n in ((16, "more than 20 free poses"), (32, "repeated (point, pose) edges"), (64, "YGZ_BA_HOST_LOOP=1")) if v & b]
+
+    def ba_light_barrier(self):
+        """1: the same-XCD barrier of the resident LM passed its self-test on this device and is in use; 0: failed (full barriers); -1: not run yet"""
+        return int(self.lib.ygz_hip_ba_light_barrier(self._ctx))
 
     def ba_set_team_placement(self, spread):
         self._chk(self.lib.ygz_hip_ba_set_team_placement(self._ctx, int(spread)), "ba_set_team_placement")

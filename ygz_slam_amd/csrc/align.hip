@@ -548,7 +548,7 @@ static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const
     if (K) { memcpy(H_(d_kfT), m->kf_T, Ks * 56); memcpy(H_(d_kfs), m->kf_slot, Ks * 4); }
     if (Cn) { memcpy(H_(d_cpx), m->cand_px_ref, Cs * 16); memcpy(H_(d_cp), m->cand_point, Cs * 4); memcpy(H_(d_ck), m->cand_kf, Cs * 4); memcpy(H_(d_cl), m->cand_level, Cs * 4); }
     if (co && co->px_given) memcpy(H_(d_proj), co->px_given, Ps * 16);
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(buf, hb, total, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ygz_kcopy(ctx, buf, hb, total, hipMemcpyHostToDevice)) != YGZ_OK) return rc;
     LmapArgs A;
     for (int L = 0; L < YGZ_MAX_LEVELS; ++L) { A.F.lvl[L] = ctx->lvl[L]; A.F.w[L] = ctx->lw[L]; A.F.h[L] = ctx->lh[L]; A.F.sstride[L] = (size_t)ctx->lw[L] * ctx->lh[L]; }
     A.F.n_levels = ctx->prm.pyramid_levels; A.F.cells = ctx->cells; A.F.n_pairs = 0;
@@ -565,7 +565,7 @@ static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const
     if (Cn) YGZ_LAUNCH(ctx, KID_LMAP_MATCH, k_lmap_match, dim3(ygz_div_up(Cn, 64)), dim3(64), A);
     if (!co) YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_gather, dim3(ygz_div_up(P, 256)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(hb, buf, total, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = ygz_kcopy(ctx, hb, buf, total, hipMemcpyDeviceToHost)) != YGZ_OK) return rc;
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(in_view, H_(d_vis), Ps); memcpy(px_proj, H_(d_proj), Ps * 16);
     if (co) {

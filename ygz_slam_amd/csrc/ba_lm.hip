@@ -8,6 +8,7 @@
 // through the resident BA window (ba.hip); only the 6K x 6K reduced system (K <= a few dozen keyframes) and the
 // per-point 3x3 back-substitution are solved on the host, in FP64.
 #include "ygz_internal.h"
+#include <chrono>
 #include "se3_dev.h"
 #include <vector>
 #include <cmath>
@@ -135,6 +136,18 @@ static bool block_solve(BlockSystem &B, const double *Hpp, const double *Hll, co
     return true;
 }
 
+namespace {
+struct AbiTrace {                                       // YGZ_HOST_TRACE=1: host clock per step of ygz_hip_ba_optimize_chi2
+    bool on = getenv("YGZ_HOST_TRACE") && atoi(getenv("YGZ_HOST_TRACE")) != 0;
+    double ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (on) { const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; } }
+    ~AbiTrace() { if (on && calls) fprintf(stderr, "ygz_hip_ba_optimize_chi2 x %ld: upload %.3f  optimize_resident %.3f  get_state %.3f  linearize %.3f  download %.3f ms per call\n",
+                                            calls, ms[0] / calls, ms[1] / calls, ms[2] / calls, ms[3] / calls, ms[4] / calls); }
+};
+AbiTrace g_abi_trace;
+}
 extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
                                    int max_iterations, ygz_ba_stats *stats)
 {
@@ -144,7 +157,9 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
     const int K = pb->n_poses, P = pb->n_points, E = pb->n_edges, W = 1022;
     ygz_ba_problem prob = *pb;
     prob.poses = poses_io; prob.points = points_io;
+    g_abi_trace.start();
     int rc = ygz_hip_ba_upload(ctx, W, &prob);
+    g_abi_trace.lap(0);
     if (rc != YGZ_OK) return rc;
     {   // the loop runs entirely on the GPU when the reduced system fits LDS (ba_resident_lm.hip); YGZ_BA_HOST_LOOP=1 forces
         // the host-side Schur / Cholesky below (kept as the large-window path and as a cross-check)
@@ -158,7 +173,9 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
         if (Kfree <= 20 && !forced && !dup) {      // (20 free poses: LM_MAXKF of ba_resident_lm.hip)  repeated (point, pose) pairs: host-side Schur sums them per edge
             ygz_ba_stats st;
             if ((rc = ygz_hip_ba_optimize_resident(ctx, W, 1, max_iterations, &st)) != YGZ_OK) return rc;
+            g_abi_trace.lap(1);
             if ((rc = ygz_hip_ba_get_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;
+            g_abi_trace.lap(2);
             if (stats) *stats = st;
             return YGZ_OK;
         }
@@ -237,9 +254,13 @@ extern "C" int ygz_hip_ba_optimize_chi2(ygz_hip_ctx *ctx, const ygz_ba_problem *
     int rc = ygz_hip_ba_optimize(ctx, pb, poses_io, points_io, max_iterations, stats);
     if (rc != YGZ_OK || !chi2_edge) return rc;
     const int W = 1022;                                       // the window ygz_hip_ba_optimize uploaded
+    g_abi_trace.start();
     if (ygz_hip_ba_last_path(ctx) != YGZ_BA_PATH_RESIDENT && (rc = ygz_hip_ba_set_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;   // (the host loop leaves its last TRIAL state there)
     if ((rc = ygz_hip_ba_linearize_resident(ctx, W, 1)) != YGZ_OK) return rc;
-    return ygz_hip_ba_download(ctx, W, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, chi2_edge, nullptr);
+    g_abi_trace.lap(3);
+    rc = ygz_hip_ba_download(ctx, W, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, chi2_edge, nullptr);
+    g_abi_trace.lap(4); ++g_abi_trace.calls;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -436,6 +457,7 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
 
 // which loop the last ygz_hip_ba_optimize / ygz_hip_ba_solve_ceres of this context ran: YGZ_BA_PATH_RESIDENT (the whole loop on the GPU) or
 // YGZ_BA_PATH_HOST_LOOP | reason bits (linearisations on the GPU, reduced system on the host: about ten times slower); 0: none yet
+extern "C" int ygz_hip_ba_light_barrier(const ygz_hip_ctx *ctx) { return ctx ? ctx->lm_light_barrier : -1; }
 extern "C" int ygz_hip_ba_last_path(const ygz_hip_ctx *ctx)
 {
     return ctx ? ctx->ba_last_path : 0;

@@ -949,6 +949,64 @@ __global__ __launch_bounds__(256) void k_ba_outliers(OutlierArgs A)
     if (tid < 4) { double t = 0.0; for (int i = 0; i < 256; ++i) t += red[tid][i]; B.lm_out[4 + tid] = t; }
 }
 
+
+// ---- self-test of the light (same-XCD) barrier, once per context before the first team launch.  The light form leaves out the
+// agent-scope release and relies on three things the HSA memory model does not promise: HW_REG_XCC_ID names the XCD a workgroup runs on, the
+// workgroups of one XCD share its L2, and a store is visible there once vmcnt has counted it.  All three hold on the MI355X boxes this was
+// measured on (SPX mode); firmware, another partition mode or another part may differ, and a wrong assumption would be a SILENT stale read in
+// the LM.  So: a message-passing litmus through lm_team_barrier itself -- pairs of workgroups (b, b + 8: the dispatcher's same-XCD pairs; pairs
+// that land on different XCDs take the full barrier and count as such), 256 rounds each way: the writer stores a line of round-dependent words
+// with plain stores, both take the barrier, the reader checks every word.  Any stale word (or no same-XCD pair at all) switches the light form
+// off for the context; YGZ_LM_XCD_BARRIER=0 / 1 overrides the test either way.
+__global__ __launch_bounds__(256) void k_lm_barrier_selftest(unsigned *__restrict__ bars, unsigned *__restrict__ data, unsigned *__restrict__ result)
+{
+    __shared__ int s_ok, s_same;
+    const int pair = blockIdx.x & 7, member = blockIdx.x >> 3, tid = threadIdx.x;       // blocks b and b + 8 form pair b
+    unsigned *bar = bars + 64 * pair, *buf = data + 1024 * pair;
+    unsigned epoch = 0;
+    if (tid == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x &= 255u;
+        __hip_atomic_fetch_max(bar + 2, x + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(bar + 3, 256u - x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!lm_team_barrier(bar, epoch, 2, &s_ok, false)) { if (tid == 0) atomicAdd(result + 2, 1u); return; }
+    if (tid == 0) s_same = __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __hip_atomic_load(bar + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 257u;
+    __syncthreads();
+    const bool same = s_same != 0;
+    unsigned stale = 0;
+    for (unsigned r = 1; r <= 512; ++r) {
+        const int writer = (int)(r & 1u);
+        if (member == writer) for (int i = tid; i < 1024; i += 256) buf[i] = r * 0x9E3779B1u + (unsigned)i;      // plain stores, as the LM's tl_st
+        if (!lm_team_barrier(bar, epoch, 2, &s_ok, same)) { if (tid == 0) atomicAdd(result + 2, 1u); return; }
+        if (member != writer) for (int i = tid; i < 1024; i += 256) stale += buf[i] != r * 0x9E3779B1u + (unsigned)i;
+        if (!lm_team_barrier(bar, epoch, 2, &s_ok, same)) { if (tid == 0) atomicAdd(result + 2, 1u); return; }  // the reader is done before the next round overwrites
+    }
+    if (stale) atomicAdd(result + 1, stale);
+    if (same && member == 0 && tid == 0) atomicAdd(result, 1u);                                                     // pairs that exercised the light form
+}
+
+static int lm_light_barrier_allowed(ygz_hip_ctx *ctx)
+{
+    static const int forced = [] { const char *e = getenv("YGZ_LM_XCD_BARRIER"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    if (forced >= 0) return ctx->lm_light_barrier = forced;
+    if (ctx->lm_light_barrier >= 0) return ctx->lm_light_barrier;
+    void *d = nullptr;
+    const size_t bytes = (8 * 64 + 8 * 1024 + 4) * sizeof(unsigned);
+    if (ygz_scratch(ctx, SCR_GEN_0 + 5, bytes, &d) != YGZ_OK) return ctx->lm_light_barrier = 0;
+    unsigned *bars = (unsigned *)d, *data = bars + 8 * 64, *result = data + 8 * 1024;
+    unsigned res[4] = { 0, 1, 1, 0 };
+    if (hipMemsetAsync(d, 0, bytes, ctx->stream) == hipSuccess) {
+        k_lm_barrier_selftest<<<dim3(16), dim3(256), 0, ctx->stream>>>(bars, data, result);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(res, result, sizeof(res), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { res[0] = 0; res[1] = 1; }
+    }
+    // passed: at least one pair ran the light form and nobody saw a stale word or a time-out
+    return ctx->lm_light_barrier = (res[0] > 0 && res[1] == 0 && res[2] == 0) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void k_ba_lm_reset(const BaDev *__restrict__ wins, unsigned char *__restrict__ scratch, size_t stride,
                                                        ygz_ba_stats *__restrict__ stats)
 {
@@ -1023,7 +1081,7 @@ int ygz_hip_ba_optimize_resident(ygz_hip_ctx *ctx, int window_begin, int n_windo
     A.wins = table + window_begin; A.n_windows = n_windows; A.G = G; A.max_iterations = max_iterations; A.stats = (ygz_ba_stats *)d_scr;
     A.scratch = (unsigned char *)d_scr + stats_bytes; A.stride = stride; A.Kmax = Kmax; A.Qcap = Qcap;
     A.dbg = nullptr; A.prio = (ctx->wave_prio_mask >> 3) & 1; A.spread = ctx->lm_spread ? 1 : 0;
-    { static const bool xb = [] { const char *e = getenv("YGZ_LM_XCD_BARRIER"); return !(e && e[0] == '0'); }(); A.xcd_barrier = xb ? 1 : 0; }
+    A.xcd_barrier = lm_light_barrier_allowed(ctx);               // self-tested once per context (k_lm_barrier_selftest); YGZ_LM_XCD_BARRIER=0 / 1 overrides
     static const bool lm_debug = getenv("YGZ_LM_DEBUG") != nullptr;
     if (lm_debug) { void *d = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 4, 16 * 8, &d) == YGZ_OK) A.dbg = (long long *)d; }
     YgzAuxScope aux(ctx, 1);

@@ -129,9 +129,20 @@ static int pack_launch(ygz_hip_ctx *ctx, const YgzPackSegs &S)
     YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
+// Small transfers of the single-frame calls WITHOUT the copy engine (round 6).  The device timeline of a frame of the surface loop
+// (profiles/r06_surface_timeline.txt) showed every hipMemcpyAsync of a few tens of KB as an SDMA operation of 7-12 us followed by ~9 us before the
+// kernel that waits for it starts -- five to six times per frame.  The page-locked staging memory is mapped into the device's address space
+// (hipHostMalloc), so the scatter / gather kernel reads (writes) it directly over PCIe: one kernel instead of copy + hand-over + kernel.
+// YGZ_ZERO_COPY=0: the copy-engine form.
+static bool zero_copy() { static const bool z = [] { const char *e = getenv("YGZ_ZERO_COPY"); return !(e && e[0] == '0'); }(); return z; }
 int ygz_pack_upload(ygz_hip_ctx *ctx, YgzPack *pk)
 {
     if (pk->used == 0) return YGZ_OK;
+    if (zero_copy()) {
+        YgzPackSegs S = pk->segs;
+        for (int k = 0; k < S.n; ++k) S.src[k] = pk->host + (S.src[k] - pk->dev);       // the host slice itself
+        return pack_launch(ctx, S);
+    }
     YGZ_HIPCHK(ctx, hipMemcpyAsync(pk->dev, pk->host, pk->used, hipMemcpyHostToDevice, ctx->stream));
     return pack_launch(ctx, pk->segs);
 }
@@ -139,10 +150,30 @@ int ygz_pack_fetch(ygz_hip_ctx *ctx, YgzPack *pk)
 {
     if (pk->used == 0) return YGZ_OK;
     YgzPackSegs S = pk->segs;
-    for (int k = 0; k < S.n; ++k) { const uint8_t *stg = S.src[k]; S.src[k] = S.dst[k]; S.dst[k] = const_cast<uint8_t *>(stg); }
+    const bool z = zero_copy();
+    for (int k = 0; k < S.n; ++k) { const uint8_t *stg = z ? pk->host + (S.src[k] - pk->dev) : S.src[k]; S.src[k] = S.dst[k]; S.dst[k] = const_cast<uint8_t *>(stg); }
     const int rc = pack_launch(ctx, S);
-    if (rc != YGZ_OK) return rc;
+    if (rc != YGZ_OK || z) return rc;
     YGZ_HIPCHK(ctx, hipMemcpyAsync(pk->host, pk->dev, pk->used, hipMemcpyDeviceToHost, ctx->stream));
+    return YGZ_OK;
+}
+// one block of bytes between device memory and PAGE-LOCKED host memory (a scratch mirror, the staging arena) on the context's stream: a copy
+// kernel for what the single-frame calls move (up to 1 MB), the copy engine beyond
+__global__ __launch_bounds__(256) void k_kcopy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t bytes)
+{
+    const bool v16 = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+    const size_t n16 = v16 ? bytes / 16 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    for (size_t i = n16 * 16 + (size_t)blockIdx.x * 256 + threadIdx.x; i < bytes; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+int ygz_kcopy(ygz_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int kind)
+{
+    if (bytes == 0) return YGZ_OK;
+    if (!zero_copy() || bytes > ((size_t)1 << 20)) { YGZ_HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, (hipMemcpyKind)kind, ctx->stream)); return YGZ_OK; }
+    const unsigned gx = (unsigned)((bytes / 16 + 255) / 256 > 64 ? 64 : (bytes / 16 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_kcopy, dim3(gx), dim3(256), 0, ctx->stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
+    YGZ_HIPCHK(ctx, hipGetLastError());
     return YGZ_OK;
 }
 

@@ -45,10 +45,55 @@ __device__ void po_rot_prep(const double *pose, double R[9], double Jl[9])
     }
 }
 
+// The features of a frame a lane visits are the same in every pass (i = tid, tid + 256, ...), and a single frame's solve makes ~45 passes whose
+// chain is load latency, not arithmetic: the first PO_CACHE of them live in registers for the whole kernel (pixel, map point, enabled bit) --
+// 4 x 256 = 1024 features (a fifth would cost the second wavefront per SIMD: 255 + 4 registers) -- and only the ones beyond are fetched per pass.
+#define PO_CACHE 4
+struct PoLane {
+    double px[PO_CACHE][2], pw[PO_CACHE][3];
+    uint32_t off;                               // bit k: cached feature k is switched off (SetEnable(false)) or absent
+};
+
+// one feature's share of a pass (residual; with `full` its Jacobian blocks); returns false when it lies behind the camera
+__device__ __forceinline__ bool po_feature(const PoArgs &A, const double R[9], const double Jl[9], double t0, double t1, double t2, double ifx, double ify,
+                                           double pxu, double pxv, double X, double Y, double Z, bool full, double acc[PO_NV])
+{
+    const double a = R[0] * X + R[1] * Y + R[2] * Z, b = R[3] * X + R[4] * Y + R[5] * Z, c = R[6] * X + R[7] * Y + R[8] * Z;
+    const double x = a + t0, y = b + t1, z = c + t2;
+    if (z < 0) return false;
+    // one division per feature and evaluation (1 / z); the quotients by fx, fy and z are products with the reciprocals -- one more rounding than the
+    // reference's divisions (1e-16 relative, the bar of the path is 1e-5), a fifth of the FP64 instructions of the loop
+    const double obx = (pxu - A.cx) * ifx, oby = (pxv - A.cy) * ify;      // Pixel2Camera2D, Camera.h:64-69
+    const double zi = 1. / z;
+    const double r0 = obx - x * zi, r1 = oby - y * zi;
+    acc[27] += 0.5 * (r0 * r0 + r1 * r1);
+    if (!full) return true;
+    const double xz = x * zi * zi, yz = y * zi * zi;
+    double M[9], Jx[12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        M[j] = -c * Jl[3 + j] + b * Jl[6 + j];
+        M[3 + j] = c * Jl[j] - a * Jl[6 + j];
+        M[6 + j] = -b * Jl[j] + a * Jl[3 + j];
+    }
+    Jx[0] = -zi; Jx[1] = 0.0; Jx[2] = xz; Jx[6] = 0.0; Jx[7] = -zi; Jx[8] = yz;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { Jx[3 + j] = zi * M[j] - xz * M[6 + j]; Jx[9 + j] = zi * M[3 + j] - yz * M[6 + j]; }
+    int q = 0;
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+#pragma unroll
+        for (int v = u; v < 6; ++v) acc[q++] += Jx[u] * Jx[v] + Jx[6 + u] * Jx[6 + v];
+    }
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc[21 + u] += -(Jx[u] * r0 + Jx[6 + u] * r1);
+    return true;
+}
+
 // One pass over the frame's enabled features at `pose`: sum[0..20] = upper triangle of J^T J, sum[21..26] = -J^T r,
 // sum[27] = cost = 1/2 sum |r|^2 (full == false: cost only).  Returns (block-uniform) whether any enabled point was behind
 // the camera.  Fixed summation order: lane-strided partials, xor-shuffle tree, the four wave partials in wave order.
-__device__ bool po_eval(const PoArgs &A, int beg, int n, const double *pose /*LDS*/, bool full, double (*red)[PO_NV], double *sum)
+__device__ __forceinline__ bool po_eval(const PoArgs &A, const PoLane &C, int beg, int n, const double *pose /*LDS*/, bool full, double (*red)[PO_NV], double *sum)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double R[9], Jl[9];
@@ -59,39 +104,15 @@ __device__ bool po_eval(const PoArgs &A, int beg, int n, const double *pose /*LD
 #pragma unroll
     for (int i = 0; i < PO_NV; ++i) acc[i] = 0.0;
     int behind = 0;
-    for (int i = tid; i < n; i += PO_THREADS) {
+#pragma unroll
+    for (int k = 0; k < PO_CACHE; ++k) {
+        if ((C.off >> k) & 1u) continue;
+        if (!po_feature(A, R, Jl, t0, t1, t2, ifx, ify, C.px[k][0], C.px[k][1], C.pw[k][0], C.pw[k][1], C.pw[k][2], full, acc)) behind = 1;
+    }
+    for (int i = tid + PO_CACHE * PO_THREADS; i < n; i += PO_THREADS) {
         const size_t g = (size_t)(beg + i);
         if (A.d.bad[g]) continue;                                   // SetEnable(false)
-        const double X = A.d.pw[3 * g], Y = A.d.pw[3 * g + 1], Z = A.d.pw[3 * g + 2];
-        const double a = R[0] * X + R[1] * Y + R[2] * Z, b = R[3] * X + R[4] * Y + R[5] * Z, c = R[6] * X + R[7] * Y + R[8] * Z;
-        const double x = a + t0, y = b + t1, z = c + t2;
-        if (z < 0) { behind = 1; continue; }
-        // one division per feature and evaluation (1 / z); the quotients by fx, fy and z are products with the reciprocals -- one more rounding than the
-        // reference's divisions (1e-16 relative, the bar of the path is 1e-5), a fifth of the FP64 instructions of the loop
-        const double obx = (A.d.px[2 * g] - A.cx) * ifx, oby = (A.d.px[2 * g + 1] - A.cy) * ify;      // Pixel2Camera2D, Camera.h:64-69
-        const double zi = 1. / z;
-        const double r0 = obx - x * zi, r1 = oby - y * zi;
-        acc[27] += 0.5 * (r0 * r0 + r1 * r1);
-        if (!full) continue;
-        const double xz = x * zi * zi, yz = y * zi * zi;
-        double M[9], Jx[12];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            M[j] = -c * Jl[3 + j] + b * Jl[6 + j];
-            M[3 + j] = c * Jl[j] - a * Jl[6 + j];
-            M[6 + j] = -b * Jl[j] + a * Jl[3 + j];
-        }
-        Jx[0] = -zi; Jx[1] = 0.0; Jx[2] = xz; Jx[6] = 0.0; Jx[7] = -zi; Jx[8] = yz;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { Jx[3 + j] = zi * M[j] - xz * M[6 + j]; Jx[9 + j] = zi * M[3 + j] - yz * M[6 + j]; }
-        int q = 0;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-#pragma unroll
-            for (int v = u; v < 6; ++v) acc[q++] += Jx[u] * Jx[v] + Jx[6 + u] * Jx[6 + v];
-        }
-#pragma unroll
-        for (int u = 0; u < 6; ++u) acc[21 + u] += -(Jx[u] * r0 + Jx[6 + u] * r1);
+        if (!po_feature(A, R, Jl, t0, t1, t2, ifx, ify, A.d.px[2 * g], A.d.px[2 * g + 1], A.d.pw[3 * g], A.d.pw[3 * g + 1], A.d.pw[3 * g + 2], full, acc)) behind = 1;
     }
     const int first = full ? 0 : 27;
     if (full) {                                                 // all 28 sums stage by stage (ygz_wave_sums_d: same additions, 28 independent chains per stage)
@@ -176,6 +197,19 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
     const ygz_ceres_options &o = A.opt;
     if (tid < 6) { const double v = A.d.poses[6 * (size_t)f + tid]; S.backup[tid] = v; S.tcw[tid] = v; }
     for (int i = tid; i < n; i += PO_THREADS) A.d.bad[beg + i] = (uint8_t)(A.d.use ? !A.d.use[beg + i] : 0);   // features that do not exist in this frame
+    PoLane C;
+    C.off = 0u;
+    uint32_t c_absent = 0u;                                      // cached slots past the end of the frame or not features of it (`use`): never enabled
+#pragma unroll
+    for (int k = 0; k < PO_CACHE; ++k) {
+        const int i = tid + k * PO_THREADS;
+        const bool have = i < n && !(A.d.use && !A.d.use[beg + (i < n ? i : 0)]);
+        const size_t g = (size_t)(beg + (i < n ? i : 0));
+        C.px[k][0] = A.d.px[2 * g]; C.px[k][1] = A.d.px[2 * g + 1];
+        C.pw[k][0] = A.d.pw[3 * g]; C.pw[k][1] = A.d.pw[3 * g + 1]; C.pw[k][2] = A.d.pw[3 * g + 2];
+        if (!have) c_absent |= 1u << k;
+    }
+    C.off = c_absent;
     __syncthreads();
 
     int it = 0, cntInlier = 0;
@@ -183,7 +217,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
         // ---------------- ceres::Solve from the entry pose
         if (tid < 6) S.pose[tid] = S.backup[tid];
         __syncthreads();
-        bool behind = po_eval(A, beg, n, S.pose, true, red, lin);
+        bool behind = po_eval(A, C, beg, n, S.pose, true, red, lin);
         if (tid == 0) {                                          // IterationZero
             S.term = PO_RUNNING; S.iterations = 0; S.invalid_run = 0;
             S.radius = o.initial_trust_region_radius; S.decrease_factor = 2.0;
@@ -212,7 +246,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
             __syncthreads();
             if (S.term != PO_RUNNING) break;                     // block-uniform: read between two barriers
             if (!S.need_eval) continue;
-            behind = po_eval(A, beg, n, S.cand, false, red, tmp);
+            behind = po_eval(A, C, beg, n, S.cand, false, red, tmp);
             if (tid == 0) {
                 const double cand_cost = behind ? 1.7976931348623157e308 : tmp[27];   // failed evaluation = a step of very high cost
                 S.accept = 0;
@@ -239,7 +273,7 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
             __syncthreads();
             if (S.term != PO_RUNNING) break;
             if (S.accept) {                                      // EvaluateGradientAndJacobian at the new iterate
-                po_eval(A, beg, n, S.pose, true, red, lin);
+                po_eval(A, C, beg, n, S.pose, true, red, lin);
                 if (tid == 0) { S.x_cost = lin[27]; po_norm_gradient(S, lin); }
             }
         }
@@ -250,18 +284,31 @@ __global__ __launch_bounds__(PO_THREADS) void k_pose_only_ba(PoArgs A)
             double q[4], th;
             so3_exp_d(S.tcw + 3, q, &th);                        // SE3(SO3::exp(aa), t), BA.cpp:254
             int mine = 0;
-            for (int i = tid; i < n; i += PO_THREADS) {
-                const size_t g = (size_t)(beg + i);
-                if (A.d.use && !A.d.use[g]) continue;
-                const double pw[3] = { A.d.pw[3 * g], A.d.pw[3 * g + 1], A.d.pw[3 * g + 2] };
+            auto classify = [&](size_t g, double X, double Y, double Z, double pxu, double pxv) {
+                const double pw[3] = { X, Y, Z };
                 double pc[3];
                 quat_rotate_d(q, pw, pc);
                 pc[0] += S.tcw[0]; pc[1] += S.tcw[1]; pc[2] += S.tcw[2];
-                const double zi = 1.0 / pc[2];
-                const double u = A.fx * pc[0] * zi + A.cx, v = A.fy * pc[1] * zi + A.cy;     // Camera2Pixel, Camera.h:48-53
-                const double dx = u - A.d.px[2 * g], dy = v - A.d.px[2 * g + 1], error2 = dx * dx + dy * dy;
-                if (error2 > (double)5.991f) A.d.bad[g] = 1;       // const float chi2Mono = 5.991, BA.cpp:195
-                else { A.d.depth[g] = pc[2]; A.d.bad[g] = 0; ++mine; }
+                // Camera2Pixel as written (Camera.h:48-53: fx * x / z + cx), with the IEEE quotients: this value decides inlier / outlier against a
+                // threshold, and a product with 1 / z could flip a feature that sits within an ulp of it.  (The solver passes above
+                // keep the reciprocal: their sums are compared at 1e-7, not thresholded.)
+                const double u = A.fx * pc[0] / pc[2] + A.cx, v = A.fy * pc[1] / pc[2] + A.cy;
+                const double dx = u - pxu, dy = v - pxv, error2 = dx * dx + dy * dy;
+                if (error2 > (double)5.991f) { A.d.bad[g] = 1; return false; }                // const float chi2Mono = 5.991, BA.cpp:195
+                A.d.depth[g] = pc[2]; A.d.bad[g] = 0;
+                return true;
+            };
+            uint32_t off = c_absent;
+#pragma unroll
+            for (int k = 0; k < PO_CACHE; ++k) {
+                if ((c_absent >> k) & 1u) continue;
+                if (classify((size_t)(beg + tid + k * PO_THREADS), C.pw[k][0], C.pw[k][1], C.pw[k][2], C.px[k][0], C.px[k][1])) ++mine; else off |= 1u << k;
+            }
+            C.off = off;
+            for (int i = tid + PO_CACHE * PO_THREADS; i < n; i += PO_THREADS) {
+                const size_t g = (size_t)(beg + i);
+                if (A.d.use && !A.d.use[g]) continue;
+                if (classify(g, A.d.pw[3 * g], A.d.pw[3 * g + 1], A.d.pw[3 * g + 2], A.d.px[2 * g], A.d.px[2 * g + 1])) ++mine;
             }
             if (mine) atomicAdd(&S.cnt, mine);
         }
@@ -335,11 +382,11 @@ extern "C" int ygz_hip_optimize_pose_only(ygz_hip_ctx *ctx, int n_frames, const 
     memcpy(H_(A.d.off), frame_off, b_off);
     if (n > 0) { memcpy(H_(d_px), px, n * 16); memcpy(H_(d_pw), pw, n * 24); memcpy(H_(A.d.depth), depth, n * 8); }     // outliers keep their depth
     memcpy(H_(A.d.poses), poses_io, b_pose);
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(blob, hb, total, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ygz_kcopy(ctx, blob, hb, total, hipMemcpyHostToDevice)) != YGZ_OK) return rc;
     YGZ_LAUNCH(ctx, KID_POSE_ONLY, k_pose_only_ba, dim3(n_frames), dim3(PO_THREADS), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     const size_t out0 = (size_t)((const uint8_t *)A.d.poses - b0);                 // poses | depth | counts | bad are the tail of the blob
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(hb + out0, (uint8_t *)blob + out0, total - out0, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = ygz_kcopy(ctx, hb + out0, (uint8_t *)blob + out0, total - out0, hipMemcpyDeviceToHost)) != YGZ_OK) return rc;
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(poses_io, H_(A.d.poses), b_pose);
     if (n > 0) { memcpy(bad, H_(A.d.bad), n); memcpy(depth, H_(A.d.depth), n * 8); }

@@ -131,6 +131,7 @@ struct ygz_hip_ctx {
     bool klt_prep_pending = false;           // ... and nobody has waited for it yet
     int  ba_last_path = 0;                   // ygz_hip_ba_last_path
     bool lm_spread = false;                  // resident-LM teams spread over the XCDs instead of one XCD each (ygz_hip_ba_set_team_placement)
+    int  lm_light_barrier = -1;              // the same-XCD barrier without the L2 write-back: -1 not tested yet, 0 failed its self-test on this device (full barrier), 1 passed
     int  lm_team_budget = 0;                 // workgroups a resident-LM launch may hold (0: half of the CUs), ygz_hip_ba_set_team_budget
     bool match_aux_reads_track = false;      // a direct projection (reads the track sets) is pending on the matcher's side stream
     bool describe_aside = false;             // ygz_hip_detect leaves the descriptor kernel on the matcher's side stream (YGZ_DESCRIBE_ASIDE=1)
@@ -202,6 +203,7 @@ int   ygz_pack_begin(ygz_hip_ctx *ctx, YgzPack *pk, size_t capacity_bytes, int s
 void *ygz_pack_add(YgzPack *pk, const void *device_ptr, size_t bytes);        // the host slice of that device array (nullptr: full)
 int   ygz_pack_upload(ygz_hip_ctx *ctx, YgzPack *pk);                          // host slices -> their device arrays (asynchronous)
 int   ygz_pack_fetch(ygz_hip_ctx *ctx, YgzPack *pk);                           // device arrays -> host slices (asynchronous: synchronise before reading)
+int   ygz_kcopy(ygz_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int kind);   // device <-> page-locked host block on the stream: a copy kernel up to 1 MB (no copy engine), hipMemcpyAsync beyond; kind = hipMemcpyKind
 // the brute-force matcher over descriptor sets desc + s * set_stride (u32 units), sizes set_count[s], pairs (pair_q[p], pair_t[p]): device
 // arrays; results in ctx->m_idx / m_dist [n_pairs][cells] (hamming.hip)
 int ygz_run_match(ygz_hip_ctx *ctx, const uint32_t *desc, size_t set_stride, const int32_t *set_count, const int32_t *pair_q,

@@ -991,9 +991,21 @@ bool DepthFromTriangulation(const SE3 &T_search_ref, const Vector3d &f_ref, cons
 namespace ba {
 void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points) { LocalBAG2O(local_keyframes, local_map_points, nullptr); }
 
+namespace {
+struct PhaseTrace {                                     // YGZ_HOST_TRACE=1: host clock per phase of LocalBAG2O, printed when the process ends
+    bool on = env_on("YGZ_HOST_TRACE", false);
+    double ms[4] = { 0, 0, 0, 0 }; long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (on) { const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; } }
+    ~PhaseTrace() { if (on && calls) fprintf(stderr, "LocalBAG2O x %ld: graph %.3f  ygz_hip_ba_optimize_chi2 %.3f  write-back %.3f ms per call\n", calls, ms[0] / calls, ms[1] / calls, ms[2] / calls); }
+};
+PhaseTrace g_ba_trace;
+}
 void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points, LocalBAStats *stats)
 {   // graph build exactly as src/Algorithm/BA.cpp:397-497, then optimize(20) and the write-back of :504-541
     hip::Runtime &rt = hip::Runtime::Get();
+    g_ba_trace.start();
     std::map<unsigned long, int> pose_index;            // keyframe id -> vertex
     std::vector<Frame *> pose_frame;
     std::vector<double> poses; std::vector<uint8_t> fixed;
@@ -1051,7 +1063,9 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     ygz_ba_stats st;
     // optimize(20), then the inlier test on the optimised state: chi2 > 5.991 -> Feature::_bad (BA.cpp:501-515) -- one call, the graph is uploaded once
     std::vector<double> chi2_edge(pb.n_edges);
+    g_ba_trace.lap(0);
     if (!hip::check(ygz_hip_ba_optimize_chi2(rt.ctx(), &pb, poses.data(), points.data(), 20, &st, chi2_edge.data()), "ba_optimize_chi2")) return;      // the map as it was
+    g_ba_trace.lap(1);
     int cntOutlier = 0;
     for (size_t i = 0; i < features.size(); ++i) if (chi2_edge[i] > 5.991) { cntOutlier++; features[i]->_bad = true; }
     for (Frame *frame : local_keyframes) {             // BA.cpp:520-531
@@ -1062,6 +1076,7 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     }
     for (size_t l = 0; l < pts.size(); ++l) pts[l]->_pos_world = Vector3d(points[3 * l], points[3 * l + 1], points[3 * l + 2]);
     if (stats) { stats->iterations = st.iterations; stats->lm_trials = st.lm_trials; stats->outliers = cntOutlier; stats->chi2_initial = st.chi2_initial; stats->chi2_final = st.chi2_final; }
+    g_ba_trace.lap(2); ++g_ba_trace.calls;
 }
 // ---- the ceres-based entry points (BA.cpp:11-384) ------------------------------------------------------------------
 namespace {

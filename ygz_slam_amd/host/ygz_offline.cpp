@@ -7,7 +7,18 @@
 // is listed at the head of include/ygz_offline.h; this file holds the schedule: shard, chunk plan, lanes, window readiness, LM launches,
 // the two exchanges.  No arithmetic of the path lives here -- every number comes out of a kernel -- so any schedule gives the same bits.
 #include "ygz_offline.h"
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// RCCL development headers are not installed: the few declarations of nccl.h the driver uses (the library itself is bound at run time with
+// dlopen, so the single-GPU class surface builds and runs without RCCL).  Values as in RCCL 2.x's nccl.h.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+}
+#endif
 #include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
