@@ -1,27 +1,30 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): everything profiles/r05_* and bench.py's tables come from, on ONE set of kernel sources.
+# Run ON THE GPU BOX (through gpurun): everything profiles/<round>_* and bench.py's tables come from, on ONE set of kernel sources
+# (ROUND=r06 by default; round 5 ran the same script as collect_r05_profiles.sh).
 #   1. kernel tables of the default bench command in TWO parts, so that every `frac` of the driver line can be reproduced from one file:
-#        step  : rocprofv3 --kernel-trace --stats of `bench.py --profile-part step`  (in-step launches only)   -> r05_step_kernel_stats.md
-#        alone : the same of `bench.py --profile-part alone` (every stage by itself)                          -> r05_alone_kernel_stats.md
+#        step  : rocprofv3 --kernel-trace --stats of `bench.py --profile-part step`  (in-step launches only)   -> <round>_step_kernel_stats.md
+#        alone : the same of `bench.py --profile-part alone` (every stage by itself)                          -> <round>_alone_kernel_stats.md
 #   2. --pmc FETCH_SIZE / WRITE_SIZE (own passes) of the step part -> pmc tables, traffic.json
 #   3. one SQ-counter pass over the stages -> sq counters, valu_counts.json
 #   4. the bench lines: default (with offline / stream / surface blocks), offline at 1024 / 512 / 256 / 128 frames, gray, surface
 #   5. the resident LM alone on the offline run's windows: phase timers + PMC traffic
-# Outputs under gpurun_out/r05p/; tools/collect_r05_profiles.sh --copy (CPU, in the container) moves them into profiles/.
+#   6. the surface loop: kernel table, device timeline of two frames (tools/surface_timeline.sh)
+# Outputs under gpurun_out/<round>p/; tools/collect_round_profiles.sh --copy (CPU, in the container) moves them into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-r06}
 if [ "${1:-}" = "--copy" ]; then
-    S=$R/gpurun_out/r05p; P=$R/profiles
+    S=$R/gpurun_out/${ROUND}p; P=$R/profiles
     for f in step_kernel_stats.md alone_kernel_stats.md pmc_fetch.md pmc_write.md sq_counters_raw.md bench_default.json bench_offline_f1024.json bench_offline_f512.json \
-             bench_offline_f256.json bench_offline_f128.json bench_offline_f1024_gray.json bench_surface.json surface_kernel_stats.md lm_phases.md lm_pmc.md offline128_trace.txt; do
-        [ -s $S/$f ] && cp $S/$f $P/r05_$f
+             bench_offline_f256.json bench_offline_f128.json bench_offline_f1024_gray.json bench_surface.json surface_kernel_stats.md surface_timeline.txt lm_phases.md lm_pmc.md offline128_trace.txt; do
+        [ -s $S/$f ] && cp $S/$f $P/${ROUND}_$f
     done
     [ -s $S/traffic.json ] && cp $S/traffic.json $P/traffic.json
     [ -s $S/valu_counts.json ] && cp $S/valu_counts.json $P/valu_counts.json
-    ls -la $P | grep r05_
+    ls -la $P | grep ${ROUND}_
     exit 0
 fi
-OUT=$R/gpurun_out/r05p
+OUT=$R/gpurun_out/${ROUND}p
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
@@ -56,6 +59,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/raw_s -- python $R/bench.py
 DB=$(find $OUT/raw_s -name '*.db' | head -1)
 [ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $OUT/surface_kernel_stats.md > /dev/null
 rm -rf $OUT/raw_s
+bash $R/tools/surface_timeline.sh ${ROUND}_surface_timeline > /dev/null 2>&1; cp $R/gpurun_out/${ROUND}_surface_timeline.txt $OUT/surface_timeline.txt
+cd /tmp
 YGZ_LM_DEBUG=1 timeout 300 python $R/tools/lm_insitu.py --frames 256 2>&1 | grep -v "^RCCL\|^HIP ver\|^ROCm\|^Hostname\|^Librccl" | tail -10 > $OUT/lm_phases.md
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/lmf -- python $R/tools/lm_insitu.py --frames 256 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/lmw -- python $R/tools/lm_insitu.py --frames 256 > /dev/null 2>&1
