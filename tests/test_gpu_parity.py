@@ -1079,7 +1079,6 @@ def test_ba_optimize_resident_windows(hip_lib, oracle):
         back = oracle.ba_linearize(pg, w["fixed"], tg, w["edge_pose"], w["edge_point"], w["obs"])
         assert abs(back["chi2"] - st.chi2_final) <= 1e-9 * st.chi2_final, i
     # host-loop form (reduced system solved on the CPU) on one of them
-    import os
     w = wins[1]
     os.environ["YGZ_BA_HOST_LOOP"] = "1"
     try:
