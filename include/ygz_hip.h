@@ -230,6 +230,16 @@ int  ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double T_ref[7],
                           const double *px, const double *depth, const uint8_t *has_mappoint, int n,
                           int max_level, int min_level, int n_iter, int *n_meas_out, int *iters_out /*[levels] or NULL*/);
 
+/* One NLLSSolver::computeResiduals(model, linearize_system = true) of SparseImgAlign (src/Algorithm/SparseImageAlign.cpp:124-223, with
+ * precomputeReferencePatches :59-122 for `level`) at a model the caller holds -- the step a solver other than the resident Gauss-Newton loop is
+ * built from; SparseImgAlign(..., LevenbergMarquardt, ...) of the class surface (include/ygz/Algorithm/NLSSolver_impl.hpp:91-212) drives its
+ * trials with it.  T_cur_from_ref = the solver's model (SparseImageAlign.cpp:37).  chi2_sum: the reference's float running sum of res^2 over the
+ * features / pixels in order (exact); n_meas: measurements (16 per feature used); H [36] row-major symmetric and Jres [6] (either may be NULL):
+ * H_ / Jres_ after the call.  Features as ygz_hip_sparse_align.  Host arrays; synchronises. */
+int  ygz_hip_sparse_align_residuals(ygz_hip_ctx *ctx, int ref_slot, int cur_slot, const double T_cur_from_ref[7],
+                                    const double *px, const double *depth, const uint8_t *has_mappoint, int n, int level,
+                                    double *chi2_sum, int *n_meas, double *H, double *Jres);
+
 /* ---- L4: pyramidal LK -- replaces cv::calcOpticalFlowPyrLK as called by Tracker::TrackKLT
  *      (src/Algorithm/Tracker.cpp:92-98) ------------------------------------------------------- */
 typedef struct {

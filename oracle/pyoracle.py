@@ -452,7 +452,8 @@ class Oracle:
         return int(n), in_view, px_proj, match, px_match, lvl
 
     def sparse_align(self, ref_levels, T_ref, cur_levels, T_cur, px, depth, has_mp, max_level=2, min_level=0,
-                     n_iter=30, cam=None):
+                     n_iter=30, cam=None, method="gn"):
+        """SparseImgAlign::run; method "gn": NLLSSolver::optimizeGaussNewton (the live path), "lm": optimizeLevenbergMarquardt"""
         cam = cam or self.camera()
         pr, pc = self._pyr_struct(ref_levels), self._pyr_struct(cur_levels)
         Tr, Tc = SE3.from_array(T_ref), SE3.from_array(T_cur)
@@ -460,8 +461,10 @@ class Oracle:
         depth = np.ascontiguousarray(depth, np.float64)
         has_mp = np.ascontiguousarray(has_mp, np.uint8)
         st = SparseAlignStats()
-        n = self.lib.yo_sparse_align(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc), _f64(px),
-                                     _f64(depth), _u8(has_mp), len(depth), max_level, min_level, n_iter, C.byref(st))
+        fn = self.lib.yo_sparse_align_lm if method == "lm" else self.lib.yo_sparse_align
+        fn.restype = C.c_size_t
+        n = fn(C.byref(cam), C.byref(pr), C.byref(Tr), C.byref(pc), C.byref(Tc), _f64(px),
+               _f64(depth), _u8(has_mp), len(depth), max_level, min_level, n_iter, C.byref(st))
         return int(n), Tc.to_array(), st
 
     def sparse_align_linearize(self, ref_levels, cur_levels, T_cur_ref, px, depth, has_mp, level, visible=None, cam=None):

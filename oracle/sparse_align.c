@@ -1,6 +1,7 @@
 /* ORACLE (test infrastructure) -- SVO-style sparse image alignment.
- * Restates src/Algorithm/SparseImageAlign.cpp:21-238 and the Gauss-Newton driver
- * include/ygz/Algorithm/NLSSolver_impl.hpp:15-89 (+ reset() :283-293), with the
+ * Restates src/Algorithm/SparseImageAlign.cpp:21-238, the Gauss-Newton driver
+ * include/ygz/Algorithm/NLSSolver_impl.hpp:15-89 and the Levenberg-Marquardt driver :91-212
+ * (+ reset() :283-293, the defaults of NLSSolver.h:75-95), with the
  * projection Jacobian cvutils::JacobXYZ2Cam (include/ygz/Algorithm/CVUtils.h:77-99).
  * [frozen spec of Eigen] H_.ldlt().solve(Jres_) = pivoted LDLT with pseudo-inverse of D.
  * Defined behaviour: ref_patch_cache_ is uninitialised memory in the reference
@@ -222,6 +223,93 @@ size_t yo_sparse_align(const yo_camera *cam, const yo_pyramid *ref, const yo_se3
     }
     yo_se3 out;
     yo_se3_mul(&T, T_ref_w, &out);                          /* :48 */
+    *T_cur_w = out;
+    const size_t ret = s.n_meas / PATCH_AREA;
+    free(s.patch_cache); free(s.jac_cache); free(s.visible);
+    return ret;
+}
+
+/* SparseImgAlign::run with method_ = LevenbergMarquardt: NLLSSolver::optimizeLevenbergMarquardt, NLSSolver_impl.hpp:91-212, per level.
+ * Reproduced as written: run() sets mu_ = 0.1 before every level (SparseImageAlign.cpp:41), so the "mu_ < 0" initialisation never runs; nu_,
+ * stop_ and n_meas_ are NOT reset between levels -- the first computeResiduals of a level (:101) adds its measurements to the count the last
+ * evaluation of the level before left, so chi2_ of a finer level starts as its float sum over BOTH counts; every trial linearises at the model
+ * again (H_, Jres_ zeroed, :133-139), damps H_ += diag(H_) mu_ (:142), solves with Eigen's ldlt, tries T exp(-x); rho_ = chi2_ - new_chi2 > 0
+ * accepts (mu_ *= max(1/3, min(1 - (2 rho_ - 1)^3, 2/3)), nu_ = 2, stop_ = |x|_max <= eps_), else mu_ *= nu_, nu_ *= 2 and after
+ * n_trials_max_ = 5 failures stop_.  No weights (use_weights_ false), no prior. */
+size_t yo_sparse_align_lm(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref_w,
+                          const yo_pyramid *cur, yo_se3 *T_cur_w,
+                          const double *px, const double *depth, const uint8_t *has_mappoint,
+                          int n, int max_level, int min_level, int n_iter,
+                          yo_sparse_align_stats *stats)
+{
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n <= 0) return 0;
+    sa_state s; memset(&s, 0, sizeof(s));
+    s.cam = cam; s.ref = ref; s.cur = cur; s.px = px; s.depth = depth; s.has_mp = has_mappoint; s.n = n;
+    s.patch_cache = (float *)calloc((size_t)n * PATCH_AREA, sizeof(float));
+    s.jac_cache = (double *)calloc((size_t)n * PATCH_AREA * 6, sizeof(double));
+    s.visible = (uint8_t *)calloc((size_t)n, 1);
+    /* reset(): chi2_ = 1e10, mu_ = mu_init_ (0.01f), nu_ = nu_init_ (2), n_meas_ = 0, stop_ = false */
+    double chi2_ = 1e10, mu_ = (double)0.01f, nu_ = 2.0, rho_ = 0;
+    int stop_ = 0;
+    const double eps_ = 0.000001;
+    const int n_trials_max_ = 5;
+    yo_se3 Tri, T;
+    yo_se3_inv(T_ref_w, &Tri);
+    yo_se3_mul(T_cur_w, &Tri, &T);
+    for (int level = max_level; level >= min_level; --level) {
+        s.level = level;
+        mu_ = 0.1;                                             /* SparseImageAlign.cpp:41 */
+        memset(s.jac_cache, 0, sizeof(double) * 6 * PATCH_AREA * (size_t)n);
+        s.have_cache = 0;
+        chi2_ = compute_residuals(&s, &T, 1);                  /* :101 -- n_meas_ (and H_, Jres_) carried over, see above */
+        if (mu_ < 0) {                                         /* :113-120 (never true here) */
+            double mx = 0;
+            for (int j = 0; j < 6; ++j) if (fabs(s.H[7 * j]) > mx) mx = fabs(s.H[7 * j]);
+            mu_ = 1e-4 * mx;
+        }
+        int it = 0;
+        for (; it < n_iter; ++it) {
+            rho_ = 0;
+            int n_trials_ = 0;
+            do {
+                yo_se3 new_model = T;
+                double new_chi2 = -1;
+                memset(s.H, 0, sizeof(s.H)); memset(s.Jres, 0, sizeof(s.Jres));
+                s.n_meas = 0;
+                compute_residuals(&s, &T, 1);
+                for (int j = 0; j < 6; ++j) s.H[7 * j] += s.H[7 * j] * mu_;
+                if (yo_ldlt6_solve(s.H, s.Jres, s.x)) {
+                    double mx[6]; for (int k = 0; k < 6; ++k) mx[k] = -s.x[k];
+                    yo_se3 E;
+                    yo_se3_exp(mx, &E);
+                    yo_se3_mul(&T, &E, &new_model);
+                    s.n_meas = 0;
+                    new_chi2 = compute_residuals(&s, &new_model, 0);
+                    rho_ = chi2_ - new_chi2;
+                } else rho_ = -1;
+                if (stats) { stats->n_iter_total++; stats->chi2_last = new_chi2; stats->n_meas_last = (int)s.n_meas; }
+                if (rho_ > 0) {
+                    T = new_model;
+                    chi2_ = new_chi2;
+                    stop_ = norm_max6(s.x) <= eps_;
+                    const double c = 1. - pow(2 * rho_ - 1, 3);
+                    const double f = c < 2. / 3. ? c : 2. / 3.;
+                    mu_ *= (1. / 3. > f ? 1. / 3. : f);
+                    nu_ = 2.;
+                } else {
+                    mu_ *= nu_;
+                    nu_ *= 2.;
+                    ++n_trials_;
+                    if (n_trials_ >= n_trials_max_) stop_ = 1;
+                }
+            } while (!(rho_ > 0 || stop_));
+            if (stop_) break;
+        }
+        if (stats && level < YO_MAX_LEVELS) stats->iters_per_level[level] = it;
+    }
+    yo_se3 out;
+    yo_se3_mul(&T, T_ref_w, &out);
     *T_cur_w = out;
     const size_t ret = s.n_meas / PATCH_AREA;
     free(s.patch_cache); free(s.jac_cache); free(s.visible);

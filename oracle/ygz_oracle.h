@@ -203,6 +203,13 @@ size_t yo_sparse_align(const yo_camera *cam, const yo_pyramid *ref, const yo_se3
                        const double *px /*[n][2]*/, const double *depth, const uint8_t *has_mappoint,
                        int n, int max_level, int min_level, int n_iter,
                        yo_sparse_align_stats *stats);
+/* the same with method_ = LevenbergMarquardt (NLLSSolver::optimizeLevenbergMarquardt, NLSSolver_impl.hpp:91-212); stats->n_iter_total counts
+ * trials, iters_per_level the value of iter_ at which each level's loop ended */
+size_t yo_sparse_align_lm(const yo_camera *cam, const yo_pyramid *ref, const yo_se3 *T_ref_w,
+                          const yo_pyramid *cur, yo_se3 *T_cur_w,
+                          const double *px /*[n][2]*/, const double *depth, const uint8_t *has_mappoint,
+                          int n, int max_level, int min_level, int n_iter,
+                          yo_sparse_align_stats *stats);
 /* one linearisation (computeResiduals with linearize_system=true) for kernel parity:
  * H 36 (row-major, symmetric), Jres 6, returns chi2/n_meas; visible in/out as the
  * reference keeps it across levels. */

@@ -256,6 +256,18 @@ int main(int argc, char **argv)
     double T7[7]; f[1]._TCW.to7(T7);
     fprintf(out, "sparse %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", (int)sa, T7[0], T7[1], T7[2], T7[3], T7[4], T7[5], T7[6]);
     fprintf(out, "sparse_err %.9g\n", (f[1]._TCW * T1_true.inverse()).log().norm());
+    // ... and SparseImgAlign with method LevenbergMarquardt (NLSSolver_impl.hpp:91-212; nobody in the reference asks for it) from the same start
+    {
+        const SE3 T_gn = f[1]._TCW;
+        f[1]._TCW = f[0]._TCW;
+        SparseImgAlign lm(2, 0, 30, SparseImgAlign::LevenbergMarquardt, false, false);
+        const size_t nm = lm.run(&f[0], &f[1]);
+        double L7[7]; f[1]._TCW.to7(L7);
+        fprintf(out, "sparse_lm %zu %d %d %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", nm, lm.iterations(2), lm.iterations(1), lm.iterations(0), lm.trials(),
+                L7[0], L7[1], L7[2], L7[3], L7[4], L7[5], L7[6]);
+        fprintf(out, "sparse_lm_err %.9g %.9g\n", (f[1]._TCW * T1_true.inverse()).log().norm(), (f[1]._TCW * T_gn.inverse()).log().norm());
+        f[1]._TCW = T_gn;
+    }
     // --- test_local_ba: 8 keyframes x 16 points, noisy state read from the input directory
     {
         auto kp = slurp_f64(in + "/ba_poses7.f64");        // [8][7] noisy T_cw

@@ -510,6 +510,35 @@ def test_sparse_align(hip_lib, oracle, lanes, monkeypatch):
         ctx.close()
 
 
+def test_sparse_align_residuals(hip_lib, oracle):
+    """ygz_hip_sparse_align_residuals = one SparseImgAlign::computeResiduals(model, linearize = true) (SparseImageAlign.cpp:124-223 with
+    precomputeReferencePatches :59-122) at a model the caller holds, per level: the float chi2 sum and the measurement count equal the oracle's bit for
+    bit, H_ and Jres_ to 1e-9 -- the step the class surface's Levenberg-Marquardt is built from"""
+    w, h, n = 640, 480, 1000
+    imgs, poses, depths = _frames(2, w, h, seed=8, step=0.4)
+    k0 = oracle.detect(oracle.pyramid(imgs[0], 3), oracle.default_params(w, h, 3))[:n]
+    px = np.stack([k0["px"], k0["py"]], 1)
+    depth = np.array([depths[0][int(p[1]), int(p[0])] for p in px])
+    has_mp = np.ones(len(px), np.uint8); has_mp[::9] = 0
+    ctx = make_ctx(hip_lib, width=w, height=h, max_frames=2)
+    for s in range(2):
+        ctx.upload_gray(s, imgs[s])
+    ctx.build_pyramid(0, 2)
+    lv = [oracle.pyramid(imgs[s], 3) for s in range(2)]
+    T_rel = oracle.se3_mul(oracle.se3_mul(synth.se3_exp([0.004, -0.003, 0.002, 0.001, -0.002, 0.001]), poses[1]), oracle.se3_inv(poses[0]))
+    for level in (2, 1, 0):
+        csum, nm, H, J = ctx.sparse_align_residuals(0, 1, T_rel, px, depth, has_mp, level)
+        o_chi2, oH, oJ, onm, _ = oracle.sparse_align_linearize(lv[0], lv[1], T_rel, px, depth, has_mp, level)
+        assert nm == onm and nm > 8000
+        assert float(np.float32(csum) / np.float32(nm)) == o_chi2                  # chi2 / n_meas_ as the reference forms it (float / size_t)
+        assert np.allclose(H, oH, rtol=1e-9, atol=1e-9 * np.abs(oH).max()) and np.allclose(J, oJ, rtol=1e-9, atol=1e-9 * np.abs(oJ).max())
+    csum, nm, H, J = ctx.sparse_align_residuals(0, 1, T_rel, np.zeros((0, 2)), np.zeros(0), np.zeros(0, np.uint8), 0)
+    assert csum == 0 and nm == 0 and not H.any()
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.sparse_align_residuals(0, 1, T_rel, px, depth, has_mp, 5)
+    ctx.close()
+
+
 def test_sparse_align_more_than_16384_grid_cells(hip_lib, oracle):
     """a 1920x1080 frame has 192 x 108 = 20 736 grid cells: beyond the 32 x 512 features the first form of the kernel could mark per problem (it
     returned YGZ_E_CAPACITY); the second form marks entering / leaving features in their flags byte.  ~6000 features against the oracle."""

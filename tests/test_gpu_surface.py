@@ -180,6 +180,14 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     sp = [float(x) for x in r["sparse"][0]]
     assert sp[0] == 1.0 and np.allclose(sp[1:], oT, rtol=1e-9, atol=1e-11)
     assert float(r["sparse_err"][0][0]) < 0.02
+    # SparseImgAlign(LevenbergMarquardt): the solver on the host, every computeResiduals one launch -- the same trials as the oracle's restatement
+    # of NLSSolver_impl.hpp:91-212 (the float chi2 sums are exact, so every accept / reject agrees), pose 1e-9
+    lm = [float(x) for x in r["sparse_lm"][0]]
+    onm, oT_lm, ost = oracle.sparse_align(lv[0], poses[0], lv[1], poses[0], px0, depth, has_mp, method="lm")
+    assert int(lm[0]) == onm and [int(x) for x in lm[1:4]] == [ost.iters_per_level[2], ost.iters_per_level[1], ost.iters_per_level[0]] and int(lm[4]) == ost.n_iter_total
+    assert np.allclose(lm[5:], oT_lm, rtol=1e-9, atol=1e-11) and int(lm[4]) >= 3
+    e_lm, d_gn = [float(x) for x in r["sparse_lm_err"][0]]
+    assert e_lm < 0.05 and lm[2] == 0 and lm[3] == 0          # (the reference's LM aligns on the coarsest level only: stop_ and n_meas_ are not reset between levels, tests/test_oracle_golden.py)
     # ba::LocalBAG2O == ygz_hip_ba_optimize on the same graph; LM must reduce chi2 by orders of magnitude
     ctx = hip_lib.HipContext(max_frames=1)
     # the C++ side starts from frame->_TCW.log() (BA.cpp:407-409): feed the ABI the same exp->log round trip

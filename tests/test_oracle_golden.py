@@ -268,6 +268,14 @@ def test_align_golden(oracle):
     err0 = np.linalg.norm(oracle.se3_log(oracle.se3_mul(g["T_init"], oracle.se3_inv(T_cur))))
     err1 = np.linalg.norm(oracle.se3_log(oracle.se3_mul(T, oracle.se3_inv(T_cur))))
     assert err1 < 0.5 * err0
+    # method_ = LevenbergMarquardt (NLSSolver_impl.hpp:91-212), reproduced as written -- quirks included: stop_ is set by the five failed trials that
+    # end the coarsest level and never reset (reset() runs once, in run(): SparseImageAlign.cpp:23), and the first computeResiduals of a finer level
+    # divides by the measurements of BOTH levels (n_meas_ is not cleared in front of NLSSolver_impl.hpp:101), so the finer levels end after one failed
+    # trial each: the reference's LM aligns on the coarsest level only (which is presumably why its only caller asks for Gauss-Newton, Matcher.cpp:18)
+    nm_lm, T_lm, st_lm = oracle.sparse_align(lv0, T_ref, lv1, g["T_init"], g["px_ref"], g["depth"], g["has_mp"], method="lm")
+    err_lm = np.linalg.norm(oracle.se3_log(oracle.se3_mul(T_lm, oracle.se3_inv(T_cur))))
+    assert nm_lm == nm and err1 < err_lm < err0
+    assert list(st_lm.iters_per_level)[:3] == [0, 0, 4] and st_lm.n_iter_total == 11
     kp, kst, kerr = oracle.klt_track(e["imgs"][0], e["imgs"][1], g["px_ref"].astype(np.float32), g["klt_init"])
     assert np.array_equal(kp, g["klt_pts"]) and np.array_equal(kst, g["klt_status"]) and np.array_equal(kerr, g["klt_err"])
 

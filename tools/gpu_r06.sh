@@ -21,6 +21,9 @@ p)  # pose-only BA with the lane's features in registers: parity, then the surfa
     timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface.py tests/test_gpu_offline.py -x -q -k "pose_only or surface or handover or unchanged" > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
     timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; tail -3 $OUT/surface.err; surf $OUT/surface.json
     ;;
+l)  # SparseImgAlign(LevenbergMarquardt): the computeResiduals primitive against the oracle, the class surface against the oracle's LM
+    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface.py tests/test_gpu_switches.py -x -q -k "sparse or class_surfaces or alternate" > $OUT/pytest.log 2>&1; grep -v amdgpu.ids $OUT/pytest.log | tail -25
+    ;;
 k)  # kernel time inside the surface loop (rocprofv3 kernel trace of bench.py --mode surface)
     bash tools/stats_cmd.sh r06_surface --mode surface --no-cpu-baseline
     cp gpurun_out/r06_surface_kernel_stats.md $OUT/; head -24 $OUT/r06_surface_kernel_stats.md

@@ -88,7 +88,7 @@ ABI_SYMBOLS = [
     "ygz_hip_upload_bgr", "ygz_hip_upload_gray", "ygz_hip_build_pyramid", "ygz_hip_download_level", "ygz_hip_download_framed_level", "ygz_hip_level_size",
     "ygz_hip_detect", "ygz_hip_keypoint_count", "ygz_hip_get_keypoints", "ygz_hip_describe", "ygz_hip_describe_given_angle", "ygz_hip_get_fast_maps",
     "ygz_hip_match_slots", "ygz_hip_match_slots_again", "ygz_hip_get_matches", "ygz_hip_hamming_match",
-    "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align",
+    "ygz_hip_find_direct_projection", "ygz_hip_align2d", "ygz_hip_sparse_align", "ygz_hip_sparse_align_residuals",
     "ygz_hip_default_klt_params", "ygz_hip_klt_track", "ygz_hip_klt_track_filtered",
     "ygz_hip_set_keypoint_depths", "ygz_hip_track_begin", "ygz_hip_track_reload", "ygz_hip_track_klt", "ygz_hip_track_klt_prepare", "ygz_hip_track_direct",
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
@@ -576,6 +576,21 @@ class HipContext:
         return dist[:n].copy(), keep[:n].astype(bool), ng.value, best.value
 
     # ---- alignment
+    def sparse_align_residuals(self, ref_slot, cur_slot, T_cur_from_ref, px, depth, has_mp, level):
+        """one SparseImgAlign::computeResiduals(model, linearize = true) at `level`: (chi2 float sum, n_meas, H [6][6], Jres [6])"""
+        T = np.ascontiguousarray(T_cur_from_ref, np.float64)
+        px = np.ascontiguousarray(px, np.float64).reshape(-1, 2); depth = np.ascontiguousarray(depth, np.float64)
+        has_mp = np.ascontiguousarray(has_mp, np.uint8)
+        chi2, nm = C.c_double(0), C.c_int(0)
+        H, J = np.zeros(36), np.zeros(6)
+        self.lib.ygz_hip_sparse_align_residuals.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                            C.POINTER(C.c_uint8), C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        self._chk(self.lib.ygz_hip_sparse_align_residuals(self._ctx, int(ref_slot), int(cur_slot), _p(T, C.c_double), _p(px, C.c_double), _p(depth, C.c_double),
+                                                          _p(has_mp, C.c_uint8), len(depth), int(level), C.byref(chi2), C.byref(nm), _p(H, C.c_double),
+                                                          _p(J, C.c_double)), "sparse_align_residuals")
+        return chi2.value, nm.value, H.reshape(6, 6), J
+
     def find_direct_projection_mp(self, cur_slot, T_cur, kf_slots, kf_T, cand_kf, pos_world, px_ref, level_ref, px_in=None):
         """Matcher::FindDirectProjection, MapPoint overload, per candidate over several reference keyframes in one launch.
         Returns dict(in_view, px_proj, ok, px, level); px_in given: no FindCandidates projection, every candidate evaluated."""

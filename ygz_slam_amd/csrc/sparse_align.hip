@@ -42,6 +42,8 @@ struct SaArgs {
     int pcap;                                     // second form: features whose reference patch lives in LDS; multiple of 64
     int n_pairs;                                  // second form: problems of the launch (a workgroup loops over blockIdx.x + k * gridDim.x)
     int prio;                                     // != 0: raise the wavefronts' issue priority (the kernel is latency-bound: one wavefront per SIMD)
+    double *lin;                                  // optional [pairs][32]: what computeResiduals(model, linearize = true) leaves -- the float chi2 sum, n_meas, H (21), Jres (6) -- of the last pass
+    int rel;                                      // != 0: out[0..6] is T_cur_from_ref itself, in and out (the solver's model, SparseImageAlign.cpp:37,48 left to the caller)
 };
 
 #define wave_sum_d ygz_wave_sum_d
@@ -268,7 +270,8 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
         for (int k = 0; k < 4; ++k) T_cur.q[k] = out[k];
         for (int k = 0; k < 3; ++k) T_cur.t[k] = out[4 + k];
         se3_inv_d(&T_ref, &Tri);
-        se3_mul_d(&T_cur, &Tri, &sT);                   // T_cur_from_ref (SparseImageAlign.cpp:37)
+        if (A.rel) sT = T_cur;
+        else se3_mul_d(&T_cur, &Tri, &sT);              // T_cur_from_ref (SparseImageAlign.cpp:37)
         for (int l = 0; l < YGZ_MAX_LEVELS; ++l) out[8 + l] = 0;
     }
     for (int f = tid; f < n; f += SA_THREADS) {          // a lane only ever touches the flags, patches and gradients of its own features
@@ -611,6 +614,11 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
                     Hm[6 * a + b] = sm; Hm[6 * b + a] = sm; ++q;
                 }
                 for (int a = 0; a < 6; ++a) { double sm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) sm += red[w2][21 + a]; Jr[a] = sm; }
+                if (A.lin) {                                     // H_ and Jres_ as computeResiduals left them (ygz_hip_sparse_align_residuals)
+                    double *lo = A.lin + 32 * (size_t)pair;
+                    for (int k = 0; k < 21; ++k) lo[2 + k] = s_H[k];
+                    for (int k = 0; k < 6; ++k) lo[23 + k] = Jr[k];
+                }
                 const bool okx = ldlt6_solve_ws(Hm, Jr, x, s_ldlt, s_ldlt + 36, s_ldlt + 42, s_tr);
                 double mx[6]; for (int k = 0; k < 6; ++k) mx[k] = -x[k];
                 Se3 E, Tn;
@@ -625,6 +633,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
             if (tid == 0) {
                 int nm = 0; for (int w2 = 0; w2 < SA_THREADS / 64; ++w2) nm += s_nmeas_w[w2];
                 n_meas_last = nm;
+                if (A.lin) { A.lin[32 * (size_t)pair] = (double)s_chi2; A.lin[32 * (size_t)pair + 1] = (double)nm; }
                 const double new_chi2 = (double)__fdiv_rn(s_chi2, (float)nm);
                 if (!s_solve_ok) stop_ = true;
                 int ctl = 0;
@@ -646,7 +655,9 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
         if (tid == 0 && level < YGZ_MAX_LEVELS) out[8 + level] = (double)it;
     }
     if (tid == 0) {
-        Se3 o; se3_mul_d(&sT, &T_ref, &o);                 // cur->_TCW = T_cur_from_ref * ref->_TCW (:48)
+        Se3 o;
+        if (A.rel) o = sT;
+        else se3_mul_d(&sT, &T_ref, &o);                   // cur->_TCW = T_cur_from_ref * ref->_TCW (:48)
         for (int k = 0; k < 4; ++k) out[k] = o.q[k];
         for (int k = 0; k < 3; ++k) out[4 + k] = o.t[k];
         out[7] = (double)n_meas_last;
@@ -681,6 +692,7 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.trk_px = ctx->trk_px; A.trk_depth = ctx->trk_depth; A.trk_has_mp = ctx->trk_has_mp;
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
     A.dbg = nullptr; A.prio = ctx->wave_prio_mask & 1; A.n_pairs = n_pairs;
+    A.lin = ctx->sa_lin; A.rel = ctx->sa_rel ? 1 : 0;
 #ifdef YGZ_SA_TIMERS
     { void *dd = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 1, (size_t)n_pairs * 16 * 8, &dd) == YGZ_OK) A.dbg = (double *)dd; }
 #endif
@@ -776,5 +788,54 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     for (int k = 0; k < 7; ++k) T_cur[k] = h_out[k];
     if (n_meas_out) *n_meas_out = (int)(h_out[7] / 16);        // run() returns n_meas_/patch_area_ (:49)
     if (iters_out) for (int l = 0; l < ctx->prm.pyramid_levels; ++l) iters_out[l] = (int)h_out[8 + l];
+    return YGZ_OK;
+}
+
+// One NLLSSolver::computeResiduals(model, linearize_system = true, false) of SparseImgAlign (src/Algorithm/SparseImageAlign.cpp:124-223, with
+// precomputeReferencePatches :59-122 for the level) at a model the CALLER holds: what a solver other than the resident Gauss-Newton loop needs --
+// the class surface's Levenberg-Marquardt (NLSSolver_impl.hpp:91-212) drives its trials with it.  One launch of the same kernel with one level and
+// one iteration; the model goes in as T_cur_from_ref itself.  chi2_sum = the reference's float running sum (exact), n_meas = measurements
+// (16 per feature used), H (6 x 6, symmetric) and Jres as H_ / Jres_ after the call.
+extern "C" int ygz_hip_sparse_align_residuals(ygz_hip_ctx *ctx, int ref_slot, int cur_slot, const double T_cur_from_ref[7], const double *px,
+                                              const double *depth, const uint8_t *has_mappoint, int n, int level, double *chi2_sum, int *n_meas,
+                                              double *H, double *Jres)
+{
+    YgzDeviceGuard dg_(ctx);
+    if (!ctx || !T_cur_from_ref || n < 0 || ref_slot < 0 || ref_slot >= ctx->prm.max_frames || cur_slot < 0 || cur_slot >= ctx->prm.max_frames ||
+        level < 0 || level >= ctx->prm.pyramid_levels || !chi2_sum || !n_meas) return YGZ_E_INVALID;
+    *chi2_sum = 0.0; *n_meas = 0;
+    if (H) for (int k = 0; k < 36; ++k) H[k] = 0.0;
+    if (Jres) for (int k = 0; k < 6; ++k) Jres[k] = 0.0;
+    if (n == 0) return YGZ_OK;
+    if (!px || !depth || !has_mappoint) return YGZ_E_INVALID;
+    if (n > ctx->cells) return YGZ_E_CAPACITY;
+    if (!ctx->pyr_valid[ref_slot] || !ctx->pyr_valid[cur_slot]) return YGZ_E_STATE;
+    const size_t N = (size_t)n;
+    YgzPack pk;
+    int rc = ygz_pack_begin(ctx, &pk, N * 25 + 64 + 14 * 8 + 16 + (size_t)ctx->prm.max_frames * 8 + 64, SCR_GEN_0 + 6);
+    if (rc != YGZ_OK) return rc;
+    const double I7[7] = { 0, 0, 0, 1, 0, 0, 0 };
+    if ((rc = ygz_track_set_pairs(ctx, &cur_slot, &ref_slot, T_cur_from_ref, I7, 1, &pk)) != YGZ_OK) return rc;
+    double *h_px = (double *)ygz_pack_add(&pk, ctx->trk_px, N * 16), *h_dep = (double *)ygz_pack_add(&pk, ctx->trk_depth, N * 8);
+    uint8_t *h_mp = (uint8_t *)ygz_pack_add(&pk, ctx->trk_has_mp, N);
+    int32_t *h_n = (int32_t *)ygz_pack_add(&pk, ctx->trk_n, 4);
+    double *h_T = (double *)ygz_pack_add(&pk, ctx->sa_out, 7 * 8);
+    if (!h_px || !h_dep || !h_mp || !h_n || !h_T) return YGZ_E_CAPACITY;
+    memcpy(h_px, px, N * 16); memcpy(h_dep, depth, N * 8); memcpy(h_mp, has_mappoint, N); memcpy(h_T, T_cur_from_ref, 56); *h_n = n;
+    if ((rc = ygz_pack_upload(ctx, &pk)) != YGZ_OK) return rc;
+    void *d_lin = nullptr;
+    if ((rc = ygz_scratch(ctx, SCR_GEN_0 + 3, 32 * 8, &d_lin)) != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipMemsetAsync(d_lin, 0, 32 * 8, ctx->stream));
+    double *h_lin = (double *)ygz_stage(ctx, 32 * 8);
+    if (!h_lin) return YGZ_E_HIP;
+    ctx->sa_n_hint = n; ctx->sa_lin = (double *)d_lin; ctx->sa_rel = true;
+    rc = ygz_launch_sparse_align(ctx, 1, level, level, 1);
+    ctx->sa_n_hint = 0; ctx->sa_lin = nullptr; ctx->sa_rel = false;
+    if (rc != YGZ_OK) return rc;
+    if ((rc = ygz_kcopy(ctx, h_lin, d_lin, 32 * 8, hipMemcpyDeviceToHost)) != YGZ_OK) return rc;
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *chi2_sum = h_lin[0]; *n_meas = (int)h_lin[1];
+    if (H) { int q = 0; for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { H[6 * a + b] = h_lin[2 + q]; H[6 * b + a] = h_lin[2 + q]; ++q; } }
+    if (Jres) for (int k = 0; k < 6; ++k) Jres[k] = h_lin[23 + k];
     return YGZ_OK;
 }

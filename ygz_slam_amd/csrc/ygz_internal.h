@@ -137,6 +137,8 @@ struct ygz_hip_ctx {
     bool describe_aside = false;             // ygz_hip_detect leaves the descriptor kernel on the matcher's side stream (YGZ_DESCRIBE_ASIDE=1)
     bool sa_attr_set = false;                // the dynamic-LDS opt-in of k_sparse_align was made on this context's device
     bool lm_attr_set = false;                // the dynamic-LDS opt-in of k_ba_lm_team was made on this context's device
+    double *sa_lin = nullptr;             // != nullptr for the launch: [32] chi2 sum, n_meas, H (21, upper triangle), Jres (6) of the LAST linearisation (ygz_hip_sparse_align_residuals)
+    bool sa_rel = false;                  // the pose in sa_out is T_cur_from_ref itself (no product with the reference pose on the way in or out)
     int sa_n_hint = 0;                    // features of the ONE problem of a single-frame call (0: unknown, the counts are on the device): sizes the LDS tiers
     int  klt_prep_levels = 0;                // levels covered by the LK working images while klt_prep_valid
     // instruction-issue priority (s_setprio 0..3) the latency- / memory-bound kernels raise their wavefronts to, so that they keep

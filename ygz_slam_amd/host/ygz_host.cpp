@@ -7,6 +7,7 @@
 #include "ygz/hip/Runtime.h"
 #include "ygz_hip.h"
 #include "../csrc/se3_dev.h"
+#include "../csrc/ldlt6.h"
 #include <fstream>
 #include <stdexcept>
 #include <cstdlib>
@@ -473,16 +474,97 @@ float Tracker::MeanDisparity() const
 
 // ------------------------------------------------------------------------------------------ SparseImgAlign
 SparseImgAlign::SparseImgAlign(int max_level, int min_level, int n_iter, Method method, bool, bool)
-    : max_level_(max_level), min_level_(min_level), n_iter_(n_iter)
+    : max_level_(max_level), min_level_(min_level), n_iter_(n_iter), method_(method) {}
+
+// method_ = LevenbergMarquardt: NLLSSolver::optimizeLevenbergMarquardt (include/ygz/Algorithm/NLSSolver_impl.hpp:91-212) per level, as
+// SparseImgAlign::run drives it (SparseImageAlign.cpp:21-50).  The bookkeeping of the solver runs here; every computeResiduals(model, ...) is one
+// launch (ygz_hip_sparse_align_residuals: precomputeReferencePatches + the residual pass of that level, the float chi2 sum exact).  Reproduced as
+// written: mu_ = 0.1 before every level (:41), nu_ / stop_ / n_meas_ carried from level to level -- the first computeResiduals of a level (:101)
+// counts its measurements ON TOP of the last evaluation of the level before --, H_ += diag(H_) mu_, Eigen's ldlt, T exp(-x), rho_ = chi2_ -
+// new_chi2, five failed trials stop.  (The reference evaluates a trial's new model without linearising; the launch linearises anyway, the sums are
+// not read.)  oracle/sparse_align.c: yo_sparse_align_lm is the same loop on the CPU.
+size_t SparseImgAlign::run_lm(Frame *ref_frame, Frame *cur_frame)
 {
-    // NLLSSolver::optimizeLevenbergMarquardt (NLSSolver_impl.hpp:91-212) is not provided: the only caller of the reference constructs the aligner
-    // with GaussNewton (Matcher.cpp:18).  Asking for it is an ERROR, not a silent Gauss-Newton run under another name.
-    if (method != GaussNewton) throw std::invalid_argument("ygz::SparseImgAlign: method LevenbergMarquardt is not provided (only GaussNewton, the reference's live path, Matcher.cpp:18)");
+    hip::Runtime &rt = hip::Runtime::Get();
+    ygz_hip_ctx *c = rt.ctx();
+    const int n = (int)ref_frame->_features.size();
+    vector<double> px(2 * (size_t)n), depth(n); vector<uint8_t> has(n);
+    for (int i = 0; i < n; ++i) {
+        const Feature *f = ref_frame->_features[i];
+        px[2 * i] = f->_pixel[0]; px[2 * i + 1] = f->_pixel[1]; depth[i] = f->_depth; has[i] = f->_mappoint != nullptr;
+    }
+    const int rs = rt.Resident(ref_frame), cs = rt.Resident(cur_frame);
+    size_t n_meas_ = 0;
+    bool failed = false;
+    // computeResiduals(model, linearize_system, false): chi2 / n_meas_ as float / size_t -> float (SparseImageAlign.cpp:222); n_meas_ accumulates
+    auto compute_residuals = [&](const SE3 &model, int level, double *H, double *Jres) -> double {
+        double t7[7], csum = 0; int cnt = 0;
+        model.to7(t7);
+        if (!hip::check(ygz_hip_sparse_align_residuals(c, rs, cs, t7, px.data(), depth.data(), has.data(), n, level, &csum, &cnt, H, Jres), "sparse_align_residuals")) failed = true;
+        n_meas_ += (size_t)cnt;
+        return (double)((float)csum / (float)n_meas_);
+    };
+    // reset() (NLSSolver_impl.hpp:283-293) with the defaults of NLSSolver.h:75-95
+    double chi2_ = 1e10, mu_ = (double)0.01f, nu_ = 2.0, rho_ = 0;
+    bool stop_ = false;
+    const double eps_ = 0.000001;                              // SparseImageAlign.cpp:18
+    const int n_trials_max_ = 5;
+    trials_ = 0;
+    for (int &it : iters_) it = 0;
+    SE3 T = cur_frame->_TCW * ref_frame->_TCW.inverse();       // T_cur_from_ref (:37)
+    double H[36], Jres[6], x[6];
+    for (int level = max_level_; level >= min_level_ && !failed; --level) {
+        mu_ = 0.1;                                             // :41
+        chi2_ = compute_residuals(T, level, H, Jres);          // :101 (n_meas_ not reset: see above)
+        if (mu_ < 0) { double mx = 0; for (int j = 0; j < 6; ++j) mx = std::max(mx, fabs(H[7 * j])); mu_ = 1e-4 * mx; }      // :113-120, never true here
+        int it = 0;
+        for (; it < n_iter_ && !failed; ++it) {
+            rho_ = 0;
+            int n_trials_ = 0;
+            do {
+                SE3 new_model = T;
+                double new_chi2 = -1;
+                n_meas_ = 0;
+                compute_residuals(T, level, H, Jres);                          // H_, Jres_ zeroed, linearised at the model (:133-139)
+                for (int j = 0; j < 6; ++j) H[7 * j] += H[7 * j] * mu_;        // :142
+                if (ldlt6_solve_d(H, Jres, x)) {                               // SparseImgAlign::solve
+                    Vector6d mx; for (int k = 0; k < 6; ++k) mx[k] = -x[k];
+                    new_model = T * SE3::exp(mx);                              // update (:233-238)
+                    n_meas_ = 0;
+                    new_chi2 = compute_residuals(new_model, level, nullptr, nullptr);
+                    rho_ = chi2_ - new_chi2;
+                } else rho_ = -1;
+                ++trials_;
+                if (rho_ > 0) {
+                    T = new_model;
+                    chi2_ = new_chi2;
+                    double nm = -1; for (int k = 0; k < 6; ++k) nm = std::max(nm, fabs(x[k]));
+                    stop_ = nm <= eps_;
+                    mu_ *= std::max(1. / 3., std::min(1. - pow(2 * rho_ - 1, 3), 2. / 3.));
+                    nu_ = 2.;
+                } else {
+                    mu_ *= nu_;
+                    nu_ *= 2.;
+                    ++n_trials_;
+                    if (n_trials_ >= n_trials_max_) stop_ = true;
+                }
+            } while (!(rho_ > 0 || stop_) && !failed);
+            if (stop_) break;
+        }
+        if (level >= 0 && level < 8) iters_[level] = it;
+    }
+    if (failed) return 0;                                      // an ABI call failed (logged): the pose as it was
+    cur_frame->_TCW = T * ref_frame->_TCW;                     // :48
+    return n_meas_ / 16;
 }
 
 size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
 {
     if (ref_frame->_features.empty()) return 0;
+    if (method_ == LevenbergMarquardt) {
+        if ((int)ref_frame->_features.size() > hip::Runtime::Get().cells()) { LOG(ERROR) << "SparseImgAlign::run: more features than grid cells" << endl; return 0; }
+        return run_lm(ref_frame, cur_frame);
+    }
     hip::Runtime &rt = hip::Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
     const int n = (int)ref_frame->_features.size();
