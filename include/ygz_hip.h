@@ -39,8 +39,9 @@ extern "C" {
 /* Bumped whenever an exported function changes its argument list under the same name (C has no mangling: a caller built against an older
  * header would still link).  Bindings compare ygz_hip_abi_version() with the header they were written against at load time
  * (ygz_slam_amd/_lib.py, include/ygz/hip/Runtime.h).  5: ygz_hip_kf_row_bytes / ygz_hip_kf_store_create / ygz_hip_ba_build_windows
- * gained their trailing int (round 4); ygz_hip_get_stream / device_alloc / copy added (round 5). */
-#define YGZ_HIP_ABI_VERSION 5
+ * gained their trailing int (round 4); ygz_hip_get_stream / device_alloc / copy added (round 5).  6: ygz_ceres_options gained trust_region_strategy
+ * (in the struct's tail padding: same size); ygz_hip_find_direct_projection_mp, ygz_hip_sparse_align_residuals, ygz_hip_ba_light_barrier added (round 6). */
+#define YGZ_HIP_ABI_VERSION 6
 
 typedef struct ygz_hip_ctx ygz_hip_ctx;
 
@@ -481,7 +482,7 @@ int  ygz_hip_ba_pack_states(ygz_hip_ctx *ctx, int window_begin, int n_windows, d
 
 
 /* ---- B6/B7: ceres::Solve as the reference configures it (src/Algorithm/BA.cpp:219-226,372-375: default options =
- *      trust-region Levenberg-Marquardt, Jacobi scaling) around the GPU linearisation of a formulation-2 problem.
+ *      trust-region Levenberg-Marquardt, Jacobi scaling; :58-62 TwoViewBACeres: DOGLEG) around the GPU linearisation of a formulation-2 problem.
  *      ba::LocalBA, OptimizeCurrent, OptimizeCurrentPointOnly and TwoViewBACeres are this call on different edge lists. */
 typedef struct {
     int    max_num_iterations;                       /* 50 */
@@ -490,7 +491,10 @@ typedef struct {
     double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;               /* 1e-3, 1e-6, 1e32 */
     int    jacobi_scaling, max_num_consecutive_invalid_steps;                     /* 1, 5 */
     int    fail_behind_camera;                       /* 1: evaluation fails when an enabled edge has p_z < 0 (PoseOnly) */
+    int    trust_region_strategy;                    /* 0 LEVENBERG_MARQUARDT (default), 1 DOGLEG (TRADITIONAL_DOGLEG: ba::TwoViewBACeres, BA.cpp:59-60);
+                                                        DOGLEG runs the loop on the host around the GPU linearisations (round 6) */
 } ygz_ceres_options;
+enum { YGZ_CERES_LEVENBERG_MARQUARDT = 0, YGZ_CERES_DOGLEG = 1 };
 enum { YGZ_CERES_FUNCTION_TOLERANCE = 0, YGZ_CERES_GRADIENT_TOLERANCE, YGZ_CERES_PARAMETER_TOLERANCE, YGZ_CERES_MIN_RADIUS,
        YGZ_CERES_NO_CONVERGENCE, YGZ_CERES_FAILURE };
 typedef struct {

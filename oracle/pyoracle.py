@@ -104,7 +104,7 @@ class CeresOptions(C.Structure):
                 ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
                 ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int)]
+                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int), ("trust_region_strategy", C.c_int)]
 
 
 class CeresSummary(C.Structure):

@@ -320,7 +320,9 @@ typedef struct {
     double initial_trust_region_radius, max_trust_region_radius, min_trust_region_radius;
     double min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
     int jacobi_scaling, max_num_consecutive_invalid_steps;
+    int trust_region_strategy;  /* 0 LEVENBERG_MARQUARDT (ceres' default), 1 DOGLEG (TRADITIONAL_DOGLEG: what ba::TwoViewBACeres asks for, BA.cpp:60) */
 } yo_ceres_options;
+enum { YO_CERES_LEVENBERG_MARQUARDT = 0, YO_CERES_DOGLEG = 1 };
 enum { YO_CERES_FUNCTION_TOLERANCE = 0, YO_CERES_GRADIENT_TOLERANCE, YO_CERES_PARAMETER_TOLERANCE, YO_CERES_MIN_RADIUS,
        YO_CERES_NO_CONVERGENCE, YO_CERES_FAILURE };
 typedef struct {

@@ -966,6 +966,30 @@ def test_ba_solve_ceres_variants(hip_lib, oracle):
     ctx.close()
 
 
+def test_ba_solve_ceres_dogleg(hip_lib, oracle):
+    """options.trust_region_strategy_type = DOGLEG (ba::TwoViewBACeres, BA.cpp:58-62): ygz_hip_ba_solve_ceres with the DoglegStrategy (host loop around the
+    GPU linearisations) against the oracle's restatement -- same accepted / rejected steps, iteration count and termination, final cost and state 1e-6 --
+    on a local-BA window, a small window and a TwoViewBACeres-shaped problem (one constant pose, HuberLoss(0.1) on some residual blocks)"""
+    ctx = make_ctx(hip_lib, max_frames=1)
+    gopt, oopt = ctx.ceres_options(trust_region_strategy=1), oracle.ceres_options(trust_region_strategy=1)
+    rng = np.random.default_rng(3)
+    for w, with_huber in ((synth.ba_window(6, 300, seed=5), False), (synth.ba_window(4, 60, seed=9), False), (synth.ba_window(2, 200, seed=4), True)):
+        c = fixtures.ba_to_ceres(w)
+        huber = np.where(rng.random(len(c["obs_n"])) < 0.3, 0.1, 0.0) if with_huber else None
+        pg, xg, sg = ctx.ba_solve_ceres(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], edge_huber=huber, options=gopt)
+        po, xo, so = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], edge_huber=huber, options=oopt)
+        assert ctx.ba_last_path()[0] is False                                  # the resident kernel has the LM strategy only
+        assert (sg["iterations"], sg["successful_steps"], sg["unsuccessful_steps"], sg["termination"]) == \
+               (so["iterations"], so["successful_steps"], so["unsuccessful_steps"], so["termination"]), (sg, so)
+        assert abs(sg["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"] + 1e-14 and so["successful_steps"] >= 2
+        # the state: a window with one constant pose keeps the monocular scale as a free direction, and the Gauss-Newton system of the dogleg carries
+        # only mu_ = 1e-8 of regularisation along it (LM damps it with 1 / radius): rounding moves the state ALONG that direction (1e-4 relative
+        # measured) without moving the cost (1e-6 above)
+        assert np.allclose(pg, po, rtol=1e-3, atol=1e-6) and np.allclose(xg, xo, rtol=1e-3, atol=1e-5)
+        assert np.isclose(sg["final_radius"], so["final_radius"], rtol=1e-3)
+    ctx.close()
+
+
 def test_ba_solve_ceres_resident_windows(hip_lib, oracle, monkeypatch):
     """SURVEY 8f-1, second half: the ceres trust-region loop resident on the GPU (k_ba_ceres), five different windows in ONE launch --
     ba::LocalBA problems of two sizes, all poses constant (OptimizeCurrentPointOnly), HuberLoss(0.1) with one free pose

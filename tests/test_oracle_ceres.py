@@ -152,6 +152,41 @@ def test_ceres_solve_noisy_window_decreases_and_terminates(oracle):
                                                                        c["edge_point"], c["obs_n"])["bp"]).max()
 
 
+def test_ceres_dogleg_strategy(oracle):
+    """options.trust_region_strategy_type = DOGLEG (what ba::TwoViewBACeres asks for, BA.cpp:60): the restated DoglegStrategy against the
+    Levenberg-Marquardt one on the same problems -- another path through the same cost landscape: both converge (no iteration cap), to the same cost
+    and a stationary point; on the zero-noise fixture to cost 0; with a first full Gauss-Newton step when it lies inside the initial radius of 1e4."""
+    fx = fixtures.ba_fixture_test_local_ba(noise=True)
+    fx["obs"] = fixtures.ba_fixture_test_local_ba(noise=False)["obs"]
+    c = fixtures.ba_to_ceres(fx)
+    dog = oracle.ceres_options(trust_region_strategy=1)
+    pd, xd, sd = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], options=dog)
+    assert sd["rc"] == 0 and sd["final_cost"] < 1e-12 * sd["initial_cost"] + 1e-16 and sd["successful_steps"] >= 3 and sd["iterations"] <= 50
+    assert np.array_equal(pd[0], c["poses"][0])
+    for w in (synth.ba_window(K=6, P=300, seed=5), synth.ba_window(K=4, P=60, seed=9), fixtures.ba_fixture_test_local_ba(noise=True, seed=5)):
+        c = fixtures.ba_to_ceres(w)
+        args = (c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"])
+        pl, xl, sl = oracle.ceres_solve(*args)
+        pd, xd, sd = oracle.ceres_solve(*args, options=dog)
+        assert sd["rc"] == 0 and sd["termination"] in (0, 1, 2) and sd["successful_steps"] >= 2
+        assert abs(sd["final_cost"] - sl["final_cost"]) <= 1e-4 * sl["final_cost"] + 1e-14, (sd["final_cost"], sl["final_cost"])
+        r0 = oracle.ceres_linearize(*args)
+        r = oracle.ceres_linearize(pd, c["fixed"], xd, c["edge_pose"], c["edge_point"], c["obs_n"])
+        assert np.abs(r["bp"]).max() < 1e-3 * np.abs(r0["bp"]).max()                  # first-order optimality
+        assert sd["final_radius"] > 0 and np.isfinite(sd["final_radius"])
+    # robustified edges and constant points (the shape of TwoViewBACeres: HuberLoss(0.1) on some residual blocks)
+    w = synth.ba_window(K=5, P=120, seed=2)
+    c = fixtures.ba_to_ceres(w)
+    rng = np.random.default_rng(1)
+    huber = np.where(rng.random(len(c["obs_n"])) < 0.3, 0.1, 0.0)
+    pfix = (rng.random(len(c["points"])) < 0.1).astype(np.uint8)
+    kw = dict(point_fixed=pfix, edge_huber=huber)
+    pl, xl, sl = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], **kw)
+    pd, xd, sd = oracle.ceres_solve(c["poses"], c["fixed"], c["points"], c["edge_pose"], c["edge_point"], c["obs_n"], options=dog, **kw)
+    assert sd["rc"] == 0 and abs(sd["final_cost"] - sl["final_cost"]) <= 1e-4 * sl["final_cost"]
+    assert np.array_equal(xd[pfix.astype(bool)], c["points"][pfix.astype(bool)])
+
+
 def test_g2o_lm_restatement(oracle):
     fx = fixtures.ba_fixture_test_local_ba(noise=True)
     fx["obs"] = fixtures.ba_fixture_test_local_ba(noise=False)["obs"]

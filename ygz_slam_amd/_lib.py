@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libygz_hip.so")
 MAX_LEVELS = 8
 
 OK, E_INVALID, E_HIP, E_NO_DEVICE, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5
-ABI_VERSION = 5                     # YGZ_HIP_ABI_VERSION of include/ygz_hip.h this file mirrors
+ABI_VERSION = 6                     # YGZ_HIP_ABI_VERSION of include/ygz_hip.h this file mirrors
 
 
 class YgzHipError(RuntimeError):
@@ -67,7 +67,8 @@ class CeresOptions(C.Structure):
                 ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
                 ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
                 ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
-                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int), ("fail_behind_camera", C.c_int)]
+                ("jacobi_scaling", C.c_int), ("max_num_consecutive_invalid_steps", C.c_int), ("fail_behind_camera", C.c_int),
+                ("trust_region_strategy", C.c_int)]
 
 
 class CeresSummary(C.Structure):

@@ -277,6 +277,7 @@ extern "C" void ygz_hip_ceres_default_options(ygz_ceres_options *o)
     o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
     o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
     o->jacobi_scaling = 1; o->max_num_consecutive_invalid_steps = 5; o->fail_behind_camera = 0;
+    o->trust_region_strategy = YGZ_CERES_LEVENBERG_MARQUARDT;
 }
 
 extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io,
@@ -297,7 +298,8 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
         int Kfree = 0;
         for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
         const char *force = getenv("YGZ_BA_HOST_LOOP");
-        const bool dup = ygz_ba_window_has_dup(ctx, W), forced = force && force[0] == '1', big = Kfree > 14 || K > 16;
+        const bool dup = ygz_ba_window_has_dup(ctx, W), big = Kfree > 14 || K > 16;
+        const bool forced = (force && force[0] == '1') || opt.trust_region_strategy == YGZ_CERES_DOGLEG;      // (the resident kernel has the Levenberg-Marquardt strategy only)
         ctx->ba_last_path = (!big && !forced && !dup) ? YGZ_BA_PATH_RESIDENT
                             : (YGZ_BA_PATH_HOST_LOOP | (big ? YGZ_BA_WHY_FREE_POSES : 0) | (dup ? YGZ_BA_WHY_REPEATED_EDGES : 0) | (forced ? YGZ_BA_WHY_FORCED : 0));
         if (!big && !forced && !dup) {
@@ -315,6 +317,12 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
     std::vector<double> scp((size_t)K * 6, 1.0), scl((size_t)P * 3, 1.0), dp((size_t)K * 6), dl((size_t)P * 3), xp, xl;
     std::vector<double> poses(poses_io, poses_io + (size_t)K * 6), points(points_io, points_io + (size_t)P * 3), cposes, cpoints;
     std::vector<double> dxp((size_t)K * 6), dxl((size_t)P * 3);
+    // DoglegStrategy (TRADITIONAL_DOGLEG; oracle/ceres_ba.c: yo_ceres_solve is the same loop on the CPU): diagonal_, gradient_, gauss_newton_step_ in
+    // the coordinates scaled by diagonal_, the regulariser mu_, the Cauchy step length alpha_, reuse_ after a rejected step
+    const bool dogleg = opt.trust_region_strategy == YGZ_CERES_DOGLEG;
+    std::vector<double> dgp((size_t)K * 6, 1.0), dgl((size_t)P * 3, 1.0), grp((size_t)K * 6, 0.0), grl((size_t)P * 3, 0.0), gnp((size_t)K * 6, 0.0), gnl((size_t)P * 3, 0.0);
+    double dl_mu = 1e-8, dl_alpha = 0, dl_step_norm = 0;
+    bool dl_reuse = false, dl_gn_ok = false;
     ygz_ceres_summary S; memset(&S, 0, sizeof(S));
     double x_cost = 0, radius = opt.initial_trust_region_radius, decrease_factor = 2.0, x_norm = 0, gmax = 0;
     int invalid_run = 0, term = YGZ_CERES_NO_CONVERGENCE;
@@ -363,25 +371,109 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
             if (gmax <= opt.gradient_tolerance) { term = YGZ_CERES_GRADIENT_TOLERANCE; break; }
             if (radius <= opt.min_trust_region_radius) { term = YGZ_CERES_MIN_RADIUS; break; }
             ++S.iterations;
-            // LevenbergMarquardtStrategy::ComputeStep on the column-scaled system
-            for (int k = 0; k < K; ++k) for (int r = 0; r < 6; ++r) {
-                for (int c = 0; c < 6; ++c) sHpp[(size_t)k * 36 + 6 * r + c] = Hpp[(size_t)k * 36 + 6 * r + c] * scp[(size_t)k * 6 + r] * scp[(size_t)k * 6 + c];
-                sbp[(size_t)k * 6 + r] = bp[(size_t)k * 6 + r] * scp[(size_t)k * 6 + r];
-                const double dg = std::min(std::max(sHpp[(size_t)k * 36 + 7 * r], opt.min_lm_diagonal), opt.max_lm_diagonal);
-                dp[(size_t)k * 6 + r] = dg / radius;
+            // the column-scaled system
+            auto clampd = [&](double v) { return std::min(std::max(v, opt.min_lm_diagonal), opt.max_lm_diagonal); };
+            if (!dogleg || !dl_reuse) {
+                for (int k = 0; k < K; ++k) for (int r = 0; r < 6; ++r) {
+                    for (int c = 0; c < 6; ++c) sHpp[(size_t)k * 36 + 6 * r + c] = Hpp[(size_t)k * 36 + 6 * r + c] * scp[(size_t)k * 6 + r] * scp[(size_t)k * 6 + c];
+                    sbp[(size_t)k * 6 + r] = bp[(size_t)k * 6 + r] * scp[(size_t)k * 6 + r];
+                }
+                for (int l = 0; l < P; ++l) for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) sHll[(size_t)l * 9 + 3 * r + c] = Hll[(size_t)l * 9 + 3 * r + c] * scl[(size_t)l * 3 + r] * scl[(size_t)l * 3 + c];
+                    sbl[(size_t)l * 3 + r] = bl[(size_t)l * 3 + r] * scl[(size_t)l * 3 + r];
+                }
+                for (int e = 0; e < E; ++e) {
+                    const int ip = pb->edge_pose[e], il = pb->edge_point[e];
+                    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c)
+                        sHpl[(size_t)e * 18 + 3 * r + c] = Hpl[(size_t)e * 18 + 3 * r + c] * scp[(size_t)ip * 6 + r] * scl[(size_t)il * 3 + c];
+                }
             }
-            for (int l = 0; l < P; ++l) for (int r = 0; r < 3; ++r) {
-                for (int c = 0; c < 3; ++c) sHll[(size_t)l * 9 + 3 * r + c] = Hll[(size_t)l * 9 + 3 * r + c] * scl[(size_t)l * 3 + r] * scl[(size_t)l * 3 + c];
-                sbl[(size_t)l * 3 + r] = bl[(size_t)l * 3 + r] * scl[(size_t)l * 3 + r];
-                const double dg = std::min(std::max(sHll[(size_t)l * 9 + 4 * r], opt.min_lm_diagonal), opt.max_lm_diagonal);
-                dl[(size_t)l * 3 + r] = dg / radius;
+            bool valid;
+            if (!dogleg) {
+                // LevenbergMarquardtStrategy::ComputeStep
+                for (int k = 0; k < K; ++k) for (int r = 0; r < 6; ++r) dp[(size_t)k * 6 + r] = clampd(sHpp[(size_t)k * 36 + 7 * r]) / radius;
+                for (int l = 0; l < P; ++l) for (int r = 0; r < 3; ++r) dl[(size_t)l * 3 + r] = clampd(sHll[(size_t)l * 9 + 4 * r]) / radius;
+                valid = block_solve(BS, sHpp.data(), sHll.data(), sHpl.data(), sbp.data(), sbl.data(), dp.data(), dl.data(), xp, xl);
+            } else {
+                // DoglegStrategy::ComputeStep
+                if (!dl_reuse) {
+                    dl_reuse = true;
+                    double g2 = 0;
+                    for (int k = 0; k < K; ++k) for (int r = 0; r < 6; ++r) {
+                        dgp[(size_t)k * 6 + r] = sqrt(clampd(sHpp[(size_t)k * 36 + 7 * r]));
+                        grp[(size_t)k * 6 + r] = fidx[k] >= 0 ? -sbp[(size_t)k * 6 + r] / dgp[(size_t)k * 6 + r] : 0.0;      // J^T r = -b
+                        g2 += grp[(size_t)k * 6 + r] * grp[(size_t)k * 6 + r];
+                    }
+                    for (int l = 0; l < P; ++l) for (int r = 0; r < 3; ++r) {
+                        dgl[(size_t)l * 3 + r] = sqrt(clampd(sHll[(size_t)l * 9 + 4 * r]));
+                        grl[(size_t)l * 3 + r] = BS.lfree[l] ? -sbl[(size_t)l * 3 + r] / dgl[(size_t)l * 3 + r] : 0.0;
+                        g2 += grl[(size_t)l * 3 + r] * grl[(size_t)l * 3 + r];
+                    }
+                    // ComputeCauchyPoint: |J_scaled v|^2 with v = D^-1 gradient_, as the quadratic form v^T (J_s^T J_s) v of the blocks (the oracle multiplies
+                    // the per-edge Jacobians: same quantity, another order of the sums)
+                    std::vector<double> vp((size_t)K * 6), vl((size_t)P * 3);
+                    for (size_t i = 0; i < vp.size(); ++i) vp[i] = grp[i] / dgp[i];
+                    for (size_t i = 0; i < vl.size(); ++i) vl[i] = grl[i] / dgl[i];
+                    double jg2 = 0;
+                    for (int k = 0; k < K; ++k) if (fidx[k] >= 0) for (int r = 0; r < 6; ++r) {
+                        double hv = 0; for (int c2 = 0; c2 < 6; ++c2) hv += sHpp[(size_t)k * 36 + 6 * r + c2] * vp[(size_t)k * 6 + c2];
+                        jg2 += vp[(size_t)k * 6 + r] * hv;
+                    }
+                    for (int l = 0; l < P; ++l) if (BS.lfree[l]) for (int r = 0; r < 3; ++r) {
+                        double hv = 0; for (int c2 = 0; c2 < 3; ++c2) hv += sHll[(size_t)l * 9 + 3 * r + c2] * vl[(size_t)l * 3 + c2];
+                        jg2 += vl[(size_t)l * 3 + r] * hv;
+                    }
+                    for (int e = 0; e < E; ++e) {
+                        const double *h = &sHpl[(size_t)e * 18], *a = &vp[(size_t)pb->edge_pose[e] * 6], *b2 = &vl[(size_t)pb->edge_point[e] * 3];
+                        for (int r = 0; r < 6; ++r) jg2 += 2.0 * a[r] * (h[3 * r] * b2[0] + h[3 * r + 1] * b2[1] + h[3 * r + 2] * b2[2]);
+                    }
+                    dl_alpha = g2 / jg2;
+                    // ComputeGaussNewtonStep: (J^T J + mu_ D^2) y = J^T r, mu_ x 10 while the factorisation fails
+                    dl_gn_ok = false;
+                    while (dl_mu < 1.0) {
+                        for (size_t i = 0; i < dp.size(); ++i) dp[i] = dgp[i] * dgp[i] * dl_mu;
+                        for (size_t i = 0; i < dl.size(); ++i) dl[i] = dgl[i] * dgl[i] * dl_mu;
+                        bool ok = block_solve(BS, sHpp.data(), sHll.data(), sHpl.data(), sbp.data(), sbl.data(), dp.data(), dl.data(), xp, xl);
+                        if (ok) { for (double v : xp) if (!std::isfinite(v)) ok = false; for (double v : xl) if (!std::isfinite(v)) ok = false; }
+                        if (!ok) { dl_mu *= 10.0; continue; }
+                        dl_gn_ok = true;
+                        break;
+                    }
+                    if (dl_gn_ok) {
+                        for (int k = 0; k < K; ++k) for (int d = 0; d < 6; ++d) gnp[(size_t)k * 6 + d] = fidx[k] >= 0 ? xp[(size_t)fidx[k] * 6 + d] * dgp[(size_t)k * 6 + d] : 0.0;
+                        for (int l = 0; l < P; ++l) for (int d = 0; d < 3; ++d) gnl[(size_t)l * 3 + d] = BS.lfree[l] ? xl[(size_t)l * 3 + d] * dgl[(size_t)l * 3 + d] : 0.0;
+                    }
+                }
+                valid = dl_gn_ok;
+                if (valid) {
+                    // ComputeTraditionalDoglegStep
+                    double g2 = 0, n2 = 0, gdn = 0;
+                    for (size_t i = 0; i < grp.size(); ++i) { g2 += grp[i] * grp[i]; n2 += gnp[i] * gnp[i]; gdn += grp[i] * gnp[i]; }
+                    for (size_t i = 0; i < grl.size(); ++i) { g2 += grl[i] * grl[i]; n2 += gnl[i] * gnl[i]; gdn += grl[i] * gnl[i]; }
+                    const double gradient_norm = sqrt(g2), gauss_newton_norm = sqrt(n2);
+                    double cg, cn;
+                    if (gauss_newton_norm <= radius) { cg = 0.0; cn = 1.0; dl_step_norm = gauss_newton_norm; }
+                    else if (gradient_norm * dl_alpha >= radius) { cg = -(radius / gradient_norm); cn = 0.0; dl_step_norm = radius; }
+                    else {
+                        const double b_dot_a = -dl_alpha * gdn, a_squared_norm = (dl_alpha * gradient_norm) * (dl_alpha * gradient_norm);
+                        const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gauss_newton_norm * gauss_newton_norm;
+                        const double c3 = b_dot_a - a_squared_norm;
+                        const double d3 = sqrt(c3 * c3 + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
+                        const double beta = (c3 <= 0) ? (d3 - c3) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (d3 + c3);
+                        cg = -dl_alpha * (1.0 - beta); cn = beta;
+                        double s2 = 0;
+                        for (size_t i = 0; i < grp.size(); ++i) { const double v = cg * grp[i] + cn * gnp[i]; s2 += v * v; }
+                        for (size_t i = 0; i < grl.size(); ++i) { const double v = cg * grl[i] + cn * gnl[i]; s2 += v * v; }
+                        dl_step_norm = sqrt(s2);
+                    }
+                    // the step in the minimizer's (column-scaled) coordinates, laid out as block_solve leaves its solution
+                    xp.assign((size_t)std::max(BS.Kf, 1) * 6, 0.0); xl.assign((size_t)P * 3, 0.0);
+                    for (int k = 0; k < K; ++k) if (fidx[k] >= 0) for (int d = 0; d < 6; ++d)
+                        xp[(size_t)fidx[k] * 6 + d] = (cg * grp[(size_t)k * 6 + d] + cn * gnp[(size_t)k * 6 + d]) / dgp[(size_t)k * 6 + d];
+                    for (int l = 0; l < P; ++l) if (BS.lfree[l]) for (int d = 0; d < 3; ++d)
+                        xl[(size_t)l * 3 + d] = (cg * grl[(size_t)l * 3 + d] + cn * gnl[(size_t)l * 3 + d]) / dgl[(size_t)l * 3 + d];
+                }
             }
-            for (int e = 0; e < E; ++e) {
-                const int ip = pb->edge_pose[e], il = pb->edge_point[e];
-                for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c)
-                    sHpl[(size_t)e * 18 + 3 * r + c] = Hpl[(size_t)e * 18 + 3 * r + c] * scp[(size_t)ip * 6 + r] * scl[(size_t)il * 3 + c];
-            }
-            bool valid = block_solve(BS, sHpp.data(), sHll.data(), sHpl.data(), sbp.data(), sbl.data(), dp.data(), dl.data(), xp, xl);
             double model_cost_change = 0;
             if (valid) {
                 std::fill(dxp.begin(), dxp.end(), 0.0);
@@ -415,7 +507,8 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
             }
             if (!valid) {     // HandleInvalidStep
                 if (++invalid_run >= opt.max_num_consecutive_invalid_steps) { term = YGZ_CERES_FAILURE; break; }
-                radius *= 0.5;
+                if (dogleg) { dl_mu *= 10.0; dl_reuse = false; }        // DoglegStrategy::StepIsInvalid
+                else radius *= 0.5;
                 ++S.unsuccessful_steps;
                 continue;
             }
@@ -436,14 +529,22 @@ extern "C" int ygz_hip_ba_solve_ceres(ygz_hip_ctx *ctx, const ygz_ba_problem *pb
                 poses = cposes; points = cpoints; x_cost = cand_cost;        // the window already holds this state's blocks
                 if ((rc = fetch_blocks()) != YGZ_OK) { hard_error = true; break; }
                 norm_and_gradient();
-                double t = 2.0 * relative_decrease - 1.0;
-                t = 1.0 - t * t * t;
-                radius = std::min(radius / std::max(1.0 / 3.0, t), opt.max_trust_region_radius);
-                decrease_factor = 2.0;
+                if (dogleg) {                                                 // DoglegStrategy::StepAccepted
+                    if (relative_decrease < 0.25) radius *= 0.5;
+                    if (relative_decrease > 0.75) radius = std::max(radius, 3.0 * dl_step_norm);
+                    radius = std::min(radius, opt.max_trust_region_radius);
+                    dl_mu = std::max(1e-8, 2.0 * dl_mu / 10.0);
+                    dl_reuse = false;
+                } else {
+                    double t = 2.0 * relative_decrease - 1.0;
+                    t = 1.0 - t * t * t;
+                    radius = std::min(radius / std::max(1.0 / 3.0, t), opt.max_trust_region_radius);
+                    decrease_factor = 2.0;
+                }
                 ++S.successful_steps;
             } else {                                                          // StepRejected
-                radius = radius / decrease_factor;
-                decrease_factor *= 2.0;
+                if (dogleg) { radius *= 0.5; dl_reuse = true; }
+                else { radius = radius / decrease_factor; decrease_factor *= 2.0; }
                 ++S.unsuccessful_steps;
             }
         }

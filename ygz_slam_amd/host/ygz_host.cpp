@@ -1192,7 +1192,7 @@ struct CeresArrays {
         const double *p = &poses[6 * (size_t)k];
         return SE3(SO3::exp(Vector3d(p[3], p[4], p[5])), Vector3d(p[0], p[1], p[2]));
     }
-    bool solve(ygz_ceres_summary *sum = nullptr)
+    bool solve(ygz_ceres_summary *sum = nullptr, int trust_region_strategy = YGZ_CERES_LEVENBERG_MARQUARDT)
     {
         if (edge_pose.empty()) return false;
         ygz_ba_problem pb; memset(&pb, 0, sizeof(pb));
@@ -1201,7 +1201,10 @@ struct CeresArrays {
         pb.edge_pose = edge_pose.data(); pb.edge_point = edge_point.data(); pb.obs = obs.data();
         pb.edge_huber = any_huber ? huber.data() : nullptr; pb.formulation = 2;
         ygz_ceres_summary s;
-        if (!hip::check(ygz_hip_ba_solve_ceres(hip::Runtime::Get().ctx(), &pb, poses.data(), points.data(), nullptr, &s), "ba_solve_ceres")) return false;
+        ygz_ceres_options opt;
+        ygz_hip_ceres_default_options(&opt);
+        opt.trust_region_strategy = trust_region_strategy;
+        if (!hip::check(ygz_hip_ba_solve_ceres(hip::Runtime::Get().ctx(), &pb, poses.data(), points.data(), &opt, &s), "ba_solve_ceres")) return false;
         if (sum) *sum = s;
         return s.termination != YGZ_CERES_FAILURE;
     }
@@ -1211,11 +1214,8 @@ struct CeresArrays {
 void TwoViewBACeres(const SE3 &ref, SE3 &curr, const vector<Vector2d> px_ref, const vector<Vector2d> px_curr,
                     vector<bool> &inlier, vector<Vector3d> &pts_ref)
 {   // BA.cpp:11-89
-    // The reference asks ceres for trust_region_strategy_type = DOGLEG here (BA.cpp:58-62); this library restates ceres' LEVENBERG_MARQUARDT strategy
-    // only (oracle/ceres_ba.c, k_ba_ceres).  Both end in a stationary point of the same cost (tests/test_oracle_witness.py holds the LM end point
-    // against scipy's dogbox), the iterates differ: said once per process, loudly, instead of silently.
-    static bool told = false;
-    if (!told) { told = true; LOG(WARNING) << "ba::TwoViewBACeres: the reference's DOGLEG strategy (BA.cpp:59) is solved with ceres' LEVENBERG_MARQUARDT restatement" << endl; }
+    // options.trust_region_strategy_type = ceres::DOGLEG (BA.cpp:58-62): the DoglegStrategy restatement (round 6; the loop runs on the host around the
+    // GPU linearisations -- this is called once per sequence, by the Initializer)
     assert(px_ref.size() == px_curr.size());
     PinholeCamera *cam = Frame::GetCamera();
     assert(cam != nullptr);
@@ -1228,7 +1228,7 @@ void TwoViewBACeres(const SE3 &ref, SE3 &curr, const vector<Vector2d> px_ref, co
         A.add_edge(kr, il, cam->Pixel2Camera2D(px_ref[i]), a);
         A.add_edge(kc, il, cam->Pixel2Camera2D(px_curr[i]), a);
     }
-    A.solve();
+    A.solve(nullptr, YGZ_CERES_DOGLEG);
     curr = A.pose(kc);
     const double ch2 = 5.991;
     for (size_t i = 0; i < px_ref.size(); ++i) {
