@@ -87,3 +87,37 @@ def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer, group=45):
             out.append((ch.pop(0),))
         out.append(tuple(ch))
     return out
+
+
+# ---- the chunk plan of the C++ driver itself (ygz_offline_plan_range of libygz_host.so) through ctypes: what the tests above compare the interpreter form with.
+# (Lived in ygz_slam_amd/offline.py until round 6; it is test plumbing, not part of the product package.)
+import ctypes as C
+import numpy as np
+
+
+def _plan_range(first, last, chunk, ramp, kf_stride, windows, defer):
+    from ygz_slam_amd import offline
+    lib = offline.host_lib()
+    wfl = np.ascontiguousarray([[w[0], w[-1]] for w in windows], np.int32).reshape(-1, 2)
+    cap = max(64, 2 * (last - first) + 64)
+    out = np.zeros((cap, 3), np.int32)
+    n = C.c_int(0)
+    rc = lib.ygz_offline_plan_range(int(first), int(last), int(chunk), int(bool(ramp)), int(kf_stride), wfl.ctypes.data_as(C.POINTER(C.c_int32)), len(wfl),
+                                    int(defer), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("ygz_offline_plan_range failed: %d" % rc)
+    plan = {}
+    for ci, a, b in out[:n.value].tolist():
+        plan.setdefault(ci, []).append((a, b))
+    return [tuple(plan[k]) for k in sorted(plan)]
+
+
+def cpp_chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
+    """[first, last) in chunks of `chunk` frames with short chunks at both ends; kf_stride > 0: the frames behind the last keyframe form the
+    last chunk (ygz_offline.cpp: chunk_schedule)"""
+    return [ch[0] for ch in _plan_range(first, last, chunk, ramp, kf_stride, [], 0)]
+
+
+def cpp_chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
+    """the chunks of the shard [first, last) in processing order, a chunk = a tuple of frame ranges (ygz_offline.cpp: chunk_plan)"""
+    return _plan_range(first, last, chunk, ramp, kf_stride, windows, defer)

@@ -9,6 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 from ygz_slam_amd import dist as ydist
 from ygz_slam_amd import synth, offline
+import plan_ref
 
 
 def test_shards_partition_frames_and_pairs():
@@ -181,7 +182,7 @@ def test_offline_driver_partition_equals_the_python_statement():
             s, c, _ = ydist.shard_frames(n, r, world)
             inside = sum(1 for w in wins if w[0] >= s and w[-1] < s + c)
             d = (13 if c >= 768 else (inside if c <= 160 else 0)) if defer < 0 else defer      # the driver's rule (ygz_offline.cpp: make_plan)
-            exp = offline.chunk_plan(s, s + c, chunk, True, stride, wins, d)
+            exp = plan_ref.cpp_chunk_plan(s, s + c, chunk, True, stride, wins, d)
             got = {}
             for ci, a, b in out[:k.value].tolist():
                 got.setdefault(ci, []).append((a, b))
@@ -203,8 +204,8 @@ def test_offline_plan_equals_the_python_restatement():
         kft = int(rng.choice([0, kf_stride]))
         wins = offline.ba_windows(n_total, kf_stride, window_kfs)
         first, count, _ = ydist.shard_frames(n_total, int(rng.integers(0, world)), world)
-        assert offline.chunk_plan(first, first + count, chunk, ramp, kft, wins, defer) == plan_ref.chunk_plan(first, first + count, chunk, ramp, kft, wins, defer)
-        assert offline.chunk_schedule(first, first + count, chunk, ramp, kft) == plan_ref.chunk_schedule(first, first + count, chunk, ramp, kft)
+        assert plan_ref.cpp_chunk_plan(first, first + count, chunk, ramp, kft, wins, defer) == plan_ref.chunk_plan(first, first + count, chunk, ramp, kft, wins, defer)
+        assert plan_ref.cpp_chunk_schedule(first, first + count, chunk, ramp, kft) == plan_ref.chunk_schedule(first, first + count, chunk, ramp, kft)
 
 
 def test_offline_chunk_schedule_and_depth_images():
@@ -212,13 +213,13 @@ def test_offline_chunk_schedule_and_depth_images():
     look-up (offline.depth_at) samples what the docstring says for every depth-image format"""
     for first, last, chunk in ((0, 1024, 128), (128, 256, 32), (0, 512, 128), (0, 16, 5), (8, 16, 16), (0, 600, 128), (3, 4, 128), (0, 1024, 64)):
         for ramp in (True, False):
-            c = offline.chunk_schedule(first, last, chunk, ramp)
+            c = plan_ref.cpp_chunk_schedule(first, last, chunk, ramp)
             assert c[0][0] == first and c[-1][1] == last and all(a[1] == b[0] for a, b in zip(c, c[1:]))
             assert all(0 < b - a <= chunk for a, b in c)
             if ramp and chunk >= 64 and last - first >= 4 * chunk:
                 assert c[0][1] - c[0][0] == chunk // 4 and c[-1][1] - c[-1][0] == chunk // 4     # short first upload, short last kernels
             # with a keyframe stride the frames behind the shard's last keyframe form the last chunk (no BA window waits for them)
-            k = offline.chunk_schedule(first, last, chunk, ramp, kf_stride=8)
+            k = plan_ref.cpp_chunk_schedule(first, last, chunk, ramp, kf_stride=8)
             assert k[0][0] == first and k[-1][1] == last and all(a[1] == b[0] for a, b in zip(k, k[1:])) and all(0 < b - a <= chunk for a, b in k)
             k_last = ((last - 1) // 8) * 8
             if first <= k_last < last - 1 and c[-1][0] <= k_last:
@@ -231,7 +232,7 @@ def test_offline_chunk_schedule_and_depth_images():
     for first, last, chunk, defer in ((0, 1024, 128, 12), (0, 1024, 128, 16), (128, 256, 32, 2), (0, 128, 32, 2), (0, 100, 32, 3), (64, 200, 32, 5), (0, 16, 5, 2),
                                       (0, 1024, 128, 13), (0, 512, 128, 13), (256, 512, 64, 13)):
         wins = offline.ba_windows(1024, 8, 8)
-        plan = offline.chunk_plan(first, last, chunk, True, 8, wins, defer)
+        plan = plan_ref.cpp_chunk_plan(first, last, chunk, True, 8, wins, defer)
         seen = np.zeros(1024, int)
         for ch in plan:
             assert len(ch) >= 1 and sum(b - a for a, b in ch) <= chunk
@@ -254,7 +255,7 @@ def test_offline_chunk_schedule_and_depth_images():
             for a, b in ch:
                 done[a:b] = True
         assert all(done[w[0]:w[-1] + 1].all() for w in inside)
-        assert offline.chunk_plan(first, last, chunk, True, 8, wins, 0) == [((a, b),) for a, b in offline.chunk_schedule(first, last, chunk, True, 8)]
+        assert plan_ref.cpp_chunk_plan(first, last, chunk, True, 8, wins, 0) == [((a, b),) for a, b in plan_ref.cpp_chunk_schedule(first, last, chunk, True, 8)]
     rng = np.random.default_rng(0)
     d = rng.uniform(0.5, 6.0, (48, 64))
     d[5, 7] = 0.0
@@ -273,7 +274,7 @@ def test_offline_chunk_schedule_and_depth_images():
 
 
 def test_offline_chunk_plan_properties_random():
-    """the C++ driver's chunk_plan (through offline.chunk_plan -> ygz_offline_plan_range) on random sequences / shards / window shapes: every frame of the shard in exactly one range, ranges of a chunk sorted
+    """the C++ driver's chunk_plan (through plan_ref.cpp_chunk_plan -> ygz_offline_plan_range) on random sequences / shards / window shapes: every frame of the shard in exactly one range, ranges of a chunk sorted
     and apart, no frame twice among a chunk's frames and halo frames (they share a lane's slots), at most `chunk` frames per chunk, every window
     that ends inside the shard complete before the first deferred chunk, and shards of all ranks together cover the sequence"""
     rng = np.random.default_rng(123)
@@ -292,7 +293,7 @@ def test_offline_chunk_plan_properties_random():
             if count <= 0:
                 continue
             last = first + count
-            plan = offline.chunk_plan(first, last, chunk, ramp, kf_stride, wins, defer)
+            plan = plan_ref.cpp_chunk_plan(first, last, chunk, ramp, kf_stride, wins, defer)
             seen = np.zeros(n_total, int)
             for ch in plan:
                 assert len(ch) >= 1 and 0 < sum(b - a for a, b in ch) <= chunk, (ch, chunk)
@@ -304,7 +305,7 @@ def test_offline_chunk_plan_properties_random():
             assert np.all(seen[first:last] == 1) and seen.sum() == count
             covered += seen
             inside = [w for w in wins if w[0] >= first and w[-1] < last]
-            plain = offline.chunk_plan(first, last, chunk, ramp, kf_stride, wins, 0)
+            plain = plan_ref.cpp_chunk_plan(first, last, chunk, ramp, kf_stride, wins, 0)
             if plan != plain:                                                       # some gaps are deferred: find the first chunk made of gap frames only
                 in_window = np.zeros(n_total, bool)
                 for w in wins:

@@ -11,6 +11,7 @@ import pytest
 from conftest import make_ctx, ROOT
 from ygz_slam_amd import synth, offline
 from ygz_slam_amd import dist as ydist
+import window_ref
 
 pytestmark = pytest.mark.gpu
 I7 = np.array([0, 0, 0, 1.0, 0, 0, 0])
@@ -269,7 +270,7 @@ def test_offline_sharded_equals_unsharded_720p(hip_lib, oracle, tmp_path, varian
 
 @pytest.mark.parametrize("obs_mode", ["direct", "match"])
 def test_device_built_window_equals_host_built(hip_lib, oracle, obs_mode):
-    """ygz_hip_ba_build_windows against the host restatement offline.build_window_host on the keyframes of a tracked sequence: the same
+    """ygz_hip_ba_build_windows against the host restatement tests/window_ref.py: build_window_host on the keyframes of a tracked sequence: the same
     map points (bit-equal), vertices (1e-13: the host chains the relative poses through numpy), and -- with the device's state installed
     in the host-built graph -- bit-identical linearisations (every edge in the same row, the same observation, the same pose).
     obs_mode "direct": the host takes its observations from per-pair ygz_hip_find_direct_projection calls on a context that holds the
@@ -294,11 +295,11 @@ def test_device_built_window_equals_host_built(hip_lib, oracle, obs_mode):
         def direct(ref, cur, T, px_ref, depth, level, px_cur):
             ok, px, _ = kc.find_direct_projection(slot[ref], offline.I7, slot[cur], T, px_ref, depth, level, px_cur)
             return ok, px
-        h = offline.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, direct=direct,
+        h = window_ref.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, direct=direct,
                                       width=640, height=480)
         kc.close()
     else:
-        h = offline.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, vo.ba.match_sets)
+        h = window_ref.build_window_host(kf_tab, vo.wins[0], T_rel, float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), 700, vo.ba.match_sets)
     assert (K, P, E, Kf) == (4, len(h["points"]), len(h["obs"]), 3) and P > 200 and E > 2 * P
     poses, points = vo.ba.ba_get_state(0, 4, 700)
     assert np.array_equal(points[:P], h["points"])

@@ -179,34 +179,6 @@ def depth_at(dimg, px, w, h, scale=1.0 / 5000.0):
     return np.where(d > 0, d, 0.0)
 
 
-# ---- the chunk plan: host logic of the C++ driver (ygz_offline_plan_range), exposed for the CPU tests ------------------------------------
-def _plan_range(first, last, chunk, ramp, kf_stride, windows, defer):
-    lib = host_lib()
-    wfl = np.ascontiguousarray([[w[0], w[-1]] for w in windows], np.int32).reshape(-1, 2)
-    cap = max(64, 2 * (last - first) + 64)
-    out = np.zeros((cap, 3), np.int32)
-    n = C.c_int(0)
-    rc = lib.ygz_offline_plan_range(int(first), int(last), int(chunk), int(bool(ramp)), int(kf_stride), wfl.ctypes.data_as(C.POINTER(C.c_int32)), len(wfl),
-                                    int(defer), out.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(n))
-    if rc != 0:
-        raise RuntimeError("ygz_offline_plan_range failed: %d" % rc)
-    plan = {}
-    for ci, a, b in out[:n.value].tolist():
-        plan.setdefault(ci, []).append((a, b))
-    return [tuple(plan[k]) for k in sorted(plan)]
-
-
-def chunk_schedule(first, last, chunk, ramp=True, kf_stride=0):
-    """[first, last) in chunks of `chunk` frames with short chunks at both ends; kf_stride > 0: the frames behind the last keyframe form the
-    last chunk (ygz_offline.cpp: chunk_schedule)"""
-    return [ch[0] for ch in _plan_range(first, last, chunk, ramp, kf_stride, [], 0)]
-
-
-def chunk_plan(first, last, chunk, ramp, kf_stride, windows, defer):
-    """the chunks of the shard [first, last) in processing order, a chunk = a tuple of frame ranges (ygz_offline.cpp: chunk_plan)"""
-    return _plan_range(first, last, chunk, ramp, kf_stride, windows, defer)
-
-
 # ---- ctypes mirror of include/ygz_offline.h ------------------------------------------------------------------------------------------------
 class OffParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("levels", C.c_int), ("n_frames", C.c_int), ("rank", C.c_int), ("world", C.c_int),
@@ -624,54 +596,3 @@ def window_pose_errors(windows, trajectory, gt):
             e1 = err(se3_exp_g2o(w["poses"][k]), G)
             tb.append(e0[0]); rb.append(e0[1]); ta.append(e1[0]); ra.append(e1[1])
     return dict(t_before=np.array(tb), t_after=np.array(ta), r_before=np.array(rb), r_after=np.array(ra))
-
-
-def build_window_host(kf_tab, kfs, T_rel, fx, fy, cx, cy, max_points, match_sets=None, direct=None, width=0, height=0):
-    """Host restatement of what ygz_hip_ba_build_windows assembles for one window (the tests compare the device-built graph with it):
-    kf_tab[f] = dict(px, level, desc, depth) of keyframe f, match_sets(descs, pair_q, pair_t) = HipContext.match_sets.  Returns the
-    graph of ba::LocalBAG2O in the anchor's gauge: poses (g2o order), points, edges sorted by (point, keyframe).
-    With direct = fn(ref_frame, cur_frame, T_cur, px_ref, depth_ref, level_ref, px_cur) -> (ok, px) (a per-pair FindDirectProjection, e.g.
-    HipContext.find_direct_projection on a context that holds the keyframes' pyramids) the observations are those of obs_mode 1: the map
-    point projected with the chained pose, FindCandidates' test (z >= 0, InFrame(px, 20) of a width x height frame), FindDirectProjection."""
-    A = kf_tab[kfs[0]]
-    sel = np.nonzero(A["depth"] > 0)[0][:max_points]
-    z = A["depth"][sel]
-    pc = np.stack([(A["px"][sel, 0] - cx) * z / fx, (A["px"][sel, 1] - cy) * z / fy, z], axis=1)     # Pixel2Camera (Camera.h:56-62)
-    ep, el, obs = [np.zeros(len(sel), np.int32)], [np.arange(len(sel), dtype=np.int32)], [A["px"][sel]]
-    others = [(j, f) for j, f in enumerate(kfs[1:], start=1)]
-    if others and len(sel) and direct is not None:
-        from . import _lib
-        Tc = _lib.se3_chain(T_rel[kfs[0]:kfs[-1] + 1])            # T(anchor) = identity, the same Sophus products as the device's chain
-        for j, f in others:
-            T = Tc[f - kfs[0]]
-            q = se3_act(T, pc)
-            pred = np.stack([fx * q[:, 0] / q[:, 2] + cx, fy * q[:, 1] / q[:, 2] + cy], axis=1)            # Camera2Pixel (Camera.h:46-51)
-            vis = ~(q[:, 2] < 0) & (pred[:, 0] >= 20) & (pred[:, 0] < width - 20) & (pred[:, 1] >= 20) & (pred[:, 1] < height - 20)
-            g = np.nonzero(vis)[0]
-            if len(g):
-                ok, pxo = direct(kfs[0], f, T, A["px"][sel][g], z[g], A["level"][sel][g], pred[g])
-                g = g[ok]; pxo = pxo[ok]
-            else:
-                pxo = np.zeros((0, 2))
-            ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(pxo)
-    elif others and len(sel):
-        res = match_sets([A["desc"][sel]] + [kf_tab[f]["desc"] for _, f in others], [0] * len(others), list(range(1, len(others) + 1)))
-        for (j, f), r in zip(others, res):
-            g = np.nonzero(r["good"])[0]
-            ep.append(np.full(len(g), j, np.int32)); el.append(g.astype(np.int32)); obs.append(kf_tab[f]["px"][r["idx"][g]])
-    ep, el, obs = np.concatenate(ep), np.concatenate(el), np.concatenate(obs)
-    n_obs = np.bincount(el, minlength=len(sel))
-    keep_pt = n_obs >= 2                                   # a point seen only by the fixed anchor constrains nothing
-    remap = -np.ones(len(sel), np.int64); remap[keep_pt] = np.arange(int(keep_pt.sum()))
-    ke = keep_pt[el]
-    ep, el, obs = ep[ke], remap[el[ke]].astype(np.int32), obs[ke]
-    order = np.lexsort((ep, el))
-    T = I7.copy()
-    poses = [se3_log_g2o(T)]
-    for f in range(kfs[0] + 1, kfs[-1] + 1):
-        T = se3_mul(T_rel[f], T)
-        if f in kfs:
-            poses.append(se3_log_g2o(T))
-    fixed = np.zeros(len(kfs), np.uint8); fixed[0] = 1
-    return dict(kfs=list(kfs), poses=np.stack(poses), fixed=fixed, points=pc[keep_pt], edge_pose=ep[order], edge_point=el[order], obs=obs[order],
-                anchor_feature=sel[keep_pt])
