@@ -48,6 +48,10 @@ public:
 private:
     SparseImgAlign *_align;
     SE3 _TCR_esti;
+    // the last SearchForTriangulation of this object (frames and matched feature index pairs): what the Feature overload of FindDirectProjection speculates
+    // on when LocalMapping::CreateNewMapPoints calls it once per matched pair (src/Module/LocalMapping.cpp:398-447)
+    Frame *_tri_kf1 = nullptr, *_tri_kf2 = nullptr;
+    vector<pair<int, int>> _tri_pairs;
 };
 }
 #endif

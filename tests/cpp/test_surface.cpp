@@ -144,6 +144,33 @@ int main(int argc, char **argv)
         const int ct = matcher.SearchForTriangulation(&f[0], &f[1], E12, tri);
         fprintf(out, "stri %d %zu %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", ct, tri.size(), E12(0, 0), E12(0, 1), E12(0, 2), E12(1, 0), E12(1, 1), E12(1, 2), E12(2, 0), E12(2, 1), E12(2, 2));
         for (auto &pr : tri) fprintf(out, "stri_m %d %d\n", pr.first, pr.second);
+        // the call LocalMapping::CreateNewMapPoints makes once per matched pair (src/Module/LocalMapping.cpp:405-447): Matcher::FindDirectProjection,
+        // Feature overload, with the triangulated depth in fea1->_depth and fea2's pixel as prediction -- answered from ONE launch over the pairs of the
+        // SearchForTriangulation above, against the same call as its own n = 1 launch
+        {
+            hip::ResetFdpMemoStats();
+            const SE3 T12 = f[0]._TCW * f[1]._TCW.inverse();
+            int n_calls = 0, n_diff = 0, n_ok = 0;
+            for (int im = 0; im < ct; ++im) {
+                Feature *fea1 = f[0]._features[tri[im].first], *fea2 = f[1]._features[tri[im].second];
+                if (fea1->_mappoint || fea2->_mappoint) continue;
+                const Vector3d pt1 = cam->Pixel2Camera(fea1->_pixel), pt2 = cam->Pixel2Camera(fea2->_pixel);
+                if (pt1.dot(pt2) / (pt1.norm() * pt2.norm()) >= 0.9998) continue;
+                double depth1 = 0, depth2 = 0;
+                if (!cvutils::DepthFromTriangulation(T12.inverse(), pt1, pt2, depth1, depth2) || depth1 < 0 || depth2 < 0) continue;
+                fea1->_depth = depth1;
+                Vector2d p1 = fea2->_pixel, p2 = fea2->_pixel; int l1 = 0, l2 = 0;
+                const bool o1 = matcher.FindDirectProjection(&f[0], &f[1], fea1, p1, l1);
+                hip::SetFdpBypass(true);
+                const bool o2 = matcher.FindDirectProjection(&f[0], &f[1], fea1, p2, l2);
+                hip::SetFdpBypass(false);
+                ++n_calls; n_ok += o1;
+                n_diff += o1 != o2 || l1 != l2 || memcmp(p1.data(), p2.data(), 16) != 0;
+                fea1->_depth = -1;
+            }
+            const hip::FdpMemoStats st = hip::GetFdpMemoStats();
+            fprintf(out, "fdpfeat %d %d %d %llu %llu %llu %llu\n", n_calls, n_diff, n_ok, st.hits, st.single, st.launches, st.speculated);
+        }
         Frame::SetORBVocabulary(nullptr);
     }
     // Detect(frame, false) keeps the old features and fills only free cells

@@ -119,6 +119,10 @@ def test_class_surfaces_against_oracle(tmp_path, oracle, hip_lib):
     assert int(st[0]) == oct_ and int(st[1]) == oct_ and oct_ > 20
     gott = np.array(r["stri_m"], dtype=int)
     assert np.array_equal(gott[:, 0], np.nonzero(omt >= 0)[0]) and np.array_equal(gott[:, 1], omt[omt >= 0])
+    # the per-pair call of LocalMapping::CreateNewMapPoints (FindDirectProjection, Feature overload): every call answered from one launch over the pairs of
+    # the SearchForTriangulation before it, bit-identical to its own n = 1 launch
+    n_calls, n_diff, n_okf, hits, single, launches, speculated = [int(x) for x in r["fdpfeat"][0]]
+    assert n_calls > 10 and n_diff == 0 and hits == n_calls and single == 0 and launches == 1 and speculated == n_calls and n_okf > 0
     # Detect(frame, overwrite=false): old features kept, only free cells refilled
     before, kept, after = [int(x) for x in r["redetect"][0]]
     occ = np.zeros(3072, np.uint8)

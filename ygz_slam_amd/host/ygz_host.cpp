@@ -722,6 +722,7 @@ int Matcher::SearchForTriangulation(Frame *kf1, Frame *kf2, const Matrix3d &E12,
                     "search_for_triangulation")) return 0;
     matched_points.reserve(cnt);
     for (size_t i = 0; i < n1.size(); ++i) if (m[i] >= 0) matched_points.push_back(make_pair((int)i, (int)m[i]));
+    _tri_kf1 = kf1; _tri_kf2 = kf2; _tri_pairs = matched_points;      // (what FindDirectProjection's Feature overload may be asked about next)
     return cnt;
 }
 
@@ -767,7 +768,8 @@ struct FdpMemo {
     };
     Frame *curr = nullptr;
     double T_cur[7];
-    std::vector<Ref> refs;
+    std::vector<Ref> refs;                             // keyframes whose map-point candidates are in the table (MapPoint overload)
+    std::vector<Ref> feat_refs;                        // keyframes whose triangulation candidates are in the table (Feature overload)
     std::vector<Entry> entries;
     std::vector<int32_t> table;                        // open addressing over (ref, key), -1 = free
     std::vector<Frame *> asked, asked_prev;            // keyframes the calls of this / the previous current frame named
@@ -777,7 +779,7 @@ struct FdpMemo {
 
     static size_t hash(const Frame *ref, const void *key)
     { uint64_t h = (uint64_t)(uintptr_t)key * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)ref * 0xC2B2AE3D27D4EB4Full; return (size_t)(h ^ (h >> 29)); }
-    void clear() { curr = nullptr; refs.clear(); entries.clear(); table.clear(); }
+    void clear() { curr = nullptr; refs.clear(); feat_refs.clear(); entries.clear(); table.clear(); }
     void begin(Frame *c)
     {   // a new current frame (or the same one with another pose): the answers of the last one are void, the keyframes it named are the guess
         if (!asked.empty()) asked_prev.swap(asked);
@@ -787,6 +789,7 @@ struct FdpMemo {
     }
     bool valid_for(Frame *c) const { return curr == c && same7(c->_TCW, T_cur); }
     const Ref *ref_of(const Frame *f) const { for (const Ref &r : refs) if (r.f == f) return &r; return nullptr; }
+    const Ref *feat_ref_of(const Frame *f) const { for (const Ref &r : feat_refs) if (r.f == f) return &r; return nullptr; }
     void note_asked(Frame *f) { for (Frame *a : asked) if (a == f) return; asked.push_back(f); }
     void rebuild_table()
     {
@@ -817,7 +820,7 @@ void hip::fdp_memo_forget(const Frame *f)
     FdpMemo &M = fdp_memo();
     auto drop = [&](std::vector<Frame *> &v) { v.erase(std::remove(v.begin(), v.end(), f), v.end()); };
     drop(M.asked); drop(M.asked_prev);
-    if (M.curr == f || M.ref_of(f)) M.clear();
+    if (M.curr == f || M.ref_of(f) || M.feat_ref_of(f)) M.clear();
 }
 void hip::SetFdpSpeculation(bool on) { fdp_memo().enabled = on; if (!on) fdp_memo().clear(); }
 void hip::SetFdpBypass(bool on) { fdp_memo().bypass = on; }
@@ -880,6 +883,53 @@ void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch
     }
     M.rebuild_table();
 }
+// Feature overload: the pairs the same Matcher's last SearchForTriangulation(ref, curr, ...) returned, with the depth and prediction
+// LocalMapping::CreateNewMapPoints forms from them before it calls (src/Module/LocalMapping.cpp:405-447): both features without a map point, rays not
+// parallel (cos < 0.9998), DepthFromTriangulation(T12^-1, pt1, pt2) positive -> fea1->_depth = depth1, prediction = fea2->_pixel.  One launch; a call is
+// answered only if its feature, depth and prediction equal the speculated ones bit for bit.
+void fdp_speculate_feat(FdpMemo &M, Frame *ref, Frame *curr, const vector<pair<int, int>> &pairs)
+{
+    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
+    hip::Runtime &rt = hip::Runtime::Get();
+    PinholeCamera *cam = Frame::_camera;
+    FdpMemo::Ref R; R.f = ref; ref->_TCW.to7(R.T);
+    M.feat_refs.push_back(R);
+    if (!cam || pairs.empty() || ref->_pyramid.empty() || curr->_pyramid.empty()) return;
+    const int levels = curr->_option._pyramid_level;
+    const SE3 T12 = ref->_TCW * curr->_TCW.inverse(), T21 = T12.inverse();
+    std::vector<const Feature *> cf; std::vector<double> pr, dep, pc; std::vector<int32_t> lvl;
+    for (const auto &pq : pairs) {
+        if (pq.first < 0 || pq.second < 0 || pq.first >= (int)ref->_features.size() || pq.second >= (int)curr->_features.size()) continue;
+        const Feature *fea1 = ref->_features[pq.first], *fea2 = curr->_features[pq.second];
+        if (fea1->_mappoint || fea2->_mappoint || fea1->_level < 0 || fea1->_level >= levels) continue;
+        const Vector3d pt1 = cam->Pixel2Camera(fea1->_pixel), pt2 = cam->Pixel2Camera(fea2->_pixel);
+        if (pt1.dot(pt2) / (pt1.norm() * pt2.norm()) >= 0.9998) continue;
+        double d1 = 0, d2 = 0;
+        if (!cvutils::DepthFromTriangulation(T21, pt1, pt2, d1, d2) || d1 < 0 || d2 < 0) continue;
+        cf.push_back(fea1); dep.push_back(d1); lvl.push_back(fea1->_level);
+        pr.push_back(fea1->_pixel[0]); pr.push_back(fea1->_pixel[1]); pc.push_back(fea2->_pixel[0]); pc.push_back(fea2->_pixel[1]);
+    }
+    const int n = (int)cf.size();
+    if (n == 0) return;
+    ygz_align_pair pair;
+    pair.ref_slot = rt.Resident(ref); pair.cur_slot = rt.Resident(curr);
+    if (ref->_hip_slot != pair.ref_slot || pair.ref_slot < 0 || pair.cur_slot < 0) return;
+    memcpy(pair.T_ref, R.T, 56); memcpy(pair.T_cur, M.T_cur, 56);
+    std::vector<double> out = pc; std::vector<int32_t> sl(n); std::vector<uint8_t> ok(n);
+    if (ygz_hip_find_direct_projection(rt.ctx(), &pair, pr.data(), dep.data(), lvl.data(), out.data(), sl.data(), ok.data(), n) != YGZ_OK) return;
+    M.st.launches++; M.st.speculated += n;
+    for (int i = 0; i < n; ++i) {
+        FdpMemo::Entry e;
+        e.ref = ref; e.key = cf[i];
+        e.a[0] = dep[i]; e.a[1] = e.a[2] = 0;
+        e.px_ref[0] = pr[2 * i]; e.px_ref[1] = pr[2 * i + 1]; e.level = lvl[i];
+        e.px_in[0] = pc[2 * i]; e.px_in[1] = pc[2 * i + 1];
+        e.px_out[0] = out[2 * i]; e.px_out[1] = out[2 * i + 1]; e.sl = sl[i]; e.ok = ok[i];
+        M.entries.push_back(e);
+    }
+    M.rebuild_table();
+}
 }  // namespace
 
 int Matcher::FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Feature *> &feas, vector<Vector2d> &px_curr,
@@ -911,9 +961,25 @@ int Matcher::FindDirectProjectionBatch(Frame *ref, Frame *curr, const vector<Fea
 }
 
 bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, Feature *fea_ref, Vector2d &px_curr, int &search_level)
-{
+{   // Matcher.cpp:385-417.  Called once per matched pair by LocalMapping::CreateNewMapPoints (:447): answered from one launch over the pairs of this
+    // object's last SearchForTriangulation(ref, curr, ...) when every input equals the speculated one bit for bit (FdpMemo above), else n = 1
     if (fea_ref->_depth < 0) { LOG(WARNING) << "invalid depth: " << fea_ref->_depth << endl; return false; }
     assert(fea_ref->_frame == ref);
+    FdpMemo &M = fdp_memo();
+    if (M.enabled && !M.bypass && ref == _tri_kf1 && curr == _tri_kf2) {
+        if (!M.valid_for(curr)) M.begin(curr);
+        const FdpMemo::Ref *R = M.feat_ref_of(ref);
+        if (R && !same7(ref->_TCW, R->T)) { Frame *c = curr; M.clear(); M.curr = c; c->_TCW.to7(M.T_cur); R = nullptr; }
+        if (!R) fdp_speculate_feat(M, ref, curr, _tri_pairs);
+        const FdpMemo::Entry *e = M.find(ref, fea_ref);
+        if (e && e->a[0] == fea_ref->_depth && e->px_ref[0] == fea_ref->_pixel[0] && e->px_ref[1] == fea_ref->_pixel[1] && e->level == fea_ref->_level
+              && e->px_in[0] == px_curr[0] && e->px_in[1] == px_curr[1]) {
+            M.st.hits++;
+            px_curr = Vector2d(e->px_out[0], e->px_out[1]); search_level = e->sl;
+            return e->ok != 0;
+        }
+        M.st.single++;
+    }
     vector<Vector2d> px(1, px_curr); vector<int> sl; vector<bool> ok;
     FindDirectProjectionBatch(ref, curr, vector<Feature *>(1, fea_ref), px, sl, ok);
     px_curr = px[0]; search_level = sl[0];
