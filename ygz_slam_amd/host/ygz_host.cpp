@@ -989,6 +989,10 @@ bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, Feature *fea_ref, Ve
 bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector2d &px_curr, int &search_level)
 {   // Matcher.cpp:356-383.  The reference does not test the sign of the depth in this overload; neither does the kernel (k_lmap_match)
     Feature *fea = mp->_obs[ref->_keyframe_id];
+    if (!fea) {                                               // (the reference dereferences the null operator[] just inserted, Matcher.cpp:361: defined here as "no projection")
+        LOG(WARNING) << "Matcher::FindDirectProjection: map point " << mp->_id << " has no observation in keyframe " << ref->_keyframe_id << endl;
+        return false;
+    }
     FdpMemo &M = fdp_memo();
     if (M.enabled && !M.bypass) {
         if (!M.valid_for(curr)) M.begin(curr);
