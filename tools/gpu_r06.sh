@@ -28,6 +28,10 @@ k)  # kernel time inside the surface loop (rocprofv3 kernel trace of bench.py --
     bash tools/stats_cmd.sh r06_surface --mode surface --no-cpu-baseline
     cp gpurun_out/r06_surface_kernel_stats.md $OUT/; head -24 $OUT/r06_surface_kernel_stats.md
     ;;
+u)  # ygz_hip_ba_upload keeps the slot's allocation and sends five packed regions: BA / LM / offline tests, then the host phases of LocalBAG2O
+    timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface.py tests/test_gpu_offline.py tests/test_gpu_switches.py -x -q -k "ba or BA or lm or surface or unchanged or offline or window or ceres" > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
+    YGZ_HOST_TRACE=1 timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; grep -i "trace\|upload\|graph" $OUT/surface.err | tail -12; surf $OUT/surface.json
+    ;;
 h)  # the whole GPU suite + the default bench line
     timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
     timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python - $OUT/bench_default.json <<'PY'

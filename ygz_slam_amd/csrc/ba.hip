@@ -165,8 +165,13 @@ static int ba_carve(ygz_hip_ctx *ctx, ygz_hip_ctx::BaWindow *w, size_t K, size_t
     const size_t ni = Rz * 64 + Q + 1 + Ez + 2 * K + 1;
     const size_t ns = P * Kfz + 1 + Rz * 64;
     const size_t bytes = nd * 8 + ni * 4 + ((ns * 2 + 3) & ~(size_t)3) + K + P + Rz * 64 + 64;
-    hipError_t he = hipMalloc(&w->blob, bytes);
-    if (he != hipSuccess) { ctx->last_hip_error = (int)he; return YGZ_E_HIP; }
+    if (!w->blob || w->blob_bytes < bytes) {             // w->blob: the allocation of the window this one replaces (ygz_hip_ba_upload)
+        if (w->blob) { (void)hipFree(w->blob); w->blob = nullptr; w->blob_bytes = 0; }
+        const size_t cap = bytes + bytes / 4;                // head room: the next window of this slot is about this size
+        hipError_t he = hipMalloc(&w->blob, cap);
+        if (he != hipSuccess) { ctx->last_hip_error = (int)he; return YGZ_E_HIP; }
+        w->blob_bytes = cap;
+    }
     double *d = (double *)w->blob;
     w->poses = d; d += K * 6; w->points = d; d += P * 3; w->posed = d; d += K * BA_POSED;
     w->obs_c = d; d += Rz * 128; w->huber_c = d; d += Rz * 64;
@@ -228,31 +233,61 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
     for (int e = 0; e < E; ++e)
         if (pb->edge_pose[e] < 0 || pb->edge_pose[e] >= K || pb->edge_point[e] < 0 || pb->edge_point[e] >= P) return YGZ_E_INVALID;
     if ((int)ctx->ba.size() <= window) ctx->ba.resize(window + 1, nullptr);
-    if (ctx->ba[window]) { YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ba_free(ctx->ba[window]); ctx->ba[window] = nullptr; }
+    // the allocation of the window this one replaces is kept when it is large enough (LocalBAG2O uploads a window of about the same size for
+    // every keyframe: a hipFree + hipMalloc pair per call otherwise)
+    void *old_blob = nullptr; size_t old_bytes = 0;
+    if (ctx->ba[window]) {
+        YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        auto *o = ctx->ba[window];
+        old_blob = o->blob; old_bytes = o->blob_bytes; o->blob = nullptr;
+        ba_free(o); ctx->ba[window] = nullptr;
+    }
     auto *w = new ygz_hip_ctx::BaWindow();
+    w->blob = old_blob; w->blob_bytes = old_bytes;
     w->K = K; w->P = P; w->E = E; w->formulation = pb->formulation;
     w->fx = pb->fx; w->fy = pb->fy; w->cx = pb->cx; w->cy = pb->cy; w->huber = pb->huber_delta;
     // ---- rows: the c-th edge (ascending edge order) of every point of a 64-point chunk
     const int Q = (P + 63) / 64;
-    std::vector<int32_t> cnt(P, 0), slot_off(Q + 1, 0);
+    std::vector<int32_t> cnt(P, 0), slot_off_v(Q + 1, 0);
     for (int e = 0; e < E; ++e) cnt[pb->edge_point[e]]++;
     for (int q = 0; q < Q; ++q) {
         int mx = 0;
         for (int l = 64 * q; l < std::min(P, 64 * q + 64); ++l) mx = std::max(mx, cnt[l]);
-        if (mx > 32767) { delete w; return YGZ_E_CAPACITY; }
-        slot_off[q + 1] = slot_off[q] + mx;
+        if (mx > 32767) { ba_free(w); return YGZ_E_CAPACITY; }
+        slot_off_v[q + 1] = slot_off_v[q] + mx;
     }
-    const int R = slot_off[Q];
+    const int R = slot_off_v[Q];
     const size_t Rz = (size_t)(R > 0 ? R : 1), Ez = (size_t)(E > 0 ? E : 1);
-    std::vector<int32_t> free_idx(K, -1), free_pose(K, -1);
     int Kf = 0;
-    for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) { free_idx[k] = Kf; free_pose[Kf] = k; ++Kf; }
+    for (int k = 0; k < K; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kf;
     const size_t Kfz = (size_t)(Kf > 0 ? Kf : 1);
     w->Kf = Kf; w->R = R; w->Q = Q;
-    std::vector<int32_t> pose_c(Rz * 64, -1), edge_rl(Ez, 0);
-    std::vector<double> obs_c(Rz * 128, 0.0), huber_c(Rz * 64, 0.0);
-    std::vector<uint8_t> enable_c(Rz * 64, 0);
-    std::vector<int16_t> ppc((size_t)P * Kfz, -1), dupn(Rz * 64, -1), last_c((size_t)P * Kfz, -1);
+    { const int rcv = ba_carve(ctx, w, (size_t)K, (size_t)P, Rz, Ez, (size_t)Q, Kfz); if (rcv != YGZ_OK) { ba_free(w); return rcv; } }
+    // ---- the host image of the five uploaded regions, assembled in ONE page-locked block in the order the blob keeps them (ba_carve), so that
+    // each region goes up as one copy: [poses | points], [obs_c | huber_c], [pose_c | slot_off | edge_rl | free_idx | free_pose],
+    // [ppc | dupn], [fixed | point_fixed | enable_c]
+    const size_t b0 = ((size_t)K * 6 + (size_t)P * 3) * 8, b1 = Rz * 192 * 8, b2 = (Rz * 64 + (size_t)Q + 1 + Ez + 2 * (size_t)K) * 4,
+                 b3 = ((size_t)P * Kfz + 1 + Rz * 64) * 2, b4 = (size_t)K + (size_t)P + Rz * 64;
+    const size_t o1 = (b0 + 63) & ~(size_t)63, o2 = o1 + ((b1 + 63) & ~(size_t)63), o3 = o2 + ((b2 + 63) & ~(size_t)63), o4 = o3 + ((b3 + 63) & ~(size_t)63);
+    uint8_t *hs = (uint8_t *)ygz_stage(ctx, o4 + b4);
+    if (!hs) { ba_free(w); return YGZ_E_HIP; }
+    double *h_poses = (double *)hs, *h_points = h_poses + (size_t)K * 6;
+    double *obs_c = (double *)(hs + o1), *huber_c = obs_c + Rz * 128;
+    int32_t *pose_c = (int32_t *)(hs + o2), *slot_off = pose_c + Rz * 64, *edge_rl = slot_off + Q + 1, *free_idx = edge_rl + Ez, *free_pose = free_idx + K;
+    int16_t *ppc = (int16_t *)(hs + o3), *dupn = ppc + (size_t)P * Kfz + 1;
+    uint8_t *fixed = hs + o4, *pfixed = fixed + K, *enable_c = pfixed + P;
+    memcpy(h_poses, pb->poses, (size_t)K * 48); memcpy(h_points, pb->points, (size_t)P * 24);
+    memset(obs_c, 0, b1);
+    memset(pose_c, 0xFF, Rz * 64 * 4);                                        // -1: no such edge
+    memcpy(slot_off, slot_off_v.data(), ((size_t)Q + 1) * 4);
+    memset(edge_rl, 0, Ez * 4);
+    memset(free_idx, 0xFF, (size_t)K * 8);                                    // free_idx and free_pose: -1
+    memset(ppc, 0xFF, b3);                                                    // ppc, the pad element and dupn: -1
+    memset(fixed, 0, b4);
+    if (pb->pose_fixed) memcpy(fixed, pb->pose_fixed, K);
+    if (pb->point_fixed) memcpy(pfixed, pb->point_fixed, P);
+    { int a = 0; for (int k = 0; k < K; ++k) if (!fixed[k]) { free_idx[k] = a; free_pose[a] = k; ++a; } }
+    std::vector<int16_t> last_c((size_t)P * Kfz, -1);
     std::fill(cnt.begin(), cnt.end(), 0);
     for (int e = 0; e < E; ++e) {
         const int l = pb->edge_point[e], c = cnt[l]++, row = slot_off[l >> 6] + c, lane = l & 63, ip = pb->edge_pose[e];
@@ -269,24 +304,15 @@ int ygz_hip_ba_upload(ygz_hip_ctx *ctx, int window, const ygz_ba_problem *pb)
             last_c[pa] = (int16_t)c;
         }
     }
-    w->h_edge_rl = edge_rl;
-    { const int rcv = ba_carve(ctx, w, (size_t)K, (size_t)P, Rz, Ez, (size_t)Q, Kfz); if (rcv != YGZ_OK) { delete w; return rcv; } }
+    w->h_edge_rl.assign(edge_rl, edge_rl + Ez);
     ctx->ba[window] = w;
     w->table_dirty = true; ctx->ba_table_dirty = true;
-    std::vector<uint8_t> fixed(K, 0), pfixed(P, 0);
-    if (pb->pose_fixed) memcpy(fixed.data(), pb->pose_fixed, K);
-    if (pb->point_fixed) memcpy(pfixed.data(), pb->point_fixed, P);
-#define UP_(dst, src, n) YGZ_HIPCHK(ctx, hipMemcpyAsync((void *)(dst), (src), (n), hipMemcpyHostToDevice, ctx->stream))
-    UP_(w->poses, pb->poses, (size_t)K * 48); UP_(w->points, pb->points, (size_t)P * 24);
-    UP_(w->obs_c, obs_c.data(), Rz * 128 * 8); UP_(w->huber_c, huber_c.data(), Rz * 64 * 8);
-    UP_(w->pose_c, pose_c.data(), Rz * 64 * 4); UP_(w->slot_off, slot_off.data(), ((size_t)Q + 1) * 4); UP_(w->edge_rl, edge_rl.data(), Ez * 4);
-    UP_(w->free_idx, free_idx.data(), (size_t)K * 4); UP_(w->free_pose, free_pose.data(), (size_t)K * 4);
-    UP_(w->ppc, ppc.data(), ppc.size() * 2); UP_(w->dupn, dupn.data(), dupn.size() * 2);
-    UP_(w->fixed, fixed.data(), (size_t)K); UP_(w->point_fixed, pfixed.data(), (size_t)P); UP_(w->enable_c, enable_c.data(), Rz * 64);
+#define UP_(dst, src, n) do { const int rk_ = ygz_kcopy(ctx, (void *)(dst), (src), (n), (int)hipMemcpyHostToDevice); if (rk_ != YGZ_OK) return rk_; } while (0)
+    UP_(w->poses, hs, b0); UP_(w->obs_c, hs + o1, b1); UP_(w->pose_c, hs + o2, b2); UP_(w->ppc, hs + o3, b3); UP_(w->fixed, hs + o4, b4);
 #undef UP_
     // blocks of constant poses / padding lanes are never written by the kernels: zero once
     YGZ_HIPCHK(ctx, hipMemsetAsync(w->Hpp, 0, ygz_ba_zero_bytes(w), ctx->stream));
-    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // host vectors go out of scope
+    // no synchronisation: the staging block stays valid until the arena wraps (ygz_stage synchronises the stream before it recycles)
     return YGZ_OK;
 }
 

@@ -19,6 +19,7 @@ struct ygz_hip_ctx::BaWindow {
     int K = 0, P = 0, E = 0, formulation = 0, Kf = 0, R = 0, Q = 0;       // R rows, Q = ceil(P / 64) chunks
     double fx = 0, fy = 0, cx = 0, cy = 0, huber = 0;
     void *blob = nullptr;            // one allocation
+    size_t blob_bytes = 0;           // its size (an upload into the same slot reuses it when it is large enough)
     double *poses, *points, *posed;
     double *obs_c, *huber_c;         // [R][2][64], [R][64]
     int32_t *pose_c;                 // [R][64] pose of the c-th edge of the lane's point, -1: no such edge
