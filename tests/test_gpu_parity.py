@@ -1181,6 +1181,37 @@ def test_ba_optimize_resident_many_free_poses(hip_lib, oracle):
     ctx.close()
 
 
+def test_ba_optimize_chi2_one_transfer(hip_lib):
+    """ygz_hip_ba_optimize_chi2 (what ba::LocalBAG2O calls, BA.cpp:497-515): upload, resident LM, one more linearisation and the unpacking of its
+    per-edge chi2 are queued back to back and statistics + state + chi2 return in one transfer.  Must equal the step-by-step calls bit for bit:
+    ygz_hip_ba_optimize for the state and the statistics, ygz_hip_ba_linearize at that state for the chi2 -- also for a window that is uploaded
+    into the slot of a LARGER one (the slot's allocation is kept) and for repeated (point, pose) edges (host loop)."""
+    ctx = make_ctx(hip_lib, max_frames=1)
+    for (K, P, seed) in ((8, 1500, 31), (5, 300, 32), (8, 1500, 31)):
+        w = synth.ba_window(K, P, seed=seed)
+        a = (w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"])
+        po, pt, st = ctx.ba_optimize(*a, iterations=12)
+        assert ctx.ba_last_path()[0]
+        po2, pt2, st2, chi = ctx.ba_optimize_chi2(*a, iterations=12)
+        assert ctx.ba_last_path()[0]
+        assert (st.iterations, st.lm_trials, st.chi2_initial, st.chi2_final) == (st2.iterations, st2.lm_trials, st2.chi2_initial, st2.chi2_final)
+        assert po.tobytes() == po2.tobytes() and pt.tobytes() == pt2.tobytes()
+        lin = ctx.ba_linearize(po, w["fixed"], pt, w["edge_pose"], w["edge_point"], w["obs"])
+        assert lin["chi2_edge"].tobytes() == chi.tobytes()
+        assert st2.chi2_final < 0.1 * st2.chi2_initial and chi.shape == (len(w["edge_pose"]),)
+    # repeated (point, pose) pair: the host loop, through the same entry point
+    w = synth.ba_window(4, 80, seed=33)
+    ep = np.concatenate([w["edge_pose"], w["edge_pose"][:3]]); el = np.concatenate([w["edge_point"], w["edge_point"][:3]])
+    ob = np.concatenate([w["obs"], w["obs"][:3] + 0.25])
+    po, pt, st = ctx.ba_optimize(w["poses"], w["fixed"], w["points"], ep, el, ob, iterations=6)
+    assert not ctx.ba_last_path()[0]
+    po2, pt2, st2, chi = ctx.ba_optimize_chi2(w["poses"], w["fixed"], w["points"], ep, el, ob, iterations=6)
+    assert not ctx.ba_last_path()[0] and po.tobytes() == po2.tobytes() and pt.tobytes() == pt2.tobytes()
+    lin = ctx.ba_linearize(po, w["fixed"], pt, ep, el, ob)
+    assert lin["chi2_edge"].tobytes() == chi.tobytes()
+    ctx.close()
+
+
 def test_ba_optimize_resident_team_size_invariance(hip_lib):
     """k_ba_lm_team gives a window to 1, 2, 4 or 8 cooperating workgroups depending on how many windows the launch holds; the points
     are reduced in 8 fixed parts whatever the team size, so the optimum, the trial sequence and the refined state must be BIT-identical

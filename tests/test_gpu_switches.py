@@ -40,6 +40,17 @@ ctx.ba_upload(0, w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_po
 st = ctx.ba_optimize_resident(0, 1, iterations=10)[0]
 pg, tg = ctx.ba_get_state(0, len(w["poses"]), len(w["points"]))
 out["lm"] = (st.iterations, st.lm_trials, st.chi2_final, pg.tobytes(), tg.tobytes())
+# the single-frame calls (what the class surfaces issue once per frame)
+kp0 = ctx.get_keypoints(0)
+d0 = seq.depth(0)[kp0["px"][:, 1].astype(int), kp0["px"][:, 0].astype(int)].astype(np.float64)
+nm, Tc, its = ctx.sparse_align(0, I7, 1, I7, kp0["px"], d0, np.ones(len(d0), np.uint8))
+po, pt, st2, chi = ctx.ba_optimize_chi2(w["poses"], w["fixed"], w["points"], w["edge_pose"], w["edge_point"], w["obs"], iterations=10)
+rng = np.random.default_rng(2)
+pw = rng.uniform([-1, -1, 3], [1, 1, 6], (300, 3)); cam = np.array([500.0, 500.0, 320.0, 240.0])
+px = np.stack([pw[:, 0] / pw[:, 2], pw[:, 1] / pw[:, 2]], 1) * cam[:2] + cam[2:] + rng.normal(0, 0.3, (300, 2))
+pp, bad, dep, inl, rounds = ctx.optimize_pose_only([0, 300], px, pw, np.array([[0.01, -0.02, 0.03, 0.002, 0.001, -0.003]]))
+out["single"] = (nm, Tc.tobytes(), tuple(its), kp0["px"].tobytes(), kp0["desc"].tobytes(), po.tobytes(), pt.tobytes(), chi.tobytes(), st2.iterations,
+                 pp.tobytes(), bad.tobytes(), dep.tobytes(), int(inl[0]), int(rounds[0]))
 ctx.close()
 pickle.dump(out, open(sys.argv[1], "wb"))
 ''' % ROOT
@@ -57,7 +68,7 @@ def _run(tmp_path, name, env):
 SWITCHES = {"valu_matcher": ({"YGZ_HAMMING_VALU": "1"}, ("match",)),
             "lm_single_workgroup": ({"YGZ_BA_LM_TEAM": "1"}, ("lm",)),
             "lm_full_team_barrier": ({"YGZ_LM_XCD_BARRIER": "0"}, ("lm",)),
-            "copy_engine_transfers": ({"YGZ_ZERO_COPY": "0"}, ("match", "sa", "lm")),      # small transfers through hipMemcpyAsync instead of kernels that read / write the page-locked staging memory
+            "copy_engine_transfers": ({"YGZ_ZERO_COPY": "0"}, ("match", "sa", "lm", "single")),      # small transfers through hipMemcpyAsync instead of kernels that read / write the page-locked staging memory
             "sparse_align_256_lanes": ({"YGZ_SA_THREADS": "256"}, ("sa~",))}     # the shape a launch of many pairs takes (default here: 512 lanes for two pairs); "~": the
                                                                                  # FP64 sums of H and J^T r run over 4 instead of 8 wavefronts -> same Gauss-Newton trajectory, pose to 1e-12
 

@@ -32,6 +32,11 @@ u)  # ygz_hip_ba_upload keeps the slot's allocation and sends five packed region
     timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface.py tests/test_gpu_offline.py tests/test_gpu_switches.py -x -q -k "ba or BA or lm or surface or unchanged or offline or window or ceres" > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
     YGZ_HOST_TRACE=1 timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err; grep -i "trace\|upload\|graph" $OUT/surface.err | tail -12; surf $OUT/surface.json
     ;;
+f)  # LocalBAG2O's results in one transfer, the sparse alignment's result written to page-locked memory by the kernel: suite + host phases
+    timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
+    YGZ_HOST_TRACE=1 timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err
+    grep "ms per call" $OUT/surface.err; surf $OUT/surface.json | cut -c1-420
+    ;;
 h)  # the whole GPU suite + the default bench line
     timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
     timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python - $OUT/bench_default.json <<'PY'

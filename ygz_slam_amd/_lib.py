@@ -971,6 +971,17 @@ class HipContext:
                   "ba_optimize")
         return po, pt, st
 
+    def ba_optimize_chi2(self, poses, fixed, points, edge_pose, edge_point, obs, iterations=20, huber_delta=5.991, cam=None):
+        """ba_optimize + the per-edge chi2 at the optimised state (what ba::LocalBAG2O marks its outliers with): one upload, one transfer back"""
+        pb = self._ba_problem(poses, fixed, points, edge_pose, edge_point, obs, huber_delta, 0, cam)
+        po = np.ascontiguousarray(poses, np.float64).copy()
+        pt = np.ascontiguousarray(points, np.float64).copy()
+        chi = np.zeros(max(len(np.atleast_1d(edge_pose)), 1), np.float64)
+        st = BaStats()
+        self._chk(self.lib.ygz_hip_ba_optimize_chi2(self._ctx, C.byref(pb), _p(po, C.c_double), _p(pt, C.c_double), iterations, C.byref(st),
+                                                    _p(chi, C.c_double)), "ba_optimize_chi2")
+        return po, pt, st, chi[:len(np.atleast_1d(edge_pose))]
+
     def ba_optimize_resident(self, window_begin, n_windows, iterations=20, want_stats=True):
         st = (BaStats * n_windows)()
         self._chk(self.lib.ygz_hip_ba_optimize_resident(self._ctx, window_begin, n_windows, iterations, st if want_stats else None),

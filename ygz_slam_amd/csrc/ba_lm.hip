@@ -251,9 +251,39 @@ extern "C" int ygz_hip_ba_optimize(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, d
 extern "C" int ygz_hip_ba_optimize_chi2(ygz_hip_ctx *ctx, const ygz_ba_problem *pb, double *poses_io, double *points_io, int max_iterations,
                                         ygz_ba_stats *stats, double *chi2_edge)
 {
-    int rc = ygz_hip_ba_optimize(ctx, pb, poses_io, points_io, max_iterations, stats);
+    const int W = 1022;                                       // the window ygz_hip_ba_optimize uploads
+    int rc = YGZ_OK;
+    if (ctx && pb && poses_io && points_io && chi2_edge && max_iterations >= 0 && pb->formulation == 0) {
+        // the resident loop (the window of LocalBAG2O): upload, LM kernel, one more linearisation and the unpacking of its chi2 are queued without a
+        // wait in between; statistics, state and chi2 come back in one transfer (ygz_ba_fetch_result)
+        YgzDeviceGuard dg_(ctx);
+        int Kfree = 0;
+        for (int k = 0; k < pb->n_poses; ++k) if (!(pb->pose_fixed && pb->pose_fixed[k])) ++Kfree;
+        const char *force = getenv("YGZ_BA_HOST_LOOP");
+        if (Kfree <= 20 && !(force && force[0] == '1')) {
+            ygz_ba_problem prob = *pb;
+            prob.poses = poses_io; prob.points = points_io;
+            g_abi_trace.start();
+            if ((rc = ygz_hip_ba_upload(ctx, W, &prob)) != YGZ_OK) return rc;
+            g_abi_trace.lap(0);
+            if (!ygz_ba_window_has_dup(ctx, W)) {              // (repeated (point, pose) pairs: the host loop below, which uploads again)
+                ctx->ba_last_path = YGZ_BA_PATH_RESIDENT;
+                if ((rc = ygz_hip_ba_optimize_resident(ctx, W, 1, max_iterations, nullptr)) != YGZ_OK) return rc;
+                const void *d_stats = ctx->scratch[SCR_BA_0];  // where the launch keeps its statistics record
+                g_abi_trace.lap(1);
+                if ((rc = ygz_hip_ba_linearize_resident(ctx, W, 1)) != YGZ_OK) return rc;
+                g_abi_trace.lap(3);
+                ygz_ba_stats st;
+                if ((rc = ygz_ba_fetch_result(ctx, W, d_stats, &st, poses_io, points_io, chi2_edge)) != YGZ_OK) return rc;
+                g_abi_trace.lap(4); ++g_abi_trace.calls;
+                if (st.iterations < 0) { ctx->last_hip_error = (int)hipErrorLaunchTimeOut; return YGZ_E_HIP; }     // a team member never reached a barrier
+                if (stats) *stats = st;
+                return YGZ_OK;
+            }
+        }
+    }
+    rc = ygz_hip_ba_optimize(ctx, pb, poses_io, points_io, max_iterations, stats);
     if (rc != YGZ_OK || !chi2_edge) return rc;
-    const int W = 1022;                                       // the window ygz_hip_ba_optimize uploaded
     g_abi_trace.start();
     if (ygz_hip_ba_last_path(ctx) != YGZ_BA_PATH_RESIDENT && (rc = ygz_hip_ba_set_state(ctx, W, poses_io, points_io)) != YGZ_OK) return rc;   // (the host loop leaves its last TRIAL state there)
     if ((rc = ygz_hip_ba_linearize_resident(ctx, W, 1)) != YGZ_OK) return rc;

@@ -134,7 +134,9 @@ static int pack_launch(ygz_hip_ctx *ctx, const YgzPackSegs &S)
 // kernel that waits for it starts -- five to six times per frame.  The page-locked staging memory is mapped into the device's address space
 // (hipHostMalloc), so the scatter / gather kernel reads (writes) it directly over PCIe: one kernel instead of copy + hand-over + kernel.
 // YGZ_ZERO_COPY=0: the copy-engine form.
-static bool zero_copy() { static const bool z = [] { const char *e = getenv("YGZ_ZERO_COPY"); return !(e && e[0] == '0'); }(); return z; }
+bool ygz_zero_copy();
+static bool zero_copy() { return ygz_zero_copy(); }
+bool ygz_zero_copy() { static const bool z = [] { const char *e = getenv("YGZ_ZERO_COPY"); return !(e && e[0] == '0'); }(); return z; }
 int ygz_pack_upload(ygz_hip_ctx *ctx, YgzPack *pk)
 {
     if (pk->used == 0) return YGZ_OK;

@@ -44,6 +44,7 @@ struct SaArgs {
     int prio;                                     // != 0: raise the wavefronts' issue priority (the kernel is latency-bound: one wavefront per SIMD)
     double *lin;                                  // optional [pairs][32]: what computeResiduals(model, linearize = true) leaves -- the float chi2 sum, n_meas, H (21), Jres (6) -- of the last pass
     int rel;                                      // != 0: out[0..6] is T_cur_from_ref itself, in and out (the solver's model, SparseImageAlign.cpp:37,48 left to the caller)
+    double *out_host;                             // optional [pairs][16]: page-locked copy of `out`, written by the kernel itself (the single-frame call: no copy back)
 };
 
 #define wave_sum_d ygz_wave_sum_d
@@ -661,6 +662,7 @@ __device__ __forceinline__ void sa2_problem(const SaArgs &A, const int pair)
         for (int k = 0; k < 4; ++k) out[k] = o.q[k];
         for (int k = 0; k < 3; ++k) out[4 + k] = o.t[k];
         out[7] = (double)n_meas_last;
+        if (A.out_host) for (int k = 0; k < 16; ++k) A.out_host[16 * (size_t)pair + k] = out[k];
 #ifdef YGZ_SA_TIMERS
         if (A.dbg) for (int k = 0; k < 16; ++k) A.dbg[16 * (size_t)pair + k] = (double)tph[k];
 #endif
@@ -693,6 +695,7 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     A.work = ctx->sa_work; A.work_stride = ctx->sa_work_stride; A.out = ctx->sa_out;
     A.dbg = nullptr; A.prio = ctx->wave_prio_mask & 1; A.n_pairs = n_pairs;
     A.lin = ctx->sa_lin; A.rel = ctx->sa_rel ? 1 : 0;
+    A.out_host = ctx->sa_out_host;
 #ifdef YGZ_SA_TIMERS
     { void *dd = nullptr; if (ygz_scratch(ctx, SCR_GEN_0 + 1, (size_t)n_pairs * 16 * 8, &dd) == YGZ_OK) A.dbg = (double *)dd; }
 #endif
@@ -710,8 +713,12 @@ int ygz_launch_sparse_align(ygz_hip_ctx *ctx, int n_pairs, int max_level, int mi
     // (a single-frame call knows its feature count: scratch for exactly those, the rest of the LDS for their patches)
     const int lcap_want = ctx->sa_n_hint > 0 ? std::min(1600, std::max(64, ctx->sa_n_hint)) : (threads == 512 ? 1600 : 1024);
     A.lcap = ((lcap_want < ctx->cells ? lcap_want : ctx->cells) + 63) / 64 * 64;
-    int lim = 64 * 1024;      // dynamic + static LDS must fit the device's per-block limit (static: < 3 KB, see -Rpass-analysis=kernel-resource-usage)
-    (void)hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
+    if (ctx->lds_per_block <= 0) {                                                 // dynamic + static LDS must fit the device's per-block limit (static: < 3 KB, see -Rpass-analysis=kernel-resource-usage)
+        int v = 64 * 1024;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device);
+        ctx->lds_per_block = v;
+    }
+    const int lim = ctx->lds_per_block;
     const size_t ctot_b = (size_t)(cells64 / 64 + 1) * 4;
     {
         const int room = (int)(((long)lim - 4096 - 16 - (long)ctot_b) / 92);       // 92 bytes per feature
@@ -779,11 +786,13 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     if ((rc = ygz_pack_upload(ctx, &pk)) != YGZ_OK) return rc;
     double *h_out = (double *)ygz_stage(ctx, 16 * 8);
     if (!h_out) return YGZ_E_HIP;
-    ctx->sa_n_hint = n;
+    // the kernel stores its 16 result doubles into the page-locked block itself (mapped into the device's address space): no copy back on the stream
+    const bool direct = ygz_zero_copy();
+    ctx->sa_n_hint = n; ctx->sa_out_host = direct ? h_out : nullptr;
     rc = ygz_launch_sparse_align(ctx, 1, max_level, min_level, n_iter);
-    ctx->sa_n_hint = 0;
+    ctx->sa_n_hint = 0; ctx->sa_out_host = nullptr;
     if (rc != YGZ_OK) return rc;
-    YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (!direct) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 7; ++k) T_cur[k] = h_out[k];
     if (n_meas_out) *n_meas_out = (int)(h_out[7] / 16);        // run() returns n_meas_/patch_area_ (:49)

@@ -10,7 +10,7 @@
 // the tracker's working images: every level inside a reflect-101 frame of KLT_B pixels (klt.hip; written by the pyramid kernels, image.hip)
 #define KLT_B      24          // >= window + 1, multiple of 4
 #define KLT_PW(w)  (((w) + 2 * KLT_B + 3) & ~3)      // framed row pitch, 4-byte aligned for any level width
-#define YGZ_N_SCRATCH  24
+#define YGZ_N_SCRATCH  28
 
 struct ygz_hip_ctx {
     ygz_hip_params prm;
@@ -120,6 +120,7 @@ struct ygz_hip_ctx {
     // window descriptors): a slice stays valid until the next ygz_hip_synchronize of this context, so no entry point has to wait for the
     // stream just because its host arguments are temporaries
     uint8_t *stage = nullptr; size_t stage_cap = 0, stage_used = 0;
+    int lds_per_block = 0;                                    // hipDeviceAttributeMaxSharedMemoryPerBlock, asked once
     // per-slot depth images (RGB-D style input of the offline run: Feature::_depth of the keypoints is sampled from them on the device)
     void *depth_img = nullptr; int depth_w = 0, depth_h = 0, depth_kind = 0; double depth_scale = 1.0;
     // keyframe store + relative-pose store of the offline run (window.hip)
@@ -138,6 +139,7 @@ struct ygz_hip_ctx {
     bool sa_attr_set = false;                // the dynamic-LDS opt-in of k_sparse_align was made on this context's device
     bool lm_attr_set = false;                // the dynamic-LDS opt-in of k_ba_lm_team was made on this context's device
     double *sa_lin = nullptr;             // != nullptr for the launch: [32] chi2 sum, n_meas, H (21, upper triangle), Jres (6) of the LAST linearisation (ygz_hip_sparse_align_residuals)
+    double *sa_out_host = nullptr;        // for the launch: page-locked copy of sa_out that the kernel writes itself (the single-frame call: no copy back)
     bool sa_rel = false;                  // the pose in sa_out is T_cur_from_ref itself (no product with the reference pose on the way in or out)
     int sa_n_hint = 0;                    // features of the ONE problem of a single-frame call (0: unknown, the counts are on the device): sizes the LDS tiers
     int  klt_prep_levels = 0;                // levels covered by the LK working images while klt_prep_valid
@@ -205,6 +207,7 @@ int   ygz_pack_begin(ygz_hip_ctx *ctx, YgzPack *pk, size_t capacity_bytes, int s
 void *ygz_pack_add(YgzPack *pk, const void *device_ptr, size_t bytes);        // the host slice of that device array (nullptr: full)
 int   ygz_pack_upload(ygz_hip_ctx *ctx, YgzPack *pk);                          // host slices -> their device arrays (asynchronous)
 int   ygz_pack_fetch(ygz_hip_ctx *ctx, YgzPack *pk);                           // device arrays -> host slices (asynchronous: synchronise before reading)
+bool  ygz_zero_copy();                                                         // small transfers by kernels that read / write the page-locked staging memory (default; YGZ_ZERO_COPY=0: the copy engine)
 int   ygz_kcopy(ygz_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int kind);   // device <-> page-locked host block on the stream: a copy kernel up to 1 MB (no copy engine), hipMemcpyAsync beyond; kind = hipMemcpyKind
 // the brute-force matcher over descriptor sets desc + s * set_stride (u32 units), sizes set_count[s], pairs (pair_q[p], pair_t[p]): device
 // arrays; results in ctx->m_idx / m_dist [n_pairs][cells] (hamming.hip)
@@ -275,6 +278,7 @@ struct YgzWinProject {
 };
 int ygz_launch_win_project(ygz_hip_ctx *ctx, const YgzWinProject &P);
 bool ygz_ba_window_has_dup(const ygz_hip_ctx *ctx, int window);    // an uploaded BA window repeats a (point, free pose) pair (ba.hip)
+int ygz_ba_fetch_result(ygz_hip_ctx *ctx, int window, const void *d_stats, ygz_ba_stats *stats, double *poses, double *points, double *chi2_edge);   // ba.hip: statistics + state + per-edge chi2 in one transfer
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

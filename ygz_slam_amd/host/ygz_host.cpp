@@ -334,8 +334,33 @@ void FeatureDetector::SetExistingFeatures(Frame *frame)
     }
 }
 
+// YGZ_HOST_TRACE=1: host clock per phase of a class-surface call (what the caller's thread does around the launches), printed when the process ends
+namespace {
+struct PhaseTrace {
+    const char *name; const char *label[4];
+    bool on = [] { const char *e = getenv("YGZ_HOST_TRACE"); return e && atoi(e) != 0; }();
+    double ms[4] = { 0, 0, 0, 0 }; long calls = 0;
+    std::chrono::steady_clock::time_point t;
+    PhaseTrace(const char *n, std::initializer_list<const char *> l) : name(n) { int i = 0; for (const char *x : l) if (i < 4) label[i++] = x; for (; i < 4; ++i) label[i] = nullptr; }
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (on) { const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; } }
+    void done() { ++calls; }
+    ~PhaseTrace()
+    {
+        if (!on || !calls) return;
+        fprintf(stderr, "%s x %ld:", name, calls);
+        for (int k = 0; k < 4 && label[k]; ++k) fprintf(stderr, " %s %.3f ", label[k], ms[k] / calls);
+        fprintf(stderr, "ms per call\n");
+    }
+};
+PhaseTrace g_detect_trace{ "FeatureDetector::Detect", { "grid", "ygz_hip_detect", "ygz_hip_get_keypoints", "new Feature" } };
+PhaseTrace g_align_trace{ "SparseImgAlign::run", { "gather", "ygz_hip_sparse_align", "write-back", nullptr } };
+PhaseTrace g_pmp_trace{ "Matcher::ProjectMapPoints", { "gather", "ygz_hip_track_local_map", "new Feature", nullptr } };
+PhaseTrace g_po_trace{ "ba::OptimizeCurrentPoseOnly", { "gather", "ygz_hip_optimize_pose_only", "write-back", nullptr } };
+}
 void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
 {
+    g_detect_trace.start();
     hip::Runtime &rt = hip::Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
     const int cells = rt.cells();
@@ -350,7 +375,9 @@ void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
         occ.resize(cells);
         for (int k = 0; k < cells; ++k) occ[k] = _old_features[k] ? 1 : 0;
     }
+    g_detect_trace.lap(0);
     if (!hip::check(ygz_hip_detect(c, slot, 1, occ.empty() ? nullptr : occ.data()), "detect")) return;
+    g_detect_trace.lap(1);
     // (result buffers of a whole grid, kept between calls: 180 KB that would otherwise be allocated and zeroed per frame)
     static thread_local std::vector<double> px; static thread_local std::vector<int32_t> lvl; static thread_local std::vector<float> sc, ang;
     static thread_local std::vector<uint8_t> desc;
@@ -358,6 +385,7 @@ void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
     ygz_kpt_soa soa = { px.data(), lvl.data(), sc.data(), ang.data(), desc.data() };
     int n = 0;
     if (!hip::check(ygz_hip_get_keypoints(c, slot, &soa, cells, &n), "get_keypoints")) return;
+    g_detect_trace.lap(2);
     LOG(INFO) << "old features: " << frame->_features.size() << endl;
     for (int i = 0; i < n; ++i) {
         Feature *fea = new Feature(Vector2d(px[2 * i], px[2 * i + 1]), lvl[i], sc[i]);
@@ -367,6 +395,7 @@ void FeatureDetector::Detect(Frame *frame, bool overwrite_existing_features)
         frame->_features.push_back(fea);
     }
     LOG(INFO) << "add total " << n << " new features." << endl;
+    g_detect_trace.lap(3); g_detect_trace.done();
 }
 
 static void describe_features(Frame *frame, const vector<Feature *> &feas, bool given_angle)
@@ -565,6 +594,7 @@ size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
         if ((int)ref_frame->_features.size() > hip::Runtime::Get().cells()) { LOG(ERROR) << "SparseImgAlign::run: more features than grid cells" << endl; return 0; }
         return run_lm(ref_frame, cur_frame);
     }
+    g_align_trace.start();
     hip::Runtime &rt = hip::Runtime::Get();
     ygz_hip_ctx *c = rt.ctx();
     const int n = (int)ref_frame->_features.size();
@@ -578,8 +608,11 @@ size_t SparseImgAlign::run(Frame *ref_frame, Frame *cur_frame)
     ref_frame->_TCW.to7(Tr); cur_frame->_TCW.to7(Tc);
     int n_meas = 0;
     const int rs = rt.Resident(ref_frame), cs = rt.Resident(cur_frame);
+    g_align_trace.lap(0);
     if (!hip::check(ygz_hip_sparse_align(c, rs, Tr, cs, Tc, px.data(), depth.data(), has.data(), n, max_level_, min_level_, n_iter_, &n_meas, iters_), "sparse_align")) return 0;
+    g_align_trace.lap(1);
     cur_frame->_TCW = SE3::from7(Tc);
+    g_align_trace.lap(2); g_align_trace.done();
     return (size_t)n_meas;
 }
 
@@ -1032,6 +1065,7 @@ bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector
 
 int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_keyframes, const std::set<MapPoint *> &local_map_points)
 {
+    g_pmp_trace.start();
     hip::Runtime &rt = hip::Runtime::Get();
     vector<Frame *> kfs(local_keyframes.begin(), local_keyframes.end());
     vector<int32_t> kf_slot; vector<double> kf_T;
@@ -1071,8 +1105,10 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
     vector<uint8_t> in_view(P); vector<double> px_proj(2 * (size_t)P), px_match(2 * (size_t)P); vector<int32_t> match(P), level(P);
     double Tc[7]; current->_TCW.to7(Tc);
     int32_t n = 0;
+    g_pmp_trace.lap(0);
     if (!hip::check(ygz_hip_track_local_map(rt.ctx(), rt.Resident(current), Tc, &m, in_view.data(), px_proj.data(), match.data(), px_match.data(),
                                             level.data(), &n), "track_local_map")) return 0;
+    g_pmp_trace.lap(1);
     current->_features.reserve(current->_features.size() + (size_t)n);
     for (int p = 0; p < P; ++p) {
         MapPoint *mp = mps[p];
@@ -1085,6 +1121,7 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
         feature->_mappoint = mp;
         current->_features.push_back(feature);
     }
+    g_pmp_trace.lap(2); g_pmp_trace.done();
     return (int)n;
 }
 
@@ -1143,17 +1180,7 @@ bool DepthFromTriangulation(const SE3 &T_search_ref, const Vector3d &f_ref, cons
 namespace ba {
 void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points) { LocalBAG2O(local_keyframes, local_map_points, nullptr); }
 
-namespace {
-struct PhaseTrace {                                     // YGZ_HOST_TRACE=1: host clock per phase of LocalBAG2O, printed when the process ends
-    bool on = env_on("YGZ_HOST_TRACE", false);
-    double ms[4] = { 0, 0, 0, 0 }; long calls = 0;
-    std::chrono::steady_clock::time_point t;
-    void start() { if (on) t = std::chrono::steady_clock::now(); }
-    void lap(int k) { if (on) { const auto n = std::chrono::steady_clock::now(); ms[k] += std::chrono::duration<double, std::milli>(n - t).count(); t = n; } }
-    ~PhaseTrace() { if (on && calls) fprintf(stderr, "LocalBAG2O x %ld: graph %.3f  ygz_hip_ba_optimize_chi2 %.3f  write-back %.3f ms per call\n", calls, ms[0] / calls, ms[1] / calls, ms[2] / calls); }
-};
-PhaseTrace g_ba_trace;
-}
+namespace { PhaseTrace g_ba_trace{ "LocalBAG2O", { "graph", "ygz_hip_ba_optimize_chi2", "write-back", nullptr } }; }
 void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_map_points, LocalBAStats *stats)
 {   // graph build exactly as src/Algorithm/BA.cpp:397-497, then optimize(20) and the write-back of :504-541
     hip::Runtime &rt = hip::Runtime::Get();
@@ -1228,7 +1255,7 @@ void LocalBAG2O(std::set<Frame *> &local_keyframes, std::set<MapPoint *> &local_
     }
     for (size_t l = 0; l < pts.size(); ++l) pts[l]->_pos_world = Vector3d(points[3 * l], points[3 * l + 1], points[3 * l + 2]);
     if (stats) { stats->iterations = st.iterations; stats->lm_trials = st.lm_trials; stats->outliers = cntOutlier; stats->chi2_initial = st.chi2_initial; stats->chi2_final = st.chi2_final; }
-    g_ba_trace.lap(2); ++g_ba_trace.calls;
+    g_ba_trace.lap(2); g_ba_trace.done();
 }
 // ---- the ceres-based entry points (BA.cpp:11-384) ------------------------------------------------------------------
 namespace {
@@ -1342,8 +1369,10 @@ void OptimizeCurrent(Frame *current)
 
 void OptimizeCurrentPoseOnlyBatch(const vector<Frame *> &frames)
 {   // BA.cpp:188-264 for every frame of the batch in one launch
+    g_po_trace.start();
     std::vector<int32_t> off(1, 0);
     std::vector<double> px, pw, poses, depth;
+    { size_t n0 = 0; for (Frame *f : frames) n0 += f->_features.size(); px.reserve(2 * n0); pw.reserve(3 * n0); depth.reserve(n0 + 1); poses.reserve(6 * frames.size()); }
     for (Frame *f : frames) {
         for (Feature *fea : f->_features) {
             assert(fea->_mappoint != nullptr);
@@ -1358,8 +1387,10 @@ void OptimizeCurrentPoseOnlyBatch(const vector<Frame *> &frames)
     }
     std::vector<uint8_t> bad(std::max<size_t>(depth.size(), 1));
     if (depth.empty()) depth.push_back(0);
+    g_po_trace.lap(0);
     if (!hip::check(ygz_hip_optimize_pose_only(hip::Runtime::Get().ctx(), (int)frames.size(), off.data(), px.data(), pw.data(), poses.data(),
                                                bad.data(), depth.data(), nullptr, nullptr), "optimize_pose_only")) return;
+    g_po_trace.lap(1);
     size_t g = 0;
     for (size_t fi = 0; fi < frames.size(); ++fi) {
         Frame *f = frames[fi];
@@ -1372,6 +1403,7 @@ void OptimizeCurrentPoseOnlyBatch(const vector<Frame *> &frames)
             ++g;
         }
     }
+    g_po_trace.lap(2); g_po_trace.done();
 }
 void OptimizeCurrentPoseOnly(Frame *current) { OptimizeCurrentPoseOnlyBatch(vector<Frame *>(1, current)); }
 
