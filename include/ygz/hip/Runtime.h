@@ -30,7 +30,9 @@ private:
 // outputs).  Only a missing device -- there is no CPU path to fall back to -- throws (Runtime::ctx).
 bool check(int rc, const char *what);
 // Matcher::FindDirectProjection behind per-candidate callers (ygz_host.cpp: FdpMemo): one speculative launch per current frame, answers handed out
-// only on bit-equal inputs.  Environment YGZ_FDP_MEMO=0 (or SetFdpSpeculation(false)) makes every call its own n = 1 launch.
+// only on bit-equal inputs.  Environment YGZ_FDP_MEMO=0 (or SetFdpSpeculation(false)) makes every call its own n = 1 launch.  When the previous
+// current frame was served that way, the launch of the next one is queued at the end of Matcher::SparseImageAlignment (its pose is known there) and
+// collected at its first per-candidate call -- the caller's own FindCandidates runs in between; YGZ_FDP_PRELAUNCH=0: launch at the first call.
 struct FdpMemoStats { unsigned long long hits = 0, single = 0, launches = 0, speculated = 0; double speculate_ms = 0; };
 void SetFdpSpeculation(bool on);
 void SetFdpBypass(bool on);             // true: calls take their own n = 1 launch and leave the memo as it is (to compare the two inside one loop)

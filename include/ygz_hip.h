@@ -40,7 +40,7 @@ extern "C" {
  * header would still link).  Bindings compare ygz_hip_abi_version() with the header they were written against at load time
  * (ygz_slam_amd/_lib.py, include/ygz/hip/Runtime.h).  5: ygz_hip_kf_row_bytes / ygz_hip_kf_store_create / ygz_hip_ba_build_windows
  * gained their trailing int (round 4); ygz_hip_get_stream / device_alloc / copy added (round 5).  6: ygz_ceres_options gained trust_region_strategy
- * (in the struct's tail padding: same size); ygz_hip_find_direct_projection_mp, ygz_hip_sparse_align_residuals, ygz_hip_ba_light_barrier added (round 6). */
+ * (in the struct's tail padding: same size); ygz_hip_find_direct_projection_mp (+ _begin / _end), ygz_hip_sparse_align_residuals, ygz_hip_ba_light_barrier added (round 6). */
 #define YGZ_HIP_ABI_VERSION 6
 
 typedef struct ygz_hip_ctx ygz_hip_ctx;
@@ -216,6 +216,15 @@ int  ygz_hip_find_direct_projection_mp(ygz_hip_ctx *ctx, int cur_slot, const dou
                                        const double *px_ref, const int32_t *level_ref, const double *px_in /*or NULL*/,
                                        uint8_t *in_view /*may be NULL with px_in*/, double *px_proj /*may be NULL with px_in*/,
                                        uint8_t *ok, double *px_cur, int32_t *search_level);
+/* The same launch in two halves: _begin (the px_in = NULL form) queues uploads, kernels and the copy back and does not wait; _end (same n) waits and
+ * hands out what ygz_hip_find_direct_projection_mp would have returned.  One run pending per context (a second _begin replaces it); YGZ_E_STATE from
+ * _end when none is (or n differs); other calls on the context in between queue behind it.  The class surface queues its speculative launch at the
+ * end of Matcher::SparseImageAlignment (src/Algorithm/Matcher.cpp:16-31) and collects at the first per-candidate call of the frame. */
+int  ygz_hip_find_direct_projection_mp_begin(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], int n_keyframes, const int32_t *kf_slot,
+                                             const double *kf_T, int n, const int32_t *cand_kf, const double *pos_world, const double *px_ref,
+                                             const int32_t *level_ref);
+int  ygz_hip_find_direct_projection_mp_end(ygz_hip_ctx *ctx, int n, uint8_t *in_view, double *px_proj, uint8_t *ok, double *px_cur,
+                                           int32_t *search_level);
 /* bare cvutils::Align2D on host-provided patches against level `level` of `cur_slot`:
  * pwb [n][100], patch [n][64], uv [n][2] in/out (level pixels), ok [n], chi2 [n] (may be NULL) */
 int  ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pwb, const uint8_t *patch,

@@ -184,6 +184,23 @@ def test_find_direct_projection_per_candidate_bit_exact(hip_lib, oracle):
         assert bool(o_ok) == bool(g["ok"][j]) and o_sl == g["level"][j] and np.array_equal(np.asarray(o_px), g["px"][j])
         one = ctx.find_direct_projection_mp(3, T_cur, [int(ck[c])], kfT[ck[c]][None], [0], pos[cp[c]][None], cx[c][None], cl[c:c + 1], px_in=pin[j][None])
         assert one["ok"][0] == g["ok"][j] and one["level"][0] == g["level"][j] and np.array_equal(one["px"][0], g["px"][j])
+    # the launch in two halves (_begin queues, _end collects) with other calls on the context in between -- among them the synchronous form, which
+    # uses its own staging block -- returns what the one-call form returned; a second _begin replaces a pending run; _end without one is refused
+    nb = ctx.find_direct_projection_mp_begin(3, T_cur, [0, 1, 2], kfT, ck, pos[cp], cx, cl)
+    g2 = ctx.find_direct_projection_mp(3, T_cur, [0, 1, 2], kfT, ck[idx[:60]], pos[cp[idx[:60]]], cx[idx[:60]], cl[idx[:60]], px_in=pin)
+    ctx.detect(0, 1); ctx.get_keypoints(0)
+    h = ctx.find_direct_projection_mp_end(nb)
+    assert all(np.array_equal(h[k], r[k]) for k in ("in_view", "ok", "level")) and np.array_equal(h["px_proj"][v], r["px_proj"][v]) and np.array_equal(h["px"][r["ok"]], r["px"][r["ok"]])
+    assert np.array_equal(g2["px"], g["px"]) and np.array_equal(g2["ok"], g["ok"])
+    ctx.find_direct_projection_mp_begin(3, T_cur, [0, 1, 2], kfT, ck[:100], pos[cp[:100]], cx[:100], cl[:100])
+    nb = ctx.find_direct_projection_mp_begin(3, T_cur, [0, 1], kfT[:2], ck[idx[:200]] % 2, pos[cp[idx[:200]]], cx[idx[:200]], cl[idx[:200]])
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.find_direct_projection_mp_end(nb + 1)
+    h = ctx.find_direct_projection_mp_end(nb)
+    h1 = ctx.find_direct_projection_mp(3, T_cur, [0, 1], kfT[:2], ck[idx[:200]] % 2, pos[cp[idx[:200]]], cx[idx[:200]], cl[idx[:200]])
+    assert np.array_equal(h["ok"], h1["ok"]) and np.array_equal(h["px"][h["ok"]], h1["px"][h1["ok"]]) and np.array_equal(h["level"], h1["level"])
+    with pytest.raises(hip_lib.YgzHipError):
+        ctx.find_direct_projection_mp_end(nb)
     # nothing to do / refused inputs
     e = ctx.find_direct_projection_mp(3, T_cur, [0], kfT[:1], [], np.zeros((0, 3)), np.zeros((0, 2)), [])
     assert len(e["ok"]) == 0

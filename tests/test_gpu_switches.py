@@ -89,7 +89,7 @@ def test_alternate_paths_give_identical_results(tmp_path):
     import re
     known = {"YGZ_HAMMING_VALU", "YGZ_BA_LM_TEAM", "YGZ_LM_XCD_BARRIER", "YGZ_SA_THREADS", "YGZ_BA_HOST_LOOP", "YGZ_LM_DEBUG", "YGZ_FAST_DEBUG", "YGZ_HIP_DEVICE",
              "YGZ_HIP_MAX_FRAMES", "YGZ_OFFLINE_TRACE", "YGZ_OFFLINE_VERBOSE", "YGZ_ZERO_COPY", "YGZ_HOST_TRACE"}
-    # (ygz_host.cpp reads YGZ_FDP_MEMO and YGZ_HOST_TRACE through its env_on() helper: the per-candidate FindDirectProjection memo -- tests/test_gpu_surface.py
+    # (ygz_host.cpp reads YGZ_FDP_MEMO, YGZ_FDP_PRELAUNCH and YGZ_HOST_TRACE through its env_on() helper: the per-candidate FindDirectProjection memo -- tests/test_gpu_surface.py
     # compares it with the n = 1 launches call by call -- and a host clock per phase of LocalBAG2O)
     found = set()
     for sub in ("csrc", "host"):

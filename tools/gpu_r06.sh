@@ -37,6 +37,13 @@ f)  # LocalBAG2O's results in one transfer, the sparse alignment's result writte
     YGZ_HOST_TRACE=1 timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface.json 2> $OUT/surface.err
     grep "ms per call" $OUT/surface.err; surf $OUT/surface.json | cut -c1-420
     ;;
+q)  # the speculative launch of the unchanged caller queued at the end of Matcher::SparseImageAlignment (collected at the first per-candidate call): tests, A/B
+    timeout 900 python -m pytest tests/test_gpu_surface.py tests/test_gpu_parity.py -x -q -k "surface or unchanged or per_candidate or class_surfaces or loop" > $OUT/pytest.log 2>&1; grep -E "passed|failed" $OUT/pytest.log | tail -3
+    for pl in 1 0 1 0; do
+        YGZ_FDP_PRELAUNCH=$pl timeout 400 python bench.py --mode surface --no-cpu-baseline > $OUT/surface_pl$pl.json 2> $OUT/surface_pl$pl.err
+        echo "== YGZ_FDP_PRELAUNCH=$pl"; surf $OUT/surface_pl$pl.json | grep unchanged | cut -c1-700
+    done
+    ;;
 h)  # the whole GPU suite + the default bench line
     timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; grep -n "passed\|failed\|error" $OUT/pytest.log | tail -5
     timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python - $OUT/bench_default.json <<'PY'

@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_set_team_budget", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ba_light_barrier", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
-    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map", "ygz_hip_find_direct_projection_mp",
+    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map", "ygz_hip_find_direct_projection_mp", "ygz_hip_find_direct_projection_mp_begin", "ygz_hip_find_direct_projection_mp_end",
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_match_sets", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",
@@ -613,6 +613,27 @@ class HipContext:
                                                              _p(level_ref, C.c_int32), None if pin is None else _p(pin, C.c_double), _p(vis, C.c_uint8),
                                                              _p(proj, C.c_double), _p(ok, C.c_uint8), _p(px, C.c_double), _p(sl, C.c_int32)),
                   "find_direct_projection_mp")
+        return dict(in_view=vis.astype(bool), px_proj=proj, ok=ok.astype(bool), px=px, level=sl)
+
+    def find_direct_projection_mp_begin(self, cur_slot, T_cur, kf_slots, kf_T, cand_kf, pos_world, px_ref, level_ref):
+        """first half of find_direct_projection_mp (px_in = None form): queued, not waited for; returns the candidate count for ..._end"""
+        T_cur = np.ascontiguousarray(T_cur, np.float64); kf_slots = np.ascontiguousarray(kf_slots, np.int32)
+        kf_T = np.ascontiguousarray(kf_T, np.float64).reshape(-1, 7); cand_kf = np.ascontiguousarray(cand_kf, np.int32)
+        pos_world = np.ascontiguousarray(pos_world, np.float64).reshape(-1, 3); px_ref = np.ascontiguousarray(px_ref, np.float64).reshape(-1, 2)
+        level_ref = np.ascontiguousarray(level_ref, np.int32)
+        self.lib.ygz_hip_find_direct_projection_mp_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                                     C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        self._chk(self.lib.ygz_hip_find_direct_projection_mp_begin(self._ctx, int(cur_slot), _p(T_cur, C.c_double), len(kf_slots), _p(kf_slots, C.c_int32),
+                                                                   _p(kf_T, C.c_double), len(cand_kf), _p(cand_kf, C.c_int32), _p(pos_world, C.c_double),
+                                                                   _p(px_ref, C.c_double), _p(level_ref, C.c_int32)), "find_direct_projection_mp_begin")
+        return len(cand_kf)
+
+    def find_direct_projection_mp_end(self, n):
+        vis = np.zeros(n, np.uint8); proj = np.zeros((n, 2)); ok = np.zeros(n, np.uint8); px = np.zeros((n, 2)); sl = np.zeros(n, np.int32)
+        self.lib.ygz_hip_find_direct_projection_mp_end.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_uint8),
+                                                                   C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        self._chk(self.lib.ygz_hip_find_direct_projection_mp_end(self._ctx, int(n), _p(vis, C.c_uint8), _p(proj, C.c_double), _p(ok, C.c_uint8),
+                                                                 _p(px, C.c_double), _p(sl, C.c_int32)), "find_direct_projection_mp_end")
         return dict(in_view=vis.astype(bool), px_proj=proj, ok=ok.astype(bool), px=px, level=sl)
 
     def find_direct_projection(self, ref_slot, T_ref, cur_slot, T_cur, px_ref, depth_ref, level_ref, px_cur):

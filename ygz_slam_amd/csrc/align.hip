@@ -507,9 +507,31 @@ int ygz_hip_align2d(ygz_hip_ctx *ctx, int cur_slot, int level, const uint8_t *pw
 struct LmapCandOut { uint8_t *ok; double *px; int32_t *sl; const double *px_given; };
 
 // one run = LocalMapping::FindCandidates + ProjectMapPoints for the current frame against K resident keyframes
+// the device / page-locked layout of one run (P points, K keyframes, Cn candidates) in a scratch block and its mirror
+struct LmapLayout {
+    size_t total;
+    double *d_T, *d_pw, *d_kfT, *d_cpx, *d_proj, *d_pm, *d_candpx;
+    int32_t *d_kfs, *d_cp, *d_ck, *d_cl, *d_mc, *d_ml, *d_csl;
+    uint8_t *d_bad, *d_vis, *d_cok;
+};
+static size_t lmap_bytes(size_t Ps, size_t Ks, size_t Cs)
+{ return (8 + 3 * Ps + 7 * Ks + 2 * Cs + 2 * Ps + 2 * Ps + 2 * Cs) * 8 + (Ks + 3 * Cs + 2 * Ps + Cs) * 4 + 2 * Ps + Cs; }
+static LmapLayout lmap_layout(uint8_t *buf, size_t Ps, size_t Ks, size_t Cs)
+{
+    LmapLayout L;
+    L.total = lmap_bytes(Ps, Ks, Cs);
+    L.d_T = (double *)buf; L.d_pw = L.d_T + 8; L.d_kfT = L.d_pw + 3 * Ps; L.d_cpx = L.d_kfT + 7 * Ks; L.d_proj = L.d_cpx + 2 * Cs;
+    L.d_pm = L.d_proj + 2 * Ps; L.d_candpx = L.d_pm + 2 * Ps;
+    L.d_kfs = (int32_t *)(L.d_candpx + 2 * Cs); L.d_cp = L.d_kfs + Ks; L.d_ck = L.d_cp + Cs; L.d_cl = L.d_ck + Cs; L.d_mc = L.d_cl + Cs;
+    L.d_ml = L.d_mc + Ps; L.d_csl = L.d_ml + Ps;
+    L.d_bad = (uint8_t *)(L.d_csl + Cs); L.d_vis = L.d_bad + Ps; L.d_cok = L.d_vis + Ps;
+    return L;
+}
+// defer: the run is queued (inputs up, kernels, results into the page-locked mirror of scratch block `scr`) and NOT waited for: lmap_collect
+// hands the per-candidate results out later (ygz_hip_find_direct_projection_mp_begin / _end)
 static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const ygz_local_map *m,
                     uint8_t *in_view, double *px_proj, int32_t *match_cand, double *px_match, int32_t *match_level, int32_t *n_matched,
-                    const LmapCandOut *co)
+                    const LmapCandOut *co, int scr = SCR_LMAP, bool defer = false)
 {
     YgzDeviceGuard dg_(ctx);
     if (!ctx || !T_cur || !m || m->n_points < 0 || m->n_keyframes < 0 || m->n_candidates < 0) return YGZ_E_INVALID;
@@ -518,7 +540,7 @@ static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const
     const int P = m->n_points, K = m->n_keyframes, Cn = m->n_candidates;
     if (n_matched) *n_matched = 0;
     if (P == 0) return YGZ_OK;
-    if (!m->pos_world || !in_view || !px_proj) return YGZ_E_INVALID;
+    if (!m->pos_world || (!defer && (!in_view || !px_proj))) return YGZ_E_INVALID;
     if (!co && (!match_cand || !px_match || !match_level)) return YGZ_E_INVALID;
     if (K > 0 && (!m->kf_slot || !m->kf_T)) return YGZ_E_INVALID;
     if (Cn > 0 && (!m->cand_point || !m->cand_kf || !m->cand_level || !m->cand_px_ref || K == 0)) return YGZ_E_INVALID;
@@ -528,19 +550,17 @@ static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const
     }
     for (int i = 0; i < Cn; ++i) if (m->cand_level[i] < 0 || m->cand_level[i] >= ctx->prm.pyramid_levels) return YGZ_E_INVALID;
     const size_t Ps = (size_t)P, Ks = (size_t)K, Cs = (size_t)Cn;
-    const size_t nd = 8 + 3 * Ps + 7 * Ks + 2 * Cs + 2 * Ps + 2 * Ps + 2 * Cs, ni = Ks + 3 * Cs + 2 * Ps + Cs, nb = 2 * Ps + Cs;
     uint8_t *buf = nullptr;
-    int rc = ygz_scratch(ctx, SCR_LMAP, nd * 8 + ni * 4 + nb + 64, (void **)&buf);
+    int rc = ygz_scratch(ctx, scr, lmap_bytes(Ps, Ks, Cs) + 64, (void **)&buf);
     if (rc != YGZ_OK) return rc;
-    double *d_T = (double *)buf, *d_pw = d_T + 8, *d_kfT = d_pw + 3 * Ps, *d_cpx = d_kfT + 7 * Ks, *d_proj = d_cpx + 2 * Cs,
-           *d_pm = d_proj + 2 * Ps, *d_candpx = d_pm + 2 * Ps;
-    int32_t *d_kfs = (int32_t *)(d_candpx + 2 * Cs), *d_cp = d_kfs + Ks, *d_ck = d_cp + Cs, *d_cl = d_ck + Cs, *d_mc = d_cl + Cs,
-            *d_ml = d_mc + Ps, *d_csl = d_ml + Ps;
-    uint8_t *d_bad = (uint8_t *)(d_csl + Cs), *d_vis = d_bad + Ps, *d_cok = d_vis + Ps;
+    const LmapLayout Y = lmap_layout(buf, Ps, Ks, Cs);
+    double *const d_T = Y.d_T, *const d_pw = Y.d_pw, *const d_kfT = Y.d_kfT, *const d_cpx = Y.d_cpx, *const d_proj = Y.d_proj, *const d_pm = Y.d_pm, *const d_candpx = Y.d_candpx;
+    int32_t *const d_kfs = Y.d_kfs, *const d_cp = Y.d_cp, *const d_ck = Y.d_ck, *const d_cl = Y.d_cl, *const d_mc = Y.d_mc, *const d_ml = Y.d_ml, *const d_csl = Y.d_csl;
+    uint8_t *const d_bad = Y.d_bad, *const d_vis = Y.d_vis, *const d_cok = Y.d_cok;
     // inputs packed into the page-locked mirror of the scratch block at the device offsets: ONE copy up (and one down below) instead of nine + five
     uint8_t *hb = nullptr;
-    if ((rc = ygz_scratch_mirror(ctx, SCR_LMAP, (void **)&hb)) != YGZ_OK) return rc;
-    const size_t total = nd * 8 + ni * 4 + nb;
+    if ((rc = ygz_scratch_mirror(ctx, scr, (void **)&hb)) != YGZ_OK) return rc;
+    const size_t total = Y.total;
 #define H_(dptr) (hb + ((const uint8_t *)(dptr) - buf))
     memcpy(H_(d_T), T_cur, 56);
     memcpy(H_(d_pw), m->pos_world, Ps * 24);
@@ -566,6 +586,7 @@ static int lmap_run(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], const
     if (!co) YGZ_LAUNCH(ctx, KID_LMAP_AUX, k_lmap_gather, dim3(ygz_div_up(P, 256)), dim3(256), A);
     YGZ_HIPCHK(ctx, hipGetLastError());
     if ((rc = ygz_kcopy(ctx, hb, buf, total, hipMemcpyDeviceToHost)) != YGZ_OK) return rc;
+    if (defer) return YGZ_OK;
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(in_view, H_(d_vis), Ps); memcpy(px_proj, H_(d_proj), Ps * 16);
     if (co) {
@@ -608,6 +629,49 @@ int ygz_hip_find_direct_projection_mp(ygz_hip_ctx *ctx, int cur_slot, const doub
     m.n_candidates = n; m.cand_point = iota.data(); m.cand_kf = cand_kf; m.cand_level = level_ref; m.cand_px_ref = px_ref;
     LmapCandOut co = { ok, px_cur, search_level, px_in };
     return lmap_run(ctx, cur_slot, T_cur, &m, in_view, px_proj, nullptr, nullptr, nullptr, nullptr, &co);
+}
+
+
+// The same launch in two halves, for a caller that has host work of its own between asking and needing the answers (the class surface queues the
+// speculative launch of FdpMemo at the end of Matcher::SparseImageAlignment and collects it at the first Matcher::FindDirectProjection call: the
+// unchanged caller spends 0.2 ms in LocalMapping::FindCandidates in between).  _begin: px_in = NULL form only (the launch makes FindCandidates'
+// prediction); queues uploads, kernels and the copy back into a page-locked block of its own, does not wait.  _end (same n): waits and hands out what
+// ygz_hip_find_direct_projection_mp would have returned.  One run can be pending per context; a second _begin replaces it (after waiting for it),
+// YGZ_E_STATE from _end when nothing is pending (or n differs).  Other calls on the context in between are fine (they queue behind it).
+int ygz_hip_find_direct_projection_mp_begin(ygz_hip_ctx *ctx, int cur_slot, const double T_cur[7], int n_keyframes, const int32_t *kf_slot, const double *kf_T,
+                                            int n, const int32_t *cand_kf, const double *pos_world, const double *px_ref, const int32_t *level_ref)
+{
+    if (!ctx || n < 1 || !cand_kf || !pos_world || !px_ref || !level_ref) return YGZ_E_INVALID;
+    YgzDeviceGuard dg_(ctx);
+    if (ctx->lmap_async_n) { YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); ctx->lmap_async_n = 0; }   // the page-locked block is about to be rewritten
+    std::vector<int32_t> iota((size_t)n);
+    for (int i = 0; i < n; ++i) iota[i] = i;
+    ygz_local_map m;
+    m.n_points = n; m.pos_world = pos_world; m.point_bad = nullptr;
+    m.n_keyframes = n_keyframes; m.kf_slot = kf_slot; m.kf_T = kf_T;
+    m.n_candidates = n; m.cand_point = iota.data(); m.cand_kf = cand_kf; m.cand_level = level_ref; m.cand_px_ref = px_ref;
+    LmapCandOut co = { nullptr, nullptr, nullptr, nullptr };
+    const int rc = lmap_run(ctx, cur_slot, T_cur, &m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &co, SCR_GEN_0 + 10, true);
+    if (rc == YGZ_OK) { ctx->lmap_async_n = n; ctx->lmap_async_k = n_keyframes; }
+    return rc;
+}
+
+int ygz_hip_find_direct_projection_mp_end(ygz_hip_ctx *ctx, int n, uint8_t *in_view, double *px_proj, uint8_t *ok, double *px_cur, int32_t *search_level)
+{
+    if (!ctx || !in_view || !px_proj || !ok || !px_cur || !search_level) return YGZ_E_INVALID;
+    if (ctx->lmap_async_n == 0 || ctx->lmap_async_n != n) return YGZ_E_STATE;
+    YgzDeviceGuard dg_(ctx);
+    const size_t Ns = (size_t)n;
+    ctx->lmap_async_n = 0;
+    YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t *buf = (uint8_t *)ctx->scratch[SCR_GEN_0 + 10], *hb = (uint8_t *)ctx->scratch_host[SCR_GEN_0 + 10];
+    if (!buf || !hb) return YGZ_E_STATE;
+    const LmapLayout Y = lmap_layout(buf, Ns, (size_t)ctx->lmap_async_k, Ns);
+#define H_(dptr) (hb + ((const uint8_t *)(dptr) - buf))
+    memcpy(in_view, H_(Y.d_vis), Ns); memcpy(px_proj, H_(Y.d_proj), Ns * 16);
+    memcpy(ok, H_(Y.d_cok), Ns); memcpy(px_cur, H_(Y.d_candpx), Ns * 16); memcpy(search_level, H_(Y.d_csl), Ns * 4);
+#undef H_
+    return YGZ_OK;
 }
 
 }  // extern "C"

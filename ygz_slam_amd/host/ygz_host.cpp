@@ -808,11 +808,17 @@ struct FdpMemo {
     std::vector<Frame *> asked, asked_prev;            // keyframes the calls of this / the previous current frame named
     hip::FdpMemoStats st;
     bool enabled = env_on("YGZ_FDP_MEMO", true);
+    bool prelaunch = env_on("YGZ_FDP_PRELAUNCH", true);   // queue the frame's speculative launch at the end of Matcher::SparseImageAlignment (below)
     bool bypass = false;                               // calls take the n = 1 launch and leave the memo alone (A/B inside one loop)
+    // a speculative launch that has been queued (ygz_hip_find_direct_projection_mp_begin) and not collected yet: what was asked
+    struct Pending {
+        int n = 0; size_t first_ref = 0;
+        std::vector<Frame *> kfs; std::vector<int32_t> ck, cl; std::vector<double> pos, cpx; std::vector<const MapPoint *> cmp;
+    } pend;
 
     static size_t hash(const Frame *ref, const void *key)
     { uint64_t h = (uint64_t)(uintptr_t)key * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)ref * 0xC2B2AE3D27D4EB4Full; return (size_t)(h ^ (h >> 29)); }
-    void clear() { curr = nullptr; refs.clear(); feat_refs.clear(); entries.clear(); table.clear(); }
+    void clear() { curr = nullptr; refs.clear(); feat_refs.clear(); entries.clear(); table.clear(); pend.n = 0; }
     void begin(Frame *c)
     {   // a new current frame (or the same one with another pose): the answers of the last one are void, the keyframes it named are the guess
         if (!asked.empty()) asked_prev.swap(asked);
@@ -861,8 +867,29 @@ hip::FdpMemoStats hip::GetFdpMemoStats() { return fdp_memo().st; }
 void hip::ResetFdpMemoStats() { fdp_memo().st = hip::FdpMemoStats(); }
 
 namespace {
-// the candidates of `batch` (keyframes that hold an image) against `curr` in one launch, appended to the memo
-void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch)
+// the answers of one launch over the gathered candidates become entries of the table
+void fdp_absorb(FdpMemo &M, const std::vector<Frame *> &kfs, const std::vector<int32_t> &ck, const std::vector<int32_t> &cl, const std::vector<const MapPoint *> &cmp,
+                const std::vector<double> &pos, const std::vector<double> &cpx, const std::vector<uint8_t> &vis, const std::vector<double> &proj,
+                const std::vector<uint8_t> &ok, const std::vector<double> &out, const std::vector<int32_t> &sl)
+{
+    const int n = (int)ck.size();
+    M.st.launches++; M.st.speculated += n;
+    M.entries.reserve(M.entries.size() + n);
+    for (int i = 0; i < n; ++i) {
+        if (!vis[i]) continue;                                         // FindCandidates drops it (LocalMapping.cpp:60-63): nobody asks
+        FdpMemo::Entry e;
+        e.ref = kfs[ck[i]]; e.key = cmp[i];
+        e.a[0] = pos[3 * i]; e.a[1] = pos[3 * i + 1]; e.a[2] = pos[3 * i + 2];
+        e.px_ref[0] = cpx[2 * i]; e.px_ref[1] = cpx[2 * i + 1]; e.level = cl[i];
+        e.px_in[0] = proj[2 * i]; e.px_in[1] = proj[2 * i + 1];
+        e.px_out[0] = out[2 * i]; e.px_out[1] = out[2 * i + 1]; e.sl = sl[i]; e.ok = ok[i];
+        M.entries.push_back(e);
+    }
+    M.rebuild_table();
+}
+// the candidates of `batch` (keyframes that hold an image) against `curr` in one launch, appended to the memo.  defer: the launch is queued and
+// collected by fdp_collect at the first look-up (the caller's own FindCandidates runs in between)
+void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch, bool defer = false)
 {
     struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
                    ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
@@ -896,25 +923,48 @@ void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch
     for (size_t k = 0; k < kfs.size(); ++k) { FdpMemo::Ref R; R.f = kfs[k]; memcpy(R.T, &kf_T[7 * k], 56); M.refs.push_back(R); }
     const int n = (int)ck.size();
     if (n == 0) return;
+    if (defer) {
+        if (ygz_hip_find_direct_projection_mp_begin(rt.ctx(), cs, M.T_cur, (int)kfs.size(), kf_slot.data(), kf_T.data(), n, ck.data(), pos.data(), cpx.data(),
+                                                    cl.data()) != YGZ_OK) { M.refs.resize(first_ref); return; }
+        FdpMemo::Pending &P = M.pend;
+        P.n = n; P.first_ref = first_ref;
+        P.kfs.swap(kfs); P.ck.swap(ck); P.cl.swap(cl); P.pos.swap(pos); P.cpx.swap(cpx); P.cmp.swap(cmp);
+        return;
+    }
     std::vector<uint8_t> vis(n), ok(n); std::vector<double> proj(2 * (size_t)n), out(2 * (size_t)n); std::vector<int32_t> sl(n);
     if (ygz_hip_find_direct_projection_mp(rt.ctx(), cs, M.T_cur, (int)kfs.size(), kf_slot.data(), kf_T.data(), n, ck.data(), pos.data(), cpx.data(),
                                           cl.data(), nullptr, vis.data(), proj.data(), ok.data(), out.data(), sl.data()) != YGZ_OK) {
         M.refs.resize(first_ref);                                      // nothing learnt; the calls take the n = 1 path (and report the error there)
         return;
     }
-    M.st.launches++; M.st.speculated += n;
-    M.entries.reserve(M.entries.size() + n);
-    for (int i = 0; i < n; ++i) {
-        if (!vis[i]) continue;                                         // FindCandidates drops it (LocalMapping.cpp:60-63): nobody asks
-        FdpMemo::Entry e;
-        e.ref = kfs[ck[i]]; e.key = cmp[i];
-        e.a[0] = pos[3 * i]; e.a[1] = pos[3 * i + 1]; e.a[2] = pos[3 * i + 2];
-        e.px_ref[0] = cpx[2 * i]; e.px_ref[1] = cpx[2 * i + 1]; e.level = cl[i];
-        e.px_in[0] = proj[2 * i]; e.px_in[1] = proj[2 * i + 1];
-        e.px_out[0] = out[2 * i]; e.px_out[1] = out[2 * i + 1]; e.sl = sl[i]; e.ok = ok[i];
-        M.entries.push_back(e);
+    fdp_absorb(M, kfs, ck, cl, cmp, pos, cpx, vis, proj, ok, out, sl);
+}
+// the queued launch, waited for and turned into table entries (first look-up of the frame)
+void fdp_collect(FdpMemo &M)
+{
+    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
+    FdpMemo::Pending &P = M.pend;
+    const int n = P.n;
+    P.n = 0;
+    if (n <= 0) return;
+    std::vector<uint8_t> vis(n), ok(n); std::vector<double> proj(2 * (size_t)n), out(2 * (size_t)n); std::vector<int32_t> sl(n);
+    if (ygz_hip_find_direct_projection_mp_end(hip::Runtime::Get().ctx(), n, vis.data(), proj.data(), ok.data(), out.data(), sl.data()) != YGZ_OK) {
+        M.refs.resize(P.first_ref);                                    // (another _begin took its place, or the run failed): nothing learnt
+        return;
     }
-    M.rebuild_table();
+    fdp_absorb(M, P.kfs, P.ck, P.cl, P.cmp, P.pos, P.cpx, vis, proj, ok, out, sl);
+}
+// Queue the frame's speculative launch as soon as its pose is known -- the end of Matcher::SparseImageAlignment -- when the previous current frame was
+// served per candidate (an unchanged caller: Tracker -> LocalMapping::TrackLocalMap, LocalMapping.cpp:24-33).  LocalMapping::FindCandidates (0.2 ms of the
+// caller's std::map work per frame) then runs while the device evaluates the candidates; a caller that changes the pose afterwards, or asks about other
+// keyframes, falls back to the launch at its first call as before.
+void fdp_prelaunch(Frame *curr)
+{
+    FdpMemo &M = fdp_memo();
+    if (!M.enabled || !M.prelaunch || M.bypass || M.asked.empty() || M.valid_for(curr)) return;
+    M.begin(curr);
+    fdp_speculate_mp(M, curr, M.asked_prev, true);
 }
 // Feature overload: the pairs the same Matcher's last SearchForTriangulation(ref, curr, ...) returned, with the depth and prediction
 // LocalMapping::CreateNewMapPoints forms from them before it calls (src/Module/LocalMapping.cpp:405-447): both features without a map point, rays not
@@ -1029,6 +1079,7 @@ bool Matcher::FindDirectProjection(Frame *ref, Frame *curr, MapPoint *mp, Vector
     FdpMemo &M = fdp_memo();
     if (M.enabled && !M.bypass) {
         if (!M.valid_for(curr)) M.begin(curr);
+        if (M.pend.n) fdp_collect(M);                                   // the launch Matcher::SparseImageAlignment queued for this frame
         M.note_asked(ref);
         for (int pass = 0; pass < 2; ++pass) {
             const FdpMemo::Ref *R = M.ref_of(ref);
@@ -1134,8 +1185,10 @@ bool Matcher::SparseImageAlignment(Frame *ref, Frame *current)
         LOG(WARNING) << "Too large motion: " << _TCR_esti.log().norm() << ". Reject this estimation. " << endl;
         _TCR_esti = SE3();
         current->_TCW = ref->_TCW;
+        fdp_prelaunch(current);
         return false;
     }
+    fdp_prelaunch(current);
     return true;
 }
 
