@@ -79,6 +79,10 @@ int  ygz_hip_join(ygz_hip_ctx *ctx);
  * stream, so they overlap with whatever is enqueued after them (KLT, direct projection); every entry point that reads or
  * overwrites their data, and ygz_hip_synchronize, joins them first.  Off by default. */
 int  ygz_hip_set_overlap(ygz_hip_ctx *ctx, int enable);
+/* Host work of the caller's own while a single-frame call waits for its kernel: fn(user) is called ONCE by the next ygz_hip_sparse_align (the longest wait
+ * of a frame: one Gauss-Newton problem, ~0.3 ms) between its launch and its wait, then the hook is cleared.  fn must not call into this context.
+ * fn == NULL clears.  (The class surface gathers the candidates of the frame's speculative FindDirectProjection launch there.) */
+int  ygz_hip_set_wait_hook(ygz_hip_ctx *ctx, void (*fn)(void *), void *user);
 const char *ygz_hip_error_string(int code);
 int  ygz_hip_last_hip_error(const ygz_hip_ctx *ctx);
 int  ygz_hip_max_keypoints(const ygz_hip_ctx *ctx);     /* = number of grid cells */

@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "ygz_hip_track_sparse_align", "ygz_hip_track_get_klt", "ygz_hip_track_get_direct", "ygz_hip_track_get_pose",
     "ygz_hip_ba_linearize", "ygz_hip_ba_upload", "ygz_hip_ba_set_state", "ygz_hip_ba_set_state_device", "ygz_hip_ba_linearize_resident", "ygz_hip_ba_download", "ygz_hip_ba_optimize",
     "ygz_hip_ba_optimize_resident", "ygz_hip_ba_set_team_budget", "ygz_hip_ba_get_state", "ygz_hip_ba_behind_camera", "ygz_hip_ba_set_enable", "ygz_hip_ba_light_barrier", "ygz_hip_ceres_default_options", "ygz_hip_ba_solve_ceres", "ygz_hip_ba_solve_ceres_resident", "ygz_hip_optimize_pose_only",
-    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map", "ygz_hip_find_direct_projection_mp", "ygz_hip_find_direct_projection_mp_begin", "ygz_hip_find_direct_projection_mp_end",
+    "ygz_hip_vocab_load", "ygz_hip_vocab_info", "ygz_hip_compute_bow", "ygz_hip_get_bow", "ygz_hip_bow_transform", "ygz_hip_search_by_bow_slots", "ygz_hip_search_by_bow", "ygz_hip_depth_from_triangulation", "ygz_hip_track_local_map", "ygz_hip_find_direct_projection_mp", "ygz_hip_find_direct_projection_mp_begin", "ygz_hip_find_direct_projection_mp_end", "ygz_hip_set_wait_hook",
     "ygz_hip_match_postfilter", "ygz_hip_get_good_matches", "ygz_hip_match_postfilter_host", "ygz_hip_match_sets", "ygz_hip_check_frame_descriptors",
     "ygz_hip_check_descriptor_pairs", "ygz_hip_track_adopt_pose", "ygz_hip_track_pose_only", "ygz_hip_track_get_pose_only",
     "ygz_hip_pinned_alloc", "ygz_hip_pinned_free", "ygz_hip_upload_bgr_batch", "ygz_hip_upload_gray_batch", "ygz_hip_get_keypoint_pixels_batch",

@@ -441,6 +441,13 @@ int ygz_hip_copy(ygz_hip_ctx *ctx, void *dst, const void *src, size_t bytes, int
     return YGZ_OK;
 }
 
+int ygz_hip_set_wait_hook(ygz_hip_ctx *ctx, void (*fn)(void *), void *user)
+{
+    if (!ctx) return YGZ_E_INVALID;
+    ctx->wait_hook = fn; ctx->wait_hook_user = fn ? user : nullptr;
+    return YGZ_OK;
+}
+
 int ygz_hip_timer_begin(ygz_hip_ctx *ctx)
 {
     YgzDeviceGuard dg_(ctx);

@@ -793,6 +793,11 @@ extern "C" int ygz_hip_sparse_align(ygz_hip_ctx *ctx, int ref_slot, const double
     ctx->sa_n_hint = 0; ctx->sa_out_host = nullptr;
     if (rc != YGZ_OK) return rc;
     if (!direct) YGZ_HIPCHK(ctx, hipMemcpyAsync(h_out, ctx->sa_out, 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->wait_hook) {                                     // the caller's own host work while the kernel runs (ygz_hip_set_wait_hook), once
+        void (*const fn)(void *) = ctx->wait_hook; void *const user = ctx->wait_hook_user;
+        ctx->wait_hook = nullptr; ctx->wait_hook_user = nullptr;
+        fn(user);
+    }
     YGZ_HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 7; ++k) T_cur[k] = h_out[k];
     if (n_meas_out) *n_meas_out = (int)(h_out[7] / 16);        // run() returns n_meas_/patch_area_ (:49)

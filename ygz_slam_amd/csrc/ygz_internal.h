@@ -120,6 +120,7 @@ struct ygz_hip_ctx {
     // window descriptors): a slice stays valid until the next ygz_hip_synchronize of this context, so no entry point has to wait for the
     // stream just because its host arguments are temporaries
     uint8_t *stage = nullptr; size_t stage_cap = 0, stage_used = 0;
+    void (*wait_hook)(void *) = nullptr; void *wait_hook_user = nullptr;   // ygz_hip_set_wait_hook: called once between launch and wait of the next single-frame sparse alignment
     int lmap_async_n = 0, lmap_async_k = 0;                   // candidates / keyframes of the pending ygz_hip_find_direct_projection_mp_begin run (0: none)
     int lds_per_block = 0;                                    // hipDeviceAttributeMaxSharedMemoryPerBlock, asked once
     // per-slot depth images (RGB-D style input of the offline run: Feature::_depth of the keypoints is sampled from them on the device)

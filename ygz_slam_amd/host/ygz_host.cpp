@@ -12,6 +12,7 @@
 #include <stdexcept>
 #include <cstdlib>
 #include <chrono>
+#include <limits>
 
 int ygz_log::verbosity = 0;
 
@@ -811,14 +812,19 @@ struct FdpMemo {
     bool prelaunch = env_on("YGZ_FDP_PRELAUNCH", true);   // queue the frame's speculative launch at the end of Matcher::SparseImageAlignment (below)
     bool bypass = false;                               // calls take the n = 1 launch and leave the memo alone (A/B inside one loop)
     // a speculative launch that has been queued (ygz_hip_find_direct_projection_mp_begin) and not collected yet: what was asked
-    struct Pending {
-        int n = 0; size_t first_ref = 0;
-        std::vector<Frame *> kfs; std::vector<int32_t> ck, cl; std::vector<double> pos, cpx; std::vector<const MapPoint *> cmp;
-    } pend;
+    struct Gathered {                                  // the candidates of some keyframes: everything a launch needs except the current frame's pose
+        std::vector<Frame *> kfs; std::vector<int32_t> kf_slot; std::vector<double> kf_T;
+        std::vector<int32_t> ck, cl; std::vector<double> pos, cpx; std::vector<const MapPoint *> cmp;
+        std::vector<Entry> ent; std::vector<int32_t> tab;   // optional: the table entries of these candidates with their input fields, and the hash table over them (fdp_prebuild)
+        void reset() { kfs.clear(); kf_slot.clear(); kf_T.clear(); ck.clear(); cl.clear(); pos.clear(); cpx.clear(); cmp.clear(); ent.clear(); tab.clear(); }
+    };
+    struct Pending : Gathered { int n = 0; size_t first_ref = 0; } pend;
+    // candidates gathered while Matcher::SparseImageAlignment waited for its kernel (ygz_hip_set_wait_hook), for the launch that follows it
+    struct Pre : Gathered { Frame *curr = nullptr; std::vector<Frame *> batch; bool valid = false; } pre;
 
     static size_t hash(const Frame *ref, const void *key)
     { uint64_t h = (uint64_t)(uintptr_t)key * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)ref * 0xC2B2AE3D27D4EB4Full; return (size_t)(h ^ (h >> 29)); }
-    void clear() { curr = nullptr; refs.clear(); feat_refs.clear(); entries.clear(); table.clear(); pend.n = 0; }
+    void clear() { curr = nullptr; refs.clear(); feat_refs.clear(); entries.clear(); table.clear(); pend.n = 0; }   // (pre survives: it belongs to the frame about to begin)
     void begin(Frame *c)
     {   // a new current frame (or the same one with another pose): the answers of the last one are void, the keyframes it named are the guess
         if (!asked.empty()) asked_prev.swap(asked);
@@ -830,17 +836,18 @@ struct FdpMemo {
     const Ref *ref_of(const Frame *f) const { for (const Ref &r : refs) if (r.f == f) return &r; return nullptr; }
     const Ref *feat_ref_of(const Frame *f) const { for (const Ref &r : feat_refs) if (r.f == f) return &r; return nullptr; }
     void note_asked(Frame *f) { for (Frame *a : asked) if (a == f) return; asked.push_back(f); }
-    void rebuild_table()
+    static void build_table(const std::vector<Entry> &ent, std::vector<int32_t> &tab)
     {
         size_t cap = 64;
-        while (cap < 2 * entries.size() + 2) cap <<= 1;
-        table.assign(cap, -1);
-        for (size_t i = 0; i < entries.size(); ++i) {
-            size_t h = hash(entries[i].ref, entries[i].key) & (cap - 1);
-            while (table[h] >= 0) h = (h + 1) & (cap - 1);
-            table[h] = (int32_t)i;
+        while (cap < 2 * ent.size() + 2) cap <<= 1;
+        tab.assign(cap, -1);
+        for (size_t i = 0; i < ent.size(); ++i) {
+            size_t h = hash(ent[i].ref, ent[i].key) & (cap - 1);
+            while (tab[h] >= 0) h = (h + 1) & (cap - 1);
+            tab[h] = (int32_t)i;
         }
     }
+    void rebuild_table() { build_table(entries, table); }
     const Entry *find(const Frame *ref, const void *key) const
     {
         if (table.empty()) return nullptr;
@@ -859,6 +866,7 @@ void hip::fdp_memo_forget(const Frame *f)
     FdpMemo &M = fdp_memo();
     auto drop = [&](std::vector<Frame *> &v) { v.erase(std::remove(v.begin(), v.end(), f), v.end()); };
     drop(M.asked); drop(M.asked_prev);
+    M.pre.valid = false;
     if (M.curr == f || M.ref_of(f) || M.feat_ref_of(f)) M.clear();
 }
 void hip::SetFdpSpeculation(bool on) { fdp_memo().enabled = on; if (!on) fdp_memo().clear(); }
@@ -887,57 +895,85 @@ void fdp_absorb(FdpMemo &M, const std::vector<Frame *> &kfs, const std::vector<i
     }
     M.rebuild_table();
 }
-// the candidates of `batch` (keyframes that hold an image) against `curr` in one launch, appended to the memo.  defer: the launch is queued and
-// collected by fdp_collect at the first look-up (the caller's own FindCandidates runs in between)
-void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch, bool defer = false)
+// pure host work, no call into the context: every observation of a good map point in the keyframes of `batch` that hold an image (`skip_covered`: and
+// are not in the table yet), with the keyframes' poses and the HBM slots they sit in as of now
+void fdp_gather(const FdpMemo &M, const Frame *curr, const std::vector<Frame *> &batch, bool skip_covered, FdpMemo::Gathered &G)
 {
-    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
-    hip::Runtime &rt = hip::Runtime::Get();
+    G.reset();
     const int levels = curr->_option._pyramid_level;
-    std::vector<Frame *> kfs;
-    for (Frame *r : batch) if (r != curr && !r->_pyramid.empty() && !M.ref_of(r) && std::find(kfs.begin(), kfs.end(), r) == kfs.end()) kfs.push_back(r);
-    if (kfs.empty() || curr->_pyramid.empty()) return;
-    const int cs = rt.Resident(curr);
-    std::vector<int32_t> kf_slot; std::vector<double> kf_T;
-    for (Frame *r : kfs) { kf_slot.push_back(rt.Resident(r)); double t7[7]; r->_TCW.to7(t7); kf_T.insert(kf_T.end(), t7, t7 + 7); }
-    if (curr->_hip_slot != cs) return;                                 // (more keyframes than HBM slots: no speculation)
-    for (size_t k = 0; k < kfs.size(); ++k) if (kfs[k]->_hip_slot != kf_slot[k]) return;
-    std::vector<int32_t> ck, cl; std::vector<double> pos, cpx; std::vector<const MapPoint *> cmp;
-    for (size_t k = 0; k < kfs.size(); ++k) {
-        Frame *r = kfs[k];
+    for (Frame *r : batch)
+        if (r != curr && !r->_pyramid.empty() && !(skip_covered && M.ref_of(r)) && std::find(G.kfs.begin(), G.kfs.end(), r) == G.kfs.end()) G.kfs.push_back(r);
+    for (size_t k = 0; k < G.kfs.size(); ++k) {
+        Frame *r = G.kfs[k];
+        G.kf_slot.push_back(r->_hip_slot); double t7[7]; r->_TCW.to7(t7); G.kf_T.insert(G.kf_T.end(), t7, t7 + 7);
         const size_t n0 = r->_features.size();
-        ck.reserve(ck.size() + n0); cl.reserve(cl.size() + n0); pos.reserve(pos.size() + 3 * n0); cpx.reserve(cpx.size() + 2 * n0); cmp.reserve(cmp.size() + n0);
+        G.ck.reserve(G.ck.size() + n0); G.cl.reserve(G.cl.size() + n0); G.pos.reserve(G.pos.size() + 3 * n0); G.cpx.reserve(G.cpx.size() + 2 * n0); G.cmp.reserve(G.cmp.size() + n0);
         for (const Feature *f : r->_features) {
             const MapPoint *mp = f->_mappoint;
             if (!mp || mp->_bad) continue;
             // (whether f is the Feature the method reads, mp->_obs[ref->_keyframe_id] (Matcher.cpp:361), is settled at look-up time by comparing
             // pixel and level: a tree look-up per feature here was a third of the gather)
             if (f->_level < 0 || f->_level >= levels) continue;
-            ck.push_back((int32_t)k); cl.push_back(f->_level); cmp.push_back(mp);
-            pos.push_back(mp->_pos_world[0]); pos.push_back(mp->_pos_world[1]); pos.push_back(mp->_pos_world[2]);
-            cpx.push_back(f->_pixel[0]); cpx.push_back(f->_pixel[1]);
+            G.ck.push_back((int32_t)k); G.cl.push_back(f->_level); G.cmp.push_back(mp);
+            G.pos.push_back(mp->_pos_world[0]); G.pos.push_back(mp->_pos_world[1]); G.pos.push_back(mp->_pos_world[2]);
+            G.cpx.push_back(f->_pixel[0]); G.cpx.push_back(f->_pixel[1]);
         }
     }
+}
+// the table entries of the gathered candidates with everything that is known before the launch (the inputs the look-up compares), and the hash table over
+// them -- host work that fits into the same wait as the gather; the launch's answers are filled in by fdp_collect
+void fdp_prebuild(FdpMemo::Gathered &G)
+{
+    const size_t n = G.ck.size();
+    G.ent.resize(n);
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    for (size_t i = 0; i < n; ++i) {
+        FdpMemo::Entry &e = G.ent[i];
+        e.ref = G.kfs[G.ck[i]]; e.key = G.cmp[i];
+        e.a[0] = G.pos[3 * i]; e.a[1] = G.pos[3 * i + 1]; e.a[2] = G.pos[3 * i + 2];
+        e.px_ref[0] = G.cpx[2 * i]; e.px_ref[1] = G.cpx[2 * i + 1]; e.level = G.cl[i];
+        e.px_in[0] = e.px_in[1] = nan; e.px_out[0] = e.px_out[1] = 0; e.sl = 0; e.ok = 0;      // no prediction equals NaN: unanswered until collected
+    }
+    FdpMemo::build_table(G.ent, G.tab);
+}
+// the gathered candidates against `curr` in one launch, appended to the memo.  defer: the launch is queued and collected by fdp_collect at the first
+// look-up (the caller's own FindCandidates runs in between)
+void fdp_launch(FdpMemo &M, Frame *curr, FdpMemo::Gathered &G, bool defer)
+{
+    hip::Runtime &rt = hip::Runtime::Get();
+    if (G.kfs.empty() || curr->_pyramid.empty()) return;
+    const int cs = rt.Resident(curr);
+    for (size_t k = 0; k < G.kfs.size(); ++k) if (rt.Resident(G.kfs[k]) != G.kf_slot[k] || G.kf_slot[k] < 0) return;   // (not resident when gathered, or more keyframes than HBM slots: no speculation)
+    if (curr->_hip_slot != cs) return;
+    for (size_t k = 0; k < G.kfs.size(); ++k) if (G.kfs[k]->_hip_slot != G.kf_slot[k]) return;
     const size_t first_ref = M.refs.size();
-    for (size_t k = 0; k < kfs.size(); ++k) { FdpMemo::Ref R; R.f = kfs[k]; memcpy(R.T, &kf_T[7 * k], 56); M.refs.push_back(R); }
-    const int n = (int)ck.size();
+    for (size_t k = 0; k < G.kfs.size(); ++k) { FdpMemo::Ref R; R.f = G.kfs[k]; memcpy(R.T, &G.kf_T[7 * k], 56); M.refs.push_back(R); }
+    const int n = (int)G.ck.size();
     if (n == 0) return;
     if (defer) {
-        if (ygz_hip_find_direct_projection_mp_begin(rt.ctx(), cs, M.T_cur, (int)kfs.size(), kf_slot.data(), kf_T.data(), n, ck.data(), pos.data(), cpx.data(),
-                                                    cl.data()) != YGZ_OK) { M.refs.resize(first_ref); return; }
+        if (ygz_hip_find_direct_projection_mp_begin(rt.ctx(), cs, M.T_cur, (int)G.kfs.size(), G.kf_slot.data(), G.kf_T.data(), n, G.ck.data(), G.pos.data(), G.cpx.data(),
+                                                    G.cl.data()) != YGZ_OK) { M.refs.resize(first_ref); return; }
         FdpMemo::Pending &P = M.pend;
         P.n = n; P.first_ref = first_ref;
-        P.kfs.swap(kfs); P.ck.swap(ck); P.cl.swap(cl); P.pos.swap(pos); P.cpx.swap(cpx); P.cmp.swap(cmp);
+        P.kfs.swap(G.kfs); P.kf_slot.swap(G.kf_slot); P.kf_T.swap(G.kf_T); P.ck.swap(G.ck); P.cl.swap(G.cl); P.pos.swap(G.pos); P.cpx.swap(G.cpx); P.cmp.swap(G.cmp);
+        P.ent.swap(G.ent); P.tab.swap(G.tab);
         return;
     }
     std::vector<uint8_t> vis(n), ok(n); std::vector<double> proj(2 * (size_t)n), out(2 * (size_t)n); std::vector<int32_t> sl(n);
-    if (ygz_hip_find_direct_projection_mp(rt.ctx(), cs, M.T_cur, (int)kfs.size(), kf_slot.data(), kf_T.data(), n, ck.data(), pos.data(), cpx.data(),
-                                          cl.data(), nullptr, vis.data(), proj.data(), ok.data(), out.data(), sl.data()) != YGZ_OK) {
+    if (ygz_hip_find_direct_projection_mp(rt.ctx(), cs, M.T_cur, (int)G.kfs.size(), G.kf_slot.data(), G.kf_T.data(), n, G.ck.data(), G.pos.data(), G.cpx.data(),
+                                          G.cl.data(), nullptr, vis.data(), proj.data(), ok.data(), out.data(), sl.data()) != YGZ_OK) {
         M.refs.resize(first_ref);                                      // nothing learnt; the calls take the n = 1 path (and report the error there)
         return;
     }
-    fdp_absorb(M, kfs, ck, cl, cmp, pos, cpx, vis, proj, ok, out, sl);
+    fdp_absorb(M, G.kfs, G.ck, G.cl, G.cmp, G.pos, G.cpx, vis, proj, ok, out, sl);
+}
+void fdp_speculate_mp(FdpMemo &M, Frame *curr, const std::vector<Frame *> &batch)
+{
+    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
+    FdpMemo::Gathered G;
+    fdp_gather(M, curr, batch, true, G);
+    fdp_launch(M, curr, G, false);
 }
 // the queued launch, waited for and turned into table entries (first look-up of the frame)
 void fdp_collect(FdpMemo &M)
@@ -953,18 +989,51 @@ void fdp_collect(FdpMemo &M)
         M.refs.resize(P.first_ref);                                    // (another _begin took its place, or the run failed): nothing learnt
         return;
     }
+    if (P.ent.size() == (size_t)n && M.entries.empty()) {              // entries and table were prepared with the gather: the answers go in, the table is adopted
+        M.st.launches++; M.st.speculated += n;
+        for (int i = 0; i < n; ++i) {
+            if (!vis[i]) continue;                                     // FindCandidates drops it (LocalMapping.cpp:60-63): nobody asks; its prediction stays NaN
+            FdpMemo::Entry &e = P.ent[i];
+            e.px_in[0] = proj[2 * i]; e.px_in[1] = proj[2 * i + 1];
+            e.px_out[0] = out[2 * i]; e.px_out[1] = out[2 * i + 1]; e.sl = sl[i]; e.ok = ok[i];
+        }
+        M.entries.swap(P.ent); M.table.swap(P.tab);
+        return;
+    }
     fdp_absorb(M, P.kfs, P.ck, P.cl, P.cmp, P.pos, P.cpx, vis, proj, ok, out, sl);
 }
 // Queue the frame's speculative launch as soon as its pose is known -- the end of Matcher::SparseImageAlignment -- when the previous current frame was
 // served per candidate (an unchanged caller: Tracker -> LocalMapping::TrackLocalMap, LocalMapping.cpp:24-33).  LocalMapping::FindCandidates (0.2 ms of the
 // caller's std::map work per frame) then runs while the device evaluates the candidates; a caller that changes the pose afterwards, or asks about other
 // keyframes, falls back to the launch at its first call as before.
+// the wait hook of Matcher::SparseImageAlignment (called by ygz_hip_sparse_align between its launch and its wait): the gather of the launch that follows,
+// which does not depend on the pose being estimated
+void fdp_pregather_hook(void *user)
+{
+    FdpMemo &M = fdp_memo();
+    Frame *curr = static_cast<Frame *>(user);
+    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
+    M.pre.valid = false; M.pre.curr = curr; M.pre.batch = M.asked;
+    fdp_gather(M, curr, M.pre.batch, false, M.pre);
+    fdp_prebuild(M.pre);
+    M.pre.valid = true;
+}
+bool fdp_prelaunch_wanted(Frame *curr)
+{
+    FdpMemo &M = fdp_memo();
+    return M.enabled && M.prelaunch && !M.bypass && !M.asked.empty() && !M.valid_for(curr);
+}
 void fdp_prelaunch(Frame *curr)
 {
     FdpMemo &M = fdp_memo();
-    if (!M.enabled || !M.prelaunch || M.bypass || M.asked.empty() || M.valid_for(curr)) return;
+    if (!fdp_prelaunch_wanted(curr)) { M.pre.valid = false; return; }
+    struct Clock { double &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Clock() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } clock_{ M.st.speculate_ms };
     M.begin(curr);
-    fdp_speculate_mp(M, curr, M.asked_prev, true);
+    if (!(M.pre.valid && M.pre.curr == curr && M.pre.batch == M.asked_prev)) { fdp_gather(M, curr, M.asked_prev, false, M.pre); fdp_prebuild(M.pre); }   // (the hook did not run: now)
+    M.pre.valid = false;
+    fdp_launch(M, curr, M.pre, true);
 }
 // Feature overload: the pairs the same Matcher's last SearchForTriangulation(ref, curr, ...) returned, with the depth and prediction
 // LocalMapping::CreateNewMapPoints forms from them before it calls (src/Module/LocalMapping.cpp:405-447): both features without a map point, rays not
@@ -1179,7 +1248,12 @@ int Matcher::ProjectMapPoints(Frame *current, const std::set<Frame *> &local_key
 bool Matcher::SparseImageAlignment(Frame *ref, Frame *current)
 {
     current->_TCW = ref->_TCW;
+    // (an unchanged caller's next step is LocalMapping::TrackLocalMap: the candidates of its speculative FindDirectProjection launch are gathered while
+    // the alignment kernel runs and the launch is queued as soon as the pose is known -- fdp_prelaunch)
+    const bool pre = fdp_prelaunch_wanted(current);
+    if (pre) ygz_hip_set_wait_hook(hip::Runtime::Get().ctx(), &fdp_pregather_hook, current);
     _align->run(ref, current);
+    if (pre) ygz_hip_set_wait_hook(hip::Runtime::Get().ctx(), nullptr, nullptr);
     _TCR_esti = current->_TCW * ref->_TCW.inverse();
     if (_TCR_esti.log().norm() > _options._max_alignment_motion) {
         LOG(WARNING) << "Too large motion: " << _TCR_esti.log().norm() << ". Reject this estimation. " << endl;
