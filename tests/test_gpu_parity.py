@@ -592,6 +592,21 @@ def test_sparse_align_golden_and_empty(hip_lib):
     no_mp = np.zeros(len(g["depth"]), np.uint8)            # no feature has a map point -> nothing visible
     nm, T, _ = ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], g["px_ref"], g["depth"], no_mp)
     assert nm == 0
+    # ygz_hip_set_wait_hook: the caller's own host work between the launch and the wait of the NEXT single-frame alignment -- called once, on the
+    # calling thread, then cleared; the result does not change; a hook that was set and cleared again is never called
+    import ctypes as C
+    calls = []
+    HOOK = C.CFUNCTYPE(None, C.c_void_p)
+    hook = HOOK(lambda user: calls.append(user))
+    ctx.lib.ygz_hip_set_wait_hook.argtypes = [C.c_void_p, HOOK, C.c_void_p]
+    assert ctx.lib.ygz_hip_set_wait_hook(ctx._ctx, hook, C.c_void_p(7)) == 0
+    nm2, T2, it2 = ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], g["px_ref"], g["depth"], g["has_mp"])
+    assert calls == [7] and nm2 == int(g["sa_nmeas"]) and it2 == list(g["sa_iters"]) and np.allclose(T2, g["sa_T"], rtol=1e-9, atol=1e-11)
+    nm3, T3, _ = ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], g["px_ref"], g["depth"], g["has_mp"])
+    assert calls == [7] and np.array_equal(T3, T2)
+    assert ctx.lib.ygz_hip_set_wait_hook(ctx._ctx, hook, C.c_void_p(8)) == 0 and ctx.lib.ygz_hip_set_wait_hook(ctx._ctx, HOOK(0), None) == 0
+    ctx.sparse_align(0, e["poses"][0], 1, g["T_init"], g["px_ref"], g["depth"], g["has_mp"])
+    assert calls == [7]
     ctx.close()
 
 
